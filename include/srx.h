@@ -1,0 +1,246 @@
+/*
+ * srx.h — C ABI of libsrx_hip.so: the MI355X (gfx950) implementation of SingleRust's
+ * sparse count-matrix hot path
+ *
+ *     normalize_total(1e4, Row) -> log1p -> per-gene moments / HVG(n) -> n_pc-component PCA
+ *
+ * This header IS the drop-in boundary.  The reference (SingleRust/SingleRust @ 2024_10_08,
+ * pure Rust) has no FFI of its own; each entry point below replaces the body of one
+ * reference function and is what a Rust shim in that function would bind (see
+ * INTEGRATION.md for the `extern "C"` block and the shim).  Paths cite the reference as
+ * <file>:<lines> relative to the reference repository root.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an srx_status (0 = ok, <0 = error) and
+ *     never throws or aborts across the boundary; srx_last_error() gives the message the
+ *     shim turns into anyhow!(..).
+ *   - the caller owns every host buffer; the library never keeps a host pointer after a
+ *     call returns.  An srx_mat owns device memory only.
+ *   - one srx_ctx per process and GPU (one process per GPU); a ctx is not thread-safe —
+ *     the reference holds the IMArrayElement RwLock for the whole op, the shim does too.
+ *   - there is NO CPU fallback: without a usable HIP device every compute call fails with
+ *     SRX_E_HIP.
+ */
+#ifndef SRX_H
+#define SRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRX_ABI_VERSION 1
+
+typedef struct srx_ctx srx_ctx;   /* one GPU + stream + (optional) RCCL communicator      */
+typedef struct srx_mat srx_mat;   /* device-resident CSR (the `X` of an IMAnnData)        */
+
+typedef enum srx_status {
+    SRX_OK = 0,
+    SRX_E_ARG = -1,      /* null pointer / inconsistent sizes                             */
+    SRX_E_DTYPE = -2,    /* dtype outside match_dyn_csr_matrix! (src/shared/mod.rs:110-129) */
+    SRX_E_FORMAT = -3,   /* "X is not a CSR matrix" (scale/mod.rs:87, transform/mod.rs:58) */
+    SRX_E_BOUNDS = -4,   /* column index >= n_cols, selection index out of range          */
+    SRX_E_HIP = -5,      /* HIP runtime error / no device                                 */
+    SRX_E_RCCL = -6,
+    SRX_E_OOM = -7,
+    SRX_E_NAN = -8,      /* NaN variance in HVG ranking: partial_cmp().unwrap() panic,
+                            dim_red/mod.rs:138                                            */
+    SRX_E_SHAPE = -9,    /* pca_inplace needs k >= 2 and N >= 5 (dim_red/mod.rs:38-41)    */
+    SRX_E_NOCONV = -10   /* subspace iteration hit max_iter before reaching tol           */
+} srx_status;
+
+/* Value dtypes: the set match_dyn_csr_matrix! accepts (src/shared/mod.rs:114-124).  The
+ * variants it panics on (I64, U64, Usize, Bool, String) map to SRX_E_DTYPE. */
+typedef enum srx_dtype {
+    SRX_I8 = 0, SRX_I16 = 1, SRX_I32 = 2, SRX_U8 = 3, SRX_U16 = 4, SRX_U32 = 5,
+    SRX_F32 = 6, SRX_F64 = 7
+} srx_dtype;
+
+/* src/shared/mod.rs:39-42 */
+typedef enum srx_direction { SRX_ROW = 0, SRX_COLUMN = 1 } srx_direction;
+
+/* The reference data model: nalgebra_sparse::CsrMatrix<T> slices as the
+ * shim obtains them under the IMArrayElement guard — row_offsets(), col_indices(),
+ * values()/values_mut().  usize == uint64_t on x86-64. */
+typedef struct srx_csr {
+    uint64_t n_rows, n_cols, nnz;
+    const uint64_t* indptr;    /* n_rows + 1                                              */
+    const uint64_t* indices;   /* nnz; sorted and unique within a row (canonical CSR)     */
+    void* values;              /* nnz elements of `dtype`                                  */
+    int32_t dtype;             /* srx_dtype                                               */
+} srx_csr;
+
+/* Device value storage chosen at upload. AUTO: I8/I16/U8/U16/F32 -> f32 (exact), I32/U32/
+ * F64 -> f64.  F32 halves the HBM traffic of every pass and still meets the 1e-5 bound;
+ * F64 reproduces the reference's f64 arithmetic to ~1e-15. */
+typedef enum srx_store { SRX_STORE_AUTO = 0, SRX_STORE_F32 = 1, SRX_STORE_F64 = 2 } srx_store;
+
+/* ---- context ---------------------------------------------------------------------------- */
+int32_t srx_abi_version(void);
+int32_t srx_device_count(int32_t* n_out);
+int32_t srx_ctx_create(int32_t device_id, srx_ctx** out);
+void    srx_ctx_destroy(srx_ctx* ctx);
+int32_t srx_ctx_synchronize(srx_ctx* ctx);
+/* Message of the last failing call on this ctx (or, with ctx == NULL, on this thread). */
+const char* srx_last_error(const srx_ctx* ctx);
+
+/* ---- row sharding over the GPUs of one node (new; the reference is single-process) ------
+ * One process per GPU.  Rank 0 obtains an id, the host broadcasts the 128 bytes by any
+ * means (torch.distributed / MPI / a file), every rank calls srx_comm_init.  Afterwards
+ * every per-gene reduction (moments, Z^T Y blocks, Gram matrices, the global cell count)
+ * is summed across ranks with ONE ncclAllReduce(f64, sum) each over xGMI; per-cell results
+ * stay local to the rank that owns the rows. */
+#define SRX_UNIQUE_ID_BYTES 128
+int32_t srx_comm_unique_id(void* id_out_128);
+int32_t srx_comm_init(srx_ctx* ctx, int32_t n_ranks, int32_t rank, const void* id_128);
+int32_t srx_comm_destroy(srx_ctx* ctx);
+/* Contiguous nnz-balanced row ranges: cut[r]..cut[r+1] is rank r's rows (cut has
+ * n_ranks+1 entries).  Pure host helper, no GPU needed. */
+int32_t srx_partition_rows(const uint64_t* indptr, uint64_t n_rows, int32_t n_ranks,
+                           uint64_t* cut_out);
+
+/* ---- matrix ------------------------------------------------------------------------------ */
+/* Narrowing upload of a reference-layout CSR (u64 -> i32 column indices on device, i64 row
+ * offsets).  Validates sortedness/bounds on device (SRX_E_FORMAT / SRX_E_BOUNDS). */
+int32_t srx_matrix_upload(srx_ctx* ctx, const srx_csr* host, int32_t store, srx_mat** out);
+/* Uninitialised device CSR for producers that fill HBM directly (synthetic generator, a
+ * host that already holds device buffers). `dtype` is the logical dtype the values are
+ * deemed to have (what DynCsrMatrix variant X is). */
+int32_t srx_matrix_alloc(srx_ctx* ctx, uint64_t n_rows, uint64_t n_cols, uint64_t nnz,
+                         int32_t dtype, int32_t store, srx_mat** out);
+/* Device pointers of an srx_mat: indptr = int64[n_rows+1], indices = int32[nnz],
+ * values = float[nnz] or double[nnz] (see srx_matrix_info). */
+int32_t srx_matrix_device_ptrs(srx_mat* m, void** indptr, void** indices, void** values);
+typedef struct srx_mat_info {
+    uint64_t n_rows, n_cols, nnz;
+    int32_t dtype;        /* current LOGICAL dtype (F64 after normalize_total, ...)       */
+    int32_t store;        /* SRX_STORE_F32 or SRX_STORE_F64                               */
+    uint64_t row_offset;  /* global index of local row 0 (sharded runs)                   */
+    uint64_t n_rows_global;
+} srx_mat_info;
+int32_t srx_matrix_info(const srx_mat* m, srx_mat_info* out);
+/* Tell a shard where it sits in the global matrix (used for deterministic seeds only). */
+int32_t srx_matrix_set_shard(srx_mat* m, uint64_t row_offset);
+/* D2H of the current values, converted to SRX_F32 or SRX_F64 (what the shim copies back
+ * into values_mut(), or into the fresh Vec<f64> when the DynCsrMatrix variant changes). */
+int32_t srx_matrix_download_values(srx_mat* m, void* values_out, int32_t dtype_out);
+/* Deep copy on device (normalize_total / log1p_transform, the copying forms,
+ * processing/mod.rs:314-322,329-332, deep_clone X). */
+int32_t srx_matrix_clone(srx_mat* m, srx_mat** out);
+/* Overwrite dst's values/dtype from src (same sparsity pattern); bench uses it to restore
+ * raw counts between steps. */
+int32_t srx_matrix_copy_values(srx_mat* dst, const srx_mat* src);
+void    srx_matrix_free(srx_mat* m);
+
+/* ---- statistics: memory::statistics::* (src/memory/statistics/mod.rs:10-46) ------------- */
+/* compute_number -> csr.rs:16-38.  out: n_rows (Row) or n_cols (Column) u32. */
+int32_t srx_compute_number(srx_mat* m, int32_t direction, uint32_t* out);
+/* compute_sum -> csr.rs:81-102. f64 accumulate; exact for integer data. */
+int32_t srx_compute_sum(srx_mat* m, int32_t direction, double* out);
+/* compute_variance -> csr.rs:149-188. Column: variance over the NON-ZERO entries,
+ * sumsq/cnt - mean^2, 0.0 when cnt == 0.  Row: two-pass, NaN for an empty row. */
+int32_t srx_compute_variance(srx_mat* m, int32_t direction, double* out);
+/* compute_std_dev -> csr.rs:225-228. */
+int32_t srx_compute_std_dev(srx_mat* m, int32_t direction, double* out);
+/* compute_min_max -> csr.rs:194-223 (+inf/-inf for empty). */
+int32_t srx_compute_min_max(srx_mat* m, int32_t direction, double* min_out, double* max_out);
+/* Superset used internally: per-gene (nnz_j, sum x, sum x^2) from ONE pass. Any output may
+ * be NULL. */
+int32_t srx_gene_moments(srx_mat* m, uint64_t* cnt, double* sum, double* sumsq);
+
+/* ---- normalise / log1p: memory::processing::* ------------------------------------------- */
+/* normalize_total_inplace (processing/mod.rs:303-312 -> scale/mod.rs:7-23,59-89;
+ * Column: :91-107,141-173).  scale = (sum == 0) ? 0 : target/sum; v *= scale.  The logical
+ * dtype becomes F64 whatever it was (scale/mod.rs:74-83). */
+int32_t srx_normalize_total_inplace(srx_mat* m, double target_sum, int32_t direction);
+/* log1p_transform_inplace (processing/mod.rs:324-326 -> transform/mod.rs:36-57). Logical
+ * F32 stays F32 (f32::ln_1p), everything else becomes F64. */
+int32_t srx_log1p_inplace(srx_mat* m);
+/* Fused fast path of the two calls above with Direction::Row: one read + one write of the
+ * values (8 B/nnz at f32 storage).  row_sums_out (host, n_rows f64) may be NULL. */
+int32_t srx_normalize_log1p_inplace(srx_mat* m, double target_sum, double* row_sums_out);
+
+/* ---- feature selection: dim_red::select_features, arm HighlyVariable(n)
+ * (dim_red/mod.rs:135-140): stable descending sort of the nz-only gene variances, first n
+ * gene indices IN RANK ORDER.  idx_out has room for min(n, n_cols) entries. */
+int32_t srx_select_hvg(srx_mat* m, uint64_t n, uint64_t* idx_out, uint64_t* n_out);
+
+/* ---- PCA: dim_red::pca_inplace (dim_red/mod.rs:24-94); arithmetic spec
+ * src/shared/processing/pca/mod.rs:74-215.  Computed by randomized block subspace
+ * iteration on the implicit standardised matrix Z = (X[:, sel] - 1 mu^T) D^-1 with a
+ * CSR x dense-panel SpMM (forward) and its transpose; never densifies X. */
+typedef struct srx_pca_opts {
+    int32_t n_components;  /* < 0 = None -> 2        (dim_red/mod.rs:52)                  */
+    int32_t center;        /* < 0 = None -> true     (:55)                                */
+    int32_t scale;         /* < 0 = None -> true     (:56)                                */
+    int32_t n_threads;     /* accepted, ignored on GPU (:61)                              */
+    int32_t block;         /* panel width l; 0 -> default (64, or n_pc rounded up)        */
+    int32_t max_iter;      /* 0 -> default 100                                            */
+    double  tol;           /* relative Ritz-residual tolerance; 0 -> default 1e-7         */
+    uint64_t seed;         /* start panel seed (the reference has no randomness here)     */
+} srx_pca_opts;
+
+typedef struct srx_pca_info {
+    uint64_t n_cells_global;
+    uint32_t k;            /* selected features                                           */
+    uint32_t n_pc;
+    uint32_t block;
+    uint32_t n_iter;       /* subspace iterations executed                                */
+    double residual;       /* final max relative Ritz residual over the n_pc pairs        */
+    uint64_t nnz_selected; /* non-zeros of the HVG-compacted CSR actually walked (local)  */
+} srx_pca_info;
+
+/* sel: k feature indices in selection order (NULL = FeatureSelection::None, all genes).
+ * Host outputs, each may be NULL:
+ *   scores      n_rows x n_pc  row-major  (obsm["X_pca"], dim_red/mod.rs:105-106)
+ *   components  k x n_pc       row-major  (V[:, :n_pc], pca/mod.rs:144)
+ *   evr         n_pc           explained_variance_ratio (pca/mod.rs:145-149)
+ *   mean, std   k              column mean / std (ddof 0) over ALL cells (pca/mod.rs:87-91)
+ * Sign convention (the reference has none): each component is flipped so that its
+ * largest-|.| entry is positive.  A zero-variance selected column gives NaN in the
+ * reference (pca/mod.rs:108); here its std is treated as 1 (documented deviation). */
+int32_t srx_pca(srx_mat* m, const uint64_t* sel, uint64_t k, const srx_pca_opts* opts,
+                double* scores, double* components, double* evr, double* mean, double* std_,
+                srx_pca_info* info);
+/* varm["PCA_loadings"] layout (dim_red/mod.rs:108-118): n_vars x n_pc, row sel[i] <-
+ * loadings row i = components[i,:] * std[i] (pca/mod.rs:204-215), other rows 0. */
+int32_t srx_pca_loadings(const double* components, const double* std_, const uint64_t* sel,
+                         uint64_t k, uint64_t n_pc, uint64_t n_vars, double* out);
+
+/* ---- fused pipeline: normalize_total_inplace(target, Row) -> log1p_transform_inplace ->
+ * pca_inplace(n_pc, center, scale, .., HighlyVariable(n_hvg)) with every intermediate
+ * resident in HBM.  Results stay on the device until fetched. */
+typedef struct srx_pipeline_result {
+    srx_pca_info pca;
+    double ms_normalize, ms_moments, ms_select, ms_compact, ms_pca; /* hipEvent stage times */
+} srx_pipeline_result;
+int32_t srx_pipeline(srx_mat* m, double target_sum, uint64_t n_hvg, const srx_pca_opts* opts,
+                     srx_pipeline_result* res);
+/* Fetch what the last srx_pca / srx_pipeline on `m` left in HBM (any pointer may be NULL;
+ * hvg_idx has room for `k` entries). */
+int32_t srx_result_fetch(srx_mat* m, double* scores, double* components, double* evr,
+                         double* mean, double* std_, uint64_t* hvg_idx);
+
+/* ---- measurement hooks --------------------------------------------------------------------
+ * When enabled, every launch of a kernel class is bracketed by hipEvents on the ctx stream.
+ * srx_prof_get returns accumulated device time, launch count and the ALGORITHMIC bytes
+ *  the launches moved. */
+typedef enum srx_kernel_class {
+    SRX_K_NORMALIZE = 0,   /* fused row-sum + scale + log1p                               */
+    SRX_K_MOMENTS = 1,     /* gene-tiled (cnt, sum, sumsq)                                */
+    SRX_K_COMPACT = 2,     /* HVG compaction                                              */
+    SRX_K_SPMM_FWD = 3,    /* Y = X_sel P - 1 c^T                                         */
+    SRX_K_SPMM_T = 4,      /* T = X_sel^T Y                                               */
+    SRX_K_COUNT_ = 5
+} srx_kernel_class;
+int32_t srx_prof_enable(srx_ctx* ctx, uint32_t class_mask);
+int32_t srx_prof_reset(srx_ctx* ctx);
+int32_t srx_prof_get(srx_ctx* ctx, int32_t kernel_class, double* total_ms, uint64_t* launches,
+                     double* algorithmic_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRX_H */

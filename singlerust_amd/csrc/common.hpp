@@ -1,0 +1,178 @@
+// common.hpp — internal definitions shared by the translation units of libsrx_hip.so.
+// gfx950 / CDNA4 only: wave = 64 lanes, 256 CUs in 8 XCDs, 160 KiB LDS per CU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/srx.h"
+
+// rccl.h is only needed by comm.hip / the all-reduce helper; keep the handle opaque here.
+struct ncclComm;
+
+namespace srx {
+
+constexpr int kWave = 64;
+
+// ---- device-side helpers -----------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;  // every lane holds the total
+}
+template <typename T>
+__device__ __forceinline__ T wave_min(T v) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        T o = __shfl_xor(v, off, kWave);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        T o = __shfl_xor(v, off, kWave);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// ---- profiling accumulators ---------------------------------------------------------------
+struct ProfAcc {
+    double ms = 0.0;
+    uint64_t launches = 0;
+    double bytes = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace srx
+
+// ---- the opaque handles of srx.h -----------------------------------------------------------
+struct srx_ctx {
+    int device = 0;
+    int n_cus = 256;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // RCCL (one process per GPU)
+    ncclComm* comm = nullptr;
+    int n_ranks = 1, rank = 0;
+    // profiling
+    uint32_t prof_mask = 0;
+    srx::ProfAcc prof[SRX_K_COUNT_];
+    std::vector<hipEvent_t> event_pool;
+    // named scratch buffers that only ever grow (no hipMalloc inside the steady-state path)
+    struct Scratch { void* p = nullptr; size_t bytes = 0; };
+    std::map<std::string, Scratch> scratch;
+    // pinned host staging for small D2H/H2D blocks
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+};
+
+struct srx_pca_state {           // what the last srx_pca / srx_pipeline left in HBM
+    bool valid = false;
+    uint32_t k = 0, n_pc = 0;
+    double* d_scores = nullptr;      // n_rows x n_pc, row-major f64
+    size_t scores_cap = 0;
+    std::vector<double> components;  // k x n_pc (host copy; small)
+    std::vector<double> evr, mean, std_;
+    std::vector<uint64_t> sel;
+    srx_pca_info info{};
+};
+
+struct srx_mat {
+    srx_ctx* ctx = nullptr;
+    uint64_t n_rows = 0, n_cols = 0, nnz = 0;
+    int32_t dtype = SRX_F32;   // logical dtype (DynCsrMatrix variant)
+    int32_t store = SRX_STORE_F32;
+    int64_t* d_indptr = nullptr;
+    int32_t* d_indices = nullptr;
+    void* d_values = nullptr;
+    uint64_t row_offset = 0;
+    // gene tiling for the LDS-privatised per-gene passes (built lazily, pattern-only)
+    int n_tiles = 0;
+    int tile_genes = 0;
+    int64_t* d_tile_ptr = nullptr;  // (n_tiles-1) x n_rows absolute positions
+    // per-gene moment cache, keyed by the value version
+    uint64_t version = 1;
+    uint64_t moments_version = 0;
+    uint64_t* d_cnt = nullptr;      // n_cols (global after all-reduce)
+    double* d_sum = nullptr;
+    double* d_sq = nullptr;
+    uint64_t n_rows_global = 0;     // valid with moments
+    double* d_row_sum = nullptr;    // n_rows f64, filled by the normalise pass
+    srx_pca_state pca;
+};
+
+namespace srx {
+
+// ---- error plumbing ------------------------------------------------------------------------
+extern thread_local std::string g_tls_err;
+
+inline int32_t fail(srx_ctx* ctx, int32_t code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_tls_err = buf;
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define SRX_HIP(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return srx::fail((ctx), e__ == hipErrorOutOfMemory ? SRX_E_OOM : SRX_E_HIP,      \
+                             "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),         \
+                             __FILE__, __LINE__);                                            \
+    } while (0)
+
+#define SRX_TRY(expr)                          \
+    do {                                       \
+        int32_t rc__ = (expr);                 \
+        if (rc__ != SRX_OK) return rc__;       \
+    } while (0)
+
+// ---- scratch / staging ---------------------------------------------------------------------
+int32_t scratch(srx_ctx* ctx, const char* name, size_t bytes, void** out);
+int32_t pinned(srx_ctx* ctx, size_t bytes, void** out);
+int32_t d2h(srx_ctx* ctx, void* host, const void* dev, size_t bytes);   // via pinned, synchronises
+int32_t h2d(srx_ctx* ctx, void* dev, const void* host, size_t bytes);
+
+// ---- profiling -------------------------------------------------------------------------------
+struct ProfScope {
+    srx_ctx* ctx;
+    int cls;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(srx_ctx* c, int cls_, double alg_bytes);
+    ~ProfScope();
+};
+
+// ---- cross-rank sum (RCCL) --------------------------------------------------------------------
+// In-place f64 sum over all ranks on ctx->stream; no-op for a single rank.
+int32_t allreduce_f64(srx_ctx* ctx, double* d_buf, size_t count);
+
+// ---- internal entry points shared between translation units -----------------------------------
+int32_t ensure_tiles(srx_mat* m);
+int32_t ensure_moments(srx_mat* m);   // fills d_cnt/d_sum/d_sq (global) for the current values
+int32_t launch_normalize(srx_mat* m, double target, bool do_norm, bool do_log);
+inline void touch(srx_mat* m) { m->version++; m->pca.valid = false; }
+
+inline bool is_f32(const srx_mat* m) { return m->store == SRX_STORE_F32; }
+inline size_t val_bytes(const srx_mat* m) { return is_f32(m) ? 4 : 8; }
+
+}  // namespace srx

@@ -1,0 +1,501 @@
+// ctx.hip — context, scratch memory, profiling hooks and the device-resident CSR
+// (upload / alloc / download) of libsrx_hip.so.
+//
+// Device layout of X (SURVEY.md §8 "device layout"): int64 row offsets, int32 column
+// indices, f32 or f64 values — the narrowing of the reference's usize indices
+// (nalgebra_sparse::CsrMatrix) happens once, here.
+#include "common.hpp"
+
+namespace srx {
+
+thread_local std::string g_tls_err;
+
+int32_t scratch(srx_ctx* ctx, const char* name, size_t bytes, void** out) {
+    auto& s = ctx->scratch[name];
+    if (s.bytes < bytes) {
+        if (s.p) SRX_HIP(ctx, hipFree(s.p));
+        s.p = nullptr;
+        s.bytes = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        SRX_HIP(ctx, hipMalloc(&s.p, want));
+        s.bytes = want;
+    }
+    *out = s.p;
+    return SRX_OK;
+}
+
+int32_t pinned(srx_ctx* ctx, size_t bytes, void** out) {
+    if (ctx->pinned_bytes < bytes) {
+        if (ctx->pinned) SRX_HIP(ctx, hipHostFree(ctx->pinned));
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+        size_t want = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 4;
+        SRX_HIP(ctx, hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+        ctx->pinned_bytes = want;
+    }
+    *out = ctx->pinned;
+    return SRX_OK;
+}
+
+// Small/medium blocks go through the pinned staging buffer so the copy is a true async DMA
+// ordered on the ctx stream; large blocks (values of the whole matrix) go direct.
+int32_t d2h(srx_ctx* ctx, void* host, const void* dev, size_t bytes) {
+    if (bytes == 0) return SRX_OK;
+    if (bytes <= (64u << 20)) {
+        void* p;
+        SRX_TRY(pinned(ctx, bytes, &p));
+        SRX_HIP(ctx, hipMemcpyAsync(p, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(host, p, bytes);
+    } else {
+        SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SRX_HIP(ctx, hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+    }
+    return SRX_OK;
+}
+
+int32_t h2d(srx_ctx* ctx, void* dev, const void* host, size_t bytes) {
+    if (bytes == 0) return SRX_OK;
+    if (bytes <= (64u << 20)) {
+        void* p;
+        // the staging buffer may still feed an earlier async copy
+        SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SRX_TRY(pinned(ctx, bytes, &p));
+        memcpy(p, host, bytes);
+        SRX_HIP(ctx, hipMemcpyAsync(dev, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SRX_HIP(ctx, hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
+    }
+    return SRX_OK;
+}
+
+// ---- profiling -------------------------------------------------------------------------------
+static hipEvent_t take_event(srx_ctx* ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+ProfScope::ProfScope(srx_ctx* c, int cls_, double alg_bytes) : ctx(c), cls(cls_) {
+    if (!(ctx->prof_mask & (1u << cls))) return;
+    e0 = take_event(ctx);
+    e1 = take_event(ctx);
+    if (!e0 || !e1) { e0 = e1 = nullptr; return; }
+    ctx->prof[cls].bytes += alg_bytes;
+    ctx->prof[cls].launches += 1;
+    (void)hipEventRecord(e0, ctx->stream);
+}
+ProfScope::~ProfScope() {
+    if (!e0) return;
+    (void)hipEventRecord(e1, ctx->stream);
+    ctx->prof[cls].pending.emplace_back(e0, e1);
+}
+
+static int32_t prof_drain(srx_ctx* ctx) {
+    SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < SRX_K_COUNT_; ++c) {
+        for (auto& pr : ctx->prof[c].pending) {
+            float ms = 0.f;
+            SRX_HIP(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
+            ctx->prof[c].ms += ms;
+            ctx->event_pool.push_back(pr.first);
+            ctx->event_pool.push_back(pr.second);
+        }
+        ctx->prof[c].pending.clear();
+    }
+    return SRX_OK;
+}
+
+// ---- upload kernels ------------------------------------------------------------------------------
+__global__ void k_narrow_indices(const uint64_t* __restrict__ src, int32_t* __restrict__ dst,
+                                 uint64_t n, uint64_t n_cols, int* __restrict__ flag) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (; i < n; i += stride) {
+        uint64_t c = src[i];
+        bad |= (c >= n_cols);
+        dst[i] = (int32_t)c;
+    }
+    if (bad) atomicOr(flag, 1);
+}
+
+template <typename S, typename D>
+__global__ void k_convert_values(const S* __restrict__ src, D* __restrict__ dst, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = (D)src[i];
+}
+
+// One wave per row: column indices strictly increasing inside the row (canonical CSR; the
+// reference's CsrNonCanonical arm is todo!(), src/shared/statistics/mod.rs:11) and row
+// offsets monotone.
+__global__ void k_validate_rows(const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx,
+                                uint64_t n_rows, uint64_t nnz, int* __restrict__ flag) {
+    uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
+    int lane = lane_id();
+    bool bad = false;
+    for (uint64_t r = wave; r < n_rows; r += n_waves) {
+        int64_t lo = indptr[r], hi = indptr[r + 1];
+        if (lo > hi || lo < 0 || (uint64_t)hi > nnz) { bad = true; continue; }
+        for (int64_t p = lo + lane; p + 1 < hi; p += kWave) bad |= !(idx[p] < idx[p + 1]);
+    }
+    if (bad) atomicOr(flag, 2);
+}
+
+static int grid_for(uint64_t n, int block, int cap) {
+    uint64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > (uint64_t)cap) g = cap;
+    return (int)g;
+}
+
+template <typename S>
+static int32_t convert_chunked(srx_ctx* ctx, const void* host, void* d_dst, uint64_t n, bool to_f32) {
+    const uint64_t chunk = 32ull << 20;  // elements per staging chunk
+    void* d_tmp;
+    SRX_TRY(scratch(ctx, "upload_tmp", (n < chunk ? n : chunk) * sizeof(S) + 16, &d_tmp));
+    for (uint64_t off = 0; off < n; off += chunk) {
+        uint64_t cnt = n - off < chunk ? n - off : chunk;
+        SRX_HIP(ctx, hipMemcpy(d_tmp, (const S*)host + off, cnt * sizeof(S), hipMemcpyHostToDevice));
+        int g = grid_for(cnt, 256, 4096);
+        if (to_f32)
+            hipLaunchKernelGGL((k_convert_values<S, float>), dim3(g), dim3(256), 0, ctx->stream,
+                               (const S*)d_tmp, (float*)d_dst + off, cnt);
+        else
+            hipLaunchKernelGGL((k_convert_values<S, double>), dim3(g), dim3(256), 0, ctx->stream,
+                               (const S*)d_tmp, (double*)d_dst + off, cnt);
+        SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return SRX_OK;
+}
+
+static void free_mat_buffers(srx_mat* m) {
+    if (!m) return;
+    (void)hipFree(m->d_indptr);
+    (void)hipFree(m->d_indices);
+    (void)hipFree(m->d_values);
+    (void)hipFree(m->d_tile_ptr);
+    (void)hipFree(m->d_cnt);
+    (void)hipFree(m->d_sum);
+    (void)hipFree(m->d_sq);
+    (void)hipFree(m->d_row_sum);
+    (void)hipFree(m->pca.d_scores);
+}
+
+static int32_t resolve_store(int32_t dtype, int32_t store) {
+    if (store == SRX_STORE_F32 || store == SRX_STORE_F64) return store;
+    switch (dtype) {
+        case SRX_I32: case SRX_U32: case SRX_F64: return SRX_STORE_F64;
+        default: return SRX_STORE_F32;
+    }
+}
+
+}  // namespace srx
+
+using namespace srx;
+
+extern "C" {
+
+int32_t srx_abi_version(void) { return SRX_ABI_VERSION; }
+
+int32_t srx_device_count(int32_t* n_out) {
+    if (!n_out) return fail(nullptr, SRX_E_ARG, "srx_device_count: null output");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *n_out = 0;
+        return fail(nullptr, SRX_E_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    }
+    *n_out = n;
+    return SRX_OK;
+}
+
+int32_t srx_ctx_create(int32_t device_id, srx_ctx** out) {
+    if (!out) return fail(nullptr, SRX_E_ARG, "srx_ctx_create: null output");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, SRX_E_HIP, "no HIP device available (%s); libsrx_hip has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device_id < 0 || device_id >= n)
+        return fail(nullptr, SRX_E_ARG, "device_id %d out of range [0,%d)", device_id, n);
+    srx_ctx* ctx = new srx_ctx();
+    ctx->device = device_id;
+    SRX_HIP(ctx, hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    SRX_HIP(ctx, hipGetDeviceProperties(&prop, device_id));
+    ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    SRX_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    *out = ctx;
+    return SRX_OK;
+}
+
+void srx_ctx_destroy(srx_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    srx_comm_destroy(ctx);
+    for (auto& kv : ctx->scratch) (void)hipFree(kv.second.p);
+    for (int c = 0; c < SRX_K_COUNT_; ++c)
+        for (auto& pr : ctx->prof[c].pending) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int32_t srx_ctx_synchronize(srx_ctx* ctx) {
+    if (!ctx) return fail(nullptr, SRX_E_ARG, "null ctx");
+    SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SRX_OK;
+}
+
+const char* srx_last_error(const srx_ctx* ctx) {
+    if (ctx) return ctx->err.c_str();
+    return g_tls_err.c_str();
+}
+
+int32_t srx_partition_rows(const uint64_t* indptr, uint64_t n_rows, int32_t n_ranks,
+                           uint64_t* cut_out) {
+    if (!indptr || !cut_out || n_ranks < 1) return fail(nullptr, SRX_E_ARG, "srx_partition_rows: bad args");
+    // cut[r] = first row whose start offset reaches r/n_ranks of the non-zeros (binary search
+    // on indptr): balances bytes walked per GPU, not row counts.
+    uint64_t base = indptr[0], nnz = indptr[n_rows] - base;
+    cut_out[0] = 0;
+    for (int r = 1; r < n_ranks; ++r) {
+        uint64_t target = base + (uint64_t)(((__uint128_t)nnz * (unsigned)r) / (unsigned)n_ranks);
+        uint64_t lo = cut_out[r - 1], hi = n_rows;
+        while (lo < hi) {
+            uint64_t mid = lo + (hi - lo) / 2;
+            if (indptr[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        cut_out[r] = lo;
+    }
+    cut_out[n_ranks] = n_rows;
+    return SRX_OK;
+}
+
+int32_t srx_matrix_alloc(srx_ctx* ctx, uint64_t n_rows, uint64_t n_cols, uint64_t nnz,
+                         int32_t dtype, int32_t store, srx_mat** out) {
+    if (!ctx || !out) return fail(ctx, SRX_E_ARG, "srx_matrix_alloc: null argument");
+    *out = nullptr;
+    if (dtype < SRX_I8 || dtype > SRX_F64)
+        return fail(ctx, SRX_E_DTYPE, "dtype %d is not supported for this operation", dtype);
+    if (n_cols >= (1ull << 31)) return fail(ctx, SRX_E_BOUNDS, "n_cols %llu exceeds int32 device indices",
+                                            (unsigned long long)n_cols);
+    SRX_HIP(ctx, hipSetDevice(ctx->device));
+    srx_mat* m = new srx_mat();
+    m->ctx = ctx;
+    m->n_rows = n_rows; m->n_cols = n_cols; m->nnz = nnz;
+    m->dtype = dtype;
+    m->store = resolve_store(dtype, store);
+    m->n_rows_global = n_rows;
+    hipError_t e;
+    e = hipMalloc((void**)&m->d_indptr, (n_rows + 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&m->d_indices, (nnz ? nnz : 1) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&m->d_values, (nnz ? nnz : 1) * val_bytes(m));
+    if (e != hipSuccess) {
+        free_mat_buffers(m);
+        delete m;
+        return fail(ctx, e == hipErrorOutOfMemory ? SRX_E_OOM : SRX_E_HIP, "hipMalloc for CSR failed: %s",
+                    hipGetErrorString(e));
+    }
+    *out = m;
+    return SRX_OK;
+}
+
+int32_t srx_matrix_upload(srx_ctx* ctx, const srx_csr* h, int32_t store, srx_mat** out) {
+    if (!ctx || !h || !out) return fail(ctx, SRX_E_ARG, "srx_matrix_upload: null argument");
+    *out = nullptr;
+    if (!h->indptr || (h->nnz && (!h->indices || !h->values)))
+        return fail(ctx, SRX_E_ARG, "srx_matrix_upload: null CSR slice");
+    if (h->indptr[h->n_rows] - h->indptr[0] != h->nnz || h->indptr[0] != 0)
+        return fail(ctx, SRX_E_FORMAT, "X is not a CSR matrix: row_offsets do not span nnz");
+    srx_mat* m = nullptr;
+    SRX_TRY(srx_matrix_alloc(ctx, h->n_rows, h->n_cols, h->nnz, h->dtype, store, &m));
+    auto bail = [&](int32_t rc) { srx_matrix_free(m); return rc; };
+    hipError_t e = hipMemcpy(m->d_indptr, h->indptr, (h->n_rows + 1) * sizeof(int64_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "H2D indptr: %s", hipGetErrorString(e)));
+
+    int* d_flag;
+    int32_t rc = scratch(ctx, "flag", 64, (void**)&d_flag);
+    if (rc) return bail(rc);
+    (void)hipMemsetAsync(d_flag, 0, sizeof(int), ctx->stream);
+
+    // indices: u64 -> i32 through a staging chunk
+    {
+        const uint64_t chunk = 32ull << 20;
+        void* d_tmp;
+        uint64_t c0 = h->nnz < chunk ? h->nnz : chunk;
+        rc = scratch(ctx, "upload_tmp", (c0 ? c0 : 1) * sizeof(uint64_t) + 16, &d_tmp);
+        if (rc) return bail(rc);
+        for (uint64_t off = 0; off < h->nnz; off += chunk) {
+            uint64_t cnt = h->nnz - off < chunk ? h->nnz - off : chunk;
+            e = hipMemcpy(d_tmp, h->indices + off, cnt * sizeof(uint64_t), hipMemcpyHostToDevice);
+            if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "H2D indices: %s", hipGetErrorString(e)));
+            hipLaunchKernelGGL(k_narrow_indices, dim3(grid_for(cnt, 256, 4096)), dim3(256), 0, ctx->stream,
+                               (const uint64_t*)d_tmp, m->d_indices + off, cnt, h->n_cols, d_flag);
+            e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "narrow indices: %s", hipGetErrorString(e)));
+        }
+    }
+    // values
+    bool f32 = is_f32(m);
+    if ((h->dtype == SRX_F32 && f32) || (h->dtype == SRX_F64 && !f32)) {
+        e = hipMemcpy(m->d_values, h->values, h->nnz * val_bytes(m), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "H2D values: %s", hipGetErrorString(e)));
+    } else if (h->nnz) {
+        switch (h->dtype) {
+            case SRX_I8:  rc = convert_chunked<int8_t>(ctx, h->values, m->d_values, h->nnz, f32); break;
+            case SRX_I16: rc = convert_chunked<int16_t>(ctx, h->values, m->d_values, h->nnz, f32); break;
+            case SRX_I32: rc = convert_chunked<int32_t>(ctx, h->values, m->d_values, h->nnz, f32); break;
+            case SRX_U8:  rc = convert_chunked<uint8_t>(ctx, h->values, m->d_values, h->nnz, f32); break;
+            case SRX_U16: rc = convert_chunked<uint16_t>(ctx, h->values, m->d_values, h->nnz, f32); break;
+            case SRX_U32: rc = convert_chunked<uint32_t>(ctx, h->values, m->d_values, h->nnz, f32); break;
+            case SRX_F32: rc = convert_chunked<float>(ctx, h->values, m->d_values, h->nnz, f32); break;
+            case SRX_F64: rc = convert_chunked<double>(ctx, h->values, m->d_values, h->nnz, f32); break;
+            default: rc = fail(ctx, SRX_E_DTYPE, "dtype %d is not supported for this operation", h->dtype);
+        }
+        if (rc) return bail(rc);
+    }
+    // validate
+    hipLaunchKernelGGL(k_validate_rows, dim3(grid_for(h->n_rows * kWave, 256, 8192)), dim3(256), 0, ctx->stream,
+                       m->d_indptr, m->d_indices, h->n_rows, h->nnz, d_flag);
+    int flag = 0;
+    rc = d2h(ctx, &flag, d_flag, sizeof(int));
+    if (rc) return bail(rc);
+    if (flag & 1) return bail(fail(ctx, SRX_E_BOUNDS, "column index out of bounds (>= n_cols = %llu)",
+                                   (unsigned long long)h->n_cols));
+    if (flag & 2) return bail(fail(ctx, SRX_E_FORMAT, "X is not a canonical CSR matrix (unsorted/duplicate column indices)"));
+    *out = m;
+    return SRX_OK;
+}
+
+int32_t srx_matrix_device_ptrs(srx_mat* m, void** indptr, void** indices, void** values) {
+    if (!m) return fail(nullptr, SRX_E_ARG, "null matrix");
+    if (indptr) *indptr = m->d_indptr;
+    if (indices) *indices = m->d_indices;
+    if (values) *values = m->d_values;
+    touch(m);  // the caller may write through these pointers
+    m->moments_version = 0;
+    if (m->d_tile_ptr) { (void)hipFree(m->d_tile_ptr); m->d_tile_ptr = nullptr; m->n_tiles = 0; }
+    return SRX_OK;
+}
+
+int32_t srx_matrix_info(const srx_mat* m, srx_mat_info* out) {
+    if (!m || !out) return fail(nullptr, SRX_E_ARG, "null argument");
+    out->n_rows = m->n_rows; out->n_cols = m->n_cols; out->nnz = m->nnz;
+    out->dtype = m->dtype; out->store = m->store;
+    out->row_offset = m->row_offset;
+    out->n_rows_global = m->n_rows_global;
+    return SRX_OK;
+}
+
+int32_t srx_matrix_set_shard(srx_mat* m, uint64_t row_offset) {
+    if (!m) return fail(nullptr, SRX_E_ARG, "null matrix");
+    m->row_offset = row_offset;
+    return SRX_OK;
+}
+
+int32_t srx_matrix_download_values(srx_mat* m, void* out, int32_t dtype_out) {
+    if (!m || !out) return fail(m ? m->ctx : nullptr, SRX_E_ARG, "null argument");
+    srx_ctx* ctx = m->ctx;
+    if (dtype_out != SRX_F32 && dtype_out != SRX_F64)
+        return fail(ctx, SRX_E_DTYPE, "values can be fetched as F32 or F64 only");
+    SRX_HIP(ctx, hipSetDevice(ctx->device));
+    bool same = (dtype_out == SRX_F32) == is_f32(m);
+    if (same) return d2h(ctx, out, m->d_values, m->nnz * val_bytes(m));
+    void* d_tmp;
+    size_t ob = dtype_out == SRX_F32 ? 4 : 8;
+    SRX_TRY(scratch(ctx, "download_tmp", (m->nnz ? m->nnz : 1) * ob, &d_tmp));
+    int g = grid_for(m->nnz, 256, 4096);
+    if (is_f32(m))
+        hipLaunchKernelGGL((k_convert_values<float, double>), dim3(g), dim3(256), 0, ctx->stream,
+                           (const float*)m->d_values, (double*)d_tmp, m->nnz);
+    else
+        hipLaunchKernelGGL((k_convert_values<double, float>), dim3(g), dim3(256), 0, ctx->stream,
+                           (const double*)m->d_values, (float*)d_tmp, m->nnz);
+    return d2h(ctx, out, d_tmp, m->nnz * ob);
+}
+
+int32_t srx_matrix_clone(srx_mat* m, srx_mat** out) {
+    if (!m || !out) return fail(m ? m->ctx : nullptr, SRX_E_ARG, "null argument");
+    srx_ctx* ctx = m->ctx;
+    srx_mat* c = nullptr;
+    SRX_TRY(srx_matrix_alloc(ctx, m->n_rows, m->n_cols, m->nnz, m->dtype, m->store, &c));
+    c->row_offset = m->row_offset;
+    hipError_t e = hipMemcpyAsync(c->d_indptr, m->d_indptr, (m->n_rows + 1) * sizeof(int64_t),
+                                  hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_indices, m->d_indices, m->nnz * sizeof(int32_t),
+                                            hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_values, m->d_values, m->nnz * val_bytes(m),
+                                            hipMemcpyDeviceToDevice, ctx->stream);
+    if (e != hipSuccess) {
+        srx_matrix_free(c);
+        return fail(ctx, SRX_E_HIP, "clone D2D: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return SRX_OK;
+}
+
+int32_t srx_matrix_copy_values(srx_mat* dst, const srx_mat* src) {
+    if (!dst || !src) return fail(nullptr, SRX_E_ARG, "null argument");
+    srx_ctx* ctx = dst->ctx;
+    if (dst->nnz != src->nnz || dst->n_rows != src->n_rows || dst->store != src->store)
+        return fail(ctx, SRX_E_ARG, "copy_values: pattern/storage mismatch");
+    SRX_HIP(ctx, hipMemcpyAsync(dst->d_values, src->d_values, src->nnz * val_bytes(src),
+                                hipMemcpyDeviceToDevice, ctx->stream));
+    dst->dtype = src->dtype;
+    touch(dst);
+    return SRX_OK;
+}
+
+void srx_matrix_free(srx_mat* m) {
+    if (!m) return;
+    if (m->ctx) {
+        (void)hipSetDevice(m->ctx->device);
+        (void)hipStreamSynchronize(m->ctx->stream);
+    }
+    free_mat_buffers(m);
+    delete m;
+}
+
+int32_t srx_prof_enable(srx_ctx* ctx, uint32_t class_mask) {
+    if (!ctx) return fail(nullptr, SRX_E_ARG, "null ctx");
+    ctx->prof_mask = class_mask;
+    return SRX_OK;
+}
+
+int32_t srx_prof_reset(srx_ctx* ctx) {
+    if (!ctx) return fail(nullptr, SRX_E_ARG, "null ctx");
+    SRX_TRY(prof_drain(ctx));
+    for (int c = 0; c < SRX_K_COUNT_; ++c) {
+        ctx->prof[c].ms = 0.0;
+        ctx->prof[c].launches = 0;
+        ctx->prof[c].bytes = 0.0;
+    }
+    return SRX_OK;
+}
+
+int32_t srx_prof_get(srx_ctx* ctx, int32_t cls, double* total_ms, uint64_t* launches, double* bytes) {
+    if (!ctx || cls < 0 || cls >= SRX_K_COUNT_) return fail(ctx, SRX_E_ARG, "bad kernel class");
+    SRX_TRY(prof_drain(ctx));
+    if (total_ms) *total_ms = ctx->prof[cls].ms;
+    if (launches) *launches = ctx->prof[cls].launches;
+    if (bytes) *bytes = ctx->prof[cls].bytes;
+    return SRX_OK;
+}
+
+}  // extern "C"

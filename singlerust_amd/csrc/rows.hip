@@ -1,0 +1,237 @@
+// rows.hip — per-cell (row-direction) kernels: nnz counts, row sums, the fused
+// normalise + log1p pass, row variance, row min/max.
+//
+// All of them are one-wave-per-row CSR walks: the 64 lanes read consecutive values of the
+// row (coalesced 256 B per instruction, 16 independent loads in flight per lane), reduce
+// with wavefront shuffles in f64, and — for the in-place ops — write the row back from
+// registers, so a row is read from HBM exactly once.
+//
+// Algorithmic bytes: fused normalise+log1p = nnz*2*s_v + (N+1)*8.
+#include "common.hpp"
+
+namespace srx {
+
+constexpr int kRowCache = 16;  // values per lane kept in registers: rows up to 1024 nnz
+
+template <typename T>
+__device__ __forceinline__ T apply_log1p(T x);
+template <>
+__device__ __forceinline__ float apply_log1p<float>(float x) { return log1pf(x); }
+template <>
+__device__ __forceinline__ double apply_log1p<double>(double x) { return log1p(x); }
+
+// Fused: s_i = sum_row f64(v); scale_i = (s_i == 0) ? 0 : target / s_i; v = v * scale_i
+// (scale/mod.rs:9-15,66-73: one division, one multiply — not v*target/s); then optionally
+// v = ln_1p(v) (transform/mod.rs:38-47).  F32SEM: the logical dtype is F32 and only log1p
+// runs, i.e. f32::ln_1p on the f32 value.
+template <typename T, bool NORM, bool LOG>
+__global__ __launch_bounds__(256) void k_row_pass(const int64_t* __restrict__ indptr, T* __restrict__ vals,
+                                                  uint64_t n_rows, double target,
+                                                  double* __restrict__ row_sum_out) {
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
+    const int lane = lane_id();
+    for (uint64_t r = wave; r < n_rows; r += n_waves) {
+        const int64_t lo = indptr[r], hi = indptr[r + 1];
+        T c[kRowCache];
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < kRowCache; ++t) {
+            int64_t p = lo + lane + (int64_t)t * kWave;
+            c[t] = p < hi ? vals[p] : T(0);
+        }
+        if (NORM) {
+#pragma unroll
+            for (int t = 0; t < kRowCache; ++t) s += (double)c[t];
+            for (int64_t p = lo + lane + (int64_t)kRowCache * kWave; p < hi; p += kWave) s += (double)vals[p];
+            s = wave_sum(s);
+            if (row_sum_out && lane == 0) row_sum_out[r] = s;
+        }
+        const double scale = NORM ? (s == 0.0 ? 0.0 : target / s) : 1.0;
+        auto f = [&](T v) -> T {
+            T x = NORM ? (T)((double)v * scale) : v;
+            return LOG ? apply_log1p<T>(x) : x;
+        };
+#pragma unroll
+        for (int t = 0; t < kRowCache; ++t) {
+            int64_t p = lo + lane + (int64_t)t * kWave;
+            if (p < hi) vals[p] = f(c[t]);
+        }
+        for (int64_t p = lo + lane + (int64_t)kRowCache * kWave; p < hi; p += kWave) vals[p] = f(vals[p]);
+    }
+}
+
+// compute_sum(Row): csr.rs:87-93.
+template <typename T>
+__global__ __launch_bounds__(256) void k_row_sum(const int64_t* __restrict__ indptr, const T* __restrict__ vals,
+                                                 uint64_t n_rows, double* __restrict__ out) {
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
+    const int lane = lane_id();
+    for (uint64_t r = wave; r < n_rows; r += n_waves) {
+        const int64_t lo = indptr[r], hi = indptr[r + 1];
+        double s = 0.0;
+        int64_t p = lo + lane;
+        for (; p + 3 * kWave < hi; p += 4 * kWave) {
+            T a = vals[p], b = vals[p + kWave], c = vals[p + 2 * kWave], d = vals[p + 3 * kWave];
+            s += (double)a; s += (double)b; s += (double)c; s += (double)d;
+        }
+        for (; p < hi; p += kWave) s += (double)vals[p];
+        s = wave_sum(s);
+        if (lane == 0) out[r] = s;
+    }
+}
+
+// compute_variance(Row): csr.rs:158-171 — mean = sum/cnt, sum((v-mean)^2)/cnt; 0/0 = NaN
+// for an empty row (kept).
+template <typename T>
+__global__ __launch_bounds__(256) void k_row_var(const int64_t* __restrict__ indptr, const T* __restrict__ vals,
+                                                 uint64_t n_rows, double* __restrict__ out) {
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
+    const int lane = lane_id();
+    for (uint64_t r = wave; r < n_rows; r += n_waves) {
+        const int64_t lo = indptr[r], hi = indptr[r + 1];
+        double s = 0.0;
+        for (int64_t p = lo + lane; p < hi; p += kWave) s += (double)vals[p];
+        s = wave_sum(s);
+        const double cnt = (double)(uint32_t)(hi - lo);
+        const double mean = s / cnt;
+        double a = 0.0;
+        for (int64_t p = lo + lane; p < hi; p += kWave) {
+            double d = (double)vals[p] - mean;
+            a += d * d;
+        }
+        a = wave_sum(a);
+        if (lane == 0) out[r] = a / cnt;
+    }
+}
+
+// compute_min_max(Row): csr.rs:200-210; f64::min/max skip NaN operands.
+template <typename T>
+__global__ __launch_bounds__(256) void k_row_minmax(const int64_t* __restrict__ indptr, const T* __restrict__ vals,
+                                                    uint64_t n_rows, double* __restrict__ mn,
+                                                    double* __restrict__ mx) {
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
+    const int lane = lane_id();
+    for (uint64_t r = wave; r < n_rows; r += n_waves) {
+        const int64_t lo = indptr[r], hi = indptr[r + 1];
+        double a = INFINITY, b = -INFINITY;
+        for (int64_t p = lo + lane; p < hi; p += kWave) {
+            double x = (double)vals[p];
+            a = fmin(a, x);
+            b = fmax(b, x);
+        }
+        a = wave_min(a);
+        b = wave_max(b);
+        if (lane == 0) { mn[r] = a; mx[r] = b; }
+    }
+}
+
+// compute_number(Row): csr.rs:21-28.
+__global__ void k_row_number(const int64_t* __restrict__ indptr, uint64_t n_rows, uint32_t* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n_rows; i += stride) out[i] = (uint32_t)(indptr[i + 1] - indptr[i]);
+}
+
+static int row_grid(const srx_mat* m) {
+    uint64_t want = (m->n_rows + 3) / 4;  // 4 waves per 256-thread block, one row per wave
+    uint64_t cap = (uint64_t)m->ctx->n_cus * 8;
+    if (want < 1) want = 1;
+    return (int)(want < cap ? want : cap);
+}
+
+int32_t launch_normalize(srx_mat* m, double target, bool do_norm, bool do_log) {
+    srx_ctx* ctx = m->ctx;
+    SRX_HIP(ctx, hipSetDevice(ctx->device));
+    if (do_norm && !m->d_row_sum) SRX_HIP(ctx, hipMalloc((void**)&m->d_row_sum, (m->n_rows ? m->n_rows : 1) * sizeof(double)));
+    const int g = row_grid(m);
+    const double bytes = (double)m->nnz * 2.0 * val_bytes(m) + (double)(m->n_rows + 1) * 8.0;
+    {
+        ProfScope ps(ctx, SRX_K_NORMALIZE, bytes);
+#define SRX_LAUNCH_ROW(T, N, L)                                                                    \
+    hipLaunchKernelGGL((k_row_pass<T, N, L>), dim3(g), dim3(256), 0, ctx->stream, m->d_indptr,      \
+                       (T*)m->d_values, m->n_rows, target, (N) ? m->d_row_sum : (double*)nullptr)
+        if (is_f32(m)) {
+            if (do_norm && do_log) SRX_LAUNCH_ROW(float, true, true);
+            else if (do_norm) SRX_LAUNCH_ROW(float, true, false);
+            else if (do_log) SRX_LAUNCH_ROW(float, false, true);
+        } else {
+            if (do_norm && do_log) SRX_LAUNCH_ROW(double, true, true);
+            else if (do_norm) SRX_LAUNCH_ROW(double, true, false);
+            else if (do_log) SRX_LAUNCH_ROW(double, false, true);
+        }
+#undef SRX_LAUNCH_ROW
+    }
+    SRX_HIP(ctx, hipGetLastError());
+    // logical dtype bookkeeping: scale/mod.rs:74-83 (-> F64), transform/mod.rs:43-55
+    if (do_norm) m->dtype = SRX_F64;
+    if (do_log && m->dtype != SRX_F32) m->dtype = SRX_F64;
+    touch(m);
+    return SRX_OK;
+}
+
+}  // namespace srx
+
+using namespace srx;
+
+extern "C" {
+
+int32_t srx_log1p_inplace(srx_mat* m) {
+    if (!m) return fail(nullptr, SRX_E_ARG, "null matrix");
+    return launch_normalize(m, 0.0, false, true);
+}
+
+int32_t srx_normalize_log1p_inplace(srx_mat* m, double target_sum, double* row_sums_out) {
+    if (!m) return fail(nullptr, SRX_E_ARG, "null matrix");
+    SRX_TRY(launch_normalize(m, target_sum, true, true));
+    if (row_sums_out) SRX_TRY(d2h(m->ctx, row_sums_out, m->d_row_sum, m->n_rows * sizeof(double)));
+    return SRX_OK;
+}
+
+}  // extern "C"
+
+namespace srx {
+
+// Row-direction halves of the statistics entry points (genes.hip holds the Column halves and
+// the extern "C" wrappers).
+int32_t row_number(srx_mat* m, uint32_t* out) {
+    srx_ctx* ctx = m->ctx;
+    uint32_t* d;
+    SRX_TRY(scratch(ctx, "row_u32", (m->n_rows ? m->n_rows : 1) * sizeof(uint32_t), (void**)&d));
+    uint64_t g = (m->n_rows + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_row_number, dim3((int)g), dim3(256), 0, ctx->stream, m->d_indptr, m->n_rows, d);
+    SRX_HIP(ctx, hipGetLastError());
+    return d2h(ctx, out, d, m->n_rows * sizeof(uint32_t));
+}
+
+int32_t row_stat(srx_mat* m, int which, double* out0, double* out1) {
+    srx_ctx* ctx = m->ctx;
+    double* d;
+    SRX_TRY(scratch(ctx, "row_f64", 2 * (m->n_rows ? m->n_rows : 1) * sizeof(double), (void**)&d));
+    double* d1 = d + m->n_rows;
+    const int g = row_grid(m);
+#define SRX_ROW_K(K, ...)                                                                          \
+    do {                                                                                           \
+        if (is_f32(m))                                                                             \
+            hipLaunchKernelGGL((K<float>), dim3(g), dim3(256), 0, ctx->stream, m->d_indptr,         \
+                               (const float*)m->d_values, m->n_rows, __VA_ARGS__);                  \
+        else                                                                                       \
+            hipLaunchKernelGGL((K<double>), dim3(g), dim3(256), 0, ctx->stream, m->d_indptr,        \
+                               (const double*)m->d_values, m->n_rows, __VA_ARGS__);                 \
+    } while (0)
+    if (which == 0) SRX_ROW_K(k_row_sum, d);
+    else if (which == 1) SRX_ROW_K(k_row_var, d);
+    else SRX_ROW_K(k_row_minmax, d, d1);
+#undef SRX_ROW_K
+    SRX_HIP(ctx, hipGetLastError());
+    SRX_TRY(d2h(ctx, out0, d, m->n_rows * sizeof(double)));
+    if (which == 2) SRX_TRY(d2h(ctx, out1, d1, m->n_rows * sizeof(double)));
+    return SRX_OK;
+}
+
+}  // namespace srx

@@ -1,0 +1,123 @@
+"""CPU tests (-m "not gpu") of the drop-in boundary: the C-ABI library loads without a GPU,
+exports every symbol include/*.h declares, and fails LOUDLY (no CPU fallback) when asked to
+compute without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    names = []
+    for h in ("srx.h", "srx_synth.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names += re.findall(r"\b(srx_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from singlerust_amd import build, _ffi
+    build.build()
+    return _ffi.lib()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from singlerust_amd import _ffi
+    decl = declared_functions()
+    assert len(decl) >= 35
+    for name in decl:
+        assert hasattr(lib, name), f"{name} declared in include/*.h but not exported"
+    # and the ctypes binding covers the whole header
+    assert set(decl) == set(_ffi.EXPORTS)
+
+
+def test_abi_version(lib):
+    assert lib.srx_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    """sizeof() of the ctypes mirrors equals what the C compiler lays out (checked with gcc)."""
+    import subprocess, tempfile
+    from singlerust_amd import _ffi
+    prog = r'''
+#include <stdio.h>
+#include "srx.h"
+#include "srx_synth.h"
+int main(void){printf("%zu %zu %zu %zu %zu %zu\n", sizeof(srx_csr), sizeof(srx_mat_info), sizeof(srx_pca_opts),
+ sizeof(srx_pca_info), sizeof(srx_pipeline_result), sizeof(srx_synth_params)); return 0;}'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(prog)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "t")]).split()]
+    mirrors = [_ffi.Csr, _ffi.MatInfo, _ffi.PcaOpts, _ffi.PcaInfo, _ffi.PipelineResult, _ffi.SynthParams]
+    assert sizes == [C.sizeof(m) for m in mirrors]
+
+
+def test_partition_rows_is_nnz_balanced(lib):
+    from singlerust_amd import _ffi
+    rng = np.random.default_rng(0)
+    lens = rng.integers(0, 200, 5000)
+    lens[100:200] = 3000                                     # a heavy stripe
+    indptr = np.zeros(5001, dtype=np.uint64)
+    indptr[1:] = np.cumsum(lens)
+    for n in (1, 2, 3, 8):
+        cut = np.zeros(n + 1, dtype=np.uint64)
+        assert lib.srx_partition_rows(_ffi.ptr(indptr), 5000, n, _ffi.ptr(cut)) == 0
+        assert cut[0] == 0 and cut[-1] == 5000 and np.all(np.diff(cut.astype(np.int64)) >= 0)
+        per = np.diff(indptr[cut.astype(np.int64)].astype(np.int64))
+        assert per.sum() == indptr[-1]
+        assert per.max() - per.min() <= 2 * 3000             # within one heavy row of balanced
+
+
+def test_synth_host_generator_is_canonical_csr(lib):
+    from singlerust_amd import _ffi
+    p = _ffi.SynthParams()
+    lib.srx_synth_defaults(C.byref(p), 11, 3000, 4000, 0.05)
+    indptr = np.zeros(3001, dtype=np.uint64)
+    assert lib.srx_synth_indptr(C.byref(p), 0, 3000, _ffi.ptr(indptr)) == 0
+    nnz = int(indptr[-1])
+    idx = np.zeros(nnz, dtype=np.uint64)
+    val = np.zeros(nnz, dtype=np.float32)
+    assert lib.srx_synth_fill_host(C.byref(p), 0, 3000, _ffi.ptr(indptr), _ffi.ptr(idx), _ffi.ptr(val)) == 0
+    assert idx.max() < 4000 and val.min() >= 1
+    lens = np.diff(indptr.astype(np.int64))
+    assert abs(lens.mean() / 4000 - 0.05) < 0.01
+    for i in range(3000):
+        assert np.all(np.diff(idx[indptr[i]:indptr[i + 1]].astype(np.int64)) > 0)   # sorted + unique
+    # any row range is reproducible on its own (shard-local generation)
+    ip2 = np.zeros(501, dtype=np.uint64)
+    lib.srx_synth_indptr(C.byref(p), 1000, 1500, _ffi.ptr(ip2))
+    idx2 = np.zeros(int(ip2[-1]), dtype=np.uint64)
+    val2 = np.zeros(int(ip2[-1]), dtype=np.float32)
+    lib.srx_synth_fill_host(C.byref(p), 1000, 1500, _ffi.ptr(ip2), _ffi.ptr(idx2), _ffi.ptr(val2))
+    a, b = int(indptr[1000]), int(indptr[1500])
+    assert np.array_equal(idx2, idx[a:b]) and np.array_equal(val2, val[a:b])
+
+
+def test_no_cpu_fallback_without_gpu(lib):
+    """Without a device every compute path must raise — never silently compute on the host."""
+    from singlerust_amd import _ffi
+    n = C.c_int32(0)
+    rc = lib.srx_device_count(C.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is visible here")
+    import singlerust_amd as sr
+    with pytest.raises(sr.SrxError) as ei:
+        sr.Context(0)
+    assert ei.value.code == _ffi.E_HIP and "no CPU fallback" in str(ei.value)
+
+
+def test_product_never_imports_oracle():
+    """The product package must not import, link or execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "singlerust_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle" not in txt.lower().replace("no cpu oracle", ""), f"{f} mentions the oracle"

@@ -1,0 +1,140 @@
+"""CPU tests (-m "not gpu"): pin the oracle before trusting it.
+
+* against the hand-derived 4x5 KAT (tests/golden/kat_4x5.json);
+* against the committed golden vectors computed with independent numpy/scipy/sklearn maths
+  (tests/golden/make_golden.py);
+* against the reference's own property test, restated: after normalize_total every
+  (non-empty) row / column sums to target ± 1e-6 (src/memory/processing/mod.rs:419-481).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import COLUMN, ROW, Csr
+from oracle import pca_oracle
+from util import create_large_test_data
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ALL_DTYPES = [np.int8, np.int16, np.int32, np.uint8, np.uint16, np.uint32, np.float32, np.float64]
+
+
+def load(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    m = Csr(int(z["n_rows"]), int(z["n_cols"]), z["indptr"], z["indices"], z["values"])
+    return m, z
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+def test_kat_4x5(dtype):
+    k = json.load(open(os.path.join(GOLD, "kat_4x5.json")))
+    m = Csr(k["n_rows"], k["n_cols"], k["indptr"], k["indices"], np.array(k["data"], dtype=dtype))
+    assert oracle.compute_number(m, ROW).tolist() == k["number_row"]
+    assert oracle.compute_number(m, COLUMN).tolist() == k["number_col"]
+    assert oracle.compute_sum(m, ROW).tolist() == k["sum_row"]
+    assert oracle.compute_sum(m, COLUMN).tolist() == k["sum_col"]
+    assert oracle.compute_variance(m, COLUMN).tolist() == k["var_col"]
+    vr = oracle.compute_variance(m, ROW)
+    assert np.isnan(vr[2]) and vr[[0, 1, 3]].tolist() == [1.0, 0.0, 2.0]      # csr.rs:161: 0/0 for the empty row
+    n = oracle.normalize_total(m, 1e4, ROW)
+    assert n.values.dtype == np.float64                                      # scale/mod.rs:82: becomes F64
+    assert [float.hex(x) for x in n.values] == k["normalized_hex"]
+    lg = oracle.log1p_transform(n)
+    assert [float.hex(x) for x in lg.values] == k["log1p_hex"]
+    v = oracle.compute_variance(lg, COLUMN)
+    np.testing.assert_allclose(v, k["log_var_col"], rtol=0, atol=5e-9)
+    assert oracle.select_hvg(v, 2).tolist() == k["hvg2"]
+    assert oracle.select_hvg(v, 5).tolist() == k["hvg5"]                      # stable ties: ascending index
+    mn, mx = oracle.compute_min_max(m, COLUMN)
+    assert mn.tolist() == [1, 1, 4, 1, np.inf] and mx.tolist() == [2, 3, 4, 1, -np.inf]
+
+
+def test_log1p_dtype_semantics():
+    """transform/mod.rs:36-57: F32 stays F32 (f32::ln_1p), ints are promoted to F64."""
+    idx = dict(n_rows=1, n_cols=3, indptr=[0, 3], indices=[0, 1, 2])
+    f32 = oracle.log1p_transform(Csr(values=np.array([0.5, 2.0, 1e-8], np.float32), **idx))
+    assert f32.values.dtype == np.float32
+    np.testing.assert_allclose(f32.values, np.log1p(np.array([0.5, 2.0, 1e-8], np.float64)), rtol=2e-7)  # libm log1pf: <= 1 ulp
+    u8 = oracle.log1p_transform(Csr(values=np.array([1, 2, 255], np.uint8), **idx))
+    assert u8.values.dtype == np.float64
+    np.testing.assert_allclose(u8.values, np.log1p(np.array([1.0, 2.0, 255.0])), rtol=5e-16)   # libm vs numpy: <= 1 ulp
+
+
+@pytest.mark.parametrize("name", ["ref_shape_1000x100", "counts_64x40", "planted_600x240"])
+def test_against_golden(name):
+    m, z = load(name)
+    assert np.array_equal(oracle.compute_number(m, ROW), z["number_row"])
+    assert np.array_equal(oracle.compute_number(m, COLUMN), z["number_col"])
+    np.testing.assert_allclose(oracle.compute_sum(m, ROW), z["sum_row"], rtol=1e-13)
+    np.testing.assert_allclose(oracle.compute_sum(m, COLUMN), z["sum_col"], rtol=1e-13)
+    np.testing.assert_allclose(oracle.compute_variance(m, COLUMN), z["var_col"], rtol=1e-9, atol=1e-9)
+    n = oracle.normalize_total(m, 1e4, ROW)
+    np.testing.assert_allclose(n.values, z["norm_values"], rtol=1e-13)
+    lg = oracle.log1p_transform(n)
+    np.testing.assert_allclose(lg.values, z["log_values"], rtol=1e-13)
+    v = oracle.compute_variance(lg, COLUMN)
+    np.testing.assert_allclose(v, z["log_var_col"], rtol=1e-9, atol=1e-12)
+    if "hvg" in z:
+        assert np.array_equal(oracle.select_hvg(v, len(z["hvg"])), z["hvg"])
+
+
+def test_integer_sums_bit_exact():
+    m, z = load("counts_64x40")
+    for dt in (np.uint8, np.int16, np.uint32, np.float32):
+        mm = m.with_values(m.values.astype(dt))
+        assert np.array_equal(oracle.compute_sum(mm, ROW), z["sum_row"])
+        assert np.array_equal(oracle.compute_sum(mm, COLUMN), z["sum_col"])
+
+
+def test_reference_property_normalize_total():
+    """src/memory/processing/mod.rs:419-481 restated (1000 x 100, sparsity 10, target 1e4)."""
+    m = create_large_test_data(1000, 100, 10.0, seed=123)
+    target = 1e4
+    n = oracle.normalize_total(m, target, ROW)
+    assert n.values.dtype == np.float64                      # `DynCsrMatrix::F64(csr)` arm, :135
+    rows = oracle.compute_sum(n, ROW)
+    nonempty = oracle.compute_number(m, ROW) > 0             # the reference test is flaky on empty rows
+    assert np.all(np.abs(rows[nonempty] - target) < 1e-6)    # check_row_sums :451-462
+    assert np.all(rows[~nonempty] == 0.0)                    # scale/mod.rs:10-11: sum == 0 -> scale 0
+    c = oracle.normalize_total(m, target, COLUMN)
+    cols = oracle.compute_sum(c, COLUMN)
+    assert np.all(np.abs(cols - target) < 1e-6)              # check_column_sums :464-481
+
+
+def test_hvg_stable_and_nan():
+    v = np.array([1.0, 3.0, 3.0, 0.5, 3.0, 0.0, 0.0])
+    assert oracle.select_hvg(v, 4).tolist() == [1, 2, 4, 0]
+    assert oracle.select_hvg(v, 100).tolist() == [1, 2, 4, 0, 3, 5, 6]       # take(n) clamps
+    with pytest.raises(ValueError):
+        oracle.select_hvg(np.array([1.0, np.nan]), 1)                        # unwrap() panic
+
+
+def test_densify_selected_order():
+    """shared/mod.rs:230-259: column c of the dense matrix is gene sel[c] (selection order)."""
+    m, _ = load("counts_64x40")
+    sel = np.array([12, 3, 30], dtype=np.uint64)
+    d = oracle.densify_selected(m, sel)
+    import scipy.sparse as sp
+    full = sp.csr_matrix((m.values, m.indices.astype(np.int64), m.indptr.astype(np.int64)),
+                         shape=(m.n_rows, m.n_cols)).toarray()
+    assert np.array_equal(d, full[:, [12, 3, 30]])
+
+
+def test_pca_oracle_vs_sklearn():
+    """The numpy restatement of pca/mod.rs:74-215 equals StandardScaler(ddof 0) + full-SVD PCA up
+    to the sign of each component; eigenvalue normalisation is s^2/(n-1) over ALL components."""
+    m, z = load("planted_600x240")
+    lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
+    sel = pca_oracle.select_features_hvg(lg, 120)
+    assert np.array_equal(sel, z["hvg"])
+    scores, comps, evr, mean, std = pca_oracle.pca_inplace(lg, 5, None, None, sel)
+    for c in range(5):
+        s = np.sign(np.dot(comps[:, c], z["pca_components"][:, c]))
+        np.testing.assert_allclose(s * comps[:, c], z["pca_components"][:, c], atol=1e-9)
+        np.testing.assert_allclose(s * scores[:, c], z["pca_scores"][:, c], atol=1e-8)
+    np.testing.assert_allclose(evr, z["pca_evr"], rtol=1e-10)
+    # defaults: n_components None -> 2 (dim_red/mod.rs:52)
+    s2, c2, *_ = pca_oracle.pca_inplace(lg, None, None, None, sel)
+    assert s2.shape == (600, 2) and c2.shape == (120, 2)

@@ -1,0 +1,245 @@
+"""GPU parity tests (-m gpu): statistics / normalise / log1p through the C ABI vs the CPU oracle.
+
+Bars (BASELINE.json north_star): integer nnz counts and integer row/column sums BIT-EXACT;
+normalised / log1p values within 1e-5 relative (observed ~1e-7 at f32 storage, ~1e-15 at f64).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import COLUMN, ROW
+from util import create_large_test_data, rel_err
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ALL_DTYPES = [np.int8, np.int16, np.int32, np.uint8, np.uint16, np.uint32, np.float32, np.float64]
+TOL = 1e-5        # north_star tolerance on normalised values
+TOL_F64 = 1e-12   # what f64 device storage actually delivers
+
+
+def adata_of(m, ctx, store=0):
+    import singlerust_amd as sr
+    return sr.IMAnnData.new_basic((m.n_rows, m.n_cols, m.indptr, m.indices, m.values), ctx=ctx, store=store)
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+def test_kat_4x5(ctx, dtype):
+    import singlerust_amd as sr
+    from singlerust_amd.memory import processing, statistics
+    D = sr.Direction
+    k = json.load(open(os.path.join(GOLD, "kat_4x5.json")))
+    m = oracle.Csr(4, 5, k["indptr"], k["indices"], np.array(k["data"], dtype=dtype))
+    a = adata_of(m, ctx)
+    assert statistics.compute_number(a, D.Row).tolist() == k["number_row"]
+    assert statistics.compute_number(a, D.Column).tolist() == k["number_col"]
+    assert statistics.compute_sum(a, D.Row).tolist() == k["sum_row"]
+    assert statistics.compute_sum(a, D.Column).tolist() == k["sum_col"]
+    assert statistics.compute_variance(a, D.Column).tolist() == k["var_col"]
+    vr = statistics.compute_variance(a, D.Row)
+    assert np.isnan(vr[2]) and vr[[0, 1, 3]].tolist() == [1.0, 0.0, 2.0]
+    mn, mx = statistics.compute_min_max(a, D.Column)
+    assert mn.tolist() == [1, 1, 4, 1, np.inf] and mx.tolist() == [2, 3, 4, 1, -np.inf]
+    processing.normalize_total_inplace(a, 1e4, D.Row)
+    assert a.x_dtype() == np.float64                                   # scale/mod.rs:82
+    want = np.array([float.fromhex(h) for h in k["normalized_hex"]])
+    assert rel_err(a.x_values(), want) < 1e-7
+    processing.log1p_transform_inplace(a)
+    want = np.array([float.fromhex(h) for h in k["log1p_hex"]])
+    assert rel_err(a.x_values(), want) < 2e-7
+    from singlerust_amd.memory.processing import dim_red
+    assert dim_red.select_features(a, sr.FeatureSelection.HighlyVariable(2)).tolist() == k["hvg2"]
+    assert dim_red.select_features(a, sr.FeatureSelection.HighlyVariable(5)).tolist() == k["hvg5"]
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+def test_statistics_match_oracle_all_dtypes(ctx, dtype):
+    import singlerust_amd as sr
+    from singlerust_amd.memory import statistics
+    D = sr.Direction
+    m = create_large_test_data(700, 300, 12.0, seed=5, dtype=dtype)
+    a = adata_of(m, ctx)
+    assert np.array_equal(statistics.compute_number(a, D.Row), oracle.compute_number(m, ROW))
+    assert np.array_equal(statistics.compute_number(a, D.Column), oracle.compute_number(m, COLUMN))
+    exact = np.issubdtype(np.dtype(dtype), np.integer)
+    for d, od in ((D.Row, ROW), (D.Column, COLUMN)):
+        got, want = statistics.compute_sum(a, d), oracle.compute_sum(m, od)
+        if exact:
+            assert np.array_equal(got, want)                           # integer sums: bit-exact
+        else:
+            assert rel_err(got, want) < 1e-6
+    gv, wv = statistics.compute_variance(a, D.Column), oracle.compute_variance(m, COLUMN)
+    np.testing.assert_allclose(gv, wv, rtol=1e-6, atol=1e-6 * np.max(np.abs(wv)))
+    gs, ws = statistics.compute_std_dev(a, D.Column), oracle.compute_std_dev(m, COLUMN)
+    np.testing.assert_allclose(gs, ws, rtol=1e-4, atol=1e-3 * np.max(np.abs(ws)))
+    gr, wr = statistics.compute_variance(a, D.Row), oracle.compute_variance(m, ROW)
+    ok = ~np.isnan(wr)
+    assert np.array_equal(np.isnan(gr), np.isnan(wr))                  # NaN exactly where the reference gives NaN
+    np.testing.assert_allclose(gr[ok], wr[ok], rtol=1e-6, atol=1e-6 * np.max(np.abs(wr[ok])))
+    for d, od in ((D.Row, ROW), (D.Column, COLUMN)):
+        (gmn, gmx), (wmn, wmx) = statistics.compute_min_max(a, d), oracle.compute_min_max(m, od)
+        assert np.array_equal(gmn, wmn) and np.array_equal(gmx, wmx)   # values are exact in storage
+
+
+@pytest.mark.parametrize("store,tol", [(1, TOL), (2, TOL_F64)])
+def test_reference_property_normalize_total(ctx, store, tol):
+    """src/memory/processing/mod.rs:419-481 run against the GPU path: 1000 x 100, sparsity 10,
+    target 1e4; row sums (Row) / column sums (Column) == target.  At f64 storage the reference's
+    own ±1e-6 absolute bar holds; f32 storage meets the north_star 1e-5 relative bar."""
+    import singlerust_amd as sr
+    from singlerust_amd.memory import processing
+    D = sr.Direction
+    m = create_large_test_data(1000, 100, 10.0, seed=123)
+    a = adata_of(m, ctx, store)
+    n = processing.normalize_total(a, 1e4, D.Row)                      # copying form, :314-322
+    assert n.x_dtype() == np.float64 and a.x_dtype() == np.float64
+    assert rel_err(a.x_values(), m.values) < 1e-6                      # the source is untouched
+    got = oracle.Csr(m.n_rows, m.n_cols, m.indptr, m.indices, n.x_values())
+    rows = oracle.compute_sum(got, ROW)
+    nonempty = oracle.compute_number(m, ROW) > 0
+    bar = 1e-6 if store == 2 else 1e4 * 1e-5
+    assert np.all(np.abs(rows[nonempty] - 1e4) < bar)
+    assert np.all(rows[~nonempty] == 0.0)
+    assert rel_err(n.x_values(), oracle.normalize_total(m, 1e4, ROW).values) < tol
+    c = processing.normalize_total(a, 1e4, D.Column)
+    gotc = oracle.Csr(m.n_rows, m.n_cols, m.indptr, m.indices, c.x_values())
+    assert np.all(np.abs(oracle.compute_sum(gotc, COLUMN) - 1e4) < bar)
+    assert rel_err(c.x_values(), oracle.normalize_total(m, 1e4, COLUMN).values) < tol
+
+
+@pytest.mark.parametrize("name", ["ref_shape_1000x100", "counts_64x40", "planted_600x240"])
+@pytest.mark.parametrize("store,tol", [(1, TOL), (2, TOL_F64)])
+def test_against_golden(ctx, name, store, tol):
+    import singlerust_amd as sr
+    from singlerust_amd.memory import processing, statistics
+    from singlerust_amd.memory.processing import dim_red
+    D = sr.Direction
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    m = oracle.Csr(int(z["n_rows"]), int(z["n_cols"]), z["indptr"], z["indices"], z["values"])
+    a = adata_of(m, ctx, store)
+    assert np.array_equal(statistics.compute_number(a, D.Row), z["number_row"])
+    assert np.array_equal(statistics.compute_number(a, D.Column), z["number_col"])
+    assert rel_err(statistics.compute_sum(a, D.Row), z["sum_row"]) < tol
+    assert rel_err(statistics.compute_sum(a, D.Column), z["sum_col"]) < tol
+    processing.normalize_total_inplace(a, 1e4, D.Row)
+    assert rel_err(a.x_values(), z["norm_values"]) < tol
+    processing.log1p_transform_inplace(a)
+    assert rel_err(a.x_values(), z["log_values"]) < tol
+    v = statistics.compute_variance(a, D.Column)
+    np.testing.assert_allclose(v, z["log_var_col"], rtol=50 * tol, atol=tol)
+    if store == 2:
+        assert np.array_equal(dim_red.select_features(a, sr.FeatureSelection.HighlyVariable(len(z["hvg"]))), z["hvg"])
+
+
+def test_fused_normalize_log1p_equals_two_calls(ctx):
+    import singlerust_amd as sr
+    from singlerust_amd.memory import processing
+    m = create_large_test_data(900, 2500, 4.0, seed=9, dtype=np.float32)     # rows > 1024 nnz exist? no: ~625
+    a, b = adata_of(m, ctx), adata_of(m, ctx)
+    sums = processing.normalize_log1p_inplace(a, 1e4)
+    processing.normalize_total_inplace(b, 1e4, sr.Direction.Row)
+    processing.log1p_transform_inplace(b)
+    assert np.array_equal(a.x_values(), b.x_values())
+    assert rel_err(sums, oracle.compute_sum(m, ROW)) < 1e-6
+    want = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW)).values
+    assert rel_err(a.x_values(), want) < TOL
+
+
+def test_long_rows_take_the_streaming_path(ctx):
+    """Rows longer than the 1024-value register cache (kRowCache*64) re-read from memory."""
+    import singlerust_amd as sr
+    from singlerust_amd.memory import processing, statistics
+    rng = np.random.default_rng(2)
+    lens = np.array([0, 1, 63, 64, 65, 1023, 1024, 1025, 4000, 7000, 2, 0])
+    G = 8000
+    indptr = np.zeros(len(lens) + 1, dtype=np.uint64)
+    indptr[1:] = np.cumsum(lens)
+    idx = np.concatenate([np.sort(rng.choice(G, l, replace=False)) for l in lens]).astype(np.uint64)
+    val = rng.integers(1, 50, int(indptr[-1])).astype(np.float32)
+    m = oracle.Csr(len(lens), G, indptr, idx, val)
+    a = adata_of(m, ctx)
+    assert np.array_equal(statistics.compute_sum(a, sr.Direction.Row), oracle.compute_sum(m, ROW))
+    assert np.array_equal(statistics.compute_sum(a, sr.Direction.Column), oracle.compute_sum(m, COLUMN))
+    processing.normalize_log1p_inplace(a, 1e4)
+    want = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW)).values
+    assert rel_err(a.x_values(), want) < TOL
+    cnt, s, sq = statistics.gene_moments(a)
+    wc, ws, wq = oracle.gene_moments(oracle.Csr(len(lens), G, indptr, idx, a.x_values()))
+    assert np.array_equal(cnt, wc)
+    np.testing.assert_allclose(s, ws, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(sq, wq, rtol=1e-12, atol=1e-12)
+
+
+def test_gene_tiling_many_genes(ctx):
+    """G = 32000 > 4 x 8000: the per-gene pass runs 4 LDS gene tiles; counts stay bit-exact."""
+    import singlerust_amd as sr
+    from singlerust_amd.memory import statistics
+    m = create_large_test_data(3000, 32000, 40.0, seed=4, dtype=np.uint16)
+    a = adata_of(m, ctx)
+    assert np.array_equal(statistics.compute_number(a, sr.Direction.Column), oracle.compute_number(m, COLUMN))
+    assert np.array_equal(statistics.compute_sum(a, sr.Direction.Column), oracle.compute_sum(m, COLUMN))
+    gv, wv = statistics.compute_variance(a, sr.Direction.Column), oracle.compute_variance(m, COLUMN)
+    np.testing.assert_allclose(gv, wv, rtol=1e-9, atol=1e-9)
+    (gmn, gmx), (wmn, wmx) = statistics.compute_min_max(a, sr.Direction.Column), oracle.compute_min_max(m, COLUMN)
+    assert np.array_equal(gmn, wmn) and np.array_equal(gmx, wmx)
+
+
+def test_error_behaviour(ctx):
+    """Unsupported dtype -> the macro's panic message; bad CSR -> SRX_E_FORMAT / SRX_E_BOUNDS;
+    NaN variance in HVG ranking -> SRX_E_NAN (partial_cmp().unwrap(), dim_red/mod.rs:138)."""
+    import singlerust_amd as sr
+    from singlerust_amd import _ffi
+    from singlerust_amd.memory.processing import dim_red
+    with pytest.raises(sr.SrxError) as e:
+        sr.IMAnnData.new_basic((2, 3, [0, 1, 2], [0, 1], np.array([1, 2], dtype=np.int64)), ctx=ctx)
+    assert e.value.code == _ffi.E_DTYPE and "not supported for this operation" in str(e.value)
+    with pytest.raises(sr.SrxError) as e:
+        sr.IMAnnData.new_basic((2, 3, [0, 1, 2], [0, 7], np.array([1.0, 2.0])), ctx=ctx)
+    assert e.value.code == _ffi.E_BOUNDS
+    with pytest.raises(sr.SrxError) as e:
+        sr.IMAnnData.new_basic((1, 3, [0, 2], [2, 1], np.array([1.0, 2.0])), ctx=ctx)
+    assert e.value.code == _ffi.E_FORMAT
+    a = sr.IMAnnData.new_basic((2, 2, [0, 1, 2], [0, 1], np.array([np.nan, 1.0])), ctx=ctx)
+    with pytest.raises(sr.SrxError) as e:
+        dim_red.select_features(a, sr.FeatureSelection.HighlyVariable(1))
+    assert e.value.code == _ffi.E_NAN
+
+
+def test_empty_matrix_and_empty_rows(ctx):
+    import singlerust_amd as sr
+    from singlerust_amd.memory import processing, statistics
+    a = sr.IMAnnData.new_basic((3, 4, [0, 0, 0, 0], np.zeros(0, np.uint64), np.zeros(0, np.float32)), ctx=ctx)
+    assert statistics.compute_sum(a, sr.Direction.Row).tolist() == [0, 0, 0]
+    assert statistics.compute_number(a, sr.Direction.Column).tolist() == [0, 0, 0, 0]
+    assert statistics.compute_variance(a, sr.Direction.Column).tolist() == [0, 0, 0, 0]
+    processing.normalize_log1p_inplace(a, 1e4)
+    assert a.x_values().size == 0
+
+
+def test_synth_device_equals_host_generator(ctx):
+    """The in-HBM generator and its host twin are bit-identical (so the oracle sees the same X)."""
+    import ctypes as C
+    from singlerust_amd import _ffi, DeviceCsr
+    lib = _ffi.lib()
+    p = _ffi.SynthParams()
+    lib.srx_synth_defaults(C.byref(p), 77, 5000, 6000, 0.04)
+    h = C.c_void_p()
+    _ffi.check(lib.srx_synth_generate(ctx.handle, C.byref(p), 1000, 4000, _ffi.F32, _ffi.STORE_F32, C.byref(h)), ctx.handle)
+    d = DeviceCsr(ctx, h)
+    ip = np.zeros(3001, dtype=np.uint64)
+    lib.srx_synth_indptr(C.byref(p), 1000, 4000, _ffi.ptr(ip))
+    idx = np.zeros(int(ip[-1]), np.uint64)
+    val = np.zeros(int(ip[-1]), np.float32)
+    lib.srx_synth_fill_host(C.byref(p), 1000, 4000, _ffi.ptr(ip), _ffi.ptr(idx), _ffi.ptr(val))
+    assert d.info().nnz == ip[-1] and d.info().row_offset == 1000
+    assert np.array_equal(d.values(), val)
+    import singlerust_amd as sr
+    from singlerust_amd.memory import statistics
+    a = sr.IMAnnData(d, ip, idx, range(3000), range(6000))
+    m = oracle.Csr(3000, 6000, ip, idx, val)
+    assert np.array_equal(statistics.compute_number(a, sr.Direction.Column), oracle.compute_number(m, COLUMN))
+    assert np.array_equal(statistics.compute_sum(a, sr.Direction.Column), oracle.compute_sum(m, COLUMN))
+    assert np.array_equal(statistics.compute_sum(a, sr.Direction.Row), oracle.compute_sum(m, ROW))
