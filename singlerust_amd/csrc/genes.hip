@@ -213,6 +213,18 @@ static void tile_geometry(const srx_mat* m, int& n_tiles, int& tile_genes) {
     tile_genes = (int)((G + n_tiles - 1) / n_tiles);
 }
 
+int32_t launch_tile_ptr(srx_ctx* ctx, const int64_t* indptr, const int32_t* idx, uint64_t n_rows, int n_tiles,
+                        int tile_genes, int64_t* tp) {
+    uint64_t total = (uint64_t)(n_tiles - 1) * n_rows;
+    uint64_t g = (total + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > 65535) g = 65535;
+    hipLaunchKernelGGL(k_tile_ptr, dim3((unsigned)g), dim3(256), 0, ctx->stream, indptr, idx, n_rows, n_tiles,
+                       tile_genes, tp);
+    SRX_HIP(ctx, hipGetLastError());
+    return SRX_OK;
+}
+
 int32_t ensure_tiles(srx_mat* m) {
     srx_ctx* ctx = m->ctx;
     if (m->n_tiles) return SRX_OK;
@@ -220,13 +232,7 @@ int32_t ensure_tiles(srx_mat* m) {
     tile_geometry(m, nt, tg);
     if (nt > 1) {
         SRX_HIP(ctx, hipMalloc((void**)&m->d_tile_ptr, (size_t)(nt - 1) * (m->n_rows ? m->n_rows : 1) * sizeof(int64_t)));
-        uint64_t total = (uint64_t)(nt - 1) * m->n_rows;
-        uint64_t g = (total + 255) / 256;
-        if (g < 1) g = 1;
-        if (g > 65535) g = 65535;
-        hipLaunchKernelGGL(k_tile_ptr, dim3((int)g), dim3(256), 0, ctx->stream, m->d_indptr, m->d_indices, m->n_rows,
-                           nt, tg, m->d_tile_ptr);
-        SRX_HIP(ctx, hipGetLastError());
+        SRX_TRY(launch_tile_ptr(ctx, m->d_indptr, m->d_indices, m->n_rows, nt, tg, m->d_tile_ptr));
     }
     m->n_tiles = nt;
     m->tile_genes = tg;

@@ -1,9 +1,907 @@
-// pca.hip — placeholder while the SpMM path is being written.
+// pca.hip — dim_red::pca_inplace (src/memory/processing/dim_red/mod.rs:24-94) on the GPU.
+//
+// The reference densifies X[:, sel] to an N x k f64 matrix (src/shared/mod.rs:230-259) and
+// runs a full SVD of the standardised copy (spec: src/shared/processing/pca/mod.rs:74-154).
+// Here the standardised matrix  Z = (X[:, sel] - c 1 mu^T) D   (c = center, D = diag(1/std)
+// when scale) is never formed.  The top eigenpairs of C = Z^T Z are found by block subspace
+// iteration with a Rayleigh–Ritz step, applying C through two sparse products per iteration:
+//
+//     forward     Y = Z W       = A (D W) - 1 (mu^T D W)          CSR x dense panel (SpMM)
+//     transposed  W' = Z^T Y    = D (A^T Y - c mu (1^T Y))        scatter form, LDS-privatised
+//
+// where A is the HVG-COMPACTED CSR (columns renumbered 0..k-1 in ascending gene order, so a
+// row stays sorted and a gene tile is one contiguous segment of every row).  Everything of
+// size k x l (l = 64 panel columns) is replicated per rank and kept in f64; across row shards
+// the only exchange per iteration is ONE all-reduce of the k x l block A^T Y (+ 1^T Y).
+//
+// Precision (measured in DESIGN.md): values and panel in f32, forward accumulate f32 (<= ~120
+// terms per row), transposed accumulate f64 — pure f32 stalls at ~2e-5 eigenvector error on
+// close eigenvalue pairs; f64 accumulation there reaches ~3e-6.
+//
+// Algorithmic bytes per launch:
+//   forward     nnz_w*(4+s_v) + (N+1)*8 + N*l*4 (write Y) + k*l*4 (panel)
+//   transposed  nnz_w*(4+s_v) + (N+1)*8 + N*l*4 (read Y)  + k*l*8 (result)
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
 #include "common.hpp"
-using namespace srx;
-extern "C" {
-int32_t srx_pca(srx_mat* m, const uint64_t*, uint64_t, const srx_pca_opts*, double*, double*, double*, double*, double*, srx_pca_info*) { return fail(m ? m->ctx : nullptr, SRX_E_ARG, "srx_pca: not built yet"); }
-int32_t srx_pca_loadings(const double*, const double*, const uint64_t*, uint64_t, uint64_t, uint64_t, double*) { return fail(nullptr, SRX_E_ARG, "not built yet"); }
-int32_t srx_pipeline(srx_mat* m, double, uint64_t, const srx_pca_opts*, srx_pipeline_result*) { return fail(m ? m->ctx : nullptr, SRX_E_ARG, "not built yet"); }
-int32_t srx_result_fetch(srx_mat* m, double*, double*, double*, double*, double*, uint64_t*) { return fail(m ? m->ctx : nullptr, SRX_E_ARG, "not built yet"); }
+#include "smallmat.hpp"
+
+namespace srx {
+
+constexpr int L = 64;               // panel width l
+constexpr int kTThreads = 1024;     // transposed kernel: one workgroup per CU
+constexpr int kTileF32 = 512;       // gene tile of the transposed kernel: 512*64*4 B = 128 KiB LDS
+constexpr int kTileF64 = 256;       //                                     256*64*8 B = 128 KiB LDS
+
+int32_t gene_variances(srx_mat* m, std::vector<double>& var);
+int32_t select_hvg_host(srx_ctx* ctx, const std::vector<double>& var, uint64_t n, std::vector<uint64_t>& out);
+int32_t launch_tile_ptr(srx_ctx* ctx, const int64_t* indptr, const int32_t* idx, uint64_t n_rows, int n_tiles,
+                        int tile_genes, int64_t* tp);
+
+// ---- HVG compaction --------------------------------------------------------------------------
+// remap[g] = position of gene g among the selected genes in ascending gene order, or -1.
+__global__ __launch_bounds__(256) void k_compact_count(const int64_t* __restrict__ indptr,
+                                                       const int32_t* __restrict__ idx,
+                                                       const int32_t* __restrict__ remap, uint64_t n_rows,
+                                                       int64_t* __restrict__ counts) {
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
+    const int lane = lane_id();
+    for (uint64_t r = wave; r < n_rows; r += n_waves) {
+        const int64_t lo = indptr[r], hi = indptr[r + 1];
+        int c = 0;
+        for (int64_t p = lo + lane; p < hi; p += kWave) c += remap[idx[p]] >= 0;
+        c = wave_sum(c);
+        if (lane == 0) counts[r] = c;
+    }
 }
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_compact_fill(const int64_t* __restrict__ indptr,
+                                                      const int32_t* __restrict__ idx, const T* __restrict__ vals,
+                                                      const int32_t* __restrict__ remap, uint64_t n_rows,
+                                                      const int64_t* __restrict__ out_ptr,
+                                                      int32_t* __restrict__ out_idx, T* __restrict__ out_vals) {
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
+    const int lane = lane_id();
+    for (uint64_t r = wave; r < n_rows; r += n_waves) {
+        const int64_t lo = indptr[r], hi = indptr[r + 1];
+        int64_t o = out_ptr[r];
+        for (int64_t base = lo; base < hi; base += kWave) {
+            int64_t p = base + lane;
+            int32_t c = p < hi ? remap[idx[p]] : -1;
+            unsigned long long mask = __ballot(c >= 0);
+            if (c >= 0) {
+                int pos = __popcll(mask & ((1ull << lane) - 1ull));
+                out_idx[o + pos] = c;
+                out_vals[o + pos] = vals[p];
+            }
+            o += __popcll(mask);
+        }
+    }
+}
+
+// ---- exclusive scan of int64 counts (3 phases, 4096 elements per block) ------------------------
+constexpr int kScanItems = 4;
+constexpr int kScanBlock = 1024;
+__global__ __launch_bounds__(kScanBlock) void k_scan_block_sums(const int64_t* __restrict__ in, uint64_t n,
+                                                                int64_t* __restrict__ block_sums) {
+    __shared__ int64_t s_w[kScanBlock / kWave];
+    uint64_t base = (uint64_t)blockIdx.x * kScanBlock * kScanItems;
+    int64_t s = 0;
+    for (int t = 0; t < kScanItems; ++t) {
+        uint64_t i = base + (uint64_t)threadIdx.x * kScanItems + t;
+        if (i < n) s += in[i];
+    }
+    s = wave_sum(s);
+    if (lane_id() == 0) s_w[threadIdx.x / kWave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t tot = 0;
+        for (int w = 0; w < kScanBlock / kWave; ++w) tot += s_w[w];
+        block_sums[blockIdx.x] = tot;
+    }
+}
+__global__ void k_scan_serial(int64_t* __restrict__ block_sums, uint64_t nb, int64_t* __restrict__ total) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int64_t acc = 0;
+        for (uint64_t b = 0; b < nb; ++b) {
+            int64_t v = block_sums[b];
+            block_sums[b] = acc;
+            acc += v;
+        }
+        *total = acc;
+    }
+}
+__global__ __launch_bounds__(kScanBlock) void k_scan_apply(const int64_t* __restrict__ in, uint64_t n,
+                                                           const int64_t* __restrict__ block_offs,
+                                                           const int64_t* __restrict__ total,
+                                                           int64_t* __restrict__ out /* n + 1 */) {
+    __shared__ int64_t s_w[kScanBlock / kWave];
+    uint64_t base = (uint64_t)blockIdx.x * kScanBlock * kScanItems;
+    int64_t v[kScanItems];
+    int64_t s = 0;
+    for (int t = 0; t < kScanItems; ++t) {
+        uint64_t i = base + (uint64_t)threadIdx.x * kScanItems + t;
+        v[t] = i < n ? in[i] : 0;
+        s += v[t];
+    }
+    // inclusive scan of the per-thread sums across the wave, then across waves
+    int64_t inc = s;
+    const int lane = lane_id();
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        int64_t o = __shfl_up(inc, off, kWave);
+        if (lane >= off) inc += o;
+    }
+    if (lane == kWave - 1) s_w[threadIdx.x / kWave] = inc;
+    __syncthreads();
+    int64_t wave_off = 0;
+    for (int w = 0; w < (int)(threadIdx.x / kWave); ++w) wave_off += s_w[w];
+    int64_t excl = block_offs[blockIdx.x] + wave_off + inc - s;
+    for (int t = 0; t < kScanItems; ++t) {
+        uint64_t i = base + (uint64_t)threadIdx.x * kScanItems + t;
+        if (i < n) out[i] = excl;
+        excl += v[t];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
+}
+
+// ---- forward SpMM: Y = A P - 1 cvec^T ----------------------------------------------------------
+// One 16-lane group per row; lane q of the group owns panel columns 4q..4q+3 (one 16-byte
+// read of the panel row per non-zero, bank-conflict free across the group).  The group loads
+// 16 (index, value) pairs with one coalesced read, then every lane walks them in rotated
+// order — lane q takes pair (q+s)%16 at step s — so no broadcast is needed: the order in
+// which a lane accumulates the row's non-zeros is irrelevant.
+template <typename PT> struct Vec4;
+template <> struct Vec4<float> {
+    float4 v;
+    __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+    __device__ __forceinline__ float& operator[](int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+};
+template <> struct Vec4<double> {
+    double2 a, b;
+    __device__ __forceinline__ void load(const double* p) {
+        a = *reinterpret_cast<const double2*>(p);
+        b = *reinterpret_cast<const double2*>(p + 2);
+    }
+    __device__ __forceinline__ void store(double* p) const {
+        *reinterpret_cast<double2*>(p) = a;
+        *reinterpret_cast<double2*>(p + 2) = b;
+    }
+    __device__ __forceinline__ double& operator[](int i) { return i == 0 ? a.x : i == 1 ? a.y : i == 2 ? b.x : b.y; }
+};
+
+template <typename VT, typename PT>
+__global__ __launch_bounds__(256) void k_spmm_fwd(const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx,
+                                                  const VT* __restrict__ vals, uint64_t n_rows,
+                                                  const PT* __restrict__ P, const PT* __restrict__ cvec,
+                                                  PT* __restrict__ Y) {
+    const uint64_t grp = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / 16;
+    const uint64_t n_grp = ((uint64_t)gridDim.x * blockDim.x) / 16;
+    const int q = threadIdx.x & 15;
+    PT c0 = cvec[4 * q], c1 = cvec[4 * q + 1], c2 = cvec[4 * q + 2], c3 = cvec[4 * q + 3];
+    for (uint64_t r = grp; r < n_rows; r += n_grp) {
+        const int64_t lo = indptr[r], hi = indptr[r + 1];
+        PT a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int64_t base = lo; base < hi; base += 16) {
+            int64_t p = base + q;
+            int32_t mj = p < hi ? idx[p] : -1;
+            PT mv = p < hi ? (PT)vals[p] : PT(0);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                int src = (q + s) & 15;
+                int32_t j = __shfl(mj, src, 16);
+                PT v = __shfl(mv, src, 16);
+                if (j >= 0) {
+                    Vec4<PT> pr;
+                    pr.load(P + (size_t)j * L + 4 * q);
+                    a0 += v * pr[0];
+                    a1 += v * pr[1];
+                    a2 += v * pr[2];
+                    a3 += v * pr[3];
+                }
+            }
+        }
+        Vec4<PT> o;
+        o[0] = a0 - c0;
+        o[1] = a1 - c1;
+        o[2] = a2 - c2;
+        o[3] = a3 - c3;
+        o.store(Y + (size_t)r * L + 4 * q);
+    }
+}
+
+// ---- transposed SpMM: T = A^T Y (k x l), s = 1^T Y ---------------------------------------------
+// Workgroup = (gene tile, row block); the tile's k_t x 64 accumulators live in LDS (128 KiB);
+// one wave per row: lane c holds y[r][c]; the row's tile segment is read 64 non-zeros at a
+// time (coalesced) and each non-zero is broadcast with v_readlane and scattered with one
+// 64-lane LDS atomic add (conflict-free: 64 consecutive words).  Partials per row block are
+// summed in fixed order by k_t_reduce.
+template <typename VT, typename YT, typename AT>
+__global__ __launch_bounds__(kTThreads) void k_spmm_t(const int64_t* __restrict__ indptr, const int64_t* __restrict__ tp,
+                                                      const int32_t* __restrict__ idx, const VT* __restrict__ vals,
+                                                      uint64_t n_rows, int k, int n_tiles, int tile_genes,
+                                                      uint64_t rows_per_block, const YT* __restrict__ Y,
+                                                      AT* __restrict__ part /* [rb][k][L] */,
+                                                      double* __restrict__ part_s /* [rb][L] */) {
+    extern __shared__ double lds_raw[];
+    AT* acc = reinterpret_cast<AT*>(lds_raw);
+    for (int e = threadIdx.x; e < tile_genes * L; e += kTThreads) acc[e] = AT(0);
+    __syncthreads();
+    const int tile = blockIdx.x % n_tiles;
+    const uint64_t rb = blockIdx.x / n_tiles;
+    const int jbase = tile * tile_genes;
+    const uint64_t r0 = rb * rows_per_block;
+    const uint64_t r1 = r0 + rows_per_block < n_rows ? r0 + rows_per_block : n_rows;
+    const int lane = lane_id();
+    const int wave = threadIdx.x / kWave;
+    constexpr int kWaves = kTThreads / kWave;
+    double ysum = 0.0;
+    for (uint64_t r = r0 + wave; r < r1; r += kWaves) {
+        int64_t lo = tile == 0 ? indptr[r] : tp[(uint64_t)(tile - 1) * n_rows + r];
+        int64_t hi = tile == n_tiles - 1 ? indptr[r + 1] : tp[(uint64_t)tile * n_rows + r];
+        const AT y = (AT)Y[(size_t)r * L + lane];
+        if (tile == 0) ysum += (double)y;
+        for (int64_t base = lo; base < hi; base += kWave) {
+            int64_t p = base + lane;
+            int32_t mj = p < hi ? idx[p] - jbase : 0;
+            AT mv = p < hi ? (AT)vals[p] : AT(0);
+            int cnt = (int)(hi - base < kWave ? hi - base : kWave);
+            for (int s = 0; s < cnt; ++s) {
+                int32_t j = __builtin_amdgcn_readlane(mj, s);
+                AT v;
+                if constexpr (sizeof(AT) == 4) {
+                    v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mv), s));
+                } else {
+                    long long b = __builtin_bit_cast(long long, mv);
+                    int blo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), s);
+                    int bhi = __builtin_amdgcn_readlane((int)(b >> 32), s);
+                    v = __builtin_bit_cast(double, ((long long)bhi << 32) | (unsigned int)blo);
+                }
+                __hip_atomic_fetch_add(&acc[j * L + lane], v * y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < tile_genes * L; e += kTThreads) {
+        int j = jbase + e / L;
+        if (j < k) part[(rb * (uint64_t)k + j) * L + (e % L)] = acc[e];
+    }
+    if (tile == 0) {
+        // per-wave column sums of Y -> LDS is busy, so reduce through a small static array
+        __shared__ double s_y[kWaves][L];
+        s_y[wave][lane] = ysum;
+        __syncthreads();
+        if (threadIdx.x < L) {
+            double t = 0.0;
+            for (int w = 0; w < kWaves; ++w) t += s_y[w][threadIdx.x];
+            part_s[rb * L + threadIdx.x] = t;
+        }
+    }
+}
+
+// T[k*L .. k*L+L) receives s.  Fixed summation order over the row blocks.
+template <typename AT>
+__global__ void k_t_reduce(const AT* __restrict__ part, const double* __restrict__ part_s, int k, uint64_t n_rb,
+                           double* __restrict__ T) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t kl = (uint64_t)k * L;
+    if (e < kl) {
+        double s = 0.0;
+        for (uint64_t b = 0; b < n_rb; ++b) s += (double)part[b * kl + e];
+        T[e] = s;
+    } else if (e < kl + L) {
+        double s = 0.0;
+        for (uint64_t b = 0; b < n_rb; ++b) s += part_s[b * L + (e - kl)];
+        T[e] = s;
+    }
+}
+
+// ---- k x l helper kernels (f64, replicated per rank) --------------------------------------------
+// P = PT(d .* W * sign), cvec = cen * mu^T P (exact f64 sum of the ROUNDED panel, so Y's column
+// sums vanish to rounding).
+template <typename PT>
+__global__ __launch_bounds__(1024) void k_make_panel(const double* __restrict__ W, const double* __restrict__ d,
+                                                     const double* __restrict__ mu, const double* __restrict__ sgn,
+                                                     int k, int cen, PT* __restrict__ P, PT* __restrict__ cvec) {
+    __shared__ double s_part[16][L];
+    const int c = threadIdx.x & (L - 1), part = threadIdx.x / L;   // 16 row slices x 64 columns
+    double acc = 0.0;
+    const double sg = sgn ? sgn[c] : 1.0;
+    for (int j = part; j < k; j += 16) {
+        PT p = (PT)(d[j] * W[(size_t)j * L + c] * sg);
+        P[(size_t)j * L + c] = p;
+        acc += mu[j] * (double)p;
+    }
+    s_part[part][c] = acc;
+    __syncthreads();
+    if (part == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += s_part[w][c];
+        cvec[c] = cen ? (PT)t : PT(0);
+    }
+}
+
+// W' = d .* (T - cen * mu s^T)
+__global__ void k_finish_t(const double* __restrict__ T, const double* __restrict__ d, const double* __restrict__ mu,
+                           int k, int cen, double* __restrict__ Wp) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (uint64_t)k * L) return;
+    int j = (int)(e / L), c = (int)(e % L);
+    double s = T[(size_t)k * L + c];
+    Wp[e] = d[j] * (T[e] - (cen ? mu[j] * s : 0.0));
+}
+
+// H = A^T B, G = B^T B for two k x 64 blocks; single workgroup, rows staged through LDS.
+__global__ __launch_bounds__(1024) void k_gram2(const double* __restrict__ A, const double* __restrict__ B, int k,
+                                                double* __restrict__ H, double* __restrict__ G) {
+    constexpr int R = 32;
+    __shared__ double sa[R][L], sb[R][L];
+    double h[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0};
+    const int b = threadIdx.x & (L - 1), a0 = threadIdx.x / L;    // entries (a0 + 16u, b), u < 4
+    for (int j0 = 0; j0 < k; j0 += R) {
+        for (int e = threadIdx.x; e < R * L; e += 1024) {
+            int j = j0 + e / L;
+            sa[e / L][e % L] = j < k ? A[(size_t)j * L + (e % L)] : 0.0;
+            sb[e / L][e % L] = j < k ? B[(size_t)j * L + (e % L)] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int r = 0; r < R; ++r) {
+            double bv = sb[r][b];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                h[u] += sa[r][a0 + 16 * u] * bv;
+                g[u] += sb[r][a0 + 16 * u] * bv;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        H[(a0 + 16 * u) * L + b] = h[u];
+        G[(a0 + 16 * u) * L + b] = g[u];
+    }
+}
+
+// Out = In * M  (k x 64 times 64 x 64), M row-major.
+__global__ __launch_bounds__(256) void k_right_mul(const double* __restrict__ In, const double* __restrict__ M, int k,
+                                                   double* __restrict__ Out) {
+    __shared__ double sm[L][L + 1];
+    for (int e = threadIdx.x; e < L * L; e += 256) sm[e / L][e % L] = M[e];
+    __syncthreads();
+    const int c = threadIdx.x & (L - 1), sub = threadIdx.x / L;    // 4 rows per pass
+    for (int j = blockIdx.x * 4 + sub; j < k; j += gridDim.x * 4) {
+        const double* row = In + (size_t)j * L;
+        double acc = 0.0;
+#pragma unroll 8
+        for (int b = 0; b < L; ++b) acc += row[b] * sm[b][c];
+        Out[(size_t)j * L + c] = acc;
+    }
+}
+
+// rho[c] = || A1[:,c] - theta[c] * A2[:,c] ||_2 ; also colmax: entry of largest |.| of A2[:,c].
+__global__ __launch_bounds__(1024) void k_col_resid(const double* __restrict__ A1, const double* __restrict__ A2,
+                                                    const double* __restrict__ theta, int k,
+                                                    double* __restrict__ rho, double* __restrict__ colmax) {
+    __shared__ double s_r[16][L], s_m[16][L];
+    const int c = threadIdx.x & (L - 1), part = threadIdx.x / L;
+    double acc = 0.0, best = 0.0;
+    const double th = theta[c];
+    for (int j = part; j < k; j += 16) {
+        double v2 = A2[(size_t)j * L + c];
+        double r = A1[(size_t)j * L + c] - th * v2;
+        acc += r * r;
+        if (fabs(v2) > fabs(best)) best = v2;
+    }
+    s_r[part][c] = acc;
+    s_m[part][c] = best;
+    __syncthreads();
+    if (part == 0) {
+        double t = 0.0, bm = 0.0;
+        for (int w = 0; w < 16; ++w) {
+            t += s_r[w][c];
+            if (fabs(s_m[w][c]) > fabs(bm)) bm = s_m[w][c];    // ties keep the lowest row slice
+        }
+        rho[c] = sqrt(t);
+        colmax[c] = bm;
+    }
+}
+
+// scores[i][c] = Y[i][c] for c < n_pc (row-major f64, the obsm["X_pca"] layout).
+template <typename YT>
+__global__ void k_scores(const YT* __restrict__ Y, uint64_t n_rows, int n_pc, double* __restrict__ out) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t total = n_rows * (uint64_t)n_pc;
+    for (; e < total; e += stride) {
+        uint64_t i = e / n_pc;
+        int c = (int)(e % n_pc);
+        out[e] = (double)Y[i * L + c];
+    }
+}
+
+// ---- compacted matrix ---------------------------------------------------------------------------
+struct Compact {
+    uint64_t n_rows = 0, nnz = 0;
+    int k = 0;
+    int64_t* indptr = nullptr;
+    int32_t* idx = nullptr;
+    void* vals = nullptr;
+    int64_t* tp32 = nullptr;   // tile pointers for the f32-accumulate tiling
+    int64_t* tp64 = nullptr;   // ... and the f64-accumulate tiling
+    int nt32 = 0, nt64 = 0;
+};
+
+static int grid_rows(const srx_ctx* ctx, uint64_t n_rows, int rows_per_block) {
+    uint64_t want = (n_rows + rows_per_block - 1) / rows_per_block;
+    uint64_t cap = (uint64_t)ctx->n_cus * 8;
+    if (want < 1) want = 1;
+    return (int)(want < cap ? want : cap);
+}
+
+static int32_t build_tile_ptr(srx_ctx* ctx, const Compact& c, int tile_genes, const char* name, int64_t** tp, int* nt) {
+    *nt = (c.k + tile_genes - 1) / tile_genes;
+    *tp = nullptr;
+    if (*nt <= 1) return SRX_OK;
+    SRX_TRY(scratch(ctx, name, (size_t)(*nt - 1) * (c.n_rows ? c.n_rows : 1) * sizeof(int64_t), (void**)tp));
+    return launch_tile_ptr(ctx, c.indptr, c.idx, c.n_rows, *nt, tile_genes, *tp);
+}
+
+static int32_t build_compact(srx_mat* m, const std::vector<int32_t>& remap, int k, Compact& c) {
+    srx_ctx* ctx = m->ctx;
+    const uint64_t N = m->n_rows;
+    int32_t* d_remap;
+    int64_t *d_counts, *d_bsum, *d_total;
+    SRX_TRY(scratch(ctx, "pca_remap", (remap.size() ? remap.size() : 1) * sizeof(int32_t), (void**)&d_remap));
+    SRX_TRY(h2d(ctx, d_remap, remap.data(), remap.size() * sizeof(int32_t)));
+    SRX_TRY(scratch(ctx, "pca_counts", (N ? N : 1) * sizeof(int64_t), (void**)&d_counts));
+    const uint64_t per_block = (uint64_t)kScanBlock * kScanItems;
+    const uint64_t nb = (N + per_block - 1) / per_block > 0 ? (N + per_block - 1) / per_block : 1;
+    SRX_TRY(scratch(ctx, "pca_bsum", (nb + 1) * sizeof(int64_t), (void**)&d_bsum));
+    d_total = d_bsum + nb;
+    SRX_TRY(scratch(ctx, "pca_cindptr", (N + 1) * sizeof(int64_t), (void**)&c.indptr));
+    const double in_bytes = (double)m->nnz * 4.0 * 2.0 + (double)(N + 1) * 8.0 * 2.0;   // idx read by count + fill
+    {
+        ProfScope ps(ctx, SRX_K_COMPACT, in_bytes);   // selected values/indices written are added below
+        hipLaunchKernelGGL(k_compact_count, dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream, m->d_indptr,
+                           m->d_indices, d_remap, N, d_counts);
+        hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, d_counts, N, d_bsum);
+        hipLaunchKernelGGL(k_scan_serial, dim3(1), dim3(64), 0, ctx->stream, d_bsum, nb, d_total);
+        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, d_counts, N, d_bsum,
+                           d_total, c.indptr);
+        SRX_HIP(ctx, hipGetLastError());
+        int64_t total = 0;
+        SRX_TRY(d2h(ctx, &total, d_total, sizeof(int64_t)));
+        c.nnz = (uint64_t)total;
+        c.n_rows = N;
+        c.k = k;
+        SRX_TRY(scratch(ctx, "pca_cidx", (c.nnz ? c.nnz : 1) * sizeof(int32_t), (void**)&c.idx));
+        SRX_TRY(scratch(ctx, "pca_cvals", (c.nnz ? c.nnz : 1) * val_bytes(m), &c.vals));
+        if (is_f32(m))
+            hipLaunchKernelGGL((k_compact_fill<float>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream,
+                               m->d_indptr, m->d_indices, (const float*)m->d_values, d_remap, N, c.indptr, c.idx,
+                               (float*)c.vals);
+        else
+            hipLaunchKernelGGL((k_compact_fill<double>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream,
+                               m->d_indptr, m->d_indices, (const double*)m->d_values, d_remap, N, c.indptr, c.idx,
+                               (double*)c.vals);
+        SRX_HIP(ctx, hipGetLastError());
+        ctx->prof[SRX_K_COMPACT].bytes += (ctx->prof_mask & (1u << SRX_K_COMPACT))
+                                              ? (double)c.nnz * (4.0 + val_bytes(m)) * 2.0 : 0.0;
+    }
+    SRX_TRY(build_tile_ptr(ctx, c, kTileF32, "pca_tp32", &c.tp32, &c.nt32));
+    SRX_TRY(build_tile_ptr(ctx, c, kTileF64, "pca_tp64", &c.tp64, &c.nt64));
+    return SRX_OK;
+}
+
+// ---- launches ---------------------------------------------------------------------------------
+template <typename VT, typename PT>
+static int32_t launch_fwd(srx_ctx* ctx, const Compact& c, const PT* P, const PT* cvec, PT* Y) {
+    const double bytes = (double)c.nnz * (4.0 + sizeof(VT)) + (double)(c.n_rows + 1) * 8.0 +
+                         (double)c.n_rows * L * sizeof(PT) + (double)c.k * L * sizeof(PT);
+    ProfScope ps(ctx, SRX_K_SPMM_FWD, bytes);
+    hipLaunchKernelGGL((k_spmm_fwd<VT, PT>), dim3(grid_rows(ctx, c.n_rows, 16)), dim3(256), 0, ctx->stream, c.indptr,
+                       c.idx, (const VT*)c.vals, c.n_rows, P, cvec, Y);
+    SRX_HIP(ctx, hipGetLastError());
+    return SRX_OK;
+}
+
+template <typename VT, typename YT, typename AT>
+static int32_t launch_t(srx_ctx* ctx, const Compact& c, const YT* Y, double* T /* k*L + L */) {
+    const bool a32 = sizeof(AT) == 4;
+    const int tile = a32 ? kTileF32 : kTileF64;
+    const int nt = a32 ? c.nt32 : c.nt64;
+    const int64_t* tp = a32 ? c.tp32 : c.tp64;
+    uint64_t want = (uint64_t)(2 * ctx->n_cus) / (uint64_t)nt;
+    if (want < 1) want = 1;
+    uint64_t by_rows = (c.n_rows + 63) / 64;
+    if (by_rows < 1) by_rows = 1;
+    const uint64_t n_rb = want < by_rows ? want : by_rows;
+    const uint64_t rpb = (c.n_rows + n_rb - 1) / n_rb > 0 ? (c.n_rows + n_rb - 1) / n_rb : 1;
+    AT* part;
+    double* part_s;
+    SRX_TRY(scratch(ctx, a32 ? "pca_tpart32" : "pca_tpart64", n_rb * (size_t)c.k * L * sizeof(AT), (void**)&part));
+    SRX_TRY(scratch(ctx, "pca_tpart_s", n_rb * L * sizeof(double), (void**)&part_s));
+    const size_t lds = (size_t)tile * L * sizeof(AT);
+    const double bytes = (double)c.nnz * (4.0 + sizeof(VT)) + (double)(c.n_rows + 1) * 8.0 +
+                         (double)c.n_rows * L * sizeof(YT) + (double)c.k * L * 8.0;
+    {
+        ProfScope ps(ctx, SRX_K_SPMM_T, bytes);
+        SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_spmm_t<VT, YT, AT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds));
+        hipLaunchKernelGGL((k_spmm_t<VT, YT, AT>), dim3((unsigned)(n_rb * nt)), dim3(kTThreads), lds, ctx->stream,
+                           c.indptr, tp, c.idx, (const VT*)c.vals, c.n_rows, c.k, nt, tile, rpb, Y, part, part_s);
+        uint64_t tot = (uint64_t)c.k * L + L;
+        hipLaunchKernelGGL((k_t_reduce<AT>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, part, part_s,
+                           c.k, n_rb, T);
+    }
+    SRX_HIP(ctx, hipGetLastError());
+    return SRX_OK;
+}
+
+// ---- the driver ---------------------------------------------------------------------------------
+struct Resolved {
+    int n_pc, center, scale, max_iter;
+    double tol;
+    uint64_t seed;
+};
+
+static uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+template <typename VT, typename PT>
+static int32_t run_subspace(srx_mat* m, const Compact& c, const Resolved& o, const std::vector<double>& mu,
+                            const std::vector<double>& dinv, int l_act, srx_pca_state& st) {
+    srx_ctx* ctx = m->ctx;
+    const int k = c.k;
+    const size_t kl = (size_t)k * L;
+    double *W, *Wp, *T, *A1, *A2, *small, *d_mu, *d_d;
+    PT *P, *cvec, *Y;
+    SRX_TRY(scratch(ctx, "pca_W", kl * 8, (void**)&W));
+    SRX_TRY(scratch(ctx, "pca_Wp", kl * 8, (void**)&Wp));
+    SRX_TRY(scratch(ctx, "pca_T", (kl + L) * 8, (void**)&T));
+    SRX_TRY(scratch(ctx, "pca_A1", kl * 8, (void**)&A1));
+    SRX_TRY(scratch(ctx, "pca_A2", kl * 8, (void**)&A2));
+    SRX_TRY(scratch(ctx, "pca_small", (6 * L * L + 8 * L) * 8, (void**)&small));
+    SRX_TRY(scratch(ctx, "pca_mu", (size_t)k * 8, (void**)&d_mu));
+    SRX_TRY(scratch(ctx, "pca_d", (size_t)k * 8, (void**)&d_d));
+    SRX_TRY(scratch(ctx, "pca_P", (kl + L) * sizeof(PT), (void**)&P));
+    cvec = P + kl;
+    SRX_TRY(scratch(ctx, "pca_Y", (c.n_rows ? c.n_rows : 1) * (size_t)L * sizeof(PT), (void**)&Y));
+    double* dH = small;                 // L x L
+    double* dG = small + L * L;         // L x L
+    double* dM = small + 2 * L * L;     // L x L   (Rinv or U)
+    double* dM2 = small + 3 * L * L;    // L x L
+    double* dTheta = small + 4 * L * L; // L
+    double* dRho = dTheta + L;          // L
+    double* dColmax = dRho + L;         // L
+    double* dSgn = dColmax + L;         // L
+    SRX_TRY(h2d(ctx, d_mu, mu.data(), (size_t)k * 8));
+    SRX_TRY(h2d(ctx, d_d, dinv.data(), (size_t)k * 8));
+
+    // start block: counter-based N(0,1) entries (deterministic in (seed, gene slot, column))
+    std::vector<double> hW(kl, 0.0);
+    for (int j = 0; j < k; ++j)
+        for (int cc = 0; cc < l_act; ++cc) {
+            uint64_t h1 = mix64(mix64(o.seed ^ mix64((uint64_t)j)) + 2 * (uint64_t)cc);
+            uint64_t h2 = mix64(mix64(o.seed ^ mix64((uint64_t)j)) + 2 * (uint64_t)cc + 1);
+            double u1 = ((double)(h1 >> 11) + 0.5) / 9007199254740992.0;
+            double u2 = ((double)(h2 >> 11) + 0.5) / 9007199254740992.0;
+            hW[(size_t)j * L + cc] = std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+        }
+    SRX_TRY(h2d(ctx, Wp, hW.data(), kl * 8));
+
+    std::vector<double> hH(L * L), hG(L * L), hHG(2 * L * L), hM(L * L), hU(L * L), hTheta(L), hRho(L), hColmax(L);
+    std::vector<double> act(l_act * l_act), ev(l_act), evec((size_t)l_act * l_act);
+
+    // orthonormalise Wp -> W  (CholeskyQR: G = Wp^T Wp = R^T R, W = Wp R^-1)
+    auto orth = [&](bool have_gram) -> int32_t {
+        if (!have_gram) {
+            hipLaunchKernelGGL(k_gram2, dim3(1), dim3(1024), 0, ctx->stream, Wp, Wp, k, dH, dG);
+            SRX_HIP(ctx, hipGetLastError());
+            SRX_TRY(d2h(ctx, hG.data(), dG, L * L * 8));
+        }
+        if (!smallmat::chol_upper_inverse(l_act, L, hG.data(), hM.data()))
+            return fail(ctx, SRX_E_NOCONV, "pca: block lost rank (Cholesky pivot <= 0); k_eff < block?");
+        SRX_TRY(h2d(ctx, dM, hM.data(), L * L * 8));
+        hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, Wp, dM, k, W);
+        SRX_HIP(ctx, hipGetLastError());
+        return SRX_OK;
+    };
+    SRX_TRY(orth(false));
+    // CholeskyQR2 on the random start (condition of a Gaussian block is mild, once more is cheap)
+    SRX_HIP(ctx, hipMemcpyAsync(Wp, W, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    SRX_TRY(orth(false));
+
+    const int n_pc = o.n_pc;
+    bool accurate = sizeof(PT) == 8;    // f64 path accumulates in f64 from the start
+    double resid = INFINITY;
+    int it = 0;
+    bool converged = false;
+    for (it = 1; it <= o.max_iter; ++it) {
+        // forward: Y = Z W
+        hipLaunchKernelGGL((k_make_panel<PT>), dim3(1), dim3(1024), 0, ctx->stream, W, d_d, d_mu, (const double*)nullptr,
+                           k, o.center, P, cvec);
+        SRX_HIP(ctx, hipGetLastError());
+        SRX_TRY((launch_fwd<VT, PT>(ctx, c, P, cvec, Y)));
+        // transposed: T = A^T Y, s = 1^T Y; f32 accumulators while far from converged
+        if (accurate) SRX_TRY((launch_t<VT, PT, double>(ctx, c, Y, T)));
+        else SRX_TRY((launch_t<VT, PT, float>(ctx, c, Y, T)));
+        SRX_TRY(allreduce_f64(ctx, T, kl + L));       // the one exchange per iteration
+        hipLaunchKernelGGL(k_finish_t, dim3((unsigned)((kl + 255) / 256)), dim3(256), 0, ctx->stream, T, d_d, d_mu, k,
+                           o.center, Wp);
+        // Rayleigh–Ritz on span(W): H = W^T C W, and G = (CW)^T (CW) for the next CholeskyQR
+        hipLaunchKernelGGL(k_gram2, dim3(1), dim3(1024), 0, ctx->stream, W, Wp, k, dH, dG);
+        SRX_HIP(ctx, hipGetLastError());
+        SRX_TRY(d2h(ctx, hHG.data(), dH, 2 * L * L * 8));   // dH and dG are contiguous
+        std::copy(hHG.begin(), hHG.begin() + L * L, hH.begin());
+        std::copy(hHG.begin() + L * L, hHG.end(), hG.begin());
+        for (int a = 0; a < l_act; ++a)
+            for (int b = 0; b < l_act; ++b) act[(size_t)a * l_act + b] = hH[a * L + b];
+        if (!smallmat::sym_eig_desc(l_act, act.data(), ev.data(), evec.data()))
+            return fail(ctx, SRX_E_NOCONV, "pca: l x l eigen-solver did not converge");
+        std::fill(hU.begin(), hU.end(), 0.0);
+        std::fill(hTheta.begin(), hTheta.end(), 0.0);
+        for (int a = 0; a < l_act; ++a) {
+            hTheta[a] = ev[a];
+            for (int b = 0; b < l_act; ++b) hU[a * L + b] = evec[(size_t)a * l_act + b];
+        }
+        // residuals || C v_i - theta_i v_i || with v_i = W u_i, evaluated on the device in f64
+        SRX_TRY(h2d(ctx, dM2, hU.data(), L * L * 8));
+        SRX_TRY(h2d(ctx, dTheta, hTheta.data(), L * 8));
+        hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, Wp, dM2, k, A1);
+        hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, W, dM2, k, A2);
+        hipLaunchKernelGGL(k_col_resid, dim3(1), dim3(1024), 0, ctx->stream, A1, A2, dTheta, k, dRho, dColmax);
+        SRX_HIP(ctx, hipGetLastError());
+        SRX_TRY(d2h(ctx, hRho.data(), dRho, L * 8));
+        resid = 0.0;
+        for (int i = 0; i < n_pc; ++i) {
+            double r = hTheta[i] > 0 ? hRho[i] / hTheta[i] : hRho[i];
+            if (!(r <= resid)) resid = r;   // NaN propagates
+        }
+        if (resid != resid) return fail(ctx, SRX_E_NOCONV, "pca: NaN in the Ritz residual");
+        if (resid <= o.tol && accurate) { converged = true; break; }
+        if (!accurate && resid <= 1e-3) accurate = true;   // last digits need f64 accumulation
+        SRX_TRY(orth(true));
+    }
+    if (!converged) it = o.max_iter;
+
+    // A2 = W U are the Ritz vectors (sorted-gene row order); sign: largest-|.| entry positive
+    SRX_TRY(d2h(ctx, hColmax.data(), dColmax, L * 8));
+    std::vector<double> sgn(L, 1.0);
+    for (int i = 0; i < L; ++i) sgn[i] = hColmax[i] < 0 ? -1.0 : 1.0;
+    SRX_TRY(h2d(ctx, dSgn, sgn.data(), L * 8));
+    std::vector<double> hV(kl);
+    SRX_TRY(d2h(ctx, hV.data(), A2, kl * 8));
+    st.components.assign((size_t)k * n_pc, 0.0);
+    for (int j = 0; j < k; ++j)
+        for (int i = 0; i < n_pc; ++i) st.components[(size_t)j * n_pc + i] = hV[(size_t)j * L + i] * sgn[i];
+    st.evr.assign(hTheta.begin(), hTheta.begin() + n_pc);   // eigenvalues of Z^T Z, normalised by the caller
+
+    // scores = Z V  (transform, pca/mod.rs:156-185): one more forward SpMM with the panel D V
+    hipLaunchKernelGGL((k_make_panel<PT>), dim3(1), dim3(1024), 0, ctx->stream, A2, d_d, d_mu, (const double*)dSgn, k,
+                       o.center, P, cvec);
+    SRX_HIP(ctx, hipGetLastError());
+    SRX_TRY((launch_fwd<VT, PT>(ctx, c, P, cvec, Y)));
+    const size_t need = (c.n_rows ? c.n_rows : 1) * (size_t)n_pc * 8;
+    if (st.scores_cap < need) {
+        if (st.d_scores) SRX_HIP(ctx, hipFree(st.d_scores));
+        st.d_scores = nullptr;
+        st.scores_cap = 0;
+        SRX_HIP(ctx, hipMalloc((void**)&st.d_scores, need));
+        st.scores_cap = need;
+    }
+    uint64_t tot = c.n_rows * (uint64_t)n_pc;
+    uint64_t g = (tot + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL((k_scores<PT>), dim3((unsigned)g), dim3(256), 0, ctx->stream, Y, c.n_rows, n_pc, st.d_scores);
+    SRX_HIP(ctx, hipGetLastError());
+    st.info.n_iter = (uint32_t)it;
+    st.info.residual = resid;
+    if (!converged)
+        return fail(ctx, SRX_E_NOCONV, "pca: subspace iteration stopped at max_iter=%d with residual %.3e > tol %.3e",
+                    o.max_iter, resid, o.tol);
+    return SRX_OK;
+}
+
+// Everything up to and including the scores, left in m->pca (device scores + small host vectors).
+static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const srx_pca_opts* opts) {
+    srx_ctx* ctx = m->ctx;
+    SRX_HIP(ctx, hipSetDevice(ctx->device));
+    srx_pca_state& st = m->pca;
+    st.valid = false;
+    const uint64_t G = m->n_cols;
+    std::vector<uint64_t> selv;
+    if (sel) selv.assign(sel, sel + k64);
+    else { selv.resize(G); std::iota(selv.begin(), selv.end(), 0ull); }      // FeatureSelection::None, :154
+    const int k = (int)selv.size();
+    SRX_TRY(ensure_moments(m));                                                // also fixes n_rows_global
+    const uint64_t Ng = m->n_rows_global;
+    // dim_red/mod.rs:38-41: column(0)/column(1) and slice(..5) panic when k < 2 or N < 5
+    if (k < 2 || Ng < 5) return fail(ctx, SRX_E_SHAPE, "pca_inplace needs >= 2 selected features and >= 5 cells (k=%d, N=%llu)",
+                                     k, (unsigned long long)Ng);
+    Resolved o;
+    int want = (!opts || opts->n_components < 0) ? 2 : opts->n_components;      // :52
+    o.n_pc = std::min(want, k);
+    o.center = (!opts || opts->center < 0) ? 1 : (opts->center != 0);           // :55
+    o.scale = (!opts || opts->scale < 0) ? 1 : (opts->scale != 0);              // :56
+    o.max_iter = (opts && opts->max_iter > 0) ? opts->max_iter : 100;
+    o.tol = (opts && opts->tol > 0) ? opts->tol : 1e-7;
+    o.seed = opts ? opts->seed : 0;
+    if (o.n_pc < 1) return fail(ctx, SRX_E_ARG, "pca: n_components must be >= 1");
+    if (opts && opts->block != 0 && opts->block != L) return fail(ctx, SRX_E_ARG, "pca: only block = %d is built", L);
+    const int l_act = std::min(L, k);
+    if (o.n_pc > l_act || (k > L && o.n_pc > L - 8))
+        return fail(ctx, SRX_E_ARG, "pca: n_components %d exceeds what the %d-column block resolves (max %d)", o.n_pc, L,
+                    k > L ? L - 8 : l_act);
+
+    // ascending-gene-order view of the selection; remap table; permutation back to selection order
+    std::vector<int> order(k);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return selv[a] < selv[b]; });
+    std::vector<int32_t> remap(G, -1);
+    std::vector<int> slot_of_sel(k);
+    for (int s = 0; s < k; ++s) {
+        uint64_t g = selv[order[s]];
+        if (g >= G) return fail(ctx, SRX_E_BOUNDS, "selected feature index %llu out of bounds (n_vars = %llu)",
+                                (unsigned long long)g, (unsigned long long)G);
+        if (remap[g] >= 0) return fail(ctx, SRX_E_ARG, "selected feature index %llu appears twice", (unsigned long long)g);
+        remap[g] = s;
+        slot_of_sel[order[s]] = s;
+    }
+    // all-cells column mean / std (ddof 0) of the selected genes from the one moments pass
+    // (pca/mod.rs:87-91): mean = sum/N, var = sumsq/N - mean^2
+    std::vector<double> hsum(G), hsq(G);
+    SRX_TRY(d2h(ctx, hsum.data(), m->d_sum, G * 8));
+    SRX_TRY(d2h(ctx, hsq.data(), m->d_sq, G * 8));
+    std::vector<double> mu(k), sd(k), dinv(k);
+    double trace = 0.0;
+    const double Nd = (double)Ng;
+    for (int s = 0; s < k; ++s) {
+        uint64_t g = selv[order[s]];
+        double mean = hsum[g] / Nd;
+        double var = hsq[g] / Nd - mean * mean;
+        if (var < 0) var = 0;
+        double std_ = std::sqrt(var);
+        mu[s] = (o.center || o.scale) ? mean : 0.0;            // :85-119: mean/std stored only if center||scale
+        sd[s] = o.scale ? std_ : 1.0;
+        // zero-variance column: the reference divides by 0 (NaN, :108); treated as std 1 here
+        dinv[s] = (o.scale && std_ > 0) ? 1.0 / std_ : 1.0;
+        double ss = o.center ? (hsq[g] - Nd * mean * mean) : hsq[g];
+        if (ss < 0) ss = 0;
+        trace += dinv[s] * dinv[s] * ss;
+    }
+    std::vector<double> mu_eff = mu;
+    if (!o.center) std::fill(mu_eff.begin(), mu_eff.end(), 0.0);
+
+    Compact c;
+    SRX_TRY(build_compact(m, remap, k, c));
+    st.info = srx_pca_info{};
+    st.info.n_cells_global = Ng;
+    st.info.k = (uint32_t)k;
+    st.info.n_pc = (uint32_t)o.n_pc;
+    st.info.block = L;
+    st.info.nnz_selected = c.nnz;
+    int32_t rc;
+    if (is_f32(m)) rc = run_subspace<float, float>(m, c, o, mu_eff, dinv, l_act, st);
+    else rc = run_subspace<double, double>(m, c, o, mu_eff, dinv, l_act, st);
+    if (rc != SRX_OK && rc != SRX_E_NOCONV) return rc;
+
+    // back to selection order; explained variance ratio = eig/total with eig = theta/(N-1),
+    // total = trace(Z^T Z)/(N-1) (pca/mod.rs:131-133)
+    std::vector<double> comp((size_t)k * o.n_pc);
+    for (int i = 0; i < k; ++i)
+        for (int p = 0; p < o.n_pc; ++p) comp[(size_t)i * o.n_pc + p] = st.components[(size_t)slot_of_sel[i] * o.n_pc + p];
+    st.components.swap(comp);
+    for (int p = 0; p < o.n_pc; ++p) st.evr[p] = trace > 0 ? st.evr[p] / trace : 0.0;
+    st.mean.resize(k);
+    st.std_.resize(k);
+    for (int i = 0; i < k; ++i) {
+        st.mean[i] = mu[slot_of_sel[i]];
+        st.std_[i] = sd[slot_of_sel[i]];
+    }
+    st.sel = selv;
+    st.k = (uint32_t)k;
+    st.n_pc = (uint32_t)o.n_pc;
+    st.valid = true;
+    return rc;
+}
+
+}  // namespace srx
+
+using namespace srx;
+
+extern "C" {
+
+int32_t srx_result_fetch(srx_mat* m, double* scores, double* components, double* evr, double* mean, double* std_,
+                         uint64_t* hvg_idx) {
+    if (!m) return fail(nullptr, SRX_E_ARG, "null matrix");
+    srx_ctx* ctx = m->ctx;
+    const srx_pca_state& st = m->pca;
+    if (!st.valid) return fail(ctx, SRX_E_ARG, "no PCA result on this matrix");
+    SRX_HIP(ctx, hipSetDevice(ctx->device));
+    if (scores) SRX_TRY(d2h(ctx, scores, st.d_scores, m->n_rows * (size_t)st.n_pc * 8));
+    if (components) memcpy(components, st.components.data(), st.components.size() * 8);
+    if (evr) memcpy(evr, st.evr.data(), st.evr.size() * 8);
+    if (mean) memcpy(mean, st.mean.data(), st.mean.size() * 8);
+    if (std_) memcpy(std_, st.std_.data(), st.std_.size() * 8);
+    if (hvg_idx) memcpy(hvg_idx, st.sel.data(), st.sel.size() * 8);
+    return SRX_OK;
+}
+
+int32_t srx_pca(srx_mat* m, const uint64_t* sel, uint64_t k, const srx_pca_opts* opts, double* scores,
+                double* components, double* evr, double* mean, double* std_, srx_pca_info* info) {
+    if (!m) return fail(nullptr, SRX_E_ARG, "null matrix");
+    int32_t rc = pca_device(m, sel, k, opts);
+    if (rc != SRX_OK && rc != SRX_E_NOCONV) return rc;
+    if (info) *info = m->pca.info;
+    int32_t rc2 = srx_result_fetch(m, scores, components, evr, mean, std_, nullptr);
+    return rc2 != SRX_OK ? rc2 : rc;
+}
+
+int32_t srx_pca_loadings(const double* components, const double* std_, const uint64_t* sel, uint64_t k,
+                         uint64_t n_pc, uint64_t n_vars, double* out) {
+    if (!components || !std_ || !sel || !out) return fail(nullptr, SRX_E_ARG, "null argument");
+    // dim_red/mod.rs:111-116: zeros(n_vars x n_pc); row sel[i] <- loadings row i;
+    // loadings = components^T * std (pca/mod.rs:204-215) i.e. component[i][p] * std[i]
+    for (uint64_t t = 0; t < n_vars * n_pc; ++t) out[t] = 0.0;
+    for (uint64_t i = 0; i < k; ++i) {
+        if (sel[i] >= n_vars) return fail(nullptr, SRX_E_BOUNDS, "feature index out of bounds");
+        for (uint64_t p = 0; p < n_pc; ++p) out[sel[i] * n_pc + p] = components[i * n_pc + p] * std_[i];
+    }
+    return SRX_OK;
+}
+
+int32_t srx_pipeline(srx_mat* m, double target_sum, uint64_t n_hvg, const srx_pca_opts* opts,
+                     srx_pipeline_result* res) {
+    if (!m) return fail(nullptr, SRX_E_ARG, "null matrix");
+    srx_ctx* ctx = m->ctx;
+    SRX_HIP(ctx, hipSetDevice(ctx->device));
+    hipEvent_t ev[5];
+    for (auto& e : ev) SRX_HIP(ctx, hipEventCreate(&e));
+    auto cleanup = [&]() { for (auto& e : ev) (void)hipEventDestroy(e); };
+    int32_t rc = SRX_OK;
+    (void)hipEventRecord(ev[0], ctx->stream);
+    // normalize_total_inplace(target, Row) + log1p_transform_inplace, fused
+    rc = launch_normalize(m, target_sum, true, true);
+    (void)hipEventRecord(ev[1], ctx->stream);
+    // per-gene moments of the transformed values (one pass, all-reduced across shards)
+    if (rc == SRX_OK) rc = ensure_moments(m);
+    (void)hipEventRecord(ev[2], ctx->stream);
+    // FeatureSelection::HighlyVariable(n_hvg)
+    std::vector<uint64_t> sel;
+    if (rc == SRX_OK) {
+        std::vector<double> var;
+        rc = gene_variances(m, var);
+        if (rc == SRX_OK) rc = select_hvg_host(ctx, var, n_hvg, sel);
+    }
+    (void)hipEventRecord(ev[3], ctx->stream);
+    if (rc == SRX_OK) rc = pca_device(m, sel.data(), sel.size(), opts);
+    (void)hipEventRecord(ev[4], ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (res) {
+        memset(res, 0, sizeof *res);
+        res->pca = m->pca.info;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) res->ms_normalize = ms;
+        if (hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) res->ms_moments = ms;
+        if (hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) res->ms_select = ms;
+        if (hipEventElapsedTime(&ms, ev[3], ev[4]) == hipSuccess) res->ms_pca = ms;
+        res->ms_compact = 0.0;
+    }
+    cleanup();
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,196 @@
+"""GPU parity tests (-m gpu) of pca_inplace / the fused pipeline vs the exact-SVD oracle
+(oracle/pca_oracle.py, restating src/shared/processing/pca/mod.rs:74-215).
+
+Bar (BASELINE.json north_star): top-PC loadings and scores within 1e-5 relative — measured
+here per component as ||got - ref||_2 / ||ref||_2 after sign alignment (the reference has no
+sign convention).  The f64-storage path is expected to be ~1e-9.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import COLUMN, ROW, pca_oracle
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-5
+
+
+def col_err(got, ref):
+    """max over components of ||got_c - s*ref_c|| / ||ref_c|| with the best sign s."""
+    worst = 0.0
+    for c in range(ref.shape[1]):
+        s = 1.0 if np.dot(got[:, c], ref[:, c]) >= 0 else -1.0
+        worst = max(worst, np.linalg.norm(got[:, c] - s * ref[:, c]) / np.linalg.norm(ref[:, c]))
+    return worst
+
+
+def adata_of(m, ctx, store=0):
+    import singlerust_amd as sr
+    return sr.IMAnnData.new_basic((m.n_rows, m.n_cols, m.indptr, m.indices, m.values), ctx=ctx, store=store)
+
+
+def synth_host(seed, n, g, density):
+    from singlerust_amd import _ffi
+    lib = _ffi.lib()
+    p = _ffi.SynthParams()
+    lib.srx_synth_defaults(C.byref(p), seed, n, g, density)
+    ip = np.zeros(n + 1, dtype=np.uint64)
+    lib.srx_synth_indptr(C.byref(p), 0, n, _ffi.ptr(ip))
+    idx = np.zeros(int(ip[-1]), np.uint64)
+    val = np.zeros(int(ip[-1]), np.float32)
+    lib.srx_synth_fill_host(C.byref(p), 0, n, _ffi.ptr(ip), _ffi.ptr(idx), _ffi.ptr(val))
+    return oracle.Csr(n, g, ip, idx, val), p
+
+
+@pytest.mark.parametrize("store,tol", [(1, TOL), (2, 1e-8)])
+def test_golden_planted(ctx, store, tol):
+    """Committed golden vectors (sklearn StandardScaler + PCA(full) on the HVG columns)."""
+    import singlerust_amd as sr
+    from singlerust_amd.memory import processing
+    from singlerust_amd.memory.processing import dim_red
+    z = np.load(os.path.join(GOLD, "planted_600x240.npz"))
+    m = oracle.Csr(int(z["n_rows"]), int(z["n_cols"]), z["indptr"], z["indices"], z["values"])
+    a = adata_of(m, ctx, store)
+    processing.normalize_total_inplace(a, 1e4, sr.Direction.Row)
+    processing.log1p_transform_inplace(a)
+    # use the golden HVG list so both storages walk the same columns
+    a.var["hv"] = np.isin(np.arange(m.n_cols), z["hvg"])
+    sel_sorted = np.sort(z["hvg"])
+    info = dim_red.pca_inplace(a, 5, None, None, 32, sr.FeatureSelection.HighlyVariableCol("hv"), None, tol=1e-9 if store == 2 else 0)
+    got = a.obsm["X_pca"]
+    assert got.shape == (600, 5) and got.dtype == np.float64
+    # golden columns are in variance-rank order; HighlyVariableCol gives ascending gene order
+    perm = np.array([np.where(z["hvg"] == g)[0][0] for g in sel_sorted])
+    assert col_err(got, z["pca_scores"]) < tol
+    assert col_err(a.uns["pca"]["components"], z["pca_components"][perm]) < tol
+    np.testing.assert_allclose(a.uns["pca"]["explained_variance_ratio"], z["pca_evr"], rtol=max(tol, 1e-9))
+    assert info.k == 120 and info.n_pc == 5 and info.n_iter >= 1
+
+
+@pytest.mark.parametrize("store,tol", [(1, TOL), (2, 1e-8)])
+def test_hvg_pipeline_vs_oracle(ctx, store, tol):
+    """normalize -> log1p -> pca_inplace(HighlyVariable(n)) on a synthetic planted matrix,
+    against the oracle's densify + exact SVD; loadings in the varm["PCA_loadings"] layout."""
+    import singlerust_amd as sr
+    from singlerust_amd.memory import processing
+    from singlerust_amd.memory.processing import dim_red
+    m, _ = synth_host(5, 4000, 3000, 0.05)
+    a = adata_of(m, ctx, store)
+    processing.normalize_total_inplace(a, 1e4, sr.Direction.Row)
+    processing.log1p_transform_inplace(a)
+    n_hvg, n_pc = 300, 10
+    info = dim_red.pca_inplace(a, n_pc, None, None, None, sr.FeatureSelection.HighlyVariable(n_hvg), None,
+                               store_loadings=True, tol=1e-9 if store == 2 else 0)
+    lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
+    # the oracle walks the columns the GPU selected (identical to its own at f64 storage)
+    sel = a.uns["pca"]["selected_features"]
+    want_sel = pca_oracle.select_features_hvg(lg, n_hvg)
+    if store == 2:
+        assert np.array_equal(sel, want_sel)
+    else:
+        assert len(set(sel.tolist()) ^ set(want_sel.tolist())) <= 2      # f32 rounding may swap a near-tie at the cut
+    scores, comps, evr, mean, std = pca_oracle.pca_inplace(lg, n_pc, None, None, sel)
+    assert col_err(a.obsm["X_pca"], scores) < tol
+    assert col_err(a.uns["pca"]["components"], comps) < tol
+    np.testing.assert_allclose(a.uns["pca"]["explained_variance_ratio"], evr, rtol=10 * tol)
+    np.testing.assert_allclose(a.uns["pca"]["mean"], mean, rtol=10 * tol, atol=1e-12)
+    np.testing.assert_allclose(a.uns["pca"]["std"], std, rtol=10 * tol)
+    # sign convention: largest-|.| loading of each component is positive
+    cg = a.uns["pca"]["components"]
+    assert np.all(cg[np.argmax(np.abs(cg), axis=0), np.arange(n_pc)] > 0)
+    # varm["PCA_loadings"] (dim_red/mod.rs:108-118): rows scattered to the original gene index
+    full = a.varm["PCA_loadings"]
+    assert full.shape == (3000, n_pc)
+    np.testing.assert_allclose(full[sel.astype(np.int64)], cg * a.uns["pca"]["std"][:, None], rtol=1e-12)
+    mask = np.ones(3000, bool); mask[sel.astype(np.int64)] = False
+    assert np.all(full[mask] == 0)
+    assert 1 <= info.n_iter <= 60 and info.residual <= (1e-7 if store == 1 else 1e-9)
+
+
+@pytest.mark.parametrize("center,scale", [(True, True), (True, False), (False, True), (False, False)])
+def test_center_scale_options(ctx, center, scale):
+    """pca/mod.rs:85-119: mean is subtracted only if center, std divides only if scale."""
+    import singlerust_amd as sr
+    from singlerust_amd.memory import processing
+    from singlerust_amd.memory.processing import dim_red
+    m, _ = synth_host(9, 1500, 1200, 0.08)
+    a = adata_of(m, ctx, 2)
+    processing.normalize_log1p_inplace(a, 1e4)
+    lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
+    sel = np.sort(pca_oracle.select_features_hvg(lg, 150))
+    a.var["hv"] = np.isin(np.arange(m.n_cols), sel)
+    dim_red.pca_inplace(a, 6, center, scale, None, sr.FeatureSelection.HighlyVariableCol("hv"), None, tol=1e-10)
+    scores, comps, evr, mean, std = pca_oracle.pca_inplace(lg, 6, center, scale, sel)
+    assert col_err(a.obsm["X_pca"], scores) < 1e-7
+    assert col_err(a.uns["pca"]["components"], comps) < 1e-7
+    np.testing.assert_allclose(a.uns["pca"]["explained_variance_ratio"], evr, rtol=1e-8)
+
+
+def test_defaults_and_small_k(ctx):
+    """n_components None -> 2 (dim_red/mod.rs:52); k < 64 panel columns; FeatureSelection::None."""
+    import singlerust_amd as sr
+    from singlerust_amd.memory import processing
+    from singlerust_amd.memory.processing import dim_red
+    z = np.load(os.path.join(GOLD, "counts_64x40.npz"))
+    m = oracle.Csr(64, 40, z["indptr"], z["indices"], z["values"])
+    # drop the two all-zero genes: the reference divides by std = 0 there (NaN)
+    lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
+    keep = np.nonzero(oracle.compute_number(m, COLUMN) > 1)[0].astype(np.uint64)
+    a = adata_of(m, ctx, 2)
+    processing.normalize_log1p_inplace(a, 1e4)
+    a.var["keep"] = np.isin(np.arange(40), keep)
+    info = dim_red.pca_inplace(a, None, None, None, None, sr.FeatureSelection.HighlyVariableCol("keep"), None, tol=1e-11)
+    assert a.obsm["X_pca"].shape == (64, 2) and info.n_pc == 2 and info.k == len(keep)
+    scores, comps, evr, *_ = pca_oracle.pca_inplace(lg, None, None, None, keep)
+    assert col_err(a.obsm["X_pca"], scores) < 1e-8
+    np.testing.assert_allclose(a.uns["pca"]["explained_variance_ratio"], evr, rtol=1e-9)
+
+
+def test_shape_errors(ctx):
+    """dim_red/mod.rs:38-41 panics for k < 2 or N < 5 -> SRX_E_SHAPE."""
+    import singlerust_amd as sr
+    from singlerust_amd import _ffi
+    from singlerust_amd.memory.processing import dim_red
+    a = sr.IMAnnData.new_basic((6, 3, [0, 1, 2, 3, 4, 5, 6], [0, 1, 2, 0, 1, 2], np.arange(1.0, 7.0)), ctx=ctx)
+    a.var["one"] = np.array([True, False, False])
+    with pytest.raises(sr.SrxError) as e:
+        dim_red.pca_inplace(a, 1, None, None, None, sr.FeatureSelection.HighlyVariableCol("one"), None)
+    assert e.value.code == _ffi.E_SHAPE
+    b = sr.IMAnnData.new_basic((3, 3, [0, 1, 2, 3], [0, 1, 2], np.arange(1.0, 4.0)), ctx=ctx)
+    with pytest.raises(sr.SrxError) as e:
+        dim_red.pca_inplace(b, 2, None, None, None, sr.FeatureSelection.None_, None)
+    assert e.value.code == _ffi.E_SHAPE
+
+
+def test_fused_pipeline_equals_separate_calls(ctx):
+    """srx_pipeline == normalize_total_inplace + log1p_transform_inplace + pca_inplace(HVG)."""
+    import singlerust_amd as sr
+    from singlerust_amd import _ffi
+    from singlerust_amd.memory import processing
+    from singlerust_amd.memory.processing import dim_red
+    m, _ = synth_host(21, 5000, 4000, 0.04)
+    a, b = adata_of(m, ctx, 1), adata_of(m, ctx, 1)
+    processing.normalize_total_inplace(a, 1e4, sr.Direction.Row)
+    processing.log1p_transform_inplace(a)
+    dim_red.pca_inplace(a, 20, None, None, None, sr.FeatureSelection.HighlyVariable(400), None)
+    opts = _ffi.PcaOpts(20, -1, -1, -1, 0, 0, 0.0, 0)
+    res = _ffi.PipelineResult()
+    _ffi.check(_ffi.lib().srx_pipeline(b.x().handle, 1e4, 400, C.byref(opts), C.byref(res)), ctx.handle)
+    scores = np.zeros((5000, 20))
+    comps = np.zeros((400, 20))
+    hv = np.zeros(400, np.uint64)
+    _ffi.check(_ffi.lib().srx_result_fetch(b.x().handle, _ffi.ptr(scores), _ffi.ptr(comps), None, None, None, _ffi.ptr(hv)), ctx.handle)
+    assert np.array_equal(hv, a.uns["pca"]["selected_features"])
+    assert np.array_equal(a.x_values(), b.x_values())
+    assert np.array_equal(scores, a.obsm["X_pca"])
+    assert np.array_equal(comps, a.uns["pca"]["components"])
+    assert res.pca.k == 400 and res.pca.n_pc == 20 and res.pca.nnz_selected > 0
+    # and against the oracle
+    lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
+    want, wc, *_ = pca_oracle.pca_inplace(lg, 20, None, None, hv)
+    assert col_err(scores, want) < TOL and col_err(comps, wc) < TOL
