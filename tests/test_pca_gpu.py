@@ -187,8 +187,9 @@ def test_fused_pipeline_equals_separate_calls(ctx):
     _ffi.check(_ffi.lib().srx_result_fetch(b.x().handle, _ffi.ptr(scores), _ffi.ptr(comps), None, None, None, _ffi.ptr(hv)), ctx.handle)
     assert np.array_equal(hv, a.uns["pca"]["selected_features"])
     assert np.array_equal(a.x_values(), b.x_values())
-    assert np.array_equal(scores, a.obsm["X_pca"])
-    assert np.array_equal(comps, a.uns["pca"]["components"])
+    # LDS atomics accumulate in a run-dependent order: equal to rounding, not bit-equal
+    assert col_err(scores, a.obsm["X_pca"]) < TOL
+    assert col_err(comps, a.uns["pca"]["components"]) < TOL
     assert res.pca.k == 400 and res.pca.n_pc == 20 and res.pca.nnz_selected > 0
     # and against the oracle
     lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
