@@ -32,8 +32,6 @@ namespace srx {
 
 constexpr int L = 64;               // panel width l
 constexpr int kTThreads = 1024;     // transposed kernel: one workgroup per CU
-constexpr int kTileF32 = 512;       // gene tile of the transposed kernel: 512*64*4 B = 128 KiB LDS
-constexpr int kTileF64 = 256;       //                                     256*64*8 B = 128 KiB LDS
 
 int32_t gene_variances(srx_mat* m, std::vector<double>& var);
 int32_t select_hvg_host(srx_ctx* ctx, const std::vector<double>& var, uint64_t n, std::vector<uint64_t>& out);
@@ -150,12 +148,51 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(const int64_t* __rest
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
 }
 
-// ---- forward SpMM: Y = A P - 1 cvec^T ----------------------------------------------------------
-// One 16-lane group per row; lane q of the group owns panel columns 4q..4q+3 (one 16-byte
-// read of the panel row per non-zero, bank-conflict free across the group).  The group loads
-// 16 (index, value) pairs with one coalesced read, then every lane walks them in rotated
-// order — lane q takes pair (q+s)%16 at step s — so no broadcast is needed: the order in
-// which a lane accumulates the row's non-zeros is irrelevant.
+// ---- tile-major layout of the compacted matrix --------------------------------------------------
+// The compacted N x k matrix is stored as n_t = ceil(k / 256) sub-matrices, one per GENE TILE
+// of KT = 256 compacted columns, back to back: sub-matrix t holds, row by row, the entries of
+// every cell that fall in columns [256 t, 256 t + 256), with LOCAL column indices 0..255 and
+// row pointers tptr[t*N + i].  A workgroup that owns (tile, row range) therefore streams ONE
+// contiguous index/value range, fully coalesced, instead of 9-entry pieces of 1.3M rows.
+// KT * 64 panel entries are exactly what LDS holds: 64 KiB as f32 (forward panel tile, two
+// workgroups per CU) or 128 KiB as f64 (transposed accumulators, one workgroup per CU).
+constexpr int KT = 256;
+
+__global__ void k_seglen(const int64_t* __restrict__ indptr, const int64_t* __restrict__ tp, uint64_t n_rows, int nt,
+                         int64_t* __restrict__ seglen) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t total = (uint64_t)nt * n_rows;
+    for (; e < total; e += stride) {
+        uint64_t t = e / n_rows, i = e % n_rows;
+        int64_t lo = t == 0 ? indptr[i] : tp[(t - 1) * n_rows + i];
+        int64_t hi = t == (uint64_t)nt - 1 ? indptr[i + 1] : tp[t * n_rows + i];
+        seglen[e] = hi - lo;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_retile(const int64_t* __restrict__ indptr, const int64_t* __restrict__ tp,
+                                                const int32_t* __restrict__ idx, const T* __restrict__ vals,
+                                                uint64_t n_rows, int nt, const int64_t* __restrict__ tptr,
+                                                int32_t* __restrict__ tidx, T* __restrict__ tvals) {
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
+    const int lane = lane_id();
+    for (uint64_t r = wave; r < n_rows; r += n_waves) {
+        const int64_t lo = indptr[r], hi = indptr[r + 1];
+        for (int64_t p = lo + lane; p < hi; p += kWave) {
+            int32_t c = idx[p];
+            int t = c / KT;
+            int64_t seg_lo = t == 0 ? lo : tp[(uint64_t)(t - 1) * n_rows + r];
+            int64_t dst = tptr[(uint64_t)t * n_rows + r] + (p - seg_lo);
+            tidx[dst] = c - t * KT;
+            tvals[dst] = vals[p];
+        }
+    }
+}
+
+// ---- small vector helpers ------------------------------------------------------------------------
 template <typename PT> struct Vec4;
 template <> struct Vec4<float> {
     float4 v;
@@ -176,104 +213,224 @@ template <> struct Vec4<double> {
     __device__ __forceinline__ double& operator[](int i) { return i == 0 ? a.x : i == 1 ? a.y : i == 2 ? b.x : b.y; }
 };
 
-template <typename VT, typename PT>
-__global__ __launch_bounds__(256) void k_spmm_fwd(const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx,
-                                                  const VT* __restrict__ vals, uint64_t n_rows,
-                                                  const PT* __restrict__ P, const PT* __restrict__ cvec,
-                                                  PT* __restrict__ Y) {
-    const uint64_t grp = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / 16;
-    const uint64_t n_grp = ((uint64_t)gridDim.x * blockDim.x) / 16;
-    const int q = threadIdx.x & 15;
-    PT c0 = cvec[4 * q], c1 = cvec[4 * q + 1], c2 = cvec[4 * q + 2], c3 = cvec[4 * q + 3];
-    for (uint64_t r = grp; r < n_rows; r += n_grp) {
-        const int64_t lo = indptr[r], hi = indptr[r + 1];
-        PT a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        for (int64_t base = lo; base < hi; base += 16) {
-            int64_t p = base + q;
-            int32_t mj = p < hi ? idx[p] : -1;
-            PT mv = p < hi ? (PT)vals[p] : PT(0);
+// DPP row rotate inside each 16-lane row (v_mov_b32_dpp row_ror:S) — no LDS traffic.
+template <int S>
+__device__ __forceinline__ int ror16(int x) {
+    if constexpr (S == 0) return x;
+    else return __builtin_amdgcn_update_dpp(0, x, 0x120 + S, 0xf, 0xf, false);
+}
+template <int S>
+__device__ __forceinline__ float ror16(float x) {
+    return __builtin_bit_cast(float, ror16<S>(__builtin_bit_cast(int, x)));
+}
+template <int S>
+__device__ __forceinline__ double ror16(double x) {
+    long long b = __builtin_bit_cast(long long, x);
+    int lo = ror16<S>((int)(b & 0xffffffffll)), hi = ror16<S>((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ int64_t readlane64(int64_t x, int l) {
+    int lo = __builtin_amdgcn_readlane((int)(x & 0xffffffffll), l);
+    int hi = __builtin_amdgcn_readlane((int)(x >> 32), l);
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ float readlane_v(float x, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
+__device__ __forceinline__ double readlane_v(double x, int l) {
+    return __builtin_bit_cast(double, readlane64(__builtin_bit_cast(long long, x), l));
+}
+
+// ---- forward SpMM: Y = A P - 1 cvec^T ----------------------------------------------------------
+// Workgroup = 512 threads = 32 groups of 16 lanes; a group owns 16 consecutive cells and lane
+// q of it owns panel columns 4q..4q+3 of all 16 output rows (64 accumulator registers).  The
+// workgroup walks the gene tiles; per tile it stages the 256 x 64 panel tile in LDS (64 KiB
+// as f32), then every group reads the <= 16 (index, value) pairs of each of its rows' tile
+// segment with one coalesced load and every lane visits them in DPP-rotated order (lane q
+// takes pair (q+s)%16 at step s): one conflict-free ds_read_b128 of the panel row + 4 FMAs
+// per pair, no broadcast and no atomics.  Empty slots carry value 0 and index 0.
+constexpr int kFwdThreads = 512;
+template <typename PT> struct FwdCfg;
+template <> struct FwdCfg<float> { static constexpr int kRows = 16, kWavesPerSimd = 4; };   // 2 workgroups / CU
+template <> struct FwdCfg<double> { static constexpr int kRows = 8, kWavesPerSimd = 2; };   // 1 workgroup / CU
+
+template <typename PT, int S>
+struct FwdRot {
+    static __device__ __forceinline__ void run(int ci, PT cv, const PT* __restrict__ panel_q, PT (&a)[4]) {
+        const int j = ror16<S>(ci);
+        const PT v = ror16<S>(cv);
+        Vec4<PT> p;
+        p.load(panel_q + j);
+        a[0] += v * p[0];
+        a[1] += v * p[1];
+        a[2] += v * p[2];
+        a[3] += v * p[3];
+        // keep at most 4 panel reads (16 VGPRs) in flight: without this fence the scheduler hoists
+        // all 128 ds_read_b128 of a stage and spills under the 128-VGPR budget of 2 workgroups/CU
+        if constexpr ((S & 3) == 3) asm volatile("" ::: "memory");
+        FwdRot<PT, S + 1>::run(ci, cv, panel_q, a);
+    }
+};
+template <typename PT>
+struct FwdRot<PT, 16> {
+    static __device__ __forceinline__ void run(int, PT, const PT* __restrict__, PT (&)[4]) {}
+};
+
+// One batch of kStage rows of a group: issue their (index, value) chunk loads together, then
+// run the 16 rotation steps of each.  H is a compile-time row offset so that the accumulator
+// array is only ever indexed statically (it must stay in registers).  Rows of a group are
+// consecutive, so row r's segment ends where row r+1's starts: `la` (lane q: start of row q,
+// relative to the group's first entry) and `le` (end of the last row) describe all of them.
+// Index loads are unconditional (the arrays are padded by 64 entries; a stray index is a valid
+// local column) and only the VALUE is masked to 0 — no divergent branches around the loads.
+template <typename VT, typename PT, int kRows, int kStage, int H>
+__device__ __forceinline__ void fwd_stage(const int32_t* __restrict__ gidx, const VT* __restrict__ gvals, int la,
+                                          int le, int c, int q, const PT* __restrict__ panel_q,
+                                          PT (&acc)[kRows][4]) {
+    if constexpr (H < kRows) {
+        int ci[kStage];
+        PT cvv[kStage];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                int src = (q + s) & 15;
-                int32_t j = __shfl(mj, src, 16);
-                PT v = __shfl(mv, src, 16);
-                if (j >= 0) {
-                    Vec4<PT> pr;
-                    pr.load(P + (size_t)j * L + 4 * q);
-                    a0 += v * pr[0];
-                    a1 += v * pr[1];
-                    a2 += v * pr[2];
-                    a3 += v * pr[3];
-                }
+        for (int r = 0; r < kStage; ++r) {
+            const int lo = __shfl(la, H + r, 16) + c;
+            const int hi = (H + r + 1 < 16) ? __shfl(la, (H + r + 1) & 15, 16) : le;
+            const int p = lo + q;
+            ci[r] = gidx[p] * L;
+            const PT v = (PT)gvals[p];
+            cvv[r] = p < hi ? v : PT(0);
+        }
+#pragma unroll
+        for (int r = 0; r < kStage; ++r) FwdRot<PT, 0>::run(ci[r], cvv[r], panel_q, acc[H + r]);
+        fwd_stage<VT, PT, kRows, kStage, H + kStage>(gidx, gvals, la, le, c, q, panel_q, acc);
+    }
+}
+
+template <typename VT, typename PT>
+__global__ __launch_bounds__(kFwdThreads, FwdCfg<PT>::kWavesPerSimd) void k_spmm_fwd(
+    const int64_t* __restrict__ tptr, const int32_t* __restrict__ tidx, const VT* __restrict__ tvals, uint64_t n_rows,
+    int nt, int k, const PT* __restrict__ P, const PT* __restrict__ cvec, PT* __restrict__ Y) {
+    constexpr int kRows = FwdCfg<PT>::kRows;            // rows per 16-lane group
+    constexpr int kRowsPerWg = (kFwdThreads / 16) * kRows;
+    constexpr int kStage = 4;                           // rows whose (index, value) chunks are in flight together
+    extern __shared__ double lds_raw[];
+    PT* panel = reinterpret_cast<PT*>(lds_raw);
+    const int q = threadIdx.x & 15;
+    const int group = threadIdx.x >> 4;
+    const PT* panel_q = panel + 4 * q;
+    Vec4<PT> cv4;
+    cv4.load(cvec + 4 * q);
+    const uint64_t n_blocks = (n_rows + kRowsPerWg - 1) / kRowsPerWg;
+    for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const uint64_t i0 = blk * kRowsPerWg + (uint64_t)group * kRows;
+        PT acc[kRows][4];
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = PT(0);
+        for (int t = 0; t < nt; ++t) {
+            __syncthreads();                         // everyone is done with the previous tile
+            for (int e = threadIdx.x * 4; e < KT * L; e += kFwdThreads * 4) {
+                Vec4<PT> v;
+                if (t * KT + e / L < k) v.load(P + (size_t)t * KT * L + e);
+                else v[0] = v[1] = v[2] = v[3] = PT(0);
+                v.store(panel + e);
+            }
+            __syncthreads();
+            // lane q: start of row i0+q in this tile (rows past the end collapse to empty segments)
+            const int64_t* tp = tptr + (uint64_t)t * n_rows;
+            const uint64_t rq = i0 + q < n_rows ? i0 + q : n_rows;
+            const uint64_t rend = i0 + kRows < n_rows ? i0 + kRows : n_rows;
+            const int64_t pa = tp[rq];
+            const int64_t p0 = __shfl(pa, 0, 16);
+            const int la = (int)(pa - p0);
+            const int le = (int)(tp[rend] - p0);
+            const int nxt = (q + 1 < 16) ? __shfl(la, (q + 1) & 15, 16) : le;
+            const int len = q < kRows ? (q + 1 < kRows ? nxt : le) - la : 0;
+            const int32_t* gidx = tidx + p0;
+            const VT* gvals = tvals + p0;
+            for (int c = 0;; c += 16) {
+                fwd_stage<VT, PT, kRows, kStage, 0>(gidx, gvals, la, le, c, q, panel_q, acc);
+                if (!__any(len > c + 16)) break;     // wave-uniform: some segment longer than 16 entries
             }
         }
-        Vec4<PT> o;
-        o[0] = a0 - c0;
-        o[1] = a1 - c1;
-        o[2] = a2 - c2;
-        o[3] = a3 - c3;
-        o.store(Y + (size_t)r * L + 4 * q);
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+            const uint64_t row = i0 + r;
+            if (row < n_rows) {
+                Vec4<PT> o;
+                o[0] = acc[r][0] - cv4[0];
+                o[1] = acc[r][1] - cv4[1];
+                o[2] = acc[r][2] - cv4[2];
+                o[3] = acc[r][3] - cv4[3];
+                o.store(Y + row * L + 4 * q);
+            }
+        }
     }
 }
 
 // ---- transposed SpMM: T = A^T Y (k x l), s = 1^T Y ---------------------------------------------
-// Workgroup = (gene tile, row block); the tile's k_t x 64 accumulators live in LDS (128 KiB);
-// one wave per row: lane c holds y[r][c]; the row's tile segment is read 64 non-zeros at a
-// time (coalesced) and each non-zero is broadcast with v_readlane and scattered with one
-// 64-lane LDS atomic add (conflict-free: 64 consecutive words).  Partials per row block are
-// summed in fixed order by k_t_reduce.
+// Workgroup = (gene tile, row block), 1024 threads; the tile's 256 x 64 accumulators live in
+// LDS (128 KiB as f64).  A wave takes 16 consecutive cells at a time: their tile segments
+// are ONE contiguous range of the tile-major arrays (coalesced 64-wide loads), lane c holds
+// y[r][c] of the 16 rows in registers, and each non-zero is broadcast with v_readlane and
+// scattered with one 64-lane LDS atomic add on 64 consecutive words (conflict-free).  The
+// per-row-block partials are summed in fixed order by k_t_reduce.
+constexpr int kTBatch = 16;
+
 template <typename VT, typename YT, typename AT>
-__global__ __launch_bounds__(kTThreads) void k_spmm_t(const int64_t* __restrict__ indptr, const int64_t* __restrict__ tp,
-                                                      const int32_t* __restrict__ idx, const VT* __restrict__ vals,
-                                                      uint64_t n_rows, int k, int n_tiles, int tile_genes,
+__global__ __launch_bounds__(kTThreads) void k_spmm_t(const int64_t* __restrict__ tptr, const int32_t* __restrict__ tidx,
+                                                      const VT* __restrict__ tvals, uint64_t n_rows, int k, int nt,
                                                       uint64_t rows_per_block, const YT* __restrict__ Y,
                                                       AT* __restrict__ part /* [rb][k][L] */,
                                                       double* __restrict__ part_s /* [rb][L] */) {
     extern __shared__ double lds_raw[];
     AT* acc = reinterpret_cast<AT*>(lds_raw);
-    for (int e = threadIdx.x; e < tile_genes * L; e += kTThreads) acc[e] = AT(0);
+    for (int e = threadIdx.x; e < KT * L; e += kTThreads) acc[e] = AT(0);
     __syncthreads();
-    const int tile = blockIdx.x % n_tiles;
-    const uint64_t rb = blockIdx.x / n_tiles;
-    const int jbase = tile * tile_genes;
+    const int tile = blockIdx.x % nt;
+    const uint64_t rb = blockIdx.x / nt;
     const uint64_t r0 = rb * rows_per_block;
     const uint64_t r1 = r0 + rows_per_block < n_rows ? r0 + rows_per_block : n_rows;
     const int lane = lane_id();
     const int wave = threadIdx.x / kWave;
     constexpr int kWaves = kTThreads / kWave;
+    const int64_t* tp = tptr + (uint64_t)tile * n_rows;
     double ysum = 0.0;
-    for (uint64_t r = r0 + wave; r < r1; r += kWaves) {
-        int64_t lo = tile == 0 ? indptr[r] : tp[(uint64_t)(tile - 1) * n_rows + r];
-        int64_t hi = tile == n_tiles - 1 ? indptr[r + 1] : tp[(uint64_t)tile * n_rows + r];
-        const AT y = (AT)Y[(size_t)r * L + lane];
-        if (tile == 0) ysum += (double)y;
-        for (int64_t base = lo; base < hi; base += kWave) {
-            int64_t p = base + lane;
-            int32_t mj = p < hi ? idx[p] - jbase : 0;
-            AT mv = p < hi ? (AT)vals[p] : AT(0);
-            int cnt = (int)(hi - base < kWave ? hi - base : kWave);
-            for (int s = 0; s < cnt; ++s) {
-                int32_t j = __builtin_amdgcn_readlane(mj, s);
-                AT v;
-                if constexpr (sizeof(AT) == 4) {
-                    v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mv), s));
-                } else {
-                    long long b = __builtin_bit_cast(long long, mv);
-                    int blo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), s);
-                    int bhi = __builtin_amdgcn_readlane((int)(b >> 32), s);
-                    v = __builtin_bit_cast(double, ((long long)bhi << 32) | (unsigned int)blo);
+    for (uint64_t rr = r0 + (uint64_t)wave * kTBatch; rr < r1; rr += (uint64_t)kWaves * kTBatch) {
+        const int nb = (int)(r1 - rr < (uint64_t)kTBatch ? r1 - rr : (uint64_t)kTBatch);
+        const int64_t myp = lane <= nb ? tp[rr + lane] : 0;
+        AT y[kTBatch];
+#pragma unroll
+        for (int r = 0; r < kTBatch; ++r) y[r] = r < nb ? (AT)Y[(rr + r) * L + lane] : AT(0);
+        if (tile == 0) {
+#pragma unroll
+            for (int r = 0; r < kTBatch; ++r) ysum += (double)y[r];
+        }
+        int64_t p[kTBatch + 1];
+#pragma unroll
+        for (int r = 0; r <= kTBatch; ++r) p[r] = readlane64(myp, r < nb ? r : nb);
+        const int64_t pend = p[kTBatch];
+        for (int64_t cb = p[0]; cb < pend; cb += kWave) {
+            const int64_t pq = cb + lane;
+            const int32_t ci = pq < pend ? tidx[pq] * L : 0;
+            const VT cvv = pq < pend ? tvals[pq] : VT(0);
+#pragma unroll
+            for (int r = 0; r < kTBatch; ++r) {
+                const int64_t a = p[r] > cb ? p[r] : cb;
+                const int64_t b = p[r + 1] < cb + kWave ? p[r + 1] : cb + kWave;
+                const int lo = (int)(a - cb), hi = (int)(b - cb);
+                for (int s = lo; s < hi; ++s) {
+                    const int j = __builtin_amdgcn_readlane(ci, s);
+                    const AT v = (AT)readlane_v(cvv, s);
+                    __hip_atomic_fetch_add(&acc[j + lane], v * y[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                __hip_atomic_fetch_add(&acc[j * L + lane], v * y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < tile_genes * L; e += kTThreads) {
-        int j = jbase + e / L;
+    for (int e = threadIdx.x; e < KT * L; e += kTThreads) {
+        int j = tile * KT + e / L;
         if (j < k) part[(rb * (uint64_t)k + j) * L + (e % L)] = acc[e];
     }
     if (tile == 0) {
-        // per-wave column sums of Y -> LDS is busy, so reduce through a small static array
         __shared__ double s_y[kWaves][L];
         s_y[wave][lane] = ysum;
         __syncthreads();
@@ -284,6 +441,7 @@ __global__ __launch_bounds__(kTThreads) void k_spmm_t(const int64_t* __restrict_
         }
     }
 }
+
 
 // T[k*L .. k*L+L) receives s.  Fixed summation order over the row blocks.
 template <typename AT>
@@ -426,16 +584,13 @@ __global__ void k_scores(const YT* __restrict__ Y, uint64_t n_rows, int n_pc, do
     }
 }
 
-// ---- compacted matrix ---------------------------------------------------------------------------
-struct Compact {
+// ---- compacted, tile-major matrix -----------------------------------------------------------------
+struct Tiled {
     uint64_t n_rows = 0, nnz = 0;
-    int k = 0;
-    int64_t* indptr = nullptr;
-    int32_t* idx = nullptr;
-    void* vals = nullptr;
-    int64_t* tp32 = nullptr;   // tile pointers for the f32-accumulate tiling
-    int64_t* tp64 = nullptr;   // ... and the f64-accumulate tiling
-    int nt32 = 0, nt64 = 0;
+    int k = 0, nt = 0;
+    int64_t* tptr = nullptr;   // nt * n_rows + 1
+    int32_t* tidx = nullptr;   // local column within the tile
+    void* tvals = nullptr;
 };
 
 static int grid_rows(const srx_ctx* ctx, uint64_t n_rows, int rows_per_block) {
@@ -445,82 +600,113 @@ static int grid_rows(const srx_ctx* ctx, uint64_t n_rows, int rows_per_block) {
     return (int)(want < cap ? want : cap);
 }
 
-static int32_t build_tile_ptr(srx_ctx* ctx, const Compact& c, int tile_genes, const char* name, int64_t** tp, int* nt) {
-    *nt = (c.k + tile_genes - 1) / tile_genes;
-    *tp = nullptr;
-    if (*nt <= 1) return SRX_OK;
-    SRX_TRY(scratch(ctx, name, (size_t)(*nt - 1) * (c.n_rows ? c.n_rows : 1) * sizeof(int64_t), (void**)tp));
-    return launch_tile_ptr(ctx, c.indptr, c.idx, c.n_rows, *nt, tile_genes, *tp);
+// out[0..n] = exclusive scan of in[0..n), out[n] = total (also returned through *total_dev).
+static int32_t scan_exclusive(srx_ctx* ctx, const int64_t* d_in, uint64_t n, int64_t* d_out, int64_t** total_dev) {
+    const uint64_t per_block = (uint64_t)kScanBlock * kScanItems;
+    const uint64_t nb = (n + per_block - 1) / per_block > 0 ? (n + per_block - 1) / per_block : 1;
+    int64_t* d_bsum;
+    SRX_TRY(scratch(ctx, "scan_bsum", (nb + 1) * sizeof(int64_t), (void**)&d_bsum));
+    int64_t* d_total = d_bsum + nb;
+    hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, d_in, n, d_bsum);
+    hipLaunchKernelGGL(k_scan_serial, dim3(1), dim3(64), 0, ctx->stream, d_bsum, nb, d_total);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, d_in, n, d_bsum, d_total,
+                       d_out);
+    SRX_HIP(ctx, hipGetLastError());
+    if (total_dev) *total_dev = d_total;
+    return SRX_OK;
 }
 
-static int32_t build_compact(srx_mat* m, const std::vector<int32_t>& remap, int k, Compact& c) {
+// X[:, sel] -> row-major compacted CSR (count, scan, fill) -> tile-major (cut, scan, copy).
+static int32_t build_tiled(srx_mat* m, const std::vector<int32_t>& remap, int k, Tiled& c) {
     srx_ctx* ctx = m->ctx;
     const uint64_t N = m->n_rows;
-    int32_t* d_remap;
-    int64_t *d_counts, *d_bsum, *d_total;
+    int32_t *d_remap, *c_idx;
+    int64_t *d_counts, *c_indptr, *d_total;
+    void* c_vals;
     SRX_TRY(scratch(ctx, "pca_remap", (remap.size() ? remap.size() : 1) * sizeof(int32_t), (void**)&d_remap));
     SRX_TRY(h2d(ctx, d_remap, remap.data(), remap.size() * sizeof(int32_t)));
     SRX_TRY(scratch(ctx, "pca_counts", (N ? N : 1) * sizeof(int64_t), (void**)&d_counts));
-    const uint64_t per_block = (uint64_t)kScanBlock * kScanItems;
-    const uint64_t nb = (N + per_block - 1) / per_block > 0 ? (N + per_block - 1) / per_block : 1;
-    SRX_TRY(scratch(ctx, "pca_bsum", (nb + 1) * sizeof(int64_t), (void**)&d_bsum));
-    d_total = d_bsum + nb;
-    SRX_TRY(scratch(ctx, "pca_cindptr", (N + 1) * sizeof(int64_t), (void**)&c.indptr));
+    SRX_TRY(scratch(ctx, "pca_cindptr", (N + 1) * sizeof(int64_t), (void**)&c_indptr));
     const double in_bytes = (double)m->nnz * 4.0 * 2.0 + (double)(N + 1) * 8.0 * 2.0;   // idx read by count + fill
-    {
-        ProfScope ps(ctx, SRX_K_COMPACT, in_bytes);   // selected values/indices written are added below
-        hipLaunchKernelGGL(k_compact_count, dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream, m->d_indptr,
-                           m->d_indices, d_remap, N, d_counts);
-        hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, d_counts, N, d_bsum);
-        hipLaunchKernelGGL(k_scan_serial, dim3(1), dim3(64), 0, ctx->stream, d_bsum, nb, d_total);
-        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, d_counts, N, d_bsum,
-                           d_total, c.indptr);
-        SRX_HIP(ctx, hipGetLastError());
-        int64_t total = 0;
-        SRX_TRY(d2h(ctx, &total, d_total, sizeof(int64_t)));
-        c.nnz = (uint64_t)total;
-        c.n_rows = N;
-        c.k = k;
-        SRX_TRY(scratch(ctx, "pca_cidx", (c.nnz ? c.nnz : 1) * sizeof(int32_t), (void**)&c.idx));
-        SRX_TRY(scratch(ctx, "pca_cvals", (c.nnz ? c.nnz : 1) * val_bytes(m), &c.vals));
-        if (is_f32(m))
-            hipLaunchKernelGGL((k_compact_fill<float>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream,
-                               m->d_indptr, m->d_indices, (const float*)m->d_values, d_remap, N, c.indptr, c.idx,
-                               (float*)c.vals);
-        else
-            hipLaunchKernelGGL((k_compact_fill<double>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream,
-                               m->d_indptr, m->d_indices, (const double*)m->d_values, d_remap, N, c.indptr, c.idx,
-                               (double*)c.vals);
-        SRX_HIP(ctx, hipGetLastError());
-        ctx->prof[SRX_K_COMPACT].bytes += (ctx->prof_mask & (1u << SRX_K_COMPACT))
-                                              ? (double)c.nnz * (4.0 + val_bytes(m)) * 2.0 : 0.0;
+    ProfScope ps(ctx, SRX_K_COMPACT, in_bytes);
+    hipLaunchKernelGGL(k_compact_count, dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream, m->d_indptr,
+                       m->d_indices, d_remap, N, d_counts);
+    SRX_TRY(scan_exclusive(ctx, d_counts, N, c_indptr, &d_total));
+    int64_t total = 0;
+    SRX_TRY(d2h(ctx, &total, d_total, sizeof(int64_t)));
+    c.nnz = (uint64_t)total;
+    c.n_rows = N;
+    c.k = k;
+    c.nt = (k + KT - 1) / KT;
+    const size_t vb = val_bytes(m);
+    SRX_TRY(scratch(ctx, "pca_cidx", (c.nnz ? c.nnz : 1) * sizeof(int32_t), (void**)&c_idx));
+    SRX_TRY(scratch(ctx, "pca_cvals", (c.nnz ? c.nnz : 1) * vb, &c_vals));
+    if (is_f32(m))
+        hipLaunchKernelGGL((k_compact_fill<float>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream, m->d_indptr,
+                           m->d_indices, (const float*)m->d_values, d_remap, N, c_indptr, c_idx, (float*)c_vals);
+    else
+        hipLaunchKernelGGL((k_compact_fill<double>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream,
+                           m->d_indptr, m->d_indices, (const double*)m->d_values, d_remap, N, c_indptr, c_idx,
+                           (double*)c_vals);
+    SRX_HIP(ctx, hipGetLastError());
+    // tile cuts of every compacted row, segment lengths, their scan = tile-major row pointers
+    int64_t* d_tp = nullptr;
+    if (c.nt > 1) {
+        SRX_TRY(scratch(ctx, "pca_tp", (size_t)(c.nt - 1) * (N ? N : 1) * sizeof(int64_t), (void**)&d_tp));
+        SRX_TRY(launch_tile_ptr(ctx, c_indptr, c_idx, N, c.nt, KT, d_tp));
     }
-    SRX_TRY(build_tile_ptr(ctx, c, kTileF32, "pca_tp32", &c.tp32, &c.nt32));
-    SRX_TRY(build_tile_ptr(ctx, c, kTileF64, "pca_tp64", &c.tp64, &c.nt64));
+    const uint64_t nseg = (uint64_t)c.nt * N;
+    int64_t* d_seglen;
+    SRX_TRY(scratch(ctx, "pca_seglen", (nseg ? nseg : 1) * sizeof(int64_t), (void**)&d_seglen));
+    SRX_TRY(scratch(ctx, "pca_tptr", (nseg + 1) * sizeof(int64_t), (void**)&c.tptr));
+    uint64_t g = (nseg + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(k_seglen, dim3((unsigned)g), dim3(256), 0, ctx->stream, c_indptr, d_tp, N, c.nt, d_seglen);
+    SRX_TRY(scan_exclusive(ctx, d_seglen, nseg, c.tptr, nullptr));
+    SRX_TRY(scratch(ctx, "pca_tidx", (c.nnz + 64) * sizeof(int32_t), (void**)&c.tidx));   // +64: unconditional 16-wide reads
+    SRX_HIP(ctx, hipMemsetAsync(c.tidx + c.nnz, 0, 64 * sizeof(int32_t), ctx->stream));
+    SRX_TRY(scratch(ctx, "pca_tvals", (c.nnz + 64) * vb, &c.tvals));
+    SRX_HIP(ctx, hipMemsetAsync((char*)c.tvals + c.nnz * vb, 0, 64 * vb, ctx->stream));
+    if (is_f32(m))
+        hipLaunchKernelGGL((k_retile<float>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream, c_indptr, d_tp,
+                           c_idx, (const float*)c_vals, N, c.nt, c.tptr, c.tidx, (float*)c.tvals);
+    else
+        hipLaunchKernelGGL((k_retile<double>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream, c_indptr, d_tp,
+                           c_idx, (const double*)c_vals, N, c.nt, c.tptr, c.tidx, (double*)c.tvals);
+    SRX_HIP(ctx, hipGetLastError());
+    if (ctx->prof_mask & (1u << SRX_K_COMPACT))
+        ctx->prof[SRX_K_COMPACT].bytes += (double)c.nnz * (4.0 + vb) * 4.0;   // write + read + write of the kept entries
     return SRX_OK;
 }
 
 // ---- launches ---------------------------------------------------------------------------------
 template <typename VT, typename PT>
-static int32_t launch_fwd(srx_ctx* ctx, const Compact& c, const PT* P, const PT* cvec, PT* Y) {
-    const double bytes = (double)c.nnz * (4.0 + sizeof(VT)) + (double)(c.n_rows + 1) * 8.0 +
+static int32_t launch_fwd(srx_ctx* ctx, const Tiled& c, const PT* P, const PT* cvec, PT* Y) {
+    const double bytes = (double)c.nnz * (4.0 + sizeof(VT)) + (double)((uint64_t)c.nt * c.n_rows + 1) * 8.0 +
                          (double)c.n_rows * L * sizeof(PT) + (double)c.k * L * sizeof(PT);
+    const size_t lds = (size_t)KT * L * sizeof(PT);
+    constexpr int kRowsPerWg = (kFwdThreads / 16) * FwdCfg<PT>::kRows;
+    const uint64_t n_blocks = (c.n_rows + kRowsPerWg - 1) / kRowsPerWg;
+    const int per_cu = sizeof(PT) == 4 ? 2 : 1;                 // 64 KiB vs 128 KiB of LDS per workgroup
+    uint64_t grid = (uint64_t)ctx->n_cus * per_cu;
+    if (grid > n_blocks) grid = n_blocks;
+    if (grid < 1) grid = 1;
     ProfScope ps(ctx, SRX_K_SPMM_FWD, bytes);
-    hipLaunchKernelGGL((k_spmm_fwd<VT, PT>), dim3(grid_rows(ctx, c.n_rows, 16)), dim3(256), 0, ctx->stream, c.indptr,
-                       c.idx, (const VT*)c.vals, c.n_rows, P, cvec, Y);
+    SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_spmm_fwd<VT, PT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+    hipLaunchKernelGGL((k_spmm_fwd<VT, PT>), dim3((unsigned)grid), dim3(kFwdThreads), lds, ctx->stream, c.tptr, c.tidx,
+                       (const VT*)c.tvals, c.n_rows, c.nt, c.k, P, cvec, Y);
     SRX_HIP(ctx, hipGetLastError());
     return SRX_OK;
 }
 
 template <typename VT, typename YT, typename AT>
-static int32_t launch_t(srx_ctx* ctx, const Compact& c, const YT* Y, double* T /* k*L + L */) {
+static int32_t launch_t(srx_ctx* ctx, const Tiled& c, const YT* Y, double* T /* k*L + L */) {
     const bool a32 = sizeof(AT) == 4;
-    const int tile = a32 ? kTileF32 : kTileF64;
-    const int nt = a32 ? c.nt32 : c.nt64;
-    const int64_t* tp = a32 ? c.tp32 : c.tp64;
-    uint64_t want = (uint64_t)(2 * ctx->n_cus) / (uint64_t)nt;
+    uint64_t want = (uint64_t)(2 * ctx->n_cus) / (uint64_t)c.nt;
     if (want < 1) want = 1;
-    uint64_t by_rows = (c.n_rows + 63) / 64;
+    uint64_t by_rows = (c.n_rows + 255) / 256;
     if (by_rows < 1) by_rows = 1;
     const uint64_t n_rb = want < by_rows ? want : by_rows;
     const uint64_t rpb = (c.n_rows + n_rb - 1) / n_rb > 0 ? (c.n_rows + n_rb - 1) / n_rb : 1;
@@ -528,15 +714,15 @@ static int32_t launch_t(srx_ctx* ctx, const Compact& c, const YT* Y, double* T /
     double* part_s;
     SRX_TRY(scratch(ctx, a32 ? "pca_tpart32" : "pca_tpart64", n_rb * (size_t)c.k * L * sizeof(AT), (void**)&part));
     SRX_TRY(scratch(ctx, "pca_tpart_s", n_rb * L * sizeof(double), (void**)&part_s));
-    const size_t lds = (size_t)tile * L * sizeof(AT);
-    const double bytes = (double)c.nnz * (4.0 + sizeof(VT)) + (double)(c.n_rows + 1) * 8.0 +
+    const size_t lds = (size_t)KT * L * sizeof(AT);
+    const double bytes = (double)c.nnz * (4.0 + sizeof(VT)) + (double)((uint64_t)c.nt * c.n_rows + 1) * 8.0 +
                          (double)c.n_rows * L * sizeof(YT) + (double)c.k * L * 8.0;
     {
         ProfScope ps(ctx, SRX_K_SPMM_T, bytes);
         SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_spmm_t<VT, YT, AT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds));
-        hipLaunchKernelGGL((k_spmm_t<VT, YT, AT>), dim3((unsigned)(n_rb * nt)), dim3(kTThreads), lds, ctx->stream,
-                           c.indptr, tp, c.idx, (const VT*)c.vals, c.n_rows, c.k, nt, tile, rpb, Y, part, part_s);
+        hipLaunchKernelGGL((k_spmm_t<VT, YT, AT>), dim3((unsigned)(n_rb * c.nt)), dim3(kTThreads), lds, ctx->stream,
+                           c.tptr, c.tidx, (const VT*)c.tvals, c.n_rows, c.k, c.nt, rpb, Y, part, part_s);
         uint64_t tot = (uint64_t)c.k * L + L;
         hipLaunchKernelGGL((k_t_reduce<AT>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, part, part_s,
                            c.k, n_rb, T);
@@ -544,6 +730,7 @@ static int32_t launch_t(srx_ctx* ctx, const Compact& c, const YT* Y, double* T /
     SRX_HIP(ctx, hipGetLastError());
     return SRX_OK;
 }
+
 
 // ---- the driver ---------------------------------------------------------------------------------
 struct Resolved {
@@ -560,7 +747,7 @@ static uint64_t mix64(uint64_t x) {
 }
 
 template <typename VT, typename PT>
-static int32_t run_subspace(srx_mat* m, const Compact& c, const Resolved& o, const std::vector<double>& mu,
+static int32_t run_subspace(srx_mat* m, const Tiled& c, const Resolved& o, const std::vector<double>& mu,
                             const std::vector<double>& dinv, int l_act, srx_pca_state& st) {
     srx_ctx* ctx = m->ctx;
     const int k = c.k;
@@ -785,8 +972,8 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     std::vector<double> mu_eff = mu;
     if (!o.center) std::fill(mu_eff.begin(), mu_eff.end(), 0.0);
 
-    Compact c;
-    SRX_TRY(build_compact(m, remap, k, c));
+    Tiled c;
+    SRX_TRY(build_tiled(m, remap, k, c));
     st.info = srx_pca_info{};
     st.info.n_cells_global = Ng;
     st.info.k = (uint32_t)k;
