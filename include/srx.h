@@ -209,6 +209,13 @@ int32_t srx_pca(srx_mat* m, const uint64_t* sel, uint64_t k, const srx_pca_opts*
 int32_t srx_pca_loadings(const double* components, const double* std_, const uint64_t* sel,
                          uint64_t k, uint64_t n_pc, uint64_t n_vars, double* out);
 
+/* The raw CSR x dense-panel operator the PCA is built from, for a caller-supplied 64-column
+ * panel: y_out (n_rows x 64) = X[:, sel] * panel, t_out (k x 64) = X[:, sel]^T * y.  `sel` must
+ * be strictly ascending; either output may be NULL; accumulate_f64 selects the f64 LDS
+ * accumulators of the transposed product. */
+int32_t srx_spmm(srx_mat* m, const uint64_t* sel, uint64_t k, const double* panel, double* y_out,
+                 double* t_out, int32_t accumulate_f64);
+
 /* ---- fused pipeline: normalize_total_inplace(target, Row) -> log1p_transform_inplace ->
  * pca_inplace(n_pc, center, scale, .., HighlyVariable(n_hvg)) with every intermediate
  * resident in HBM.  Results stay on the device until fetched. */

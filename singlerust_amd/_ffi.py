@@ -103,6 +103,7 @@ _SIGS = {
     "srx_select_hvg": (C.c_int32, [P, C.c_uint64, P, C.POINTER(C.c_uint64)]),
     "srx_pca": (C.c_int32, [P, P, C.c_uint64, C.POINTER(PcaOpts), P, P, P, P, P, C.POINTER(PcaInfo)]),
     "srx_pca_loadings": (C.c_int32, [P, P, P, C.c_uint64, C.c_uint64, C.c_uint64, P]),
+    "srx_spmm": (C.c_int32, [P, P, C.c_uint64, P, P, P, C.c_int32]),
     "srx_pipeline": (C.c_int32, [P, C.c_double, C.c_uint64, C.POINTER(PcaOpts), C.POINTER(PipelineResult)]),
     "srx_result_fetch": (C.c_int32, [P, P, P, P, P, P, P]),
     "srx_prof_enable": (C.c_int32, [P, C.c_uint32]),

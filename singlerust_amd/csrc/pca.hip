@@ -342,7 +342,10 @@ __global__ __launch_bounds__(kFwdThreads, FwdCfg<PT>::kWavesPerSimd) void k_spmm
             const int64_t p0 = __shfl(pa, 0, 16);
             const int la = (int)(pa - p0);
             const int le = (int)(tp[rend] - p0);
-            const int nxt = (q + 1 < 16) ? __shfl(la, (q + 1) & 15, 16) : le;
+            // NB: the shuffle must run with every lane active (a lane-dependent ?: would mask lane 15
+            // out of the ds_bpermute and lane 14 would read 0 from it)
+            const int la_next = __shfl(la, (q + 1) & 15, 16);
+            const int nxt = (q + 1 < 16) ? la_next : le;
             const int len = q < kRows ? (q + 1 < kRows ? nxt : le) - la : 0;
             const int32_t* gidx = tidx + p0;
             const VT* gvals = tvals + p0;
@@ -1035,6 +1038,52 @@ int32_t srx_pca(srx_mat* m, const uint64_t* sel, uint64_t k, const srx_pca_opts*
     if (info) *info = m->pca.info;
     int32_t rc2 = srx_result_fetch(m, scores, components, evr, mean, std_, nullptr);
     return rc2 != SRX_OK ? rc2 : rc;
+}
+
+// Kernel-level entry point: Y = X[:, sel] * P and T = X[:, sel]^T * Y for a caller-supplied
+// 64-column panel (no centring / scaling).  Exists so the two SpMM kernels can be checked
+// against the CPU oracle in isolation, and as the raw CSR x dense-panel operator.
+int32_t srx_spmm(srx_mat* m, const uint64_t* sel, uint64_t k64, const double* panel, double* y_out, double* t_out,
+                 int32_t accumulate_f64) {
+    if (!m || !sel || !panel) return fail(m ? m->ctx : nullptr, SRX_E_ARG, "null argument");
+    srx_ctx* ctx = m->ctx;
+    SRX_HIP(ctx, hipSetDevice(ctx->device));
+    const int k = (int)k64;
+    const uint64_t G = m->n_cols;
+    std::vector<int32_t> remap(G, -1);
+    for (int s = 0; s < k; ++s) {
+        if (sel[s] >= G) return fail(ctx, SRX_E_BOUNDS, "selected feature index out of bounds");
+        if (s > 0 && sel[s] <= sel[s - 1]) return fail(ctx, SRX_E_ARG, "srx_spmm: sel must be strictly ascending");
+        remap[sel[s]] = s;
+    }
+    Tiled c;
+    SRX_TRY(build_tiled(m, remap, k, c));
+    const size_t kl = (size_t)k * L;
+    double* T;
+    SRX_TRY(scratch(ctx, "pca_T", (kl + L) * 8, (void**)&T));
+    auto run = [&](auto vt, auto pt) -> int32_t {
+        using VT = decltype(vt);
+        using PT = decltype(pt);
+        PT *P, *Y;
+        SRX_TRY(scratch(ctx, "pca_P", (kl + L) * sizeof(PT), (void**)&P));
+        SRX_TRY(scratch(ctx, "pca_Y", (c.n_rows ? c.n_rows : 1) * (size_t)L * sizeof(PT), (void**)&Y));
+        std::vector<PT> hp(kl + L, PT(0));
+        for (size_t e = 0; e < kl; ++e) hp[e] = (PT)panel[e];
+        SRX_TRY(h2d(ctx, P, hp.data(), (kl + L) * sizeof(PT)));
+        SRX_TRY((launch_fwd<VT, PT>(ctx, c, P, P + kl, Y)));
+        if (y_out) {
+            std::vector<PT> hy(c.n_rows * (size_t)L);
+            SRX_TRY(d2h(ctx, hy.data(), Y, hy.size() * sizeof(PT)));
+            for (size_t e = 0; e < hy.size(); ++e) y_out[e] = (double)hy[e];
+        }
+        if (t_out) {
+            if (accumulate_f64 || sizeof(PT) == 8) SRX_TRY((launch_t<VT, PT, double>(ctx, c, Y, T)));
+            else SRX_TRY((launch_t<VT, PT, float>(ctx, c, Y, T)));
+            SRX_TRY(d2h(ctx, t_out, T, kl * 8));
+        }
+        return SRX_OK;
+    };
+    return is_f32(m) ? run(float{}, float{}) : run(double{}, double{});
 }
 
 int32_t srx_pca_loadings(const double* components, const double* std_, const uint64_t* sel, uint64_t k,

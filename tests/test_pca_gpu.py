@@ -195,3 +195,34 @@ def test_fused_pipeline_equals_separate_calls(ctx):
     lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
     want, wc, *_ = pca_oracle.pca_inplace(lg, 20, None, None, hv)
     assert col_err(scores, want) < TOL and col_err(comps, wc) < TOL
+
+
+@pytest.mark.parametrize("store", [1, 2])
+@pytest.mark.parametrize("n,g,density,k", [(700, 500, 0.1, 100), (5000, 4000, 0.04, 700), (20000, 3000, 0.2, 1500)])
+def test_spmm_kernels_vs_scipy(ctx, store, n, g, density, k):
+    """The CSR x dense-panel forward product and its transpose, kernel level, against scipy."""
+    import scipy.sparse as sp
+    from singlerust_amd import _ffi
+    rng = np.random.default_rng(n + k)
+    m, _ = synth_host(3, n, g, density)
+    a = adata_of(m, ctx, store)
+    sel = np.sort(rng.choice(g, k, replace=False)).astype(np.uint64)
+    # make a few rows long inside one gene tile (> 16 entries per 256-column tile)
+    P = rng.standard_normal((k, 64))
+    y = np.zeros((n, 64))
+    t32 = np.zeros((k, 64))
+    t64 = np.zeros((k, 64))
+    lib = _ffi.lib()
+    _ffi.check(lib.srx_spmm(a.x().handle, _ffi.ptr(sel), k, _ffi.ptr(P), _ffi.ptr(y), _ffi.ptr(t32), 0), ctx.handle)
+    _ffi.check(lib.srx_spmm(a.x().handle, _ffi.ptr(sel), k, _ffi.ptr(P), None, _ffi.ptr(t64), 1), ctx.handle)
+    A = sp.csr_matrix((m.values.astype(np.float64), m.indices.astype(np.int64), m.indptr.astype(np.int64)),
+                      shape=(n, g))[:, sel.astype(np.int64)]
+    P_used = P.astype(np.float32).astype(np.float64) if store == 1 else P
+    want_y = A @ P_used
+    scale = np.abs(want_y).max()
+    tol = 2e-6 if store == 1 else 1e-12
+    assert np.abs(y - want_y).max() / scale < tol
+    want_t = A.T @ y                                        # the transpose applied to the y the kernel produced
+    ts = np.abs(want_t).max()
+    assert np.abs(t64 - want_t).max() / ts < (1e-7 if store == 1 else 1e-12)
+    assert np.abs(t32 - want_t).max() / ts < (2e-5 if store == 1 else 1e-12)
