@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--hvg", type=int, default=2000)
     ap.add_argument("--npc", type=int, default=50)
     ap.add_argument("--target-sum", type=float, default=1e4)
+    ap.add_argument("--solver", type=int, default=0, help="0 auto, 1 explicit Gram, 2 matrix-free SpMM iteration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=12000)
     ap.add_argument("--max-copies-gb", type=float, default=180.0)
@@ -133,7 +134,7 @@ def main():
     copies = [pristine.clone() for _ in range(n_copies)]
     ctx.synchronize()
 
-    opts = F.PcaOpts(a.npc, -1, -1, -1, 0, 0, 0.0, 12345)
+    opts = F.PcaOpts(a.npc, -1, -1, -1, 0, 0, a.solver, 0.0, 12345)
     res = F.PipelineResult()
 
     def step(mat):
@@ -151,7 +152,7 @@ def main():
     for _ in range(a.warmup):
         step(copies[used]); used += 1
     # timed: chunks of fresh copies; restoring copies from the pristine matrix is outside the clock
-    prof_mask = (1 << F.K_NORMALIZE) | (1 << F.K_MOMENTS) | (1 << F.K_COMPACT) | (1 << F.K_SPMM_FWD) | (1 << F.K_SPMM_T)
+    prof_mask = sum(1 << c for c in (F.K_NORMALIZE, F.K_MOMENTS, F.K_COMPACT, F.K_SPMM_FWD, F.K_SPMM_T, F.K_GRAM, F.K_DENSE))
     ctx.prof_enable(prof_mask)
     ctx.prof_reset()
     elapsed = 0.0
@@ -182,7 +183,7 @@ def main():
 
     prof = {}
     names = {F.K_NORMALIZE: "normalize_log1p", F.K_MOMENTS: "gene_moments", F.K_COMPACT: "hvg_compact",
-             F.K_SPMM_FWD: "spmm_fwd", F.K_SPMM_T: "spmm_t"}
+             F.K_SPMM_FWD: "spmm_fwd", F.K_SPMM_T: "spmm_t", F.K_GRAM: "gram_sparse", F.K_DENSE: "dense_apply"}
     for cls_, name in names.items():
         ms, n, b = ctx.prof_get(cls_)
         if n:
@@ -206,6 +207,7 @@ def main():
                 "panel_width": 64, "parallelism": f"row-shard x{world}",
                 "nnz_hvg_compacted_per_gpu": int(res.pca.nnz_selected),
                 "subspace_iterations": iters, "pca_residual": float(res.pca.residual),
+                "pca_solver": {1: "gram", 2: "spmm"}.get(int(res.pca.solver), "?"),
             },
             "roofline": {
                 "bound": "hbm", "kernel": "k_spmm_fwd (CSR x 64-col panel)",

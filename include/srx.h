@@ -170,15 +170,24 @@ int32_t srx_select_hvg(srx_mat* m, uint64_t n, uint64_t* idx_out, uint64_t* n_ou
 /* ---- PCA: dim_red::pca_inplace (dim_red/mod.rs:24-94); arithmetic spec
  * src/shared/processing/pca/mod.rs:74-215.  Computed by randomized block subspace
  * iteration on the implicit standardised matrix Z = (X[:, sel] - 1 mu^T) D^-1 with a
- * CSR x dense-panel SpMM (forward) and its transpose; never densifies X. */
+ * CSR x dense-panel SpMM (forward) and its transpose, or — Gram solver — with X_sel^T X_sel
+ * accumulated once from the sparse rows; never densifies X. */
+typedef enum srx_pca_solver {
+    SRX_SOLVER_AUTO = 0,
+    SRX_SOLVER_GRAM = 1,   /* explicit sparse Gram X_sel^T X_sel once, dense k x k iteration  */
+    SRX_SOLVER_SPMM = 2    /* matrix-free: forward + transposed SpMM every iteration         */
+} srx_pca_solver;
+
 typedef struct srx_pca_opts {
     int32_t n_components;  /* < 0 = None -> 2        (dim_red/mod.rs:52)                  */
     int32_t center;        /* < 0 = None -> true     (:55)                                */
     int32_t scale;         /* < 0 = None -> true     (:56)                                */
     int32_t n_threads;     /* accepted, ignored on GPU (:61)                              */
-    int32_t block;         /* panel width l; 0 -> default (64, or n_pc rounded up)        */
-    int32_t max_iter;      /* 0 -> default 100                                            */
-    double  tol;           /* relative Ritz-residual tolerance; 0 -> default 1e-7         */
+    int32_t block;         /* panel width l; 0 -> default (64)                            */
+    int32_t max_iter;      /* 0 -> default 200                                            */
+    int32_t solver;        /* srx_pca_solver; 0 = auto (Gram when k <= 4096)              */
+    double  tol;           /* relative Ritz-residual tolerance; 0 -> default (1e-9 Gram /
+                              f64 storage, 1e-7 matrix-free SpMM with f32 storage)        */
     uint64_t seed;         /* start panel seed (the reference has no randomness here)     */
 } srx_pca_opts;
 
@@ -190,6 +199,8 @@ typedef struct srx_pca_info {
     uint32_t n_iter;       /* subspace iterations executed                                */
     double residual;       /* final max relative Ritz residual over the n_pc pairs        */
     uint64_t nnz_selected; /* non-zeros of the HVG-compacted CSR actually walked (local)  */
+    uint32_t solver;       /* srx_pca_solver actually used                                */
+    uint32_t reserved_;
 } srx_pca_info;
 
 /* sel: k feature indices in selection order (NULL = FeatureSelection::None, all genes).
@@ -209,12 +220,12 @@ int32_t srx_pca(srx_mat* m, const uint64_t* sel, uint64_t k, const srx_pca_opts*
 int32_t srx_pca_loadings(const double* components, const double* std_, const uint64_t* sel,
                          uint64_t k, uint64_t n_pc, uint64_t n_vars, double* out);
 
-/* The raw CSR x dense-panel operator the PCA is built from, for a caller-supplied 64-column
- * panel: y_out (n_rows x 64) = X[:, sel] * panel, t_out (k x 64) = X[:, sel]^T * y.  `sel` must
- * be strictly ascending; either output may be NULL; accumulate_f64 selects the f64 LDS
- * accumulators of the transposed product. */
+/* The raw operators the PCA is built from, for a caller-supplied 64-column panel (k x 64
+ * row-major): y_out (n_rows x 64) = X[:, sel] * panel, t_out (k x 64) = X[:, sel]^T * y, and
+ * gram_out (k x k) = X[:, sel]^T X[:, sel] (panel not needed).  `sel` must be strictly
+ * ascending; any output may be NULL. */
 int32_t srx_spmm(srx_mat* m, const uint64_t* sel, uint64_t k, const double* panel, double* y_out,
-                 double* t_out, int32_t accumulate_f64);
+                 double* t_out, double* gram_out);
 
 /* ---- fused pipeline: normalize_total_inplace(target, Row) -> log1p_transform_inplace ->
  * pca_inplace(n_pc, center, scale, .., HighlyVariable(n_hvg)) with every intermediate
@@ -240,7 +251,9 @@ typedef enum srx_kernel_class {
     SRX_K_COMPACT = 2,     /* HVG compaction                                              */
     SRX_K_SPMM_FWD = 3,    /* Y = X_sel P - 1 c^T                                         */
     SRX_K_SPMM_T = 4,      /* T = X_sel^T Y                                               */
-    SRX_K_COUNT_ = 5
+    SRX_K_GRAM = 5,        /* G = X_sel^T X_sel (sparse outer products into LDS tiles)     */
+    SRX_K_DENSE = 6,       /* dense k x k times k x 64 products of the Gram solver        */
+    SRX_K_COUNT_ = 7
 } srx_kernel_class;
 int32_t srx_prof_enable(srx_ctx* ctx, uint32_t class_mask);
 int32_t srx_prof_reset(srx_ctx* ctx);

@@ -22,7 +22,8 @@ STATUS_NAMES = {0: "SRX_OK", -1: "SRX_E_ARG", -2: "SRX_E_DTYPE", -3: "SRX_E_FORM
 I8, I16, I32, U8, U16, U32, F32, F64 = range(8)
 ROW, COLUMN = 0, 1
 STORE_AUTO, STORE_F32, STORE_F64 = 0, 1, 2
-K_NORMALIZE, K_MOMENTS, K_COMPACT, K_SPMM_FWD, K_SPMM_T = range(5)
+K_NORMALIZE, K_MOMENTS, K_COMPACT, K_SPMM_FWD, K_SPMM_T, K_GRAM, K_DENSE = range(7)
+SOLVER_AUTO, SOLVER_GRAM, SOLVER_SPMM = 0, 1, 2
 UNIQUE_ID_BYTES = 128
 
 
@@ -48,13 +49,13 @@ class MatInfo(C.Structure):
 class PcaOpts(C.Structure):
     _fields_ = [("n_components", C.c_int32), ("center", C.c_int32), ("scale", C.c_int32),
                 ("n_threads", C.c_int32), ("block", C.c_int32), ("max_iter", C.c_int32),
-                ("tol", C.c_double), ("seed", C.c_uint64)]
+                ("solver", C.c_int32), ("tol", C.c_double), ("seed", C.c_uint64)]
 
 
 class PcaInfo(C.Structure):
     _fields_ = [("n_cells_global", C.c_uint64), ("k", C.c_uint32), ("n_pc", C.c_uint32),
                 ("block", C.c_uint32), ("n_iter", C.c_uint32), ("residual", C.c_double),
-                ("nnz_selected", C.c_uint64)]
+                ("nnz_selected", C.c_uint64), ("solver", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 class PipelineResult(C.Structure):
@@ -103,7 +104,7 @@ _SIGS = {
     "srx_select_hvg": (C.c_int32, [P, C.c_uint64, P, C.POINTER(C.c_uint64)]),
     "srx_pca": (C.c_int32, [P, P, C.c_uint64, C.POINTER(PcaOpts), P, P, P, P, P, C.POINTER(PcaInfo)]),
     "srx_pca_loadings": (C.c_int32, [P, P, P, C.c_uint64, C.c_uint64, C.c_uint64, P]),
-    "srx_spmm": (C.c_int32, [P, P, C.c_uint64, P, P, P, C.c_int32]),
+    "srx_spmm": (C.c_int32, [P, P, C.c_uint64, P, P, P, P]),
     "srx_pipeline": (C.c_int32, [P, C.c_double, C.c_uint64, C.POINTER(PcaOpts), C.POINTER(PipelineResult)]),
     "srx_result_fetch": (C.c_int32, [P, P, P, P, P, P, P]),
     "srx_prof_enable": (C.c_int32, [P, C.c_uint32]),

@@ -4,23 +4,30 @@
 // runs a full SVD of the standardised copy (spec: src/shared/processing/pca/mod.rs:74-154).
 // Here the standardised matrix  Z = (X[:, sel] - c 1 mu^T) D   (c = center, D = diag(1/std)
 // when scale) is never formed.  The top eigenpairs of C = Z^T Z are found by block subspace
-// iteration with a Rayleigh–Ritz step, applying C through two sparse products per iteration:
+// iteration with a Rayleigh–Ritz step on a k x 64 block W; two ways of applying C:
 //
-//     forward     Y = Z W       = A (D W) - 1 (mu^T D W)          CSR x dense panel (SpMM)
-//     transposed  W' = Z^T Y    = D (A^T Y - c mu (1^T Y))        scatter form, LDS-privatised
+//  GRAM solver (default for k <= 4096)
+//     G = A^T A is accumulated ONCE, exactly, in f64: gene-tile pairs (128 x 128 f64 tiles in
+//     LDS), every cell contributing the outer product of its two tile segments through LDS
+//     atomics — N m^2/2 lane-atomics in total (m = non-zeros per cell among the k genes).
+//     C = D (G - c N mu mu^T) D is then a dense k x k matrix and every iteration is a dense
+//     (k x k)(k x 64) product.  Across row shards: ONE all-reduce of G.
+//  SPMM solver (matrix-free, any k)
+//     forward     Y  = Z W   = A (D W) - 1 (mu^T D W)        CSR x dense panel, panel in LDS
+//     transposed  W' = Z^T Y = D (A^T Y - c mu (1^T Y))      scatter form, LDS f64 atomics
+//     N m 64 lane-atomics PER ITERATION; across shards one all-reduce of the k x 64 block each.
 //
-// where A is the HVG-COMPACTED CSR (columns renumbered 0..k-1 in ascending gene order, so a
-// row stays sorted and a gene tile is one contiguous segment of every row).  Everything of
-// size k x l (l = 64 panel columns) is replicated per rank and kept in f64; across row shards
-// the only exchange per iteration is ONE all-reduce of the k x l block A^T Y (+ 1^T Y).
+// Either way the scores are one forward SpMM  Z V  (transform, pca/mod.rs:156-185).
+// A is the HVG-COMPACTED matrix in TILE-MAJOR layout (see below); everything of size k x 64 is
+// replicated per rank and kept in f64.
 //
-// Precision (measured in DESIGN.md): values and panel in f32, forward accumulate f32 (<= ~120
-// terms per row), transposed accumulate f64 — pure f32 stalls at ~2e-5 eigenvector error on
-// close eigenvalue pairs; f64 accumulation there reaches ~3e-6.
+// Measured on MI355X (profiles/r01_*): LDS f32 float atomics (ds_add_f32) run ~10x slower than
+// ds_add_f64, so every LDS accumulation here is f64; pure-f32 accumulation also stalls at ~2e-5
+// eigenvector error on close eigenvalue pairs, f64 accumulation reaches ~3e-6 with f32 values.
 //
-// Algorithmic bytes per launch:
-//   forward     nnz_w*(4+s_v) + (N+1)*8 + N*l*4 (write Y) + k*l*4 (panel)
-//   transposed  nnz_w*(4+s_v) + (N+1)*8 + N*l*4 (read Y)  + k*l*8 (result)
+// Algorithmic bytes per launch, s_v = bytes per stored value:
+//   forward     nnz_w*(4+s_v) + (n_t N+1)*8 + N*64*4 (write Y) + k*64*4 (panel)
+//   transposed  nnz_w*(4+s_v) + (n_t N+1)*8 + N*64*4 (read Y)  + k*64*8 (result)
 #include <algorithm>
 #include <cmath>
 #include <numeric>
@@ -31,7 +38,7 @@
 namespace srx {
 
 constexpr int L = 64;               // panel width l
-constexpr int kTThreads = 1024;     // transposed kernel: one workgroup per CU
+constexpr int kTThreads = 1024;     // transposed / Gram kernels: one workgroup per CU
 
 int32_t gene_variances(srx_mat* m, std::vector<double>& var);
 int32_t select_hvg_host(srx_ctx* ctx, const std::vector<double>& var, uint64_t n, std::vector<uint64_t>& out);
@@ -149,14 +156,17 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(const int64_t* __rest
 }
 
 // ---- tile-major layout of the compacted matrix --------------------------------------------------
-// The compacted N x k matrix is stored as n_t = ceil(k / 256) sub-matrices, one per GENE TILE
-// of KT = 256 compacted columns, back to back: sub-matrix t holds, row by row, the entries of
-// every cell that fall in columns [256 t, 256 t + 256), with LOCAL column indices 0..255 and
-// row pointers tptr[t*N + i].  A workgroup that owns (tile, row range) therefore streams ONE
-// contiguous index/value range, fully coalesced, instead of 9-entry pieces of 1.3M rows.
-// KT * 64 panel entries are exactly what LDS holds: 64 KiB as f32 (forward panel tile, two
-// workgroups per CU) or 128 KiB as f64 (transposed accumulators, one workgroup per CU).
+// The compacted N x k matrix is stored as n_t = ceil(k / kt) sub-matrices, one per GENE TILE of
+// kt compacted columns, back to back: sub-matrix t holds, row by row, the entries of every
+// cell that fall in columns [kt t, kt t + kt), with LOCAL column indices and row pointers
+// tptr[t*N + i].  A workgroup that owns (tile, row range) therefore streams ONE contiguous
+// index/value range, fully coalesced, instead of ~9-entry pieces of 1.3M rows.
+//   kt = 256 (KT)  SpMM kernels: 256 x 64 panel entries are what LDS holds — 64 KiB as f32
+//                  (forward panel tile, two workgroups per CU), 128 KiB as f64 (transposed
+//                  accumulators, one workgroup per CU);
+//   kt = 128 (KG)  Gram kernel: a 128 x 128 f64 tile of A^T A is 128 KiB.
 constexpr int KT = 256;
+constexpr int KG = 128;
 
 __global__ void k_seglen(const int64_t* __restrict__ indptr, const int64_t* __restrict__ tp, uint64_t n_rows, int nt,
                          int64_t* __restrict__ seglen) {
@@ -174,7 +184,7 @@ __global__ void k_seglen(const int64_t* __restrict__ indptr, const int64_t* __re
 template <typename T>
 __global__ __launch_bounds__(256) void k_retile(const int64_t* __restrict__ indptr, const int64_t* __restrict__ tp,
                                                 const int32_t* __restrict__ idx, const T* __restrict__ vals,
-                                                uint64_t n_rows, int nt, const int64_t* __restrict__ tptr,
+                                                uint64_t n_rows, int nt, int kt, const int64_t* __restrict__ tptr,
                                                 int32_t* __restrict__ tidx, T* __restrict__ tvals) {
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
@@ -183,10 +193,10 @@ __global__ __launch_bounds__(256) void k_retile(const int64_t* __restrict__ indp
         const int64_t lo = indptr[r], hi = indptr[r + 1];
         for (int64_t p = lo + lane; p < hi; p += kWave) {
             int32_t c = idx[p];
-            int t = c / KT;
+            int t = c / kt;
             int64_t seg_lo = t == 0 ? lo : tp[(uint64_t)(t - 1) * n_rows + r];
             int64_t dst = tptr[(uint64_t)t * n_rows + r] + (p - seg_lo);
-            tidx[dst] = c - t * KT;
+            tidx[dst] = c - t * kt;
             tvals[dst] = vals[p];
         }
     }
@@ -463,6 +473,144 @@ __global__ void k_t_reduce(const AT* __restrict__ part, const double* __restrict
     }
 }
 
+// ---- explicit sparse Gram: G = A^T A, one 128 x 128 f64 tile per workgroup --------------------------
+// Workgroup = (gene-tile pair (a <= b), row block); LDS holds the 128 x 128 f64 tile.  A wave
+// takes 64 consecutive cells: their tile-a entries are one contiguous range (coalesced load,
+// one entry per lane); the lane finds the cell of its entry by a 6-step shuffle search over the
+// 64 row ends, then walks that cell's tile-b segment and adds va*vb at (ja, jb) with an LDS f64
+// atomic.  Diagonal pairs compute the full tile.  Per-(row block, pair) partial tiles are summed
+// in fixed order by k_gram_reduce.
+template <typename VT>
+__global__ __launch_bounds__(kTThreads) void k_gram_sparse(const int64_t* __restrict__ tptr,
+                                                           const int32_t* __restrict__ tidx,
+                                                           const VT* __restrict__ tvals, uint64_t n_rows, int ntg,
+                                                           uint64_t rows_per_block, int n_pairs,
+                                                           double* __restrict__ part) {
+    extern __shared__ double lds_raw[];
+    double* acc = lds_raw;
+    for (int e = threadIdx.x; e < KG * KG; e += kTThreads) acc[e] = 0.0;
+    __syncthreads();
+    const int pair = blockIdx.x % n_pairs;
+    const uint64_t rb = blockIdx.x / n_pairs;
+    int a = 0, rem = pair;
+    while (rem >= ntg - a) { rem -= ntg - a; ++a; }
+    const int b = a + rem;
+    const uint64_t r0 = rb * rows_per_block;
+    const uint64_t r1 = r0 + rows_per_block < n_rows ? r0 + rows_per_block : n_rows;
+    const int64_t* pa = tptr + (uint64_t)a * n_rows;
+    const int64_t* pb = tptr + (uint64_t)b * n_rows;
+    const int lane = lane_id();
+    const int wave = threadIdx.x / kWave;
+    constexpr int kWaves = kTThreads / kWave;
+    for (uint64_t rr = r0 + (uint64_t)wave * kWave; rr < r1; rr += (uint64_t)kWaves * kWave) {
+        const int nb = (int)(r1 - rr < (uint64_t)kWave ? r1 - rr : (uint64_t)kWave);
+        const int l0 = lane < nb ? lane : nb, l1 = lane + 1 < nb ? lane + 1 : nb;
+        const int64_t a0 = pa[rr];                                   // wave-uniform
+        const int ea = (int)(pa[rr + l1] - a0);                      // end of my row, relative
+        const int64_t sb = pb[rr + l0];
+        const int lenb = (int)(pb[rr + l1] - sb);
+        const int total_a = (int)(pa[rr + nb] - a0);
+        for (int cb = 0; cb < total_a; cb += kWave) {
+            const int e = cb + lane;
+            const bool valid = e < total_a;
+            // row of entry e = number of rows whose end is <= e (ends are non-decreasing over lanes)
+            int row = 0;
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const int probe = __shfl(ea, row + step - 1, kWave);
+                if (probe <= e) row += step;
+            }
+            // every shuffle runs with all 64 lanes active: a ds_bpermute only sees data of ACTIVE
+            // source lanes, so none of them may sit behind the `valid` predicate
+            const int64_t sbr = __shfl(sb, row, kWave);
+            const int lb_row = __shfl(lenb, row, kWave);
+            const int ec = valid ? e : 0;                               // clamped: loads stay unconditional
+            const int ja = tidx[a0 + ec];
+            const double va = valid ? (double)tvals[a0 + ec] : 0.0;
+            const int lb = valid ? lb_row : 0;
+            for (int w = 0; __any(w < lb); ++w) {
+                if (w < lb) {
+                    const int jb = tidx[sbr + w];
+                    const double vb = (double)tvals[sbr + w];
+                    __hip_atomic_fetch_add(&acc[ja * KG + jb], va * vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    double* out = part + (rb * (uint64_t)n_pairs + pair) * (uint64_t)(KG * KG);
+    for (int e = threadIdx.x; e < KG * KG; e += kTThreads) out[e] = acc[e];
+}
+
+// Graw (k x k, both triangles) = sum over row blocks of the partial tiles.
+__global__ void k_gram_reduce(const double* __restrict__ part, uint64_t n_rb, int n_pairs, int ntg, int k,
+                              double* __restrict__ G) {
+    const int pair = blockIdx.y;
+    int a = 0, rem = pair;
+    while (rem >= ntg - a) { rem -= ntg - a; ++a; }
+    const int b = a + rem;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= KG * KG) return;
+    const int ja = a * KG + e / KG, jb = b * KG + e % KG;
+    if (ja >= k || jb >= k) return;
+    if (a == b && jb < ja) return;            // diagonal tiles: take the upper triangle, mirror it
+    double s = 0.0;
+    for (uint64_t r = 0; r < n_rb; ++r) s += part[(r * (uint64_t)n_pairs + pair) * (uint64_t)(KG * KG) + e];
+    G[(size_t)ja * k + jb] = s;
+    G[(size_t)jb * k + ja] = s;
+}
+
+// C = D (G - cen * N mu mu^T) D, in place.
+__global__ void k_gram_finish(double* __restrict__ G, const double* __restrict__ d, const double* __restrict__ mu, int k,
+                              int cen, double n_cells) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (uint64_t)k * k) return;
+    int i = (int)(e / k), j = (int)(e % k);
+    double g = G[e];
+    if (cen) g -= n_cells * mu[i] * mu[j];
+    G[e] = d[i] * d[j] * g;
+}
+
+// Wp = C W for the dense symmetric k x k matrix C and a k x 64 block (f64).  32 x 64 outputs per
+// 256-thread workgroup (2 rows x 4 columns per thread), K staged through LDS 32 at a time.
+__global__ __launch_bounds__(256) void k_dense_apply(const double* __restrict__ C, const double* __restrict__ W, int k,
+                                                     double* __restrict__ Wp) {
+    constexpr int BM = 32, BK = 32;
+    __shared__ double sC[BM][BK + 1];
+    __shared__ double sW[BK][L];
+    const int row0 = blockIdx.x * BM;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c0 = 4 * tx;
+    double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int k0 = 0; k0 < k; k0 += BK) {
+        for (int e = threadIdx.x; e < BM * BK; e += 256) {
+            int r = e / BK, c = e % BK;
+            sC[r][c] = (row0 + r < k && k0 + c < k) ? C[(size_t)(row0 + r) * k + k0 + c] : 0.0;
+        }
+        for (int e = threadIdx.x; e < BK * L; e += 256) {
+            int r = e / L, c = e % L;
+            sW[r][c] = (k0 + r < k) ? W[(size_t)(k0 + r) * L + c] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < BK; ++kk) {
+            const double a0 = sC[ty][kk], a1 = sC[ty + 16][kk];
+            const double b0 = sW[kk][c0], b1 = sW[kk][c0 + 1], b2 = sW[kk][c0 + 2], b3 = sW[kk][c0 + 3];
+            acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[0][2] += a0 * b2; acc[0][3] += a0 * b3;
+            acc[1][0] += a1 * b0; acc[1][1] += a1 * b1; acc[1][2] += a1 * b2; acc[1][3] += a1 * b3;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int r = row0 + ty + 16 * u;
+        if (r < k) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Wp[(size_t)r * L + c0 + v] = acc[u][v];
+        }
+    }
+}
+
 // ---- k x l helper kernels (f64, replicated per rank) --------------------------------------------
 // P = PT(d .* W * sign), cvec = cen * mu^T P (exact f64 sum of the ROUNDED panel, so Y's column
 // sums vanish to rounding).
@@ -498,18 +646,23 @@ __global__ void k_finish_t(const double* __restrict__ T, const double* __restric
     Wp[e] = d[j] * (T[e] - (cen ? mu[j] * s : 0.0));
 }
 
-// H = A^T B, G = B^T B for two k x 64 blocks; single workgroup, rows staged through LDS.
-__global__ __launch_bounds__(1024) void k_gram2(const double* __restrict__ A, const double* __restrict__ B, int k,
-                                                double* __restrict__ H, double* __restrict__ G) {
+// H = A^T B, G = B^T B for two k x 64 blocks (f64).  Each workgroup reduces a slice of the k rows
+// (staged through LDS) into a partial 64 x 64 pair; k_gram2_reduce sums the slices in fixed order.
+constexpr int kGram2Blocks = 32;
+__global__ __launch_bounds__(1024) void k_gram2_part(const double* __restrict__ A, const double* __restrict__ B, int k,
+                                                     double* __restrict__ part /* [blocks][2][64*64] */) {
     constexpr int R = 32;
     __shared__ double sa[R][L], sb[R][L];
     double h[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0};
     const int b = threadIdx.x & (L - 1), a0 = threadIdx.x / L;    // entries (a0 + 16u, b), u < 4
-    for (int j0 = 0; j0 < k; j0 += R) {
+    const int rows_per = (k + gridDim.x - 1) / gridDim.x;
+    const int jb0 = blockIdx.x * rows_per;
+    const int jb1 = jb0 + rows_per < k ? jb0 + rows_per : k;
+    for (int j0 = jb0; j0 < jb1; j0 += R) {
         for (int e = threadIdx.x; e < R * L; e += 1024) {
             int j = j0 + e / L;
-            sa[e / L][e % L] = j < k ? A[(size_t)j * L + (e % L)] : 0.0;
-            sb[e / L][e % L] = j < k ? B[(size_t)j * L + (e % L)] : 0.0;
+            sa[e / L][e % L] = j < jb1 ? A[(size_t)j * L + (e % L)] : 0.0;
+            sb[e / L][e % L] = j < jb1 ? B[(size_t)j * L + (e % L)] : 0.0;
         }
         __syncthreads();
 #pragma unroll 4
@@ -523,11 +676,19 @@ __global__ __launch_bounds__(1024) void k_gram2(const double* __restrict__ A, co
         }
         __syncthreads();
     }
+    double* out = part + (size_t)blockIdx.x * 2 * L * L;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        H[(a0 + 16 * u) * L + b] = h[u];
-        G[(a0 + 16 * u) * L + b] = g[u];
+        out[(a0 + 16 * u) * L + b] = h[u];
+        out[L * L + (a0 + 16 * u) * L + b] = g[u];
     }
+}
+__global__ void k_gram2_reduce(const double* __restrict__ part, int n_blocks, double* __restrict__ HG /* 2*64*64 */) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * L * L) return;
+    double s = 0.0;
+    for (int b = 0; b < n_blocks; ++b) s += part[(size_t)b * 2 * L * L + e];
+    HG[e] = s;
 }
 
 // Out = In * M  (k x 64 times 64 x 64), M row-major.
@@ -587,10 +748,17 @@ __global__ void k_scores(const YT* __restrict__ Y, uint64_t n_rows, int n_pc, do
     }
 }
 
-// ---- compacted, tile-major matrix -----------------------------------------------------------------
+// ---- compacted matrix: row-major CSR first, then tile-major views of it ----------------------------
+struct CompactCsr {
+    uint64_t n_rows = 0, nnz = 0;
+    int k = 0;
+    int64_t* indptr = nullptr;
+    int32_t* idx = nullptr;
+    void* vals = nullptr;
+};
 struct Tiled {
     uint64_t n_rows = 0, nnz = 0;
-    int k = 0, nt = 0;
+    int k = 0, kt = 0, nt = 0;
     int64_t* tptr = nullptr;   // nt * n_rows + 1
     int32_t* tidx = nullptr;   // local column within the tile
     void* tvals = nullptr;
@@ -603,7 +771,7 @@ static int grid_rows(const srx_ctx* ctx, uint64_t n_rows, int rows_per_block) {
     return (int)(want < cap ? want : cap);
 }
 
-// out[0..n] = exclusive scan of in[0..n), out[n] = total (also returned through *total_dev).
+// out[0..n] = exclusive scan of in[0..n), out[n] = total (also left in *total_dev).
 static int32_t scan_exclusive(srx_ctx* ctx, const int64_t* d_in, uint64_t n, int64_t* d_out, int64_t** total_dev) {
     const uint64_t per_block = (uint64_t)kScanBlock * kScanItems;
     const uint64_t nb = (n + per_block - 1) / per_block > 0 ? (n + per_block - 1) / per_block : 1;
@@ -619,67 +787,78 @@ static int32_t scan_exclusive(srx_ctx* ctx, const int64_t* d_in, uint64_t n, int
     return SRX_OK;
 }
 
-// X[:, sel] -> row-major compacted CSR (count, scan, fill) -> tile-major (cut, scan, copy).
-static int32_t build_tiled(srx_mat* m, const std::vector<int32_t>& remap, int k, Tiled& c) {
+// X[:, sel] -> row-major compacted CSR (count, scan, fill); columns renumbered by `remap`.
+static int32_t build_compact(srx_mat* m, const std::vector<int32_t>& remap, int k, CompactCsr& c) {
     srx_ctx* ctx = m->ctx;
     const uint64_t N = m->n_rows;
-    int32_t *d_remap, *c_idx;
-    int64_t *d_counts, *c_indptr, *d_total;
-    void* c_vals;
+    int32_t* d_remap;
+    int64_t *d_counts, *d_total;
     SRX_TRY(scratch(ctx, "pca_remap", (remap.size() ? remap.size() : 1) * sizeof(int32_t), (void**)&d_remap));
     SRX_TRY(h2d(ctx, d_remap, remap.data(), remap.size() * sizeof(int32_t)));
     SRX_TRY(scratch(ctx, "pca_counts", (N ? N : 1) * sizeof(int64_t), (void**)&d_counts));
-    SRX_TRY(scratch(ctx, "pca_cindptr", (N + 1) * sizeof(int64_t), (void**)&c_indptr));
+    SRX_TRY(scratch(ctx, "pca_cindptr", (N + 1) * sizeof(int64_t), (void**)&c.indptr));
     const double in_bytes = (double)m->nnz * 4.0 * 2.0 + (double)(N + 1) * 8.0 * 2.0;   // idx read by count + fill
     ProfScope ps(ctx, SRX_K_COMPACT, in_bytes);
     hipLaunchKernelGGL(k_compact_count, dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream, m->d_indptr,
                        m->d_indices, d_remap, N, d_counts);
-    SRX_TRY(scan_exclusive(ctx, d_counts, N, c_indptr, &d_total));
+    SRX_TRY(scan_exclusive(ctx, d_counts, N, c.indptr, &d_total));
     int64_t total = 0;
     SRX_TRY(d2h(ctx, &total, d_total, sizeof(int64_t)));
     c.nnz = (uint64_t)total;
     c.n_rows = N;
     c.k = k;
-    c.nt = (k + KT - 1) / KT;
     const size_t vb = val_bytes(m);
-    SRX_TRY(scratch(ctx, "pca_cidx", (c.nnz ? c.nnz : 1) * sizeof(int32_t), (void**)&c_idx));
-    SRX_TRY(scratch(ctx, "pca_cvals", (c.nnz ? c.nnz : 1) * vb, &c_vals));
+    SRX_TRY(scratch(ctx, "pca_cidx", (c.nnz ? c.nnz : 1) * sizeof(int32_t), (void**)&c.idx));
+    SRX_TRY(scratch(ctx, "pca_cvals", (c.nnz ? c.nnz : 1) * vb, &c.vals));
     if (is_f32(m))
         hipLaunchKernelGGL((k_compact_fill<float>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream, m->d_indptr,
-                           m->d_indices, (const float*)m->d_values, d_remap, N, c_indptr, c_idx, (float*)c_vals);
+                           m->d_indices, (const float*)m->d_values, d_remap, N, c.indptr, c.idx, (float*)c.vals);
     else
         hipLaunchKernelGGL((k_compact_fill<double>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream,
-                           m->d_indptr, m->d_indices, (const double*)m->d_values, d_remap, N, c_indptr, c_idx,
-                           (double*)c_vals);
+                           m->d_indptr, m->d_indices, (const double*)m->d_values, d_remap, N, c.indptr, c.idx,
+                           (double*)c.vals);
     SRX_HIP(ctx, hipGetLastError());
-    // tile cuts of every compacted row, segment lengths, their scan = tile-major row pointers
+    if (ctx->prof_mask & (1u << SRX_K_COMPACT)) ctx->prof[SRX_K_COMPACT].bytes += (double)c.nnz * (4.0 + vb);
+    return SRX_OK;
+}
+
+// Tile-major copy of a compacted CSR for gene tiles of kt columns (cut, scan, copy).
+static int32_t retile(srx_mat* m, const CompactCsr& c, int kt, Tiled& t) {
+    srx_ctx* ctx = m->ctx;
+    const uint64_t N = c.n_rows;
+    const size_t vb = val_bytes(m);
+    const std::string tag = "pca_t" + std::to_string(kt) + "_";
+    t.n_rows = N;
+    t.nnz = c.nnz;
+    t.k = c.k;
+    t.kt = kt;
+    t.nt = (c.k + kt - 1) / kt;
     int64_t* d_tp = nullptr;
-    if (c.nt > 1) {
-        SRX_TRY(scratch(ctx, "pca_tp", (size_t)(c.nt - 1) * (N ? N : 1) * sizeof(int64_t), (void**)&d_tp));
-        SRX_TRY(launch_tile_ptr(ctx, c_indptr, c_idx, N, c.nt, KT, d_tp));
+    if (t.nt > 1) {
+        SRX_TRY(scratch(ctx, "pca_tp", (size_t)(t.nt - 1) * (N ? N : 1) * sizeof(int64_t), (void**)&d_tp));
+        SRX_TRY(launch_tile_ptr(ctx, c.indptr, c.idx, N, t.nt, kt, d_tp));
     }
-    const uint64_t nseg = (uint64_t)c.nt * N;
+    const uint64_t nseg = (uint64_t)t.nt * N;
     int64_t* d_seglen;
     SRX_TRY(scratch(ctx, "pca_seglen", (nseg ? nseg : 1) * sizeof(int64_t), (void**)&d_seglen));
-    SRX_TRY(scratch(ctx, "pca_tptr", (nseg + 1) * sizeof(int64_t), (void**)&c.tptr));
+    SRX_TRY(scratch(ctx, (tag + "ptr").c_str(), (nseg + 1) * sizeof(int64_t), (void**)&t.tptr));
     uint64_t g = (nseg + 255) / 256;
     if (g < 1) g = 1;
     if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(k_seglen, dim3((unsigned)g), dim3(256), 0, ctx->stream, c_indptr, d_tp, N, c.nt, d_seglen);
-    SRX_TRY(scan_exclusive(ctx, d_seglen, nseg, c.tptr, nullptr));
-    SRX_TRY(scratch(ctx, "pca_tidx", (c.nnz + 64) * sizeof(int32_t), (void**)&c.tidx));   // +64: unconditional 16-wide reads
-    SRX_HIP(ctx, hipMemsetAsync(c.tidx + c.nnz, 0, 64 * sizeof(int32_t), ctx->stream));
-    SRX_TRY(scratch(ctx, "pca_tvals", (c.nnz + 64) * vb, &c.tvals));
-    SRX_HIP(ctx, hipMemsetAsync((char*)c.tvals + c.nnz * vb, 0, 64 * vb, ctx->stream));
+    hipLaunchKernelGGL(k_seglen, dim3((unsigned)g), dim3(256), 0, ctx->stream, c.indptr, d_tp, N, t.nt, d_seglen);
+    SRX_TRY(scan_exclusive(ctx, d_seglen, nseg, t.tptr, nullptr));
+    // +64 entries of padding: the forward kernel reads 16-wide chunks unconditionally
+    SRX_TRY(scratch(ctx, (tag + "idx").c_str(), (c.nnz + 64) * sizeof(int32_t), (void**)&t.tidx));
+    SRX_TRY(scratch(ctx, (tag + "vals").c_str(), (c.nnz + 64) * vb, &t.tvals));
+    SRX_HIP(ctx, hipMemsetAsync(t.tidx + c.nnz, 0, 64 * sizeof(int32_t), ctx->stream));
+    SRX_HIP(ctx, hipMemsetAsync((char*)t.tvals + c.nnz * vb, 0, 64 * vb, ctx->stream));
     if (is_f32(m))
-        hipLaunchKernelGGL((k_retile<float>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream, c_indptr, d_tp,
-                           c_idx, (const float*)c_vals, N, c.nt, c.tptr, c.tidx, (float*)c.tvals);
+        hipLaunchKernelGGL((k_retile<float>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream, c.indptr, d_tp, c.idx,
+                           (const float*)c.vals, N, t.nt, kt, t.tptr, t.tidx, (float*)t.tvals);
     else
-        hipLaunchKernelGGL((k_retile<double>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream, c_indptr, d_tp,
-                           c_idx, (const double*)c_vals, N, c.nt, c.tptr, c.tidx, (double*)c.tvals);
+        hipLaunchKernelGGL((k_retile<double>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream, c.indptr, d_tp,
+                           c.idx, (const double*)c.vals, N, t.nt, kt, t.tptr, t.tidx, (double*)t.tvals);
     SRX_HIP(ctx, hipGetLastError());
-    if (ctx->prof_mask & (1u << SRX_K_COMPACT))
-        ctx->prof[SRX_K_COMPACT].bytes += (double)c.nnz * (4.0 + vb) * 4.0;   // write + read + write of the kept entries
     return SRX_OK;
 }
 
@@ -704,40 +883,63 @@ static int32_t launch_fwd(srx_ctx* ctx, const Tiled& c, const PT* P, const PT* c
     return SRX_OK;
 }
 
-template <typename VT, typename YT, typename AT>
+template <typename VT, typename YT>
 static int32_t launch_t(srx_ctx* ctx, const Tiled& c, const YT* Y, double* T /* k*L + L */) {
-    const bool a32 = sizeof(AT) == 4;
     uint64_t want = (uint64_t)(2 * ctx->n_cus) / (uint64_t)c.nt;
     if (want < 1) want = 1;
     uint64_t by_rows = (c.n_rows + 255) / 256;
     if (by_rows < 1) by_rows = 1;
     const uint64_t n_rb = want < by_rows ? want : by_rows;
     const uint64_t rpb = (c.n_rows + n_rb - 1) / n_rb > 0 ? (c.n_rows + n_rb - 1) / n_rb : 1;
-    AT* part;
-    double* part_s;
-    SRX_TRY(scratch(ctx, a32 ? "pca_tpart32" : "pca_tpart64", n_rb * (size_t)c.k * L * sizeof(AT), (void**)&part));
+    double *part, *part_s;
+    SRX_TRY(scratch(ctx, "pca_tpart", n_rb * (size_t)c.k * L * sizeof(double), (void**)&part));
     SRX_TRY(scratch(ctx, "pca_tpart_s", n_rb * L * sizeof(double), (void**)&part_s));
-    const size_t lds = (size_t)KT * L * sizeof(AT);
+    const size_t lds = (size_t)KT * L * sizeof(double);
     const double bytes = (double)c.nnz * (4.0 + sizeof(VT)) + (double)((uint64_t)c.nt * c.n_rows + 1) * 8.0 +
                          (double)c.n_rows * L * sizeof(YT) + (double)c.k * L * 8.0;
     {
         ProfScope ps(ctx, SRX_K_SPMM_T, bytes);
-        SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_spmm_t<VT, YT, AT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)lds));
-        hipLaunchKernelGGL((k_spmm_t<VT, YT, AT>), dim3((unsigned)(n_rb * c.nt)), dim3(kTThreads), lds, ctx->stream,
+        SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_spmm_t<VT, YT, double>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_spmm_t<VT, YT, double>), dim3((unsigned)(n_rb * c.nt)), dim3(kTThreads), lds, ctx->stream,
                            c.tptr, c.tidx, (const VT*)c.tvals, c.n_rows, c.k, c.nt, rpb, Y, part, part_s);
         uint64_t tot = (uint64_t)c.k * L + L;
-        hipLaunchKernelGGL((k_t_reduce<AT>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, part, part_s,
-                           c.k, n_rb, T);
+        hipLaunchKernelGGL((k_t_reduce<double>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, part,
+                           part_s, c.k, n_rb, T);
     }
     SRX_HIP(ctx, hipGetLastError());
     return SRX_OK;
 }
 
+// G (k x k, raw A^T A summed over ranks) from the 128-tiled matrix.
+template <typename VT>
+static int32_t launch_gram(srx_ctx* ctx, const Tiled& g, double* G) {
+    const int ntg = g.nt;
+    const int n_pairs = ntg * (ntg + 1) / 2;
+    uint64_t n_rb = ((uint64_t)ctx->n_cus * 8 + n_pairs - 1) / n_pairs;      // ~8 workgroups per CU in total
+    uint64_t by_rows = (g.n_rows + 1023) / 1024;
+    if (by_rows < 1) by_rows = 1;
+    if (n_rb > by_rows) n_rb = by_rows;
+    if (n_rb < 1) n_rb = 1;
+    const uint64_t rpb = (g.n_rows + n_rb - 1) / n_rb > 0 ? (g.n_rows + n_rb - 1) / n_rb : 1;
+    double* part;
+    SRX_TRY(scratch(ctx, "pca_gpart", n_rb * (size_t)n_pairs * KG * KG * sizeof(double), (void**)&part));
+    const size_t lds = (size_t)KG * KG * sizeof(double);
+    // algorithmic bytes: every 128-tile is walked once per tile pair it belongs to (n_t + 1 pairs)
+    ProfScope ps(ctx, SRX_K_GRAM, ((double)g.nnz * (4.0 + sizeof(VT)) + (double)ntg * g.n_rows * 8.0) * (ntg + 1) / 2.0 +
+                                      (double)g.k * g.k * 8.0);
+    SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_sparse<VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_gram_sparse<VT>), dim3((unsigned)(n_rb * n_pairs)), dim3(kTThreads), lds, ctx->stream, g.tptr,
+                       g.tidx, (const VT*)g.tvals, g.n_rows, ntg, rpb, n_pairs, part);
+    hipLaunchKernelGGL(k_gram_reduce, dim3((KG * KG + 255) / 256, n_pairs), dim3(256), 0, ctx->stream, part, n_rb, n_pairs,
+                       ntg, g.k, G);
+    SRX_HIP(ctx, hipGetLastError());
+    return SRX_OK;
+}
 
 // ---- the driver ---------------------------------------------------------------------------------
 struct Resolved {
-    int n_pc, center, scale, max_iter;
+    int n_pc, center, scale, max_iter, solver;
     double tol;
     uint64_t seed;
 };
@@ -749,36 +951,49 @@ static uint64_t mix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 
-template <typename VT, typename PT>
-static int32_t run_subspace(srx_mat* m, const Tiled& c, const Resolved& o, const std::vector<double>& mu,
-                            const std::vector<double>& dinv, int l_act, srx_pca_state& st) {
-    srx_ctx* ctx = m->ctx;
-    const int k = c.k;
-    const size_t kl = (size_t)k * L;
-    double *W, *Wp, *T, *A1, *A2, *small, *d_mu, *d_d;
-    PT *P, *cvec, *Y;
-    SRX_TRY(scratch(ctx, "pca_W", kl * 8, (void**)&W));
-    SRX_TRY(scratch(ctx, "pca_Wp", kl * 8, (void**)&Wp));
-    SRX_TRY(scratch(ctx, "pca_T", (kl + L) * 8, (void**)&T));
-    SRX_TRY(scratch(ctx, "pca_A1", kl * 8, (void**)&A1));
-    SRX_TRY(scratch(ctx, "pca_A2", kl * 8, (void**)&A2));
-    SRX_TRY(scratch(ctx, "pca_small", (6 * L * L + 8 * L) * 8, (void**)&small));
-    SRX_TRY(scratch(ctx, "pca_mu", (size_t)k * 8, (void**)&d_mu));
-    SRX_TRY(scratch(ctx, "pca_d", (size_t)k * 8, (void**)&d_d));
-    SRX_TRY(scratch(ctx, "pca_P", (kl + L) * sizeof(PT), (void**)&P));
-    cvec = P + kl;
-    SRX_TRY(scratch(ctx, "pca_Y", (c.n_rows ? c.n_rows : 1) * (size_t)L * sizeof(PT), (void**)&Y));
-    double* dH = small;                 // L x L
-    double* dG = small + L * L;         // L x L
-    double* dM = small + 2 * L * L;     // L x L   (Rinv or U)
-    double* dM2 = small + 3 * L * L;    // L x L
-    double* dTheta = small + 4 * L * L; // L
-    double* dRho = dTheta + L;          // L
-    double* dColmax = dRho + L;         // L
-    double* dSgn = dColmax + L;         // L
-    SRX_TRY(h2d(ctx, d_mu, mu.data(), (size_t)k * 8));
-    SRX_TRY(h2d(ctx, d_d, dinv.data(), (size_t)k * 8));
+struct Work {                   // k x 64 f64 state, replicated per rank
+    double *W, *Wp, *T, *A1, *A2, *small, *mu, *d, *gpart;
+    double *dHG, *dM, *dM2, *dTheta, *dRho, *dColmax, *dSgn;
+};
 
+static int32_t alloc_work(srx_ctx* ctx, int k, Work& w) {
+    const size_t kl = (size_t)k * L;
+    SRX_TRY(scratch(ctx, "pca_W", kl * 8, (void**)&w.W));
+    SRX_TRY(scratch(ctx, "pca_Wp", kl * 8, (void**)&w.Wp));
+    SRX_TRY(scratch(ctx, "pca_T", (kl + L) * 8, (void**)&w.T));
+    SRX_TRY(scratch(ctx, "pca_A1", kl * 8, (void**)&w.A1));
+    SRX_TRY(scratch(ctx, "pca_A2", kl * 8, (void**)&w.A2));
+    SRX_TRY(scratch(ctx, "pca_small", (6 * L * L + 8 * L) * 8, (void**)&w.small));
+    SRX_TRY(scratch(ctx, "pca_mu", (size_t)k * 8, (void**)&w.mu));
+    SRX_TRY(scratch(ctx, "pca_d", (size_t)k * 8, (void**)&w.d));
+    SRX_TRY(scratch(ctx, "pca_g2part", (size_t)kGram2Blocks * 2 * L * L * 8, (void**)&w.gpart));
+    w.dHG = w.small;                    // H then G, contiguous 2 x L x L
+    w.dM = w.small + 2 * L * L;
+    w.dM2 = w.small + 3 * L * L;
+    w.dTheta = w.small + 4 * L * L;
+    w.dRho = w.dTheta + L;
+    w.dColmax = w.dRho + L;
+    w.dSgn = w.dColmax + L;
+    return SRX_OK;
+}
+
+static int32_t gram2(srx_ctx* ctx, const Work& w, const double* A, const double* B, int k) {
+    int nb = (k + 63) / 64;
+    if (nb > kGram2Blocks) nb = kGram2Blocks;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_gram2_part, dim3(nb), dim3(1024), 0, ctx->stream, A, B, k, w.gpart);
+    hipLaunchKernelGGL(k_gram2_reduce, dim3((2 * L * L + 255) / 256), dim3(256), 0, ctx->stream, w.gpart, nb, w.dHG);
+    SRX_HIP(ctx, hipGetLastError());
+    return SRX_OK;
+}
+
+// Block subspace iteration with Rayleigh–Ritz on span(W); `apply(W, Wp)` computes Wp = C W.
+// On return w.A2 = W U holds the Ritz vectors (k x 64, leading n_pc columns meaningful),
+// theta their Ritz values, w.dColmax the largest-|.| entry of each Ritz vector.
+template <typename Apply>
+static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, const Resolved& o, Apply&& apply,
+                                std::vector<double>& theta, double& resid, int& iters, bool& converged) {
+    const size_t kl = (size_t)k * L;
     // start block: counter-based N(0,1) entries (deterministic in (seed, gene slot, column))
     std::vector<double> hW(kl, 0.0);
     for (int j = 0; j < k; ++j)
@@ -789,101 +1004,141 @@ static int32_t run_subspace(srx_mat* m, const Tiled& c, const Resolved& o, const
             double u2 = ((double)(h2 >> 11) + 0.5) / 9007199254740992.0;
             hW[(size_t)j * L + cc] = std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
         }
-    SRX_TRY(h2d(ctx, Wp, hW.data(), kl * 8));
+    SRX_TRY(h2d(ctx, w.Wp, hW.data(), kl * 8));
 
-    std::vector<double> hH(L * L), hG(L * L), hHG(2 * L * L), hM(L * L), hU(L * L), hTheta(L), hRho(L), hColmax(L);
-    std::vector<double> act(l_act * l_act), ev(l_act), evec((size_t)l_act * l_act);
+    std::vector<double> hHG(2 * L * L), hM(L * L), hU(L * L), hRho(L);
+    std::vector<double> act((size_t)l_act * l_act), ev(l_act), evec((size_t)l_act * l_act);
+    theta.assign(L, 0.0);
+    double* hG = hHG.data() + L * L;
 
     // orthonormalise Wp -> W  (CholeskyQR: G = Wp^T Wp = R^T R, W = Wp R^-1)
     auto orth = [&](bool have_gram) -> int32_t {
         if (!have_gram) {
-            hipLaunchKernelGGL(k_gram2, dim3(1), dim3(1024), 0, ctx->stream, Wp, Wp, k, dH, dG);
-            SRX_HIP(ctx, hipGetLastError());
-            SRX_TRY(d2h(ctx, hG.data(), dG, L * L * 8));
+            SRX_TRY(gram2(ctx, w, w.Wp, w.Wp, k));
+            SRX_TRY(d2h(ctx, hHG.data(), w.dHG, 2 * L * L * 8));
         }
-        if (!smallmat::chol_upper_inverse(l_act, L, hG.data(), hM.data()))
-            return fail(ctx, SRX_E_NOCONV, "pca: block lost rank (Cholesky pivot <= 0); k_eff < block?");
-        SRX_TRY(h2d(ctx, dM, hM.data(), L * L * 8));
-        hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, Wp, dM, k, W);
+        if (!smallmat::chol_upper_inverse(l_act, L, hG, hM.data()))
+            return fail(ctx, SRX_E_NOCONV, "pca: block lost rank (Cholesky pivot <= 0)");
+        SRX_TRY(h2d(ctx, w.dM, hM.data(), L * L * 8));
+        hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.Wp, w.dM, k, w.W);
         SRX_HIP(ctx, hipGetLastError());
         return SRX_OK;
     };
     SRX_TRY(orth(false));
-    // CholeskyQR2 on the random start (condition of a Gaussian block is mild, once more is cheap)
-    SRX_HIP(ctx, hipMemcpyAsync(Wp, W, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    SRX_TRY(orth(false));
+    SRX_HIP(ctx, hipMemcpyAsync(w.Wp, w.W, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    SRX_TRY(orth(false));              // CholeskyQR2 on the random start
 
-    const int n_pc = o.n_pc;
-    bool accurate = sizeof(PT) == 8;    // f64 path accumulates in f64 from the start
-    double resid = INFINITY;
-    int it = 0;
-    bool converged = false;
-    for (it = 1; it <= o.max_iter; ++it) {
-        // forward: Y = Z W
-        hipLaunchKernelGGL((k_make_panel<PT>), dim3(1), dim3(1024), 0, ctx->stream, W, d_d, d_mu, (const double*)nullptr,
-                           k, o.center, P, cvec);
-        SRX_HIP(ctx, hipGetLastError());
-        SRX_TRY((launch_fwd<VT, PT>(ctx, c, P, cvec, Y)));
-        // transposed: T = A^T Y, s = 1^T Y; f32 accumulators while far from converged
-        if (accurate) SRX_TRY((launch_t<VT, PT, double>(ctx, c, Y, T)));
-        else SRX_TRY((launch_t<VT, PT, float>(ctx, c, Y, T)));
-        SRX_TRY(allreduce_f64(ctx, T, kl + L));       // the one exchange per iteration
-        hipLaunchKernelGGL(k_finish_t, dim3((unsigned)((kl + 255) / 256)), dim3(256), 0, ctx->stream, T, d_d, d_mu, k,
-                           o.center, Wp);
+    resid = INFINITY;
+    converged = false;
+    for (iters = 1; iters <= o.max_iter; ++iters) {
+        SRX_TRY(apply(w.W, w.Wp));
         // Rayleigh–Ritz on span(W): H = W^T C W, and G = (CW)^T (CW) for the next CholeskyQR
-        hipLaunchKernelGGL(k_gram2, dim3(1), dim3(1024), 0, ctx->stream, W, Wp, k, dH, dG);
-        SRX_HIP(ctx, hipGetLastError());
-        SRX_TRY(d2h(ctx, hHG.data(), dH, 2 * L * L * 8));   // dH and dG are contiguous
-        std::copy(hHG.begin(), hHG.begin() + L * L, hH.begin());
-        std::copy(hHG.begin() + L * L, hHG.end(), hG.begin());
+        SRX_TRY(gram2(ctx, w, w.W, w.Wp, k));
+        SRX_TRY(d2h(ctx, hHG.data(), w.dHG, 2 * L * L * 8));
         for (int a = 0; a < l_act; ++a)
-            for (int b = 0; b < l_act; ++b) act[(size_t)a * l_act + b] = hH[a * L + b];
+            for (int b = 0; b < l_act; ++b) act[(size_t)a * l_act + b] = hHG[a * L + b];
         if (!smallmat::sym_eig_desc(l_act, act.data(), ev.data(), evec.data()))
             return fail(ctx, SRX_E_NOCONV, "pca: l x l eigen-solver did not converge");
         std::fill(hU.begin(), hU.end(), 0.0);
-        std::fill(hTheta.begin(), hTheta.end(), 0.0);
+        std::fill(theta.begin(), theta.end(), 0.0);
         for (int a = 0; a < l_act; ++a) {
-            hTheta[a] = ev[a];
+            theta[a] = ev[a];
             for (int b = 0; b < l_act; ++b) hU[a * L + b] = evec[(size_t)a * l_act + b];
         }
         // residuals || C v_i - theta_i v_i || with v_i = W u_i, evaluated on the device in f64
-        SRX_TRY(h2d(ctx, dM2, hU.data(), L * L * 8));
-        SRX_TRY(h2d(ctx, dTheta, hTheta.data(), L * 8));
-        hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, Wp, dM2, k, A1);
-        hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, W, dM2, k, A2);
-        hipLaunchKernelGGL(k_col_resid, dim3(1), dim3(1024), 0, ctx->stream, A1, A2, dTheta, k, dRho, dColmax);
+        SRX_TRY(h2d(ctx, w.dM2, hU.data(), L * L * 8));
+        SRX_TRY(h2d(ctx, w.dTheta, theta.data(), L * 8));
+        hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.Wp, w.dM2, k, w.A1);
+        hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.W, w.dM2, k, w.A2);
+        hipLaunchKernelGGL(k_col_resid, dim3(1), dim3(1024), 0, ctx->stream, w.A1, w.A2, w.dTheta, k, w.dRho, w.dColmax);
         SRX_HIP(ctx, hipGetLastError());
-        SRX_TRY(d2h(ctx, hRho.data(), dRho, L * 8));
+        SRX_TRY(d2h(ctx, hRho.data(), w.dRho, L * 8));
         resid = 0.0;
-        for (int i = 0; i < n_pc; ++i) {
-            double r = hTheta[i] > 0 ? hRho[i] / hTheta[i] : hRho[i];
+        for (int i = 0; i < o.n_pc; ++i) {
+            double r = theta[i] > 0 ? hRho[i] / theta[i] : hRho[i];
             if (!(r <= resid)) resid = r;   // NaN propagates
         }
         if (resid != resid) return fail(ctx, SRX_E_NOCONV, "pca: NaN in the Ritz residual");
-        if (resid <= o.tol && accurate) { converged = true; break; }
-        if (!accurate && resid <= 1e-3) accurate = true;   // last digits need f64 accumulation
+        if (resid <= o.tol) { converged = true; break; }
         SRX_TRY(orth(true));
     }
-    if (!converged) it = o.max_iter;
+    if (!converged) iters = o.max_iter;
+    return SRX_OK;
+}
 
-    // A2 = W U are the Ritz vectors (sorted-gene row order); sign: largest-|.| entry positive
-    SRX_TRY(d2h(ctx, hColmax.data(), dColmax, L * 8));
-    std::vector<double> sgn(L, 1.0);
+template <typename VT, typename PT>
+static int32_t run_pca(srx_mat* m, const CompactCsr& cc, const Resolved& o, const std::vector<double>& mu,
+                       const std::vector<double>& dinv, int l_act, double n_cells, srx_pca_state& st) {
+    srx_ctx* ctx = m->ctx;
+    const int k = cc.k;
+    const size_t kl = (size_t)k * L;
+    Work w;
+    SRX_TRY(alloc_work(ctx, k, w));
+    SRX_TRY(h2d(ctx, w.mu, mu.data(), (size_t)k * 8));
+    SRX_TRY(h2d(ctx, w.d, dinv.data(), (size_t)k * 8));
+    Tiled t256;
+    SRX_TRY(retile(m, cc, KT, t256));
+    PT *P, *cvec, *Y;
+    SRX_TRY(scratch(ctx, "pca_P", (kl + L) * sizeof(PT), (void**)&P));
+    cvec = P + kl;
+    SRX_TRY(scratch(ctx, "pca_Y", (cc.n_rows ? cc.n_rows : 1) * (size_t)L * sizeof(PT), (void**)&Y));
+
+    std::vector<double> theta;
+    double resid = INFINITY;
+    int iters = 0;
+    bool converged = false;
+    if (o.solver == 1) {
+        // explicit Gram: G = A^T A once (all-reduced), C = D (G - c N mu mu^T) D dense
+        Tiled t128;
+        SRX_TRY(retile(m, cc, KG, t128));
+        double* C;
+        SRX_TRY(scratch(ctx, "pca_C", (size_t)k * k * 8, (void**)&C));
+        SRX_TRY(launch_gram<VT>(ctx, t128, C));
+        SRX_TRY(allreduce_f64(ctx, C, (size_t)k * k));            // the one exchange of this solver
+        hipLaunchKernelGGL(k_gram_finish, dim3((unsigned)(((size_t)k * k + 255) / 256)), dim3(256), 0, ctx->stream, C,
+                           w.d, w.mu, k, o.center, n_cells);
+        SRX_HIP(ctx, hipGetLastError());
+        auto apply = [&](const double* Win, double* Wout) -> int32_t {
+            ProfScope ps(ctx, SRX_K_DENSE, (double)k * k * 8.0 + 2.0 * k * L * 8.0);
+            hipLaunchKernelGGL(k_dense_apply, dim3((k + 31) / 32), dim3(256), 0, ctx->stream, C, Win, k, Wout);
+            SRX_HIP(ctx, hipGetLastError());
+            return SRX_OK;
+        };
+        SRX_TRY(subspace_iterate(ctx, w, k, l_act, o, apply, theta, resid, iters, converged));
+    } else {
+        auto apply = [&](const double* Win, double* Wout) -> int32_t {
+            hipLaunchKernelGGL((k_make_panel<PT>), dim3(1), dim3(1024), 0, ctx->stream, Win, w.d, w.mu,
+                               (const double*)nullptr, k, o.center, P, cvec);
+            SRX_HIP(ctx, hipGetLastError());
+            SRX_TRY((launch_fwd<VT, PT>(ctx, t256, P, cvec, Y)));
+            SRX_TRY((launch_t<VT, PT>(ctx, t256, Y, w.T)));
+            SRX_TRY(allreduce_f64(ctx, w.T, kl + L));             // the one exchange per iteration
+            hipLaunchKernelGGL(k_finish_t, dim3((unsigned)((kl + 255) / 256)), dim3(256), 0, ctx->stream, w.T, w.d, w.mu,
+                               k, o.center, Wout);
+            SRX_HIP(ctx, hipGetLastError());
+            return SRX_OK;
+        };
+        SRX_TRY(subspace_iterate(ctx, w, k, l_act, o, apply, theta, resid, iters, converged));
+    }
+
+    // A2 = W U are the Ritz vectors (ascending-gene row order); sign: largest-|.| entry positive
+    const int n_pc = o.n_pc;
+    std::vector<double> hColmax(L), sgn(L, 1.0), hV(kl);
+    SRX_TRY(d2h(ctx, hColmax.data(), w.dColmax, L * 8));
     for (int i = 0; i < L; ++i) sgn[i] = hColmax[i] < 0 ? -1.0 : 1.0;
-    SRX_TRY(h2d(ctx, dSgn, sgn.data(), L * 8));
-    std::vector<double> hV(kl);
-    SRX_TRY(d2h(ctx, hV.data(), A2, kl * 8));
+    SRX_TRY(h2d(ctx, w.dSgn, sgn.data(), L * 8));
+    SRX_TRY(d2h(ctx, hV.data(), w.A2, kl * 8));
     st.components.assign((size_t)k * n_pc, 0.0);
     for (int j = 0; j < k; ++j)
         for (int i = 0; i < n_pc; ++i) st.components[(size_t)j * n_pc + i] = hV[(size_t)j * L + i] * sgn[i];
-    st.evr.assign(hTheta.begin(), hTheta.begin() + n_pc);   // eigenvalues of Z^T Z, normalised by the caller
+    st.evr.assign(theta.begin(), theta.begin() + n_pc);     // eigenvalues of Z^T Z, normalised by the caller
 
-    // scores = Z V  (transform, pca/mod.rs:156-185): one more forward SpMM with the panel D V
-    hipLaunchKernelGGL((k_make_panel<PT>), dim3(1), dim3(1024), 0, ctx->stream, A2, d_d, d_mu, (const double*)dSgn, k,
+    // scores = Z V  (transform, pca/mod.rs:156-185): one forward SpMM with the panel D V
+    hipLaunchKernelGGL((k_make_panel<PT>), dim3(1), dim3(1024), 0, ctx->stream, w.A2, w.d, w.mu, (const double*)w.dSgn, k,
                        o.center, P, cvec);
     SRX_HIP(ctx, hipGetLastError());
-    SRX_TRY((launch_fwd<VT, PT>(ctx, c, P, cvec, Y)));
-    const size_t need = (c.n_rows ? c.n_rows : 1) * (size_t)n_pc * 8;
+    SRX_TRY((launch_fwd<VT, PT>(ctx, t256, P, cvec, Y)));
+    const size_t need = (cc.n_rows ? cc.n_rows : 1) * (size_t)n_pc * 8;
     if (st.scores_cap < need) {
         if (st.d_scores) SRX_HIP(ctx, hipFree(st.d_scores));
         st.d_scores = nullptr;
@@ -891,13 +1146,13 @@ static int32_t run_subspace(srx_mat* m, const Tiled& c, const Resolved& o, const
         SRX_HIP(ctx, hipMalloc((void**)&st.d_scores, need));
         st.scores_cap = need;
     }
-    uint64_t tot = c.n_rows * (uint64_t)n_pc;
+    uint64_t tot = cc.n_rows * (uint64_t)n_pc;
     uint64_t g = (tot + 255) / 256;
     if (g < 1) g = 1;
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL((k_scores<PT>), dim3((unsigned)g), dim3(256), 0, ctx->stream, Y, c.n_rows, n_pc, st.d_scores);
+    hipLaunchKernelGGL((k_scores<PT>), dim3((unsigned)g), dim3(256), 0, ctx->stream, Y, cc.n_rows, n_pc, st.d_scores);
     SRX_HIP(ctx, hipGetLastError());
-    st.info.n_iter = (uint32_t)it;
+    st.info.n_iter = (uint32_t)iters;
     st.info.residual = resid;
     if (!converged)
         return fail(ctx, SRX_E_NOCONV, "pca: subspace iteration stopped at max_iter=%d with residual %.3e > tol %.3e",
@@ -926,9 +1181,15 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     o.n_pc = std::min(want, k);
     o.center = (!opts || opts->center < 0) ? 1 : (opts->center != 0);           // :55
     o.scale = (!opts || opts->scale < 0) ? 1 : (opts->scale != 0);              // :56
-    o.max_iter = (opts && opts->max_iter > 0) ? opts->max_iter : 100;
-    o.tol = (opts && opts->tol > 0) ? opts->tol : 1e-7;
+    o.max_iter = (opts && opts->max_iter > 0) ? opts->max_iter : 200;
+    o.tol = (opts && opts->tol > 0) ? opts->tol : 0.0;
     o.seed = opts ? opts->seed : 0;
+    o.solver = opts ? opts->solver : 0;
+    if (o.solver < 0 || o.solver > 2) return fail(ctx, SRX_E_ARG, "pca: solver must be 0 (auto), 1 (gram) or 2 (spmm)");
+    if (o.solver == 0) o.solver = k <= 4096 ? 1 : 2;
+    if (o.solver == 1 && k > 16384) return fail(ctx, SRX_E_ARG, "pca: the Gram solver holds a k x k f64 matrix; k=%d is too large", k);
+    // default tolerance on the relative Ritz residual: what the arithmetic of the solver supports
+    if (o.tol == 0.0) o.tol = (o.solver == 1 || !is_f32(m)) ? 1e-9 : 1e-7;
     if (o.n_pc < 1) return fail(ctx, SRX_E_ARG, "pca: n_components must be >= 1");
     if (opts && opts->block != 0 && opts->block != L) return fail(ctx, SRX_E_ARG, "pca: only block = %d is built", L);
     const int l_act = std::min(L, k);
@@ -975,17 +1236,18 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     std::vector<double> mu_eff = mu;
     if (!o.center) std::fill(mu_eff.begin(), mu_eff.end(), 0.0);
 
-    Tiled c;
-    SRX_TRY(build_tiled(m, remap, k, c));
+    CompactCsr cc;
+    SRX_TRY(build_compact(m, remap, k, cc));
     st.info = srx_pca_info{};
     st.info.n_cells_global = Ng;
     st.info.k = (uint32_t)k;
     st.info.n_pc = (uint32_t)o.n_pc;
     st.info.block = L;
-    st.info.nnz_selected = c.nnz;
+    st.info.nnz_selected = cc.nnz;
+    st.info.solver = (uint32_t)o.solver;
     int32_t rc;
-    if (is_f32(m)) rc = run_subspace<float, float>(m, c, o, mu_eff, dinv, l_act, st);
-    else rc = run_subspace<double, double>(m, c, o, mu_eff, dinv, l_act, st);
+    if (is_f32(m)) rc = run_pca<float, float>(m, cc, o, mu_eff, dinv, l_act, Nd, st);
+    else rc = run_pca<double, double>(m, cc, o, mu_eff, dinv, l_act, Nd, st);
     if (rc != SRX_OK && rc != SRX_E_NOCONV) return rc;
 
     // back to selection order; explained variance ratio = eig/total with eig = theta/(N-1),
@@ -1040,12 +1302,13 @@ int32_t srx_pca(srx_mat* m, const uint64_t* sel, uint64_t k, const srx_pca_opts*
     return rc2 != SRX_OK ? rc2 : rc;
 }
 
-// Kernel-level entry point: Y = X[:, sel] * P and T = X[:, sel]^T * Y for a caller-supplied
-// 64-column panel (no centring / scaling).  Exists so the two SpMM kernels can be checked
-// against the CPU oracle in isolation, and as the raw CSR x dense-panel operator.
+// Kernel-level entry point: Y = X[:, sel] * P, T = X[:, sel]^T * Y and G = X[:, sel]^T X[:, sel]
+// for a caller-supplied 64-column panel (no centring / scaling).  Exists so the SpMM and Gram
+// kernels can be checked against a CPU reference in isolation, and as the raw operators.
 int32_t srx_spmm(srx_mat* m, const uint64_t* sel, uint64_t k64, const double* panel, double* y_out, double* t_out,
-                 int32_t accumulate_f64) {
-    if (!m || !sel || !panel) return fail(m ? m->ctx : nullptr, SRX_E_ARG, "null argument");
+                 double* gram_out) {
+    if (!m || !sel) return fail(m ? m->ctx : nullptr, SRX_E_ARG, "null argument");
+    if ((y_out || t_out) && !panel) return fail(m->ctx, SRX_E_ARG, "srx_spmm: panel is required for y/t");
     srx_ctx* ctx = m->ctx;
     SRX_HIP(ctx, hipSetDevice(ctx->device));
     const int k = (int)k64;
@@ -1056,30 +1319,41 @@ int32_t srx_spmm(srx_mat* m, const uint64_t* sel, uint64_t k64, const double* pa
         if (s > 0 && sel[s] <= sel[s - 1]) return fail(ctx, SRX_E_ARG, "srx_spmm: sel must be strictly ascending");
         remap[sel[s]] = s;
     }
-    Tiled c;
-    SRX_TRY(build_tiled(m, remap, k, c));
+    CompactCsr cc;
+    SRX_TRY(build_compact(m, remap, k, cc));
     const size_t kl = (size_t)k * L;
     double* T;
     SRX_TRY(scratch(ctx, "pca_T", (kl + L) * 8, (void**)&T));
     auto run = [&](auto vt, auto pt) -> int32_t {
         using VT = decltype(vt);
         using PT = decltype(pt);
-        PT *P, *Y;
-        SRX_TRY(scratch(ctx, "pca_P", (kl + L) * sizeof(PT), (void**)&P));
-        SRX_TRY(scratch(ctx, "pca_Y", (c.n_rows ? c.n_rows : 1) * (size_t)L * sizeof(PT), (void**)&Y));
-        std::vector<PT> hp(kl + L, PT(0));
-        for (size_t e = 0; e < kl; ++e) hp[e] = (PT)panel[e];
-        SRX_TRY(h2d(ctx, P, hp.data(), (kl + L) * sizeof(PT)));
-        SRX_TRY((launch_fwd<VT, PT>(ctx, c, P, P + kl, Y)));
-        if (y_out) {
-            std::vector<PT> hy(c.n_rows * (size_t)L);
-            SRX_TRY(d2h(ctx, hy.data(), Y, hy.size() * sizeof(PT)));
-            for (size_t e = 0; e < hy.size(); ++e) y_out[e] = (double)hy[e];
+        if (y_out || t_out) {
+            Tiled c;
+            SRX_TRY(retile(m, cc, KT, c));
+            PT *P, *Y;
+            SRX_TRY(scratch(ctx, "pca_P", (kl + L) * sizeof(PT), (void**)&P));
+            SRX_TRY(scratch(ctx, "pca_Y", (c.n_rows ? c.n_rows : 1) * (size_t)L * sizeof(PT), (void**)&Y));
+            std::vector<PT> hp(kl + L, PT(0));
+            for (size_t e = 0; e < kl; ++e) hp[e] = (PT)panel[e];
+            SRX_TRY(h2d(ctx, P, hp.data(), (kl + L) * sizeof(PT)));
+            SRX_TRY((launch_fwd<VT, PT>(ctx, c, P, P + kl, Y)));
+            if (y_out) {
+                std::vector<PT> hy(c.n_rows * (size_t)L);
+                SRX_TRY(d2h(ctx, hy.data(), Y, hy.size() * sizeof(PT)));
+                for (size_t e = 0; e < hy.size(); ++e) y_out[e] = (double)hy[e];
+            }
+            if (t_out) {
+                SRX_TRY((launch_t<VT, PT>(ctx, c, Y, T)));
+                SRX_TRY(d2h(ctx, t_out, T, kl * 8));
+            }
         }
-        if (t_out) {
-            if (accumulate_f64 || sizeof(PT) == 8) SRX_TRY((launch_t<VT, PT, double>(ctx, c, Y, T)));
-            else SRX_TRY((launch_t<VT, PT, float>(ctx, c, Y, T)));
-            SRX_TRY(d2h(ctx, t_out, T, kl * 8));
+        if (gram_out) {
+            Tiled g;
+            SRX_TRY(retile(m, cc, KG, g));
+            double* C;
+            SRX_TRY(scratch(ctx, "pca_C", (size_t)k * k * 8, (void**)&C));
+            SRX_TRY(launch_gram<VT>(ctx, g, C));
+            SRX_TRY(d2h(ctx, gram_out, C, (size_t)k * k * 8));
         }
         return SRX_OK;
     };

@@ -41,7 +41,7 @@ def select_features(adata: IMAnnData, feature_selection) -> np.ndarray:
 
 def pca_inplace(adata: IMAnnData, n_components=None, center=None, scale=None, n_threads=None,
                 feature_selection=FeatureSelection.None_, svd_mode=None, *, block=0, max_iter=0, tol=0.0,
-                seed=0, store_loadings=False) -> F.PcaInfo:
+                seed=0, store_loadings=False, solver=0) -> F.PcaInfo:
     """dim_red/mod.rs:24-94.  Stores obsm["X_pca"] (n_obs x n_pc f64), the only output the
     reference keeps (:105-106); with store_loadings also varm["PCA_loadings"] in the layout
     of :108-118.  ``svd_mode`` (FaerSVD / LapackSVD marker) is accepted and ignored: the GPU
@@ -53,7 +53,7 @@ def pca_inplace(adata: IMAnnData, n_components=None, center=None, scale=None, n_
                      -1 if center is None else int(bool(center)),
                      -1 if scale is None else int(bool(scale)),
                      -1 if n_threads is None else int(n_threads),
-                     int(block), int(max_iter), float(tol), int(seed))
+                     int(block), int(max_iter), int(solver), float(tol), int(seed))
     n = adata.n_obs()
     scores = np.zeros((n, n_pc), dtype=np.float64)
     comps = np.zeros((k, n_pc), dtype=np.float64)
@@ -65,7 +65,8 @@ def pca_inplace(adata: IMAnnData, n_components=None, center=None, scale=None, n_
                             F.ptr(evr), F.ptr(mean), F.ptr(std), C.byref(info)), adata.x().ctx.handle)
     adata.obsm["X_pca"] = scores                                                # :105-106
     adata.uns["pca"] = {"components": comps, "explained_variance_ratio": evr, "mean": mean, "std": std,
-                        "selected_features": sel, "n_iter": info.n_iter, "residual": info.residual}
+                        "selected_features": sel, "n_iter": info.n_iter, "residual": info.residual,
+                        "solver": info.solver}
     if store_loadings:                                                          # :108-118
         full = np.zeros((adata.n_vars(), n_pc), dtype=np.float64)
         F.check(F.lib().srx_pca_loadings(F.ptr(comps), F.ptr(std), F.ptr(sel), k, n_pc, adata.n_vars(),
