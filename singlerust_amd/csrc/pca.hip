@@ -202,6 +202,136 @@ __global__ __launch_bounds__(256) void k_retile(const int64_t* __restrict__ indp
     }
 }
 
+// ---- fused HVG compaction straight into the tile-major layouts (<= 64 tiles of 128) ----------------
+// Pass 1 (k_tcount): per cell, the number of kept entries in each 128-column tile (and, summed in
+// pairs, in each 256-column tile).  Kept entries of a row are sorted by compacted column, so the
+// tiles present in a 64-entry chunk are found with a short ballot-match loop; lane t of the wave
+// is the counter of tile t.  Pass 2 (k_tfill) re-reads the row and scatters every kept entry to
+//   tptr[tile*N + i] + (rank of the entry among the row's kept entries - kept entries in earlier tiles)
+// in BOTH layouts.  The scans of the counts in between give tptr.
+// Membership + compacted column of a gene WITHOUT a G-entry remap table in L2 (a 4-byte gather per
+// non-zero drags a 64-byte line each: 70 GB of L2 traffic at c3): the selection is a bitmask
+// (G/32 words) plus the number of selected genes before each word, both staged in LDS (7 KB at
+// G = 28k); column = prefix[w] + popcount(bits[w] below the gene's bit).
+struct SelLds {
+    const uint32_t* bits;
+    const uint32_t* prefix;
+    __device__ __forceinline__ int column(int32_t gene) const {
+        const uint32_t w = bits[gene >> 5];
+        const uint32_t bit = 1u << (gene & 31);
+        return (w & bit) ? (int)(prefix[gene >> 5] + __popc(w & (bit - 1u))) : -1;
+    }
+};
+__device__ __forceinline__ SelLds stage_selection(const uint32_t* __restrict__ g_bits,
+                                                  const uint32_t* __restrict__ g_prefix, int n_words, uint32_t* lds) {
+    for (int e = threadIdx.x; e < n_words; e += blockDim.x) {
+        lds[e] = g_bits[e];
+        lds[n_words + e] = g_prefix[e];
+    }
+    __syncthreads();
+    return SelLds{lds, lds + n_words};
+}
+
+constexpr int kCompactUnroll = 4;    // 64-entry chunks of a row in flight per wave
+
+__global__ __launch_bounds__(256) void k_tcount(const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx,
+                                                const uint32_t* __restrict__ g_bits,
+                                                const uint32_t* __restrict__ g_prefix, int n_words, uint64_t n_rows,
+                                                int nt128, int nt256, int64_t* __restrict__ cnt128,
+                                                int64_t* __restrict__ cnt256) {
+    extern __shared__ double lds_raw[];
+    const SelLds sel = stage_selection(g_bits, g_prefix, n_words, reinterpret_cast<uint32_t*>(lds_raw));
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
+    const int lane = lane_id();
+    for (uint64_t r = wave; r < n_rows; r += n_waves) {
+        const int64_t lo = indptr[r], hi = indptr[r + 1];
+        int cnt = 0;                                    // lane t: kept entries of this row in tile t
+        for (int64_t base = lo; base < hi; base += kCompactUnroll * kWave) {
+            int32_t g[kCompactUnroll];
+#pragma unroll
+            for (int u = 0; u < kCompactUnroll; ++u) {
+                const int64_t p = base + u * kWave + lane;
+                g[u] = p < hi ? idx[p] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < kCompactUnroll; ++u) {
+                const int tile = g[u] >= 0 ? (sel.column(g[u]) >> 7) : -1;     // -1 for dropped entries
+                unsigned long long rem = __ballot(tile >= 0);
+                while (rem) {
+                    const int leader = __ffsll((long long)rem) - 1;
+                    const int tv = __builtin_amdgcn_readlane(tile, leader);
+                    const unsigned long long mt = __ballot(tile == tv);
+                    if (lane == tv) cnt += __popcll(mt);
+                    rem &= ~mt;
+                }
+            }
+        }
+        if (lane < nt128) cnt128[(uint64_t)lane * n_rows + r] = cnt;
+        const int pair = cnt + __shfl_xor(cnt, 1, kWave);      // lanes 2T and 2T+1 both hold the 256-tile count
+        if (lane < 2 * nt256 && !(lane & 1)) cnt256[(uint64_t)(lane >> 1) * n_rows + r] = pair;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_tfill(const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx,
+                                               const T* __restrict__ vals, const uint32_t* __restrict__ g_bits,
+                                               const uint32_t* __restrict__ g_prefix, int n_words, uint64_t n_rows,
+                                               int nt128, int nt256, const int64_t* __restrict__ cnt128,
+                                               const int64_t* __restrict__ tptr128,
+                                               const int64_t* __restrict__ tptr256, int32_t* __restrict__ tidx128,
+                                               T* __restrict__ tvals128, int32_t* __restrict__ tidx256,
+                                               T* __restrict__ tvals256) {
+    extern __shared__ double lds_raw[];
+    const SelLds sel = stage_selection(g_bits, g_prefix, n_words, reinterpret_cast<uint32_t*>(lds_raw));
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
+    const int lane = lane_id();
+    for (uint64_t r = wave; r < n_rows; r += n_waves) {
+        const int64_t lo = indptr[r], hi = indptr[r + 1];
+        // lane t: kept entries before tile t in this row (exclusive prefix over the tile counters)
+        const int c_t = lane < nt128 ? (int)cnt128[(uint64_t)lane * n_rows + r] : 0;
+        int inc = c_t;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const int o = __shfl_up(inc, off, kWave);
+            if (lane >= off) inc += o;
+        }
+        const int before128 = inc - c_t;
+        const int before256 = __shfl(before128, (2 * lane) & 63, kWave);     // lane T: before 256-tile T
+        // destination bias of each tile: tptr - (kept entries before the tile)
+        const int64_t off128 = (lane < nt128 ? tptr128[(uint64_t)lane * n_rows + r] : 0) - before128;
+        const int64_t off256 = (lane < nt256 ? tptr256[(uint64_t)lane * n_rows + r] : 0) - before256;
+        int rank0 = 0;                                  // kept entries of the row before this chunk
+        for (int64_t base = lo; base < hi; base += kCompactUnroll * kWave) {
+            int32_t g[kCompactUnroll];
+#pragma unroll
+            for (int u = 0; u < kCompactUnroll; ++u) {
+                const int64_t p = base + u * kWave + lane;
+                g[u] = p < hi ? idx[p] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < kCompactUnroll; ++u) {
+                const int64_t p = base + u * kWave + lane;
+                const int32_t c = g[u] >= 0 ? sel.column(g[u]) : -1;
+                const unsigned long long mask = __ballot(c >= 0);
+                const int cc = c >= 0 ? c : 0;
+                const int64_t o128 = __shfl(off128, cc >> 7, kWave);   // shuffles run with all lanes active
+                const int64_t o256 = __shfl(off256, cc >> 8, kWave);
+                if (c >= 0) {
+                    const int rank = rank0 + __popcll(mask & ((1ull << lane) - 1ull));
+                    const T v = vals[p];
+                    tidx128[o128 + rank] = c & 127;
+                    tvals128[o128 + rank] = v;
+                    tidx256[o256 + rank] = c & 255;
+                    tvals256[o256 + rank] = v;
+                }
+                rank0 += __popcll(mask);
+            }
+        }
+    }
+}
+
 // ---- small vector helpers ------------------------------------------------------------------------
 template <typename PT> struct Vec4;
 template <> struct Vec4<float> {
@@ -315,6 +445,23 @@ __device__ __forceinline__ void fwd_stage(const int32_t* __restrict__ gidx, cons
     }
 }
 
+// Entries 16.. of row H (and, recursively, of the rows after it) for the groups that have them.
+template <typename VT, typename PT, int kRows, int H>
+__device__ __forceinline__ void fwd_overflow(const int32_t* __restrict__ gidx, const VT* __restrict__ gvals, int la,
+                                             int le, int q, const PT* __restrict__ panel_q, PT (&acc)[kRows][4]) {
+    if constexpr (H < kRows) {
+        const int lo = __shfl(la, H, 16);
+        const int hi = (H + 1 < 16) ? __shfl(la, (H + 1) & 15, 16) : le;
+        for (int c = 16; __any(hi - lo > c); c += 16) {
+            const int p = lo + c + q;
+            const int ci = gidx[p] * L;
+            const PT v = (PT)gvals[p];
+            FwdRot<PT, 0>::run(ci, p < hi ? v : PT(0), panel_q, acc[H]);
+        }
+        fwd_overflow<VT, PT, kRows, H + 1>(gidx, gvals, la, le, q, panel_q, acc);
+    }
+}
+
 template <typename VT, typename PT>
 __global__ __launch_bounds__(kFwdThreads, FwdCfg<PT>::kWavesPerSimd) void k_spmm_fwd(
     const int64_t* __restrict__ tptr, const int32_t* __restrict__ tidx, const VT* __restrict__ tvals, uint64_t n_rows,
@@ -359,10 +506,10 @@ __global__ __launch_bounds__(kFwdThreads, FwdCfg<PT>::kWavesPerSimd) void k_spmm
             const int len = q < kRows ? (q + 1 < kRows ? nxt : le) - la : 0;
             const int32_t* gidx = tidx + p0;
             const VT* gvals = tvals + p0;
-            for (int c = 0;; c += 16) {
-                fwd_stage<VT, PT, kRows, kStage, 0>(gidx, gvals, la, le, c, q, panel_q, acc);
-                if (!__any(len > c + 16)) break;     // wave-uniform: some segment longer than 16 entries
-            }
+            fwd_stage<VT, PT, kRows, kStage, 0>(gidx, gvals, la, le, 0, q, panel_q, acc);
+            // segments longer than 16 entries are rare (~1 % of rows at m/k*256 = 9): finish them row by
+            // row instead of sending the whole wave through another 16-row pass
+            if (__any(len > 16)) fwd_overflow<VT, PT, kRows, 0>(gidx, gvals, la, le, q, panel_q, acc);
         }
 #pragma unroll
         for (int r = 0; r < kRows; ++r) {
@@ -480,6 +627,7 @@ __global__ void k_t_reduce(const AT* __restrict__ part, const double* __restrict
 // 64 row ends, then walks that cell's tile-b segment and adds va*vb at (ja, jb) with an LDS f64
 // atomic.  Diagonal pairs compute the full tile.  Per-(row block, pair) partial tiles are summed
 // in fixed order by k_gram_reduce.
+constexpr int kGramB = 8;
 template <typename VT>
 __global__ __launch_bounds__(kTThreads) void k_gram_sparse(const int64_t* __restrict__ tptr,
                                                            const int32_t* __restrict__ tidx,
@@ -528,11 +676,23 @@ __global__ __launch_bounds__(kTThreads) void k_gram_sparse(const int64_t* __rest
             const int ja = tidx[a0 + ec];
             const double va = valid ? (double)tvals[a0 + ec] : 0.0;
             const int lb = valid ? lb_row : 0;
-            for (int w = 0; __any(w < lb); ++w) {
-                if (w < lb) {
-                    const int jb = tidx[sbr + w];
-                    const double vb = (double)tvals[sbr + w];
-                    __hip_atomic_fetch_add(&acc[ja * KG + jb], va * vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // tile-b entries of the lane's cell, kGramB at a time: all loads of a round are issued
+            // together (clamped addresses, no branch), then the predicated LDS atomics
+            for (int base = 0; __any(base < lb); base += kGramB) {
+                int jb[kGramB];
+                VT vb[kGramB];
+#pragma unroll
+                for (int u = 0; u < kGramB; ++u) {
+                    const int w = base + u;
+                    const int64_t q = sbr + (w < lb ? w : 0);
+                    jb[u] = tidx[q];
+                    vb[u] = tvals[q];
+                }
+#pragma unroll
+                for (int u = 0; u < kGramB; ++u) {
+                    if (base + u < lb)
+                        __hip_atomic_fetch_add(&acc[ja * KG + jb[u]], va * (double)vb[u], __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
@@ -571,42 +731,56 @@ __global__ void k_gram_finish(double* __restrict__ G, const double* __restrict__
     G[e] = d[i] * d[j] * g;
 }
 
-// Wp = C W for the dense symmetric k x k matrix C and a k x 64 block (f64).  32 x 64 outputs per
-// 256-thread workgroup (2 rows x 4 columns per thread), K staged through LDS 32 at a time.
+// Wp += C[:, krange] W[krange, :] for the dense symmetric k x k matrix C and a k x 64 block (f64).
+// Workgroup = (64-row block, K split): 64 x 64 outputs, 4 x 4 per thread, K staged through LDS 32
+// at a time; the K splits are combined with f64 global atomics into the zeroed Wp (split-K keeps
+// all 256 CUs busy on a matrix that only has k/64 = 32 row blocks).
+constexpr int kDenseSplit = 8;
 __global__ __launch_bounds__(256) void k_dense_apply(const double* __restrict__ C, const double* __restrict__ W, int k,
                                                      double* __restrict__ Wp) {
-    constexpr int BM = 32, BK = 32;
+    constexpr int BM = 64, BK = 32;
     __shared__ double sC[BM][BK + 1];
     __shared__ double sW[BK][L];
     const int row0 = blockIdx.x * BM;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int c0 = 4 * tx;
-    double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    for (int k0 = 0; k0 < k; k0 += BK) {
+    const int kchunk = (((k + kDenseSplit - 1) / kDenseSplit) + BK - 1) / BK * BK;
+    const int kbeg = blockIdx.y * kchunk;
+    const int kend = kbeg + kchunk < k ? kbeg + kchunk : k;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;     // columns 4tx..4tx+3, rows ty + 16u
+    double acc[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
         for (int e = threadIdx.x; e < BM * BK; e += 256) {
             int r = e / BK, c = e % BK;
-            sC[r][c] = (row0 + r < k && k0 + c < k) ? C[(size_t)(row0 + r) * k + k0 + c] : 0.0;
+            sC[r][c] = (row0 + r < k && k0 + c < kend) ? C[(size_t)(row0 + r) * k + k0 + c] : 0.0;
         }
         for (int e = threadIdx.x; e < BK * L; e += 256) {
             int r = e / L, c = e % L;
-            sW[r][c] = (k0 + r < k) ? W[(size_t)(k0 + r) * L + c] : 0.0;
+            sW[r][c] = (k0 + r < kend) ? W[(size_t)(k0 + r) * L + c] : 0.0;
         }
         __syncthreads();
 #pragma unroll 8
         for (int kk = 0; kk < BK; ++kk) {
-            const double a0 = sC[ty][kk], a1 = sC[ty + 16][kk];
-            const double b0 = sW[kk][c0], b1 = sW[kk][c0 + 1], b2 = sW[kk][c0 + 2], b3 = sW[kk][c0 + 3];
-            acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[0][2] += a0 * b2; acc[0][3] += a0 * b3;
-            acc[1][0] += a1 * b0; acc[1][1] += a1 * b1; acc[1][2] += a1 * b2; acc[1][3] += a1 * b3;
+            double a[4], bb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = sC[ty + 16 * u][kk];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) bb[v] = sW[kk][4 * tx + v];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * bb[v];
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < 4; ++u) {
         const int r = row0 + ty + 16 * u;
         if (r < k) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) Wp[(size_t)r * L + c0 + v] = acc[u][v];
+            for (int v = 0; v < 4; ++v) atomicAdd(&Wp[(size_t)r * L + 4 * tx + v], acc[u][v]);
         }
     }
 }
@@ -862,6 +1036,73 @@ static int32_t retile(srx_mat* m, const CompactCsr& c, int kt, Tiled& t) {
     return SRX_OK;
 }
 
+// Fast path: both tile-major layouts straight from X (count, two scans, fill); needs <= 64 tiles
+// of 128 columns (k <= 8192) because lane t of a wave is the counter of tile t.
+static int32_t alloc_tiled(srx_mat* m, uint64_t N, uint64_t nnz, int k, int kt, Tiled& t) {
+    srx_ctx* ctx = m->ctx;
+    const size_t vb = val_bytes(m);
+    const std::string tag = "pca_t" + std::to_string(kt) + "_";
+    t.n_rows = N;
+    t.nnz = nnz;
+    t.k = k;
+    t.kt = kt;
+    t.nt = (k + kt - 1) / kt;
+    SRX_TRY(scratch(ctx, (tag + "idx").c_str(), (nnz + 64) * sizeof(int32_t), (void**)&t.tidx));
+    SRX_TRY(scratch(ctx, (tag + "vals").c_str(), (nnz + 64) * vb, &t.tvals));
+    SRX_HIP(ctx, hipMemsetAsync(t.tidx + nnz, 0, 64 * sizeof(int32_t), ctx->stream));
+    SRX_HIP(ctx, hipMemsetAsync((char*)t.tvals + nnz * vb, 0, 64 * vb, ctx->stream));
+    return SRX_OK;
+}
+
+static int32_t build_tiled_fused(srx_mat* m, const std::vector<int32_t>& remap, int k, Tiled& t128, Tiled& t256) {
+    srx_ctx* ctx = m->ctx;
+    const uint64_t N = m->n_rows;
+    const int nt128 = (k + KG - 1) / KG, nt256 = (k + KT - 1) / KT;
+    int64_t *cnt128, *cnt256, *d_total;
+    // selection bitmask + per-word prefix counts (the compacted column of a gene is its rank among
+    // the selected genes in ascending gene order, which is exactly what `remap` holds)
+    const int n_words = (int)((remap.size() + 31) / 32);
+    std::vector<uint32_t> hsel(2 * (size_t)n_words, 0u);
+    for (size_t g = 0; g < remap.size(); ++g)
+        if (remap[g] >= 0) hsel[g >> 5] |= 1u << (g & 31);
+    uint32_t run = 0;
+    for (int w = 0; w < n_words; ++w) {
+        hsel[n_words + w] = run;
+        run += (uint32_t)__builtin_popcount(hsel[w]);
+    }
+    uint32_t* d_sel;
+    SRX_TRY(scratch(ctx, "pca_selbits", (hsel.size() ? hsel.size() : 1) * sizeof(uint32_t), (void**)&d_sel));
+    SRX_TRY(h2d(ctx, d_sel, hsel.data(), hsel.size() * sizeof(uint32_t)));
+    const size_t sel_lds = 2 * (size_t)n_words * sizeof(uint32_t);
+    if (sel_lds > 60000) return fail(ctx, SRX_E_ARG, "pca: %zu genes exceed the LDS selection table", remap.size());
+    const uint64_t n128 = (uint64_t)nt128 * N, n256 = (uint64_t)nt256 * N;
+    SRX_TRY(scratch(ctx, "pca_cnt128", (n128 ? n128 : 1) * sizeof(int64_t), (void**)&cnt128));
+    SRX_TRY(scratch(ctx, "pca_cnt256", (n256 ? n256 : 1) * sizeof(int64_t), (void**)&cnt256));
+    SRX_TRY(scratch(ctx, "pca_t128_ptr", (n128 + 1) * sizeof(int64_t), (void**)&t128.tptr));
+    SRX_TRY(scratch(ctx, "pca_t256_ptr", (n256 + 1) * sizeof(int64_t), (void**)&t256.tptr));
+    ProfScope ps(ctx, SRX_K_COMPACT, (double)m->nnz * 4.0 * 2.0 + (double)(N + 1) * 8.0 * 2.0);
+    hipLaunchKernelGGL(k_tcount, dim3(grid_rows(ctx, N, 4)), dim3(256), sel_lds, ctx->stream, m->d_indptr, m->d_indices,
+                       d_sel, d_sel + n_words, n_words, N, nt128, nt256, cnt128, cnt256);
+    SRX_TRY(scan_exclusive(ctx, cnt128, n128, t128.tptr, &d_total));
+    int64_t total = 0;
+    SRX_TRY(d2h(ctx, &total, d_total, sizeof(int64_t)));
+    SRX_TRY(scan_exclusive(ctx, cnt256, n256, t256.tptr, nullptr));
+    SRX_TRY(alloc_tiled(m, N, (uint64_t)total, k, KG, t128));
+    SRX_TRY(alloc_tiled(m, N, (uint64_t)total, k, KT, t256));
+    if (is_f32(m))
+        hipLaunchKernelGGL((k_tfill<float>), dim3(grid_rows(ctx, N, 4)), dim3(256), sel_lds, ctx->stream, m->d_indptr,
+                           m->d_indices, (const float*)m->d_values, d_sel, d_sel + n_words, n_words, N, nt128, nt256,
+                           cnt128, t128.tptr, t256.tptr, t128.tidx, (float*)t128.tvals, t256.tidx, (float*)t256.tvals);
+    else
+        hipLaunchKernelGGL((k_tfill<double>), dim3(grid_rows(ctx, N, 4)), dim3(256), sel_lds, ctx->stream, m->d_indptr,
+                           m->d_indices, (const double*)m->d_values, d_sel, d_sel + n_words, n_words, N, nt128, nt256,
+                           cnt128, t128.tptr, t256.tptr, t128.tidx, (double*)t128.tvals, t256.tidx, (double*)t256.tvals);
+    SRX_HIP(ctx, hipGetLastError());
+    if (ctx->prof_mask & (1u << SRX_K_COMPACT))
+        ctx->prof[SRX_K_COMPACT].bytes += (double)total * (4.0 + val_bytes(m)) * 3.0;   // read once, written twice
+    return SRX_OK;
+}
+
 // ---- launches ---------------------------------------------------------------------------------
 template <typename VT, typename PT>
 static int32_t launch_fwd(srx_ctx* ctx, const Tiled& c, const PT* P, const PT* cvec, PT* Y) {
@@ -940,6 +1181,7 @@ static int32_t launch_gram(srx_ctx* ctx, const Tiled& g, double* G) {
 // ---- the driver ---------------------------------------------------------------------------------
 struct Resolved {
     int n_pc, center, scale, max_iter, solver;
+    int power = 1;           // applications of C per Rayleigh–Ritz step
     double tol;
     uint64_t seed;
 };
@@ -1060,24 +1302,30 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         }
         if (resid != resid) return fail(ctx, SRX_E_NOCONV, "pca: NaN in the Ritz residual");
         if (resid <= o.tol) { converged = true; break; }
-        SRX_TRY(orth(true));
+        // extra applications of C before the next Rayleigh–Ritz step (cheap dense products only):
+        // Wp <- C^(power-1) Wp; the block stays well conditioned (kappa ~ (theta_1/theta_l)^power)
+        for (int extra = 1; extra < o.power; ++extra) {
+            SRX_TRY(apply(w.Wp, w.A1));
+            SRX_HIP(ctx, hipMemcpyAsync(w.Wp, w.A1, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        SRX_TRY(orth(o.power == 1));
     }
     if (!converged) iters = o.max_iter;
     return SRX_OK;
 }
 
 template <typename VT, typename PT>
-static int32_t run_pca(srx_mat* m, const CompactCsr& cc, const Resolved& o, const std::vector<double>& mu,
-                       const std::vector<double>& dinv, int l_act, double n_cells, srx_pca_state& st) {
+static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const Resolved& o,
+                       const std::vector<double>& mu, const std::vector<double>& dinv, int l_act, double n_cells,
+                       srx_pca_state& st) {
     srx_ctx* ctx = m->ctx;
-    const int k = cc.k;
+    const int k = t256.k;
+    struct { uint64_t n_rows; } cc{t256.n_rows};
     const size_t kl = (size_t)k * L;
     Work w;
     SRX_TRY(alloc_work(ctx, k, w));
     SRX_TRY(h2d(ctx, w.mu, mu.data(), (size_t)k * 8));
     SRX_TRY(h2d(ctx, w.d, dinv.data(), (size_t)k * 8));
-    Tiled t256;
-    SRX_TRY(retile(m, cc, KT, t256));
     PT *P, *cvec, *Y;
     SRX_TRY(scratch(ctx, "pca_P", (kl + L) * sizeof(PT), (void**)&P));
     cvec = P + kl;
@@ -1089,8 +1337,7 @@ static int32_t run_pca(srx_mat* m, const CompactCsr& cc, const Resolved& o, cons
     bool converged = false;
     if (o.solver == 1) {
         // explicit Gram: G = A^T A once (all-reduced), C = D (G - c N mu mu^T) D dense
-        Tiled t128;
-        SRX_TRY(retile(m, cc, KG, t128));
+        const Tiled& t128 = *t128p;
         double* C;
         SRX_TRY(scratch(ctx, "pca_C", (size_t)k * k * 8, (void**)&C));
         SRX_TRY(launch_gram<VT>(ctx, t128, C));
@@ -1100,7 +1347,8 @@ static int32_t run_pca(srx_mat* m, const CompactCsr& cc, const Resolved& o, cons
         SRX_HIP(ctx, hipGetLastError());
         auto apply = [&](const double* Win, double* Wout) -> int32_t {
             ProfScope ps(ctx, SRX_K_DENSE, (double)k * k * 8.0 + 2.0 * k * L * 8.0);
-            hipLaunchKernelGGL(k_dense_apply, dim3((k + 31) / 32), dim3(256), 0, ctx->stream, C, Win, k, Wout);
+            SRX_HIP(ctx, hipMemsetAsync(Wout, 0, kl * 8, ctx->stream));
+            hipLaunchKernelGGL(k_dense_apply, dim3((k + 63) / 64, kDenseSplit), dim3(256), 0, ctx->stream, C, Win, k, Wout);
             SRX_HIP(ctx, hipGetLastError());
             return SRX_OK;
         };
@@ -1187,6 +1435,7 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     o.solver = opts ? opts->solver : 0;
     if (o.solver < 0 || o.solver > 2) return fail(ctx, SRX_E_ARG, "pca: solver must be 0 (auto), 1 (gram) or 2 (spmm)");
     if (o.solver == 0) o.solver = k <= 4096 ? 1 : 2;
+    o.power = o.solver == 1 ? 3 : 1;
     if (o.solver == 1 && k > 16384) return fail(ctx, SRX_E_ARG, "pca: the Gram solver holds a k x k f64 matrix; k=%d is too large", k);
     // default tolerance on the relative Ritz residual: what the arithmetic of the solver supports
     if (o.tol == 0.0) o.tol = (o.solver == 1 || !is_f32(m)) ? 1e-9 : 1e-7;
@@ -1236,18 +1485,28 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     std::vector<double> mu_eff = mu;
     if (!o.center) std::fill(mu_eff.begin(), mu_eff.end(), 0.0);
 
-    CompactCsr cc;
-    SRX_TRY(build_compact(m, remap, k, cc));
+    // tile-major views of X[:, sel]: fused count/fill when the tile counters fit a wave, else the
+    // general route through a row-major compacted CSR
+    Tiled t256, t128;
+    const bool need128 = o.solver == 1;
+    if ((k + KG - 1) / KG <= kWave) {
+        SRX_TRY(build_tiled_fused(m, remap, k, t128, t256));
+    } else {
+        CompactCsr cc;
+        SRX_TRY(build_compact(m, remap, k, cc));
+        SRX_TRY(retile(m, cc, KT, t256));
+        if (need128) SRX_TRY(retile(m, cc, KG, t128));
+    }
     st.info = srx_pca_info{};
     st.info.n_cells_global = Ng;
     st.info.k = (uint32_t)k;
     st.info.n_pc = (uint32_t)o.n_pc;
     st.info.block = L;
-    st.info.nnz_selected = cc.nnz;
+    st.info.nnz_selected = t256.nnz;
     st.info.solver = (uint32_t)o.solver;
     int32_t rc;
-    if (is_f32(m)) rc = run_pca<float, float>(m, cc, o, mu_eff, dinv, l_act, Nd, st);
-    else rc = run_pca<double, double>(m, cc, o, mu_eff, dinv, l_act, Nd, st);
+    if (is_f32(m)) rc = run_pca<float, float>(m, t256, need128 ? &t128 : nullptr, o, mu_eff, dinv, l_act, Nd, st);
+    else rc = run_pca<double, double>(m, t256, need128 ? &t128 : nullptr, o, mu_eff, dinv, l_act, Nd, st);
     if (rc != SRX_OK && rc != SRX_E_NOCONV) return rc;
 
     // back to selection order; explained variance ratio = eig/total with eig = theta/(N-1),
@@ -1319,8 +1578,15 @@ int32_t srx_spmm(srx_mat* m, const uint64_t* sel, uint64_t k64, const double* pa
         if (s > 0 && sel[s] <= sel[s - 1]) return fail(ctx, SRX_E_ARG, "srx_spmm: sel must be strictly ascending");
         remap[sel[s]] = s;
     }
-    CompactCsr cc;
-    SRX_TRY(build_compact(m, remap, k, cc));
+    Tiled c256, c128;
+    if ((k + KG - 1) / KG <= kWave) {
+        SRX_TRY(build_tiled_fused(m, remap, k, c128, c256));
+    } else {
+        CompactCsr cc;
+        SRX_TRY(build_compact(m, remap, k, cc));
+        SRX_TRY(retile(m, cc, KT, c256));
+        SRX_TRY(retile(m, cc, KG, c128));
+    }
     const size_t kl = (size_t)k * L;
     double* T;
     SRX_TRY(scratch(ctx, "pca_T", (kl + L) * 8, (void**)&T));
@@ -1328,8 +1594,7 @@ int32_t srx_spmm(srx_mat* m, const uint64_t* sel, uint64_t k64, const double* pa
         using VT = decltype(vt);
         using PT = decltype(pt);
         if (y_out || t_out) {
-            Tiled c;
-            SRX_TRY(retile(m, cc, KT, c));
+            const Tiled& c = c256;
             PT *P, *Y;
             SRX_TRY(scratch(ctx, "pca_P", (kl + L) * sizeof(PT), (void**)&P));
             SRX_TRY(scratch(ctx, "pca_Y", (c.n_rows ? c.n_rows : 1) * (size_t)L * sizeof(PT), (void**)&Y));
@@ -1348,8 +1613,7 @@ int32_t srx_spmm(srx_mat* m, const uint64_t* sel, uint64_t k64, const double* pa
             }
         }
         if (gram_out) {
-            Tiled g;
-            SRX_TRY(retile(m, cc, KG, g));
+            const Tiled& g = c128;
             double* C;
             SRX_TRY(scratch(ctx, "pca_C", (size_t)k * k * 8, (void**)&C));
             SRX_TRY(launch_gram<VT>(ctx, g, C));
