@@ -621,22 +621,46 @@ __global__ void k_t_reduce(const AT* __restrict__ part, const double* __restrict
 }
 
 // ---- explicit sparse Gram: G = A^T A, one 128 x 128 f64 tile per workgroup --------------------------
-// Workgroup = (gene-tile pair (a <= b), row block); LDS holds the 128 x 128 f64 tile.  A wave
-// takes 64 consecutive cells: their tile-a entries are one contiguous range (coalesced load,
-// one entry per lane); the lane finds the cell of its entry by a 6-step shuffle search over the
-// 64 row ends, then walks that cell's tile-b segment and adds va*vb at (ja, jb) with an LDS f64
-// atomic.  Diagonal pairs compute the full tile.  Per-(row block, pair) partial tiles are summed
-// in fixed order by k_gram_reduce.
-constexpr int kGramB = 8;
+// Workgroup = (gene-tile pair (a <= b), row block); LDS holds the 128 x 128 f64 tile (128 KiB,
+// column index XOR-swizzled by the row so that products sharing jb spread over the banks) and a
+// small staging area per wave.  A wave walks its contiguous share of the row block in batches of
+// up to 32 cells whose tile-a and tile-b entries fit the staging area (two contiguous ranges:
+// coalesced loads -> LDS as packed (index, value) pairs).  Each 16-lane group then takes one cell
+// at a time and spreads that cell's la*lb products over its lanes: (ia, ib) = divmod(p, lb) with a
+// group-uniform lb, two staged reads, one LDS f64 atomic at (ja, jb).  [A lane-per-entry walk runs
+// every lane to the longest segment of the wave (19 % utilisation on the bench matrix); flattening
+// the products of the whole batch over the lanes costs ~117 VALU instructions per 64 products for
+// the per-product cell search — profiles/r01_pmc_gram_flattened.md.]  Diagonal pairs compute the
+// full tile.  Per-(row block, pair) partial tiles are summed in fixed order by k_gram_reduce.
+template <typename VT> struct GramCfg;
+template <> struct GramCfg<float> { static constexpr int kWavesPerWg = 14; };    // 14 x 2048 B of staging
+template <> struct GramCfg<double> { static constexpr int kWavesPerWg = 7; };    //  7 x 4096 B
+constexpr int kGramRows = 32;          // cells per batch (lane l < 32 holds cell l's extents)
+constexpr int kGramCap = 128;          // staged entries per side (a cell holds <= 128 entries of a tile)
+
 template <typename VT>
-__global__ __launch_bounds__(kTThreads) void k_gram_sparse(const int64_t* __restrict__ tptr,
-                                                           const int32_t* __restrict__ tidx,
-                                                           const VT* __restrict__ tvals, uint64_t n_rows, int ntg,
-                                                           uint64_t rows_per_block, int n_pairs,
-                                                           double* __restrict__ part) {
+struct __attribute__((aligned(8))) GramEntry {
+    int32_t j;
+    VT v;
+};
+
+template <typename VT>
+__global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
+    const int64_t* __restrict__ tptr, const int32_t* __restrict__ tidx, const VT* __restrict__ tvals, uint64_t n_rows,
+    int ntg, uint64_t rows_per_block, int n_pairs, double* __restrict__ part) {
+    constexpr int kWaves = GramCfg<VT>::kWavesPerWg;
+    constexpr int kThreads = kWaves * kWave;
+    using Entry = GramEntry<VT>;
+    constexpr int kStageBytes = 2 * kGramCap * (int)sizeof(Entry);
+    static_assert(KG * KG * 8 + kWaves * kStageBytes <= 163840, "LDS budget");
     extern __shared__ double lds_raw[];
     double* acc = lds_raw;
-    for (int e = threadIdx.x; e < KG * KG; e += kTThreads) acc[e] = 0.0;
+    const int lane = lane_id();
+    const int wave = threadIdx.x / kWave;
+    char* stage = reinterpret_cast<char*>(lds_raw + KG * KG) + wave * kStageBytes;
+    Entry* s_a = reinterpret_cast<Entry*>(stage);
+    Entry* s_b = s_a + kGramCap;
+    for (int e = threadIdx.x; e < KG * KG; e += kThreads) acc[e] = 0.0;
     __syncthreads();
     const int pair = blockIdx.x % n_pairs;
     const uint64_t rb = blockIdx.x / n_pairs;
@@ -647,59 +671,86 @@ __global__ __launch_bounds__(kTThreads) void k_gram_sparse(const int64_t* __rest
     const uint64_t r1 = r0 + rows_per_block < n_rows ? r0 + rows_per_block : n_rows;
     const int64_t* pa = tptr + (uint64_t)a * n_rows;
     const int64_t* pb = tptr + (uint64_t)b * n_rows;
-    const int lane = lane_id();
-    const int wave = threadIdx.x / kWave;
-    constexpr int kWaves = kTThreads / kWave;
-    for (uint64_t rr = r0 + (uint64_t)wave * kWave; rr < r1; rr += (uint64_t)kWaves * kWave) {
-        const int nb = (int)(r1 - rr < (uint64_t)kWave ? r1 - rr : (uint64_t)kWave);
-        const int l0 = lane < nb ? lane : nb, l1 = lane + 1 < nb ? lane + 1 : nb;
-        const int64_t a0 = pa[rr];                                   // wave-uniform
-        const int ea = (int)(pa[rr + l1] - a0);                      // end of my row, relative
-        const int64_t sb = pb[rr + l0];
-        const int lenb = (int)(pb[rr + l1] - sb);
-        const int total_a = (int)(pa[rr + nb] - a0);
-        for (int cb = 0; cb < total_a; cb += kWave) {
-            const int e = cb + lane;
-            const bool valid = e < total_a;
-            // row of entry e = number of rows whose end is <= e (ends are non-decreasing over lanes)
-            int row = 0;
+    const uint64_t per_wave = r1 > r0 ? (r1 - r0 + kWaves - 1) / kWaves : 0;
+    const uint64_t w0 = r0 + (uint64_t)wave * per_wave < r1 ? r0 + (uint64_t)wave * per_wave : r1;
+    const uint64_t w1 = w0 + per_wave < r1 ? w0 + per_wave : r1;
+    const int grp = lane >> 4, q = lane & 15;
+    // software pipeline: the row pointers of the NEXT batch are requested as soon as this batch's
+    // extent is known, and both entry ranges of a batch are loaded together
+    auto load_ptrs = [&](uint64_t rr, int64_t& pal, int64_t& pbl) {
+        const uint64_t at = rr < w1 ? rr : w1;
+        const uint64_t left = w1 - at;
+        const int nbmax = (int)(left < (uint64_t)kGramRows ? left : (uint64_t)kGramRows);
+        const int li = lane < nbmax ? lane : nbmax;
+        pal = pa[at + li];
+        pbl = pb[at + li];
+    };
+    int64_t pal = 0, pbl = 0;
+    if (w0 < w1) load_ptrs(w0, pal, pbl);
+    for (uint64_t rr = w0; rr < w1;) {
+        const int nbmax = (int)(w1 - rr < (uint64_t)kGramRows ? w1 - rr : (uint64_t)kGramRows);
+        const int64_t a0 = readlane64(pal, 0), b0 = readlane64(pbl, 0);
+        const int nxt = lane + 1 < kWave ? lane + 1 : kWave - 1;
+        const int startA = (int)(pal - a0), startB = (int)(pbl - b0);
+        const int endA = (int)(__shfl(pal, nxt, kWave) - a0);       // end of row `lane` (valid for lane < nbmax)
+        const int endB = (int)(__shfl(pbl, nxt, kWave) - b0);
+        // rows of this batch: the longest prefix whose entries fit the staging area on both sides
+        // (one row holds <= 128 entries of a tile, so nr >= 1)
+        const unsigned long long fit = __ballot(lane < nbmax && endA <= kGramCap && endB <= kGramCap);
+        const int nr = __popcll(fit);
+        const int nA = __builtin_amdgcn_readlane(endA, nr - 1);
+        const int nB = __builtin_amdgcn_readlane(endB, nr - 1);
+        Entry ea[kGramCap / kWave], eb[kGramCap / kWave];
 #pragma unroll
-            for (int step = 32; step >= 1; step >>= 1) {
-                const int probe = __shfl(ea, row + step - 1, kWave);
-                if (probe <= e) row += step;
-            }
-            // every shuffle runs with all 64 lanes active: a ds_bpermute only sees data of ACTIVE
-            // source lanes, so none of them may sit behind the `valid` predicate
-            const int64_t sbr = __shfl(sb, row, kWave);
-            const int lb_row = __shfl(lenb, row, kWave);
-            const int ec = valid ? e : 0;                               // clamped: loads stay unconditional
-            const int ja = tidx[a0 + ec];
-            const double va = valid ? (double)tvals[a0 + ec] : 0.0;
-            const int lb = valid ? lb_row : 0;
-            // tile-b entries of the lane's cell, kGramB at a time: all loads of a round are issued
-            // together (clamped addresses, no branch), then the predicated LDS atomics
-            for (int base = 0; __any(base < lb); base += kGramB) {
-                int jb[kGramB];
-                VT vb[kGramB];
+        for (int u = 0; u < kGramCap / kWave; ++u) {
+            const int c = u * kWave + lane;
+            const int ca = c < nA ? c : 0, cb = c < nB ? c : 0;
+            ea[u].j = tidx[a0 + ca];
+            ea[u].v = tvals[a0 + ca];
+            eb[u].j = tidx[b0 + cb];
+            eb[u].v = tvals[b0 + cb];
+        }
+        int64_t pal_n, pbl_n;
+        load_ptrs(rr + (uint64_t)nr, pal_n, pbl_n);
+        const int la = lane < nr ? endA - startA : 0;
+        const int lb = lane < nr ? endB - startB : 0;
 #pragma unroll
-                for (int u = 0; u < kGramB; ++u) {
-                    const int w = base + u;
-                    const int64_t q = sbr + (w < lb ? w : 0);
-                    jb[u] = tidx[q];
-                    vb[u] = tvals[q];
-                }
-#pragma unroll
-                for (int u = 0; u < kGramB; ++u) {
-                    if (base + u < lb)
-                        __hip_atomic_fetch_add(&acc[ja * KG + jb[u]], va * (double)vb[u], __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int u = 0; u < kGramCap / kWave; ++u) {
+            const int c = u * kWave + lane;
+            if (c < nA) s_a[c] = ea[u];
+            if (c < nB) s_b[c] = eb[u];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // group g takes cells g, g+4, g+8, ... of the batch; all shuffles run with every lane active
+        for (int rsub = 0; rsub * 4 < nr; ++rsub) {
+            const int row = grp + 4 * rsub;                          // group-uniform, < 32
+            const int sA = __shfl(startA, row, kWave), sB = __shfl(startB, row, kWave);
+            const int laR = __shfl(la, row, kWave), lbR = __shfl(lb, row, kWave);
+            const int np = laR * lbR;                                // 0 for cells past the batch
+            const float rcp = __frcp_rn((float)(lbR > 0 ? lbR : 1));
+            for (int p = q; __any(p < np); p += 16) {
+                if (p < np) {
+                    const int ia = (int)(((float)p + 0.5f) * rcp);   // p / lbR, exact for p < 2^14
+                    const int ib = p - ia * lbR;
+                    const Entry xa = s_a[sA + ia], xb = s_b[sB + ib];
+                    __hip_atomic_fetch_add(&acc[xa.j * KG + (xb.j ^ (xa.j & 31))], (double)xa.v * (double)xb.v,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        rr += (uint64_t)nr;
+        pal = pal_n;
+        pbl = pbl_n;
     }
     __syncthreads();
     double* out = part + (rb * (uint64_t)n_pairs + pair) * (uint64_t)(KG * KG);
-    for (int e = threadIdx.x; e < KG * KG; e += kTThreads) out[e] = acc[e];
+    for (int e = threadIdx.x; e < KG * KG; e += kThreads) {
+        const int ja = e / KG, jb = e % KG;
+        out[e] = acc[ja * KG + (jb ^ (ja & 31))];
+    }
 }
 
 // Graw (k x k, both triangles) = sum over row blocks of the partial tiles.
@@ -1165,12 +1216,14 @@ static int32_t launch_gram(srx_ctx* ctx, const Tiled& g, double* G) {
     const uint64_t rpb = (g.n_rows + n_rb - 1) / n_rb > 0 ? (g.n_rows + n_rb - 1) / n_rb : 1;
     double* part;
     SRX_TRY(scratch(ctx, "pca_gpart", n_rb * (size_t)n_pairs * KG * KG * sizeof(double), (void**)&part));
-    const size_t lds = (size_t)KG * KG * sizeof(double);
+    constexpr int kGramWaves = GramCfg<VT>::kWavesPerWg;
+    const size_t lds = (size_t)KG * KG * sizeof(double) +
+                       (size_t)kGramWaves * (2 * kGramCap * sizeof(GramEntry<VT>));
     // algorithmic bytes: every 128-tile is walked once per tile pair it belongs to (n_t + 1 pairs)
     ProfScope ps(ctx, SRX_K_GRAM, ((double)g.nnz * (4.0 + sizeof(VT)) + (double)ntg * g.n_rows * 8.0) * (ntg + 1) / 2.0 +
                                       (double)g.k * g.k * 8.0);
     SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_sparse<VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_gram_sparse<VT>), dim3((unsigned)(n_rb * n_pairs)), dim3(kTThreads), lds, ctx->stream, g.tptr,
+    hipLaunchKernelGGL((k_gram_sparse<VT>), dim3((unsigned)(n_rb * n_pairs)), dim3(kGramWaves * kWave), lds, ctx->stream, g.tptr,
                        g.tidx, (const VT*)g.tvals, g.n_rows, ntg, rpb, n_pairs, part);
     hipLaunchKernelGGL(k_gram_reduce, dim3((KG * KG + 255) / 256, n_pairs), dim3(256), 0, ctx->stream, part, n_rb, n_pairs,
                        ntg, g.k, G);
