@@ -186,8 +186,8 @@ typedef struct srx_pca_opts {
     int32_t block;         /* panel width l; 0 -> default (64)                            */
     int32_t max_iter;      /* 0 -> default 200                                            */
     int32_t solver;        /* srx_pca_solver; 0 = auto (Gram when k <= 4096)              */
-    double  tol;           /* relative Ritz-residual tolerance; 0 -> default (1e-9 Gram /
-                              f64 storage, 1e-7 matrix-free SpMM with f32 storage)        */
+    double  tol;           /* relative Ritz-residual tolerance; 0 -> default (1e-7 with
+                              f32 storage, 1e-9 with f64 storage)                         */
     uint64_t seed;         /* start panel seed (the reference has no randomness here)     */
 } srx_pca_opts;
 

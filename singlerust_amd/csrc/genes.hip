@@ -340,10 +340,14 @@ int32_t gene_variances(srx_mat* m, std::vector<double>& var) {
 int32_t select_hvg_host(srx_ctx* ctx, const std::vector<double>& var, uint64_t n, std::vector<uint64_t>& out) {
     for (double v : var)
         if (v != v) return fail(ctx, SRX_E_NAN, "NaN gene variance: called `Option::unwrap()` on a `None` value (partial_cmp)");
+    // stable descending order == the strict total order (variance desc, gene index asc), so a
+    // partial sort of the first n under that order gives exactly the stable sort's prefix
     std::vector<uint64_t> order(var.size());
     for (uint64_t j = 0; j < order.size(); ++j) order[j] = j;
-    std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return var[a] > var[b]; });
     uint64_t take = n < order.size() ? n : order.size();
+    auto before = [&](uint64_t a, uint64_t b) { return var[a] > var[b] || (var[a] == var[b] && a < b); };
+    std::nth_element(order.begin(), order.begin() + (take ? take - 1 : 0), order.end(), before);
+    std::sort(order.begin(), order.begin() + take, before);
     out.assign(order.begin(), order.begin() + take);
     return SRX_OK;
 }

@@ -1235,6 +1235,7 @@ static int32_t launch_gram(srx_ctx* ctx, const Tiled& g, double* G) {
 struct Resolved {
     int n_pc, center, scale, max_iter, solver;
     int power = 1;           // applications of C per Rayleigh–Ritz step
+    int warm = 0;            // leading sweeps of `power` applications + CholeskyQR WITHOUT a Rayleigh–Ritz step
     double tol;
     uint64_t seed;
 };
@@ -1323,6 +1324,15 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     SRX_HIP(ctx, hipMemcpyAsync(w.Wp, w.W, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
     SRX_TRY(orth(false));              // CholeskyQR2 on the random start
 
+    // warm-up: the first Ritz residuals are O(1) whatever happens — do not pay an l x l host
+    // eigen-solve (0.8 ms) to learn that
+    for (int sweep = 0; sweep < o.warm; ++sweep) {
+        for (int t = 0; t < o.power; ++t) {
+            SRX_TRY(apply(t == 0 ? w.W : w.Wp, w.A1));
+            SRX_HIP(ctx, hipMemcpyAsync(w.Wp, w.A1, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        SRX_TRY(orth(false));
+    }
     resid = INFINITY;
     converged = false;
     for (iters = 1; iters <= o.max_iter; ++iters) {
@@ -1453,7 +1463,7 @@ static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const 
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL((k_scores<PT>), dim3((unsigned)g), dim3(256), 0, ctx->stream, Y, cc.n_rows, n_pc, st.d_scores);
     SRX_HIP(ctx, hipGetLastError());
-    st.info.n_iter = (uint32_t)iters;
+    st.info.n_iter = (uint32_t)(iters + o.warm);
     st.info.residual = resid;
     if (!converged)
         return fail(ctx, SRX_E_NOCONV, "pca: subspace iteration stopped at max_iter=%d with residual %.3e > tol %.3e",
@@ -1489,9 +1499,10 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     if (o.solver < 0 || o.solver > 2) return fail(ctx, SRX_E_ARG, "pca: solver must be 0 (auto), 1 (gram) or 2 (spmm)");
     if (o.solver == 0) o.solver = k <= 4096 ? 1 : 2;
     o.power = o.solver == 1 ? 3 : 1;
+    o.warm = o.solver == 1 ? 2 : 0;
     if (o.solver == 1 && k > 16384) return fail(ctx, SRX_E_ARG, "pca: the Gram solver holds a k x k f64 matrix; k=%d is too large", k);
     // default tolerance on the relative Ritz residual: what the arithmetic of the solver supports
-    if (o.tol == 0.0) o.tol = (o.solver == 1 || !is_f32(m)) ? 1e-9 : 1e-7;
+    if (o.tol == 0.0) o.tol = is_f32(m) ? 1e-7 : 1e-9;
     if (o.n_pc < 1) return fail(ctx, SRX_E_ARG, "pca: n_components must be >= 1");
     if (opts && opts->block != 0 && opts->block != L) return fail(ctx, SRX_E_ARG, "pca: only block = %d is built", L);
     const int l_act = std::min(L, k);
