@@ -304,8 +304,11 @@ int32_t srx_matrix_alloc(srx_ctx* ctx, uint64_t n_rows, uint64_t n_cols, uint64_
     m->n_rows_global = n_rows;
     hipError_t e;
     e = hipMalloc((void**)&m->d_indptr, (n_rows + 1) * sizeof(int64_t));
-    if (e == hipSuccess) e = hipMalloc((void**)&m->d_indices, (nnz ? nnz : 1) * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc(&m->d_values, (nnz ? nnz : 1) * val_bytes(m));
+    // +16 elements: the streaming kernels read 16-byte vectors that may run past a row's last entry
+    if (e == hipSuccess) e = hipMalloc((void**)&m->d_indices, (nnz + 16) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&m->d_values, (nnz + 16) * val_bytes(m));
+    if (e == hipSuccess) e = hipMemsetAsync(m->d_indices + nnz, 0, 16 * sizeof(int32_t), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync((char*)m->d_values + nnz * val_bytes(m), 0, 16 * val_bytes(m), ctx->stream);
     if (e != hipSuccess) {
         free_mat_buffers(m);
         delete m;

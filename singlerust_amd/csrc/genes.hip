@@ -72,27 +72,36 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     const int wave = threadIdx.x / kWave;
     constexpr int kWaves = kMomThreads / kWave;
 
+    // 4 consecutive entries per lane: one 16-byte load of the indices and one (f32) or two (f64)
+    // of the values, from the 16-byte boundary at or before the segment start; entries outside
+    // [lo, hi) are masked (the arrays are padded by 16 entries)
     for (uint64_t r = r0 + wave; r < r1; r += kWaves) {
         int64_t lo, hi;
         seg_bounds(indptr, tp, n_rows, n_tiles, tile, r, lo, hi);
-        int64_t p = lo + lane;
-        for (; p + kWave < hi; p += 2 * kWave) {   // two independent loads in flight
-            int32_t g0 = idx[p], g1 = idx[p + kWave];
-            double x0 = (double)vals[p], x1 = (double)vals[p + kWave];
-            g0 -= gbase; g1 -= gbase;
-            __hip_atomic_fetch_add(&s_cnt[g0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&s_sum[g0], x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&s_sq[g0], x0 * x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&s_cnt[g1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&s_sum[g1], x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&s_sq[g1], x1 * x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        if (p < hi) {
-            int32_t g0 = idx[p] - gbase;
-            double x0 = (double)vals[p];
-            __hip_atomic_fetch_add(&s_cnt[g0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&s_sum[g0], x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&s_sq[g0], x0 * x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int64_t base = lo & ~(int64_t)3;
+        for (int64_t e0 = base + 4 * lane; e0 < hi; e0 += 4 * kWave) {
+            const int4 g4 = *reinterpret_cast<const int4*>(idx + e0);
+            T v[4];
+            if constexpr (sizeof(T) == 4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(vals + e0);
+                v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+            } else {
+                const double2 a2 = *reinterpret_cast<const double2*>(vals + e0);
+                const double2 b2 = *reinterpret_cast<const double2*>(vals + e0 + 2);
+                v[0] = a2.x; v[1] = a2.y; v[2] = b2.x; v[3] = b2.y;
+            }
+            const int gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t pos = e0 + j;
+                if (pos >= lo && pos < hi) {
+                    const int32_t g0 = gg[j] - gbase;
+                    const double x0 = (double)v[j];
+                    __hip_atomic_fetch_add(&s_cnt[g0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&s_sum[g0], x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&s_sq[g0], x0 * x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
         }
     }
     __syncthreads();

@@ -243,3 +243,20 @@ def test_synth_device_equals_host_generator(ctx):
     assert np.array_equal(statistics.compute_number(a, sr.Direction.Column), oracle.compute_number(m, COLUMN))
     assert np.array_equal(statistics.compute_sum(a, sr.Direction.Column), oracle.compute_sum(m, COLUMN))
     assert np.array_equal(statistics.compute_sum(a, sr.Direction.Row), oracle.compute_sum(m, ROW))
+
+
+def test_log1p_f32_accuracy(ctx):
+    """The f32 ln_1p of the fused pass (hardware log2 + Goldberg correction) against f64 log1p over
+    the whole positive range, tiny and huge arguments included; F32 stays F32 (transform/mod.rs:43-47)."""
+    import singlerust_amd as sr
+    from singlerust_amd.memory import processing
+    x = np.concatenate([np.logspace(-30, 30, 20001), np.linspace(0, 100, 5001), [0.0, 1e-45, 3.4e38]]).astype(np.float32)
+    n = x.size
+    a = sr.IMAnnData.new_basic((1, n, [0, n], np.arange(n), x), ctx=ctx)
+    processing.log1p_transform_inplace(a)
+    assert a.x_dtype() == np.float32
+    got = a.x_values().astype(np.float64)
+    want = np.log1p(x.astype(np.float64))
+    ok = want > 0
+    assert np.max(np.abs(got[ok] - want[ok]) / want[ok]) < 3e-7
+    assert np.all(got[~ok] == 0.0)
