@@ -633,7 +633,7 @@ __global__ void k_t_reduce(const AT* __restrict__ part, const double* __restrict
 // the per-product cell search — profiles/r01_pmc_gram_flattened.md.]  Diagonal pairs compute the
 // full tile.  Per-(row block, pair) partial tiles are summed in fixed order by k_gram_reduce.
 template <typename VT> struct GramCfg;
-template <> struct GramCfg<float> { static constexpr int kWavesPerWg = 14; };    // 14 x 2048 B of staging
+template <> struct GramCfg<float> { static constexpr int kWavesPerWg = 16; };    // 16 x 2048 B of staging
 template <> struct GramCfg<double> { static constexpr int kWavesPerWg = 7; };    //  7 x 4096 B
 constexpr int kGramRows = 32;          // cells per batch (lane l < 32 holds cell l's extents)
 constexpr int kGramCap = 128;          // staged entries per side (a cell holds <= 128 entries of a tile)
@@ -675,8 +675,13 @@ __global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
     const uint64_t w0 = r0 + (uint64_t)wave * per_wave < r1 ? r0 + (uint64_t)wave * per_wave : r1;
     const uint64_t w1 = w0 + per_wave < r1 ? w0 + per_wave : r1;
     const int grp = lane >> 4, q = lane & 15;
-    // software pipeline: the row pointers of the NEXT batch are requested as soon as this batch's
-    // extent is known, and both entry ranges of a batch are loaded together
+    // Two-deep software pipeline (a wave has only itself — 16 waves per CU, LDS-limited — to hide
+    // HBM latency behind): while batch n is staged and multiplied out of LDS, the entry loads of
+    // batch n+1 and the row pointers of batch n+2 are in flight.
+    struct Ext {                    // extents of a batch, from its row pointers
+        int64_t a0, b0;
+        int startA, startB, la, lb, nr, nA, nB;
+    };
     auto load_ptrs = [&](uint64_t rr, int64_t& pal, int64_t& pbl) {
         const uint64_t at = rr < w1 ? rr : w1;
         const uint64_t left = w1 - at;
@@ -685,48 +690,73 @@ __global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
         pal = pa[at + li];
         pbl = pb[at + li];
     };
-    int64_t pal = 0, pbl = 0;
-    if (w0 < w1) load_ptrs(w0, pal, pbl);
-    for (uint64_t rr = w0; rr < w1;) {
-        const int nbmax = (int)(w1 - rr < (uint64_t)kGramRows ? w1 - rr : (uint64_t)kGramRows);
-        const int64_t a0 = readlane64(pal, 0), b0 = readlane64(pbl, 0);
+    auto extents = [&](uint64_t rr, int64_t pal, int64_t pbl) -> Ext {
+        Ext x;
+        const uint64_t at = rr < w1 ? rr : w1;
+        const int nbmax = (int)(w1 - at < (uint64_t)kGramRows ? w1 - at : (uint64_t)kGramRows);
+        x.a0 = readlane64(pal, 0);
+        x.b0 = readlane64(pbl, 0);
         const int nxt = lane + 1 < kWave ? lane + 1 : kWave - 1;
-        const int startA = (int)(pal - a0), startB = (int)(pbl - b0);
-        const int endA = (int)(__shfl(pal, nxt, kWave) - a0);       // end of row `lane` (valid for lane < nbmax)
-        const int endB = (int)(__shfl(pbl, nxt, kWave) - b0);
-        // rows of this batch: the longest prefix whose entries fit the staging area on both sides
-        // (one row holds <= 128 entries of a tile, so nr >= 1)
+        x.startA = (int)(pal - x.a0);
+        x.startB = (int)(pbl - x.b0);
+        const int endA = (int)(__shfl(pal, nxt, kWave) - x.a0);      // end of row `lane` (valid for lane < nbmax)
+        const int endB = (int)(__shfl(pbl, nxt, kWave) - x.b0);
+        // rows of the batch: the longest prefix whose entries fit the staging area on both sides
+        // (one row holds <= 128 entries of a tile, so nr >= 1 whenever rows are left)
         const unsigned long long fit = __ballot(lane < nbmax && endA <= kGramCap && endB <= kGramCap);
-        const int nr = __popcll(fit);
-        const int nA = __builtin_amdgcn_readlane(endA, nr - 1);
-        const int nB = __builtin_amdgcn_readlane(endB, nr - 1);
-        Entry ea[kGramCap / kWave], eb[kGramCap / kWave];
+        x.nr = __popcll(fit);
+        const int last = x.nr > 0 ? x.nr - 1 : 0;
+        x.nA = x.nr > 0 ? __builtin_amdgcn_readlane(endA, last) : 0;
+        x.nB = x.nr > 0 ? __builtin_amdgcn_readlane(endB, last) : 0;
+        x.la = lane < x.nr ? endA - x.startA : 0;
+        x.lb = lane < x.nr ? endB - x.startB : 0;
+        return x;
+    };
+    auto load_entries = [&](const Ext& x, Entry (&ea)[kGramCap / kWave], Entry (&eb)[kGramCap / kWave]) {
 #pragma unroll
         for (int u = 0; u < kGramCap / kWave; ++u) {
             const int c = u * kWave + lane;
-            const int ca = c < nA ? c : 0, cb = c < nB ? c : 0;
-            ea[u].j = tidx[a0 + ca];
-            ea[u].v = tvals[a0 + ca];
-            eb[u].j = tidx[b0 + cb];
-            eb[u].v = tvals[b0 + cb];
+            const int ca = c < x.nA ? c : 0, cb = c < x.nB ? c : 0;
+            ea[u].j = tidx[x.a0 + ca];
+            ea[u].v = tvals[x.a0 + ca];
+            eb[u].j = tidx[x.b0 + cb];
+            eb[u].v = tvals[x.b0 + cb];
         }
-        int64_t pal_n, pbl_n;
-        load_ptrs(rr + (uint64_t)nr, pal_n, pbl_n);
-        const int la = lane < nr ? endA - startA : 0;
-        const int lb = lane < nr ? endB - startB : 0;
+    };
+    int64_t pal = 0, pbl = 0;
+    Ext cur{};
+    Entry ea[kGramCap / kWave], eb[kGramCap / kWave];
+    uint64_t rr = w0;
+    if (w0 < w1) {
+        load_ptrs(rr, pal, pbl);
+        cur = extents(rr, pal, pbl);
+        load_entries(cur, ea, eb);
+        load_ptrs(rr + (uint64_t)cur.nr, pal, pbl);              // row pointers of batch 1
+    }
+    while (rr < w1) {
+        // extents + entry loads of the NEXT batch, row pointers of the one after
+        const uint64_t rr_n = rr + (uint64_t)cur.nr;
+        const Ext nxt_x = extents(rr_n, pal, pbl);
+        Entry ea_n[kGramCap / kWave], eb_n[kGramCap / kWave];
+        load_entries(nxt_x, ea_n, eb_n);
+        load_ptrs(rr_n + (uint64_t)nxt_x.nr, pal, pbl);
+        // stage the current batch
 #pragma unroll
         for (int u = 0; u < kGramCap / kWave; ++u) {
             const int c = u * kWave + lane;
-            if (c < nA) s_a[c] = ea[u];
-            if (c < nB) s_b[c] = eb[u];
+            if (c < cur.nA) s_a[c] = ea[u];
+            if (c < cur.nB) s_b[c] = eb[u];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // group g takes cells g, g+4, g+8, ... of the batch; all shuffles run with every lane active
-        for (int rsub = 0; rsub * 4 < nr; ++rsub) {
+        // group g takes cells g, g+4, g+8, ... of the batch.  A cell's four extents travel in ONE
+        // shuffle: startA (8 bits) | startB (8) | la (8) | lb (8), each <= 128 by construction.
+        const int packed = (cur.startA & 0xff) | ((cur.startB & 0xff) << 8) | (cur.la << 16) | (cur.lb << 24);
+        for (int rsub = 0; rsub * 4 < cur.nr; ++rsub) {
             const int row = grp + 4 * rsub;                          // group-uniform, < 32
-            const int sA = __shfl(startA, row, kWave), sB = __shfl(startB, row, kWave);
-            const int laR = __shfl(la, row, kWave), lbR = __shfl(lb, row, kWave);
+            const unsigned info = (unsigned)__shfl(packed, row, kWave);   // every lane active
+            const int sA = info & 0xff, sB = (info >> 8) & 0xff;
+            const int laR = (info >> 16) & 0xff, lbR = info >> 24;
             const int np = laR * lbR;                                // 0 for cells past the batch
             const float rcp = __frcp_rn((float)(lbR > 0 ? lbR : 1));
             for (int p = q; __any(p < np); p += 16) {
@@ -741,9 +771,13 @@ __global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        rr += (uint64_t)nr;
-        pal = pal_n;
-        pbl = pbl_n;
+        rr = rr_n;
+        cur = nxt_x;
+#pragma unroll
+        for (int u = 0; u < kGramCap / kWave; ++u) {
+            ea[u] = ea_n[u];
+            eb[u] = eb_n[u];
+        }
     }
     __syncthreads();
     double* out = part + (rb * (uint64_t)n_pairs + pair) * (uint64_t)(KG * KG);
