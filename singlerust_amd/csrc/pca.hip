@@ -396,24 +396,21 @@ template <> struct FwdCfg<double> { static constexpr int kRows = 8, kWavesPerSim
 
 template <typename PT, int S>
 struct FwdRot {
+    // Step S uses the pair currently in (ci, cv), then rotates both by ONE lane for the next step.
+    // (Rotating the original pair by S at every step gives the scheduler 30 independent DPP moves
+    // per row to hoist — it did, and spilled; the chain keeps one live copy.)
     static __device__ __forceinline__ void run(int ci, PT cv, const PT* __restrict__ panel_q, PT (&a)[4]) {
-        const int j = ror16<S>(ci);
-        const PT v = ror16<S>(cv);
         Vec4<PT> p;
-        p.load(panel_q + j);
-        a[0] += v * p[0];
-        a[1] += v * p[1];
-        a[2] += v * p[2];
-        a[3] += v * p[3];
-        // keep at most 4 panel reads (16 VGPRs) in flight: without this fence the scheduler hoists
-        // all 128 ds_read_b128 of a stage and spills under the 128-VGPR budget of 2 workgroups/CU
+        p.load(panel_q + ci);
+        a[0] += cv * p[0];
+        a[1] += cv * p[1];
+        a[2] += cv * p[2];
+        a[3] += cv * p[3];
+        // at most 4 panel reads (16 VGPRs) in flight: without the fence the scheduler hoists the
+        // ds_read_b128 of all 16 steps (64 VGPRs per row) and spills under the 128-VGPR budget
         if constexpr ((S & 3) == 3) asm volatile("" ::: "memory");
-        FwdRot<PT, S + 1>::run(ci, cv, panel_q, a);
+        if constexpr (S + 1 < 16) FwdRot<PT, S + 1>::run(ror16<1>(ci), ror16<1>(cv), panel_q, a);
     }
-};
-template <typename PT>
-struct FwdRot<PT, 16> {
-    static __device__ __forceinline__ void run(int, PT, const PT* __restrict__, PT (&)[4]) {}
 };
 
 // One batch of kStage rows of a group: issue their (index, value) chunk loads together, then
