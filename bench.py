@@ -124,6 +124,7 @@ def main():
     h = C.c_void_p()
     F.check(lib.srx_synth_generate(ctx.handle, C.byref(params), row0, row1, F.F32, F.STORE_F32, C.byref(h)), ctx.handle)
     pristine = sr.DeviceCsr(ctx, h)
+    pristine.prepare()          # pattern-only row/gene-tile cuts: part of the resident layout, like indptr
     info = pristine.info()
     nnz = int(info.nnz)
     t_gen = time.perf_counter() - t_gen

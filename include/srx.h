@@ -126,6 +126,10 @@ int32_t srx_matrix_set_shard(srx_mat* m, uint64_t row_offset);
 /* D2H of the current values, converted to SRX_F32 or SRX_F64 (what the shim copies back
  * into values_mut(), or into the fresh Vec<f64> when the DynCsrMatrix variant changes). */
 int32_t srx_matrix_download_values(srx_mat* m, void* values_out, int32_t dtype_out);
+/* Build the pattern-only index structures of the device layout now (the gene-tile cuts of every
+ * row used by the per-gene passes) instead of lazily at first use; clones inherit them.  They
+ * depend on indptr/indices only, never on the values. */
+int32_t srx_matrix_prepare(srx_mat* m);
 /* Deep copy on device (normalize_total / log1p_transform, the copying forms,
  * processing/mod.rs:314-322,329-332, deep_clone X). */
 int32_t srx_matrix_clone(srx_mat* m, srx_mat** out);

@@ -148,6 +148,10 @@ class DeviceCsr:
                 self.ctx.handle)
         return out
 
+    def prepare(self) -> None:
+        """Build the pattern-only index structures of the device layout now (clones inherit them)."""
+        F.check(F.lib().srx_matrix_prepare(self._h), self.ctx.handle)
+
     def clone(self) -> "DeviceCsr":
         h = C.c_void_p()
         F.check(F.lib().srx_matrix_clone(self._h, C.byref(h)), self.ctx.handle)

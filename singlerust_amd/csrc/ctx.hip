@@ -445,12 +445,28 @@ int32_t srx_matrix_clone(srx_mat* m, srx_mat** out) {
                                             hipMemcpyDeviceToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c->d_values, m->d_values, m->nnz * val_bytes(m),
                                             hipMemcpyDeviceToDevice, ctx->stream);
+    // pattern-only index structure (gene-tile cuts of every row) travels with the pattern
+    if (e == hipSuccess && m->n_tiles > 0) {
+        c->n_tiles = m->n_tiles;
+        c->tile_genes = m->tile_genes;
+        if (m->d_tile_ptr) {
+            const size_t tb = (size_t)(m->n_tiles - 1) * (m->n_rows ? m->n_rows : 1) * sizeof(int64_t);
+            e = hipMalloc((void**)&c->d_tile_ptr, tb);
+            if (e == hipSuccess) e = hipMemcpyAsync(c->d_tile_ptr, m->d_tile_ptr, tb, hipMemcpyDeviceToDevice, ctx->stream);
+        }
+    }
     if (e != hipSuccess) {
         srx_matrix_free(c);
         return fail(ctx, SRX_E_HIP, "clone D2D: %s", hipGetErrorString(e));
     }
     *out = c;
     return SRX_OK;
+}
+
+int32_t srx_matrix_prepare(srx_mat* m) {
+    if (!m) return fail(nullptr, SRX_E_ARG, "null matrix");
+    SRX_HIP(m->ctx, hipSetDevice(m->ctx->device));
+    return ensure_tiles(m);
 }
 
 int32_t srx_matrix_copy_values(srx_mat* dst, const srx_mat* src) {

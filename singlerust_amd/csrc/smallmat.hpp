@@ -17,7 +17,9 @@ namespace smallmat {
 // form; on return V holds the accumulated orthogonal transform, d the diagonal, e the
 // sub-diagonal (e[0] = 0).  Classic EISPACK tred2 scheme.
 inline void tridiagonalize(int n, double* V, double* d, double* e) {
-    auto A = [&](int i, int j) -> double& { return V[(size_t)i * n + j]; };
+    // A(i, j) is stored at V[j*n + i] (column-major): every inner loop below runs over the FIRST
+    // index, i.e. over contiguous memory, and vectorises
+    auto A = [&](int i, int j) -> double& { return V[(size_t)j * n + i]; };
     for (int j = 0; j < n; ++j) d[j] = A(n - 1, j);
     for (int i = n - 1; i > 0; --i) {
         double scale = 0.0, h = 0.0;
@@ -93,7 +95,7 @@ inline void tridiagonalize(int n, double* V, double* d, double* e) {
 // Implicit-shift QL on the tridiagonal (d, e), rotating the columns of V along.
 // Returns false if an eigenvalue fails to converge in 60 sweeps.
 inline bool tridiagonal_ql(int n, double* V, double* d, double* e) {
-    auto A = [&](int i, int j) -> double& { return V[(size_t)i * n + j]; };
+    auto A = [&](int i, int j) -> double& { return V[(size_t)j * n + i]; };   // column-major, as above
     for (int i = 1; i < n; ++i) e[i - 1] = e[i];
     e[n - 1] = 0.0;
     double f = 0.0, tst1 = 0.0;
@@ -171,7 +173,7 @@ inline bool sym_eig_desc(int n, const double* Ain, double* evals, double* evecs)
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return d[a] > d[b]; });
     for (int c = 0; c < n; ++c) {
         evals[c] = d[order[c]];
-        for (int r = 0; r < n; ++r) evecs[(size_t)r * n + c] = V[(size_t)r * n + order[c]];
+        for (int r = 0; r < n; ++r) evecs[(size_t)r * n + c] = V[(size_t)order[c] * n + r];
     }
     return true;
 }

