@@ -110,16 +110,36 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_block_sums(const int64_t* _
         block_sums[blockIdx.x] = tot;
     }
 }
-__global__ void k_scan_serial(int64_t* __restrict__ block_sums, uint64_t nb, int64_t* __restrict__ total) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        int64_t acc = 0;
-        for (uint64_t b = 0; b < nb; ++b) {
-            int64_t v = block_sums[b];
-            block_sums[b] = acc;
-            acc += v;
-        }
-        *total = acc;
+// Exclusive scan of the block sums in place by ONE workgroup (nb is n/4096: a few thousand).
+__global__ __launch_bounds__(kScanBlock) void k_scan_serial(int64_t* __restrict__ block_sums, uint64_t nb,
+                                                            int64_t* __restrict__ total) {
+    __shared__ int64_t s_w[kScanBlock / kWave];
+    const uint64_t per = (nb + kScanBlock - 1) / kScanBlock;
+    const uint64_t b0 = (uint64_t)threadIdx.x * per;
+    const uint64_t b1 = b0 + per < nb ? b0 + per : nb;
+    int64_t s = 0;
+    for (uint64_t b = b0; b < b1; ++b) s += block_sums[b];
+    int64_t inc = s;
+    const int lane = lane_id();
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        int64_t o = __shfl_up(inc, off, kWave);
+        if (lane >= off) inc += o;
     }
+    if (lane == kWave - 1) s_w[threadIdx.x / kWave] = inc;
+    __syncthreads();
+    int64_t wave_off = 0, all = 0;
+    for (int w = 0; w < kScanBlock / kWave; ++w) {
+        if (w < (int)(threadIdx.x / kWave)) wave_off += s_w[w];
+        all += s_w[w];
+    }
+    int64_t acc = wave_off + inc - s;
+    for (uint64_t b = b0; b < b1; ++b) {
+        int64_t v = block_sums[b];
+        block_sums[b] = acc;
+        acc += v;
+    }
+    if (threadIdx.x == 0) *total = all;
 }
 __global__ __launch_bounds__(kScanBlock) void k_scan_apply(const int64_t* __restrict__ in, uint64_t n,
                                                            const int64_t* __restrict__ block_offs,
@@ -1035,7 +1055,7 @@ static int32_t scan_exclusive(srx_ctx* ctx, const int64_t* d_in, uint64_t n, int
     SRX_TRY(scratch(ctx, "scan_bsum", (nb + 1) * sizeof(int64_t), (void**)&d_bsum));
     int64_t* d_total = d_bsum + nb;
     hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, d_in, n, d_bsum);
-    hipLaunchKernelGGL(k_scan_serial, dim3(1), dim3(64), 0, ctx->stream, d_bsum, nb, d_total);
+    hipLaunchKernelGGL(k_scan_serial, dim3(1), dim3(kScanBlock), 0, ctx->stream, d_bsum, nb, d_total);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, d_in, n, d_bsum, d_total,
                        d_out);
     SRX_HIP(ctx, hipGetLastError());
