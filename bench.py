@@ -97,7 +97,8 @@ def main():
     lib = F.lib()
 
     dist = None
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # under torch.distributed.run
+    if world > 1 or launched:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist_
@@ -106,8 +107,7 @@ def main():
         dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
 
     ctx = sr.Context(local_rank)
-    if world > 1:
-        import torch
+    if dist is not None:
         uid = [sr.Context.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(world, rank, uid[0])
