@@ -96,21 +96,27 @@ def main():
     from singlerust_amd import _ffi as F
     lib = F.lib()
 
-    dist = None
-    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # under torch.distributed.run
-    if world > 1 or launched:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        import torch
-        import torch.distributed as dist_
-        dist = dist_
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
-
+    # One process per GPU.  The handshake (128-byte RCCL id, barriers, max over ranks) uses a
+    # stdlib socket star, not torch.distributed: the torch wheel bundles its own HIP runtime and RCCL,
+    # and once it is imported into this process ncclCommInitRank of the system RCCL that
+    # libsrx_hip.so uses fails; nothing on the data path needs torch.  Device synchronisation goes
+    # through the library (hipStreamSynchronize on the stream every kernel of the path runs on).
     ctx = sr.Context(local_rank)
+    from singlerust_amd.rendezvous import StarGroup
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # under torch.distributed.run
+    group = StarGroup(rank, world)
+    dist = group if (world > 1 or launched) else None
     if dist is not None:
-        uid = [sr.Context.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(world, rank, uid[0])
+        # RCCL prints a version banner on stdout at init: keep stdout clean for the one JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            uid = group.broadcast_bytes(sr.Context.comm_unique_id() if rank == 0 else None, F.UNIQUE_ID_BYTES)
+            ctx.comm_init(world, rank, uid)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
 
     cells, genes, density, seed = CONFIGS[a.config]
     if a.cells:
@@ -142,10 +148,8 @@ def main():
         F.check(lib.srx_pipeline(mat.handle, a.target_sum, a.hvg, C.byref(opts), C.byref(res)), ctx.handle)
 
     def sync_all():
-        ctx.synchronize()
+        ctx.synchronize()               # every kernel of the path runs on this context's stream
         if dist is not None:
-            import torch
-            torch.cuda.synchronize()
             dist.barrier()
 
     # warmup (untimed)
@@ -177,10 +181,7 @@ def main():
         elapsed += time.perf_counter() - t0
         done += chunk
     if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = dist.allreduce_max(elapsed)
 
     prof = {}
     names = {F.K_NORMALIZE: "normalize_log1p", F.K_MOMENTS: "gene_moments", F.K_COMPACT: "hvg_compact",
@@ -236,7 +237,7 @@ def main():
     pristine.free()
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        dist.close()
     ctx.close()
 
 

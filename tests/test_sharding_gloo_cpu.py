@@ -130,3 +130,30 @@ def test_partition_rows_edge_cases():
     cut2 = np.zeros(3, dtype=np.uint64)
     assert lib.srx_partition_rows(_ffi.ptr(empty), 0, 2, _ffi.ptr(cut2)) == 0
     assert cut2.tolist() == [0, 0, 0]
+
+
+def _star_worker(rank, world, key, q):
+    from singlerust_amd.rendezvous import StarGroup
+    g = StarGroup(rank, world, key=key, timeout=60)
+    data = g.broadcast_bytes(bytes(range(128)) if rank == 0 else None, 128)
+    g.barrier()
+    m = g.allreduce_max(float(rank) * 1.5)
+    g.barrier()
+    g.close()
+    q.put((rank, data == bytes(range(128)), m))
+
+
+def test_star_rendezvous_three_ranks():
+    """bench.py's handshake (RCCL id broadcast, barrier, max over ranks) without torch."""
+    import multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    key = f"test_{os.getpid()}"
+    ps = [ctxm.Process(target=_star_worker, args=(r, 3, key, q)) for r in range(3)]
+    for p in ps:
+        p.start()
+    out = sorted(q.get(timeout=60) for _ in ps)
+    for p in ps:
+        p.join(30)
+        assert p.exitcode == 0
+    assert [o[0] for o in out] == [0, 1, 2] and all(o[1] for o in out) and all(o[2] == 3.0 for o in out)
