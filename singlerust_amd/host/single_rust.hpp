@@ -1,0 +1,262 @@
+// single_rust.hpp — C++ host-side mirror of the reference's API for the hot path, over the C ABI
+// of include/srx.h.
+//
+// The reference is Rust (src/lib.rs:5-15 re-exports `memory::{processing, statistics}`); this image
+// has no Rust toolchain, so the host side above the C ABI is C++ (the reference is compiled code).
+// Names, argument order and error behaviour follow the reference so that a test written against
+// this header reads like the reference's own (`src/memory/processing/mod.rs:334-482`):
+//
+//   single_rust::IMAnnData adata = single_rust::IMAnnData::new_basic(x, obs_names, var_names);
+//   single_rust::memory::processing::normalize_total_inplace(adata, 1e4, Direction::Row);
+//   single_rust::memory::processing::log1p_transform_inplace(adata);
+//   single_rust::memory::processing::dim_red::pca_inplace(adata, 50, {}, {}, {}, FeatureSelection::HighlyVariable(2000));
+//   const Array2& x_pca = adata.obsm().at("X_pca");
+//
+// `anyhow::Result<T>` becomes "returns T or throws single_rust::Error" (message = srx_last_error).
+// Header-only; link with -lsrx_hip.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <map>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <variant>
+#include <vector>
+
+#include "../../include/srx.h"
+
+namespace single_rust {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+enum class Direction { Row = 0, Column = 1 };                   // src/shared/mod.rs:39-42
+
+struct FeatureSelection {                                        // src/shared/mod.rs:17-23
+    enum Kind { HighlyVariableColK, HighlyVariableK, RandomizedK, VarianceThresholdK, NoneK } kind = NoneK;
+    std::string col;
+    std::size_t n = 0;
+    double threshold = 0.0;
+    static FeatureSelection HighlyVariable(std::size_t n) { FeatureSelection f; f.kind = HighlyVariableK; f.n = n; return f; }
+    static FeatureSelection VarianceThreshold(double t) { FeatureSelection f; f.kind = VarianceThresholdK; f.threshold = t; return f; }
+    static FeatureSelection None() { return FeatureSelection(); }
+};
+
+// nalgebra_sparse::CsrMatrix<T> as the reference holds it (usize offsets/indices, typed values).
+template <typename T>
+struct CsrMatrix {
+    std::size_t nrows = 0, ncols = 0;
+    std::vector<std::uint64_t> row_offsets, col_indices;
+    std::vector<T> values;
+};
+template <typename T> struct DTypeOf;
+template <> struct DTypeOf<std::int8_t> { static constexpr int v = SRX_I8; };
+template <> struct DTypeOf<std::int16_t> { static constexpr int v = SRX_I16; };
+template <> struct DTypeOf<std::int32_t> { static constexpr int v = SRX_I32; };
+template <> struct DTypeOf<std::uint8_t> { static constexpr int v = SRX_U8; };
+template <> struct DTypeOf<std::uint16_t> { static constexpr int v = SRX_U16; };
+template <> struct DTypeOf<std::uint32_t> { static constexpr int v = SRX_U32; };
+template <> struct DTypeOf<float> { static constexpr int v = SRX_F32; };
+template <> struct DTypeOf<double> { static constexpr int v = SRX_F64; };
+
+struct Array2 {                                                  // ndarray::Array2<f64>, row-major
+    std::size_t nrows = 0, ncols = 0;
+    std::vector<double> data;
+    double operator()(std::size_t r, std::size_t c) const { return data[r * ncols + c]; }
+};
+
+class Context {
+public:
+    explicit Context(int device_id = 0) {
+        int rc = srx_ctx_create(device_id, &h_);
+        if (rc != SRX_OK) throw Error(rc, srx_last_error(nullptr));
+    }
+    ~Context() { srx_ctx_destroy(h_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    srx_ctx* handle() const { return h_; }
+    void check(int rc) const {
+        if (rc != SRX_OK) throw Error(rc, srx_last_error(h_));
+    }
+
+private:
+    srx_ctx* h_ = nullptr;
+};
+
+// anndata_memory::IMAnnData reduced to what the path touches: X (device-resident), names, obsm/varm.
+class IMAnnData {
+public:
+    template <typename T>
+    static IMAnnData new_basic(Context& ctx, const CsrMatrix<T>& x, std::vector<std::string> obs_names,
+                               std::vector<std::string> var_names, int store = SRX_STORE_AUTO) {
+        IMAnnData a(ctx);
+        srx_csr h{x.nrows, x.ncols, x.values.size(), x.row_offsets.data(), x.col_indices.data(),
+                  const_cast<T*>(x.values.data()), DTypeOf<T>::v};
+        ctx.check(srx_matrix_upload(ctx.handle(), &h, store, &a.x_));
+        a.row_offsets_ = x.row_offsets;
+        a.col_indices_ = x.col_indices;
+        a.obs_names_ = std::move(obs_names);
+        a.var_names_ = std::move(var_names);
+        return a;
+    }
+    IMAnnData(IMAnnData&& o) noexcept : ctx_(o.ctx_) { *this = std::move(o); }
+    IMAnnData& operator=(IMAnnData&& o) noexcept {
+        std::swap(x_, o.x_);
+        row_offsets_ = std::move(o.row_offsets_);
+        col_indices_ = std::move(o.col_indices_);
+        obs_names_ = std::move(o.obs_names_);
+        var_names_ = std::move(o.var_names_);
+        obsm_ = std::move(o.obsm_);
+        varm_ = std::move(o.varm_);
+        return *this;
+    }
+    ~IMAnnData() { srx_matrix_free(x_); }
+
+    std::size_t n_obs() const { return info().n_rows; }
+    std::size_t n_vars() const { return info().n_cols; }
+    srx_mat* x() const { return x_; }
+    Context& ctx() const { return *ctx_; }
+    srx_mat_info info() const {
+        srx_mat_info i{};
+        ctx_->check(srx_matrix_info(x_, &i));
+        return i;
+    }
+    // x().get_data(): the current values as the DynCsrMatrix variant X now is (F32 or F64)
+    bool x_is_f64() const { return info().dtype != SRX_F32; }
+    CsrMatrix<double> x_f64() const {
+        CsrMatrix<double> m;
+        auto i = info();
+        m.nrows = i.n_rows;
+        m.ncols = i.n_cols;
+        m.row_offsets = row_offsets_;
+        m.col_indices = col_indices_;
+        m.values.resize(i.nnz);
+        ctx_->check(srx_matrix_download_values(x_, m.values.data(), SRX_F64));
+        return m;
+    }
+    IMAnnData deep_clone() const {                               // processing/mod.rs:315,330
+        IMAnnData c(*ctx_);
+        ctx_->check(srx_matrix_clone(x_, &c.x_));
+        c.row_offsets_ = row_offsets_;
+        c.col_indices_ = col_indices_;
+        c.obs_names_ = obs_names_;
+        c.var_names_ = var_names_;
+        c.obsm_ = obsm_;
+        c.varm_ = varm_;
+        return c;
+    }
+    std::map<std::string, Array2>& obsm() { return obsm_; }
+    std::map<std::string, Array2>& varm() { return varm_; }
+
+private:
+    explicit IMAnnData(Context& ctx) : ctx_(&ctx) {}
+    Context* ctx_;
+    srx_mat* x_ = nullptr;
+    std::vector<std::uint64_t> row_offsets_, col_indices_;
+    std::vector<std::string> obs_names_, var_names_;
+    std::map<std::string, Array2> obsm_, varm_;
+};
+
+namespace memory {
+
+namespace statistics {                                           // src/memory/statistics/mod.rs:10-46
+inline std::size_t len(const IMAnnData& a, Direction d) { return d == Direction::Row ? a.n_obs() : a.n_vars(); }
+inline std::vector<std::uint32_t> compute_number(const IMAnnData& a, Direction d) {
+    std::vector<std::uint32_t> v(len(a, d));
+    a.ctx().check(srx_compute_number(a.x(), (int)d, v.data()));
+    return v;
+}
+inline std::vector<double> compute_sum(const IMAnnData& a, Direction d) {
+    std::vector<double> v(len(a, d));
+    a.ctx().check(srx_compute_sum(a.x(), (int)d, v.data()));
+    return v;
+}
+inline std::vector<double> compute_variance(const IMAnnData& a, Direction d) {
+    std::vector<double> v(len(a, d));
+    a.ctx().check(srx_compute_variance(a.x(), (int)d, v.data()));
+    return v;
+}
+inline std::vector<double> compute_std_dev(const IMAnnData& a, Direction d) {
+    std::vector<double> v(len(a, d));
+    a.ctx().check(srx_compute_std_dev(a.x(), (int)d, v.data()));
+    return v;
+}
+inline std::pair<std::vector<double>, std::vector<double>> compute_min_max(const IMAnnData& a, Direction d) {
+    std::vector<double> mn(len(a, d)), mx(len(a, d));
+    a.ctx().check(srx_compute_min_max(a.x(), (int)d, mn.data(), mx.data()));
+    return {mn, mx};
+}
+}  // namespace statistics
+
+namespace processing {                                           // src/memory/processing/mod.rs:303-332
+inline void normalize_total_inplace(IMAnnData& a, double target_sum, Direction d) {
+    a.ctx().check(srx_normalize_total_inplace(a.x(), target_sum, (int)d));
+}
+inline IMAnnData normalize_total(const IMAnnData& a, double target_sum, Direction d) {
+    IMAnnData n = a.deep_clone();
+    normalize_total_inplace(n, target_sum, d);
+    return n;
+}
+inline void log1p_transform_inplace(IMAnnData& a) { a.ctx().check(srx_log1p_inplace(a.x())); }
+inline IMAnnData log1p_transform(const IMAnnData& a) {
+    IMAnnData n = a.deep_clone();
+    log1p_transform_inplace(n);
+    return n;
+}
+
+namespace dim_red {                                              // src/memory/processing/dim_red/mod.rs
+inline std::vector<std::uint64_t> select_features(const IMAnnData& a, const FeatureSelection& fs) {   // :123-156
+    switch (fs.kind) {
+        case FeatureSelection::HighlyVariableK: {
+            std::vector<std::uint64_t> idx(std::min<std::size_t>(fs.n, a.n_vars()));
+            std::uint64_t n_out = 0;
+            a.ctx().check(srx_select_hvg(a.x(), fs.n, idx.data(), &n_out));
+            idx.resize(n_out);
+            return idx;
+        }
+        case FeatureSelection::VarianceThresholdK: {
+            auto var = statistics::compute_variance(a, Direction::Column);
+            std::vector<std::uint64_t> idx;
+            for (std::size_t i = 0; i < var.size(); ++i)
+                if (var[i] > fs.threshold) idx.push_back(i);
+            return idx;
+        }
+        case FeatureSelection::NoneK: {
+            std::vector<std::uint64_t> idx(a.n_vars());
+            for (std::size_t i = 0; i < idx.size(); ++i) idx[i] = i;
+            return idx;
+        }
+        default: throw Error(SRX_E_ARG, "this FeatureSelection arm needs the var DataFrame (host-side only)");
+    }
+}
+// pca_inplace(anndata, n_components, center, scale, n_threads, feature_selection, svd_mode) (:24-94);
+// svd_mode (FaerSVD / LapackSVD marker) has no counterpart.  Stores obsm["X_pca"] (:105-106).
+inline srx_pca_info pca_inplace(IMAnnData& a, std::optional<std::size_t> n_components, std::optional<bool> center,
+                                std::optional<bool> scale, std::optional<std::size_t> n_threads,
+                                const FeatureSelection& fs) {
+    auto sel = select_features(a, fs);
+    srx_pca_opts o{};
+    o.n_components = n_components ? (int)*n_components : -1;
+    o.center = center ? (int)*center : -1;
+    o.scale = scale ? (int)*scale : -1;
+    o.n_threads = n_threads ? (int)*n_threads : -1;
+    const std::size_t n_pc = std::min<std::size_t>(n_components.value_or(2), sel.size());    // :52
+    Array2 scores;
+    scores.nrows = a.n_obs();
+    scores.ncols = n_pc;
+    scores.data.resize(scores.nrows * n_pc);
+    srx_pca_info info{};
+    a.ctx().check(srx_pca(a.x(), sel.data(), sel.size(), &o, scores.data.data(), nullptr, nullptr, nullptr, nullptr,
+                          &info));
+    a.obsm()["X_pca"] = std::move(scores);
+    return info;
+}
+}  // namespace dim_red
+}  // namespace processing
+}  // namespace memory
+}  // namespace single_rust

@@ -1,0 +1,164 @@
+// The reference's own tests for the path (src/memory/processing/mod.rs:421-481 test_normalize_total
+// with check_row_sums / check_column_sums; the path's remaining stages have no reference tests),
+// restated against the C++ host mirror singlerust_amd/host/single_rust.hpp.  Same workload shape:
+// 1000 x 100, nnz = nrows*ncols/10 COO draws of Uniform(0, 50) with duplicates summed, f64 values,
+// assert |sum - 1e4| < 1e-6 on every row / column with at least one entry.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+#include "../../singlerust_amd/host/single_rust.hpp"
+
+using namespace single_rust;
+namespace proc = single_rust::memory::processing;
+namespace stats = single_rust::memory::statistics;
+
+static int failures = 0;
+#define EXPECT(cond, ...)                                     \
+    do {                                                      \
+        if (!(cond)) {                                        \
+            ++failures;                                       \
+            std::fprintf(stderr, "FAIL %s:%d: ", __FILE__, __LINE__); \
+            std::fprintf(stderr, __VA_ARGS__);                \
+            std::fprintf(stderr, "\n");                       \
+        }                                                     \
+    } while (0)
+
+// CsrMatrix::from(&CooMatrix): duplicates are summed, columns sorted within a row
+static CsrMatrix<double> create_large_test_data(std::size_t nrows, std::size_t ncols, double sparsity, unsigned seed) {
+    std::mt19937_64 rng(seed);
+    std::uniform_real_distribution<double> value(0.0, 50.0);
+    const std::size_t nnz = (std::size_t)std::llround((double)(nrows * ncols) * (1.0 / sparsity));
+    std::vector<std::map<std::uint64_t, double>> rows(nrows);
+    for (std::size_t t = 0; t < nnz; ++t) {
+        std::size_t r = rng() % nrows, c = rng() % ncols;
+        rows[r][c] += value(rng);
+    }
+    CsrMatrix<double> m;
+    m.nrows = nrows;
+    m.ncols = ncols;
+    m.row_offsets.push_back(0);
+    for (auto& r : rows) {
+        for (auto& kv : r) {
+            m.col_indices.push_back(kv.first);
+            m.values.push_back(kv.second);
+        }
+        m.row_offsets.push_back(m.col_indices.size());
+    }
+    return m;
+}
+
+static std::vector<std::string> names(const char* p, std::size_t n) {
+    std::vector<std::string> v;
+    for (std::size_t i = 0; i < n; ++i) v.push_back(p + std::to_string(i));
+    return v;
+}
+
+static void check_row_sums(const CsrMatrix<double>& csr, double target) {
+    for (std::size_t r = 0; r < csr.nrows; ++r) {
+        if (csr.row_offsets[r] == csr.row_offsets[r + 1]) continue;
+        double s = 0.0;
+        for (auto p = csr.row_offsets[r]; p < csr.row_offsets[r + 1]; ++p) s += csr.values[p];
+        EXPECT(std::fabs(s - target) < 1e-6, "row %zu sum %.12g does not match target sum %g", r, s, target);
+    }
+}
+
+static void check_column_sums(const CsrMatrix<double>& csr, double target) {
+    std::vector<double> sums(csr.ncols, 0.0);
+    std::vector<int> seen(csr.ncols, 0);
+    for (std::size_t p = 0; p < csr.values.size(); ++p) {
+        sums[csr.col_indices[p]] += csr.values[p];
+        seen[csr.col_indices[p]] = 1;
+    }
+    for (std::size_t c = 0; c < csr.ncols; ++c)
+        if (seen[c]) EXPECT(std::fabs(sums[c] - target) < 1e-6, "column %zu sum %.12g does not match %g", c, sums[c], target);
+}
+
+static void test_normalize_total(Context& ctx) {
+    auto x = create_large_test_data(1000, 100, 10.0, 7);
+    IMAnnData adata = IMAnnData::new_basic(ctx, x, names("obs", 1000), names("var", 100));
+    const double target_sum = 1e4;
+
+    IMAnnData normalized = proc::normalize_total(adata, target_sum, Direction::Row);
+    EXPECT(normalized.x_is_f64(), "expected the F64 arm after normalisation");
+    check_row_sums(normalized.x_f64(), target_sum);
+
+    IMAnnData by_col = proc::normalize_total(adata, target_sum, Direction::Column);
+    check_column_sums(by_col.x_f64(), target_sum);
+
+    // the input was not touched by the cloning variants
+    auto sums = stats::compute_sum(adata, Direction::Row);
+    double ref0 = 0.0;
+    for (auto p = x.row_offsets[0]; p < x.row_offsets[1]; ++p) ref0 += x.values[p];
+    EXPECT(sums[0] == ref0, "input modified by normalize_total: %.17g vs %.17g", sums[0], ref0);
+}
+
+static void test_path_end_to_end(Context& ctx) {
+    auto x = create_large_test_data(1000, 100, 10.0, 11);
+    IMAnnData adata = IMAnnData::new_basic(ctx, x, names("obs", 1000), names("var", 100));
+    proc::normalize_total_inplace(adata, 1e4, Direction::Row);
+    proc::log1p_transform_inplace(adata);
+    auto vals = adata.x_f64().values;
+    // spot-check log1p(v * (1e4 / rowsum)) on the first row, two roundings as the reference has them
+    double s = 0.0;
+    for (auto p = x.row_offsets[0]; p < x.row_offsets[1]; ++p) s += x.values[p];
+    for (auto p = x.row_offsets[0]; p < x.row_offsets[1]; ++p) {
+        double want = std::log1p(x.values[p] * (1e4 / s));
+        EXPECT(std::fabs(vals[p] - want) <= 4e-16 * std::fabs(want), "log1p mismatch at %zu: %.17g vs %.17g", (size_t)p,
+               vals[p], want);
+    }
+    auto hv = proc::dim_red::select_features(adata, FeatureSelection::HighlyVariable(40));
+    EXPECT(hv.size() == 40, "HVG count %zu", hv.size());
+    auto var = stats::compute_variance(adata, Direction::Column);
+    for (std::size_t i = 1; i < hv.size(); ++i)
+        EXPECT(var[hv[i - 1]] > var[hv[i]] || (var[hv[i - 1]] == var[hv[i]] && hv[i - 1] < hv[i]),
+               "HVG order broken at %zu", i);
+
+    auto info = proc::dim_red::pca_inplace(adata, 10, {}, {}, {}, FeatureSelection::HighlyVariable(40));
+    const Array2& pcs = adata.obsm().at("X_pca");
+    EXPECT(pcs.nrows == 1000 && pcs.ncols == 10, "X_pca shape %zu x %zu", pcs.nrows, pcs.ncols);
+    EXPECT(info.n_pc == 10 && info.k == 40, "pca info n_pc=%d k=%llu", info.n_pc, (unsigned long long)info.k);
+    // scores are centred and their variances descend
+    double prev = INFINITY;
+    for (std::size_t c = 0; c < pcs.ncols; ++c) {
+        double m = 0.0, q = 0.0;
+        for (std::size_t r = 0; r < pcs.nrows; ++r) m += pcs(r, c);
+        m /= (double)pcs.nrows;
+        for (std::size_t r = 0; r < pcs.nrows; ++r) q += (pcs(r, c) - m) * (pcs(r, c) - m);
+        EXPECT(std::fabs(m) < 1e-8, "PC %zu mean %.3g", c, m);
+        EXPECT(q <= prev * (1 + 1e-9), "PC variances not descending at %zu", c);
+        prev = q;
+    }
+    // defaults: n_components None -> 2 (dim_red/mod.rs:52)
+    IMAnnData again = adata.deep_clone();
+    proc::dim_red::pca_inplace(again, {}, {}, {}, {}, FeatureSelection::None());
+    EXPECT(again.obsm().at("X_pca").ncols == 2, "default n_components");
+}
+
+static void test_errors(Context& ctx) {
+    auto x = create_large_test_data(4, 6, 2.0, 3);
+    IMAnnData tiny = IMAnnData::new_basic(ctx, x, names("obs", 4), names("var", 6));
+    bool threw = false;
+    try {
+        proc::dim_red::pca_inplace(tiny, 2, {}, {}, {}, FeatureSelection::None());   // N < 5 panics in the reference
+    } catch (const Error& e) {
+        threw = e.code == SRX_E_SHAPE;
+    }
+    EXPECT(threw, "PCA on 4 cells must fail with SRX_E_SHAPE");
+}
+
+int main() {
+    try {
+        Context ctx(0);
+        test_normalize_total(ctx);
+        test_path_end_to_end(ctx);
+        test_errors(ctx);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "exception: %s\n", e.what());
+        return 2;
+    }
+    if (failures) return 1;
+    std::puts("host mirror: all checks passed");
+    return 0;
+}
