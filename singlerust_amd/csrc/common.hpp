@@ -79,6 +79,10 @@ struct srx_ctx {
     // pinned host staging for small D2H/H2D blocks
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
+    // asynchronous read-back slots of the PCA driver (residual + status per Rayleigh–Ritz step)
+    static constexpr int kAsyncSlots = 4;
+    double* pin_async = nullptr;             // kAsyncSlots x 2 doubles, pinned
+    hipEvent_t async_ev[kAsyncSlots] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 struct srx_pca_state {           // what the last srx_pca / srx_pipeline left in HBM

@@ -252,6 +252,9 @@ void srx_ctx_destroy(srx_ctx* ctx) {
         }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->pin_async) (void)hipHostFree(ctx->pin_async);
+    for (auto e : ctx->async_ev)
+        if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

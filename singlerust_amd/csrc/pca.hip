@@ -411,8 +411,8 @@ __device__ __forceinline__ double readlane_v(double x, int l) {
 // per pair, no broadcast and no atomics.  Empty slots carry value 0 and index 0.
 constexpr int kFwdThreads = 512;
 template <typename PT> struct FwdCfg;
-template <> struct FwdCfg<float> { static constexpr int kRows = 16, kWavesPerSimd = 4; };   // 2 workgroups / CU
-template <> struct FwdCfg<double> { static constexpr int kRows = 8, kWavesPerSimd = 2; };   // 1 workgroup / CU
+template <> struct FwdCfg<float> { static constexpr int kRows = 8, kWavesPerSimd = 4, kStage = 8; };   // 2 workgroups / CU
+template <> struct FwdCfg<double> { static constexpr int kRows = 8, kWavesPerSimd = 2, kStage = 4; };   // 1 workgroup / CU
 
 template <typename PT, int S>
 struct FwdRot {
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(kFwdThreads, FwdCfg<PT>::kWavesPerSimd) void k_spmm
     int nt, int k, const PT* __restrict__ P, const PT* __restrict__ cvec, PT* __restrict__ Y) {
     constexpr int kRows = FwdCfg<PT>::kRows;            // rows per 16-lane group
     constexpr int kRowsPerWg = (kFwdThreads / 16) * kRows;
-    constexpr int kStage = 4;                           // rows whose (index, value) chunks are in flight together
+    constexpr int kStage = FwdCfg<PT>::kStage;          // rows whose (index, value) chunks are in flight together
     extern __shared__ double lds_raw[];
     PT* panel = reinterpret_cast<PT*>(lds_raw);
     const int q = threadIdx.x & 15;
@@ -1011,6 +1011,228 @@ __global__ __launch_bounds__(1024) void k_col_resid(const double* __restrict__ A
     }
 }
 
+// ---- l x l algebra of the subspace iteration, on the device ---------------------------------------
+// One workgroup each; they exist so that a whole PCA is ONE uninterrupted stream of launches: with
+// the l x l Cholesky / eigen-solves on the host every sweep cost two or three stream drains plus
+// whatever the host cores happened to be doing (measured: 3.5 ms per pipeline step on an idle box,
+// 17 ms on a busy one).  Status bits are OR-ed into *status and read back with the residual.
+constexpr int kStatChol = 1, kStatEig = 2;
+constexpr size_t kCholLds = (2 * L * (L + 1) + L) * sizeof(double);
+constexpr size_t kJacobiLds = (2 * L * (L + 1) + L + 32) * sizeof(double) + 2 * L * sizeof(int);
+
+// Start block: counter-based N(0,1) entries, deterministic in (seed, gene slot, column).
+__device__ __forceinline__ uint64_t dmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ void k_init_block(uint64_t seed, int k, int l_act, double* __restrict__ Wp) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= k * L) return;
+    const int j = e / L, cc = e % L;
+    double v = 0.0;
+    if (cc < l_act) {
+        const uint64_t base = dmix64(seed ^ dmix64((uint64_t)j));
+        const uint64_t h1 = dmix64(base + 2 * (uint64_t)cc), h2 = dmix64(base + 2 * (uint64_t)cc + 1);
+        const double u1 = ((double)(h1 >> 11) + 0.5) / 9007199254740992.0;
+        const double u2 = ((double)(h2 >> 11) + 0.5) / 9007199254740992.0;
+        v = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+    }
+    Wp[e] = v;
+}
+
+// Rinv = R^-1 with G = R^T R (upper Cholesky of the leading n x n block of G, ld = L); entries outside
+// the leading block are 0.  One wave; lane i owns column i; left-looking rows, then back-substitution.
+__global__ __launch_bounds__(64) void k_chol_inv(const double* __restrict__ G, int n, double* __restrict__ Rinv,
+                                                 int* __restrict__ status) {
+    // every loop below has wave-uniform bounds (entries outside the triangles are kept at 0 instead of
+    // being skipped), so the LDS reads pipeline; one reciprocal per row instead of one division per entry
+    extern __shared__ double lds_raw[];
+    double (*R)[L + 1] = reinterpret_cast<double (*)[L + 1]>(lds_raw);
+    double (*X)[L + 1] = reinterpret_cast<double (*)[L + 1]>(lds_raw + L * (L + 1));
+    double* dinv = lds_raw + 2 * L * (L + 1);
+    const int i = threadIdx.x;
+    for (int r = 0; r < L; ++r) {
+        R[r][i] = 0.0;
+        X[r][i] = 0.0;
+    }
+    __syncthreads();
+    bool bad = false;
+    for (int j = 0; j < n; ++j) {
+        double t = (i < n) ? G[(size_t)j * L + i] : 0.0;
+        double t1 = 0.0, t2 = 0.0, t3 = 0.0;         // four chains: the f64 FMA latency is not the critical path
+        int kk = 0;
+        for (; kk + 4 <= j; kk += 4) {
+            t -= R[kk][j] * R[kk][i];
+            t1 -= R[kk + 1][j] * R[kk + 1][i];
+            t2 -= R[kk + 2][j] * R[kk + 2][i];
+            t3 -= R[kk + 3][j] * R[kk + 3][i];
+        }
+        for (; kk < j; ++kk) t -= R[kk][j] * R[kk][i];
+        t += (t1 + t2) + t3;
+        const double tj = __shfl(t, j);
+        if (!(tj > 0.0)) bad = true;
+        const double inv = rsqrt(tj);
+        R[j][i] = (i >= j && i < n) ? t * inv : 0.0;
+        if (i == j) dinv[j] = inv;
+        __syncthreads();
+    }
+    // column i of X solves R X = I (upper triangular), bottom row first; X[r][i] = 0 for r > i falls out
+    for (int r = n - 1; r >= 0; --r) {
+        double sacc = (r == i) ? 1.0 : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int kk = r + 1;
+        for (; kk + 4 <= n; kk += 4) {
+            sacc -= R[r][kk] * X[kk][i];
+            s1 -= R[r][kk + 1] * X[kk + 1][i];
+            s2 -= R[r][kk + 2] * X[kk + 2][i];
+            s3 -= R[r][kk + 3] * X[kk + 3][i];
+        }
+        for (; kk < n; ++kk) sacc -= R[r][kk] * X[kk][i];
+        X[r][i] = (sacc + (s1 + s2) + s3) * dinv[r];
+    }
+    for (int r = 0; r < L; ++r) Rinv[(size_t)r * L + i] = (bad || r >= n || i >= n) ? 0.0 : X[r][i];
+    if (bad && i == 0) atomicOr(status, kStatChol);
+}
+
+// Eigen-decomposition of the symmetric leading n x n block of H (ld = L) by two-sided cyclic Jacobi,
+// 32 disjoint rotations per round in the round-robin ordering (63 rounds = one sweep).  Thread (I, J)
+// owns the 2 x 2 block (pair I) x (pair J) and applies J_I^T . B . J_J in place: the rotated matrix
+// stays exactly symmetric and a round needs two barriers.  The projected matrices of successive
+// Rayleigh–Ritz steps are close to diagonal, so late solves take two or three sweeps.
+// U (L x L, row-major) receives eigenvector c in COLUMN c, eigenvalues descending; rows / columns
+// >= n are 0, theta[c >= n] = 0.
+__device__ __forceinline__ void jacobi_pair(int m, int r, int& p, int& q) {
+    if (m == 0) {
+        p = L - 1;
+        q = r;
+    } else {
+        p = (r + m) % (L - 1);
+        q = (r + (L - 1) - m) % (L - 1);
+    }
+}
+__global__ __launch_bounds__(1024) void k_jacobi_eig(const double* __restrict__ H, int n, double* __restrict__ U,
+                                                     double* __restrict__ theta, int* __restrict__ status) {
+    static_assert(L == 64, "the block mapping below is written for l = 64");
+    extern __shared__ double lds_raw[];
+    double (*A)[L + 1] = reinterpret_cast<double (*)[L + 1]>(lds_raw);
+    double (*V)[L + 1] = reinterpret_cast<double (*)[L + 1]>(lds_raw + L * (L + 1));
+    double (*cs)[2] = reinterpret_cast<double (*)[2]>(lds_raw + 2 * L * (L + 1));
+    double (*red)[16] = reinterpret_cast<double (*)[16]>(lds_raw + 2 * L * (L + 1) + L);
+    int* rank = reinterpret_cast<int*>(lds_raw + 2 * L * (L + 1) + L + 32);
+    int (*pq)[2] = reinterpret_cast<int (*)[2]>(rank + L);
+    const int tid = threadIdx.x, I = tid >> 5, J = tid & 31;
+    for (int e = tid; e < L * L; e += 1024) {
+        const int a = e >> 6, b = e & 63;
+        A[a][b] = (a < n && b < n) ? 0.5 * (H[(size_t)a * L + b] + H[(size_t)b * L + a]) : 0.0;
+        V[a][b] = a == b ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    bool done = false;
+    for (int sweep = 0; sweep < 30 && !done; ++sweep) {
+        double off = 0.0, dg = 0.0;
+        for (int e = tid; e < L * L; e += 1024) {
+            const int a = e >> 6, b = e & 63;
+            const double x = A[a][b];
+            if (a < b) off += x * x;
+            if (a == b) dg += x * x;
+        }
+        off = wave_sum(off);
+        dg = wave_sum(dg);
+        if ((tid & 63) == 0) {
+            red[0][tid >> 6] = off;
+            red[1][tid >> 6] = dg;
+        }
+        __syncthreads();
+        off = dg = 0.0;
+        for (int w = 0; w < 16; ++w) {
+            off += red[0][w];
+            dg += red[1][w];
+        }
+        __syncthreads();
+        if (!(off > 1e-30 * dg)) {            // also leaves on NaN (reported through the residual)
+            done = true;
+            break;
+        }
+        for (int r = 0; r < L - 1; ++r) {
+            if (tid < L / 2) {
+                int p, q;
+                jacobi_pair(tid, r, p, q);
+                pq[tid][0] = p;
+                pq[tid][1] = q;
+                // rotation annihilating a_pq, division-free: with d = a_qq - a_pp, b = 2 a_pq,
+                // h = hypot(b, d), u = |d| + h:  c = u / hypot(u, b),  s = sgn(d b) |b| / hypot(u, b)
+                const double b = 2.0 * A[p][q], d = A[q][q] - A[p][p];
+                double c = 1.0, sn = 0.0;
+                if (b != 0.0) {
+                    const double u = fabs(d) + sqrt(b * b + d * d);
+                    const double wv = rsqrt(u * u + b * b);
+                    c = u * wv;
+                    sn = ((d >= 0.0) == (b >= 0.0) ? fabs(b) : -fabs(b)) * wv;
+                }
+                cs[tid][0] = c;
+                cs[tid][1] = sn;
+            }
+            __syncthreads();
+            const int p = pq[I][0], q = pq[I][1], rr = pq[J][0], ss = pq[J][1];
+            const double cP = cs[I][0], sP = cs[I][1], cR = cs[J][0], sR = cs[J][1];
+            const double b00 = A[p][rr], b01 = A[p][ss], b10 = A[q][rr], b11 = A[q][ss];
+            const double t00 = cP * b00 - sP * b10, t01 = cP * b01 - sP * b11;
+            const double t10 = sP * b00 + cP * b10, t11 = sP * b01 + cP * b11;
+            double n00 = cR * t00 - sR * t01, n01 = sR * t00 + cR * t01;
+            double n10 = cR * t10 - sR * t11, n11 = sR * t10 + cR * t11;
+            if (I == J) n01 = n10 = 0.0;      // the pivot, annihilated exactly
+            A[p][rr] = n00;
+            A[p][ss] = n01;
+            A[q][rr] = n10;
+            A[q][ss] = n11;
+            // eigenvectors: V <- V J_J on rows 2I, 2I+1
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = 2 * I + h;
+                const double v0 = V[row][rr], v1 = V[row][ss];
+                V[row][rr] = cR * v0 - sR * v1;
+                V[row][ss] = sR * v0 + cR * v1;
+            }
+            __syncthreads();
+        }
+    }
+    if (!done && tid == 0) atomicOr(status, kStatEig);
+    // descending order; padded indices (>= n) go last
+    if (tid < L) {
+        const double mine = A[tid][tid];
+        int rk = 0;
+        for (int j = 0; j < L; ++j) {
+            if (j == tid) continue;
+            const double other = A[j][j];
+            bool before;
+            if (tid >= n) before = (j < n) || j < tid;
+            else before = (j < n) && (other > mine || (other == mine && j < tid));
+            rk += before ? 1 : 0;
+        }
+        rank[tid] = rk;
+        theta[rk] = tid < n ? mine : 0.0;
+    }
+    __syncthreads();
+    for (int e = tid; e < L * L; e += 1024) {
+        const int a = e >> 6, b = e & 63;
+        U[(size_t)a * L + rank[b]] = (a < n && b < n) ? V[a][b] : 0.0;
+    }
+}
+
+// out[0] = max_{i < n_pc} rho_i / theta_i (NaN-propagating), out[1] = status bits
+__global__ void k_resid_scalar(const double* __restrict__ rho, const double* __restrict__ theta, int n_pc,
+                               const int* __restrict__ status, double* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    double resid = 0.0;
+    for (int i = 0; i < n_pc; ++i) {
+        const double r = theta[i] > 0 ? rho[i] / theta[i] : rho[i];
+        if (!(r <= resid)) resid = r;
+    }
+    out[0] = resid;
+    out[1] = (double)*status;
+}
+
 // scores[i][c] = Y[i][c] for c < n_pc (row-major f64, the obsm["X_pca"] layout).
 template <typename YT>
 __global__ void k_scores(const YT* __restrict__ Y, uint64_t n_rows, int n_pc, double* __restrict__ out) {
@@ -1270,8 +1492,10 @@ static int32_t launch_gram(srx_ctx* ctx, const Tiled& g, double* G) {
     constexpr int kGramWaves = GramCfg<VT>::kWavesPerWg;
     const size_t lds = (size_t)KG * KG * sizeof(double) +
                        (size_t)kGramWaves * (2 * kGramCap * sizeof(GramEntry<VT>));
-    // algorithmic bytes: every 128-tile is walked once per tile pair it belongs to (n_t + 1 pairs)
-    ProfScope ps(ctx, SRX_K_GRAM, ((double)g.nnz * (4.0 + sizeof(VT)) + (double)ntg * g.n_rows * 8.0) * (ntg + 1) / 2.0 +
+    // algorithmic bytes: the compacted matrix (index + value + per-tile row pointers) read ONCE and G written
+    // once.  The kernel re-reads every 128-tile once per tile pair it belongs to (n_t + 1 times, from L2 /
+    // Infinity Cache for the most part): that shows up in the PMC traffic, not here.
+    ProfScope ps(ctx, SRX_K_GRAM, (double)g.nnz * (4.0 + sizeof(VT)) + (double)ntg * g.n_rows * 8.0 +
                                       (double)g.k * g.k * 8.0);
     SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_sparse<VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_gram_sparse<VT>), dim3((unsigned)(n_rb * n_pairs)), dim3(kGramWaves * kWave), lds, ctx->stream, g.tptr,
@@ -1341,42 +1565,78 @@ template <typename Apply>
 static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, const Resolved& o, Apply&& apply,
                                 std::vector<double>& theta, double& resid, int& iters, bool& converged) {
     const size_t kl = (size_t)k * L;
-    // start block: counter-based N(0,1) entries (deterministic in (seed, gene slot, column))
-    std::vector<double> hW(kl, 0.0);
-    for (int j = 0; j < k; ++j)
-        for (int cc = 0; cc < l_act; ++cc) {
-            uint64_t h1 = mix64(mix64(o.seed ^ mix64((uint64_t)j)) + 2 * (uint64_t)cc);
-            uint64_t h2 = mix64(mix64(o.seed ^ mix64((uint64_t)j)) + 2 * (uint64_t)cc + 1);
-            double u1 = ((double)(h1 >> 11) + 0.5) / 9007199254740992.0;
-            double u2 = ((double)(h2 >> 11) + 0.5) / 9007199254740992.0;
-            hW[(size_t)j * L + cc] = std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
-        }
-    SRX_TRY(h2d(ctx, w.Wp, hW.data(), kl * 8));
+    constexpr int kSlots = srx_ctx::kAsyncSlots;
+    if (!ctx->pin_async) {
+        SRX_HIP(ctx, hipHostMalloc((void**)&ctx->pin_async, kSlots * 2 * sizeof(double), hipHostMallocDefault));
+        for (auto& e : ctx->async_ev) SRX_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    int* d_status;
+    double* d_res;
+    SRX_TRY(scratch(ctx, "pca_status", 256, (void**)&d_status));
+    SRX_TRY(scratch(ctx, "pca_res", kSlots * 2 * sizeof(double), (void**)&d_res));
+    SRX_HIP(ctx, hipMemsetAsync(d_status, 0, 256, ctx->stream));
+    SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_jacobi_eig, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)kJacobiLds));
+    SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_chol_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCholLds));
 
-    std::vector<double> hHG(2 * L * L), hM(L * L), hU(L * L), hRho(L);
-    std::vector<double> act((size_t)l_act * l_act), ev(l_act), evec((size_t)l_act * l_act);
-    theta.assign(L, 0.0);
-    double* hG = hHG.data() + L * L;
+    hipLaunchKernelGGL(k_init_block, dim3((unsigned)((kl + 255) / 256)), dim3(256), 0, ctx->stream, o.seed, k, l_act, w.Wp);
 
-    // orthonormalise Wp -> W  (CholeskyQR: G = Wp^T Wp = R^T R, W = Wp R^-1)
+    // Everything below only ENQUEUES work: the l x l factorisations run on the device, and the one
+    // number the host needs per Rayleigh–Ritz step (the residual) comes back through a pinned slot
+    // and an event, read one step late so that the stream never drains.
+
+    // orthonormalise Wp -> W  (CholeskyQR: G = Wp^T Wp = R^T R, W = Wp R^-1); G is in dHG + L*L
     auto orth = [&](bool have_gram) -> int32_t {
-        if (!have_gram) {
-            SRX_TRY(gram2(ctx, w, w.Wp, w.Wp, k));
-            SRX_TRY(d2h(ctx, hHG.data(), w.dHG, 2 * L * L * 8));
-        }
-        if (!smallmat::chol_upper_inverse(l_act, L, hG, hM.data()))
-            return fail(ctx, SRX_E_NOCONV, "pca: block lost rank (Cholesky pivot <= 0)");
-        SRX_TRY(h2d(ctx, w.dM, hM.data(), L * L * 8));
+        if (!have_gram) SRX_TRY(gram2(ctx, w, w.Wp, w.Wp, k));
+        hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(64), kCholLds, ctx->stream, w.dHG + L * L, l_act, w.dM, d_status);
         hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.Wp, w.dM, k, w.W);
         SRX_HIP(ctx, hipGetLastError());
         return SRX_OK;
     };
+    // one Rayleigh–Ritz step on span(W): Wp = C W, H = W^T Wp = U diag(theta) U^T, Ritz vectors
+    // A2 = W U, residuals || C v_i - theta_i v_i || in f64; slot <- (residual, status)
+    auto ritz = [&](int slot) -> int32_t {
+        SRX_TRY(apply(w.W, w.Wp));
+        SRX_TRY(gram2(ctx, w, w.W, w.Wp, k));
+        hipLaunchKernelGGL(k_jacobi_eig, dim3(1), dim3(1024), kJacobiLds, ctx->stream, w.dHG, l_act, w.dM2, w.dTheta,
+                           d_status);
+        hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.Wp, w.dM2, k, w.A1);
+        hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.W, w.dM2, k, w.A2);
+        hipLaunchKernelGGL(k_col_resid, dim3(1), dim3(1024), 0, ctx->stream, w.A1, w.A2, w.dTheta, k, w.dRho, w.dColmax);
+        hipLaunchKernelGGL(k_resid_scalar, dim3(1), dim3(64), 0, ctx->stream, w.dRho, w.dTheta, o.n_pc, d_status,
+                           d_res + 2 * slot);
+        SRX_HIP(ctx, hipGetLastError());
+        SRX_HIP(ctx, hipMemcpyAsync(ctx->pin_async + 2 * slot, d_res + 2 * slot, 2 * sizeof(double),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        SRX_HIP(ctx, hipEventRecord(ctx->async_ev[slot], ctx->stream));
+        return SRX_OK;
+    };
+    // the extra applications of C between two Rayleigh–Ritz steps (cheap dense products only; the
+    // block stays well conditioned: kappa ~ (theta_1/theta_l)^power) and the next CholeskyQR
+    auto advance = [&]() -> int32_t {
+        // continue from the ROTATED block A1 = (C W) U (same span): its columns are close to eigenvectors,
+        // so the next projected matrix is close to diagonal and its Jacobi solve takes 2-3 sweeps, not 8
+        SRX_HIP(ctx, hipMemcpyAsync(w.Wp, w.A1, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        for (int extra = 1; extra < o.power; ++extra) {
+            SRX_TRY(apply(w.Wp, w.A1));
+            SRX_HIP(ctx, hipMemcpyAsync(w.Wp, w.A1, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        return orth(false);
+    };
+    auto collect = [&](int slot, double& r) -> int32_t {
+        SRX_HIP(ctx, hipEventSynchronize(ctx->async_ev[slot]));
+        r = ctx->pin_async[2 * slot];
+        const int st = (int)ctx->pin_async[2 * slot + 1];
+        if (st & kStatChol) return fail(ctx, SRX_E_NOCONV, "pca: block lost rank (Cholesky pivot <= 0)");
+        if (st & kStatEig) return fail(ctx, SRX_E_NOCONV, "pca: l x l eigen-solver did not converge");
+        if (r != r) return fail(ctx, SRX_E_NOCONV, "pca: NaN in the Ritz residual");
+        return SRX_OK;
+    };
+
     SRX_TRY(orth(false));
     SRX_HIP(ctx, hipMemcpyAsync(w.Wp, w.W, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
     SRX_TRY(orth(false));              // CholeskyQR2 on the random start
-
-    // warm-up: the first Ritz residuals are O(1) whatever happens — do not pay an l x l host
-    // eigen-solve (0.8 ms) to learn that
+    // warm-up: the first Ritz residuals are O(1) whatever happens — no Rayleigh–Ritz step to learn that
     for (int sweep = 0; sweep < o.warm; ++sweep) {
         for (int t = 0; t < o.power; ++t) {
             SRX_TRY(apply(t == 0 ? w.W : w.Wp, w.A1));
@@ -1384,47 +1644,44 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         }
         SRX_TRY(orth(false));
     }
+
+    // Step `it` is enqueued before the residual of step it-1 is looked at.  Convergence is geometric, so
+    // the last two residuals predict the next one: when step `it` (already in flight) is expected to
+    // meet the tolerance with a 4x margin nothing is queued behind it; otherwise step it+1 is queued
+    // speculatively and, should step `it` turn out to have converged, simply becomes the (better) answer.
     resid = INFINITY;
     converged = false;
+    double r_prev = INFINITY, r_prev2 = INFINITY;
+    SRX_TRY(ritz(0));
     for (iters = 1; iters <= o.max_iter; ++iters) {
-        SRX_TRY(apply(w.W, w.Wp));
-        // Rayleigh–Ritz on span(W): H = W^T C W, and G = (CW)^T (CW) for the next CholeskyQR
-        SRX_TRY(gram2(ctx, w, w.W, w.Wp, k));
-        SRX_TRY(d2h(ctx, hHG.data(), w.dHG, 2 * L * L * 8));
-        for (int a = 0; a < l_act; ++a)
-            for (int b = 0; b < l_act; ++b) act[(size_t)a * l_act + b] = hHG[a * L + b];
-        if (!smallmat::sym_eig_desc(l_act, act.data(), ev.data(), evec.data()))
-            return fail(ctx, SRX_E_NOCONV, "pca: l x l eigen-solver did not converge");
-        std::fill(hU.begin(), hU.end(), 0.0);
-        std::fill(theta.begin(), theta.end(), 0.0);
-        for (int a = 0; a < l_act; ++a) {
-            theta[a] = ev[a];
-            for (int b = 0; b < l_act; ++b) hU[a * L + b] = evec[(size_t)a * l_act + b];
+        const bool predicted = r_prev2 < INFINITY && r_prev > 0 && r_prev * (r_prev / r_prev2) * 4.0 <= o.tol;
+        const bool spec = !predicted && iters < o.max_iter;
+        if (spec) {
+            SRX_TRY(advance());
+            SRX_TRY(ritz(iters % kSlots));
         }
-        // residuals || C v_i - theta_i v_i || with v_i = W u_i, evaluated on the device in f64
-        SRX_TRY(h2d(ctx, w.dM2, hU.data(), L * L * 8));
-        SRX_TRY(h2d(ctx, w.dTheta, theta.data(), L * 8));
-        hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.Wp, w.dM2, k, w.A1);
-        hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.W, w.dM2, k, w.A2);
-        hipLaunchKernelGGL(k_col_resid, dim3(1), dim3(1024), 0, ctx->stream, w.A1, w.A2, w.dTheta, k, w.dRho, w.dColmax);
-        SRX_HIP(ctx, hipGetLastError());
-        SRX_TRY(d2h(ctx, hRho.data(), w.dRho, L * 8));
-        resid = 0.0;
-        for (int i = 0; i < o.n_pc; ++i) {
-            double r = theta[i] > 0 ? hRho[i] / theta[i] : hRho[i];
-            if (!(r <= resid)) resid = r;   // NaN propagates
+        double r;
+        SRX_TRY(collect((iters - 1) % kSlots, r));
+        resid = r;
+        if (r <= o.tol) {
+            converged = true;
+            if (spec) {
+                ++iters;
+                SRX_TRY(collect((iters - 1) % kSlots, resid));
+            }
+            break;
         }
-        if (resid != resid) return fail(ctx, SRX_E_NOCONV, "pca: NaN in the Ritz residual");
-        if (resid <= o.tol) { converged = true; break; }
-        // extra applications of C before the next Rayleigh–Ritz step (cheap dense products only):
-        // Wp <- C^(power-1) Wp; the block stays well conditioned (kappa ~ (theta_1/theta_l)^power)
-        for (int extra = 1; extra < o.power; ++extra) {
-            SRX_TRY(apply(w.Wp, w.A1));
-            SRX_HIP(ctx, hipMemcpyAsync(w.Wp, w.A1, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        if (!spec) {
+            if (iters == o.max_iter) break;
+            SRX_TRY(advance());
+            SRX_TRY(ritz(iters % kSlots));
         }
-        SRX_TRY(orth(o.power == 1));
+        r_prev2 = r_prev;
+        r_prev = r;
     }
-    if (!converged) iters = o.max_iter;
+    if (!converged && iters > o.max_iter) iters = o.max_iter;
+    theta.assign(L, 0.0);
+    SRX_TRY(d2h(ctx, theta.data(), w.dTheta, L * 8));
     return SRX_OK;
 }
 
