@@ -293,15 +293,34 @@ __global__ __launch_bounds__(256) void k_tcount(const int64_t* __restrict__ indp
     }
 }
 
+// One entry of the 128-tiled (Gram) layout: local column and value side by side, so that the Gram
+// kernel fetches an entry with ONE 8-byte (f32 storage) or 16-byte (f64) load.
+template <typename VT> struct GramPk;
+template <> struct __attribute__((aligned(8))) GramPk<float> { int32_t j; float v; };
+template <> struct __attribute__((aligned(16))) GramPk<double> { int32_t j; int32_t pad_; double v; };
+
+// (tidx, tvals) -> packed entries: only the general (non-fused) compaction route needs it
+template <typename T>
+__global__ void k_pack128(const int32_t* __restrict__ tidx, const T* __restrict__ tvals, uint64_t n,
+                          GramPk<T>* __restrict__ out) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; e < n; e += stride) {
+        GramPk<T> x{};
+        x.j = tidx[e];
+        x.v = tvals[e];
+        out[e] = x;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_tfill(const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx,
                                                const T* __restrict__ vals, const uint32_t* __restrict__ g_bits,
                                                const uint32_t* __restrict__ g_prefix, int n_words, uint64_t n_rows,
                                                int nt128, int nt256, const int64_t* __restrict__ cnt128,
                                                const int64_t* __restrict__ tptr128,
-                                               const int64_t* __restrict__ tptr256, int32_t* __restrict__ tidx128,
-                                               T* __restrict__ tvals128, int32_t* __restrict__ tidx256,
-                                               T* __restrict__ tvals256) {
+                                               const int64_t* __restrict__ tptr256, GramPk<T>* __restrict__ pk128,
+                                               int32_t* __restrict__ tidx256, T* __restrict__ tvals256) {
     extern __shared__ double lds_raw[];
     const SelLds sel = stage_selection(g_bits, g_prefix, n_words, reinterpret_cast<uint32_t*>(lds_raw));
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
@@ -341,8 +360,10 @@ __global__ __launch_bounds__(256) void k_tfill(const int64_t* __restrict__ indpt
                 if (c >= 0) {
                     const int rank = rank0 + __popcll(mask & ((1ull << lane) - 1ull));
                     const T v = vals[p];
-                    tidx128[o128 + rank] = c & 127;
-                    tvals128[o128 + rank] = v;
+                    GramPk<T> e{};
+                    e.j = c & 127;
+                    e.v = v;
+                    pk128[o128 + rank] = e;
                     tidx256[o256 + rank] = c & 255;
                     tvals256[o256 + rank] = v;
                 }
@@ -641,14 +662,25 @@ __global__ void k_t_reduce(const AT* __restrict__ part, const double* __restrict
 // Workgroup = (gene-tile pair (a <= b), row block); LDS holds the 128 x 128 f64 tile (128 KiB,
 // column index XOR-swizzled by the row so that products sharing jb spread over the banks) and a
 // small staging area per wave.  A wave walks its contiguous share of the row block in batches of
-// up to 32 cells whose tile-a and tile-b entries fit the staging area (two contiguous ranges:
-// coalesced loads -> LDS as packed (index, value) pairs).  Each 16-lane group then takes one cell
-// at a time and spreads that cell's la*lb products over its lanes: (ia, ib) = divmod(p, lb) with a
-// group-uniform lb, two staged reads, one LDS f64 atomic at (ja, jb).  [A lane-per-entry walk runs
-// every lane to the longest segment of the wave (19 % utilisation on the bench matrix); flattening
-// the products of the whole batch over the lanes costs ~117 VALU instructions per 64 products for
-// the per-product cell search — profiles/r01_pmc_gram_flattened.md.]  Diagonal pairs compute the
-// full tile.  Per-(row block, pair) partial tiles are summed in fixed order by k_gram_reduce.
+// up to 32 cells whose tile-a and tile-b entries fit the staging area (two contiguous ranges of
+// packed 8-byte (column, value) records: coalesced loads -> LDS).  Each 16-lane group then takes
+// TWO cells at a time and spreads each cell's la*lb products over its lanes: (ia, ib) = divmod(p, lb)
+// with a group-uniform lb, two staged reads, one LDS f64 atomic at (ja, jb) per product.
+//
+// What bounds it (bench_micro/lds_atomic_banks.hip, MI355X): an LDS f64 atomic instruction costs
+// ~9 clk + ~0.26 clk per active lane on random addresses (25 clk for 64 lanes, 10 clk for 8), a
+// staged ds_read_b64 ~4 clk, and every wave-level operation queues behind those of the other 15
+// waves, so one product pass has ~1000 clk of latency.  Hence: full instructions (16-lane groups,
+// not lane-per-entry: 19 % utilisation), entries fetched from LDS not L1 (a global-load variant
+// ran 17.5 ms against 10.7), and two independent cells per pass so that a wave keeps two chains in
+// the LDS queue.  [Flattening the products of the whole batch over the lanes costs ~117 VALU
+// instructions per 64 products for the per-product cell search — profiles/r01_pmc_gram_flattened.md.]
+// Diagonal pairs compute the full tile.  Per-(row block, pair) partial tiles are summed in fixed
+// order by k_gram_reduce.
+// f32 storage: the product is formed in f32 (one rounding of 2^-24, the precision the stored values
+// have anyway) and widened once; f64 storage multiplies in f64.
+__device__ __forceinline__ double gram_product(float a, float b) { return (double)(a * b); }
+__device__ __forceinline__ double gram_product(double a, double b) { return a * b; }
 template <typename VT> struct GramCfg;
 template <> struct GramCfg<float> { static constexpr int kWavesPerWg = 16; };    // 16 x 2048 B of staging
 template <> struct GramCfg<double> { static constexpr int kWavesPerWg = 7; };    //  7 x 4096 B
@@ -656,18 +688,12 @@ constexpr int kGramRows = 32;          // cells per batch (lane l < 32 holds cel
 constexpr int kGramCap = 128;          // staged entries per side (a cell holds <= 128 entries of a tile)
 
 template <typename VT>
-struct __attribute__((aligned(8))) GramEntry {
-    int32_t j;
-    VT v;
-};
-
-template <typename VT>
 __global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
-    const int64_t* __restrict__ tptr, const int32_t* __restrict__ tidx, const VT* __restrict__ tvals, uint64_t n_rows,
-    int ntg, uint64_t rows_per_block, int n_pairs, double* __restrict__ part) {
+    const int64_t* __restrict__ tptr, const GramPk<VT>* __restrict__ tpk, uint64_t n_rows, int ntg,
+    uint64_t rows_per_block, int n_pairs, double* __restrict__ part) {
     constexpr int kWaves = GramCfg<VT>::kWavesPerWg;
     constexpr int kThreads = kWaves * kWave;
-    using Entry = GramEntry<VT>;
+    using Entry = GramPk<VT>;
     constexpr int kStageBytes = 2 * kGramCap * (int)sizeof(Entry);
     static_assert(KG * KG * 8 + kWaves * kStageBytes <= 163840, "LDS budget");
     extern __shared__ double lds_raw[];
@@ -692,9 +718,8 @@ __global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
     const uint64_t w0 = r0 + (uint64_t)wave * per_wave < r1 ? r0 + (uint64_t)wave * per_wave : r1;
     const uint64_t w1 = w0 + per_wave < r1 ? w0 + per_wave : r1;
     const int grp = lane >> 4, q = lane & 15;
-    // Two-deep software pipeline (a wave has only itself — 16 waves per CU, LDS-limited — to hide
-    // HBM latency behind): while batch n is staged and multiplied out of LDS, the entry loads of
-    // batch n+1 and the row pointers of batch n+2 are in flight.
+    // Two-deep software pipeline on the global side: while batch n is staged and multiplied out of
+    // LDS, the entry loads of batch n+1 and the row pointers of batch n+2 are in flight.
     struct Ext {                    // extents of a batch, from its row pointers
         int64_t a0, b0;
         int startA, startB, la, lb, nr, nA, nB;
@@ -733,11 +758,8 @@ __global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
 #pragma unroll
         for (int u = 0; u < kGramCap / kWave; ++u) {
             const int c = u * kWave + lane;
-            const int ca = c < x.nA ? c : 0, cb = c < x.nB ? c : 0;
-            ea[u].j = tidx[x.a0 + ca];
-            ea[u].v = tvals[x.a0 + ca];
-            eb[u].j = tidx[x.b0 + cb];
-            eb[u].v = tvals[x.b0 + cb];
+            ea[u] = tpk[x.a0 + (c < x.nA ? c : 0)];
+            eb[u] = tpk[x.b0 + (c < x.nB ? c : 0)];
         }
     };
     int64_t pal = 0, pbl = 0;
@@ -757,32 +779,46 @@ __global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
         Entry ea_n[kGramCap / kWave], eb_n[kGramCap / kWave];
         load_entries(nxt_x, ea_n, eb_n);
         load_ptrs(rr_n + (uint64_t)nxt_x.nr, pal, pbl);
-        // stage the current batch
+        // stage the current batch with the address arithmetic done ONCE per entry instead of once per
+        // product: the accumulator of (ja, jb) lives at byte  ja*1024 + ((jb ^ (ja & 31)) * 8)  =  P ^ (jb*8)
+        // with P = (ja << 10) | ((ja & 31) << 3)  (the two terms of P and jb*8 < 1024 never carry).
+        // a-side records hold P, b-side records hold jb*8: one XOR per product.
 #pragma unroll
         for (int u = 0; u < kGramCap / kWave; ++u) {
             const int c = u * kWave + lane;
-            if (c < cur.nA) s_a[c] = ea[u];
-            if (c < cur.nB) s_b[c] = eb[u];
+            Entry xa = ea[u], xb = eb[u];
+            xa.j = (xa.j << 10) | ((xa.j & 31) << 3);
+            xb.j = xb.j << 3;
+            if (c < cur.nA) s_a[c] = xa;
+            if (c < cur.nB) s_b[c] = xb;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // group g takes cells g, g+4, g+8, ... of the batch.  A cell's four extents travel in ONE
         // shuffle: startA (8 bits) | startB (8) | la (8) | lb (8), each <= 128 by construction.
+        // The product loop is VALU-issue bound as much as LDS bound (~17 instructions per pass after
+        // the diet below, 32 before): no 64-bit arithmetic, no clamps, one multiply in storage precision.
         const int packed = (cur.startA & 0xff) | ((cur.startB & 0xff) << 8) | (cur.la << 16) | (cur.lb << 24);
+        const char* sa_bytes = reinterpret_cast<const char*>(s_a);
+        const char* sb_bytes = reinterpret_cast<const char*>(s_b);
         for (int rsub = 0; rsub * 4 < cur.nr; ++rsub) {
             const int row = grp + 4 * rsub;                          // group-uniform, < 32
             const unsigned info = (unsigned)__shfl(packed, row, kWave);   // every lane active
-            const int sA = info & 0xff, sB = (info >> 8) & 0xff;
-            const int laR = (info >> 16) & 0xff, lbR = info >> 24;
-            const int np = laR * lbR;                                // 0 for cells past the batch
-            const float rcp = __frcp_rn((float)(lbR > 0 ? lbR : 1));
-            for (int p = q; __any(p < np); p += 16) {
+            const int lbR = info >> 24;
+            const int np = (int)((info >> 16) & 0xff) * lbR;         // 0 for cells past the batch
+            const char* base_a = sa_bytes + (info & 0xff) * (int)sizeof(Entry);
+            const char* base_b = sb_bytes + ((info >> 8) & 0xff) * (int)sizeof(Entry);
+            // 1-ulp reciprocal: (p + 0.5) / lb stays >= 0.5 / 128 away from an integer, p < 2^14
+            const float rcp = __builtin_amdgcn_rcpf((float)(lbR > 0 ? lbR : 1));
+            float pf = (float)q + 0.5f;
+            for (int p = q; __any(p < np); p += 16, pf += 16.0f) {
                 if (p < np) {
-                    const int ia = (int)(((float)p + 0.5f) * rcp);   // p / lbR, exact for p < 2^14
-                    const int ib = p - ia * lbR;
-                    const Entry xa = s_a[sA + ia], xb = s_b[sB + ib];
-                    __hip_atomic_fetch_add(&acc[xa.j * KG + (xb.j ^ (xa.j & 31))], (double)xa.v * (double)xb.v,
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const int ia = (int)(pf * rcp);                  // p / lbR
+                    const int ib = p - __mul24(ia, lbR);             // full-rate 24-bit multiply
+                    const Entry xa = *reinterpret_cast<const Entry*>(base_a + ia * (int)sizeof(Entry));
+                    const Entry xb = *reinterpret_cast<const Entry*>(base_b + ib * (int)sizeof(Entry));
+                    double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa.j ^ xb.j));
+                    __hip_atomic_fetch_add(dst, gram_product(xa.v, xb.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
@@ -829,62 +865,77 @@ __global__ void k_gram_finish(double* __restrict__ G, const double* __restrict__
     if (e >= (uint64_t)k * k) return;
     int i = (int)(e / k), j = (int)(e % k);
     double g = G[e];
-    if (cen) g -= n_cells * mu[i] * mu[j];
+    if (cen) g -= n_cells * (mu[i] * mu[j]);     // (mu_i mu_j) first: C stays EXACTLY symmetric, k_dense_apply reads it transposed
     G[e] = d[i] * d[j] * g;
 }
 
-// Wp += C[:, krange] W[krange, :] for the dense symmetric k x k matrix C and a k x 64 block (f64).
-// Workgroup = (64-row block, K split): 64 x 64 outputs, 4 x 4 per thread, K staged through LDS 32
-// at a time; the K splits are combined with f64 global atomics into the zeroed Wp (split-K keeps
-// all 256 CUs busy on a matrix that only has k/64 = 32 row blocks).
-constexpr int kDenseSplit = 8;
-__global__ __launch_bounds__(256) void k_dense_apply(const double* __restrict__ C, const double* __restrict__ W, int k,
-                                                     double* __restrict__ Wp) {
-    constexpr int BM = 64, BK = 32;
-    __shared__ double sC[BM][BK + 1];
-    __shared__ double sW[BK][L];
-    const int row0 = blockIdx.x * BM;
-    const int kchunk = (((k + kDenseSplit - 1) / kDenseSplit) + BK - 1) / BK * BK;
+// Wp += C[:, krange] W[krange, :] for the dense SYMMETRIC k x k matrix C and a k x 64 block (f64), on the
+// f64 matrix cores.  One wave = 32 output rows x 64 columns x one K slice: eight v_mfma_f64_16x16x4
+// accumulators.  Both operands are read straight from global memory in fragment order with no LDS
+// staging: lane l of the A fragment needs C[row0 + (l & 15)][kk + (l >> 4)], which by symmetry is
+// C[kk + (l >> 4)][row0 + (l & 15)] — 16 consecutive doubles per K index, fully coalesced; the B
+// fragment W[kk + (l >> 4)][16 t + (l & 15)] is coalesced as it stands.  The K slices (split-K 16:
+// ~1000 waves for k = 2000, one per SIMD) are combined with f64 atomics into the zeroed Wp.
+// C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg (not the f32 map).
+constexpr int kDenseSplit = 16;
+typedef double dvec4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void k_dense_apply(const double* __restrict__ C, const double* __restrict__ W, int k,
+                                                    double* __restrict__ Wp) {
+    const int lane = threadIdx.x;
+    const int li = lane & 15, lk = lane >> 4;
+    const int row0 = blockIdx.x * 32;
+    const int kchunk = (((k + kDenseSplit - 1) / kDenseSplit) + 3) / 4 * 4;
     const int kbeg = blockIdx.y * kchunk;
     const int kend = kbeg + kchunk < k ? kbeg + kchunk : k;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;     // columns 4tx..4tx+3, rows ty + 16u
-    double acc[4][4];
+    dvec4 acc[2][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int sI = 0; sI < 2; ++sI)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        for (int e = threadIdx.x; e < BM * BK; e += 256) {
-            int r = e / BK, c = e % BK;
-            sC[r][c] = (row0 + r < k && k0 + c < kend) ? C[(size_t)(row0 + r) * k + k0 + c] : 0.0;
+        for (int t = 0; t < 4; ++t) acc[sI][t] = dvec4{0.0, 0.0, 0.0, 0.0};
+    const bool r0ok = row0 + li < k, r1ok = row0 + 16 + li < k;
+    // groups of 4 K-steps (16 K indices), two register buffers: the 24 loads of group g+1 are in flight
+    // while the 32 MFMAs of group g issue (one wave per SIMD: nothing else would hide the latency)
+    struct Frag { double a0[4], a1[4], bq[4][4]; };
+    auto load = [&](Frag& f, int kk) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kr = kk + 4 * u + lk;
+            const bool kok = kr < kend;
+            const double* crow = C + (size_t)(kok ? kr : 0) * k + row0 + li;
+            const double* wrow = W + (size_t)(kok ? kr : 0) * L + li;
+            f.a0[u] = (kok && r0ok) ? crow[0] : 0.0;
+            f.a1[u] = (kok && r1ok) ? crow[16] : 0.0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) f.bq[u][t] = kok ? wrow[16 * t] : 0.0;
         }
-        for (int e = threadIdx.x; e < BK * L; e += 256) {
-            int r = e / L, c = e % L;
-            sW[r][c] = (k0 + r < kend) ? W[(size_t)(k0 + r) * L + c] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll 8
-        for (int kk = 0; kk < BK; ++kk) {
-            double a[4], bb[4];
+    };
+    auto fma = [&](const Frag& f) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] = sC[ty + 16 * u][kk];
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) bb[v] = sW[kk][4 * tx + v];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * bb[v];
-        }
-        __syncthreads();
+            for (int t = 0; t < 4; ++t) {
+                acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a0[u], f.bq[u][t], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a1[u], f.bq[u][t], acc[1][t], 0, 0, 0);
+            }
+    };
+    Frag f0, f1;
+    load(f0, kbeg);
+    for (int kk = kbeg; kk < kend; kk += 32) {
+        load(f1, kk + 16);
+        fma(f0);
+        load(f0, kk + 32);
+        fma(f1);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int r = row0 + ty + 16 * u;
-        if (r < k) {
+    for (int sI = 0; sI < 2; ++sI)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) atomicAdd(&Wp[(size_t)r * L + 4 * tx + v], acc[u][v]);
+        for (int v = 0; v < 4; ++v) {
+            const int r = row0 + 16 * sI + lk + 4 * v;
+            if (r < k) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) atomicAdd(&Wp[(size_t)r * L + 16 * t + li], acc[sI][t][v]);
+            }
         }
-    }
 }
 
 // ---- k x l helper kernels (f64, replicated per rank) --------------------------------------------
@@ -1220,6 +1271,11 @@ __global__ __launch_bounds__(1024) void k_jacobi_eig(const double* __restrict__ 
     }
 }
 
+// sign convention of the components: the largest-|.| entry of each Ritz vector is positive
+__global__ void k_signs(const double* __restrict__ colmax, double* __restrict__ sgn) {
+    sgn[threadIdx.x] = colmax[threadIdx.x] < 0 ? -1.0 : 1.0;
+}
+
 // out[0] = max_{i < n_pc} rho_i / theta_i (NaN-propagating), out[1] = status bits
 __global__ void k_resid_scalar(const double* __restrict__ rho, const double* __restrict__ theta, int n_pc,
                                const int* __restrict__ status, double* __restrict__ out) {
@@ -1260,6 +1316,7 @@ struct Tiled {
     int64_t* tptr = nullptr;   // nt * n_rows + 1
     int32_t* tidx = nullptr;   // local column within the tile
     void* tvals = nullptr;
+    void* tpk = nullptr;       // kt == KG only: GramPk<VT> entries (then tidx / tvals are not filled by the fused route)
 };
 
 static int grid_rows(const srx_ctx* ctx, uint64_t n_rows, int rows_per_block) {
@@ -1371,6 +1428,12 @@ static int32_t alloc_tiled(srx_mat* m, uint64_t N, uint64_t nnz, int k, int kt, 
     t.k = k;
     t.kt = kt;
     t.nt = (k + kt - 1) / kt;
+    if (kt == KG) {
+        const size_t pb = vb == 4 ? sizeof(GramPk<float>) : sizeof(GramPk<double>);
+        SRX_TRY(scratch(ctx, (tag + "pk").c_str(), (nnz + 64) * pb, &t.tpk));
+        SRX_HIP(ctx, hipMemsetAsync((char*)t.tpk + nnz * pb, 0, 64 * pb, ctx->stream));
+        return SRX_OK;
+    }
     SRX_TRY(scratch(ctx, (tag + "idx").c_str(), (nnz + 64) * sizeof(int32_t), (void**)&t.tidx));
     SRX_TRY(scratch(ctx, (tag + "vals").c_str(), (nnz + 64) * vb, &t.tvals));
     SRX_HIP(ctx, hipMemsetAsync(t.tidx + nnz, 0, 64 * sizeof(int32_t), ctx->stream));
@@ -1416,11 +1479,11 @@ static int32_t build_tiled_fused(srx_mat* m, const std::vector<int32_t>& remap, 
     if (is_f32(m))
         hipLaunchKernelGGL((k_tfill<float>), dim3(grid_rows(ctx, N, 4)), dim3(256), sel_lds, ctx->stream, m->d_indptr,
                            m->d_indices, (const float*)m->d_values, d_sel, d_sel + n_words, n_words, N, nt128, nt256,
-                           cnt128, t128.tptr, t256.tptr, t128.tidx, (float*)t128.tvals, t256.tidx, (float*)t256.tvals);
+                           cnt128, t128.tptr, t256.tptr, (GramPk<float>*)t128.tpk, t256.tidx, (float*)t256.tvals);
     else
         hipLaunchKernelGGL((k_tfill<double>), dim3(grid_rows(ctx, N, 4)), dim3(256), sel_lds, ctx->stream, m->d_indptr,
                            m->d_indices, (const double*)m->d_values, d_sel, d_sel + n_words, n_words, N, nt128, nt256,
-                           cnt128, t128.tptr, t256.tptr, t128.tidx, (double*)t128.tvals, t256.tidx, (double*)t256.tvals);
+                           cnt128, t128.tptr, t256.tptr, (GramPk<double>*)t128.tpk, t256.tidx, (double*)t256.tvals);
     SRX_HIP(ctx, hipGetLastError());
     if (ctx->prof_mask & (1u << SRX_K_COMPACT))
         ctx->prof[SRX_K_COMPACT].bytes += (double)total * (4.0 + val_bytes(m)) * 3.0;   // read once, written twice
@@ -1490,16 +1553,15 @@ static int32_t launch_gram(srx_ctx* ctx, const Tiled& g, double* G) {
     double* part;
     SRX_TRY(scratch(ctx, "pca_gpart", n_rb * (size_t)n_pairs * KG * KG * sizeof(double), (void**)&part));
     constexpr int kGramWaves = GramCfg<VT>::kWavesPerWg;
-    const size_t lds = (size_t)KG * KG * sizeof(double) +
-                       (size_t)kGramWaves * (2 * kGramCap * sizeof(GramEntry<VT>));
-    // algorithmic bytes: the compacted matrix (index + value + per-tile row pointers) read ONCE and G written
+    const size_t lds = (size_t)KG * KG * sizeof(double) + (size_t)kGramWaves * (2 * kGramCap * sizeof(GramPk<VT>));
+    // algorithmic bytes: the compacted matrix (8-byte entries + per-tile row pointers) read ONCE and G written
     // once.  The kernel re-reads every 128-tile once per tile pair it belongs to (n_t + 1 times, from L2 /
     // Infinity Cache for the most part): that shows up in the PMC traffic, not here.
-    ProfScope ps(ctx, SRX_K_GRAM, (double)g.nnz * (4.0 + sizeof(VT)) + (double)ntg * g.n_rows * 8.0 +
+    ProfScope ps(ctx, SRX_K_GRAM, (double)g.nnz * sizeof(GramPk<VT>) + (double)ntg * g.n_rows * 8.0 +
                                       (double)g.k * g.k * 8.0);
     SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_sparse<VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_gram_sparse<VT>), dim3((unsigned)(n_rb * n_pairs)), dim3(kGramWaves * kWave), lds, ctx->stream, g.tptr,
-                       g.tidx, (const VT*)g.tvals, g.n_rows, ntg, rpb, n_pairs, part);
+                       (const GramPk<VT>*)g.tpk, g.n_rows, ntg, rpb, n_pairs, part);
     hipLaunchKernelGGL(k_gram_reduce, dim3((KG * KG + 255) / 256, n_pairs), dim3(256), 0, ctx->stream, part, n_rb, n_pairs,
                        ntg, g.k, G);
     SRX_HIP(ctx, hipGetLastError());
@@ -1680,8 +1742,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         r_prev = r;
     }
     if (!converged && iters > o.max_iter) iters = o.max_iter;
-    theta.assign(L, 0.0);
-    SRX_TRY(d2h(ctx, theta.data(), w.dTheta, L * 8));
+    (void)theta;                   // the Ritz values stay in w.dTheta; the caller reads them with its other results
     return SRX_OK;
 }
 
@@ -1719,7 +1780,7 @@ static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const 
         auto apply = [&](const double* Win, double* Wout) -> int32_t {
             ProfScope ps(ctx, SRX_K_DENSE, (double)k * k * 8.0 + 2.0 * k * L * 8.0);
             SRX_HIP(ctx, hipMemsetAsync(Wout, 0, kl * 8, ctx->stream));
-            hipLaunchKernelGGL(k_dense_apply, dim3((k + 63) / 64, kDenseSplit), dim3(256), 0, ctx->stream, C, Win, k, Wout);
+            hipLaunchKernelGGL(k_dense_apply, dim3((k + 31) / 32, kDenseSplit), dim3(64), 0, ctx->stream, C, Win, k, Wout);
             SRX_HIP(ctx, hipGetLastError());
             return SRX_OK;
         };
@@ -1740,19 +1801,11 @@ static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const 
         SRX_TRY(subspace_iterate(ctx, w, k, l_act, o, apply, theta, resid, iters, converged));
     }
 
-    // A2 = W U are the Ritz vectors (ascending-gene row order); sign: largest-|.| entry positive
+    // A2 = W U are the Ritz vectors (ascending-gene row order); sign: largest-|.| entry positive.
+    // scores = Z V (transform, pca/mod.rs:156-185): one forward SpMM with the panel D V.  Everything is
+    // enqueued first; the host copies of (theta, signs, V) are read afterwards, behind the kernels.
     const int n_pc = o.n_pc;
-    std::vector<double> hColmax(L), sgn(L, 1.0), hV(kl);
-    SRX_TRY(d2h(ctx, hColmax.data(), w.dColmax, L * 8));
-    for (int i = 0; i < L; ++i) sgn[i] = hColmax[i] < 0 ? -1.0 : 1.0;
-    SRX_TRY(h2d(ctx, w.dSgn, sgn.data(), L * 8));
-    SRX_TRY(d2h(ctx, hV.data(), w.A2, kl * 8));
-    st.components.assign((size_t)k * n_pc, 0.0);
-    for (int j = 0; j < k; ++j)
-        for (int i = 0; i < n_pc; ++i) st.components[(size_t)j * n_pc + i] = hV[(size_t)j * L + i] * sgn[i];
-    st.evr.assign(theta.begin(), theta.begin() + n_pc);     // eigenvalues of Z^T Z, normalised by the caller
-
-    // scores = Z V  (transform, pca/mod.rs:156-185): one forward SpMM with the panel D V
+    hipLaunchKernelGGL(k_signs, dim3(1), dim3(L), 0, ctx->stream, w.dColmax, w.dSgn);
     hipLaunchKernelGGL((k_make_panel<PT>), dim3(1), dim3(1024), 0, ctx->stream, w.A2, w.d, w.mu, (const double*)w.dSgn, k,
                        o.center, P, cvec);
     SRX_HIP(ctx, hipGetLastError());
@@ -1771,6 +1824,16 @@ static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const 
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL((k_scores<PT>), dim3((unsigned)g), dim3(256), 0, ctx->stream, Y, cc.n_rows, n_pc, st.d_scores);
     SRX_HIP(ctx, hipGetLastError());
+
+    std::vector<double> sgn(L, 1.0), hV(kl);
+    theta.assign(L, 0.0);
+    SRX_TRY(d2h(ctx, hV.data(), w.A2, kl * 8));
+    SRX_TRY(d2h(ctx, theta.data(), w.dTheta, L * 8));
+    SRX_TRY(d2h(ctx, sgn.data(), w.dSgn, L * 8));
+    st.components.assign((size_t)k * n_pc, 0.0);
+    for (int j = 0; j < k; ++j)
+        for (int i = 0; i < n_pc; ++i) st.components[(size_t)j * n_pc + i] = hV[(size_t)j * L + i] * sgn[i];
+    st.evr.assign(theta.begin(), theta.begin() + n_pc);     // eigenvalues of Z^T Z, normalised by the caller
     st.info.n_iter = (uint32_t)(iters + o.warm);
     st.info.residual = resid;
     if (!converged)
@@ -1867,7 +1930,19 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
         CompactCsr cc;
         SRX_TRY(build_compact(m, remap, k, cc));
         SRX_TRY(retile(m, cc, KT, t256));
-        if (need128) SRX_TRY(retile(m, cc, KG, t128));
+        if (need128) {
+            SRX_TRY(retile(m, cc, KG, t128));
+            const size_t pb = is_f32(m) ? sizeof(GramPk<float>) : sizeof(GramPk<double>);
+            SRX_TRY(scratch(ctx, "pca_t128_pk", (t128.nnz + 64) * pb, &t128.tpk));
+            SRX_HIP(ctx, hipMemsetAsync((char*)t128.tpk + t128.nnz * pb, 0, 64 * pb, ctx->stream));
+            if (is_f32(m))
+                hipLaunchKernelGGL((k_pack128<float>), dim3(2048), dim3(256), 0, ctx->stream, t128.tidx,
+                                   (const float*)t128.tvals, t128.nnz, (GramPk<float>*)t128.tpk);
+            else
+                hipLaunchKernelGGL((k_pack128<double>), dim3(2048), dim3(256), 0, ctx->stream, t128.tidx,
+                                   (const double*)t128.tvals, t128.nnz, (GramPk<double>*)t128.tpk);
+            SRX_HIP(ctx, hipGetLastError());
+        }
     }
     st.info = srx_pca_info{};
     st.info.n_cells_global = Ng;
