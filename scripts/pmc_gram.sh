@@ -1,0 +1,10 @@
+# PMC passes over a short bench run, Gram kernel only (development helper)
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+B="python bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY" "SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_LDS_ADDR_CONFLICT"; do
+  i=$((i+1))
+  rm -rf gpurun_out/pmcg$i
+  rocprofv3 --kernel-trace --pmc $set -d gpurun_out/pmcg$i -o g -- $B > gpurun_out/pmcg$i.log 2>&1
+  python profiles/summarize_pmc.py gpurun_out/pmcg$i/g_results.db k_gram_sparse
+done

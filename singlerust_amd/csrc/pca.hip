@@ -1276,8 +1276,10 @@ __global__ void k_signs(const double* __restrict__ colmax, double* __restrict__ 
     sgn[threadIdx.x] = colmax[threadIdx.x] < 0 ? -1.0 : 1.0;
 }
 
-// out[0] = max_{i < n_pc} rho_i / theta_i (NaN-propagating), out[1] = status bits
-__global__ void k_resid_scalar(const double* __restrict__ rho, const double* __restrict__ theta, int n_pc,
+// out[0] = max_{i < n_pc} rho_i / theta_i (NaN-propagating), out[1] = status bits,
+// out[2] = theta[l_act - 1] / theta[n_pc - 1]: the smallest Ritz value of the block over the last wanted
+// one — an upper estimate of the per-application convergence factor of the wanted pairs
+__global__ void k_resid_scalar(const double* __restrict__ rho, const double* __restrict__ theta, int n_pc, int l_act,
                                const int* __restrict__ status, double* __restrict__ out) {
     if (threadIdx.x != 0) return;
     double resid = 0.0;
@@ -1287,6 +1289,7 @@ __global__ void k_resid_scalar(const double* __restrict__ rho, const double* __r
     }
     out[0] = resid;
     out[1] = (double)*status;
+    out[2] = theta[n_pc - 1] > 0 ? theta[l_act - 1] / theta[n_pc - 1] : 1.0;
 }
 
 // scores[i][c] = Y[i][c] for c < n_pc (row-major f64, the obsm["X_pca"] layout).
@@ -1627,15 +1630,15 @@ template <typename Apply>
 static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, const Resolved& o, Apply&& apply,
                                 std::vector<double>& theta, double& resid, int& iters, bool& converged) {
     const size_t kl = (size_t)k * L;
-    constexpr int kSlots = srx_ctx::kAsyncSlots;
+    constexpr int kSlots = srx_ctx::kAsyncSlots, kSlotDoubles = 4;
     if (!ctx->pin_async) {
-        SRX_HIP(ctx, hipHostMalloc((void**)&ctx->pin_async, kSlots * 2 * sizeof(double), hipHostMallocDefault));
+        SRX_HIP(ctx, hipHostMalloc((void**)&ctx->pin_async, kSlots * kSlotDoubles * sizeof(double), hipHostMallocDefault));
         for (auto& e : ctx->async_ev) SRX_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     int* d_status;
     double* d_res;
     SRX_TRY(scratch(ctx, "pca_status", 256, (void**)&d_status));
-    SRX_TRY(scratch(ctx, "pca_res", kSlots * 2 * sizeof(double), (void**)&d_res));
+    SRX_TRY(scratch(ctx, "pca_res", kSlots * kSlotDoubles * sizeof(double), (void**)&d_res));
     SRX_HIP(ctx, hipMemsetAsync(d_status, 0, 256, ctx->stream));
     SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_jacobi_eig, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)kJacobiLds));
@@ -1665,11 +1668,11 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.Wp, w.dM2, k, w.A1);
         hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.W, w.dM2, k, w.A2);
         hipLaunchKernelGGL(k_col_resid, dim3(1), dim3(1024), 0, ctx->stream, w.A1, w.A2, w.dTheta, k, w.dRho, w.dColmax);
-        hipLaunchKernelGGL(k_resid_scalar, dim3(1), dim3(64), 0, ctx->stream, w.dRho, w.dTheta, o.n_pc, d_status,
-                           d_res + 2 * slot);
+        hipLaunchKernelGGL(k_resid_scalar, dim3(1), dim3(64), 0, ctx->stream, w.dRho, w.dTheta, o.n_pc, l_act, d_status,
+                           d_res + kSlotDoubles * slot);
         SRX_HIP(ctx, hipGetLastError());
-        SRX_HIP(ctx, hipMemcpyAsync(ctx->pin_async + 2 * slot, d_res + 2 * slot, 2 * sizeof(double),
-                                    hipMemcpyDeviceToHost, ctx->stream));
+        SRX_HIP(ctx, hipMemcpyAsync(ctx->pin_async + kSlotDoubles * slot, d_res + kSlotDoubles * slot,
+                                    kSlotDoubles * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         SRX_HIP(ctx, hipEventRecord(ctx->async_ev[slot], ctx->stream));
         return SRX_OK;
     };
@@ -1685,63 +1688,78 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         }
         return orth(false);
     };
-    auto collect = [&](int slot, double& r) -> int32_t {
+    auto collect = [&](int slot, double& r, double& ratio) -> int32_t {
         SRX_HIP(ctx, hipEventSynchronize(ctx->async_ev[slot]));
-        r = ctx->pin_async[2 * slot];
-        const int st = (int)ctx->pin_async[2 * slot + 1];
+        r = ctx->pin_async[kSlotDoubles * slot];
+        const int st = (int)ctx->pin_async[kSlotDoubles * slot + 1];
+        ratio = ctx->pin_async[kSlotDoubles * slot + 2];
         if (st & kStatChol) return fail(ctx, SRX_E_NOCONV, "pca: block lost rank (Cholesky pivot <= 0)");
         if (st & kStatEig) return fail(ctx, SRX_E_NOCONV, "pca: l x l eigen-solver did not converge");
         if (r != r) return fail(ctx, SRX_E_NOCONV, "pca: NaN in the Ritz residual");
         return SRX_OK;
+    };
+    // one sweep WITHOUT a Rayleigh–Ritz step: `power` applications of C, then CholeskyQR
+    auto plain_sweep = [&]() -> int32_t {
+        for (int t = 0; t < o.power; ++t) {
+            SRX_TRY(apply(t == 0 ? w.W : w.Wp, w.A1));
+            SRX_HIP(ctx, hipMemcpyAsync(w.Wp, w.A1, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        return orth(false);
     };
 
     SRX_TRY(orth(false));
     SRX_HIP(ctx, hipMemcpyAsync(w.Wp, w.W, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
     SRX_TRY(orth(false));              // CholeskyQR2 on the random start
     // warm-up: the first Ritz residuals are O(1) whatever happens — no Rayleigh–Ritz step to learn that
-    for (int sweep = 0; sweep < o.warm; ++sweep) {
-        for (int t = 0; t < o.power; ++t) {
-            SRX_TRY(apply(t == 0 ? w.W : w.Wp, w.A1));
-            SRX_HIP(ctx, hipMemcpyAsync(w.Wp, w.A1, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        }
-        SRX_TRY(orth(false));
-    }
+    for (int sweep = 0; sweep < o.warm; ++sweep) SRX_TRY(plain_sweep());
 
-    // Step `it` is enqueued before the residual of step it-1 is looked at.  Convergence is geometric, so
-    // the last two residuals predict the next one: when step `it` (already in flight) is expected to
-    // meet the tolerance with a 4x margin nothing is queued behind it; otherwise step it+1 is queued
-    // speculatively and, should step `it` turn out to have converged, simply becomes the (better) answer.
+    // A Rayleigh–Ritz step costs as much as a plain sweep (an l x l Jacobi solve on ONE compute unit),
+    // and convergence is geometric, so Ritz steps are only taken where a decision is due.  After a step
+    // with residual r the number of sweeps still needed is  m = ceil(log(tol / r) / log(rate))  with
+    // rate = the factor measured between the last two steps or, before there are two, the estimate
+    // (theta_l / theta_npc)^power from the Ritz values (an upper bound: theta_l >= theta_{l+1});
+    // m - 1 plain sweeps and one Ritz step follow.  The first half-sweep after a step is queued before
+    // its residual is looked at (it is needed unless the step had already converged), so the stream
+    // only drains when a prediction is being checked — normally once, at the end.
     resid = INFINITY;
     converged = false;
-    double r_prev = INFINITY, r_prev2 = INFINITY;
-    SRX_TRY(ritz(0));
-    for (iters = 1; iters <= o.max_iter; ++iters) {
-        const bool predicted = r_prev2 < INFINITY && r_prev > 0 && r_prev * (r_prev / r_prev2) * 4.0 <= o.tol;
-        const bool spec = !predicted && iters < o.max_iter;
-        if (spec) {
-            SRX_TRY(advance());
-            SRX_TRY(ritz(iters % kSlots));
-        }
-        double r;
-        SRX_TRY(collect((iters - 1) % kSlots, r));
+    iters = 0;                         // sweeps after the warm-up
+    int n_ritz = 0, slot = 0;
+    double r_last = INFINITY, rate_meas = 0.0;
+    int sweeps_since = 0;
+    SRX_TRY(ritz(slot));
+    for (;;) {
+        ++iters;
+        ++n_ritz;
+        const bool first = n_ritz == 1;
+        if (first) SRX_TRY(advance());                 // speculative: completes this sweep
+        double r, ratio;
+        SRX_TRY(collect(slot, r, ratio));
         resid = r;
+        if (getenv("SRX_PCA_TRACE"))
+            fprintf(stderr, "[srx pca] sweep %d (ritz step %d): residual %.3e, theta_l/theta_npc %.3e\n", iters + o.warm,
+                    n_ritz, r, ratio);
         if (r <= o.tol) {
             converged = true;
-            if (spec) {
-                ++iters;
-                SRX_TRY(collect((iters - 1) % kSlots, resid));
-            }
             break;
         }
-        if (!spec) {
-            if (iters == o.max_iter) break;
-            SRX_TRY(advance());
-            SRX_TRY(ritz(iters % kSlots));
-        }
-        r_prev2 = r_prev;
-        r_prev = r;
+        if (iters >= o.max_iter) break;
+        if (r_last < INFINITY && sweeps_since > 0 && r < r_last) rate_meas = std::pow(r / r_last, 1.0 / sweeps_since);
+        double rate = rate_meas > 0.0 ? rate_meas : std::pow(ratio < 1.0 ? ratio : 1.0, (double)o.power);
+        if (!(rate > 1e-8)) rate = 1e-8;
+        if (rate > 0.9) rate = 0.9;
+        int m = (int)std::ceil(std::log(o.tol / r) / std::log(rate) - 1e-9);
+        if (m < 1) m = 1;
+        if (m > 6) m = 6;
+        if (iters + m > o.max_iter) m = o.max_iter - iters;
+        if (!first) SRX_TRY(advance());
+        for (int sI = 1; sI < m; ++sI) SRX_TRY(plain_sweep());
+        iters += m - 1;
+        slot = (slot + 1) % kSlots;
+        SRX_TRY(ritz(slot));
+        r_last = r;
+        sweeps_since = m;
     }
-    if (!converged && iters > o.max_iter) iters = o.max_iter;
     (void)theta;                   // the Ritz values stay in w.dTheta; the caller reads them with its other results
     return SRX_OK;
 }
