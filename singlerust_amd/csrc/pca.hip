@@ -1068,7 +1068,6 @@ __global__ __launch_bounds__(1024) void k_col_resid(const double* __restrict__ A
 // whatever the host cores happened to be doing (measured: 3.5 ms per pipeline step on an idle box,
 // 17 ms on a busy one).  Status bits are OR-ed into *status and read back with the residual.
 constexpr int kStatChol = 1, kStatEig = 2;
-constexpr size_t kCholLds = (2 * L * (L + 1) + L) * sizeof(double);
 constexpr size_t kJacobiLds = (2 * L * (L + 1) + L + 32) * sizeof(double) + 2 * L * sizeof(int);
 
 // Start block: counter-based N(0,1) entries, deterministic in (seed, gene slot, column).
@@ -1093,57 +1092,79 @@ __global__ void k_init_block(uint64_t seed, int k, int l_act, double* __restrict
     Wp[e] = v;
 }
 
-// Rinv = R^-1 with G = R^T R (upper Cholesky of the leading n x n block of G, ld = L); entries outside
-// the leading block are 0.  One wave; lane i owns column i; left-looking rows, then back-substitution.
-__global__ __launch_bounds__(64) void k_chol_inv(const double* __restrict__ G, int n, double* __restrict__ Rinv,
-                                                 int* __restrict__ status) {
-    // every loop below has wave-uniform bounds (entries outside the triangles are kept at 0 instead of
-    // being skipped), so the LDS reads pipeline; one reciprocal per row instead of one division per entry
-    extern __shared__ double lds_raw[];
-    double (*R)[L + 1] = reinterpret_cast<double (*)[L + 1]>(lds_raw);
-    double (*X)[L + 1] = reinterpret_cast<double (*)[L + 1]>(lds_raw + L * (L + 1));
-    double* dinv = lds_raw + 2 * L * (L + 1);
-    const int i = threadIdx.x;
-    for (int r = 0; r < L; ++r) {
-        R[r][i] = 0.0;
-        X[r][i] = 0.0;
+// CholeskyQR, device side: G = R^T R (upper Cholesky of the leading n x n block of G, ld = L), then
+// W = Wp R^-1 by one forward substitution per ROW of Wp (k independent rows) — no explicit inverse.
+//
+// k_chol_factor: one workgroup, right-looking: at step j every thread subtracts a_jr a_jc / a_jj from the
+// trailing elements it owns (one barrier per step).  Rout (L x L, row-major) receives R, zero outside
+// the upper triangle of the leading block; dinv[j] = 1 / R[j][j] (0 for j >= n).
+__global__ __launch_bounds__(1024) void k_chol_factor(const double* __restrict__ G, int n, double* __restrict__ Rout,
+                                                      double* __restrict__ dinv, int* __restrict__ status) {
+    __shared__ double A[L][L + 1];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < L * L; e += 1024) {
+        const int r = e >> 6, c = e & 63;
+        A[r][c] = (r < n && c < n) ? G[(size_t)r * L + c] : 0.0;
     }
     __syncthreads();
     bool bad = false;
     for (int j = 0; j < n; ++j) {
-        double t = (i < n) ? G[(size_t)j * L + i] : 0.0;
-        double t1 = 0.0, t2 = 0.0, t3 = 0.0;         // four chains: the f64 FMA latency is not the critical path
-        int kk = 0;
-        for (; kk + 4 <= j; kk += 4) {
-            t -= R[kk][j] * R[kk][i];
-            t1 -= R[kk + 1][j] * R[kk + 1][i];
-            t2 -= R[kk + 2][j] * R[kk + 2][i];
-            t3 -= R[kk + 3][j] * R[kk + 3][i];
+        const double d = A[j][j];
+        if (!(d > 0.0)) bad = true;
+        const double inv = rsqrt(d), inv2 = inv * inv;
+        if (tid < L) {
+            Rout[(size_t)j * L + tid] = (tid >= j && tid < n) ? A[j][tid] * inv : 0.0;
+            if (tid == j) dinv[j] = inv;
         }
-        for (; kk < j; ++kk) t -= R[kk][j] * R[kk][i];
-        t += (t1 + t2) + t3;
-        const double tj = __shfl(t, j);
-        if (!(tj > 0.0)) bad = true;
-        const double inv = rsqrt(tj);
-        R[j][i] = (i >= j && i < n) ? t * inv : 0.0;
-        if (i == j) dinv[j] = inv;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 1024 * u, r = e >> 6, c = e & 63;
+            if (r > j && c >= r && c < n) A[r][c] -= A[j][r] * A[j][c] * inv2;
+        }
         __syncthreads();
     }
-    // column i of X solves R X = I (upper triangular), bottom row first; X[r][i] = 0 for r > i falls out
-    for (int r = n - 1; r >= 0; --r) {
-        double sacc = (r == i) ? 1.0 : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int kk = r + 1;
-        for (; kk + 4 <= n; kk += 4) {
-            sacc -= R[r][kk] * X[kk][i];
-            s1 -= R[r][kk + 1] * X[kk + 1][i];
-            s2 -= R[r][kk + 2] * X[kk + 2][i];
-            s3 -= R[r][kk + 3] * X[kk + 3][i];
-        }
-        for (; kk < n; ++kk) sacc -= R[r][kk] * X[kk][i];
-        X[r][i] = (sacc + (s1 + s2) + s3) * dinv[r];
+    for (int e = tid; e < L * L; e += 1024) {
+        const int r = e >> 6, c = e & 63;
+        if (r >= n) Rout[e] = 0.0;
     }
-    for (int r = 0; r < L; ++r) Rinv[(size_t)r * L + i] = (bad || r >= n || i >= n) ? 0.0 : X[r][i];
-    if (bad && i == 0) atomicOr(status, kStatChol);
+    if (tid < L && tid >= n) dinv[tid] = 0.0;
+    if (bad && tid == 0) atomicOr(status, kStatChol);
+}
+
+// W[row] R = Wp[row]: w_j = (wp_j - sum_{i<j} w_i R[i][j]) / R[j][j], one thread per row, the row in
+// registers (the j / i loops are fully unrolled: static register indices), R transposed in LDS so that
+// the i-loop of a column reads consecutive words (wave-uniform addresses: broadcast, no conflicts).
+// One wave per workgroup: k / 64 workgroups spread over as many compute units.
+__global__ __launch_bounds__(64) void k_trsm_rows(const double* __restrict__ Wp, const double* __restrict__ R,
+                                                  const double* __restrict__ dinv, int k, double* __restrict__ W) {
+    __shared__ double Rt[L][L];          // Rt[j][i] = R[i][j]
+    __shared__ double di[L];
+    for (int e = threadIdx.x; e < L * L; e += 64) Rt[e & 63][e >> 6] = R[e];
+    di[threadIdx.x] = dinv[threadIdx.x];
+    __syncthreads();
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= k) return;
+    double w[L];
+    const double* src = Wp + (size_t)row * L;
+#pragma unroll
+    for (int j = 0; j < L; ++j) w[j] = src[j];
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        double acc0 = w[j], acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+#pragma unroll
+        for (int i = 0; i + 3 < j; i += 4) {
+            acc0 -= w[i] * Rt[j][i];
+            acc1 -= w[i + 1] * Rt[j][i + 1];
+            acc2 -= w[i + 2] * Rt[j][i + 2];
+            acc3 -= w[i + 3] * Rt[j][i + 3];
+        }
+#pragma unroll
+        for (int i = j & ~3; i < j; ++i) acc0 -= w[i] * Rt[j][i];
+        w[j] = ((acc0 + acc1) + (acc2 + acc3)) * di[j];
+    }
+    double* dst = W + (size_t)row * L;
+#pragma unroll
+    for (int j = 0; j < L; ++j) dst[j] = w[j];
 }
 
 // Eigen-decomposition of the symmetric leading n x n block of H (ld = L) by two-sided cyclic Jacobi,
@@ -1589,7 +1610,7 @@ static uint64_t mix64(uint64_t x) {
 
 struct Work {                   // k x 64 f64 state, replicated per rank
     double *W, *Wp, *T, *A1, *A2, *small, *mu, *d, *gpart;
-    double *dHG, *dM, *dM2, *dTheta, *dRho, *dColmax, *dSgn;
+    double *dHG, *dM, *dM2, *dTheta, *dRho, *dColmax, *dSgn, *dDinv;
 };
 
 static int32_t alloc_work(srx_ctx* ctx, int k, Work& w) {
@@ -1610,6 +1631,7 @@ static int32_t alloc_work(srx_ctx* ctx, int k, Work& w) {
     w.dRho = w.dTheta + L;
     w.dColmax = w.dRho + L;
     w.dSgn = w.dColmax + L;
+    w.dDinv = w.dSgn + L;
     return SRX_OK;
 }
 
@@ -1642,7 +1664,6 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     SRX_HIP(ctx, hipMemsetAsync(d_status, 0, 256, ctx->stream));
     SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_jacobi_eig, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)kJacobiLds));
-    SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_chol_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCholLds));
 
     hipLaunchKernelGGL(k_init_block, dim3((unsigned)((kl + 255) / 256)), dim3(256), 0, ctx->stream, o.seed, k, l_act, w.Wp);
 
@@ -1653,8 +1674,8 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     // orthonormalise Wp -> W  (CholeskyQR: G = Wp^T Wp = R^T R, W = Wp R^-1); G is in dHG + L*L
     auto orth = [&](bool have_gram) -> int32_t {
         if (!have_gram) SRX_TRY(gram2(ctx, w, w.Wp, w.Wp, k));
-        hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(64), kCholLds, ctx->stream, w.dHG + L * L, l_act, w.dM, d_status);
-        hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.Wp, w.dM, k, w.W);
+        hipLaunchKernelGGL(k_chol_factor, dim3(1), dim3(1024), 0, ctx->stream, w.dHG + L * L, l_act, w.dM, w.dDinv, d_status);
+        hipLaunchKernelGGL(k_trsm_rows, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, w.Wp, w.dM, w.dDinv, k, w.W);
         SRX_HIP(ctx, hipGetLastError());
         return SRX_OK;
     };
