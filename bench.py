@@ -37,9 +37,11 @@ KERNEL_SYMBOL = {"normalize_log1p": "k_row_pass<float,NORM,LOG>", "gene_moments"
                  "spmm_t": "k_spmm_t", "gram_sparse": "k_gram_sparse<float> (+ k_gram_reduce)",
                  "dense_apply": "k_dense_apply"}
 ROOF_NOTE = {
-    "gram_sparse": "algorithmic bytes = HVG-compacted matrix read once + G written once; the kernel is bound by the "
-                   "rate of random-address f64 LDS atomics (~0.5 lane/clk/CU achieved vs ~0.65 measured ceiling), "
-                   "not by HBM: see DESIGN.md",
+    "gram_sparse": "algorithmic bytes = HVG-compacted matrix (8-byte records + tile row pointers) read once + G "
+                   "written once. Not an HBM-bound kernel: one f64 LDS atomic per product (3.4e9 per launch at c3) "
+                   "plus two staged LDS reads and ~16 VALU instructions per 64-lane pass; the LDS pipe and VALU issue "
+                   "are each 50-65 % busy (profiles/r01_pmc_gram_v3.md), random-address f64 LDS atomics alone would "
+                   "take 2.2 ms at the 2.5 lanes/clk/CU measured by bench_micro/lds_atomic_banks.hip",
     "spmm_fwd": "algorithmic bytes per SURVEY.md 8(d): nnz_w*(4+4) + (N+1)*8 + N*64*4 + k*64*4",
 }
 
