@@ -109,6 +109,10 @@ struct srx_mat {
     int n_tiles = 0;
     int tile_genes = 0;
     int64_t* d_tile_ptr = nullptr;  // (n_tiles-1) x n_rows absolute positions
+    // 16-bit mirror of `d_indices` (n_cols <= 65536; pattern-only, built with the tiles, inherited by clones):
+    // the three passes that stream the column indices of the WHOLE matrix (gene moments, HVG count / fill)
+    // read 2 bytes per non-zero instead of 4
+    uint16_t* d_idx16 = nullptr;
     // per-gene moment cache, keyed by the value version
     uint64_t version = 1;
     uint64_t moments_version = 0;

@@ -183,6 +183,7 @@ static void free_mat_buffers(srx_mat* m) {
     (void)hipFree(m->d_indices);
     (void)hipFree(m->d_values);
     (void)hipFree(m->d_tile_ptr);
+    (void)hipFree(m->d_idx16);
     (void)hipFree(m->d_cnt);
     (void)hipFree(m->d_sum);
     (void)hipFree(m->d_sq);
@@ -396,7 +397,9 @@ int32_t srx_matrix_device_ptrs(srx_mat* m, void** indptr, void** indices, void**
     if (values) *values = m->d_values;
     touch(m);  // the caller may write through these pointers
     m->moments_version = 0;
-    if (m->d_tile_ptr) { (void)hipFree(m->d_tile_ptr); m->d_tile_ptr = nullptr; m->n_tiles = 0; }
+    if (m->d_tile_ptr) { (void)hipFree(m->d_tile_ptr); m->d_tile_ptr = nullptr; }
+    if (m->d_idx16) { (void)hipFree(m->d_idx16); m->d_idx16 = nullptr; }
+    m->n_tiles = 0;
     return SRX_OK;
 }
 
@@ -456,6 +459,11 @@ int32_t srx_matrix_clone(srx_mat* m, srx_mat** out) {
             const size_t tb = (size_t)(m->n_tiles - 1) * (m->n_rows ? m->n_rows : 1) * sizeof(int64_t);
             e = hipMalloc((void**)&c->d_tile_ptr, tb);
             if (e == hipSuccess) e = hipMemcpyAsync(c->d_tile_ptr, m->d_tile_ptr, tb, hipMemcpyDeviceToDevice, ctx->stream);
+        }
+        if (e == hipSuccess && m->d_idx16) {
+            const size_t ib = (m->nnz + 16) * sizeof(uint16_t);
+            e = hipMalloc((void**)&c->d_idx16, ib);
+            if (e == hipSuccess) e = hipMemcpyAsync(c->d_idx16, m->d_idx16, ib, hipMemcpyDeviceToDevice, ctx->stream);
         }
     }
     if (e != hipSuccess) {

@@ -50,9 +50,9 @@ __device__ __forceinline__ void seg_bounds(const int64_t* __restrict__ indptr, c
 
 // The three column passes of the reference — histogram (csr.rs:29-36), scatter-add of x
 // (csr.rs:94-100) and of x^2 (csr.rs:175-178) — in ONE walk.
-template <typename T>
+template <typename T, typename I>
 __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
-    const int64_t* __restrict__ indptr, const int64_t* __restrict__ tp, const int32_t* __restrict__ idx,
+    const int64_t* __restrict__ indptr, const int64_t* __restrict__ tp, const I* __restrict__ idx,
     const T* __restrict__ vals, uint64_t n_rows, uint64_t n_cols, int n_tiles, int tile_genes,
     uint64_t rows_per_block, uint32_t* __restrict__ part_cnt, double* __restrict__ part_sum,
     double* __restrict__ part_sq) {
@@ -80,7 +80,15 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
         seg_bounds(indptr, tp, n_rows, n_tiles, tile, r, lo, hi);
         const int64_t base = lo & ~(int64_t)3;
         for (int64_t e0 = base + 4 * lane; e0 < hi; e0 += 4 * kWave) {
-            const int4 g4 = *reinterpret_cast<const int4*>(idx + e0);
+            int gg[4];
+            if constexpr (sizeof(I) == 4) {
+                const int4 g4 = *reinterpret_cast<const int4*>(idx + e0);
+                gg[0] = g4.x; gg[1] = g4.y; gg[2] = g4.z; gg[3] = g4.w;
+            } else {                                   // four 16-bit indices in one 8-byte load
+                const uint2 g2 = *reinterpret_cast<const uint2*>(idx + e0);
+                gg[0] = (int)(g2.x & 0xffffu); gg[1] = (int)(g2.x >> 16);
+                gg[2] = (int)(g2.y & 0xffffu); gg[3] = (int)(g2.y >> 16);
+            }
             T v[4];
             if constexpr (sizeof(T) == 4) {
                 const float4 t4 = *reinterpret_cast<const float4*>(vals + e0);
@@ -90,7 +98,6 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
                 const double2 b2 = *reinterpret_cast<const double2*>(vals + e0 + 2);
                 v[0] = a2.x; v[1] = a2.y; v[2] = b2.x; v[3] = b2.y;
             }
-            const int gg[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int64_t pos = e0 + j;
@@ -234,6 +241,13 @@ int32_t launch_tile_ptr(srx_ctx* ctx, const int64_t* indptr, const int32_t* idx,
     return SRX_OK;
 }
 
+// d_indices -> 16-bit mirror (entries past nnz: 0, the arrays are padded for the vector walks)
+__global__ void k_narrow16(const int32_t* __restrict__ idx, uint64_t nnz, uint64_t n_out, uint16_t* __restrict__ out) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; e < n_out; e += stride) out[e] = e < nnz ? (uint16_t)idx[e] : (uint16_t)0;
+}
+
 int32_t ensure_tiles(srx_mat* m) {
     srx_ctx* ctx = m->ctx;
     if (m->n_tiles) return SRX_OK;
@@ -242,6 +256,15 @@ int32_t ensure_tiles(srx_mat* m) {
     if (nt > 1) {
         SRX_HIP(ctx, hipMalloc((void**)&m->d_tile_ptr, (size_t)(nt - 1) * (m->n_rows ? m->n_rows : 1) * sizeof(int64_t)));
         SRX_TRY(launch_tile_ptr(ctx, m->d_indptr, m->d_indices, m->n_rows, nt, tg, m->d_tile_ptr));
+    }
+    if (m->n_cols <= 65536 && !m->d_idx16) {
+        SRX_HIP(ctx, hipMalloc((void**)&m->d_idx16, (m->nnz + 16) * sizeof(uint16_t)));
+        uint64_t g = (m->nnz + 16 + 1023) / 1024;
+        if (g < 1) g = 1;
+        if (g > 65535) g = 65535;
+        hipLaunchKernelGGL(k_narrow16, dim3((unsigned)g), dim3(256), 0, ctx->stream, m->d_indices, m->nnz, m->nnz + 16,
+                           m->d_idx16);
+        SRX_HIP(ctx, hipGetLastError());
     }
     m->n_tiles = nt;
     m->tile_genes = tg;
@@ -278,20 +301,24 @@ int32_t ensure_moments(srx_mat* m) {
     SRX_TRY(scratch(ctx, "mom_part_sq", nb * (G ? G : 1) * sizeof(double), (void**)&p_sq));
     SRX_TRY(scratch(ctx, "mom_packed", (3 * G + 1) * sizeof(double), (void**)&packed));
     const size_t lds = (size_t)m->tile_genes * 20;
-    const double bytes = (double)m->nnz * (4.0 + val_bytes(m)) + (double)(m->n_rows + 1) * 8.0 + (double)G * 24.0;
+    // s_i = 2 when the 16-bit index mirror exists (n_cols <= 65536), 4 otherwise
+    const double bytes = (double)m->nnz * ((m->n_cols <= 65536 ? 2.0 : 4.0) + val_bytes(m)) + (double)(m->n_rows + 1) * 8.0 +
+                         (double)G * 24.0;
     {
         ProfScope ps(ctx, SRX_K_MOMENTS, bytes);
         dim3 grid((unsigned)(nb * m->n_tiles));
+        auto launch = [&](auto kern, const auto* idxp, const auto* valp) -> int32_t {
+            SRX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, grid, dim3(kMomThreads), lds, ctx->stream, m->d_indptr, m->d_tile_ptr, idxp, valp,
+                               m->n_rows, G, m->n_tiles, m->tile_genes, rpb, p_cnt, p_sum, p_sq);
+            return SRX_OK;
+        };
         if (is_f32(m)) {
-            SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_gene_moments<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_gene_moments<float>), grid, dim3(kMomThreads), lds, ctx->stream, m->d_indptr,
-                               m->d_tile_ptr, m->d_indices, (const float*)m->d_values, m->n_rows, G, m->n_tiles,
-                               m->tile_genes, rpb, p_cnt, p_sum, p_sq);
+            if (m->d_idx16) SRX_TRY(launch(k_gene_moments<float, uint16_t>, (const uint16_t*)m->d_idx16, (const float*)m->d_values));
+            else SRX_TRY(launch(k_gene_moments<float, int32_t>, (const int32_t*)m->d_indices, (const float*)m->d_values));
         } else {
-            SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_gene_moments<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_gene_moments<double>), grid, dim3(kMomThreads), lds, ctx->stream, m->d_indptr,
-                               m->d_tile_ptr, m->d_indices, (const double*)m->d_values, m->n_rows, G, m->n_tiles,
-                               m->tile_genes, rpb, p_cnt, p_sum, p_sq);
+            if (m->d_idx16) SRX_TRY(launch(k_gene_moments<double, uint16_t>, (const uint16_t*)m->d_idx16, (const double*)m->d_values));
+            else SRX_TRY(launch(k_gene_moments<double, int32_t>, (const int32_t*)m->d_indices, (const double*)m->d_values));
         }
         hipLaunchKernelGGL(k_moments_reduce, dim3((unsigned)((G + 255) / 256 + 1)), dim3(256), 0, ctx->stream, p_cnt,
                            p_sum, p_sq, G, nb, m->n_rows, packed);

@@ -254,7 +254,8 @@ __device__ __forceinline__ SelLds stage_selection(const uint32_t* __restrict__ g
 
 constexpr int kCompactUnroll = 4;    // 64-entry chunks of a row in flight per wave
 
-__global__ __launch_bounds__(256) void k_tcount(const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx,
+template <typename I>
+__global__ __launch_bounds__(256) void k_tcount(const int64_t* __restrict__ indptr, const I* __restrict__ idx,
                                                 const uint32_t* __restrict__ g_bits,
                                                 const uint32_t* __restrict__ g_prefix, int n_words, uint64_t n_rows,
                                                 int nt128, int nt256, int64_t* __restrict__ cnt128,
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void k_tcount(const int64_t* __restrict__ indp
 #pragma unroll
             for (int u = 0; u < kCompactUnroll; ++u) {
                 const int64_t p = base + u * kWave + lane;
-                g[u] = p < hi ? idx[p] : -1;
+                g[u] = p < hi ? (int32_t)idx[p] : -1;
             }
 #pragma unroll
             for (int u = 0; u < kCompactUnroll; ++u) {
@@ -313,8 +314,8 @@ __global__ void k_pack128(const int32_t* __restrict__ tidx, const T* __restrict_
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_tfill(const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx,
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void k_tfill(const int64_t* __restrict__ indptr, const I* __restrict__ idx,
                                                const T* __restrict__ vals, const uint32_t* __restrict__ g_bits,
                                                const uint32_t* __restrict__ g_prefix, int n_words, uint64_t n_rows,
                                                int nt128, int nt256, const int64_t* __restrict__ cnt128,
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256) void k_tfill(const int64_t* __restrict__ indpt
 #pragma unroll
             for (int u = 0; u < kCompactUnroll; ++u) {
                 const int64_t p = base + u * kWave + lane;
-                g[u] = p < hi ? idx[p] : -1;
+                g[u] = p < hi ? (int32_t)idx[p] : -1;
             }
 #pragma unroll
             for (int u = 0; u < kCompactUnroll; ++u) {
@@ -1491,23 +1492,35 @@ static int32_t build_tiled_fused(srx_mat* m, const std::vector<int32_t>& remap, 
     SRX_TRY(scratch(ctx, "pca_cnt256", (n256 ? n256 : 1) * sizeof(int64_t), (void**)&cnt256));
     SRX_TRY(scratch(ctx, "pca_t128_ptr", (n128 + 1) * sizeof(int64_t), (void**)&t128.tptr));
     SRX_TRY(scratch(ctx, "pca_t256_ptr", (n256 + 1) * sizeof(int64_t), (void**)&t256.tptr));
-    ProfScope ps(ctx, SRX_K_COMPACT, (double)m->nnz * 4.0 * 2.0 + (double)(N + 1) * 8.0 * 2.0);
-    hipLaunchKernelGGL(k_tcount, dim3(grid_rows(ctx, N, 4)), dim3(256), sel_lds, ctx->stream, m->d_indptr, m->d_indices,
-                       d_sel, d_sel + n_words, n_words, N, nt128, nt256, cnt128, cnt256);
+    const double s_i = m->d_idx16 ? 2.0 : 4.0;          // bytes per column index streamed by the two passes
+    ProfScope ps(ctx, SRX_K_COMPACT, (double)m->nnz * s_i * 2.0 + (double)m->nnz * val_bytes(m) + (double)(N + 1) * 8.0 * 2.0);
+    if (m->d_idx16)
+        hipLaunchKernelGGL((k_tcount<uint16_t>), dim3(grid_rows(ctx, N, 4)), dim3(256), sel_lds, ctx->stream, m->d_indptr,
+                           (const uint16_t*)m->d_idx16, d_sel, d_sel + n_words, n_words, N, nt128, nt256, cnt128, cnt256);
+    else
+        hipLaunchKernelGGL((k_tcount<int32_t>), dim3(grid_rows(ctx, N, 4)), dim3(256), sel_lds, ctx->stream, m->d_indptr,
+                           (const int32_t*)m->d_indices, d_sel, d_sel + n_words, n_words, N, nt128, nt256, cnt128, cnt256);
     SRX_TRY(scan_exclusive(ctx, cnt128, n128, t128.tptr, &d_total));
     int64_t total = 0;
     SRX_TRY(d2h(ctx, &total, d_total, sizeof(int64_t)));
     SRX_TRY(scan_exclusive(ctx, cnt256, n256, t256.tptr, nullptr));
     SRX_TRY(alloc_tiled(m, N, (uint64_t)total, k, KG, t128));
     SRX_TRY(alloc_tiled(m, N, (uint64_t)total, k, KT, t256));
-    if (is_f32(m))
-        hipLaunchKernelGGL((k_tfill<float>), dim3(grid_rows(ctx, N, 4)), dim3(256), sel_lds, ctx->stream, m->d_indptr,
-                           m->d_indices, (const float*)m->d_values, d_sel, d_sel + n_words, n_words, N, nt128, nt256,
-                           cnt128, t128.tptr, t256.tptr, (GramPk<float>*)t128.tpk, t256.tidx, (float*)t256.tvals);
-    else
-        hipLaunchKernelGGL((k_tfill<double>), dim3(grid_rows(ctx, N, 4)), dim3(256), sel_lds, ctx->stream, m->d_indptr,
-                           m->d_indices, (const double*)m->d_values, d_sel, d_sel + n_words, n_words, N, nt128, nt256,
-                           cnt128, t128.tptr, t256.tptr, (GramPk<double>*)t128.tpk, t256.tidx, (double*)t256.tvals);
+    auto fill = [&](auto kern, const auto* idxp, const auto* valp, auto* pk, auto* tv256) {
+        hipLaunchKernelGGL(kern, dim3(grid_rows(ctx, N, 4)), dim3(256), sel_lds, ctx->stream, m->d_indptr, idxp, valp, d_sel,
+                           d_sel + n_words, n_words, N, nt128, nt256, cnt128, t128.tptr, t256.tptr, pk, t256.tidx, tv256);
+    };
+    if (is_f32(m)) {
+        if (m->d_idx16) fill(k_tfill<float, uint16_t>, (const uint16_t*)m->d_idx16, (const float*)m->d_values,
+                             (GramPk<float>*)t128.tpk, (float*)t256.tvals);
+        else fill(k_tfill<float, int32_t>, (const int32_t*)m->d_indices, (const float*)m->d_values,
+                  (GramPk<float>*)t128.tpk, (float*)t256.tvals);
+    } else {
+        if (m->d_idx16) fill(k_tfill<double, uint16_t>, (const uint16_t*)m->d_idx16, (const double*)m->d_values,
+                             (GramPk<double>*)t128.tpk, (double*)t256.tvals);
+        else fill(k_tfill<double, int32_t>, (const int32_t*)m->d_indices, (const double*)m->d_values,
+                  (GramPk<double>*)t128.tpk, (double*)t256.tvals);
+    }
     SRX_HIP(ctx, hipGetLastError());
     if (ctx->prof_mask & (1u << SRX_K_COMPACT))
         ctx->prof[SRX_K_COMPACT].bytes += (double)total * (4.0 + val_bytes(m)) * 3.0;   // read once, written twice
