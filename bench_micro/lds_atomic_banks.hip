@@ -31,6 +31,10 @@ __global__ __launch_bounds__(1024) void k(int iters, double* out) {
             atomicAdd(reinterpret_cast<unsigned long long*>(acc) + idx, (unsigned long long)h);
         } else if (MODE == 6) {                                                           // random, 32-bit integer add
             atomicAdd(reinterpret_cast<unsigned int*>(acc) + (h & 32767), h);
+        } else if (MODE == 15) {                                                          // random, f32 add
+            atomicAdd(reinterpret_cast<float*>(acc) + (h & 32767), 1.0f + lane);
+        } else if (MODE == 16) {                                                          // random, f32 add, 32 lanes active
+            if (lane & 1) atomicAdd(reinterpret_cast<float*>(acc) + (h & 32767), 1.0f + lane);
         } else if (MODE == 7) {                                                           // random, non-atomic f64 store
             acc[idx] = (double)h;
         } else if (MODE == 11) {                                                          // random, 32 of 64 lanes active
@@ -76,6 +80,8 @@ int main() {
     run<5>("u64 add, random", d_out);
     run<6>("u32 add, random over 32768 words", d_out);
     run<7>("f64 plain store, random", d_out);
+    run<15>("f32 add, random over 32768 words", d_out);
+    run<16>("f32 add, random, 32 of 64 lanes active (x2)", d_out);
     run<9>("f64 add, random, lane pairs on the SAME address", d_out);
     run<10>("f64 add, random, 4 lanes per address", d_out);
     run<11>("f64 add, random, 32 of 64 lanes active (rate per ACTIVE lane x2)", d_out);

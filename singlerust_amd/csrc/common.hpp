@@ -176,6 +176,15 @@ int32_t allreduce_f64(srx_ctx* ctx, double* d_buf, size_t count);
 
 // ---- internal entry points shared between translation units -----------------------------------
 int32_t ensure_tiles(srx_mat* m);
+// device-resident result of FeatureSelection::HighlyVariable(n) (genes.hip), consumed by the PCA driver
+struct HvgDev {
+    int k = 0, n_words = 0;
+    int32_t* d_sel_rank = nullptr;   // k gene ids in variance-rank order (what select_features returns)
+    uint32_t* d_bits = nullptr;      // n_words selection bits, then n_words prefix counts
+    double *d_mu = nullptr, *d_sd = nullptr, *d_dinv = nullptr, *d_tr = nullptr, *d_trace = nullptr;   // slot order
+    int* d_status = nullptr;         // bit 0: NaN variance
+};
+int32_t select_hvg_device(srx_mat* m, uint64_t n, int center, int scale, HvgDev& out);
 int32_t ensure_moments(srx_mat* m);   // fills d_cnt/d_sum/d_sq (global) for the current values
 int32_t launch_normalize(srx_mat* m, double target, bool do_norm, bool do_log);
 inline void touch(srx_mat* m) { m->version++; m->pca.valid = false; }

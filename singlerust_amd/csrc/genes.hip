@@ -388,6 +388,186 @@ int32_t select_hvg_host(srx_ctx* ctx, const std::vector<double>& var, uint64_t n
     return SRX_OK;
 }
 
+// ---- FeatureSelection::HighlyVariable(n) on the device (the pipeline's route: no host round trip) ----
+// Same semantics as select_hvg_host / dim_red/mod.rs:135-140: nz-only population variance in the reference's
+// operation order (csr.rs:179-185: no FMA contraction — explicit _rn intrinsics), stable descending order
+// (ties keep the ascending gene index), NaN -> status bit 1 (the reference panics).
+__global__ void k_gene_var(const uint64_t* __restrict__ cnt, const double* __restrict__ sum, const double* __restrict__ sq,
+                           uint64_t G, double* __restrict__ var, int* __restrict__ status) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= G) return;
+    double v = 0.0;
+    if (cnt[j] > 0) {
+        const double c = (double)(uint32_t)cnt[j];
+        const double mean = __ddiv_rn(sum[j], c);
+        v = __dsub_rn(__ddiv_rn(sq[j], c), __dmul_rn(mean, mean));
+    }
+    var[j] = v;
+    if (v != v) atomicOr(status, 1);
+}
+
+// rank of every gene under (variance desc, index asc) by counting.  Block (x, y): genes 256 x .. 256 x + 255
+// against the comparison slice y (kRankTile variances staged in LDS, read as broadcast b128 pairs); a tile
+// wholly before the block's genes wins ties (>=), wholly after loses them (>), only the tile holding the
+// block's own genes needs the index compare.  Partial ranks are summed with integer atomics (exact, any order).
+constexpr int kRankTile = 2048;
+__global__ __launch_bounds__(256) void k_hvg_rank(const double* __restrict__ var, uint32_t G, uint32_t* __restrict__ rank_out) {
+    __shared__ double tile[kRankTile];
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t base = blockIdx.y * kRankTile;
+    for (uint32_t e = threadIdx.x; e < kRankTile; e += 256) tile[e] = base + e < G ? var[base + e] : -INFINITY;
+    __syncthreads();
+    if (j >= G) return;
+    const double mine = var[j];
+    const uint32_t j_lo = blockIdx.x * 256, j_hi = j_lo + 255;
+    uint32_t rank = 0;
+    if (base + kRankTile - 1 < j_lo) {                       // every gene of the tile precedes every gene of the block
+#pragma unroll 8
+        for (int e = 0; e < kRankTile; ++e) rank += tile[e] >= mine ? 1u : 0u;
+    } else if (base > j_hi) {
+#pragma unroll 8
+        for (int e = 0; e < kRankTile; ++e) rank += tile[e] > mine ? 1u : 0u;
+    } else {
+#pragma unroll 4
+        for (int e = 0; e < kRankTile; ++e) {
+            const double o = tile[e];
+            rank += (o > mine || (o == mine && base + e < j)) ? 1u : 0u;
+        }
+    }
+    atomicAdd(&rank_out[j], rank);
+}
+
+// gene of rank r < n goes to sel_rank[r]; flag[gene] = rank < n
+__global__ void k_hvg_take(const uint32_t* __restrict__ rank, uint32_t G, uint32_t n, int32_t* __restrict__ sel_rank,
+                           uint8_t* __restrict__ flag) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= G) return;
+    const bool take = rank[j] < n;
+    flag[j] = take ? 1 : 0;
+    if (take) sel_rank[rank[j]] = (int32_t)j;
+}
+
+// One workgroup: selection bitmask + per-word prefix counts (what the compaction kernels stage in LDS), and
+// the per-slot (ascending gene order) centring / scaling vectors of the PCA from the all-cells moments
+// (pca/mod.rs:87-91: mean = sum/N, var = sumsq/N - mean^2, ddof 0); trace = sum_s dinv_s^2 ss_s, summed in a
+// fixed tree.  n_words <= 2048 (G <= 65536).
+__global__ __launch_bounds__(1024) void k_sel_finish(const uint8_t* __restrict__ flag, const double* __restrict__ sum,
+                                                     const double* __restrict__ sq, uint32_t G, int n_words, double n_cells,
+                                                     int center, int scale, uint32_t* __restrict__ bits,
+                                                     uint32_t* __restrict__ prefix, double* __restrict__ mu,
+                                                     double* __restrict__ sd, double* __restrict__ dinv,
+                                                     double* __restrict__ trace) {
+    __shared__ uint32_t s_bits[2048], s_pre[2048], s_wave[16];
+    __shared__ double s_tr[1024];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    // two words per thread
+    uint32_t b[2] = {0u, 0u};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int w = 2 * t + h;
+        if (w < n_words) {
+            const uint32_t g0 = (uint32_t)w * 32;
+            uint32_t acc = 0;
+            if (g0 + 32 <= G) {
+                const uint4 f0 = *reinterpret_cast<const uint4*>(flag + g0), f1 = *reinterpret_cast<const uint4*>(flag + g0 + 16);
+                const uint32_t ws[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc |= ((ws[q] >> (8 * r)) & 1u) << (4 * q + r);
+            } else {
+                for (int r = 0; r < 32; ++r)
+                    if (g0 + r < G && flag[g0 + r]) acc |= 1u << r;
+            }
+            b[h] = acc;
+            s_bits[w] = acc;
+        }
+    }
+    // exclusive scan of the popcounts: per-thread pair, wave scan, wave totals
+    const uint32_t c0 = (uint32_t)__popc(b[0]), c1 = (uint32_t)__popc(b[1]);
+    uint32_t inc = c0 + c1;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < wv; ++w) before += s_wave[w];
+    const uint32_t excl = before + inc - (c0 + c1);
+    if (2 * t < n_words) s_pre[2 * t] = excl;
+    if (2 * t + 1 < n_words) s_pre[2 * t + 1] = excl + c0;
+    __syncthreads();
+    for (int w = t; w < n_words; w += 1024) {
+        bits[w] = s_bits[w];
+        prefix[w] = s_pre[w];
+    }
+    double tr = 0.0;
+    for (uint32_t g = t; g < G; g += 1024) {
+        const uint32_t w = s_bits[g >> 5], bit = 1u << (g & 31);
+        if (!(w & bit)) continue;
+        const uint32_t s = s_pre[g >> 5] + (uint32_t)__popc(w & (bit - 1u));
+        const double mean = sum[g] / n_cells;
+        double var = sq[g] / n_cells - mean * mean;
+        if (var < 0) var = 0;
+        const double std_ = sqrt(var);
+        mu[s] = (center || scale) ? mean : 0.0;          // pca/mod.rs:85-119: stored only if center || scale
+        sd[s] = scale ? std_ : 1.0;
+        const double di = (scale && std_ > 0) ? 1.0 / std_ : 1.0;      // zero-variance column: std treated as 1
+        dinv[s] = di;
+        double ss = center ? (sq[g] - n_cells * mean * mean) : sq[g];
+        if (ss < 0) ss = 0;
+        tr += di * di * ss;
+    }
+    s_tr[t] = tr;
+    __syncthreads();
+    for (int half = 512; half > 0; half >>= 1) {
+        if (t < half) s_tr[t] += s_tr[t + half];
+        __syncthreads();
+    }
+    if (t == 0) *trace = s_tr[0];
+}
+
+// Device-side HighlyVariable(n): fills the scratch buffers named below; nothing is read back.
+int32_t select_hvg_device(srx_mat* m, uint64_t n, int center, int scale, HvgDev& out) {
+    srx_ctx* ctx = m->ctx;
+    SRX_TRY(ensure_moments(m));
+    const uint64_t G = m->n_cols;
+    const uint64_t take = n < G ? n : G;
+    const int n_words = (int)((G + 31) / 32);
+    double *d_var, *d_f;
+    uint8_t* d_flag;
+    uint32_t* d_rank;
+    SRX_TRY(scratch(ctx, "hvg_var", (G ? G : 1) * sizeof(double), (void**)&d_var));
+    SRX_TRY(scratch(ctx, "hvg_flag", (G ? G : 1) + 64, (void**)&d_flag));
+    SRX_TRY(scratch(ctx, "hvg_rankv", (G ? G : 1) * sizeof(uint32_t), (void**)&d_rank));
+    SRX_TRY(scratch(ctx, "hvg_rank", (take ? take : 1) * sizeof(int32_t), (void**)&out.d_sel_rank));
+    SRX_TRY(scratch(ctx, "pca_selbits", (size_t)(2 * n_words ? 2 * n_words : 1) * sizeof(uint32_t), (void**)&out.d_bits));
+    SRX_TRY(scratch(ctx, "hvg_f", (3 * (take ? take : 1) + 8) * sizeof(double), (void**)&d_f));
+    SRX_TRY(scratch(ctx, "hvg_status", 256, (void**)&out.d_status));
+    out.d_mu = d_f;
+    out.d_sd = d_f + take;
+    out.d_dinv = d_f + 2 * take;
+    out.d_tr = nullptr;
+    out.d_trace = d_f + 3 * take;
+    out.k = (int)take;
+    out.n_words = n_words;
+    SRX_HIP(ctx, hipMemsetAsync(out.d_status, 0, 256, ctx->stream));
+    SRX_HIP(ctx, hipMemsetAsync(d_rank, 0, (G ? G : 1) * sizeof(uint32_t), ctx->stream));
+    const unsigned gb = (unsigned)((G + 255) / 256 ? (G + 255) / 256 : 1);
+    const unsigned gy = (unsigned)((G + kRankTile - 1) / kRankTile ? (G + kRankTile - 1) / kRankTile : 1);
+    hipLaunchKernelGGL(k_gene_var, dim3(gb), dim3(256), 0, ctx->stream, m->d_cnt, m->d_sum, m->d_sq, G, d_var, out.d_status);
+    hipLaunchKernelGGL(k_hvg_rank, dim3(gb, gy), dim3(256), 0, ctx->stream, d_var, (uint32_t)G, d_rank);
+    hipLaunchKernelGGL(k_hvg_take, dim3(gb), dim3(256), 0, ctx->stream, d_rank, (uint32_t)G, (uint32_t)take, out.d_sel_rank,
+                       d_flag);
+    hipLaunchKernelGGL(k_sel_finish, dim3(1), dim3(1024), 0, ctx->stream, d_flag, m->d_sum, m->d_sq, (uint32_t)G, n_words,
+                       (double)m->n_rows_global, center, scale, out.d_bits, out.d_bits + n_words, out.d_mu, out.d_sd,
+                       out.d_dinv, out.d_trace);
+    SRX_HIP(ctx, hipGetLastError());
+    return SRX_OK;
+}
+
 int32_t row_number(srx_mat* m, uint32_t* out);
 int32_t row_stat(srx_mat* m, int which, double* out0, double* out1);
 

@@ -1466,27 +1466,15 @@ static int32_t alloc_tiled(srx_mat* m, uint64_t N, uint64_t nnz, int k, int kt, 
     return SRX_OK;
 }
 
-static int32_t build_tiled_fused(srx_mat* m, const std::vector<int32_t>& remap, int k, Tiled& t128, Tiled& t256) {
+// `d_sel`: n_words selection bits followed by n_words prefix counts, on the device (the compacted column of a
+// gene is its rank among the selected genes in ascending gene order)
+static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words, int k, Tiled& t128, Tiled& t256) {
     srx_ctx* ctx = m->ctx;
     const uint64_t N = m->n_rows;
     const int nt128 = (k + KG - 1) / KG, nt256 = (k + KT - 1) / KT;
     int64_t *cnt128, *cnt256, *d_total;
-    // selection bitmask + per-word prefix counts (the compacted column of a gene is its rank among
-    // the selected genes in ascending gene order, which is exactly what `remap` holds)
-    const int n_words = (int)((remap.size() + 31) / 32);
-    std::vector<uint32_t> hsel(2 * (size_t)n_words, 0u);
-    for (size_t g = 0; g < remap.size(); ++g)
-        if (remap[g] >= 0) hsel[g >> 5] |= 1u << (g & 31);
-    uint32_t run = 0;
-    for (int w = 0; w < n_words; ++w) {
-        hsel[n_words + w] = run;
-        run += (uint32_t)__builtin_popcount(hsel[w]);
-    }
-    uint32_t* d_sel;
-    SRX_TRY(scratch(ctx, "pca_selbits", (hsel.size() ? hsel.size() : 1) * sizeof(uint32_t), (void**)&d_sel));
-    SRX_TRY(h2d(ctx, d_sel, hsel.data(), hsel.size() * sizeof(uint32_t)));
     const size_t sel_lds = 2 * (size_t)n_words * sizeof(uint32_t);
-    if (sel_lds > 60000) return fail(ctx, SRX_E_ARG, "pca: %zu genes exceed the LDS selection table", remap.size());
+    if (sel_lds > 60000) return fail(ctx, SRX_E_ARG, "pca: %llu genes exceed the LDS selection table", (unsigned long long)m->n_cols);
     const uint64_t n128 = (uint64_t)nt128 * N, n256 = (uint64_t)nt256 * N;
     SRX_TRY(scratch(ctx, "pca_cnt128", (n128 ? n128 : 1) * sizeof(int64_t), (void**)&cnt128));
     SRX_TRY(scratch(ctx, "pca_cnt256", (n256 ? n256 : 1) * sizeof(int64_t), (void**)&cnt256));
@@ -1525,6 +1513,24 @@ static int32_t build_tiled_fused(srx_mat* m, const std::vector<int32_t>& remap, 
     if (ctx->prof_mask & (1u << SRX_K_COMPACT))
         ctx->prof[SRX_K_COMPACT].bytes += (double)total * (4.0 + val_bytes(m)) * 3.0;   // read once, written twice
     return SRX_OK;
+}
+
+// host-side selection (srx_pca with an explicit feature list): bitmask + prefix counts from the remap table
+static int32_t build_tiled_fused(srx_mat* m, const std::vector<int32_t>& remap, int k, Tiled& t128, Tiled& t256) {
+    srx_ctx* ctx = m->ctx;
+    const int n_words = (int)((remap.size() + 31) / 32);
+    std::vector<uint32_t> hsel(2 * (size_t)n_words, 0u);
+    for (size_t g = 0; g < remap.size(); ++g)
+        if (remap[g] >= 0) hsel[g >> 5] |= 1u << (g & 31);
+    uint32_t run = 0;
+    for (int w = 0; w < n_words; ++w) {
+        hsel[n_words + w] = run;
+        run += (uint32_t)__builtin_popcount(hsel[w]);
+    }
+    uint32_t* d_sel;
+    SRX_TRY(scratch(ctx, "pca_selbits", (hsel.size() ? hsel.size() : 1) * sizeof(uint32_t), (void**)&d_sel));
+    SRX_TRY(h2d(ctx, d_sel, hsel.data(), hsel.size() * sizeof(uint32_t)));
+    return build_tiled_fused(m, d_sel, n_words, k, t128, t256);
 }
 
 // ---- launches ---------------------------------------------------------------------------------
@@ -1800,16 +1806,22 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
 
 template <typename VT, typename PT>
 static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const Resolved& o,
-                       const std::vector<double>& mu, const std::vector<double>& dinv, int l_act, double n_cells,
-                       srx_pca_state& st) {
+                       const std::vector<double>& mu, const std::vector<double>& dinv, const HvgDev* hv, int l_act,
+                       double n_cells, srx_pca_state& st) {
     srx_ctx* ctx = m->ctx;
     const int k = t256.k;
     struct { uint64_t n_rows; } cc{t256.n_rows};
     const size_t kl = (size_t)k * L;
     Work w;
     SRX_TRY(alloc_work(ctx, k, w));
-    SRX_TRY(h2d(ctx, w.mu, mu.data(), (size_t)k * 8));
-    SRX_TRY(h2d(ctx, w.d, dinv.data(), (size_t)k * 8));
+    if (hv) {                          // selection made on the device: centring / scaling vectors are already there
+        if (o.center) SRX_HIP(ctx, hipMemcpyAsync(w.mu, hv->d_mu, (size_t)k * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        else SRX_HIP(ctx, hipMemsetAsync(w.mu, 0, (size_t)k * 8, ctx->stream));
+        SRX_HIP(ctx, hipMemcpyAsync(w.d, hv->d_dinv, (size_t)k * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        SRX_TRY(h2d(ctx, w.mu, mu.data(), (size_t)k * 8));
+        SRX_TRY(h2d(ctx, w.d, dinv.data(), (size_t)k * 8));
+    }
     PT *P, *cvec, *Y;
     SRX_TRY(scratch(ctx, "pca_P", (kl + L) * sizeof(PT), (void**)&P));
     cvec = P + kl;
@@ -1895,14 +1907,19 @@ static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const 
 }
 
 // Everything up to and including the scores, left in m->pca (device scores + small host vectors).
-static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const srx_pca_opts* opts) {
+// `hvg_n` > 0: FeatureSelection::HighlyVariable(hvg_n) made on the device (the pipeline's route: no host round
+// trip between the moments pass and the compaction); otherwise `sel` (nullptr = all features).
+static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const srx_pca_opts* opts, uint64_t hvg_n = 0) {
     srx_ctx* ctx = m->ctx;
     SRX_HIP(ctx, hipSetDevice(ctx->device));
     srx_pca_state& st = m->pca;
     st.valid = false;
     const uint64_t G = m->n_cols;
+    // the fused compaction holds one tile counter per lane (<= 64 tiles of 128) and the rank kernel is O(G^2)
+    const bool dev_sel = hvg_n > 0 && (hvg_n < G ? hvg_n : G) <= (uint64_t)kWave * KG && G <= 65536;
     std::vector<uint64_t> selv;
-    if (sel) selv.assign(sel, sel + k64);
+    if (dev_sel) selv.resize(hvg_n < G ? hvg_n : G);                          // filled after the solve
+    else if (sel) selv.assign(sel, sel + k64);
     else { selv.resize(G); std::iota(selv.begin(), selv.end(), 0ull); }      // FeatureSelection::None, :154
     const int k = (int)selv.size();
     SRX_TRY(ensure_moments(m));                                                // also fixes n_rows_global
@@ -1933,41 +1950,46 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
         return fail(ctx, SRX_E_ARG, "pca: n_components %d exceeds what the %d-column block resolves (max %d)", o.n_pc, L,
                     k > L ? L - 8 : l_act);
 
-    // ascending-gene-order view of the selection; remap table; permutation back to selection order
-    std::vector<int> order(k);
-    std::iota(order.begin(), order.end(), 0);
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return selv[a] < selv[b]; });
-    std::vector<int32_t> remap(G, -1);
-    std::vector<int> slot_of_sel(k);
-    for (int s = 0; s < k; ++s) {
-        uint64_t g = selv[order[s]];
-        if (g >= G) return fail(ctx, SRX_E_BOUNDS, "selected feature index %llu out of bounds (n_vars = %llu)",
-                                (unsigned long long)g, (unsigned long long)G);
-        if (remap[g] >= 0) return fail(ctx, SRX_E_ARG, "selected feature index %llu appears twice", (unsigned long long)g);
-        remap[g] = s;
-        slot_of_sel[order[s]] = s;
-    }
-    // all-cells column mean / std (ddof 0) of the selected genes from the one moments pass
-    // (pca/mod.rs:87-91): mean = sum/N, var = sumsq/N - mean^2
-    std::vector<double> hsum(G), hsq(G);
-    SRX_TRY(d2h(ctx, hsum.data(), m->d_sum, G * 8));
-    SRX_TRY(d2h(ctx, hsq.data(), m->d_sq, G * 8));
+    std::vector<int> order(k), slot_of_sel(k);
+    std::vector<int32_t> remap;
     std::vector<double> mu(k), sd(k), dinv(k);
     double trace = 0.0;
     const double Nd = (double)Ng;
-    for (int s = 0; s < k; ++s) {
-        uint64_t g = selv[order[s]];
-        double mean = hsum[g] / Nd;
-        double var = hsq[g] / Nd - mean * mean;
-        if (var < 0) var = 0;
-        double std_ = std::sqrt(var);
-        mu[s] = (o.center || o.scale) ? mean : 0.0;            // :85-119: mean/std stored only if center||scale
-        sd[s] = o.scale ? std_ : 1.0;
-        // zero-variance column: the reference divides by 0 (NaN, :108); treated as std 1 here
-        dinv[s] = (o.scale && std_ > 0) ? 1.0 / std_ : 1.0;
-        double ss = o.center ? (hsq[g] - Nd * mean * mean) : hsq[g];
-        if (ss < 0) ss = 0;
-        trace += dinv[s] * dinv[s] * ss;
+    HvgDev hv;
+    if (dev_sel) {
+        SRX_TRY(select_hvg_device(m, hvg_n, o.center, o.scale, hv));
+    } else {
+        // ascending-gene-order view of the selection; remap table; permutation back to selection order
+        std::iota(order.begin(), order.end(), 0);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return selv[a] < selv[b]; });
+        remap.assign(G, -1);
+        for (int s = 0; s < k; ++s) {
+            uint64_t g = selv[order[s]];
+            if (g >= G) return fail(ctx, SRX_E_BOUNDS, "selected feature index %llu out of bounds (n_vars = %llu)",
+                                    (unsigned long long)g, (unsigned long long)G);
+            if (remap[g] >= 0) return fail(ctx, SRX_E_ARG, "selected feature index %llu appears twice", (unsigned long long)g);
+            remap[g] = s;
+            slot_of_sel[order[s]] = s;
+        }
+        // all-cells column mean / std (ddof 0) of the selected genes from the one moments pass
+        // (pca/mod.rs:87-91): mean = sum/N, var = sumsq/N - mean^2
+        std::vector<double> hsum(G), hsq(G);
+        SRX_TRY(d2h(ctx, hsum.data(), m->d_sum, G * 8));
+        SRX_TRY(d2h(ctx, hsq.data(), m->d_sq, G * 8));
+        for (int s = 0; s < k; ++s) {
+            uint64_t g = selv[order[s]];
+            double mean = hsum[g] / Nd;
+            double var = hsq[g] / Nd - mean * mean;
+            if (var < 0) var = 0;
+            double std_ = std::sqrt(var);
+            mu[s] = (o.center || o.scale) ? mean : 0.0;            // :85-119: mean/std stored only if center||scale
+            sd[s] = o.scale ? std_ : 1.0;
+            // zero-variance column: the reference divides by 0 (NaN, :108); treated as std 1 here
+            dinv[s] = (o.scale && std_ > 0) ? 1.0 / std_ : 1.0;
+            double ss = o.center ? (hsq[g] - Nd * mean * mean) : hsq[g];
+            if (ss < 0) ss = 0;
+            trace += dinv[s] * dinv[s] * ss;
+        }
     }
     std::vector<double> mu_eff = mu;
     if (!o.center) std::fill(mu_eff.begin(), mu_eff.end(), 0.0);
@@ -1976,7 +1998,9 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     // general route through a row-major compacted CSR
     Tiled t256, t128;
     const bool need128 = o.solver == 1;
-    if ((k + KG - 1) / KG <= kWave) {
+    if (dev_sel) {
+        SRX_TRY(build_tiled_fused(m, hv.d_bits, hv.n_words, k, t128, t256));
+    } else if ((k + KG - 1) / KG <= kWave) {
         SRX_TRY(build_tiled_fused(m, remap, k, t128, t256));
     } else {
         CompactCsr cc;
@@ -2004,8 +2028,25 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     st.info.nnz_selected = t256.nnz;
     st.info.solver = (uint32_t)o.solver;
     int32_t rc;
-    if (is_f32(m)) rc = run_pca<float, float>(m, t256, need128 ? &t128 : nullptr, o, mu_eff, dinv, l_act, Nd, st);
-    else rc = run_pca<double, double>(m, t256, need128 ? &t128 : nullptr, o, mu_eff, dinv, l_act, Nd, st);
+    const HvgDev* hvp = dev_sel ? &hv : nullptr;
+    if (is_f32(m)) rc = run_pca<float, float>(m, t256, need128 ? &t128 : nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
+    else rc = run_pca<double, double>(m, t256, need128 ? &t128 : nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
+    if (dev_sel) {
+        // now that the solve is over: the selection (variance-rank order), its status, and the per-slot vectors
+        int hstat = 0;
+        SRX_TRY(d2h(ctx, &hstat, hv.d_status, sizeof(int)));
+        if (hstat & 1)
+            return fail(ctx, SRX_E_NAN, "NaN gene variance: called `Option::unwrap()` on a `None` value (partial_cmp)");
+        std::vector<int32_t> hsel(k);
+        SRX_TRY(d2h(ctx, hsel.data(), hv.d_sel_rank, (size_t)k * sizeof(int32_t)));
+        SRX_TRY(d2h(ctx, mu.data(), hv.d_mu, (size_t)k * 8));
+        SRX_TRY(d2h(ctx, sd.data(), hv.d_sd, (size_t)k * 8));
+        SRX_TRY(d2h(ctx, &trace, hv.d_trace, 8));
+        for (int i = 0; i < k; ++i) selv[i] = (uint64_t)hsel[i];
+        std::iota(order.begin(), order.end(), 0);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return selv[a] < selv[b]; });
+        for (int sI = 0; sI < k; ++sI) slot_of_sel[order[sI]] = sI;
+    }
     if (rc != SRX_OK && rc != SRX_E_NOCONV) return rc;
 
     // back to selection order; explained variance ratio = eig/total with eig = theta/(N-1),
@@ -2152,15 +2193,18 @@ int32_t srx_pipeline(srx_mat* m, double target_sum, uint64_t n_hvg, const srx_pc
     // per-gene moments of the transformed values (one pass, all-reduced across shards)
     if (rc == SRX_OK) rc = ensure_moments(m);
     (void)hipEventRecord(ev[2], ctx->stream);
-    // FeatureSelection::HighlyVariable(n_hvg)
+    // FeatureSelection::HighlyVariable(n_hvg): on the device, inside pca_device (the selection is fetched with the
+    // other results once the solve is over); the host route only for shapes the device kernels do not take
     std::vector<uint64_t> sel;
-    if (rc == SRX_OK) {
+    const uint64_t take = n_hvg < m->n_cols ? n_hvg : m->n_cols;
+    const bool dev_sel = n_hvg > 0 && take <= (uint64_t)kWave * KG && m->n_cols <= 65536;
+    if (rc == SRX_OK && !dev_sel) {
         std::vector<double> var;
         rc = gene_variances(m, var);
         if (rc == SRX_OK) rc = select_hvg_host(ctx, var, n_hvg, sel);
     }
     (void)hipEventRecord(ev[3], ctx->stream);
-    if (rc == SRX_OK) rc = pca_device(m, sel.data(), sel.size(), opts);
+    if (rc == SRX_OK) rc = dev_sel ? pca_device(m, nullptr, 0, opts, n_hvg) : pca_device(m, sel.data(), sel.size(), opts);
     (void)hipEventRecord(ev[4], ctx->stream);
     (void)hipStreamSynchronize(ctx->stream);
     if (res) {
