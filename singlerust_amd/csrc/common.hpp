@@ -94,6 +94,15 @@ struct srx_pca_state {           // what the last srx_pca / srx_pipeline left in
     std::vector<double> evr, mean, std_;
     std::vector<uint64_t> sel;
     srx_pca_info info{};
+    // Deferred host copies ("results stay on the device until fetched"): the solve leaves its small results in
+    // `d_small` (carved from the d_scores allocation) and the host vectors above are produced by the first
+    // fetch — pca_materialize() in pca.hip.  Layout in doubles:
+    //   V k*64 | theta 64 | sgn 64 | mu k | sd k | trace 1 | pad 1 | sel_rank (int32) k
+    double* d_small = nullptr;
+    bool host_pending = false;
+    bool dev_sel = false;            // mu / sd / trace / selection are in d_small (else in the pend_* fields)
+    std::vector<double> pend_mu, pend_sd;      // slot order
+    double pend_trace = 0.0;
 };
 
 struct srx_mat {

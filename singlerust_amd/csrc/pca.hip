@@ -1302,7 +1302,8 @@ __global__ void k_signs(const double* __restrict__ colmax, double* __restrict__ 
 // out[2] = theta[l_act - 1] / theta[n_pc - 1]: the smallest Ritz value of the block over the last wanted
 // one — an upper estimate of the per-application convergence factor of the wanted pairs
 __global__ void k_resid_scalar(const double* __restrict__ rho, const double* __restrict__ theta, int n_pc, int l_act,
-                               const int* __restrict__ status, double* __restrict__ out) {
+                               const int* __restrict__ status, const int* __restrict__ status_sel,
+                               double* __restrict__ out) {
     if (threadIdx.x != 0) return;
     double resid = 0.0;
     for (int i = 0; i < n_pc; ++i) {
@@ -1312,6 +1313,7 @@ __global__ void k_resid_scalar(const double* __restrict__ rho, const double* __r
     out[0] = resid;
     out[1] = (double)*status;
     out[2] = theta[n_pc - 1] > 0 ? theta[l_act - 1] / theta[n_pc - 1] : 1.0;
+    out[3] = status_sel ? (double)*status_sel : 0.0;      // device-side feature selection: bit 0 = NaN variance
 }
 
 // scores[i][c] = Y[i][c] for c < n_pc (row-major f64, the obsm["X_pca"] layout).
@@ -1669,7 +1671,7 @@ static int32_t gram2(srx_ctx* ctx, const Work& w, const double* A, const double*
 // theta their Ritz values, w.dColmax the largest-|.| entry of each Ritz vector.
 template <typename Apply>
 static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, const Resolved& o, Apply&& apply,
-                                std::vector<double>& theta, double& resid, int& iters, bool& converged) {
+                                const int* d_status_sel, double& resid, int& iters, bool& converged) {
     const size_t kl = (size_t)k * L;
     constexpr int kSlots = srx_ctx::kAsyncSlots, kSlotDoubles = 4;
     if (!ctx->pin_async) {
@@ -1709,7 +1711,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.W, w.dM2, k, w.A2);
         hipLaunchKernelGGL(k_col_resid, dim3(1), dim3(1024), 0, ctx->stream, w.A1, w.A2, w.dTheta, k, w.dRho, w.dColmax);
         hipLaunchKernelGGL(k_resid_scalar, dim3(1), dim3(64), 0, ctx->stream, w.dRho, w.dTheta, o.n_pc, l_act, d_status,
-                           d_res + kSlotDoubles * slot);
+                           d_status_sel, d_res + kSlotDoubles * slot);
         SRX_HIP(ctx, hipGetLastError());
         SRX_HIP(ctx, hipMemcpyAsync(ctx->pin_async + kSlotDoubles * slot, d_res + kSlotDoubles * slot,
                                     kSlotDoubles * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1733,6 +1735,8 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         r = ctx->pin_async[kSlotDoubles * slot];
         const int st = (int)ctx->pin_async[kSlotDoubles * slot + 1];
         ratio = ctx->pin_async[kSlotDoubles * slot + 2];
+        if ((int)ctx->pin_async[kSlotDoubles * slot + 3] & 1)
+            return fail(ctx, SRX_E_NAN, "NaN gene variance: called `Option::unwrap()` on a `None` value (partial_cmp)");
         if (st & kStatChol) return fail(ctx, SRX_E_NOCONV, "pca: block lost rank (Cholesky pivot <= 0)");
         if (st & kStatEig) return fail(ctx, SRX_E_NOCONV, "pca: l x l eigen-solver did not converge");
         if (r != r) return fail(ctx, SRX_E_NOCONV, "pca: NaN in the Ritz residual");
@@ -1800,7 +1804,6 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         r_last = r;
         sweeps_since = m;
     }
-    (void)theta;                   // the Ritz values stay in w.dTheta; the caller reads them with its other results
     return SRX_OK;
 }
 
@@ -1813,6 +1816,7 @@ static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const 
     struct { uint64_t n_rows; } cc{t256.n_rows};
     const size_t kl = (size_t)k * L;
     Work w;
+    st.d_small = nullptr;
     SRX_TRY(alloc_work(ctx, k, w));
     if (hv) {                          // selection made on the device: centring / scaling vectors are already there
         if (o.center) SRX_HIP(ctx, hipMemcpyAsync(w.mu, hv->d_mu, (size_t)k * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1827,7 +1831,6 @@ static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const 
     cvec = P + kl;
     SRX_TRY(scratch(ctx, "pca_Y", (cc.n_rows ? cc.n_rows : 1) * (size_t)L * sizeof(PT), (void**)&Y));
 
-    std::vector<double> theta;
     double resid = INFINITY;
     int iters = 0;
     bool converged = false;
@@ -1848,7 +1851,7 @@ static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const 
             SRX_HIP(ctx, hipGetLastError());
             return SRX_OK;
         };
-        SRX_TRY(subspace_iterate(ctx, w, k, l_act, o, apply, theta, resid, iters, converged));
+        SRX_TRY(subspace_iterate(ctx, w, k, l_act, o, apply, hv ? hv->d_status : nullptr, resid, iters, converged));
     } else {
         auto apply = [&](const double* Win, double* Wout) -> int32_t {
             hipLaunchKernelGGL((k_make_panel<PT>), dim3(1), dim3(1024), 0, ctx->stream, Win, w.d, w.mu,
@@ -1862,7 +1865,7 @@ static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const 
             SRX_HIP(ctx, hipGetLastError());
             return SRX_OK;
         };
-        SRX_TRY(subspace_iterate(ctx, w, k, l_act, o, apply, theta, resid, iters, converged));
+        SRX_TRY(subspace_iterate(ctx, w, k, l_act, o, apply, hv ? hv->d_status : nullptr, resid, iters, converged));
     }
 
     // A2 = W U are the Ritz vectors (ascending-gene row order); sign: largest-|.| entry positive.
@@ -1874,7 +1877,10 @@ static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const 
                        o.center, P, cvec);
     SRX_HIP(ctx, hipGetLastError());
     SRX_TRY((launch_fwd<VT, PT>(ctx, t256, P, cvec, Y)));
-    const size_t need = (cc.n_rows ? cc.n_rows : 1) * (size_t)n_pc * 8;
+    // one allocation: the scores, then the block of small results (layout: srx_pca_state::d_small)
+    const size_t score_bytes = (cc.n_rows ? cc.n_rows : 1) * (size_t)n_pc * 8;
+    const size_t small_doubles = kl + 2 * L + 2 * (size_t)k + 2 + ((size_t)k + 1) / 2;
+    const size_t need = score_bytes + small_doubles * 8;
     if (st.scores_cap < need) {
         if (st.d_scores) SRX_HIP(ctx, hipFree(st.d_scores));
         st.d_scores = nullptr;
@@ -1882,22 +1888,18 @@ static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const 
         SRX_HIP(ctx, hipMalloc((void**)&st.d_scores, need));
         st.scores_cap = need;
     }
+    st.d_small = st.d_scores + score_bytes / 8;
     uint64_t tot = cc.n_rows * (uint64_t)n_pc;
     uint64_t g = (tot + 255) / 256;
     if (g < 1) g = 1;
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL((k_scores<PT>), dim3((unsigned)g), dim3(256), 0, ctx->stream, Y, cc.n_rows, n_pc, st.d_scores);
     SRX_HIP(ctx, hipGetLastError());
-
-    std::vector<double> sgn(L, 1.0), hV(kl);
-    theta.assign(L, 0.0);
-    SRX_TRY(d2h(ctx, hV.data(), w.A2, kl * 8));
-    SRX_TRY(d2h(ctx, theta.data(), w.dTheta, L * 8));
-    SRX_TRY(d2h(ctx, sgn.data(), w.dSgn, L * 8));
-    st.components.assign((size_t)k * n_pc, 0.0);
-    for (int j = 0; j < k; ++j)
-        for (int i = 0; i < n_pc; ++i) st.components[(size_t)j * n_pc + i] = hV[(size_t)j * L + i] * sgn[i];
-    st.evr.assign(theta.begin(), theta.begin() + n_pc);     // eigenvalues of Z^T Z, normalised by the caller
+    // the Ritz vectors, values and signs move out of the (per-context) scratch into the matrix's own block;
+    // their host copies are made by the first fetch (pca_materialize)
+    SRX_HIP(ctx, hipMemcpyAsync(st.d_small, w.A2, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    SRX_HIP(ctx, hipMemcpyAsync(st.d_small + kl, w.dTheta, L * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    SRX_HIP(ctx, hipMemcpyAsync(st.d_small + kl + L, w.dSgn, L * 8, hipMemcpyDeviceToDevice, ctx->stream));
     st.info.n_iter = (uint32_t)(iters + o.warm);
     st.info.residual = resid;
     if (!converged)
@@ -2031,42 +2033,78 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     const HvgDev* hvp = dev_sel ? &hv : nullptr;
     if (is_f32(m)) rc = run_pca<float, float>(m, t256, need128 ? &t128 : nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
     else rc = run_pca<double, double>(m, t256, need128 ? &t128 : nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
+    if ((rc != SRX_OK && rc != SRX_E_NOCONV) || !st.d_small) return rc;      // d_small unset: the solve broke down early
+    // Everything the host side of the result needs stays on the device until the first fetch.
+    const size_t kl = (size_t)k * L;
+    double* sm = st.d_small;
+    st.dev_sel = dev_sel;
     if (dev_sel) {
-        // now that the solve is over: the selection (variance-rank order), its status, and the per-slot vectors
-        int hstat = 0;
-        SRX_TRY(d2h(ctx, &hstat, hv.d_status, sizeof(int)));
-        if (hstat & 1)
-            return fail(ctx, SRX_E_NAN, "NaN gene variance: called `Option::unwrap()` on a `None` value (partial_cmp)");
-        std::vector<int32_t> hsel(k);
-        SRX_TRY(d2h(ctx, hsel.data(), hv.d_sel_rank, (size_t)k * sizeof(int32_t)));
-        SRX_TRY(d2h(ctx, mu.data(), hv.d_mu, (size_t)k * 8));
-        SRX_TRY(d2h(ctx, sd.data(), hv.d_sd, (size_t)k * 8));
-        SRX_TRY(d2h(ctx, &trace, hv.d_trace, 8));
-        for (int i = 0; i < k; ++i) selv[i] = (uint64_t)hsel[i];
-        std::iota(order.begin(), order.end(), 0);
-        std::sort(order.begin(), order.end(), [&](int a, int b) { return selv[a] < selv[b]; });
-        for (int sI = 0; sI < k; ++sI) slot_of_sel[order[sI]] = sI;
+        SRX_HIP(ctx, hipMemcpyAsync(sm + kl + 2 * L, hv.d_mu, (size_t)k * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        SRX_HIP(ctx, hipMemcpyAsync(sm + kl + 2 * L + k, hv.d_sd, (size_t)k * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        SRX_HIP(ctx, hipMemcpyAsync(sm + kl + 2 * L + 2 * (size_t)k, hv.d_trace, 8, hipMemcpyDeviceToDevice, ctx->stream));
+        SRX_HIP(ctx, hipMemcpyAsync(sm + kl + 2 * L + 2 * (size_t)k + 2, hv.d_sel_rank, (size_t)k * sizeof(int32_t),
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+        st.sel.clear();
+    } else {
+        st.pend_mu = mu;
+        st.pend_sd = sd;
+        st.pend_trace = trace;
+        st.sel = selv;
     }
-    if (rc != SRX_OK && rc != SRX_E_NOCONV) return rc;
+    st.k = (uint32_t)k;
+    st.n_pc = (uint32_t)o.n_pc;
+    st.host_pending = true;
+    st.valid = true;
+    return rc;
+}
 
-    // back to selection order; explained variance ratio = eig/total with eig = theta/(N-1),
-    // total = trace(Z^T Z)/(N-1) (pca/mod.rs:131-133)
-    std::vector<double> comp((size_t)k * o.n_pc);
-    for (int i = 0; i < k; ++i)
-        for (int p = 0; p < o.n_pc; ++p) comp[(size_t)i * o.n_pc + p] = st.components[(size_t)slot_of_sel[i] * o.n_pc + p];
-    st.components.swap(comp);
-    for (int p = 0; p < o.n_pc; ++p) st.evr[p] = trace > 0 ? st.evr[p] / trace : 0.0;
+// Host copies of the last solve: components (k x n_pc, rows in SELECTION order, sign-fixed), explained variance
+// ratio = theta / trace(Z^T Z) (pca/mod.rs:131-133: eigenvalues s^2/(N-1) over ALL components), mean / std per
+// selected feature, the selection itself.  One D2H of the matrix's result block.
+static int32_t pca_materialize(srx_mat* m) {
+    srx_pca_state& st = m->pca;
+    if (!st.valid || !st.host_pending) return SRX_OK;
+    srx_ctx* ctx = m->ctx;
+    const int k = (int)st.k, n_pc = (int)st.n_pc;
+    const size_t kl = (size_t)k * L;
+    const size_t small_doubles = kl + 2 * L + 2 * (size_t)k + 2 + ((size_t)k + 1) / 2;
+    std::vector<double> blk(small_doubles);
+    SRX_TRY(d2h(ctx, blk.data(), st.d_small, small_doubles * 8));
+    const double* hV = blk.data();
+    const double* theta = hV + kl;
+    const double* sgn = theta + L;
+    std::vector<double> mu, sd;
+    double trace;
+    if (st.dev_sel) {
+        mu.assign(sgn + L, sgn + L + k);
+        sd.assign(sgn + L + k, sgn + L + 2 * (size_t)k);
+        trace = sgn[L + 2 * (size_t)k];
+        const int32_t* hsel = reinterpret_cast<const int32_t*>(sgn + L + 2 * (size_t)k + 2);
+        st.sel.resize(k);
+        for (int i = 0; i < k; ++i) st.sel[i] = (uint64_t)hsel[i];
+    } else {
+        mu = st.pend_mu;
+        sd = st.pend_sd;
+        trace = st.pend_trace;
+    }
+    // slot (ascending gene order) of every selected feature
+    std::vector<int> order(k), slot_of_sel(k);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return st.sel[a] < st.sel[b]; });
+    for (int sI = 0; sI < k; ++sI) slot_of_sel[order[sI]] = sI;
+    st.components.assign((size_t)k * n_pc, 0.0);
     st.mean.resize(k);
     st.std_.resize(k);
     for (int i = 0; i < k; ++i) {
-        st.mean[i] = mu[slot_of_sel[i]];
-        st.std_[i] = sd[slot_of_sel[i]];
+        const int sl = slot_of_sel[i];
+        for (int p = 0; p < n_pc; ++p) st.components[(size_t)i * n_pc + p] = hV[(size_t)sl * L + p] * sgn[p];
+        st.mean[i] = mu[sl];
+        st.std_[i] = sd[sl];
     }
-    st.sel = selv;
-    st.k = (uint32_t)k;
-    st.n_pc = (uint32_t)o.n_pc;
-    st.valid = true;
-    return rc;
+    st.evr.resize(n_pc);
+    for (int p = 0; p < n_pc; ++p) st.evr[p] = trace > 0 ? theta[p] / trace : 0.0;
+    st.host_pending = false;
+    return SRX_OK;
 }
 
 }  // namespace srx
@@ -2079,9 +2117,10 @@ int32_t srx_result_fetch(srx_mat* m, double* scores, double* components, double*
                          uint64_t* hvg_idx) {
     if (!m) return fail(nullptr, SRX_E_ARG, "null matrix");
     srx_ctx* ctx = m->ctx;
-    const srx_pca_state& st = m->pca;
-    if (!st.valid) return fail(ctx, SRX_E_ARG, "no PCA result on this matrix");
+    if (!m->pca.valid) return fail(ctx, SRX_E_ARG, "no PCA result on this matrix");
     SRX_HIP(ctx, hipSetDevice(ctx->device));
+    if (components || evr || mean || std_ || hvg_idx) SRX_TRY(pca_materialize(m));
+    const srx_pca_state& st = m->pca;
     if (scores) SRX_TRY(d2h(ctx, scores, st.d_scores, m->n_rows * (size_t)st.n_pc * 8));
     if (components) memcpy(components, st.components.data(), st.components.size() * 8);
     if (evr) memcpy(evr, st.evr.data(), st.evr.size() * 8);
