@@ -812,14 +812,24 @@ __global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
             // 1-ulp reciprocal: (p + 0.5) / lb stays >= 0.5 / 128 away from an integer, p < 2^14
             const float rcp = __builtin_amdgcn_rcpf((float)(lbR > 0 ? lbR : 1));
             float pf = (float)q + 0.5f;
-            for (int p = q; __any(p < np); p += 16, pf += 16.0f) {
+            // two product slices (p and p + 16) per pass of the loop: their four staged reads are issued
+            // together and unconditionally (a lane past np reads some record at or past the staging area —
+            // LDS reads beyond the allocation return 0 — and drops it), so a wave has two independent
+            // read -> multiply -> atomic chains behind each wait
+            for (int p = q; __any(p < np); p += 32, pf += 32.0f) {
+                const int ia0 = (int)(pf * rcp), ia1 = (int)((pf + 16.0f) * rcp);          // p / lbR
+                const int ib0 = p - __mul24(ia0, lbR), ib1 = p + 16 - __mul24(ia1, lbR);   // full-rate 24-bit multiply
+                const Entry xa0 = *reinterpret_cast<const Entry*>(base_a + ia0 * (int)sizeof(Entry));
+                const Entry xb0 = *reinterpret_cast<const Entry*>(base_b + ib0 * (int)sizeof(Entry));
+                const Entry xa1 = *reinterpret_cast<const Entry*>(base_a + ia1 * (int)sizeof(Entry));
+                const Entry xb1 = *reinterpret_cast<const Entry*>(base_b + ib1 * (int)sizeof(Entry));
                 if (p < np) {
-                    const int ia = (int)(pf * rcp);                  // p / lbR
-                    const int ib = p - __mul24(ia, lbR);             // full-rate 24-bit multiply
-                    const Entry xa = *reinterpret_cast<const Entry*>(base_a + ia * (int)sizeof(Entry));
-                    const Entry xb = *reinterpret_cast<const Entry*>(base_b + ib * (int)sizeof(Entry));
-                    double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa.j ^ xb.j));
-                    __hip_atomic_fetch_add(dst, gram_product(xa.v, xb.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa0.j ^ xb0.j));
+                    __hip_atomic_fetch_add(dst, gram_product(xa0.v, xb0.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (p + 16 < np) {
+                    double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa1.j ^ xb1.j));
+                    __hip_atomic_fetch_add(dst, gram_product(xa1.v, xb1.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
@@ -1589,7 +1599,9 @@ template <typename VT>
 static int32_t launch_gram(srx_ctx* ctx, const Tiled& g, double* G) {
     const int ntg = g.nt;
     const int n_pairs = ntg * (ntg + 1) / 2;
-    uint64_t n_rb = ((uint64_t)ctx->n_cus * 8 + n_pairs - 1) / n_pairs;      // ~8 workgroups per CU in total
+    const char* kw = getenv("SRX_GRAM_WG_PER_CU");
+    const uint64_t per_cu = kw ? (uint64_t)atoi(kw) : 16;      // 8 -> 16: shorter tail of the last round (8.90 -> 8.69 ms at c3)
+    uint64_t n_rb = ((uint64_t)ctx->n_cus * per_cu + n_pairs - 1) / n_pairs;      // workgroups per CU in total
     uint64_t by_rows = (g.n_rows + 1023) / 1024;
     if (by_rows < 1) by_rows = 1;
     if (n_rb > by_rows) n_rb = by_rows;
