@@ -72,42 +72,72 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     const int wave = threadIdx.x / kWave;
     constexpr int kWaves = kMomThreads / kWave;
 
-    // 4 consecutive entries per lane: one 16-byte load of the indices and one (f32) or two (f64)
-    // of the values, from the 16-byte boundary at or before the segment start; entries outside
-    // [lo, hi) are masked (the arrays are padded by 16 entries)
-    for (uint64_t r = r0 + wave; r < r1; r += kWaves) {
-        int64_t lo, hi;
-        seg_bounds(indptr, tp, n_rows, n_tiles, tile, r, lo, hi);
-        const int64_t base = lo & ~(int64_t)3;
-        for (int64_t e0 = base + 4 * lane; e0 < hi; e0 += 4 * kWave) {
-            int gg[4];
-            if constexpr (sizeof(I) == 4) {
-                const int4 g4 = *reinterpret_cast<const int4*>(idx + e0);
-                gg[0] = g4.x; gg[1] = g4.y; gg[2] = g4.z; gg[3] = g4.w;
-            } else {                                   // four 16-bit indices in one 8-byte load
-                const uint2 g2 = *reinterpret_cast<const uint2*>(idx + e0);
-                gg[0] = (int)(g2.x & 0xffffu); gg[1] = (int)(g2.x >> 16);
-                gg[2] = (int)(g2.y & 0xffffu); gg[3] = (int)(g2.y >> 16);
-            }
-            T v[4];
-            if constexpr (sizeof(T) == 4) {
-                const float4 t4 = *reinterpret_cast<const float4*>(vals + e0);
-                v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
-            } else {
-                const double2 a2 = *reinterpret_cast<const double2*>(vals + e0);
-                const double2 b2 = *reinterpret_cast<const double2*>(vals + e0 + 2);
-                v[0] = a2.x; v[1] = a2.y; v[2] = b2.x; v[3] = b2.y;
-            }
+    // 4 consecutive entries per lane: one 16-byte (8-byte for 16-bit indices) load of the indices and one
+    // (f32) or two (f64) of the values, from the 4-entry boundary at or before the segment start; entries
+    // outside [lo, hi) are masked (the arrays are padded by 16 entries).
+    // A row's segment in one of the 4 gene tiles is ~200 entries — one load pair per lane — and the 140 KB
+    // of accumulators allow 16 waves per CU, so a wave keeps kMomRows row segments in flight (pointer loads
+    // of all of them, then data loads of all of them, then the atomics): with one segment per wave only
+    // ~20 KB per CU were outstanding against the ~60 KB that HBM latency x bandwidth asks for.
+    constexpr int kMomRows = 4;
+    struct Chunk {
+        int gg[4];
+        T v[4];
+    };
+    auto load_chunk = [&](int64_t e0, Chunk& c) {
+        if constexpr (sizeof(I) == 4) {
+            const int4 g4 = *reinterpret_cast<const int4*>(idx + e0);
+            c.gg[0] = g4.x; c.gg[1] = g4.y; c.gg[2] = g4.z; c.gg[3] = g4.w;
+        } else {                                   // four 16-bit indices in one 8-byte load
+            const uint2 g2 = *reinterpret_cast<const uint2*>(idx + e0);
+            c.gg[0] = (int)(g2.x & 0xffffu); c.gg[1] = (int)(g2.x >> 16);
+            c.gg[2] = (int)(g2.y & 0xffffu); c.gg[3] = (int)(g2.y >> 16);
+        }
+        if constexpr (sizeof(T) == 4) {
+            const float4 t4 = *reinterpret_cast<const float4*>(vals + e0);
+            c.v[0] = t4.x; c.v[1] = t4.y; c.v[2] = t4.z; c.v[3] = t4.w;
+        } else {
+            const double2 a2 = *reinterpret_cast<const double2*>(vals + e0);
+            const double2 b2 = *reinterpret_cast<const double2*>(vals + e0 + 2);
+            c.v[0] = a2.x; c.v[1] = a2.y; c.v[2] = b2.x; c.v[3] = b2.y;
+        }
+    };
+    auto add_chunk = [&](int64_t e0, int64_t lo, int64_t hi, const Chunk& c) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t pos = e0 + j;
-                if (pos >= lo && pos < hi) {
-                    const int32_t g0 = gg[j] - gbase;
-                    const double x0 = (double)v[j];
-                    __hip_atomic_fetch_add(&s_cnt[g0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&s_sum[g0], x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&s_sq[g0], x0 * x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+        for (int j = 0; j < 4; ++j) {
+            const int64_t pos = e0 + j;
+            if (pos >= lo && pos < hi) {
+                const int32_t g0 = c.gg[j] - gbase;
+                const double x0 = (double)c.v[j];
+                __hip_atomic_fetch_add(&s_cnt[g0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&s_sum[g0], x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&s_sq[g0], x0 * x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    };
+    for (uint64_t rbase = r0 + wave; rbase < r1; rbase += (uint64_t)kWaves * kMomRows) {
+        int64_t lo[kMomRows], hi[kMomRows];
+#pragma unroll
+        for (int u = 0; u < kMomRows; ++u) {
+            const uint64_t r = rbase + (uint64_t)u * kWaves;
+            if (r < r1) seg_bounds(indptr, tp, n_rows, n_tiles, tile, r, lo[u], hi[u]);
+            else lo[u] = hi[u] = 0;
+        }
+        Chunk c[kMomRows];
+#pragma unroll
+        for (int u = 0; u < kMomRows; ++u) {
+            const int64_t e0 = (lo[u] & ~(int64_t)3) + 4 * lane;
+            if (e0 < hi[u]) load_chunk(e0, c[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kMomRows; ++u) {
+            const int64_t e0 = (lo[u] & ~(int64_t)3) + 4 * lane;
+            if (e0 < hi[u]) add_chunk(e0, lo[u], hi[u], c[u]);
+            // segments longer than 256 entries: the rest, one chunk at a time
+            for (int64_t e1 = e0 + 4 * kWave; e1 < hi[u]; e1 += 4 * kWave) {
+                Chunk cc;
+                load_chunk(e1, cc);
+                add_chunk(e1, lo[u], hi[u], cc);
             }
         }
     }
