@@ -231,3 +231,70 @@ def test_spmm_and_gram_kernels_vs_scipy(ctx, store, n, g, density, k):
     want_g = (A.T @ A).toarray()
     assert np.array_equal(gram, gram.T)
     assert np.array_equal(gram, want_g)                     # integer counts: exact in f64, any order
+
+
+@pytest.mark.gpu
+def test_pipeline_device_selection_ties_and_results(ctx):
+    """The pipeline selects HighlyVariable(n) on the device (k_gene_var / k_hvg_rank / k_sel_finish): the
+    selection and its ORDER must equal the stable descending sort of the oracle (dim_red/mod.rs:135-140)
+    — with ties (duplicated genes: equal variances keep the ascending index), empty genes (variance 0)
+    and the cut falling inside a tie group — and mean / std / explained variance must agree with the
+    host-selection route."""
+    import scipy.sparse as sp
+    import singlerust_amd as sr
+    from singlerust_amd import _ffi
+    from singlerust_amd.memory import processing
+    from singlerust_amd.memory.processing import dim_red
+    rng = np.random.default_rng(5)
+    n, g0 = 3000, 300
+    base = sp.random(n, g0, density=0.08, random_state=7, data_rvs=lambda s: rng.integers(1, 9, s).astype(np.float32),
+                     format="csc", dtype=np.float32)
+    # genes: [base | exact copy of base | 40 empty genes]: every variance appears twice -> ties everywhere
+    x = sp.hstack([base, base, sp.csc_matrix((n, 40), dtype=np.float32)]).tocsr()
+    x.sort_indices()
+    m = oracle.Csr(n, x.shape[1], x.indptr, x.indices, x.data)
+    n_hvg = 151                                       # odd: the cut splits a tie pair
+    lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
+    want_sel = oracle.select_hvg(oracle.compute_variance(lg, COLUMN), n_hvg)
+
+    a, b = adata_of(m, ctx, 1), adata_of(m, ctx, 1)
+    opts = _ffi.PcaOpts(10, -1, -1, -1, 0, 0, 0, 0.0, 3)
+    res = _ffi.PipelineResult()
+    _ffi.check(_ffi.lib().srx_pipeline(b.x().handle, 1e4, n_hvg, C.byref(opts), C.byref(res)), ctx.handle)
+    k = int(res.pca.k)
+    assert k == n_hvg
+    scores, comps = np.zeros((n, 10)), np.zeros((k, 10))
+    evr, mean, std, hv = np.zeros(10), np.zeros(k), np.zeros(k), np.zeros(k, np.uint64)
+    _ffi.check(_ffi.lib().srx_result_fetch(b.x().handle, _ffi.ptr(scores), _ffi.ptr(comps), _ffi.ptr(evr), _ffi.ptr(mean),
+                                           _ffi.ptr(std), _ffi.ptr(hv)), ctx.handle)
+    assert np.array_equal(hv, want_sel)               # identical set AND order
+
+    # host-selection route on the same data
+    processing.normalize_total_inplace(a, 1e4, sr.Direction.Row)
+    processing.log1p_transform_inplace(a)
+    dim_red.pca_inplace(a, 10, None, None, None, sr.FeatureSelection.HighlyVariable(n_hvg), None, seed=3)
+    ref = a.uns["pca"]
+    assert np.array_equal(hv, ref["selected_features"])
+    np.testing.assert_allclose(mean, ref["mean"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(std, ref["std"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(evr, ref["explained_variance_ratio"], rtol=1e-6)
+    # duplicated genes make C rank-deficient but the leading subspace is well defined: compare projectors
+    q1, _ = np.linalg.qr(comps[:, :5]); q2, _ = np.linalg.qr(ref["components"][:, :5])
+    assert np.linalg.norm(q1 @ q1.T - q2 @ q2.T) < 1e-4
+
+
+@pytest.mark.gpu
+def test_pipeline_nan_variance_is_an_error(ctx):
+    """A NaN value makes a gene variance NaN: the reference's partial_cmp().unwrap() panics
+    (dim_red/mod.rs:138); the device-side selection reports it as SRX_E_NAN through the pipeline."""
+    import singlerust_amd as sr
+    from singlerust_amd import _ffi
+    m, _ = synth_host(33, 600, 300, 0.1)
+    vals = m.values.copy()
+    vals[5] = np.nan
+    a = adata_of(m.with_values(vals), ctx, 1)
+    opts = _ffi.PcaOpts(5, -1, -1, -1, 0, 0, 0, 0.0, 0)
+    res = _ffi.PipelineResult()
+    with pytest.raises(sr.SrxError) as e:
+        _ffi.check(_ffi.lib().srx_pipeline(a.x().handle, 1e4, 50, C.byref(opts), C.byref(res)), ctx.handle)
+    assert e.value.code == _ffi.E_NAN
