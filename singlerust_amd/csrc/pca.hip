@@ -1706,12 +1706,25 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     // number the host needs per Rayleigh–Ritz step (the residual) comes back through a pinned slot
     // and an event, read one step late so that the stream never drains.
 
-    // orthonormalise Wp -> W  (CholeskyQR: G = Wp^T Wp = R^T R, W = Wp R^-1); G is in dHG + L*L
-    auto orth = [&](bool have_gram) -> int32_t {
-        if (!have_gram) SRX_TRY(gram2(ctx, w, w.Wp, w.Wp, k));
+    // orthonormalise src -> W  (CholeskyQR: G = src^T src = R^T R, W = src R^-1; src == W is fine: every
+    // thread of the substitution owns one row); G lands in dHG + L*L
+    auto orth = [&](const double* src) -> int32_t {
+        SRX_TRY(gram2(ctx, w, src, src, k));
         hipLaunchKernelGGL(k_chol_factor, dim3(1), dim3(1024), 0, ctx->stream, w.dHG + L * L, l_act, w.dM, w.dDinv, d_status);
-        hipLaunchKernelGGL(k_trsm_rows, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, w.Wp, w.dM, w.dDinv, k, w.W);
+        hipLaunchKernelGGL(k_trsm_rows, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, src, w.dM, w.dDinv, k, w.W);
         SRX_HIP(ctx, hipGetLastError());
+        return SRX_OK;
+    };
+    // `n` applications of C starting from `src`, ping-ponging between Wp and A1 (no copies); returns where
+    // the result is
+    auto apply_n = [&](const double* src, int n, const double** out) -> int32_t {
+        const double* cur = src;
+        for (int t = 0; t < n; ++t) {
+            double* dst = (cur == w.Wp) ? w.A1 : w.Wp;
+            SRX_TRY(apply(cur, dst));
+            cur = dst;
+        }
+        *out = cur;
         return SRX_OK;
     };
     // one Rayleigh–Ritz step on span(W): Wp = C W, H = W^T Wp = U diag(theta) U^T, Ritz vectors
@@ -1737,12 +1750,9 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     auto advance = [&]() -> int32_t {
         // continue from the ROTATED block A1 = (C W) U (same span): its columns are close to eigenvectors,
         // so the next projected matrix is close to diagonal and its Jacobi solve takes 2-3 sweeps, not 8
-        SRX_HIP(ctx, hipMemcpyAsync(w.Wp, w.A1, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        for (int extra = 1; extra < o.power; ++extra) {
-            SRX_TRY(apply(w.Wp, w.A1));
-            SRX_HIP(ctx, hipMemcpyAsync(w.Wp, w.A1, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        }
-        return orth(false);
+        const double* res;
+        SRX_TRY(apply_n(w.A1, o.power - 1, &res));
+        return orth(res);
     };
     auto collect = [&](int slot, double& r, double& ratio) -> int32_t {
         SRX_HIP(ctx, hipEventSynchronize(ctx->async_ev[slot]));
@@ -1758,16 +1768,13 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     };
     // one sweep WITHOUT a Rayleigh–Ritz step: `power` applications of C, then CholeskyQR
     auto plain_sweep = [&]() -> int32_t {
-        for (int t = 0; t < o.power; ++t) {
-            SRX_TRY(apply(t == 0 ? w.W : w.Wp, w.A1));
-            SRX_HIP(ctx, hipMemcpyAsync(w.Wp, w.A1, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        }
-        return orth(false);
+        const double* res;
+        SRX_TRY(apply_n(w.W, o.power, &res));
+        return orth(res);
     };
 
-    SRX_TRY(orth(false));
-    SRX_HIP(ctx, hipMemcpyAsync(w.Wp, w.W, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    SRX_TRY(orth(false));              // CholeskyQR2 on the random start
+    SRX_TRY(orth(w.Wp));
+    SRX_TRY(orth(w.W));                // CholeskyQR2 on the random start
     // warm-up: the first Ritz residuals are O(1) whatever happens — no Rayleigh–Ritz step to learn that
     for (int sweep = 0; sweep < o.warm; ++sweep) SRX_TRY(plain_sweep());
 
