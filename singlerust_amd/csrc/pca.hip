@@ -800,7 +800,25 @@ __global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
         // shuffle: startA (8 bits) | startB (8) | la (8) | lb (8), each <= 128 by construction.
         // The product loop is VALU-issue bound as much as LDS bound (~17 instructions per pass after
         // the diet below, 32 before): no 64-bit arithmetic, no clamps, one multiply in storage precision.
-        const int packed = (cur.startA & 0xff) | ((cur.startB & 0xff) << 8) | (cur.la << 16) | (cur.lb << 24);
+        const int packed_cell = (cur.startA & 0xff) | ((cur.startB & 0xff) << 8) | (cur.la << 16) | (cur.lb << 24);
+        // A pass runs as long as its LONGEST cell needs, so the cells of the batch are first grouped by
+        // product count (<= 16: one atomic slice; <= 32: two; more) with three ballots and one ds_permute:
+        // a pass then holds four cells of the same class and its lanes stay busy (21.6 -> ~16 slices per
+        // batch of 32 cells on the bench matrix).  Order inside a class is the original one.
+        int packed;
+        {
+            const int npl = cur.la * cur.lb;                         // 0 for lanes past the batch
+            const bool valid = lane < cur.nr;
+            const int cls = !valid ? 3 : npl <= 16 ? 0 : npl <= 32 ? 1 : 2;
+            const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const int n0 = __popcll(m0), n1 = __popcll(m1);
+            const int pos = cls == 0 ? __popcll(m0 & below)
+                          : cls == 1 ? n0 + __popcll(m1 & below)
+                          : cls == 2 ? n0 + n1 + __popcll(m2 & below)
+                                     : lane;                          // lanes >= nr keep their place (they are >= nr)
+            packed = __builtin_amdgcn_ds_permute(pos << 2, valid ? packed_cell : 0);
+        }
         const char* sa_bytes = reinterpret_cast<const char*>(s_a);
         const char* sb_bytes = reinterpret_cast<const char*>(s_b);
         for (int rsub = 0; rsub * 4 < cur.nr; ++rsub) {
