@@ -150,6 +150,14 @@ int32_t srx_compute_variance(srx_mat* m, int32_t direction, double* out);
 int32_t srx_compute_std_dev(srx_mat* m, int32_t direction, double* out);
 /* compute_min_max -> csr.rs:194-223 (+inf/-inf for empty). */
 int32_t srx_compute_min_max(srx_mat* m, int32_t direction, double* min_out, double* max_out);
+/* compute_qc_variables (statistics/mod.rs:48-72): the eight vectors of StatisticsContainer
+ * (structs/mod.rs:1-10) from ONE pass over the rows (number, sum, variance per cell; NaN variance
+ * for an empty cell, csr.rs:161) and ONE pass over the columns (the cached per-gene moments) — the
+ * reference makes ~14 serial passes.  Per-cell outputs have n_rows entries, per-gene outputs n_cols;
+ * any pointer may be NULL. */
+int32_t srx_compute_qc_variables(srx_mat* m, uint32_t* num_per_cell, uint32_t* num_per_gene, double* expr_per_gene,
+                                 double* expr_per_cell, double* variance_per_gene, double* variance_per_cell,
+                                 double* std_dev_per_cell, double* std_dev_per_gene);
 /* Superset used internally: per-gene (nnz_j, sum x, sum x^2) from ONE pass. Any output may
  * be NULL. */
 int32_t srx_gene_moments(srx_mat* m, uint64_t* cnt, double* sum, double* sumsq);

@@ -98,6 +98,7 @@ _SIGS = {
     "srx_compute_variance": (C.c_int32, [P, C.c_int32, P]),
     "srx_compute_std_dev": (C.c_int32, [P, C.c_int32, P]),
     "srx_compute_min_max": (C.c_int32, [P, C.c_int32, P, P]),
+    "srx_compute_qc_variables": (C.c_int32, [P, P, P, P, P, P, P, P, P]),
     "srx_gene_moments": (C.c_int32, [P, P, P, P]),
     "srx_normalize_total_inplace": (C.c_int32, [P, C.c_double, C.c_int32]),
     "srx_log1p_inplace": (C.c_int32, [P]),

@@ -599,6 +599,7 @@ int32_t select_hvg_device(srx_mat* m, uint64_t n, int center, int scale, HvgDev&
 }
 
 int32_t row_number(srx_mat* m, uint32_t* out);
+int32_t row_qc(srx_mat* m, uint32_t* num, double* sum, double* var);
 int32_t row_stat(srx_mat* m, int which, double* out0, double* out1);
 
 }  // namespace srx
@@ -651,6 +652,39 @@ int32_t srx_compute_std_dev(srx_mat* m, int32_t direction, double* out) {
     SRX_TRY(srx_compute_variance(m, direction, out));
     uint64_t n = direction == SRX_ROW ? m->n_rows : m->n_cols;
     for (uint64_t i = 0; i < n; ++i) out[i] = std::sqrt(out[i]);   // csr.rs:227
+    return SRX_OK;
+}
+
+int32_t srx_compute_qc_variables(srx_mat* m, uint32_t* num_per_cell, uint32_t* num_per_gene, double* expr_per_gene,
+                                 double* expr_per_cell, double* variance_per_gene, double* variance_per_cell,
+                                 double* std_dev_per_cell, double* std_dev_per_gene) {
+    if (!m) return fail(nullptr, SRX_E_ARG, "null matrix");
+    srx_ctx* ctx = m->ctx;
+    SRX_HIP(ctx, hipSetDevice(ctx->device));
+    // per cell: ONE row pass
+    if (num_per_cell || expr_per_cell || variance_per_cell || std_dev_per_cell) {
+        std::vector<double> var;
+        double* vp = variance_per_cell;
+        if (!vp && std_dev_per_cell) { var.resize(m->n_rows); vp = var.data(); }
+        SRX_TRY(row_qc(m, num_per_cell, expr_per_cell, vp));
+        if (std_dev_per_cell)
+            for (uint64_t i = 0; i < m->n_rows; ++i) std_dev_per_cell[i] = std::sqrt(vp[i]);       // csr.rs:225-228
+    }
+    // per gene: ONE column pass (the cached moments)
+    if (num_per_gene || expr_per_gene || variance_per_gene || std_dev_per_gene) {
+        std::vector<uint64_t> cnt;
+        std::vector<double> sum, sq;
+        SRX_TRY(fetch_moments(m, cnt, sum, sq));
+        const uint64_t G = m->n_cols;
+        if (num_per_gene) for (uint64_t j = 0; j < G; ++j) num_per_gene[j] = (uint32_t)cnt[j];
+        if (expr_per_gene) memcpy(expr_per_gene, sum.data(), G * sizeof(double));
+        if (variance_per_gene || std_dev_per_gene) {
+            std::vector<double> var(G);
+            finalize_variance(cnt.data(), sum.data(), sq.data(), G, var.data());
+            if (variance_per_gene) memcpy(variance_per_gene, var.data(), G * sizeof(double));
+            if (std_dev_per_gene) for (uint64_t j = 0; j < G; ++j) std_dev_per_gene[j] = std::sqrt(var[j]);
+        }
+    }
     return SRX_OK;
 }
 

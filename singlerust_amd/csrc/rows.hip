@@ -156,6 +156,71 @@ __global__ __launch_bounds__(256) void k_row_var(const int64_t* __restrict__ ind
     }
 }
 
+// compute_qc_variables, the per-cell half (statistics/mod.rs:48-72): number (csr.rs:24-27), sum (:87-93) and
+// variance (:158-171: mean = sum/cnt, sum((v - mean)^2)/cnt, 0/0 = NaN for an empty row) of every row in ONE
+// pass — the row stays in registers between the two reductions (rows longer than the cache re-read the tail).
+template <typename T>
+__global__ __launch_bounds__(256) void k_row_qc(const int64_t* __restrict__ indptr, const T* __restrict__ vals,
+                                                uint64_t n_rows, uint32_t* __restrict__ num, double* __restrict__ sum,
+                                                double* __restrict__ var) {
+    constexpr int V = 16 / sizeof(T);
+    constexpr int NV = kRowCache / V;
+    using Vec = RowVec<T>;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
+    const int lane = lane_id();
+    for (uint64_t r = wave; r < n_rows; r += n_waves) {
+        const int64_t lo = indptr[r], hi = indptr[r + 1];
+        const int64_t base = lo & ~(int64_t)(V - 1);
+        const int64_t tail = base + (int64_t)NV * kWave * V;
+        Vec c[NV];
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int64_t e0 = base + ((int64_t)t * kWave + lane) * V;
+            if (e0 < hi) c[t] = *reinterpret_cast<const Vec*>(vals + e0);
+            else {
+#pragma unroll
+                for (int j = 0; j < V; ++j) c[t].x[j] = T(0);
+            }
+        }
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int64_t e0 = base + ((int64_t)t * kWave + lane) * V;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const int64_t pos = e0 + j;
+                s += (pos >= lo && pos < hi) ? (double)c[t].x[j] : 0.0;
+            }
+        }
+        for (int64_t p = tail + lane; p < hi; p += kWave) s += (double)vals[p];
+        s = wave_sum(s);
+        const double cnt = (double)(uint32_t)(hi - lo);
+        const double mean = s / cnt;
+        double a = 0.0;
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+            const int64_t e0 = base + ((int64_t)t * kWave + lane) * V;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const int64_t pos = e0 + j;
+                const double d = (double)c[t].x[j] - mean;
+                a += (pos >= lo && pos < hi) ? d * d : 0.0;
+            }
+        }
+        for (int64_t p = tail + lane; p < hi; p += kWave) {
+            const double d = (double)vals[p] - mean;
+            a += d * d;
+        }
+        a = wave_sum(a);
+        if (lane == 0) {
+            num[r] = (uint32_t)(hi - lo);
+            sum[r] = s;
+            var[r] = a / cnt;
+        }
+    }
+}
+
 // compute_min_max(Row): csr.rs:200-210; f64::min/max skip NaN operands.
 template <typename T>
 __global__ __launch_bounds__(256) void k_row_minmax(const int64_t* __restrict__ indptr, const T* __restrict__ vals,
@@ -219,6 +284,28 @@ int32_t launch_normalize(srx_mat* m, double target, bool do_norm, bool do_log) {
     if (do_norm) m->dtype = SRX_F64;
     if (do_log && m->dtype != SRX_F32) m->dtype = SRX_F64;
     touch(m);
+    return SRX_OK;
+}
+
+// per-cell (number, sum, variance) of compute_qc_variables in one pass; any output may be null
+int32_t row_qc(srx_mat* m, uint32_t* num, double* sum, double* var) {
+    srx_ctx* ctx = m->ctx;
+    const uint64_t N = m->n_rows ? m->n_rows : 1;
+    uint32_t* d_num;
+    double* d_f;
+    SRX_TRY(scratch(ctx, "row_u32", N * sizeof(uint32_t), (void**)&d_num));
+    SRX_TRY(scratch(ctx, "row_f64", 2 * N * sizeof(double), (void**)&d_f));
+    const int g = row_grid(m);
+    if (is_f32(m))
+        hipLaunchKernelGGL((k_row_qc<float>), dim3(g), dim3(256), 0, ctx->stream, m->d_indptr, (const float*)m->d_values,
+                           m->n_rows, d_num, d_f, d_f + N);
+    else
+        hipLaunchKernelGGL((k_row_qc<double>), dim3(g), dim3(256), 0, ctx->stream, m->d_indptr, (const double*)m->d_values,
+                           m->n_rows, d_num, d_f, d_f + N);
+    SRX_HIP(ctx, hipGetLastError());
+    if (num) SRX_TRY(d2h(ctx, num, d_num, m->n_rows * sizeof(uint32_t)));
+    if (sum) SRX_TRY(d2h(ctx, sum, d_f, m->n_rows * sizeof(double)));
+    if (var) SRX_TRY(d2h(ctx, var, d_f + N, m->n_rows * sizeof(double)));
     return SRX_OK;
 }
 

@@ -191,6 +191,24 @@ inline std::pair<std::vector<double>, std::vector<double>> compute_min_max(const
     a.ctx().check(srx_compute_min_max(a.x(), (int)d, mn.data(), mx.data()));
     return {mn, mx};
 }
+// StatisticsContainer (src/memory/statistics/structs/mod.rs:1-10) and compute_qc_variables (mod.rs:48-72)
+struct StatisticsContainer {
+    std::vector<std::uint32_t> num_per_cell, num_per_gene;
+    std::vector<double> expr_per_gene, expr_per_cell, variance_per_gene, variance_per_cell, std_dev_per_cell,
+        std_dev_per_gene;
+};
+inline StatisticsContainer compute_qc_variables(const IMAnnData& a) {
+    const std::size_t n = a.n_obs(), g = a.n_vars();
+    StatisticsContainer c;
+    c.num_per_cell.resize(n); c.num_per_gene.resize(g);
+    c.expr_per_gene.resize(g); c.expr_per_cell.resize(n);
+    c.variance_per_gene.resize(g); c.variance_per_cell.resize(n);
+    c.std_dev_per_cell.resize(n); c.std_dev_per_gene.resize(g);
+    a.ctx().check(srx_compute_qc_variables(a.x(), c.num_per_cell.data(), c.num_per_gene.data(), c.expr_per_gene.data(),
+                                           c.expr_per_cell.data(), c.variance_per_gene.data(), c.variance_per_cell.data(),
+                                           c.std_dev_per_cell.data(), c.std_dev_per_gene.data()));
+    return c;
+}
 }  // namespace statistics
 
 namespace processing {                                           // src/memory/processing/mod.rs:303-332

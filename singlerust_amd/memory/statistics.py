@@ -74,14 +74,28 @@ class StatisticsContainer:          # src/memory/statistics/structs/mod.rs:1-10
 
 
 def compute_qc_variables(adata: IMAnnData) -> StatisticsContainer:
-    """statistics/mod.rs:48-72 (the per-gene vectors all come from ONE cached moments pass)."""
-    return StatisticsContainer(
-        num_per_cell=compute_number(adata, Direction.Row),
-        num_per_gene=compute_number(adata, Direction.Column),
-        expr_per_gene=compute_sum(adata, Direction.Column),
-        expr_per_cell=compute_sum(adata, Direction.Row),
-        variance_per_gene=compute_variance(adata, Direction.Column),
-        variance_per_cell=compute_variance(adata, Direction.Row),
-        std_dev_per_cell=compute_std_dev(adata, Direction.Row),
-        std_dev_per_gene=compute_std_dev(adata, Direction.Column),
-    )
+    """statistics/mod.rs:48-72: one row pass + one column pass on the device (srx_compute_qc_variables)."""
+    n, g = adata.n_obs(), adata.n_vars()
+    out = StatisticsContainer(
+        num_per_cell=np.zeros(n, np.uint32), num_per_gene=np.zeros(g, np.uint32),
+        expr_per_gene=np.zeros(g), expr_per_cell=np.zeros(n),
+        variance_per_gene=np.zeros(g), variance_per_cell=np.zeros(n),
+        std_dev_per_cell=np.zeros(n), std_dev_per_gene=np.zeros(g))
+    F.check(F.lib().srx_compute_qc_variables(
+        adata.x().handle, F.ptr(out.num_per_cell), F.ptr(out.num_per_gene), F.ptr(out.expr_per_gene),
+        F.ptr(out.expr_per_cell), F.ptr(out.variance_per_gene), F.ptr(out.variance_per_cell),
+        F.ptr(out.std_dev_per_cell), F.ptr(out.std_dev_per_gene)), adata.x().ctx.handle)
+    return out
+
+
+def qc_vars_inplace(adata: IMAnnData) -> None:
+    """statistics/mod.rs:74-103: the eight vectors as obs / var columns (same column names)."""
+    d = compute_qc_variables(adata)
+    adata.obs["num_genes_per_cell"] = d.num_per_cell
+    adata.obs["sum_expr_per_cell"] = d.expr_per_cell
+    adata.obs["var_expr_per_cell"] = d.variance_per_cell
+    adata.obs["std_dev_per_cell"] = d.std_dev_per_cell
+    adata.var["num_cells_per_gene"] = d.num_per_gene
+    adata.var["sum_expr_per_gene"] = d.expr_per_gene
+    adata.var["var_expr_per_gene"] = d.variance_per_gene
+    adata.var["std_dev_per_gene"] = d.std_dev_per_gene

@@ -279,3 +279,37 @@ def test_prepare_and_clone_share_the_pattern_index(ctx):
     np.testing.assert_allclose(statistics.compute_variance(b, sr.Direction.Column),
                                statistics.compute_variance(c, sr.Direction.Column), rtol=1e-12, atol=1e-14)
     assert np.array_equal(statistics.compute_sum(a, sr.Direction.Column), oracle.compute_sum(m, COLUMN) if False else statistics.compute_sum(adata_of(m, ctx), sr.Direction.Column))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.uint16])
+def test_compute_qc_variables_matches_oracle(ctx, dtype):
+    """compute_qc_variables (statistics/mod.rs:48-72): the eight vectors from one row pass + one column
+    pass, against the oracle's eight separate reference loops — counts bit-exact, sums of integer data
+    bit-exact, variances to rounding, NaN exactly for the empty cells (csr.rs:161)."""
+    import scipy.sparse as sp
+    import singlerust_amd as sr
+    from singlerust_amd.memory import statistics
+    rng = np.random.default_rng(11)
+    n, g = 700, 450
+    x = sp.random(n, g, density=0.05, random_state=3, format="csr",
+                  data_rvs=lambda s: rng.integers(1, 40, s).astype(np.float64)).astype(dtype)
+    x[17] = 0; x[300] = 0                                   # two empty cells
+    x.eliminate_zeros(); x.sort_indices()
+    m = oracle.Csr(n, g, x.indptr, x.indices, x.data.astype(dtype))
+    a = sr.IMAnnData.new_basic((n, g, m.indptr, m.indices, m.values), ctx=ctx)
+    got = statistics.compute_qc_variables(a)
+    assert np.array_equal(got.num_per_cell, oracle.compute_number(m, ROW))
+    assert np.array_equal(got.num_per_gene, oracle.compute_number(m, COLUMN))
+    assert np.array_equal(got.expr_per_cell, oracle.compute_sum(m, ROW))        # integer data: exact
+    assert np.array_equal(got.expr_per_gene, oracle.compute_sum(m, COLUMN))
+    wv = oracle.compute_variance(m, ROW)
+    assert np.array_equal(np.isnan(got.variance_per_cell), np.isnan(wv)) and np.isnan(wv).sum() == 2
+    ok = ~np.isnan(wv)
+    np.testing.assert_allclose(got.variance_per_cell[ok], wv[ok], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(got.variance_per_gene, oracle.compute_variance(m, COLUMN), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(got.std_dev_per_cell[ok], oracle.compute_std_dev(m, ROW)[ok], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(got.std_dev_per_gene, oracle.compute_std_dev(m, COLUMN), rtol=1e-12, atol=1e-12)
+    statistics.qc_vars_inplace(a)
+    assert set(a.obs) >= {"num_genes_per_cell", "sum_expr_per_cell", "var_expr_per_cell", "std_dev_per_cell"}
+    assert set(a.var) >= {"num_cells_per_gene", "sum_expr_per_gene", "var_expr_per_gene", "std_dev_per_gene"}
