@@ -162,6 +162,25 @@ int32_t srx_compute_qc_variables(srx_mat* m, uint32_t* num_per_cell, uint32_t* n
  * be NULL. */
 int32_t srx_gene_moments(srx_mat* m, uint64_t* cnt, double* sum, double* sumsq);
 
+/* ---- QC filters: memory::processing::filter_cells / filter_genes (processing/mod.rs:86-146, :245-299) -------
+ * FlexValue (src/shared/mod.rs:62-66): Absolute(u32) thresholds the nnz COUNT of the cell / gene, Relative(p)
+ * the linear-interpolated p-quantile of the SUMS (calculate_percentiles, mod.rs:148-174), None = no limit; the
+ * nine (lower, upper) combinations of create_filter_mask (mod.rs:33-84).  `*out` receives a NEW matrix holding
+ * the kept rows / columns in their original order (the reference's `subset`; the in-place forms swap it in);
+ * `mask_out` (n_rows resp. n_cols bytes, may be NULL) receives the boolean mask. */
+enum { SRX_FLEX_NONE = 0, SRX_FLEX_ABSOLUTE = 1, SRX_FLEX_RELATIVE = 2 };
+typedef struct srx_flex {
+    int32_t kind;      /* SRX_FLEX_* */
+    uint32_t absolute; /* FlexValue::Absolute(u32) */
+    double relative;   /* FlexValue::Relative(f64), a quantile in [0, 1] */
+} srx_flex;
+int32_t srx_filter_cells(srx_mat* m, srx_flex lower, srx_flex upper, srx_mat** out, uint8_t* mask_out);
+int32_t srx_filter_genes(srx_mat* m, srx_flex lower, srx_flex upper, srx_mat** out, uint8_t* mask_out);
+/* anndata `subset` on X: boolean masks over rows / columns (NULL = keep all), order preserved. */
+int32_t srx_subset(srx_mat* m, const uint8_t* row_mask, const uint8_t* col_mask, srx_mat** out);
+/* Sparsity pattern back to the host in the reference's layout (u64 offsets / indices); either may be NULL. */
+int32_t srx_matrix_download_pattern(srx_mat* m, uint64_t* indptr_out, uint64_t* indices_out);
+
 /* ---- normalise / log1p: memory::processing::* ------------------------------------------- */
 /* normalize_total_inplace (processing/mod.rs:303-312 -> scale/mod.rs:7-23,59-89;
  * Column: :91-107,141-173).  scale = (sum == 0) ? 0 : target/sum; v *= scale.  The logical

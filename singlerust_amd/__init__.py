@@ -7,7 +7,7 @@ lib/libsrx_hip.so (hand-written HIP); nothing here computes on the CPU.
 """
 from . import _ffi
 from ._ffi import SrxError
-from .anndata import Context, DeviceCsr, Direction, FeatureSelection, IMAnnData
+from .anndata import Context, DeviceCsr, Direction, FeatureSelection, FlexValue, IMAnnData
 from . import memory
 
-__all__ = ["Context", "DeviceCsr", "Direction", "FeatureSelection", "IMAnnData", "SrxError", "memory", "_ffi"]
+__all__ = ["Context", "DeviceCsr", "Direction", "FeatureSelection", "FlexValue", "IMAnnData", "SrxError", "memory", "_ffi"]

@@ -70,6 +70,11 @@ class SynthParams(C.Structure):
                 ("value_boost", C.c_uint32)]
 
 
+class Flex(C.Structure):            # srx_flex: FlexValue (src/shared/mod.rs:62-66)
+    _fields_ = [("kind", C.c_int32), ("absolute", C.c_uint32), ("relative", C.c_double)]
+
+
+FLEX_NONE, FLEX_ABSOLUTE, FLEX_RELATIVE = 0, 1, 2
 P = C.c_void_p
 _SIGS = {
     # name: (restype, argtypes)
@@ -99,6 +104,10 @@ _SIGS = {
     "srx_compute_std_dev": (C.c_int32, [P, C.c_int32, P]),
     "srx_compute_min_max": (C.c_int32, [P, C.c_int32, P, P]),
     "srx_compute_qc_variables": (C.c_int32, [P, P, P, P, P, P, P, P, P]),
+    "srx_filter_cells": (C.c_int32, [P, Flex, Flex, C.POINTER(C.c_void_p), P]),
+    "srx_filter_genes": (C.c_int32, [P, Flex, Flex, C.POINTER(C.c_void_p), P]),
+    "srx_subset": (C.c_int32, [P, P, P, C.POINTER(C.c_void_p)]),
+    "srx_matrix_download_pattern": (C.c_int32, [P, P, P]),
     "srx_gene_moments": (C.c_int32, [P, P, P, P]),
     "srx_normalize_total_inplace": (C.c_int32, [P, C.c_double, C.c_int32]),
     "srx_log1p_inplace": (C.c_int32, [P]),

@@ -50,6 +50,32 @@ class FeatureSelection:                 # src/shared/mod.rs:17-23
     None_ = NoSelection()
 
 
+class FlexValue:                        # src/shared/mod.rs:62-66
+    @dataclass(frozen=True)
+    class Absolute:
+        value: int
+
+    @dataclass(frozen=True)
+    class Relative:
+        value: float
+
+    @dataclass(frozen=True)
+    class NoLimit:
+        pass
+
+    None_ = NoLimit()
+
+    @staticmethod
+    def to_c(v) -> "F.Flex":
+        if v is None or isinstance(v, FlexValue.NoLimit):
+            return F.Flex(F.FLEX_NONE, 0, 0.0)
+        if isinstance(v, FlexValue.Absolute):
+            return F.Flex(F.FLEX_ABSOLUTE, int(v.value), 0.0)
+        if isinstance(v, FlexValue.Relative):
+            return F.Flex(F.FLEX_RELATIVE, 0, float(v.value))
+        raise TypeError(f"not a FlexValue: {v!r}")
+
+
 NP_OF_DTYPE = {F.I8: np.int8, F.I16: np.int16, F.I32: np.int32, F.U8: np.uint8, F.U16: np.uint16,
                F.U32: np.uint32, F.F32: np.float32, F.F64: np.float64}
 DTYPE_OF_NP = {np.dtype(v): k for k, v in NP_OF_DTYPE.items()}
@@ -220,8 +246,26 @@ class IMAnnData:
     def x_dtype(self) -> np.dtype:
         return np.dtype(NP_OF_DTYPE[self._x.info().dtype])
 
-    def x_values(self) -> np.ndarray:
-        return self._x.values()
+    def x_values(self, dtype=None) -> np.ndarray:
+        return self._x.values(dtype)
+
+    @classmethod
+    def _from_device(cls, dev: DeviceCsr, obs_names, var_names) -> "IMAnnData":
+        """Wrap a matrix the library produced (filter / subset): the host pattern copy is downloaded."""
+        i = dev.info()
+        indptr = np.zeros(i.n_rows + 1, dtype=np.uint64)
+        indices = np.zeros(i.nnz, dtype=np.uint64)
+        F.check(F.lib().srx_matrix_download_pattern(dev.handle, F.ptr(indptr), F.ptr(indices)), dev.ctx.handle)
+        return cls(dev, indptr, indices, obs_names, var_names)
+
+    def _adopt(self, other: "IMAnnData") -> None:
+        """subset_inplace: this object takes over `other`'s X and names; per-row / per-column annotations that no
+        longer match are dropped."""
+        self._x.free()
+        self._x = other._x
+        self.indptr, self.indices = other.indptr, other.indices
+        self.obs_names, self.var_names = other.obs_names, other.var_names
+        self.obsm, self.varm, self.obs, self.var = {}, {}, {}, {}
 
     def deep_clone(self) -> "IMAnnData":
         c = IMAnnData(self._x.clone(), self.indptr, self.indices, self.obs_names, self.var_names)

@@ -1383,7 +1383,7 @@ static int grid_rows(const srx_ctx* ctx, uint64_t n_rows, int rows_per_block) {
 }
 
 // out[0..n] = exclusive scan of in[0..n), out[n] = total (also left in *total_dev).
-static int32_t scan_exclusive(srx_ctx* ctx, const int64_t* d_in, uint64_t n, int64_t* d_out, int64_t** total_dev) {
+int32_t scan_exclusive(srx_ctx* ctx, const int64_t* d_in, uint64_t n, int64_t* d_out, int64_t** total_dev) {
     const uint64_t per_block = (uint64_t)kScanBlock * kScanItems;
     const uint64_t nb = (n + per_block - 1) / per_block > 0 ? (n + per_block - 1) / per_block : 1;
     int64_t* d_bsum;

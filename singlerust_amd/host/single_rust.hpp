@@ -47,6 +47,13 @@ struct FeatureSelection {                                        // src/shared/m
     static FeatureSelection None() { return FeatureSelection(); }
 };
 
+struct FlexValue {                                               // src/shared/mod.rs:62-66
+    srx_flex c{SRX_FLEX_NONE, 0, 0.0};
+    static FlexValue Absolute(std::uint32_t v) { FlexValue f; f.c = srx_flex{SRX_FLEX_ABSOLUTE, v, 0.0}; return f; }
+    static FlexValue Relative(double p) { FlexValue f; f.c = srx_flex{SRX_FLEX_RELATIVE, 0, p}; return f; }
+    static FlexValue None() { return FlexValue(); }
+};
+
 // nalgebra_sparse::CsrMatrix<T> as the reference holds it (usize offsets/indices, typed values).
 template <typename T>
 struct CsrMatrix {
@@ -150,6 +157,21 @@ public:
         c.varm_ = varm_;
         return c;
     }
+    // a matrix the library produced (filter / subset): the host copy of the pattern is downloaded
+    static IMAnnData from_device(Context& ctx, srx_mat* x, std::vector<std::string> obs_names,
+                                 std::vector<std::string> var_names) {
+        IMAnnData a(ctx);
+        a.x_ = x;
+        auto i = a.info();
+        a.row_offsets_.resize(i.n_rows + 1);
+        a.col_indices_.resize(i.nnz);
+        ctx.check(srx_matrix_download_pattern(x, a.row_offsets_.data(), a.col_indices_.data()));
+        a.obs_names_ = std::move(obs_names);
+        a.var_names_ = std::move(var_names);
+        return a;
+    }
+    const std::vector<std::string>& obs_names() const { return obs_names_; }
+    const std::vector<std::string>& var_names() const { return var_names_; }
     std::map<std::string, Array2>& obsm() { return obsm_; }
     std::map<std::string, Array2>& varm() { return varm_; }
 
@@ -226,6 +248,25 @@ inline IMAnnData log1p_transform(const IMAnnData& a) {
     log1p_transform_inplace(n);
     return n;
 }
+
+// filter_cells / filter_genes (processing/mod.rs:118-146, :271-299) and their in-place forms (:86-116, :245-269)
+inline IMAnnData filter_impl(const IMAnnData& a, const FlexValue& lo, const FlexValue& hi, bool genes) {
+    const std::size_t n = genes ? a.n_vars() : a.n_obs();
+    std::vector<std::uint8_t> mask(n ? n : 1);
+    srx_mat* out = nullptr;
+    a.ctx().check(genes ? srx_filter_genes(a.x(), lo.c, hi.c, &out, mask.data())
+                        : srx_filter_cells(a.x(), lo.c, hi.c, &out, mask.data()));
+    std::vector<std::string> obs, var;
+    for (std::size_t i = 0; i < a.obs_names().size(); ++i)
+        if (genes || mask[i]) obs.push_back(a.obs_names()[i]);
+    for (std::size_t j = 0; j < a.var_names().size(); ++j)
+        if (!genes || mask[j]) var.push_back(a.var_names()[j]);
+    return IMAnnData::from_device(a.ctx(), out, std::move(obs), std::move(var));
+}
+inline IMAnnData filter_cells(const IMAnnData& a, const FlexValue& lo, const FlexValue& hi) { return filter_impl(a, lo, hi, false); }
+inline IMAnnData filter_genes(const IMAnnData& a, const FlexValue& lo, const FlexValue& hi) { return filter_impl(a, lo, hi, true); }
+inline void filter_cells_inplace(IMAnnData& a, const FlexValue& lo, const FlexValue& hi) { a = filter_impl(a, lo, hi, false); }
+inline void filter_genes_inplace(IMAnnData& a, const FlexValue& lo, const FlexValue& hi) { a = filter_impl(a, lo, hi, true); }
 
 namespace dim_red {                                              // src/memory/processing/dim_red/mod.rs
 inline std::vector<std::uint64_t> select_features(const IMAnnData& a, const FeatureSelection& fs) {   // :123-156

@@ -137,6 +137,24 @@ static void test_path_end_to_end(Context& ctx) {
     EXPECT(again.obsm().at("X_pca").ncols == 2, "default n_components");
 }
 
+// mod.rs:385-417 (test_filter_cells / test_filter_genes): every filter drops something on the random matrix
+static void test_filters(Context& ctx) {
+    auto x = create_large_test_data(1000, 100, 10.0, 19);
+    IMAnnData adata = IMAnnData::new_basic(ctx, x, names("obs", 1000), names("var", 100));
+    IMAnnData f1 = proc::filter_cells(adata, FlexValue::Absolute(5), FlexValue::Absolute(15));
+    EXPECT(f1.n_obs() < adata.n_obs(), "cells after absolute filtering: %zu", f1.n_obs());
+    auto num = stats::compute_number(f1, Direction::Row);
+    for (auto c : num) EXPECT(c >= 5 && c <= 15, "kept cell with %u genes", c);
+    IMAnnData f2 = proc::filter_cells(adata, FlexValue::Relative(0.1), FlexValue::Relative(0.9));
+    EXPECT(f2.n_obs() < adata.n_obs(), "cells after relative filtering: %zu", f2.n_obs());
+    IMAnnData g1 = proc::filter_genes(adata, FlexValue::Absolute(50), FlexValue::Absolute(100));
+    EXPECT(g1.n_vars() < adata.n_vars(), "genes after absolute filtering: %zu", g1.n_vars());
+    IMAnnData g2 = proc::filter_genes(adata, FlexValue::Relative(0.1), FlexValue::Relative(0.9));
+    EXPECT(g2.n_vars() < adata.n_vars(), "genes after relative filtering: %zu", g2.n_vars());
+    proc::filter_genes_inplace(adata, FlexValue::Relative(0.1), FlexValue::None());
+    EXPECT(adata.n_vars() == 90 && adata.var_names().size() == 90, "in-place gene filter kept %zu", adata.n_vars());
+}
+
 static void test_errors(Context& ctx) {
     auto x = create_large_test_data(4, 6, 2.0, 3);
     IMAnnData tiny = IMAnnData::new_basic(ctx, x, names("obs", 4), names("var", 6));
@@ -154,6 +172,7 @@ int main() {
         Context ctx(0);
         test_normalize_total(ctx);
         test_path_end_to_end(ctx);
+        test_filters(ctx);
         test_errors(ctx);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "exception: %s\n", e.what());

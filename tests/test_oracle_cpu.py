@@ -138,3 +138,29 @@ def test_pca_oracle_vs_sklearn():
     # defaults: n_components None -> 2 (dim_red/mod.rs:52)
     s2, c2, *_ = pca_oracle.pca_inplace(lg, None, None, None, sel)
     assert s2.shape == (600, 2) and c2.shape == (120, 2)
+
+
+def test_filter_oracle_kat_4x5():
+    """Hand-derived from the cited loops (processing/mod.rs:33-84, 148-174) on the 4x5 KAT matrix:
+    row counts [2,1,0,3], row sums [4,2,0,6]; column counts [2,2,1,1,0], column sums [3,4,4,1,0]."""
+    from oracle import filter_oracle as fo
+    m = oracle.Csr(4, 5, [0, 2, 3, 3, 6], [1, 3, 0, 0, 1, 2], np.array([3, 1, 2, 1, 1, 4], dtype=np.float64))
+    out, mask = fo.filter_cells(m, fo.absolute(2), fo.NONE)                 # n_genes >= 2
+    assert mask.tolist() == [True, False, False, True]
+    assert out.indptr.tolist() == [0, 2, 5] and out.indices.tolist() == [1, 3, 0, 1, 2]
+    # Relative limits act on the SUMS: sorted [0,2,4,6]; q(0.5) = 2 + (4-2)*0.5 = 3; q(1.0) = 6
+    out, mask = fo.filter_cells(m, fo.relative(0.5), fo.relative(1.0))
+    assert mask.tolist() == [True, False, False, True]
+    # mixed: count >= 1 and sum <= q(0.5) = 3  -> only row 1 (count 1, sum 2)
+    out, mask = fo.filter_cells(m, fo.absolute(1), fo.relative(0.5))
+    assert mask.tolist() == [False, True, False, False] and out.values.tolist() == [2.0]
+    # genes: sums sorted [0,1,3,4,4]: q(0.25) = 1, q(0.9): idx 3.6 -> 4 + (4-4)*0.6 = 4
+    out, mask = fo.filter_genes(m, fo.relative(0.25), fo.relative(0.9))
+    assert mask.tolist() == [True, True, True, True, False] and out.n_cols == 4
+    out, mask = fo.filter_genes(m, fo.absolute(2), fo.absolute(2))
+    assert mask.tolist() == [True, True, False, False, False]
+    assert out.indptr.tolist() == [0, 1, 2, 2, 4] and out.indices.tolist() == [1, 0, 0, 1] and out.values.tolist() == [3, 2, 1, 1]
+    # (None, None) keeps everything; not-Relative limits use f64::MIN / f64::MAX
+    assert fo.calculate_percentiles(np.array([1.0, 2.0]), fo.NONE, fo.absolute(3)) == (fo.F64_MIN, fo.F64_MAX)
+    out, mask = fo.filter_cells(m, fo.NONE, fo.NONE)
+    assert mask.all() and out.values.tolist() == m.values.tolist()
