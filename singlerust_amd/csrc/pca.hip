@@ -870,33 +870,37 @@ __global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
     }
 }
 
-// Graw (k x k, both triangles) = sum over row blocks of the partial tiles.
-__global__ void k_gram_reduce(const double* __restrict__ part, uint64_t n_rb, int n_pairs, int ntg, int k,
-                              double* __restrict__ G) {
+// Packed Gram: P[pair][128 x 128] = sum over row blocks of the partial tiles (fixed order), pairs (a <= b)
+// a-major.  Only these n_t (n_t + 1) / 2 tiles cross the xGMI links when the rows are sharded (17.8 MB instead
+// of the 32 MB of the full k x k matrix at k = 2000).
+__global__ void k_gram_reduce(const double* __restrict__ part, uint64_t n_rb, int n_pairs, double* __restrict__ P) {
     const int pair = blockIdx.y;
-    int a = 0, rem = pair;
-    while (rem >= ntg - a) { rem -= ntg - a; ++a; }
-    const int b = a + rem;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= KG * KG) return;
-    const int ja = a * KG + e / KG, jb = b * KG + e % KG;
-    if (ja >= k || jb >= k) return;
-    if (a == b && jb < ja) return;            // diagonal tiles: take the upper triangle, mirror it
     double s = 0.0;
     for (uint64_t r = 0; r < n_rb; ++r) s += part[(r * (uint64_t)n_pairs + pair) * (uint64_t)(KG * KG) + e];
-    G[(size_t)ja * k + jb] = s;
-    G[(size_t)jb * k + ja] = s;
+    P[(size_t)pair * (KG * KG) + e] = s;
 }
 
-// C = D (G - cen * N mu mu^T) D, in place.
-__global__ void k_gram_finish(double* __restrict__ G, const double* __restrict__ d, const double* __restrict__ mu, int k,
-                              int cen, double n_cells) {
-    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// C (k x k, both triangles) from the packed tiles: entry (i, j) with i <= j in tile order comes from pair
+// (a, b) = (i / 128, j / 128) — diagonal tiles hold their upper triangle — and (j, i) mirrors it, so C is
+// EXACTLY symmetric (k_dense_apply reads it transposed).  With d != nullptr: C = D (G - cen N mu mu^T) D.
+__global__ void k_gram_expand(const double* __restrict__ P, int ntg, int k, const double* __restrict__ d,
+                              const double* __restrict__ mu, int cen, double n_cells, double* __restrict__ C) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (uint64_t)k * k) return;
-    int i = (int)(e / k), j = (int)(e % k);
-    double g = G[e];
-    if (cen) g -= n_cells * (mu[i] * mu[j]);     // (mu_i mu_j) first: C stays EXACTLY symmetric, k_dense_apply reads it transposed
-    G[e] = d[i] * d[j] * g;
+    const int i = (int)(e / k), j = (int)(e % k);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const int a = lo / KG, b = hi / KG;                     // a <= b
+    int ra = lo % KG, rb = hi % KG;
+    if (a == b && rb < ra) { const int t = ra; ra = rb; rb = t; }     // same tile: upper triangle
+    const int pair = a * ntg - a * (a - 1) / 2 + (b - a);
+    double g = P[(size_t)pair * (KG * KG) + ra * KG + rb];
+    if (d) {
+        if (cen) g -= n_cells * (mu[i] * mu[j]);            // (mu_i mu_j) first: symmetric to the last bit
+        g = d[i] * d[j] * g;
+    }
+    C[e] = g;
 }
 
 // Wp += C[:, krange] W[krange, :] for the dense SYMMETRIC k x k matrix C and a k x 64 block (f64), on the
@@ -1616,7 +1620,7 @@ static int32_t launch_t(srx_ctx* ctx, const Tiled& c, const YT* Y, double* T /* 
 
 // G (k x k, raw A^T A summed over ranks) from the 128-tiled matrix.
 template <typename VT>
-static int32_t launch_gram(srx_ctx* ctx, const Tiled& g, double* G) {
+static int32_t launch_gram(srx_ctx* ctx, const Tiled& g, double** packed_out, size_t* packed_count) {
     const int ntg = g.nt;
     const int n_pairs = ntg * (ntg + 1) / 2;
     const char* kw = getenv("SRX_GRAM_WG_PER_CU");
@@ -1639,9 +1643,12 @@ static int32_t launch_gram(srx_ctx* ctx, const Tiled& g, double* G) {
     SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_sparse<VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_gram_sparse<VT>), dim3((unsigned)(n_rb * n_pairs)), dim3(kGramWaves * kWave), lds, ctx->stream, g.tptr,
                        (const GramPk<VT>*)g.tpk, g.n_rows, ntg, rpb, n_pairs, part);
-    hipLaunchKernelGGL(k_gram_reduce, dim3((KG * KG + 255) / 256, n_pairs), dim3(256), 0, ctx->stream, part, n_rb, n_pairs,
-                       ntg, g.k, G);
+    double* P;
+    SRX_TRY(scratch(ctx, "pca_gpacked", (size_t)n_pairs * KG * KG * sizeof(double), (void**)&P));
+    hipLaunchKernelGGL(k_gram_reduce, dim3((KG * KG + 255) / 256, n_pairs), dim3(256), 0, ctx->stream, part, n_rb, n_pairs, P);
     SRX_HIP(ctx, hipGetLastError());
+    *packed_out = P;
+    *packed_count = (size_t)n_pairs * KG * KG;
     return SRX_OK;
 }
 
@@ -1878,10 +1885,12 @@ static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const 
         const Tiled& t128 = *t128p;
         double* C;
         SRX_TRY(scratch(ctx, "pca_C", (size_t)k * k * 8, (void**)&C));
-        SRX_TRY(launch_gram<VT>(ctx, t128, C));
-        SRX_TRY(allreduce_f64(ctx, C, (size_t)k * k));            // the one exchange of this solver
-        hipLaunchKernelGGL(k_gram_finish, dim3((unsigned)(((size_t)k * k + 255) / 256)), dim3(256), 0, ctx->stream, C,
-                           w.d, w.mu, k, o.center, n_cells);
+        double* Pk;
+        size_t n_packed;
+        SRX_TRY(launch_gram<VT>(ctx, t128, &Pk, &n_packed));
+        SRX_TRY(allreduce_f64(ctx, Pk, n_packed));                // the one exchange of this solver: upper tiles only
+        hipLaunchKernelGGL(k_gram_expand, dim3((unsigned)(((size_t)k * k + 255) / 256)), dim3(256), 0, ctx->stream, Pk,
+                           t128.nt, k, (const double*)w.d, (const double*)w.mu, o.center, n_cells, C);
         SRX_HIP(ctx, hipGetLastError());
         auto apply = [&](const double* Win, double* Wout) -> int32_t {
             ProfScope ps(ctx, SRX_K_DENSE, (double)k * k * 8.0 + 2.0 * k * L * 8.0);
@@ -2234,7 +2243,12 @@ int32_t srx_spmm(srx_mat* m, const uint64_t* sel, uint64_t k64, const double* pa
             const Tiled& g = c128;
             double* C;
             SRX_TRY(scratch(ctx, "pca_C", (size_t)k * k * 8, (void**)&C));
-            SRX_TRY(launch_gram<VT>(ctx, g, C));
+            double* Pk;
+            size_t n_packed;
+            SRX_TRY(launch_gram<VT>(ctx, g, &Pk, &n_packed));
+            hipLaunchKernelGGL(k_gram_expand, dim3((unsigned)(((size_t)k * k + 255) / 256)), dim3(256), 0, ctx->stream, Pk,
+                               g.nt, k, (const double*)nullptr, (const double*)nullptr, 0, 0.0, C);
+            SRX_HIP(ctx, hipGetLastError());
             SRX_TRY(d2h(ctx, gram_out, C, (size_t)k * k * 8));
         }
         return SRX_OK;
