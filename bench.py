@@ -266,6 +266,9 @@ def main():
                 "nnz_hvg_compacted_per_gpu": int(res.pca.nnz_selected),
                 "subspace_iterations": iters, "pca_residual": float(res.pca.residual),
                 "pca_solver": {1: "gram", 2: "spmm"}.get(int(res.pca.solver), "?"),
+                # the ~80 small launches of the subspace iteration are replayed from captured hipGraphs (three
+                # segments per solve); their kernels are therefore not bracketed by per-class events
+                "pca_iteration_hip_graphs": int(res.pca.solver) == 1 and not os.environ.get("SRX_NO_GRAPH"),
             },
             # the kernel with the largest share of the step (live HIP-event timing on the ctx stream)
             "roofline": roof(dom_name, dom, KERNEL_SYMBOL.get(dom_name, dom_name), ROOF_NOTE.get(dom_name, "")),

@@ -81,7 +81,12 @@ struct srx_ctx {
     size_t pinned_bytes = 0;
     // asynchronous read-back slots of the PCA driver (residual + status per Rayleigh–Ritz step)
     static constexpr int kAsyncSlots = 4;
-    double* pin_async = nullptr;             // kAsyncSlots x 2 doubles, pinned
+    // hipGraph cache of the PCA driver: the subspace iteration is ~100 small dependent launches per pipeline
+    // step; captured once per (shape, schedule, buffers) and replayed with one hipGraphLaunch per segment
+    std::map<std::string, hipGraphExec_t> graphs;
+    bool graphs_off = false;                 // capture failed once (or SRX_NO_GRAPH): plain launches from then on
+    bool capturing = false;                  // ProfScope and friends stay out of a capture
+    double* pin_async = nullptr;             // kAsyncSlots x 4 doubles, pinned
     hipEvent_t async_ev[kAsyncSlots] = {nullptr, nullptr, nullptr, nullptr};
 };
 

@@ -83,7 +83,7 @@ static hipEvent_t take_event(srx_ctx* ctx) {
 }
 
 ProfScope::ProfScope(srx_ctx* c, int cls_, double alg_bytes) : ctx(c), cls(cls_) {
-    if (!(ctx->prof_mask & (1u << cls))) return;
+    if (!(ctx->prof_mask & (1u << cls)) || ctx->capturing) return;      // no event nodes inside a captured graph
     e0 = take_event(ctx);
     e1 = take_event(ctx);
     if (!e0 || !e1) { e0 = e1 = nullptr; return; }
@@ -253,6 +253,7 @@ void srx_ctx_destroy(srx_ctx* ctx) {
         }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
     if (ctx->pin_async) (void)hipHostFree(ctx->pin_async);
     for (auto e : ctx->async_ev)
         if (e) (void)hipEventDestroy(e);

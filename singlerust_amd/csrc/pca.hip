@@ -1705,13 +1705,53 @@ static int32_t gram2(srx_ctx* ctx, const Work& w, const double* A, const double*
     return SRX_OK;
 }
 
+// Run `enqueue` (kernel launches / async memsets and copies on ctx->stream, no host synchronisation, no
+// allocation) through a cached hipGraph: captured the first time a key is seen, one hipGraphLaunch afterwards.
+// The key must name everything the launches depend on (shapes, schedule, device pointers).  Any failure of the
+// graph machinery switches the context back to plain launches for good.
+template <typename Fn>
+static int32_t graphed(srx_ctx* ctx, bool enable, const std::string& key, Fn&& enqueue) {
+    if (!enable || ctx->graphs_off) return enqueue();
+    auto it = ctx->graphs.find(key);
+    if (it == ctx->graphs.end()) {
+        if (ctx->graphs.size() >= 32) {                     // stale keys (scratch regrown): start over
+            for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
+            ctx->graphs.clear();
+        }
+        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->graphs_off = true;
+            return enqueue();
+        }
+        ctx->capturing = true;
+        const int32_t rc = enqueue();
+        ctx->capturing = false;
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+        hipGraphExec_t ex = nullptr;
+        if (rc == SRX_OK && e == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess) {
+            (void)hipGraphDestroy(g);
+            it = ctx->graphs.emplace(key, ex).first;
+        } else {
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            ctx->graphs_off = true;
+            return rc != SRX_OK ? rc : enqueue();
+        }
+    }
+    SRX_HIP(ctx, hipGraphLaunch(it->second, ctx->stream));
+    return SRX_OK;
+}
+
 // Block subspace iteration with Rayleigh–Ritz on span(W); `apply(W, Wp)` computes Wp = C W.
 // On return w.A2 = W U holds the Ritz vectors (k x 64, leading n_pc columns meaningful),
 // theta their Ritz values, w.dColmax the largest-|.| entry of each Ritz vector.
 template <typename Apply>
 static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, const Resolved& o, Apply&& apply,
-                                const int* d_status_sel, double& resid, int& iters, bool& converged) {
+                                const void* apply_id, bool graphable, const int* d_status_sel, double& resid, int& iters,
+                                bool& converged) {
     const size_t kl = (size_t)k * L;
+    const bool use_graph = graphable && !getenv("SRX_NO_GRAPH");
     constexpr int kSlots = srx_ctx::kAsyncSlots, kSlotDoubles = 4;
     if (!ctx->pin_async) {
         SRX_HIP(ctx, hipHostMalloc((void**)&ctx->pin_async, kSlots * kSlotDoubles * sizeof(double), hipHostMallocDefault));
@@ -1721,11 +1761,14 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     double* d_res;
     SRX_TRY(scratch(ctx, "pca_status", 256, (void**)&d_status));
     SRX_TRY(scratch(ctx, "pca_res", kSlots * kSlotDoubles * sizeof(double), (void**)&d_res));
-    SRX_HIP(ctx, hipMemsetAsync(d_status, 0, 256, ctx->stream));
     SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_jacobi_eig, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)kJacobiLds));
-
-    hipLaunchKernelGGL(k_init_block, dim3((unsigned)((kl + 255) / 256)), dim3(256), 0, ctx->stream, o.seed, k, l_act, w.Wp);
+    // what a captured segment depends on besides its own schedule: shapes, options, every buffer it touches
+    char key0[256];
+    snprintf(key0, sizeof key0, "k%d l%d p%d w%d n%d s%llu|%p %p %p %p %p %p %p %p %p", k, l_act, o.power, o.warm, o.n_pc,
+             (unsigned long long)o.seed, apply_id, (void*)w.W, (void*)w.Wp, (void*)w.A1, (void*)w.A2, (void*)w.small,
+             (void*)w.gpart, (void*)d_status, (void*)d_status_sel);
+    const std::string key_base(key0);
 
     // Everything below only ENQUEUES work: the l x l factorisations run on the device, and the one
     // number the host needs per Rayleigh–Ritz step (the residual) comes back through a pinned slot
@@ -1754,7 +1797,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     };
     // one Rayleigh–Ritz step on span(W): Wp = C W, H = W^T Wp = U diag(theta) U^T, Ritz vectors
     // A2 = W U, residuals || C v_i - theta_i v_i || in f64; slot <- (residual, status)
-    auto ritz = [&](int slot) -> int32_t {
+    auto ritz_kernels = [&](int slot) -> int32_t {
         SRX_TRY(apply(w.W, w.Wp));
         SRX_TRY(gram2(ctx, w, w.W, w.Wp, k));
         hipLaunchKernelGGL(k_jacobi_eig, dim3(1), dim3(1024), kJacobiLds, ctx->stream, w.dHG, l_act, w.dM2, w.dTheta,
@@ -1765,6 +1808,10 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         hipLaunchKernelGGL(k_resid_scalar, dim3(1), dim3(64), 0, ctx->stream, w.dRho, w.dTheta, o.n_pc, l_act, d_status,
                            d_status_sel, d_res + kSlotDoubles * slot);
         SRX_HIP(ctx, hipGetLastError());
+        return SRX_OK;
+    };
+    // the read-back of a Ritz step (pinned slot + event): always a plain stream operation, never captured
+    auto ritz_readback = [&](int slot) -> int32_t {
         SRX_HIP(ctx, hipMemcpyAsync(ctx->pin_async + kSlotDoubles * slot, d_res + kSlotDoubles * slot,
                                     kSlotDoubles * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         SRX_HIP(ctx, hipEventRecord(ctx->async_ev[slot], ctx->stream));
@@ -1798,31 +1845,37 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         return orth(res);
     };
 
-    SRX_TRY(orth(w.Wp));
-    SRX_TRY(orth(w.W));                // CholeskyQR2 on the random start
-    // warm-up: the first Ritz residuals are O(1) whatever happens — no Rayleigh–Ritz step to learn that
-    for (int sweep = 0; sweep < o.warm; ++sweep) SRX_TRY(plain_sweep());
+    // segment "start": random block, CholeskyQR2, warm-up sweeps (the first Ritz residuals are O(1) whatever
+    // happens — no Rayleigh–Ritz step to learn that), first Ritz step
+    auto seg_start = [&]() -> int32_t {
+        SRX_HIP(ctx, hipMemsetAsync(d_status, 0, 256, ctx->stream));
+        hipLaunchKernelGGL(k_init_block, dim3((unsigned)((kl + 255) / 256)), dim3(256), 0, ctx->stream, o.seed, k, l_act,
+                           w.Wp);
+        SRX_TRY(orth(w.Wp));
+        SRX_TRY(orth(w.W));            // CholeskyQR2 on the random start
+        for (int sweep = 0; sweep < o.warm; ++sweep) SRX_TRY(plain_sweep());
+        return ritz_kernels(0);
+    };
+    // segment "next": [advance] + (m - 1) plain sweeps + a Ritz step into `slot`
+    auto seg_next = [&](bool with_advance, int m, int slot) -> int32_t {
+        if (with_advance) SRX_TRY(advance());
+        for (int sI = 1; sI < m; ++sI) SRX_TRY(plain_sweep());
+        return ritz_kernels(slot);
+    };
 
-    // A Rayleigh–Ritz step costs as much as a plain sweep (an l x l Jacobi solve on ONE compute unit),
-    // and convergence is geometric, so Ritz steps are only taken where a decision is due.  After a step
-    // with residual r the number of sweeps still needed is  m = ceil(log(tol / r) / log(rate))  with
-    // rate = the factor measured between the last two steps or, before there are two, the estimate
-    // (theta_l / theta_npc)^power from the Ritz values (an upper bound: theta_l >= theta_{l+1});
-    // m - 1 plain sweeps and one Ritz step follow.  The first half-sweep after a step is queued before
-    // its residual is looked at (it is needed unless the step had already converged), so the stream
-    // only drains when a prediction is being checked — normally once, at the end.
     resid = INFINITY;
     converged = false;
     iters = 0;                         // sweeps after the warm-up
     int n_ritz = 0, slot = 0;
     double r_last = INFINITY, rate_meas = 0.0;
     int sweeps_since = 0;
-    SRX_TRY(ritz(slot));
+    SRX_TRY(graphed(ctx, use_graph, key_base + "|start", seg_start));
+    SRX_TRY(ritz_readback(slot));
     for (;;) {
         ++iters;
         ++n_ritz;
         const bool first = n_ritz == 1;
-        if (first) SRX_TRY(advance());                 // speculative: completes this sweep
+        if (first) SRX_TRY(graphed(ctx, use_graph, key_base + "|adv", advance));      // speculative: completes this sweep
         double r, ratio;
         SRX_TRY(collect(slot, r, ratio));
         resid = r;
@@ -1842,11 +1895,14 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         if (m < 1) m = 1;
         if (m > 6) m = 6;
         if (iters + m > o.max_iter) m = o.max_iter - iters;
-        if (!first) SRX_TRY(advance());
-        for (int sI = 1; sI < m; ++sI) SRX_TRY(plain_sweep());
         iters += m - 1;
         slot = (slot + 1) % kSlots;
-        SRX_TRY(ritz(slot));
+        {
+            char kn[64];
+            snprintf(kn, sizeof kn, "|next a%d m%d s%d", first ? 0 : 1, m, slot);
+            SRX_TRY(graphed(ctx, use_graph, key_base + kn, [&]() { return seg_next(!first, m, slot); }));
+        }
+        SRX_TRY(ritz_readback(slot));
         r_last = r;
         sweeps_since = m;
     }
@@ -1899,7 +1955,7 @@ static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const 
             SRX_HIP(ctx, hipGetLastError());
             return SRX_OK;
         };
-        SRX_TRY(subspace_iterate(ctx, w, k, l_act, o, apply, hv ? hv->d_status : nullptr, resid, iters, converged));
+        SRX_TRY(subspace_iterate(ctx, w, k, l_act, o, apply, C, true, hv ? hv->d_status : nullptr, resid, iters, converged));
     } else {
         auto apply = [&](const double* Win, double* Wout) -> int32_t {
             hipLaunchKernelGGL((k_make_panel<PT>), dim3(1), dim3(1024), 0, ctx->stream, Win, w.d, w.mu,
@@ -1913,7 +1969,8 @@ static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const 
             SRX_HIP(ctx, hipGetLastError());
             return SRX_OK;
         };
-        SRX_TRY(subspace_iterate(ctx, w, k, l_act, o, apply, hv ? hv->d_status : nullptr, resid, iters, converged));
+        SRX_TRY(subspace_iterate(ctx, w, k, l_act, o, apply, nullptr, false, hv ? hv->d_status : nullptr, resid, iters,
+                                 converged));
     }
 
     // A2 = W U are the Ritz vectors (ascending-gene row order); sign: largest-|.| entry positive.
