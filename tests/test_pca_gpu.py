@@ -298,3 +298,45 @@ def test_pipeline_nan_variance_is_an_error(ctx):
     with pytest.raises(sr.SrxError) as e:
         _ffi.check(_ffi.lib().srx_pipeline(a.x().handle, 1e4, 50, C.byref(opts), C.byref(res)), ctx.handle)
     assert e.value.code == _ffi.E_NAN
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,g,hvg,npc,store", [
+    (60, 40, 12, 3, 2),          # k < 64: the block is narrower than l
+    (300, 170, 129, 5, 2),       # k just over one 128-tile
+    (1500, 520, 257, 8, 1),      # k just over one 256-tile, f32 storage
+    (2111, 700, 700, 6, 2),      # n_hvg == n_vars (every gene selected, incl. empty ones)
+    (901, 333, 1000, 4, 1),      # n_hvg > n_vars
+])
+def test_fused_pipeline_odd_shapes(ctx, n, g, hvg, npc, store):
+    """srx_pipeline (device-side selection, fused compaction, Gram solver, graphs) at shapes that sit on the
+    tile / block boundaries, against the oracle end to end: selection identical (f64 storage), the spanned
+    subspace of the leading components and the scores to 1e-5."""
+    from singlerust_amd import _ffi
+    m, _ = synth_host(100 + n, n, g, 0.08)
+    a = adata_of(m, ctx, store)
+    opts = _ffi.PcaOpts(npc, -1, -1, -1, 0, 0, 0, 0.0, 7)
+    res = _ffi.PipelineResult()
+    _ffi.check(_ffi.lib().srx_pipeline(a.x().handle, 1e4, hvg, C.byref(opts), C.byref(res)), ctx.handle)
+    k = int(res.pca.k)
+    assert k == min(hvg, g) and int(res.pca.n_pc) == npc
+    scores, comps = np.zeros((n, npc)), np.zeros((k, npc))
+    evr, hv = np.zeros(npc), np.zeros(k, np.uint64)
+    _ffi.check(_ffi.lib().srx_result_fetch(a.x().handle, _ffi.ptr(scores), _ffi.ptr(comps), _ffi.ptr(evr), None, None,
+                                           _ffi.ptr(hv)), ctx.handle)
+    lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
+    want_sel = pca_oracle.select_features_hvg(lg, hvg)
+    if store == 2:
+        assert np.array_equal(hv, want_sel)
+    else:
+        assert len(set(hv.tolist()) ^ set(want_sel.tolist())) <= 2
+    # zero-variance selected genes (n_hvg >= n_vars picks the empty ones): the reference divides by std = 0 there;
+    # compare on the columns with a positive std, as test_defaults_and_small_k does
+    dense = oracle.densify_selected(lg, hv)
+    live = dense.std(axis=0) > 0
+    want_scores, want_comps, want_evr, *_ = pca_oracle.pca_inplace(lg, npc, None, None, hv[live])
+    tol = 1e-5 if store == 1 else 1e-7
+    assert col_err(scores, want_scores) < tol
+    assert col_err(comps[live], want_comps) < tol
+    assert np.all(comps[~live] == 0)
+    np.testing.assert_allclose(evr * k / live.sum(), want_evr, rtol=1e-5)      # trace counts the dead columns as 0
