@@ -28,6 +28,9 @@ CONFIGS = {
     # name: (cells per GPU, genes, density, seed)       SURVEY.md §8 table
     "c2": (100_000, 20_000, 0.05, 2002),
     "c3": (1_300_000, 28_000, 0.03, 3003),
+    # config 5's total size on ONE GPU (48 GB of CSR in HBM: no out-of-core tiling needed on 288 GB); a
+    # large-offset (nnz > 2^32) correctness / scale check, not the headline
+    "c5": (10_000_000, 30_000, 0.02, 5005),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
