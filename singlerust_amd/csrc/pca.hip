@@ -1623,8 +1623,7 @@ template <typename VT>
 static int32_t launch_gram(srx_ctx* ctx, const Tiled& g, double** packed_out, size_t* packed_count) {
     const int ntg = g.nt;
     const int n_pairs = ntg * (ntg + 1) / 2;
-    const char* kw = getenv("SRX_GRAM_WG_PER_CU");
-    const uint64_t per_cu = kw ? (uint64_t)atoi(kw) : 16;      // 8 -> 16: shorter tail of the last round (8.90 -> 8.69 ms at c3)
+    const uint64_t per_cu = 16;      // 4: 9.58 ms, 8: 8.90, 12: 8.76, 16: 8.69, 24: 8.68 at c3 (shorter tail of the last round)
     uint64_t n_rb = ((uint64_t)ctx->n_cus * per_cu + n_pairs - 1) / n_pairs;      // workgroups per CU in total
     uint64_t by_rows = (g.n_rows + 1023) / 1024;
     if (by_rows < 1) by_rows = 1;

