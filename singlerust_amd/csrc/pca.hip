@@ -11,7 +11,10 @@
 //     LDS), every cell contributing the outer product of its two tile segments through LDS
 //     atomics — N m^2/2 lane-atomics in total (m = non-zeros per cell among the k genes).
 //     C = D (G - c N mu mu^T) D is then a dense k x k matrix and every iteration is a dense
-//     (k x k)(k x 64) product.  Across row shards: ONE all-reduce of G.
+//     (k x k)(k x 64) product on the f64 matrix cores.  Across row shards: ONE all-reduce of G's
+//     upper tiles.  The whole iteration (CholeskyQR, Jacobi eigen-solve of the projected matrix,
+//     residuals) runs on the device, replayed from hipGraphs; the host reads one residual per
+//     Rayleigh–Ritz step.
 //  SPMM solver (matrix-free, any k)
 //     forward     Y  = Z W   = A (D W) - 1 (mu^T D W)        CSR x dense panel, panel in LDS
 //     transposed  W' = Z^T Y = D (A^T Y - c mu (1^T Y))      scatter form, LDS f64 atomics
@@ -33,7 +36,6 @@
 #include <numeric>
 
 #include "common.hpp"
-#include "smallmat.hpp"
 
 namespace srx {
 
