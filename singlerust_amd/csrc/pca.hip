@@ -1944,9 +1944,9 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         ++iters;
         ++n_ritz;
         const bool first = n_ritz == 1;
-        const bool cheb = first && use_cheb;
-        if (cheb) SRX_TRY(graphed(ctx, use_graph, key_base + "|cheb0", cheb_spec));     // speculative: Y1, C Y1
-        else if (first) SRX_TRY(graphed(ctx, use_graph, key_base + "|adv", advance));   // speculative: completes this sweep
+        const bool cheb = use_cheb;
+        if (cheb && first) SRX_TRY(graphed(ctx, use_graph, key_base + "|cheb0", cheb_spec));   // speculative: Y1, C Y1
+        else if (first) SRX_TRY(graphed(ctx, use_graph, key_base + "|adv", advance));          // speculative: completes this sweep
         double r, ratio;
         SRX_TRY(collect(slot, r, ratio));
         resid = r;
@@ -1964,12 +1964,15 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
             int d = 3;
             if (ta > 1.0) d = (int)std::ceil(std::acosh(std::max(4.0 * r / o.tol, 1.0)) / std::acosh(ta) - 1e-9);
             if (d < 2) d = 2;
-            if (d > 8) d = 8;
-            iters += 1;
+            if (d > 12) d = 12;                // T_12 of the largest t stays far inside f64; harder spectra take more rounds
+            iters += (d + o.power - 1) / o.power;      // counted in sweep equivalents (max_iter bounds applications of C)
             slot = (slot + 1) % kSlots;
             char kn[64];
-            snprintf(kn, sizeof kn, "|cheb d%d s%d", d, slot);
-            SRX_TRY(graphed(ctx, use_graph, key_base + kn, [&]() { return cheb_rest(d, slot); }));
+            snprintf(kn, sizeof kn, "|cheb f%d d%d s%d", first ? 1 : 0, d, slot);
+            SRX_TRY(graphed(ctx, use_graph, key_base + kn, [&]() -> int32_t {
+                if (!first) SRX_TRY(cheb_spec());      // later rounds: nothing was queued speculatively
+                return cheb_rest(d, slot);
+            }));
             SRX_TRY(ritz_readback(slot));
             if (getenv("SRX_PCA_TRACE")) fprintf(stderr, "[srx pca] Chebyshev filter of degree %d (t_a = %.3f)\n", d, ta);
             r_last = INFINITY;                 // the filter's gain says nothing about the rate of plain sweeps
