@@ -1795,7 +1795,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
                                 bool& converged) {
     const size_t kl = (size_t)k * L;
     const bool use_graph = graphable && !getenv("SRX_NO_GRAPH");
-    const bool use_cheb = graphable && l_act > o.n_pc && !getenv("SRX_NO_CHEB");
+    const bool use_cheb = l_act > o.n_pc && !getenv("SRX_NO_CHEB");      // both solvers: the filter only needs `apply`
     constexpr int kSlots = srx_ctx::kAsyncSlots, kSlotDoubles = 4;
     if (!ctx->pin_async) {
         SRX_HIP(ctx, hipHostMalloc((void**)&ctx->pin_async, kSlots * kSlotDoubles * sizeof(double), hipHostMallocDefault));
@@ -1936,6 +1936,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     converged = false;
     iters = 0;                         // sweeps after the warm-up
     int n_ritz = 0, slot = 0;
+    int q_applied = o.warm * o.power + 1;          // applications of C the block has seen (warm-up + first Ritz step)
     double r_last = INFINITY, rate_meas = 0.0;
     int sweeps_since = 0;
     SRX_TRY(graphed(ctx, use_graph, key_base + "|start", seg_start));
@@ -1963,8 +1964,14 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
             const double ta = ratio > 0 && ratio < 1 ? 2.0 / ratio - 1.0 : 1.0;
             int d = 3;
             if (ta > 1.0) d = (int)std::ceil(std::acosh(std::max(4.0 * r / o.tol, 1.0)) / std::acosh(ta) - 1e-9);
-            if (d < 2) d = 2;
+            // The block captures eigenvector j up to an error ~ (b / lambda_j)^q after q applications of C, and a
+            // degree-d filter multiplies that error (relative to the column's own component) by ~ (lambda_j / b)^d:
+            // with d <= q the leading eigenvectors cannot swamp the other columns.  A degree-12 filter on a block
+            // that had seen ONE application (SpMM solver, no warm-up) collapsed it ("block lost rank").
+            if (d > q_applied) d = q_applied;
             if (d > 12) d = 12;                // T_12 of the largest t stays far inside f64; harder spectra take more rounds
+            if (d < 2) d = 2;
+            q_applied += d;                    // d - 1 applications in the filter + the one of the Ritz step
             iters += (d + o.power - 1) / o.power;      // counted in sweep equivalents (max_iter bounds applications of C)
             slot = (slot + 1) % kSlots;
             char kn[64];
