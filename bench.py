@@ -45,7 +45,8 @@ ROOF_NOTE = {
                    "plus two staged LDS reads and ~16 VALU instructions per 64-lane pass; the LDS pipe and VALU issue "
                    "are each 50-65 % busy (profiles/r01_pmc_gram_v3.md), random-address f64 LDS atomics alone would "
                    "take 2.2 ms at the 2.5 lanes/clk/CU measured by bench_micro/lds_atomic_banks.hip",
-    "spmm_fwd": "algorithmic bytes per SURVEY.md 8(d): nnz_w*(4+4) + (N+1)*8 + N*64*4 + k*64*4",
+    "spmm_fwd": "algorithmic bytes per SURVEY.md 8(d): nnz_w*(4+4) + (n_t*N+1)*8 + k*64*4 + the output, which for this "
+                "launch (the transform) is the N x n_pc f64 score matrix written by the SpMM itself",
 }
 
 

@@ -507,7 +507,8 @@ __device__ __forceinline__ void fwd_overflow(const int32_t* __restrict__ gidx, c
 template <typename VT, typename PT>
 __global__ __launch_bounds__(kFwdThreads, FwdCfg<PT>::kWavesPerSimd) void k_spmm_fwd(
     const int64_t* __restrict__ tptr, const int32_t* __restrict__ tidx, const VT* __restrict__ tvals, uint64_t n_rows,
-    int nt, int k, const PT* __restrict__ P, const PT* __restrict__ cvec, PT* __restrict__ Y) {
+    int nt, int k, const PT* __restrict__ P, const PT* __restrict__ cvec, PT* __restrict__ Y,
+    double* __restrict__ scores /* nullable: n_rows x n_pc row-major f64, written INSTEAD of Y */, int n_pc) {
     constexpr int kRows = FwdCfg<PT>::kRows;            // rows per 16-lane group
     constexpr int kRowsPerWg = (kFwdThreads / 16) * kRows;
     constexpr int kStage = FwdCfg<PT>::kStage;          // rows whose (index, value) chunks are in flight together
@@ -562,7 +563,13 @@ __global__ __launch_bounds__(kFwdThreads, FwdCfg<PT>::kWavesPerSimd) void k_spmm
                 o[1] = acc[r][1] - cv4[1];
                 o[2] = acc[r][2] - cv4[2];
                 o[3] = acc[r][3] - cv4[3];
-                o.store(Y + row * L + 4 * q);
+                if (scores) {            // the transform pass: obsm["X_pca"] layout directly (dim_red/mod.rs:105-106)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (4 * q + j < n_pc) scores[row * (uint64_t)n_pc + 4 * q + j] = (double)o[j];
+                } else {
+                    o.store(Y + row * L + 4 * q);
+                }
             }
         }
     }
@@ -1159,10 +1166,8 @@ __global__ __launch_bounds__(1024) void k_chol_factor(const double* __restrict__
         }
         __syncthreads();
     }
-    for (int e = tid; e < L * L; e += 1024) {
-        const int r = e >> 6, c = e & 63;
-        if (r >= n) Rout[e] = 0.0;
-    }
+    for (int e = tid; e < L * L; e += 1024)
+        if ((e >> 6) >= n) Rout[e] = 0.0;
     if (tid < L && tid >= n) dinv[tid] = 0.0;
     if (bad && tid == 0) atomicOr(status, kStatChol);
 }
@@ -1393,18 +1398,6 @@ __global__ void k_resid_scalar(const double* __restrict__ rho, const double* __r
     out[3] = status_sel ? (double)*status_sel : 0.0;      // device-side feature selection: bit 0 = NaN variance
 }
 
-// scores[i][c] = Y[i][c] for c < n_pc (row-major f64, the obsm["X_pca"] layout).
-template <typename YT>
-__global__ void k_scores(const YT* __restrict__ Y, uint64_t n_rows, int n_pc, double* __restrict__ out) {
-    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    uint64_t total = n_rows * (uint64_t)n_pc;
-    for (; e < total; e += stride) {
-        uint64_t i = e / n_pc;
-        int c = (int)(e % n_pc);
-        out[e] = (double)Y[i * L + c];
-    }
-}
 
 // ---- compacted matrix: row-major CSR first, then tile-major views of it ----------------------------
 struct CompactCsr {
@@ -1615,9 +1608,12 @@ static int32_t build_tiled_fused(srx_mat* m, const std::vector<int32_t>& remap, 
 
 // ---- launches ---------------------------------------------------------------------------------
 template <typename VT, typename PT>
-static int32_t launch_fwd(srx_ctx* ctx, const Tiled& c, const PT* P, const PT* cvec, PT* Y) {
-    const double bytes = (double)c.nnz * (4.0 + sizeof(VT)) + (double)((uint64_t)c.nt * c.n_rows + 1) * 8.0 +
-                         (double)c.n_rows * L * sizeof(PT) + (double)c.k * L * sizeof(PT);
+static int32_t launch_fwd(srx_ctx* ctx, const Tiled& c, const PT* P, const PT* cvec, PT* Y, double* scores = nullptr,
+                          int n_pc = 0) {
+    // the output is either the N x 64 panel product (SpMM solver) or, for the transform, the N x n_pc f64 scores
+    const double out_bytes = scores ? (double)c.n_rows * n_pc * 8.0 : (double)c.n_rows * L * sizeof(PT);
+    const double bytes = (double)c.nnz * (4.0 + sizeof(VT)) + (double)((uint64_t)c.nt * c.n_rows + 1) * 8.0 + out_bytes +
+                         (double)c.k * L * sizeof(PT);
     const size_t lds = (size_t)KT * L * sizeof(PT);
     constexpr int kRowsPerWg = (kFwdThreads / 16) * FwdCfg<PT>::kRows;
     const uint64_t n_blocks = (c.n_rows + kRowsPerWg - 1) / kRowsPerWg;
@@ -1629,7 +1625,7 @@ static int32_t launch_fwd(srx_ctx* ctx, const Tiled& c, const PT* P, const PT* c
     SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_spmm_fwd<VT, PT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));
     hipLaunchKernelGGL((k_spmm_fwd<VT, PT>), dim3((unsigned)grid), dim3(kFwdThreads), lds, ctx->stream, c.tptr, c.tidx,
-                       (const VT*)c.tvals, c.n_rows, c.nt, c.k, P, cvec, Y);
+                       (const VT*)c.tvals, c.n_rows, c.nt, c.k, P, cvec, Y, scores, n_pc);
     SRX_HIP(ctx, hipGetLastError());
     return SRX_OK;
 }
@@ -2081,7 +2077,6 @@ static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const 
     hipLaunchKernelGGL((k_make_panel<PT>), dim3(1), dim3(1024), 0, ctx->stream, w.A2, w.d, w.mu, (const double*)w.dSgn, k,
                        o.center, P, cvec);
     SRX_HIP(ctx, hipGetLastError());
-    SRX_TRY((launch_fwd<VT, PT>(ctx, t256, P, cvec, Y)));
     // one allocation: the scores, then the block of small results (layout: srx_pca_state::d_small)
     const size_t score_bytes = (cc.n_rows ? cc.n_rows : 1) * (size_t)n_pc * 8;
     const size_t small_doubles = kl + 2 * L + 2 * (size_t)k + 2 + ((size_t)k + 1) / 2;
@@ -2094,12 +2089,7 @@ static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const 
         st.scores_cap = need;
     }
     st.d_small = st.d_scores + score_bytes / 8;
-    uint64_t tot = cc.n_rows * (uint64_t)n_pc;
-    uint64_t g = (tot + 255) / 256;
-    if (g < 1) g = 1;
-    if (g > 8192) g = 8192;
-    hipLaunchKernelGGL((k_scores<PT>), dim3((unsigned)g), dim3(256), 0, ctx->stream, Y, cc.n_rows, n_pc, st.d_scores);
-    SRX_HIP(ctx, hipGetLastError());
+    SRX_TRY((launch_fwd<VT, PT>(ctx, t256, P, cvec, Y, st.d_scores, n_pc)));      // f64 scores written by the SpMM itself
     // the Ritz vectors, values and signs move out of the (per-context) scratch into the matrix's own block;
     // their host copies are made by the first fetch (pca_materialize)
     SRX_HIP(ctx, hipMemcpyAsync(st.d_small, w.A2, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
