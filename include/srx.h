@@ -202,7 +202,10 @@ int32_t srx_select_hvg(srx_mat* m, uint64_t n, uint64_t* idx_out, uint64_t* n_ou
  * src/shared/processing/pca/mod.rs:74-215.  Computed by randomized block subspace
  * iteration on the implicit standardised matrix Z = (X[:, sel] - 1 mu^T) D^-1 with a
  * CSR x dense-panel SpMM (forward) and its transpose, or — Gram solver — with X_sel^T X_sel
- * accumulated once from the sparse rows; never densifies X. */
+ * accumulated once from the sparse rows; never densifies X.  Between Rayleigh–Ritz steps the
+ * block is advanced by Chebyshev filters of C = Z^T Z (plain powers during the warm-up); the
+ * whole iteration runs on the device (SRX_NO_GRAPH=1 / SRX_NO_CHEB=1 / SRX_PCA_TRACE=1 in the
+ * environment: no hipGraph replay / plain sweeps instead of filters / residual trace on stderr). */
 typedef enum srx_pca_solver {
     SRX_SOLVER_AUTO = 0,
     SRX_SOLVER_GRAM = 1,   /* explicit sparse Gram X_sel^T X_sel once, dense k x k iteration  */
@@ -215,7 +218,9 @@ typedef struct srx_pca_opts {
     int32_t scale;         /* < 0 = None -> true     (:56)                                */
     int32_t n_threads;     /* accepted, ignored on GPU (:61)                              */
     int32_t block;         /* panel width l; 0 -> default (64)                            */
-    int32_t max_iter;      /* 0 -> default 200                                            */
+    int32_t max_iter;      /* bound on the sweeps (one sweep = power applications of C:
+                              3 in the Gram solver, 1 in the SpMM solver) after the
+                              warm-up; 0 -> default 200                                   */
     int32_t solver;        /* srx_pca_solver; 0 = auto (Gram when k <= 4096)              */
     double  tol;           /* relative Ritz-residual tolerance; 0 -> default (1e-7 with
                               f32 storage, 1e-9 with f64 storage)                         */
@@ -227,7 +232,7 @@ typedef struct srx_pca_info {
     uint32_t k;            /* selected features                                           */
     uint32_t n_pc;
     uint32_t block;
-    uint32_t n_iter;       /* subspace iterations executed                                */
+    uint32_t n_iter;       /* sweep equivalents executed (applications of C / power)      */
     double residual;       /* final max relative Ritz residual over the n_pc pairs        */
     uint64_t nnz_selected; /* non-zeros of the HVG-compacted CSR actually walked (local)  */
     uint32_t solver;       /* srx_pca_solver actually used                                */
