@@ -203,11 +203,18 @@ __global__ void k_seglen(const int64_t* __restrict__ indptr, const int64_t* __re
     }
 }
 
+// One entry of a tile-major layout: local column and value side by side, so that every consumer (Gram kernel,
+// forward / transposed SpMM) fetches an entry with ONE 8-byte (f32 storage) or 16-byte (f64) load and the
+// compaction writes it with one store.
+template <typename VT> struct GramPk;
+template <> struct __attribute__((aligned(8))) GramPk<float> { int32_t j; float v; };
+template <> struct __attribute__((aligned(16))) GramPk<double> { int32_t j; int32_t pad_; double v; };
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_retile(const int64_t* __restrict__ indptr, const int64_t* __restrict__ tp,
                                                 const int32_t* __restrict__ idx, const T* __restrict__ vals,
                                                 uint64_t n_rows, int nt, int kt, const int64_t* __restrict__ tptr,
-                                                int32_t* __restrict__ tidx, T* __restrict__ tvals) {
+                                                GramPk<T>* __restrict__ tpk) {
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
@@ -218,8 +225,10 @@ __global__ __launch_bounds__(256) void k_retile(const int64_t* __restrict__ indp
             int t = c / kt;
             int64_t seg_lo = t == 0 ? lo : tp[(uint64_t)(t - 1) * n_rows + r];
             int64_t dst = tptr[(uint64_t)t * n_rows + r] + (p - seg_lo);
-            tidx[dst] = c - t * kt;
-            tvals[dst] = vals[p];
+            GramPk<T> e{};
+            e.j = c - t * kt;
+            e.v = vals[p];
+            tpk[dst] = e;
         }
     }
 }
@@ -297,26 +306,6 @@ __global__ __launch_bounds__(256) void k_tcount(const int64_t* __restrict__ indp
     }
 }
 
-// One entry of the 128-tiled (Gram) layout: local column and value side by side, so that the Gram
-// kernel fetches an entry with ONE 8-byte (f32 storage) or 16-byte (f64) load.
-template <typename VT> struct GramPk;
-template <> struct __attribute__((aligned(8))) GramPk<float> { int32_t j; float v; };
-template <> struct __attribute__((aligned(16))) GramPk<double> { int32_t j; int32_t pad_; double v; };
-
-// (tidx, tvals) -> packed entries: only the general (non-fused) compaction route needs it
-template <typename T>
-__global__ void k_pack128(const int32_t* __restrict__ tidx, const T* __restrict__ tvals, uint64_t n,
-                          GramPk<T>* __restrict__ out) {
-    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (; e < n; e += stride) {
-        GramPk<T> x{};
-        x.j = tidx[e];
-        x.v = tvals[e];
-        out[e] = x;
-    }
-}
-
 template <typename T, typename I>
 __global__ __launch_bounds__(256) void k_tfill(const int64_t* __restrict__ indptr, const I* __restrict__ idx,
                                                const T* __restrict__ vals, const uint32_t* __restrict__ g_bits,
@@ -324,7 +313,7 @@ __global__ __launch_bounds__(256) void k_tfill(const int64_t* __restrict__ indpt
                                                int nt128, int nt256, const int64_t* __restrict__ cnt128,
                                                const int64_t* __restrict__ tptr128,
                                                const int64_t* __restrict__ tptr256, GramPk<T>* __restrict__ pk128,
-                                               int32_t* __restrict__ tidx256, T* __restrict__ tvals256) {
+                                               GramPk<T>* __restrict__ pk256) {
     extern __shared__ double lds_raw[];
     const SelLds sel = stage_selection(g_bits, g_prefix, n_words, reinterpret_cast<uint32_t*>(lds_raw));
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
@@ -368,8 +357,8 @@ __global__ __launch_bounds__(256) void k_tfill(const int64_t* __restrict__ indpt
                     e.j = c & 127;
                     e.v = v;
                     pk128[o128 + rank] = e;
-                    tidx256[o256 + rank] = c & 255;
-                    tvals256[o256 + rank] = v;
+                    e.j = c & 255;
+                    pk256[o256 + rank] = e;
                 }
                 rank0 += __popcll(mask);
             }
@@ -466,9 +455,8 @@ struct FwdRot {
 // Index loads are unconditional (the arrays are padded by 64 entries; a stray index is a valid
 // local column) and only the VALUE is masked to 0 — no divergent branches around the loads.
 template <typename VT, typename PT, int kRows, int kStage, int H>
-__device__ __forceinline__ void fwd_stage(const int32_t* __restrict__ gidx, const VT* __restrict__ gvals, int la,
-                                          int le, int c, int q, const PT* __restrict__ panel_q,
-                                          PT (&acc)[kRows][4]) {
+__device__ __forceinline__ void fwd_stage(const GramPk<VT>* __restrict__ gpk, int la, int le, int c, int q,
+                                          const PT* __restrict__ panel_q, PT (&acc)[kRows][4]) {
     if constexpr (H < kRows) {
         int ci[kStage];
         PT cvv[kStage];
@@ -477,36 +465,35 @@ __device__ __forceinline__ void fwd_stage(const int32_t* __restrict__ gidx, cons
             const int lo = __shfl(la, H + r, 16) + c;
             const int hi = (H + r + 1 < 16) ? __shfl(la, (H + r + 1) & 15, 16) : le;
             const int p = lo + q;
-            ci[r] = gidx[p] * L;
-            const PT v = (PT)gvals[p];
-            cvv[r] = p < hi ? v : PT(0);
+            const GramPk<VT> e = gpk[p];
+            ci[r] = e.j * L;
+            cvv[r] = p < hi ? (PT)e.v : PT(0);
         }
 #pragma unroll
         for (int r = 0; r < kStage; ++r) FwdRot<PT, 0>::run(ci[r], cvv[r], panel_q, acc[H + r]);
-        fwd_stage<VT, PT, kRows, kStage, H + kStage>(gidx, gvals, la, le, c, q, panel_q, acc);
+        fwd_stage<VT, PT, kRows, kStage, H + kStage>(gpk, la, le, c, q, panel_q, acc);
     }
 }
 
 // Entries 16.. of row H (and, recursively, of the rows after it) for the groups that have them.
 template <typename VT, typename PT, int kRows, int H>
-__device__ __forceinline__ void fwd_overflow(const int32_t* __restrict__ gidx, const VT* __restrict__ gvals, int la,
-                                             int le, int q, const PT* __restrict__ panel_q, PT (&acc)[kRows][4]) {
+__device__ __forceinline__ void fwd_overflow(const GramPk<VT>* __restrict__ gpk, int la, int le, int q,
+                                             const PT* __restrict__ panel_q, PT (&acc)[kRows][4]) {
     if constexpr (H < kRows) {
         const int lo = __shfl(la, H, 16);
         const int hi = (H + 1 < 16) ? __shfl(la, (H + 1) & 15, 16) : le;
         for (int c = 16; __any(hi - lo > c); c += 16) {
             const int p = lo + c + q;
-            const int ci = gidx[p] * L;
-            const PT v = (PT)gvals[p];
-            FwdRot<PT, 0>::run(ci, p < hi ? v : PT(0), panel_q, acc[H]);
+            const GramPk<VT> e = gpk[p];
+            FwdRot<PT, 0>::run(e.j * L, p < hi ? (PT)e.v : PT(0), panel_q, acc[H]);
         }
-        fwd_overflow<VT, PT, kRows, H + 1>(gidx, gvals, la, le, q, panel_q, acc);
+        fwd_overflow<VT, PT, kRows, H + 1>(gpk, la, le, q, panel_q, acc);
     }
 }
 
 template <typename VT, typename PT>
 __global__ __launch_bounds__(kFwdThreads, FwdCfg<PT>::kWavesPerSimd) void k_spmm_fwd(
-    const int64_t* __restrict__ tptr, const int32_t* __restrict__ tidx, const VT* __restrict__ tvals, uint64_t n_rows,
+    const int64_t* __restrict__ tptr, const GramPk<VT>* __restrict__ tpk, uint64_t n_rows,
     int nt, int k, const PT* __restrict__ P, const PT* __restrict__ cvec, PT* __restrict__ Y,
     double* __restrict__ scores /* nullable: n_rows x n_pc row-major f64, written INSTEAD of Y */, int n_pc) {
     constexpr int kRows = FwdCfg<PT>::kRows;            // rows per 16-lane group
@@ -547,12 +534,11 @@ __global__ __launch_bounds__(kFwdThreads, FwdCfg<PT>::kWavesPerSimd) void k_spmm
             const int la_next = __shfl(la, (q + 1) & 15, 16);
             const int nxt = (q + 1 < 16) ? la_next : le;
             const int len = q < kRows ? (q + 1 < kRows ? nxt : le) - la : 0;
-            const int32_t* gidx = tidx + p0;
-            const VT* gvals = tvals + p0;
-            fwd_stage<VT, PT, kRows, kStage, 0>(gidx, gvals, la, le, 0, q, panel_q, acc);
+            const GramPk<VT>* gpk = tpk + p0;
+            fwd_stage<VT, PT, kRows, kStage, 0>(gpk, la, le, 0, q, panel_q, acc);
             // segments longer than 16 entries are rare (~1 % of rows at m/k*256 = 9): finish them row by
             // row instead of sending the whole wave through another 16-row pass
-            if (__any(len > 16)) fwd_overflow<VT, PT, kRows, 0>(gidx, gvals, la, le, q, panel_q, acc);
+            if (__any(len > 16)) fwd_overflow<VT, PT, kRows, 0>(gpk, la, le, q, panel_q, acc);
         }
 #pragma unroll
         for (int r = 0; r < kRows; ++r) {
@@ -585,8 +571,8 @@ __global__ __launch_bounds__(kFwdThreads, FwdCfg<PT>::kWavesPerSimd) void k_spmm
 constexpr int kTBatch = 16;
 
 template <typename VT, typename YT, typename AT>
-__global__ __launch_bounds__(kTThreads) void k_spmm_t(const int64_t* __restrict__ tptr, const int32_t* __restrict__ tidx,
-                                                      const VT* __restrict__ tvals, uint64_t n_rows, int k, int nt,
+__global__ __launch_bounds__(kTThreads) void k_spmm_t(const int64_t* __restrict__ tptr,
+                                                      const GramPk<VT>* __restrict__ tpk, uint64_t n_rows, int k, int nt,
                                                       uint64_t rows_per_block, const YT* __restrict__ Y,
                                                       AT* __restrict__ part /* [rb][k][L] */,
                                                       double* __restrict__ part_s /* [rb][L] */) {
@@ -619,8 +605,9 @@ __global__ __launch_bounds__(kTThreads) void k_spmm_t(const int64_t* __restrict_
         const int64_t pend = p[kTBatch];
         for (int64_t cb = p[0]; cb < pend; cb += kWave) {
             const int64_t pq = cb + lane;
-            const int32_t ci = pq < pend ? tidx[pq] * L : 0;
-            const VT cvv = pq < pend ? tvals[pq] : VT(0);
+            const GramPk<VT> e = tpk[pq < pend ? pq : p[0]];
+            const int32_t ci = pq < pend ? e.j * L : 0;
+            const VT cvv = pq < pend ? e.v : VT(0);
 #pragma unroll
             for (int r = 0; r < kTBatch; ++r) {
                 const int64_t a = p[r] > cb ? p[r] : cb;
@@ -1411,9 +1398,7 @@ struct Tiled {
     uint64_t n_rows = 0, nnz = 0;
     int k = 0, kt = 0, nt = 0;
     int64_t* tptr = nullptr;   // nt * n_rows + 1
-    int32_t* tidx = nullptr;   // local column within the tile
-    void* tvals = nullptr;
-    void* tpk = nullptr;       // kt == KG only: GramPk<VT> entries (then tidx / tvals are not filled by the fused route)
+    void* tpk = nullptr;       // GramPk<VT> records: (local column within the tile, value)
 };
 
 static int grid_rows(const srx_ctx* ctx, uint64_t n_rows, int rows_per_block) {
@@ -1499,17 +1484,16 @@ static int32_t retile(srx_mat* m, const CompactCsr& c, int kt, Tiled& t) {
     if (g > 16384) g = 16384;
     hipLaunchKernelGGL(k_seglen, dim3((unsigned)g), dim3(256), 0, ctx->stream, c.indptr, d_tp, N, t.nt, d_seglen);
     SRX_TRY(scan_exclusive(ctx, d_seglen, nseg, t.tptr, nullptr));
-    // +64 entries of padding: the forward kernel reads 16-wide chunks unconditionally
-    SRX_TRY(scratch(ctx, (tag + "idx").c_str(), (c.nnz + 64) * sizeof(int32_t), (void**)&t.tidx));
-    SRX_TRY(scratch(ctx, (tag + "vals").c_str(), (c.nnz + 64) * vb, &t.tvals));
-    SRX_HIP(ctx, hipMemsetAsync(t.tidx + c.nnz, 0, 64 * sizeof(int32_t), ctx->stream));
-    SRX_HIP(ctx, hipMemsetAsync((char*)t.tvals + c.nnz * vb, 0, 64 * vb, ctx->stream));
+    // +64 records of padding: the forward kernel reads 16-wide chunks unconditionally
+    const size_t pb = vb == 4 ? sizeof(GramPk<float>) : sizeof(GramPk<double>);
+    SRX_TRY(scratch(ctx, (tag + "pk").c_str(), (c.nnz + 64) * pb, &t.tpk));
+    SRX_HIP(ctx, hipMemsetAsync((char*)t.tpk + c.nnz * pb, 0, 64 * pb, ctx->stream));
     if (is_f32(m))
         hipLaunchKernelGGL((k_retile<float>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream, c.indptr, d_tp, c.idx,
-                           (const float*)c.vals, N, t.nt, kt, t.tptr, t.tidx, (float*)t.tvals);
+                           (const float*)c.vals, N, t.nt, kt, t.tptr, (GramPk<float>*)t.tpk);
     else
         hipLaunchKernelGGL((k_retile<double>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream, c.indptr, d_tp,
-                           c.idx, (const double*)c.vals, N, t.nt, kt, t.tptr, t.tidx, (double*)t.tvals);
+                           c.idx, (const double*)c.vals, N, t.nt, kt, t.tptr, (GramPk<double>*)t.tpk);
     SRX_HIP(ctx, hipGetLastError());
     return SRX_OK;
 }
@@ -1525,16 +1509,9 @@ static int32_t alloc_tiled(srx_mat* m, uint64_t N, uint64_t nnz, int k, int kt, 
     t.k = k;
     t.kt = kt;
     t.nt = (k + kt - 1) / kt;
-    if (kt == KG) {
-        const size_t pb = vb == 4 ? sizeof(GramPk<float>) : sizeof(GramPk<double>);
-        SRX_TRY(scratch(ctx, (tag + "pk").c_str(), (nnz + 64) * pb, &t.tpk));
-        SRX_HIP(ctx, hipMemsetAsync((char*)t.tpk + nnz * pb, 0, 64 * pb, ctx->stream));
-        return SRX_OK;
-    }
-    SRX_TRY(scratch(ctx, (tag + "idx").c_str(), (nnz + 64) * sizeof(int32_t), (void**)&t.tidx));
-    SRX_TRY(scratch(ctx, (tag + "vals").c_str(), (nnz + 64) * vb, &t.tvals));
-    SRX_HIP(ctx, hipMemsetAsync(t.tidx + nnz, 0, 64 * sizeof(int32_t), ctx->stream));
-    SRX_HIP(ctx, hipMemsetAsync((char*)t.tvals + nnz * vb, 0, 64 * vb, ctx->stream));
+    const size_t pb = vb == 4 ? sizeof(GramPk<float>) : sizeof(GramPk<double>);
+    SRX_TRY(scratch(ctx, (tag + "pk").c_str(), (nnz + 64) * pb, &t.tpk));
+    SRX_HIP(ctx, hipMemsetAsync((char*)t.tpk + nnz * pb, 0, 64 * pb, ctx->stream));
     return SRX_OK;
 }
 
@@ -1567,20 +1544,20 @@ static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words,
     SRX_TRY(scan_exclusive(ctx, cnt256, n256, t256.tptr, nullptr));
     SRX_TRY(alloc_tiled(m, N, (uint64_t)total, k, KG, t128));
     SRX_TRY(alloc_tiled(m, N, (uint64_t)total, k, KT, t256));
-    auto fill = [&](auto kern, const auto* idxp, const auto* valp, auto* pk, auto* tv256) {
+    auto fill = [&](auto kern, const auto* idxp, const auto* valp, auto* pk128, auto* pk256) {
         hipLaunchKernelGGL(kern, dim3(grid_rows(ctx, N, 4)), dim3(256), sel_lds, ctx->stream, m->d_indptr, idxp, valp, d_sel,
-                           d_sel + n_words, n_words, N, nt128, nt256, cnt128, t128.tptr, t256.tptr, pk, t256.tidx, tv256);
+                           d_sel + n_words, n_words, N, nt128, nt256, cnt128, t128.tptr, t256.tptr, pk128, pk256);
     };
     if (is_f32(m)) {
         if (m->d_idx16) fill(k_tfill<float, uint16_t>, (const uint16_t*)m->d_idx16, (const float*)m->d_values,
-                             (GramPk<float>*)t128.tpk, (float*)t256.tvals);
+                             (GramPk<float>*)t128.tpk, (GramPk<float>*)t256.tpk);
         else fill(k_tfill<float, int32_t>, (const int32_t*)m->d_indices, (const float*)m->d_values,
-                  (GramPk<float>*)t128.tpk, (float*)t256.tvals);
+                  (GramPk<float>*)t128.tpk, (GramPk<float>*)t256.tpk);
     } else {
         if (m->d_idx16) fill(k_tfill<double, uint16_t>, (const uint16_t*)m->d_idx16, (const double*)m->d_values,
-                             (GramPk<double>*)t128.tpk, (double*)t256.tvals);
+                             (GramPk<double>*)t128.tpk, (GramPk<double>*)t256.tpk);
         else fill(k_tfill<double, int32_t>, (const int32_t*)m->d_indices, (const double*)m->d_values,
-                  (GramPk<double>*)t128.tpk, (double*)t256.tvals);
+                  (GramPk<double>*)t128.tpk, (GramPk<double>*)t256.tpk);
     }
     SRX_HIP(ctx, hipGetLastError());
     if (ctx->prof_mask & (1u << SRX_K_COMPACT))
@@ -1624,8 +1601,8 @@ static int32_t launch_fwd(srx_ctx* ctx, const Tiled& c, const PT* P, const PT* c
     ProfScope ps(ctx, SRX_K_SPMM_FWD, bytes);
     SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_spmm_fwd<VT, PT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));
-    hipLaunchKernelGGL((k_spmm_fwd<VT, PT>), dim3((unsigned)grid), dim3(kFwdThreads), lds, ctx->stream, c.tptr, c.tidx,
-                       (const VT*)c.tvals, c.n_rows, c.nt, c.k, P, cvec, Y, scores, n_pc);
+    hipLaunchKernelGGL((k_spmm_fwd<VT, PT>), dim3((unsigned)grid), dim3(kFwdThreads), lds, ctx->stream, c.tptr,
+                       (const GramPk<VT>*)c.tpk, c.n_rows, c.nt, c.k, P, cvec, Y, scores, n_pc);
     SRX_HIP(ctx, hipGetLastError());
     return SRX_OK;
 }
@@ -1649,7 +1626,7 @@ static int32_t launch_t(srx_ctx* ctx, const Tiled& c, const YT* Y, double* T /* 
         SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_spmm_t<VT, YT, double>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((k_spmm_t<VT, YT, double>), dim3((unsigned)(n_rb * c.nt)), dim3(kTThreads), lds, ctx->stream,
-                           c.tptr, c.tidx, (const VT*)c.tvals, c.n_rows, c.k, c.nt, rpb, Y, part, part_s);
+                           c.tptr, (const GramPk<VT>*)c.tpk, c.n_rows, c.k, c.nt, rpb, Y, part, part_s);
         uint64_t tot = (uint64_t)c.k * L + L;
         hipLaunchKernelGGL((k_t_reduce<double>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, part,
                            part_s, c.k, n_rb, T);
@@ -2205,16 +2182,6 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
         SRX_TRY(retile(m, cc, KT, t256));
         if (need128) {
             SRX_TRY(retile(m, cc, KG, t128));
-            const size_t pb = is_f32(m) ? sizeof(GramPk<float>) : sizeof(GramPk<double>);
-            SRX_TRY(scratch(ctx, "pca_t128_pk", (t128.nnz + 64) * pb, &t128.tpk));
-            SRX_HIP(ctx, hipMemsetAsync((char*)t128.tpk + t128.nnz * pb, 0, 64 * pb, ctx->stream));
-            if (is_f32(m))
-                hipLaunchKernelGGL((k_pack128<float>), dim3(2048), dim3(256), 0, ctx->stream, t128.tidx,
-                                   (const float*)t128.tvals, t128.nnz, (GramPk<float>*)t128.tpk);
-            else
-                hipLaunchKernelGGL((k_pack128<double>), dim3(2048), dim3(256), 0, ctx->stream, t128.tidx,
-                                   (const double*)t128.tvals, t128.nnz, (GramPk<double>*)t128.tpk);
-            SRX_HIP(ctx, hipGetLastError());
         }
     }
     st.info = srx_pca_info{};
