@@ -277,6 +277,47 @@ int32_t srx_pipeline(srx_mat* m, double target_sum, uint64_t n_hvg, const srx_pc
 int32_t srx_result_fetch(srx_mat* m, double* scores, double* components, double* evr,
                          double* mean, double* std_, uint64_t* hvg_idx);
 
+/* ---- backed (out-of-core) mode: the matrix is visited as consecutive ROW TILES ---------------
+ * Replaces src/backed/statistics/mod.rs:5-45 (compute_number / compute_sum with
+ * ComputationMode::Chunked(size); chunk loops src/shared/statistics/mod.rs:17-41,59-83,
+ * csr.rs:48-74,112-143) and carries the whole path for matrices larger than HBM: two sweeps over
+ * the row tiles, only the per-gene moments, the k x k Gram tiles and the HVG-compacted rows stay
+ * on the device.  Unlike the reference's Direction::Row chunk loop (csr.rs:126 drops the chunk's
+ * row offset), per-row outputs of a tile are written by the caller at the tile's global offset.
+ *
+ * A tile is an srx_csr whose `indptr` may be a WINDOW of the matrix's row_offsets (n_rows+1
+ * entries, indptr[0] != 0 allowed) with `indices` / `values` pointing at the tile's first entry.
+ * The upload of a tile overlaps the kernels of the previous one (own stream + staging buffers).
+ * Multi-GPU: every rank runs its own session over its own row range; srx_backed_select and
+ * srx_backed_solve are collective (one all-reduce each).
+ *
+ *   sweep 1  srx_backed_stats_tile  per tile: [normalize_total(Row)] [log1p] -> (cnt,sum,sumsq) +=
+ *            srx_backed_moments     column statistics so far (compute_number / compute_sum, Column)
+ *   select   srx_backed_select      FeatureSelection::HighlyVariable(n) | explicit list | all
+ *   sweep 2  srx_backed_gram_tile   per tile, same transform: compaction + Gram tiles +=
+ *   solve    srx_backed_solve       PCA (Gram solver) + scores of every tile; srx_backed_fetch  */
+typedef struct srx_backed srx_backed;
+enum { SRX_BACKED_NORMALIZE = 1, SRX_BACKED_LOG1P = 2 };   /* `transform` bits                    */
+int32_t srx_backed_create(srx_ctx* ctx, uint64_t n_cols, int32_t store, srx_backed** out);
+void    srx_backed_destroy(srx_backed* b);
+/* row_number_out / row_sum_out (NULL or tile->n_rows entries): compute_number / compute_sum in
+ * Direction::Row of the tile's RAW values. */
+int32_t srx_backed_stats_tile(srx_backed* b, const srx_csr* tile, double target_sum, int32_t transform,
+                              uint32_t* row_number_out, double* row_sum_out);
+/* per-gene count / sum / sum of squares of the (transformed) values over all tiles so far, summed
+ * over ranks; any pointer may be NULL. */
+int32_t srx_backed_moments(srx_backed* b, uint64_t* cnt, double* sum, double* sumsq, uint64_t* n_rows_global);
+/* n_hvg > 0: HighlyVariable(n_hvg); else `sel` (n_sel indices) or, with sel == NULL, all features
+ * (at most 8192 selected).  opts as for srx_pca (solver 2 is refused).  sel_out (room for
+ * min(n_hvg, n_cols) or n_sel entries) receives the selection in the reference's order. */
+int32_t srx_backed_select(srx_backed* b, uint64_t n_hvg, const uint64_t* sel, uint64_t n_sel,
+                          const srx_pca_opts* opts, uint64_t* sel_out, uint64_t* n_out);
+int32_t srx_backed_gram_tile(srx_backed* b, const srx_csr* tile, double target_sum, int32_t transform);
+int32_t srx_backed_solve(srx_backed* b, srx_pca_info* info);
+/* as srx_result_fetch; scores = (rows of this rank, in tile order) x n_pc */
+int32_t srx_backed_fetch(srx_backed* b, double* scores, double* components, double* evr, double* mean,
+                         double* std_, uint64_t* sel);
+
 /* ---- measurement hooks --------------------------------------------------------------------
  * When enabled, every launch of a kernel class is bracketed by hipEvents on the ctx stream.
  * srx_prof_get returns accumulated device time, launch count and the ALGORITHMIC bytes

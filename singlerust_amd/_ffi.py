@@ -75,6 +75,7 @@ class Flex(C.Structure):            # srx_flex: FlexValue (src/shared/mod.rs:62-
 
 
 FLEX_NONE, FLEX_ABSOLUTE, FLEX_RELATIVE = 0, 1, 2
+BACKED_NORMALIZE, BACKED_LOG1P = 1, 2
 P = C.c_void_p
 _SIGS = {
     # name: (restype, argtypes)
@@ -118,6 +119,14 @@ _SIGS = {
     "srx_spmm": (C.c_int32, [P, P, C.c_uint64, P, P, P, P]),
     "srx_pipeline": (C.c_int32, [P, C.c_double, C.c_uint64, C.POINTER(PcaOpts), C.POINTER(PipelineResult)]),
     "srx_result_fetch": (C.c_int32, [P, P, P, P, P, P, P]),
+    "srx_backed_create": (C.c_int32, [P, C.c_uint64, C.c_int32, C.POINTER(P)]),
+    "srx_backed_destroy": (None, [P]),
+    "srx_backed_stats_tile": (C.c_int32, [P, C.POINTER(Csr), C.c_double, C.c_int32, P, P]),
+    "srx_backed_moments": (C.c_int32, [P, P, P, P, C.POINTER(C.c_uint64)]),
+    "srx_backed_select": (C.c_int32, [P, C.c_uint64, P, C.c_uint64, C.POINTER(PcaOpts), P, C.POINTER(C.c_uint64)]),
+    "srx_backed_gram_tile": (C.c_int32, [P, C.POINTER(Csr), C.c_double, C.c_int32]),
+    "srx_backed_solve": (C.c_int32, [P, C.POINTER(PcaInfo)]),
+    "srx_backed_fetch": (C.c_int32, [P, P, P, P, P, P, P]),
     "srx_prof_enable": (C.c_int32, [P, C.c_uint32]),
     "srx_prof_reset": (C.c_int32, [P]),
     "srx_prof_get": (C.c_int32, [P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),

@@ -189,6 +189,7 @@ struct ProfScope {
 int32_t allreduce_f64(srx_ctx* ctx, double* d_buf, size_t count);
 
 // ---- internal entry points shared between translation units -----------------------------------
+int32_t upload_on(srx_ctx* ctx, const srx_csr* h, int32_t store, hipStream_t stream, srx_mat** out);   // ctx.hip
 int32_t ensure_tiles(srx_mat* m);
 // device-resident result of FeatureSelection::HighlyVariable(n) (genes.hip), consumed by the PCA driver
 struct HvgDev {
@@ -200,6 +201,8 @@ struct HvgDev {
 };
 int32_t select_hvg_device(srx_mat* m, uint64_t n, int center, int scale, HvgDev& out);
 int32_t ensure_moments(srx_mat* m);   // fills d_cnt/d_sum/d_sq (global) for the current values
+int32_t moments_accumulate(srx_mat* m, double* d_acc);     // backed mode: this tile's (cnt,sum,sumsq,N) += into d_acc
+int32_t moments_install(srx_mat* m, double* d_packed);     // all-reduce d_packed and make it m's global moments
 int32_t launch_normalize(srx_mat* m, double target, bool do_norm, bool do_log);
 inline void touch(srx_mat* m) { m->version++; m->pca.valid = false; }
 

@@ -158,21 +158,22 @@ static int grid_for(uint64_t n, int block, int cap) {
 }
 
 template <typename S>
-static int32_t convert_chunked(srx_ctx* ctx, const void* host, void* d_dst, uint64_t n, bool to_f32) {
+static int32_t convert_chunked(srx_ctx* ctx, hipStream_t stream, const char* tmp_tag, const void* host, void* d_dst,
+                               uint64_t n, bool to_f32) {
     const uint64_t chunk = 32ull << 20;  // elements per staging chunk
     void* d_tmp;
-    SRX_TRY(scratch(ctx, "upload_tmp", (n < chunk ? n : chunk) * sizeof(S) + 16, &d_tmp));
+    SRX_TRY(scratch(ctx, tmp_tag, (n < chunk ? n : chunk) * sizeof(S) + 16, &d_tmp));
     for (uint64_t off = 0; off < n; off += chunk) {
         uint64_t cnt = n - off < chunk ? n - off : chunk;
         SRX_HIP(ctx, hipMemcpy(d_tmp, (const S*)host + off, cnt * sizeof(S), hipMemcpyHostToDevice));
         int g = grid_for(cnt, 256, 4096);
         if (to_f32)
-            hipLaunchKernelGGL((k_convert_values<S, float>), dim3(g), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL((k_convert_values<S, float>), dim3(g), dim3(256), 0, stream,
                                (const S*)d_tmp, (float*)d_dst + off, cnt);
         else
-            hipLaunchKernelGGL((k_convert_values<S, double>), dim3(g), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL((k_convert_values<S, double>), dim3(g), dim3(256), 0, stream,
                                (const S*)d_tmp, (double*)d_dst + off, cnt);
-        SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SRX_HIP(ctx, hipStreamSynchronize(stream));
     }
     return SRX_OK;
 }
@@ -197,6 +198,88 @@ static int32_t resolve_store(int32_t dtype, int32_t store) {
         case SRX_I32: case SRX_U32: case SRX_F64: return SRX_STORE_F64;
         default: return SRX_STORE_F32;
     }
+}
+
+
+__global__ void k_rebase_indptr(int64_t* __restrict__ indptr, uint64_t n, int64_t base) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) indptr[i] -= base;
+}
+
+// H2D of a host CSR slice with the u64 -> i32 index narrowing, the value conversion and the canonical-CSR
+// validation, every kernel on `stream`.  `h->indptr` may be a window of a larger row-offset array (a row tile of
+// a backed matrix: indptr[0] != 0, indices / values pointing at the tile's first entry) — it is rebased on the
+// device.  With a stream other than ctx->stream the staging buffers are separate ones, so a tile can be
+// uploaded while the previous one is still being worked on.
+int32_t upload_on(srx_ctx* ctx, const srx_csr* h, int32_t store, hipStream_t stream, srx_mat** out) {
+    *out = nullptr;
+    const bool side = stream != ctx->stream;
+    const char* tmp_tag = side ? "upload_tmp_side" : "upload_tmp";
+    const uint64_t base = h->indptr[0];
+    if (h->indptr[h->n_rows] - base != h->nnz)
+        return fail(ctx, SRX_E_FORMAT, "X is not a CSR matrix: row_offsets do not span nnz");
+    srx_mat* m = nullptr;
+    SRX_TRY(srx_matrix_alloc(ctx, h->n_rows, h->n_cols, h->nnz, h->dtype, store, &m));
+    auto bail = [&](int32_t rc) { srx_matrix_free(m); return rc; };
+    hipError_t e = hipMemcpy(m->d_indptr, h->indptr, (h->n_rows + 1) * sizeof(int64_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "H2D indptr: %s", hipGetErrorString(e)));
+    if (base)
+        hipLaunchKernelGGL(k_rebase_indptr, dim3((unsigned)((h->n_rows + 256) / 256)), dim3(256), 0, stream, m->d_indptr,
+                           h->n_rows + 1, (int64_t)base);
+
+    int* d_flag;
+    int32_t rc = scratch(ctx, side ? "flag_side" : "flag", 64, (void**)&d_flag);
+    if (rc) return bail(rc);
+    (void)hipMemsetAsync(d_flag, 0, sizeof(int), stream);
+
+    // indices: u64 -> i32 through a staging chunk
+    {
+        const uint64_t chunk = 32ull << 20;
+        void* d_tmp;
+        uint64_t c0 = h->nnz < chunk ? h->nnz : chunk;
+        rc = scratch(ctx, tmp_tag, (c0 ? c0 : 1) * sizeof(uint64_t) + 16, &d_tmp);
+        if (rc) return bail(rc);
+        for (uint64_t off = 0; off < h->nnz; off += chunk) {
+            uint64_t cnt = h->nnz - off < chunk ? h->nnz - off : chunk;
+            e = hipMemcpy(d_tmp, h->indices + off, cnt * sizeof(uint64_t), hipMemcpyHostToDevice);
+            if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "H2D indices: %s", hipGetErrorString(e)));
+            hipLaunchKernelGGL(k_narrow_indices, dim3(grid_for(cnt, 256, 4096)), dim3(256), 0, stream,
+                               (const uint64_t*)d_tmp, m->d_indices + off, cnt, h->n_cols, d_flag);
+            e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "narrow indices: %s", hipGetErrorString(e)));
+        }
+    }
+    // values
+    bool f32 = is_f32(m);
+    if ((h->dtype == SRX_F32 && f32) || (h->dtype == SRX_F64 && !f32)) {
+        e = hipMemcpy(m->d_values, h->values, h->nnz * val_bytes(m), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "H2D values: %s", hipGetErrorString(e)));
+    } else if (h->nnz) {
+        switch (h->dtype) {
+            case SRX_I8:  rc = convert_chunked<int8_t>(ctx, stream, tmp_tag, h->values, m->d_values, h->nnz, f32); break;
+            case SRX_I16: rc = convert_chunked<int16_t>(ctx, stream, tmp_tag, h->values, m->d_values, h->nnz, f32); break;
+            case SRX_I32: rc = convert_chunked<int32_t>(ctx, stream, tmp_tag, h->values, m->d_values, h->nnz, f32); break;
+            case SRX_U8:  rc = convert_chunked<uint8_t>(ctx, stream, tmp_tag, h->values, m->d_values, h->nnz, f32); break;
+            case SRX_U16: rc = convert_chunked<uint16_t>(ctx, stream, tmp_tag, h->values, m->d_values, h->nnz, f32); break;
+            case SRX_U32: rc = convert_chunked<uint32_t>(ctx, stream, tmp_tag, h->values, m->d_values, h->nnz, f32); break;
+            case SRX_F32: rc = convert_chunked<float>(ctx, stream, tmp_tag, h->values, m->d_values, h->nnz, f32); break;
+            case SRX_F64: rc = convert_chunked<double>(ctx, stream, tmp_tag, h->values, m->d_values, h->nnz, f32); break;
+            default: rc = fail(ctx, SRX_E_DTYPE, "dtype %d is not supported for this operation", h->dtype);
+        }
+        if (rc) return bail(rc);
+    }
+    // validate
+    hipLaunchKernelGGL(k_validate_rows, dim3(grid_for(h->n_rows * kWave, 256, 8192)), dim3(256), 0, stream,
+                       m->d_indptr, m->d_indices, h->n_rows, h->nnz, d_flag);
+    int flag = 0;
+    e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) e = hipMemcpy(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "validate CSR: %s", hipGetErrorString(e)));
+    if (flag & 1) return bail(fail(ctx, SRX_E_BOUNDS, "column index out of bounds (>= n_cols = %llu)",
+                                   (unsigned long long)h->n_cols));
+    if (flag & 2) return bail(fail(ctx, SRX_E_FORMAT, "X is not a canonical CSR matrix (unsorted/duplicate column indices)"));
+    *out = m;
+    return SRX_OK;
 }
 
 }  // namespace srx
@@ -331,64 +414,7 @@ int32_t srx_matrix_upload(srx_ctx* ctx, const srx_csr* h, int32_t store, srx_mat
         return fail(ctx, SRX_E_ARG, "srx_matrix_upload: null CSR slice");
     if (h->indptr[h->n_rows] - h->indptr[0] != h->nnz || h->indptr[0] != 0)
         return fail(ctx, SRX_E_FORMAT, "X is not a CSR matrix: row_offsets do not span nnz");
-    srx_mat* m = nullptr;
-    SRX_TRY(srx_matrix_alloc(ctx, h->n_rows, h->n_cols, h->nnz, h->dtype, store, &m));
-    auto bail = [&](int32_t rc) { srx_matrix_free(m); return rc; };
-    hipError_t e = hipMemcpy(m->d_indptr, h->indptr, (h->n_rows + 1) * sizeof(int64_t), hipMemcpyHostToDevice);
-    if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "H2D indptr: %s", hipGetErrorString(e)));
-
-    int* d_flag;
-    int32_t rc = scratch(ctx, "flag", 64, (void**)&d_flag);
-    if (rc) return bail(rc);
-    (void)hipMemsetAsync(d_flag, 0, sizeof(int), ctx->stream);
-
-    // indices: u64 -> i32 through a staging chunk
-    {
-        const uint64_t chunk = 32ull << 20;
-        void* d_tmp;
-        uint64_t c0 = h->nnz < chunk ? h->nnz : chunk;
-        rc = scratch(ctx, "upload_tmp", (c0 ? c0 : 1) * sizeof(uint64_t) + 16, &d_tmp);
-        if (rc) return bail(rc);
-        for (uint64_t off = 0; off < h->nnz; off += chunk) {
-            uint64_t cnt = h->nnz - off < chunk ? h->nnz - off : chunk;
-            e = hipMemcpy(d_tmp, h->indices + off, cnt * sizeof(uint64_t), hipMemcpyHostToDevice);
-            if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "H2D indices: %s", hipGetErrorString(e)));
-            hipLaunchKernelGGL(k_narrow_indices, dim3(grid_for(cnt, 256, 4096)), dim3(256), 0, ctx->stream,
-                               (const uint64_t*)d_tmp, m->d_indices + off, cnt, h->n_cols, d_flag);
-            e = hipStreamSynchronize(ctx->stream);
-            if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "narrow indices: %s", hipGetErrorString(e)));
-        }
-    }
-    // values
-    bool f32 = is_f32(m);
-    if ((h->dtype == SRX_F32 && f32) || (h->dtype == SRX_F64 && !f32)) {
-        e = hipMemcpy(m->d_values, h->values, h->nnz * val_bytes(m), hipMemcpyHostToDevice);
-        if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "H2D values: %s", hipGetErrorString(e)));
-    } else if (h->nnz) {
-        switch (h->dtype) {
-            case SRX_I8:  rc = convert_chunked<int8_t>(ctx, h->values, m->d_values, h->nnz, f32); break;
-            case SRX_I16: rc = convert_chunked<int16_t>(ctx, h->values, m->d_values, h->nnz, f32); break;
-            case SRX_I32: rc = convert_chunked<int32_t>(ctx, h->values, m->d_values, h->nnz, f32); break;
-            case SRX_U8:  rc = convert_chunked<uint8_t>(ctx, h->values, m->d_values, h->nnz, f32); break;
-            case SRX_U16: rc = convert_chunked<uint16_t>(ctx, h->values, m->d_values, h->nnz, f32); break;
-            case SRX_U32: rc = convert_chunked<uint32_t>(ctx, h->values, m->d_values, h->nnz, f32); break;
-            case SRX_F32: rc = convert_chunked<float>(ctx, h->values, m->d_values, h->nnz, f32); break;
-            case SRX_F64: rc = convert_chunked<double>(ctx, h->values, m->d_values, h->nnz, f32); break;
-            default: rc = fail(ctx, SRX_E_DTYPE, "dtype %d is not supported for this operation", h->dtype);
-        }
-        if (rc) return bail(rc);
-    }
-    // validate
-    hipLaunchKernelGGL(k_validate_rows, dim3(grid_for(h->n_rows * kWave, 256, 8192)), dim3(256), 0, ctx->stream,
-                       m->d_indptr, m->d_indices, h->n_rows, h->nnz, d_flag);
-    int flag = 0;
-    rc = d2h(ctx, &flag, d_flag, sizeof(int));
-    if (rc) return bail(rc);
-    if (flag & 1) return bail(fail(ctx, SRX_E_BOUNDS, "column index out of bounds (>= n_cols = %llu)",
-                                   (unsigned long long)h->n_cols));
-    if (flag & 2) return bail(fail(ctx, SRX_E_FORMAT, "X is not a canonical CSR matrix (unsorted/duplicate column indices)"));
-    *out = m;
-    return SRX_OK;
+    return upload_on(ctx, h, store, ctx->stream, out);
 }
 
 int32_t srx_matrix_device_ptrs(srx_mat* m, void** indptr, void** indices, void** values) {

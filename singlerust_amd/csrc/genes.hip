@@ -311,17 +311,11 @@ static void block_geometry(const srx_mat* m, uint64_t& n_blocks, uint64_t& rows_
     if (rows_per_block < 1) rows_per_block = 1;
 }
 
-int32_t ensure_moments(srx_mat* m) {
+// This shard's (cnt, sum, sumsq) per gene and its row count, packed as 3G+1 doubles in a scratch buffer.
+static int32_t local_moments(srx_mat* m, double** packed_out) {
     srx_ctx* ctx = m->ctx;
-    if (m->moments_version == m->version) return SRX_OK;
-    SRX_HIP(ctx, hipSetDevice(ctx->device));
     SRX_TRY(ensure_tiles(m));
     const uint64_t G = m->n_cols;
-    if (!m->d_cnt) {
-        SRX_HIP(ctx, hipMalloc((void**)&m->d_cnt, (G ? G : 1) * sizeof(uint64_t)));
-        SRX_HIP(ctx, hipMalloc((void**)&m->d_sum, (G ? G : 1) * sizeof(double)));
-        SRX_HIP(ctx, hipMalloc((void**)&m->d_sq, (G ? G : 1) * sizeof(double)));
-    }
     uint64_t nb, rpb;
     block_geometry(m, nb, rpb);
     uint32_t* p_cnt;
@@ -354,6 +348,63 @@ int32_t ensure_moments(srx_mat* m) {
                            p_sum, p_sq, G, nb, m->n_rows, packed);
     }
     SRX_HIP(ctx, hipGetLastError());
+    *packed_out = packed;
+    return SRX_OK;
+}
+
+__global__ void k_add_f64(double* __restrict__ acc, const double* __restrict__ x, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acc[i] += x[i];
+}
+
+// Backed mode: the moments of one row tile ADDED to `d_acc` (3G+1 doubles; counts stay exact below 2^53).
+int32_t moments_accumulate(srx_mat* m, double* d_acc) {
+    srx_ctx* ctx = m->ctx;
+    SRX_HIP(ctx, hipSetDevice(ctx->device));
+    double* packed;
+    SRX_TRY(local_moments(m, &packed));
+    const uint64_t n = 3 * m->n_cols + 1;
+    hipLaunchKernelGGL(k_add_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_acc, packed, n);
+    SRX_HIP(ctx, hipGetLastError());
+    return SRX_OK;
+}
+
+static int32_t alloc_moments(srx_mat* m) {
+    srx_ctx* ctx = m->ctx;
+    const uint64_t G = m->n_cols;
+    if (!m->d_cnt) {
+        SRX_HIP(ctx, hipMalloc((void**)&m->d_cnt, (G ? G : 1) * sizeof(uint64_t)));
+        SRX_HIP(ctx, hipMalloc((void**)&m->d_sum, (G ? G : 1) * sizeof(double)));
+        SRX_HIP(ctx, hipMalloc((void**)&m->d_sq, (G ? G : 1) * sizeof(double)));
+    }
+    return SRX_OK;
+}
+
+// All-reduces `d_packed` (3G+1 doubles, this rank's totals) and installs it as the global moments of `m`.
+int32_t moments_install(srx_mat* m, double* d_packed) {
+    srx_ctx* ctx = m->ctx;
+    const uint64_t G = m->n_cols;
+    SRX_HIP(ctx, hipSetDevice(ctx->device));
+    SRX_TRY(alloc_moments(m));
+    SRX_TRY(allreduce_f64(ctx, d_packed, 3 * G + 1));
+    hipLaunchKernelGGL(k_moments_unpack, dim3((unsigned)((G + 255) / 256 + 1)), dim3(256), 0, ctx->stream, d_packed, G,
+                       m->d_cnt, m->d_sum, m->d_sq);
+    SRX_HIP(ctx, hipGetLastError());
+    double ng = 0.0;
+    SRX_TRY(d2h(ctx, &ng, d_packed + 3 * G, sizeof(double)));
+    m->n_rows_global = (uint64_t)ng;
+    m->moments_version = m->version;
+    return SRX_OK;
+}
+
+int32_t ensure_moments(srx_mat* m) {
+    srx_ctx* ctx = m->ctx;
+    if (m->moments_version == m->version) return SRX_OK;
+    SRX_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t G = m->n_cols;
+    SRX_TRY(alloc_moments(m));
+    double* packed;
+    SRX_TRY(local_moments(m, &packed));
     // one all-reduce for (cnt, sum, sumsq, N) across the row shards
     SRX_TRY(allreduce_f64(ctx, packed, 3 * G + 1));
     hipLaunchKernelGGL(k_moments_unpack, dim3((unsigned)((G + 255) / 256 + 1)), dim3(256), 0, ctx->stream, packed, G,

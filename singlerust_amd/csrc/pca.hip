@@ -1983,12 +1983,18 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
 }
 
 template <typename VT, typename PT>
-static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const Resolved& o,
-                       const std::vector<double>& mu, const std::vector<double>& dinv, const HvgDev* hv, int l_act,
-                       double n_cells, srx_pca_state& st) {
-    srx_ctx* ctx = m->ctx;
+static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tiled* t128p, double* gram_packed,
+                       const Resolved& o, const std::vector<double>& mu, const std::vector<double>& dinv,
+                       const HvgDev* hv, int l_act, double n_cells, srx_pca_state& st) {
+    // `parts`: the 256-tiled views of this rank's rows — one for a resident matrix, one per row tile in backed
+    // mode (then `gram_packed` holds the Gram tiles already summed over the row tiles and `t128p` is null)
+    const Tiled& t256 = parts[0];
     const int k = t256.k;
-    struct { uint64_t n_rows; } cc{t256.n_rows};
+    struct { uint64_t n_rows, max_rows; } cc{0, 0};
+    for (int i = 0; i < n_parts; ++i) {
+        cc.n_rows += parts[i].n_rows;
+        cc.max_rows = std::max(cc.max_rows, parts[i].n_rows);
+    }
     const size_t kl = (size_t)k * L;
     Work w;
     st.d_small = nullptr;
@@ -2004,22 +2010,22 @@ static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const 
     PT *P, *cvec, *Y;
     SRX_TRY(scratch(ctx, "pca_P", (kl + L) * sizeof(PT), (void**)&P));
     cvec = P + kl;
-    SRX_TRY(scratch(ctx, "pca_Y", (cc.n_rows ? cc.n_rows : 1) * (size_t)L * sizeof(PT), (void**)&Y));
+    SRX_TRY(scratch(ctx, "pca_Y", (cc.max_rows ? cc.max_rows : 1) * (size_t)L * sizeof(PT), (void**)&Y));
 
     double resid = INFINITY;
     int iters = 0;
     bool converged = false;
     if (o.solver == 1) {
         // explicit Gram: G = A^T A once (all-reduced), C = D (G - c N mu mu^T) D dense
-        const Tiled& t128 = *t128p;
         double* C;
         SRX_TRY(scratch(ctx, "pca_C", (size_t)k * k * 8, (void**)&C));
-        double* Pk;
-        size_t n_packed;
-        SRX_TRY(launch_gram<VT>(ctx, t128, &Pk, &n_packed));
+        const int nt128 = (k + KG - 1) / KG;
+        double* Pk = gram_packed;
+        size_t n_packed = (size_t)(nt128 * (nt128 + 1) / 2) * KG * KG;
+        if (!Pk) SRX_TRY(launch_gram<VT>(ctx, *t128p, &Pk, &n_packed));
         SRX_TRY(allreduce_f64(ctx, Pk, n_packed));                // the one exchange of this solver: upper tiles only
         hipLaunchKernelGGL(k_gram_expand, dim3((unsigned)(((size_t)k * k + 255) / 256)), dim3(256), 0, ctx->stream, Pk,
-                           t128.nt, k, (const double*)w.d, (const double*)w.mu, o.center, n_cells, C);
+                           nt128, k, (const double*)w.d, (const double*)w.mu, o.center, n_cells, C);
         SRX_HIP(ctx, hipGetLastError());
         auto apply = [&](const double* Win, double* Wout) -> int32_t {
             ProfScope ps(ctx, SRX_K_DENSE, (double)k * k * 8.0 + 2.0 * k * L * 8.0);
@@ -2030,6 +2036,7 @@ static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const 
         };
         SRX_TRY(subspace_iterate(ctx, w, k, l_act, o, apply, C, true, hv ? hv->d_status : nullptr, resid, iters, converged));
     } else {
+        if (n_parts != 1) return fail(ctx, SRX_E_ARG, "pca: the SpMM solver needs the matrix resident in one piece");
         auto apply = [&](const double* Win, double* Wout) -> int32_t {
             hipLaunchKernelGGL((k_make_panel<PT>), dim3(1), dim3(1024), 0, ctx->stream, Win, w.d, w.mu,
                                (const double*)nullptr, k, o.center, P, cvec);
@@ -2066,7 +2073,13 @@ static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const 
         st.scores_cap = need;
     }
     st.d_small = st.d_scores + score_bytes / 8;
-    SRX_TRY((launch_fwd<VT, PT>(ctx, t256, P, cvec, Y, st.d_scores, n_pc)));      // f64 scores written by the SpMM itself
+    {
+        uint64_t row0 = 0;                                           // f64 scores written by the SpMM itself
+        for (int i = 0; i < n_parts; ++i) {
+            SRX_TRY((launch_fwd<VT, PT>(ctx, parts[i], P, cvec, Y, st.d_scores + row0 * (size_t)n_pc, n_pc)));
+            row0 += parts[i].n_rows;
+        }
+    }
     // the Ritz vectors, values and signs move out of the (per-context) scratch into the matrix's own block;
     // their host copies are made by the first fetch (pca_materialize)
     SRX_HIP(ctx, hipMemcpyAsync(st.d_small, w.A2, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -2077,6 +2090,107 @@ static int32_t run_pca(srx_mat* m, const Tiled& t256, const Tiled* t128p, const 
     if (!converged)
         return fail(ctx, SRX_E_NOCONV, "pca: subspace iteration stopped at max_iter=%d with residual %.3e > tol %.3e",
                     o.max_iter, resid, o.tol);
+    return SRX_OK;
+}
+
+// Defaults and limits of pca_inplace (dim_red/mod.rs:38-57) and of this solver.
+static int32_t resolve_opts(srx_ctx* ctx, const srx_pca_opts* opts, int k, uint64_t Ng, bool f32, Resolved& o, int& l_act) {
+    // dim_red/mod.rs:38-41: column(0)/column(1) and slice(..5) panic when k < 2 or N < 5
+    if (k < 2 || Ng < 5) return fail(ctx, SRX_E_SHAPE, "pca_inplace needs >= 2 selected features and >= 5 cells (k=%d, N=%llu)",
+                                     k, (unsigned long long)Ng);
+    int want = (!opts || opts->n_components < 0) ? 2 : opts->n_components;      // :52
+    o.n_pc = std::min(want, k);
+    o.center = (!opts || opts->center < 0) ? 1 : (opts->center != 0);           // :55
+    o.scale = (!opts || opts->scale < 0) ? 1 : (opts->scale != 0);              // :56
+    o.max_iter = (opts && opts->max_iter > 0) ? opts->max_iter : 200;
+    o.tol = (opts && opts->tol > 0) ? opts->tol : 0.0;
+    o.seed = opts ? opts->seed : 0;
+    o.solver = opts ? opts->solver : 0;
+    if (o.solver < 0 || o.solver > 2) return fail(ctx, SRX_E_ARG, "pca: solver must be 0 (auto), 1 (gram) or 2 (spmm)");
+    if (o.solver == 0) o.solver = k <= 4096 ? 1 : 2;
+    o.power = o.solver == 1 ? 3 : 1;
+    o.warm = o.solver == 1 ? 2 : 0;
+    if (o.solver == 1 && k > 16384) return fail(ctx, SRX_E_ARG, "pca: the Gram solver holds a k x k f64 matrix; k=%d is too large", k);
+    // default tolerance on the relative Ritz residual: what the arithmetic of the solver supports
+    if (o.tol == 0.0) o.tol = f32 ? 1e-7 : 1e-9;
+    if (o.n_pc < 1) return fail(ctx, SRX_E_ARG, "pca: n_components must be >= 1");
+    if (opts && opts->block != 0 && opts->block != L) return fail(ctx, SRX_E_ARG, "pca: only block = %d is built", L);
+    l_act = std::min(L, k);
+    if (o.n_pc > l_act || (k > L && o.n_pc > L - 8))
+        return fail(ctx, SRX_E_ARG, "pca: n_components %d exceeds what the %d-column block resolves (max %d)", o.n_pc, L,
+                    k > L ? L - 8 : l_act);
+    return SRX_OK;
+}
+
+// Everything the host side of the result needs stays on the device until the first fetch (pca_materialize).
+static int32_t stash_results(srx_ctx* ctx, srx_pca_state& st, int k, int n_pc, const HvgDev* hv,
+                             const std::vector<double>& mu, const std::vector<double>& sd, double trace,
+                             const std::vector<uint64_t>& selv) {
+    // Everything the host side of the result needs stays on the device until the first fetch.
+    const size_t kl = (size_t)k * L;
+    double* sm = st.d_small;
+    st.dev_sel = hv != nullptr;
+    if (hv) {
+        SRX_HIP(ctx, hipMemcpyAsync(sm + kl + 2 * L, hv->d_mu, (size_t)k * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        SRX_HIP(ctx, hipMemcpyAsync(sm + kl + 2 * L + k, hv->d_sd, (size_t)k * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        SRX_HIP(ctx, hipMemcpyAsync(sm + kl + 2 * L + 2 * (size_t)k, hv->d_trace, 8, hipMemcpyDeviceToDevice, ctx->stream));
+        SRX_HIP(ctx, hipMemcpyAsync(sm + kl + 2 * L + 2 * (size_t)k + 2, hv->d_sel_rank, (size_t)k * sizeof(int32_t),
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+        st.sel.clear();
+    } else {
+        st.pend_mu = mu;
+        st.pend_sd = sd;
+        st.pend_trace = trace;
+        st.sel = selv;
+    }
+    st.k = (uint32_t)k;
+    st.n_pc = (uint32_t)n_pc;
+    st.host_pending = true;
+    st.valid = true;
+    return SRX_OK;
+}
+
+// Host-side view of an explicit selection: ascending-gene order, remap table, and the all-cells mean / std
+// (ddof 0) of the selected genes from the (global) moments of `m`.
+static int32_t prepare_host_selection(srx_mat* m, const std::vector<uint64_t>& selv, const Resolved& o,
+                                      std::vector<int>& order, std::vector<int>& slot_of_sel,
+                                      std::vector<int32_t>& remap, std::vector<double>& mu, std::vector<double>& sd,
+                                      std::vector<double>& dinv, double& trace) {
+    srx_ctx* ctx = m->ctx;
+    const uint64_t G = m->n_cols;
+    const int k = (int)selv.size();
+    const double Nd = (double)m->n_rows_global;
+    // ascending-gene-order view of the selection; remap table; permutation back to selection order
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return selv[a] < selv[b]; });
+    remap.assign(G, -1);
+    for (int s = 0; s < k; ++s) {
+        uint64_t g = selv[order[s]];
+        if (g >= G) return fail(ctx, SRX_E_BOUNDS, "selected feature index %llu out of bounds (n_vars = %llu)",
+                                (unsigned long long)g, (unsigned long long)G);
+        if (remap[g] >= 0) return fail(ctx, SRX_E_ARG, "selected feature index %llu appears twice", (unsigned long long)g);
+        remap[g] = s;
+        slot_of_sel[order[s]] = s;
+    }
+    // all-cells column mean / std (ddof 0) of the selected genes from the one moments pass
+    // (pca/mod.rs:87-91): mean = sum/N, var = sumsq/N - mean^2
+    std::vector<double> hsum(G), hsq(G);
+    SRX_TRY(d2h(ctx, hsum.data(), m->d_sum, G * 8));
+    SRX_TRY(d2h(ctx, hsq.data(), m->d_sq, G * 8));
+    for (int s = 0; s < k; ++s) {
+        uint64_t g = selv[order[s]];
+        double mean = hsum[g] / Nd;
+        double var = hsq[g] / Nd - mean * mean;
+        if (var < 0) var = 0;
+        double std_ = std::sqrt(var);
+        mu[s] = (o.center || o.scale) ? mean : 0.0;            // :85-119: mean/std stored only if center||scale
+        sd[s] = o.scale ? std_ : 1.0;
+        // zero-variance column: the reference divides by 0 (NaN, :108); treated as std 1 here
+        dinv[s] = (o.scale && std_ > 0) ? 1.0 / std_ : 1.0;
+        double ss = o.center ? (hsq[g] - Nd * mean * mean) : hsq[g];
+        if (ss < 0) ss = 0;
+        trace += dinv[s] * dinv[s] * ss;
+    }
     return SRX_OK;
 }
 
@@ -2098,31 +2212,9 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     const int k = (int)selv.size();
     SRX_TRY(ensure_moments(m));                                                // also fixes n_rows_global
     const uint64_t Ng = m->n_rows_global;
-    // dim_red/mod.rs:38-41: column(0)/column(1) and slice(..5) panic when k < 2 or N < 5
-    if (k < 2 || Ng < 5) return fail(ctx, SRX_E_SHAPE, "pca_inplace needs >= 2 selected features and >= 5 cells (k=%d, N=%llu)",
-                                     k, (unsigned long long)Ng);
     Resolved o;
-    int want = (!opts || opts->n_components < 0) ? 2 : opts->n_components;      // :52
-    o.n_pc = std::min(want, k);
-    o.center = (!opts || opts->center < 0) ? 1 : (opts->center != 0);           // :55
-    o.scale = (!opts || opts->scale < 0) ? 1 : (opts->scale != 0);              // :56
-    o.max_iter = (opts && opts->max_iter > 0) ? opts->max_iter : 200;
-    o.tol = (opts && opts->tol > 0) ? opts->tol : 0.0;
-    o.seed = opts ? opts->seed : 0;
-    o.solver = opts ? opts->solver : 0;
-    if (o.solver < 0 || o.solver > 2) return fail(ctx, SRX_E_ARG, "pca: solver must be 0 (auto), 1 (gram) or 2 (spmm)");
-    if (o.solver == 0) o.solver = k <= 4096 ? 1 : 2;
-    o.power = o.solver == 1 ? 3 : 1;
-    o.warm = o.solver == 1 ? 2 : 0;
-    if (o.solver == 1 && k > 16384) return fail(ctx, SRX_E_ARG, "pca: the Gram solver holds a k x k f64 matrix; k=%d is too large", k);
-    // default tolerance on the relative Ritz residual: what the arithmetic of the solver supports
-    if (o.tol == 0.0) o.tol = is_f32(m) ? 1e-7 : 1e-9;
-    if (o.n_pc < 1) return fail(ctx, SRX_E_ARG, "pca: n_components must be >= 1");
-    if (opts && opts->block != 0 && opts->block != L) return fail(ctx, SRX_E_ARG, "pca: only block = %d is built", L);
-    const int l_act = std::min(L, k);
-    if (o.n_pc > l_act || (k > L && o.n_pc > L - 8))
-        return fail(ctx, SRX_E_ARG, "pca: n_components %d exceeds what the %d-column block resolves (max %d)", o.n_pc, L,
-                    k > L ? L - 8 : l_act);
+    int l_act = 0;
+    SRX_TRY(resolve_opts(ctx, opts, k, Ng, is_f32(m), o, l_act));
 
     std::vector<int> order(k), slot_of_sel(k);
     std::vector<int32_t> remap;
@@ -2133,37 +2225,7 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     if (dev_sel) {
         SRX_TRY(select_hvg_device(m, hvg_n, o.center, o.scale, hv));
     } else {
-        // ascending-gene-order view of the selection; remap table; permutation back to selection order
-        std::iota(order.begin(), order.end(), 0);
-        std::sort(order.begin(), order.end(), [&](int a, int b) { return selv[a] < selv[b]; });
-        remap.assign(G, -1);
-        for (int s = 0; s < k; ++s) {
-            uint64_t g = selv[order[s]];
-            if (g >= G) return fail(ctx, SRX_E_BOUNDS, "selected feature index %llu out of bounds (n_vars = %llu)",
-                                    (unsigned long long)g, (unsigned long long)G);
-            if (remap[g] >= 0) return fail(ctx, SRX_E_ARG, "selected feature index %llu appears twice", (unsigned long long)g);
-            remap[g] = s;
-            slot_of_sel[order[s]] = s;
-        }
-        // all-cells column mean / std (ddof 0) of the selected genes from the one moments pass
-        // (pca/mod.rs:87-91): mean = sum/N, var = sumsq/N - mean^2
-        std::vector<double> hsum(G), hsq(G);
-        SRX_TRY(d2h(ctx, hsum.data(), m->d_sum, G * 8));
-        SRX_TRY(d2h(ctx, hsq.data(), m->d_sq, G * 8));
-        for (int s = 0; s < k; ++s) {
-            uint64_t g = selv[order[s]];
-            double mean = hsum[g] / Nd;
-            double var = hsq[g] / Nd - mean * mean;
-            if (var < 0) var = 0;
-            double std_ = std::sqrt(var);
-            mu[s] = (o.center || o.scale) ? mean : 0.0;            // :85-119: mean/std stored only if center||scale
-            sd[s] = o.scale ? std_ : 1.0;
-            // zero-variance column: the reference divides by 0 (NaN, :108); treated as std 1 here
-            dinv[s] = (o.scale && std_ > 0) ? 1.0 / std_ : 1.0;
-            double ss = o.center ? (hsq[g] - Nd * mean * mean) : hsq[g];
-            if (ss < 0) ss = 0;
-            trace += dinv[s] * dinv[s] * ss;
-        }
+        SRX_TRY(prepare_host_selection(m, selv, o, order, slot_of_sel, remap, mu, sd, dinv, trace));
     }
     std::vector<double> mu_eff = mu;
     if (!o.center) std::fill(mu_eff.begin(), mu_eff.end(), 0.0);
@@ -2193,30 +2255,10 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     st.info.solver = (uint32_t)o.solver;
     int32_t rc;
     const HvgDev* hvp = dev_sel ? &hv : nullptr;
-    if (is_f32(m)) rc = run_pca<float, float>(m, t256, need128 ? &t128 : nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
-    else rc = run_pca<double, double>(m, t256, need128 ? &t128 : nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
+    if (is_f32(m)) rc = run_pca<float, float>(ctx, &t256, 1, need128 ? &t128 : nullptr, nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
+    else rc = run_pca<double, double>(ctx, &t256, 1, need128 ? &t128 : nullptr, nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
     if ((rc != SRX_OK && rc != SRX_E_NOCONV) || !st.d_small) return rc;      // d_small unset: the solve broke down early
-    // Everything the host side of the result needs stays on the device until the first fetch.
-    const size_t kl = (size_t)k * L;
-    double* sm = st.d_small;
-    st.dev_sel = dev_sel;
-    if (dev_sel) {
-        SRX_HIP(ctx, hipMemcpyAsync(sm + kl + 2 * L, hv.d_mu, (size_t)k * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        SRX_HIP(ctx, hipMemcpyAsync(sm + kl + 2 * L + k, hv.d_sd, (size_t)k * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        SRX_HIP(ctx, hipMemcpyAsync(sm + kl + 2 * L + 2 * (size_t)k, hv.d_trace, 8, hipMemcpyDeviceToDevice, ctx->stream));
-        SRX_HIP(ctx, hipMemcpyAsync(sm + kl + 2 * L + 2 * (size_t)k + 2, hv.d_sel_rank, (size_t)k * sizeof(int32_t),
-                                    hipMemcpyDeviceToDevice, ctx->stream));
-        st.sel.clear();
-    } else {
-        st.pend_mu = mu;
-        st.pend_sd = sd;
-        st.pend_trace = trace;
-        st.sel = selv;
-    }
-    st.k = (uint32_t)k;
-    st.n_pc = (uint32_t)o.n_pc;
-    st.host_pending = true;
-    st.valid = true;
+    SRX_TRY(stash_results(ctx, st, k, o.n_pc, dev_sel ? &hv : nullptr, mu, sd, trace, selv));
     return rc;
 }
 
@@ -2272,6 +2314,8 @@ static int32_t pca_materialize(srx_mat* m) {
 }  // namespace srx
 
 using namespace srx;
+
+#include "backed.inl"
 
 extern "C" {
 

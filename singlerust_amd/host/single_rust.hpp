@@ -318,4 +318,140 @@ inline srx_pca_info pca_inplace(IMAnnData& a, std::optional<std::size_t> n_compo
 }  // namespace dim_red
 }  // namespace processing
 }  // namespace memory
+
+// ---- single_rust::backed (src/backed/mod.rs): the matrix is not resident, it is visited as row chunks ----------
+struct ComputationMode {                                          // src/shared/mod.rs:25-28
+    enum Kind { ChunkedK, WholeK } kind = WholeK;
+    std::size_t size = 0;
+    static ComputationMode Chunked(std::size_t n) { ComputationMode m; m.kind = ChunkedK; m.size = n; return m; }
+    static ComputationMode Whole() { return ComputationMode(); }
+};
+
+namespace backed {
+
+// The CSR group of an h5ad `X` (indptr / indices / data) held by the caller: borrowed host arrays (a memory-mapped
+// flat store, or the in-memory arrays).  `iter(chunk)` visits consecutive row ranges like ArrayElemOp::iter.
+class BackedAnnData {
+public:
+    BackedAnnData(Context& ctx, std::size_t n_obs, std::size_t n_vars, const std::uint64_t* row_offsets,
+                  const std::uint64_t* col_indices, const void* values, int dtype)
+        : ctx_(&ctx), n_obs_(n_obs), n_vars_(n_vars), ip_(row_offsets), ix_(col_indices), v_(values), dtype_(dtype) {}
+    template <typename T>
+    static BackedAnnData of(Context& ctx, const CsrMatrix<T>& x) {
+        return BackedAnnData(ctx, x.nrows, x.ncols, x.row_offsets.data(), x.col_indices.data(), x.values.data(), DTypeOf<T>::v);
+    }
+    std::size_t n_obs() const { return n_obs_; }
+    std::size_t n_vars() const { return n_vars_; }
+    Context& ctx() const { return *ctx_; }
+    // rows [start, end) as an srx_csr tile: a window of the row offsets, nothing copied
+    srx_csr tile(std::size_t start, std::size_t end) const {
+        static const std::size_t width[] = {1, 2, 4, 1, 2, 4, 4, 8};      // SRX_I8 .. SRX_F64
+        const std::uint64_t lo = ip_[start];
+        return srx_csr{end - start, n_vars_, ip_[end] - lo, ip_ + start, ix_ + lo,
+                       const_cast<char*>(static_cast<const char*>(v_)) + lo * width[dtype_], dtype_};
+    }
+
+private:
+    Context* ctx_;
+    std::size_t n_obs_, n_vars_;
+    const std::uint64_t *ip_, *ix_;
+    const void* v_;
+    int dtype_;
+};
+
+class Session {                                                   // owning wrapper of an srx_backed
+public:
+    Session(Context& ctx, std::size_t n_cols, int store = SRX_STORE_AUTO) : ctx_(&ctx) {
+        ctx.check(srx_backed_create(ctx.handle(), n_cols, store, &h_));
+    }
+    ~Session() { srx_backed_destroy(h_); }
+    Session(const Session&) = delete;
+    Session& operator=(const Session&) = delete;
+    srx_backed* handle() const { return h_; }
+
+private:
+    Context* ctx_;
+    srx_backed* h_ = nullptr;
+};
+
+namespace statistics {                                            // src/backed/statistics/mod.rs:5-45
+namespace detail {
+inline void sweep(const BackedAnnData& a, std::size_t size, Session& s, std::uint32_t* row_num, double* row_sum) {
+    if (size == 0) throw Error(SRX_E_ARG, "ComputationMode::Chunked(0)");
+    for (std::size_t start = 0; start < a.n_obs(); start += size) {
+        const std::size_t end = std::min(start + size, a.n_obs());
+        srx_csr t = a.tile(start, end);
+        // every chunk writes at ITS rows (the reference's chunk helpers use the chunk-local index, csr.rs:57-62)
+        a.ctx().check(srx_backed_stats_tile(s.handle(), &t, 0.0, 0, row_num ? row_num + start : nullptr,
+                                            row_sum ? row_sum + start : nullptr));
+    }
+}
+}  // namespace detail
+
+inline std::vector<std::uint32_t> compute_number(const BackedAnnData& a, Direction d, const ComputationMode& mode) {
+    const std::size_t chunk = mode.kind == ComputationMode::ChunkedK ? mode.size : std::max<std::size_t>(a.n_obs(), 1);
+    Session s(a.ctx(), a.n_vars());
+    std::vector<std::uint32_t> out(d == Direction::Row ? a.n_obs() : a.n_vars());
+    detail::sweep(a, chunk, s, d == Direction::Row ? out.data() : nullptr, nullptr);
+    if (d == Direction::Column) {
+        std::vector<std::uint64_t> cnt(a.n_vars());
+        a.ctx().check(srx_backed_moments(s.handle(), cnt.data(), nullptr, nullptr, nullptr));
+        for (std::size_t j = 0; j < cnt.size(); ++j) out[j] = (std::uint32_t)cnt[j];
+    }
+    return out;
+}
+
+inline std::vector<double> compute_sum(const BackedAnnData& a, Direction d, const ComputationMode& mode) {
+    const std::size_t chunk = mode.kind == ComputationMode::ChunkedK ? mode.size : std::max<std::size_t>(a.n_obs(), 1);
+    Session s(a.ctx(), a.n_vars());
+    std::vector<double> out(d == Direction::Row ? a.n_obs() : a.n_vars());
+    detail::sweep(a, chunk, s, nullptr, d == Direction::Row ? out.data() : nullptr);
+    if (d == Direction::Column) a.ctx().check(srx_backed_moments(s.handle(), nullptr, out.data(), nullptr, nullptr));
+    return out;
+}
+}  // namespace statistics
+
+namespace processing {
+// The whole path over row chunks (the reference's backed::processing is empty; include/srx.h "backed mode").
+struct PcaResult {
+    Array2 x_pca;                      // n_obs x n_pc
+    Array2 components;                 // k x n_pc, rows in selection order
+    std::vector<double> explained_variance_ratio, mean, std_;
+    std::vector<std::uint64_t> selected;
+    srx_pca_info info{};
+};
+inline PcaResult pca_pipeline(const BackedAnnData& a, std::size_t chunk, double target_sum, std::size_t n_hvg,
+                              int n_components, int store = SRX_STORE_AUTO) {
+    if (chunk == 0) throw Error(SRX_E_ARG, "chunk size 0");
+    Context& ctx = a.ctx();
+    Session s(ctx, a.n_vars(), store);
+    const int tf = SRX_BACKED_NORMALIZE | SRX_BACKED_LOG1P;
+    for (std::size_t start = 0; start < a.n_obs(); start += chunk) {
+        srx_csr t = a.tile(start, std::min(start + chunk, a.n_obs()));
+        ctx.check(srx_backed_stats_tile(s.handle(), &t, target_sum, tf, nullptr, nullptr));
+    }
+    srx_pca_opts o{};
+    o.n_components = n_components;
+    o.center = o.scale = -1;
+    std::uint64_t k = 0;
+    ctx.check(srx_backed_select(s.handle(), n_hvg, nullptr, 0, &o, nullptr, &k));
+    for (std::size_t start = 0; start < a.n_obs(); start += chunk) {
+        srx_csr t = a.tile(start, std::min(start + chunk, a.n_obs()));
+        ctx.check(srx_backed_gram_tile(s.handle(), &t, target_sum, tf));
+    }
+    PcaResult r;
+    ctx.check(srx_backed_solve(s.handle(), &r.info));
+    const std::size_t n_pc = r.info.n_pc;
+    r.x_pca = Array2{a.n_obs(), n_pc, std::vector<double>(a.n_obs() * n_pc)};
+    r.components = Array2{(std::size_t)k, n_pc, std::vector<double>(k * n_pc)};
+    r.explained_variance_ratio.resize(n_pc);
+    r.mean.resize(k);
+    r.std_.resize(k);
+    r.selected.resize(k);
+    ctx.check(srx_backed_fetch(s.handle(), r.x_pca.data.data(), r.components.data.data(), r.explained_variance_ratio.data(),
+                               r.mean.data(), r.std_.data(), r.selected.data()));
+    return r;
+}
+}  // namespace processing
+}  // namespace backed
 }  // namespace single_rust

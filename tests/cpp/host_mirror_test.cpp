@@ -155,6 +155,43 @@ static void test_filters(Context& ctx) {
     EXPECT(adata.n_vars() == 90 && adata.var_names().size() == 90, "in-place gene filter kept %zu", adata.n_vars());
 }
 
+// src/backed/statistics/mod.rs:5-45 over row chunks == the resident statistics; the whole path over chunks == resident
+static void test_backed(Context& ctx) {
+    namespace bk = single_rust::backed;
+    auto x = create_large_test_data(1000, 100, 10.0, 23);
+    IMAnnData adata = IMAnnData::new_basic(ctx, x, names("obs", 1000), names("var", 100));
+    bk::BackedAnnData b = bk::BackedAnnData::of(ctx, x);
+    for (std::size_t chunk : {std::size_t(64), std::size_t(333), std::size_t(5000)}) {
+        for (Direction d : {Direction::Row, Direction::Column}) {
+            auto n1 = bk::statistics::compute_number(b, d, ComputationMode::Chunked(chunk));
+            EXPECT(n1 == stats::compute_number(adata, d), "chunked compute_number differs (chunk %zu)", chunk);
+            auto s1 = bk::statistics::compute_sum(b, d, ComputationMode::Chunked(chunk));
+            auto s0 = stats::compute_sum(adata, d);
+            for (std::size_t i = 0; i < s0.size(); ++i)
+                EXPECT(std::fabs(s1[i] - s0[i]) <= 1e-12 * std::fabs(s0[i]), "chunked compute_sum differs at %zu", i);
+        }
+    }
+    EXPECT(bk::statistics::compute_number(b, Direction::Row, ComputationMode::Whole()) == stats::compute_number(adata, Direction::Row),
+           "ComputationMode::Whole differs");
+    auto r = bk::processing::pca_pipeline(b, 300, 1e4, 40, 10);
+    proc::normalize_total_inplace(adata, 1e4, Direction::Row);
+    proc::log1p_transform_inplace(adata);
+    auto hv = proc::dim_red::select_features(adata, FeatureSelection::HighlyVariable(40));
+    EXPECT(r.selected == hv, "backed HVG list differs from the resident one");
+    proc::dim_red::pca_inplace(adata, 10, {}, {}, {}, FeatureSelection::HighlyVariable(40));
+    const Array2& pcs = adata.obsm().at("X_pca");
+    for (std::size_t c = 0; c < 10; ++c) {
+        double dot = 0, nn = 0, dd = 0;
+        for (std::size_t i = 0; i < 1000; ++i) dot += pcs(i, c) * r.x_pca(i, c);
+        const double sgn = dot >= 0 ? 1.0 : -1.0;
+        for (std::size_t i = 0; i < 1000; ++i) {
+            nn += pcs(i, c) * pcs(i, c);
+            dd += (r.x_pca(i, c) - sgn * pcs(i, c)) * (r.x_pca(i, c) - sgn * pcs(i, c));
+        }
+        EXPECT(std::sqrt(dd / nn) < 1e-8, "backed PC %zu differs from the resident one by %.3g", c, std::sqrt(dd / nn));
+    }
+}
+
 static void test_errors(Context& ctx) {
     auto x = create_large_test_data(4, 6, 2.0, 3);
     IMAnnData tiny = IMAnnData::new_basic(ctx, x, names("obs", 4), names("var", 6));
@@ -173,6 +210,7 @@ int main() {
         test_normalize_total(ctx);
         test_path_end_to_end(ctx);
         test_filters(ctx);
+        test_backed(ctx);
         test_errors(ctx);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "exception: %s\n", e.what());

@@ -164,3 +164,32 @@ def test_filter_oracle_kat_4x5():
     assert fo.calculate_percentiles(np.array([1.0, 2.0]), fo.NONE, fo.absolute(3)) == (fo.F64_MIN, fo.F64_MAX)
     out, mask = fo.filter_cells(m, fo.NONE, fo.NONE)
     assert mask.all() and out.values.tolist() == m.values.tolist()
+
+
+def test_backed_oracle_chunked_equals_whole_and_flat_store_roundtrip(tmp_path):
+    """oracle/backed_oracle.py: chunked number / sum == the whole-matrix helpers for every chunk size (Column
+    always; Row with per-chunk offsets), the as-written Row loop folds all chunks onto the first `size` entries;
+    the flat store (singlerust_amd.backed.BackedCsr) round-trips and iterates like ArrayElemOp::iter."""
+    from oracle import backed_oracle
+    from singlerust_amd.backed import BackedCsr
+    from util import create_large_test_data
+    m = create_large_test_data(300, 40, 10.0, seed=1, dtype=np.uint16)
+    for ch in (1, 37, 100, 500):
+        for d in (ROW, COLUMN):
+            assert np.array_equal(backed_oracle.number_chunked(m, ch, d), oracle.compute_number(m, d))
+            assert np.array_equal(backed_oracle.sum_chunked(m, ch, d), oracle.compute_sum(m, d))
+    whole = oracle.compute_number(m, ROW)
+    aw = backed_oracle.number_chunked(m, 100, ROW, as_written=True)
+    assert np.array_equal(aw[:100], whole[:100] + whole[100:200] + whole[200:300]) and not aw[100:].any()
+    p = str(tmp_path / "store")
+    BackedCsr.write(p, m.indptr, m.indices, m.values, m.n_cols)
+    b = BackedCsr.open(p)
+    assert (b.n_rows, b.n_cols, b.nnz) == (300, 40, len(m.values)) and b.values.dtype == np.uint16
+    seen = 0
+    for chunk, start, end in b.iter(64):
+        assert chunk.n_rows == end - start and start == seen
+        lo, hi = int(m.indptr[start]), int(m.indptr[end])
+        assert chunk.nnz == hi - lo and np.array_equal(chunk.indices, np.asarray(m.indices[lo:hi], dtype=np.uint64))
+        assert int(chunk.indptr[0]) == lo                  # a window of the row offsets, not rebased
+        seen = end
+    assert seen == 300

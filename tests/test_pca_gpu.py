@@ -25,7 +25,10 @@ def col_err(got, ref):
     worst = 0.0
     for c in range(ref.shape[1]):
         s = 1.0 if np.dot(got[:, c], ref[:, c]) >= 0 else -1.0
-        worst = max(worst, np.linalg.norm(got[:, c] - s * ref[:, c]) / np.linalg.norm(ref[:, c]))
+        e = np.linalg.norm(got[:, c] - s * ref[:, c]) / np.linalg.norm(ref[:, c])
+        if not np.isfinite(e):
+            return float("inf")                      # NaN / inf anywhere fails every `< tol` comparison
+        worst = max(worst, e)
     return worst
 
 
