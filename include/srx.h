@@ -105,6 +105,22 @@ int32_t srx_partition_rows(const uint64_t* indptr, uint64_t n_rows, int32_t n_ra
 /* Narrowing upload of a reference-layout CSR (u64 -> i32 column indices on device, i64 row
  * offsets).  Validates sortedness/bounds on device (SRX_E_FORMAT / SRX_E_BOUNDS). */
 int32_t srx_matrix_upload(srx_ctx* ctx, const srx_csr* host, int32_t store, srx_mat** out);
+/* CSC storage (ArrayData::CscMatrix / DynCscMatrix): `host` describes X (n_rows cells x n_cols
+ * genes) with indptr = col_offsets[n_cols+1], indices = row_indices[nnz] (sorted per column).
+ * Replaces the CSC arms of the reference: src/shared/statistics/helper/csc.rs:15-216,
+ * scale_row_csc / scale_col_csc (src/memory/processing/scale/mod.rs:25-57,104-139), log1p on a
+ * CSC matrix, convert_to_array_f64_csc[_selected] (src/shared/mod.rs:204-215,261-290) for the PCA.
+ * Every entry point that takes an srx_mat accepts the handle and follows the reference's CSC
+ * arithmetic (e.g. compute_variance(Column) is the two-pass form with NaN for an empty gene,
+ * csc.rs:164-177); srx_matrix_info reports the shape of X; srx_matrix_download_pattern / _values
+ * return the CSC arrays.  srx_pca / srx_pipeline transpose on the device first.  Not available
+ * on a CSC handle: srx_gene_moments, srx_spmm, multi-rank contexts (shard by cells = CSR rows). */
+int32_t srx_matrix_upload_csc(srx_ctx* ctx, const srx_csr* host, int32_t store, srx_mat** out);
+enum { SRX_FORMAT_CSR = 0, SRX_FORMAT_CSC = 1 };
+int32_t srx_matrix_format(const srx_mat* m, int32_t* format_out);
+/* Storage conversion on the device (a copy; the input is left as it is). */
+int32_t srx_matrix_to_csr(srx_mat* m, srx_mat** out);
+int32_t srx_matrix_to_csc(srx_mat* m, srx_mat** out);
 /* Uninitialised device CSR for producers that fill HBM directly (synthetic generator, a
  * host that already holds device buffers). `dtype` is the logical dtype the values are
  * deemed to have (what DynCsrMatrix variant X is). */
@@ -114,7 +130,7 @@ int32_t srx_matrix_alloc(srx_ctx* ctx, uint64_t n_rows, uint64_t n_cols, uint64_
  * values = float[nnz] or double[nnz] (see srx_matrix_info). */
 int32_t srx_matrix_device_ptrs(srx_mat* m, void** indptr, void** indices, void** values);
 typedef struct srx_mat_info {
-    uint64_t n_rows, n_cols, nnz;
+    uint64_t n_rows, n_cols, nnz;  /* shape of X (cells x genes), CSR or CSC                  */
     int32_t dtype;        /* current LOGICAL dtype (F64 after normalize_total, ...)       */
     int32_t store;        /* SRX_STORE_F32 or SRX_STORE_F64                               */
     uint64_t row_offset;  /* global index of local row 0 (sharded runs)                   */

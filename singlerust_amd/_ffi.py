@@ -90,6 +90,10 @@ _SIGS = {
     "srx_comm_destroy": (C.c_int32, [P]),
     "srx_partition_rows": (C.c_int32, [P, C.c_uint64, C.c_int32, P]),
     "srx_matrix_upload": (C.c_int32, [P, C.POINTER(Csr), C.c_int32, C.POINTER(P)]),
+    "srx_matrix_upload_csc": (C.c_int32, [P, C.POINTER(Csr), C.c_int32, C.POINTER(P)]),
+    "srx_matrix_format": (C.c_int32, [P, C.POINTER(C.c_int32)]),
+    "srx_matrix_to_csr": (C.c_int32, [P, C.POINTER(P)]),
+    "srx_matrix_to_csc": (C.c_int32, [P, C.POINTER(P)]),
     "srx_matrix_alloc": (C.c_int32, [P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(P)]),
     "srx_matrix_device_ptrs": (C.c_int32, [P, C.POINTER(P), C.POINTER(P), C.POINTER(P)]),
     "srx_matrix_info": (C.c_int32, [P, C.POINTER(MatInfo)]),

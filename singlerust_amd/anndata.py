@@ -141,7 +141,8 @@ class DeviceCsr:
         self._h = handle
 
     @classmethod
-    def upload(cls, ctx: Context, n_rows, n_cols, indptr, indices, values, store=F.STORE_AUTO):
+    def upload(cls, ctx: Context, n_rows, n_cols, indptr, indices, values, store=F.STORE_AUTO, csc=False):
+        """CSR arrays of X, or with ``csc`` its CSC arrays (col_offsets, row_indices, values)."""
         indptr = np.ascontiguousarray(indptr, dtype=np.uint64)
         indices = np.ascontiguousarray(indices, dtype=np.uint64)
         values = np.ascontiguousarray(values)
@@ -151,8 +152,24 @@ class DeviceCsr:
         d = F.Csr(int(n_rows), int(n_cols), int(values.shape[0]), indptr.ctypes.data,
                   indices.ctypes.data, values.ctypes.data, DTYPE_OF_NP[values.dtype])
         h = C.c_void_p()
-        F.check(F.lib().srx_matrix_upload(ctx.handle, C.byref(d), int(store), C.byref(h)), ctx.handle)
+        up = F.lib().srx_matrix_upload_csc if csc else F.lib().srx_matrix_upload
+        F.check(up(ctx.handle, C.byref(d), int(store), C.byref(h)), ctx.handle)
         return cls(ctx, h)
+
+    def is_csc(self) -> bool:
+        f = C.c_int32(0)
+        F.check(F.lib().srx_matrix_format(self._h, C.byref(f)), self.ctx.handle)
+        return f.value == 1
+
+    def to_csr(self) -> "DeviceCsr":
+        h = C.c_void_p()
+        F.check(F.lib().srx_matrix_to_csr(self._h, C.byref(h)), self.ctx.handle)
+        return DeviceCsr(self.ctx, h)
+
+    def to_csc(self) -> "DeviceCsr":
+        h = C.c_void_p()
+        F.check(F.lib().srx_matrix_to_csc(self._h, C.byref(h)), self.ctx.handle)
+        return DeviceCsr(self.ctx, h)
 
     @property
     def handle(self):
@@ -214,22 +231,24 @@ class IMAnnData:
         self.uns: dict[str, object] = {}
 
     @classmethod
-    def new_basic(cls, x, obs_names=None, var_names=None, ctx: Context | None = None, store=F.STORE_AUTO):
+    def new_basic(cls, x, obs_names=None, var_names=None, ctx: Context | None = None, store=F.STORE_AUTO, csc=False):
         """IMAnnData::new_basic(x, obs_names, var_names) (src/memory/processing/mod.rs:381).
 
-        ``x``: ``(n_rows, n_cols, indptr, indices, values)`` or a scipy.sparse CSR matrix."""
+        ``x``: ``(n_rows, n_cols, indptr, indices, values)`` (CSR arrays; with ``csc=True`` the CSC arrays
+        col_offsets / row_indices / values) or a scipy.sparse CSR / CSC matrix (ArrayData::CsrMatrix / CscMatrix)."""
         ctx = ctx or Context.default()
         if hasattr(x, "indptr") and hasattr(x, "tocsr"):
             fmt = getattr(x, "format", "csr")
-            if fmt != "csr":
-                raise F.SrxError(F.E_FORMAT, "X is not a CSR matrix")
+            if fmt not in ("csr", "csc"):
+                raise F.SrxError(F.E_FORMAT, "X is neither a CSC nor a CSR matrix")
+            csc = fmt == "csc"
             n_rows, n_cols = x.shape
             indptr, indices, values = x.indptr, x.indices, x.data
         else:
             n_rows, n_cols, indptr, indices, values = x
         indptr = np.ascontiguousarray(indptr, dtype=np.uint64)
         indices = np.ascontiguousarray(indices, dtype=np.uint64)
-        dev = DeviceCsr.upload(ctx, n_rows, n_cols, indptr, indices, values, store)
+        dev = DeviceCsr.upload(ctx, n_rows, n_cols, indptr, indices, values, store, csc=csc)
         obs_names = obs_names if obs_names is not None else [f"obs{i}" for i in range(n_rows)]
         var_names = var_names if var_names is not None else [f"var{i}" for i in range(n_cols)]
         return cls(dev, indptr, indices, obs_names, var_names)
@@ -253,7 +272,7 @@ class IMAnnData:
     def _from_device(cls, dev: DeviceCsr, obs_names, var_names) -> "IMAnnData":
         """Wrap a matrix the library produced (filter / subset): the host pattern copy is downloaded."""
         i = dev.info()
-        indptr = np.zeros(i.n_rows + 1, dtype=np.uint64)
+        indptr = np.zeros((i.n_cols if dev.is_csc() else i.n_rows) + 1, dtype=np.uint64)
         indices = np.zeros(i.nnz, dtype=np.uint64)
         F.check(F.lib().srx_matrix_download_pattern(dev.handle, F.ptr(indptr), F.ptr(indices)), dev.ctx.handle)
         return cls(dev, indptr, indices, obs_names, var_names)

@@ -135,6 +135,9 @@ struct srx_mat {
     double* d_sq = nullptr;
     uint64_t n_rows_global = 0;     // valid with moments
     double* d_row_sum = nullptr;    // n_rows f64, filled by the normalise pass
+    // CSC storage (DynCscMatrix): the arrays above are the CSR of X^T (n_rows = n_vars, n_cols = n_obs) and the
+    // entry points exchange Row and Column (csc.hip)
+    bool csc = false;
     srx_pca_state pca;
 };
 
@@ -207,6 +210,9 @@ int32_t launch_normalize(srx_mat* m, double target, bool do_norm, bool do_log);
 inline void touch(srx_mat* m) { m->version++; m->pca.valid = false; }
 
 inline bool is_f32(const srx_mat* m) { return m->store == SRX_STORE_F32; }
+// direction as the STORED matrix sees it: a CSC matrix is the CSR of the transpose
+inline int32_t eff_dir(const srx_mat* m, int32_t d) { return (m->csc && (d == SRX_ROW || d == SRX_COLUMN)) ? 1 - d : d; }
+int32_t transpose_device(srx_mat* m, srx_mat** out);      // csc.hip: CSR of the transpose of the stored matrix
 inline size_t val_bytes(const srx_mat* m) { return is_f32(m) ? 4 : 8; }
 
 }  // namespace srx

@@ -432,7 +432,9 @@ int32_t srx_matrix_device_ptrs(srx_mat* m, void** indptr, void** indices, void**
 
 int32_t srx_matrix_info(const srx_mat* m, srx_mat_info* out) {
     if (!m || !out) return fail(nullptr, SRX_E_ARG, "null argument");
-    out->n_rows = m->n_rows; out->n_cols = m->n_cols; out->nnz = m->nnz;
+    out->n_rows = m->csc ? m->n_cols : m->n_rows;      // the shape of X, whatever the storage
+    out->n_cols = m->csc ? m->n_rows : m->n_cols;
+    out->nnz = m->nnz;
     out->dtype = m->dtype; out->store = m->store;
     out->row_offset = m->row_offset;
     out->n_rows_global = m->n_rows_global;
@@ -472,6 +474,7 @@ int32_t srx_matrix_clone(srx_mat* m, srx_mat** out) {
     srx_mat* c = nullptr;
     SRX_TRY(srx_matrix_alloc(ctx, m->n_rows, m->n_cols, m->nnz, m->dtype, m->store, &c));
     c->row_offset = m->row_offset;
+    c->csc = m->csc;
     hipError_t e = hipMemcpyAsync(c->d_indptr, m->d_indptr, (m->n_rows + 1) * sizeof(int64_t),
                                   hipMemcpyDeviceToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c->d_indices, m->d_indices, m->nnz * sizeof(int32_t),

@@ -181,15 +181,21 @@ using namespace srx;
 
 extern "C" {
 
+// masks in the STORED orientation; the result keeps the storage format of the input
+static int32_t subset_stored(srx_mat* m, const uint8_t* row_mask, const uint8_t* col_mask, srx_mat** out) {
+    SRX_TRY(subset_device(m, row_mask, col_mask, out));
+    (*out)->csc = m->csc;
+    return SRX_OK;
+}
+
 int32_t srx_subset(srx_mat* m, const uint8_t* row_mask, const uint8_t* col_mask, srx_mat** out) {
     if (!m || !out) return fail(m ? m->ctx : nullptr, SRX_E_ARG, "null argument");
     *out = nullptr;
-    return subset_device(m, row_mask, col_mask, out);
+    return m->csc ? subset_stored(m, col_mask, row_mask, out) : subset_stored(m, row_mask, col_mask, out);
 }
 
-int32_t srx_filter_cells(srx_mat* m, srx_flex lower, srx_flex upper, srx_mat** out, uint8_t* mask_out) {
-    if (!m || !out) return fail(m ? m->ctx : nullptr, SRX_E_ARG, "null argument");
-    *out = nullptr;
+// filter along the stored rows / the stored columns; cells are the rows of a CSR matrix and the columns of a CSC one
+static int32_t filter_stored_rows(srx_mat* m, srx_flex lower, srx_flex upper, srx_mat** out, uint8_t* mask_out) {
     srx_ctx* ctx = m->ctx;
     SRX_HIP(ctx, hipSetDevice(ctx->device));
     const bool need_count = lower.kind == SRX_FLEX_ABSOLUTE || upper.kind == SRX_FLEX_ABSOLUTE;      // mod.rs:91-92
@@ -203,24 +209,35 @@ int32_t srx_filter_cells(srx_mat* m, srx_flex lower, srx_flex upper, srx_mat** o
     std::vector<uint8_t> mask;
     SRX_TRY(filter_mask(ctx, m->n_rows, need_count ? &counts : nullptr, sums, lower, upper, mask));
     if (mask_out) memcpy(mask_out, mask.data(), mask.size());
-    return subset_device(m, mask.data(), nullptr, out);
+    return subset_stored(m, mask.data(), nullptr, out);
+}
+
+static int32_t filter_stored_cols(srx_mat* m, srx_flex lower, srx_flex upper, srx_mat** out, uint8_t* mask_out) {
+    srx_ctx* ctx = m->ctx;
+    SRX_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t G = m->n_cols;
+    std::vector<uint32_t> counts(G);
+    std::vector<double> sums(G);
+    // one column pass (the cached moments): counts AND sums; eff_dir() maps the stored Column to the caller's direction
+    const int32_t col = m->csc ? SRX_ROW : SRX_COLUMN;
+    SRX_TRY(srx_compute_number(m, col, counts.data()));
+    SRX_TRY(srx_compute_sum(m, col, sums.data()));
+    std::vector<uint8_t> mask;
+    SRX_TRY(filter_mask(ctx, G, &counts, sums, lower, upper, mask));
+    if (mask_out) memcpy(mask_out, mask.data(), mask.size());
+    return subset_stored(m, nullptr, mask.data(), out);
+}
+
+int32_t srx_filter_cells(srx_mat* m, srx_flex lower, srx_flex upper, srx_mat** out, uint8_t* mask_out) {
+    if (!m || !out) return fail(m ? m->ctx : nullptr, SRX_E_ARG, "null argument");
+    *out = nullptr;
+    return m->csc ? filter_stored_cols(m, lower, upper, out, mask_out) : filter_stored_rows(m, lower, upper, out, mask_out);
 }
 
 int32_t srx_filter_genes(srx_mat* m, srx_flex lower, srx_flex upper, srx_mat** out, uint8_t* mask_out) {
     if (!m || !out) return fail(m ? m->ctx : nullptr, SRX_E_ARG, "null argument");
     *out = nullptr;
-    srx_ctx* ctx = m->ctx;
-    SRX_HIP(ctx, hipSetDevice(ctx->device));
-    const uint64_t G = m->n_cols;
-    std::vector<uint64_t> cnt(G);
-    std::vector<double> sums(G);
-    SRX_TRY(srx_gene_moments(m, cnt.data(), sums.data(), nullptr));      // one column pass: counts AND sums
-    std::vector<uint32_t> counts(G);
-    for (uint64_t j = 0; j < G; ++j) counts[j] = (uint32_t)cnt[j];
-    std::vector<uint8_t> mask;
-    SRX_TRY(filter_mask(ctx, G, &counts, sums, lower, upper, mask));
-    if (mask_out) memcpy(mask_out, mask.data(), mask.size());
-    return subset_device(m, nullptr, mask.data(), out);
+    return m->csc ? filter_stored_rows(m, lower, upper, out, mask_out) : filter_stored_cols(m, lower, upper, out, mask_out);
 }
 
 int32_t srx_matrix_download_pattern(srx_mat* m, uint64_t* indptr_out, uint64_t* indices_out) {

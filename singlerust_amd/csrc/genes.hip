@@ -659,8 +659,8 @@ using namespace srx;
 
 extern "C" {
 
-int32_t srx_gene_moments(srx_mat* m, uint64_t* cnt, double* sum, double* sumsq) {
-    if (!m) return fail(nullptr, SRX_E_ARG, "null matrix");
+// per-column moments of the STORED matrix (for a CSC matrix: per cell)
+static int32_t stored_col_moments(srx_mat* m, uint64_t* cnt, double* sum, double* sumsq) {
     SRX_TRY(ensure_moments(m));
     const uint64_t G = m->n_cols;
     if (cnt) SRX_TRY(d2h(m->ctx, cnt, m->d_cnt, G * sizeof(uint64_t)));
@@ -669,13 +669,20 @@ int32_t srx_gene_moments(srx_mat* m, uint64_t* cnt, double* sum, double* sumsq) 
     return SRX_OK;
 }
 
+int32_t srx_gene_moments(srx_mat* m, uint64_t* cnt, double* sum, double* sumsq) {
+    if (!m) return fail(nullptr, SRX_E_ARG, "null matrix");
+    if (m->csc) return fail(m->ctx, SRX_E_FORMAT, "srx_gene_moments walks cells: convert the CSC matrix with srx_matrix_to_csr");
+    return stored_col_moments(m, cnt, sum, sumsq);
+}
+
 int32_t srx_compute_number(srx_mat* m, int32_t direction, uint32_t* out) {
     if (!m || !out) return fail(m ? m->ctx : nullptr, SRX_E_ARG, "null argument");
     SRX_HIP(m->ctx, hipSetDevice(m->ctx->device));
+    direction = eff_dir(m, direction);           // CSC: csc.rs:15-35 is csr.rs:16-38 with the directions exchanged
     if (direction == SRX_ROW) return row_number(m, out);
     if (direction != SRX_COLUMN) return fail(m->ctx, SRX_E_ARG, "bad direction %d", direction);
     std::vector<uint64_t> cnt(m->n_cols);
-    SRX_TRY(srx_gene_moments(m, cnt.data(), nullptr, nullptr));
+    SRX_TRY(stored_col_moments(m, cnt.data(), nullptr, nullptr));
     for (uint64_t j = 0; j < m->n_cols; ++j) out[j] = (uint32_t)cnt[j];   // reference counts in u32
     return SRX_OK;
 }
@@ -683,14 +690,16 @@ int32_t srx_compute_number(srx_mat* m, int32_t direction, uint32_t* out) {
 int32_t srx_compute_sum(srx_mat* m, int32_t direction, double* out) {
     if (!m || !out) return fail(m ? m->ctx : nullptr, SRX_E_ARG, "null argument");
     SRX_HIP(m->ctx, hipSetDevice(m->ctx->device));
+    direction = eff_dir(m, direction);           // csc.rs:71-95
     if (direction == SRX_ROW) return row_stat(m, 0, out, nullptr);
     if (direction != SRX_COLUMN) return fail(m->ctx, SRX_E_ARG, "bad direction %d", direction);
-    return srx_gene_moments(m, nullptr, out, nullptr);
+    return stored_col_moments(m, nullptr, out, nullptr);
 }
 
 int32_t srx_compute_variance(srx_mat* m, int32_t direction, double* out) {
     if (!m || !out) return fail(m ? m->ctx : nullptr, SRX_E_ARG, "null argument");
     SRX_HIP(m->ctx, hipSetDevice(m->ctx->device));
+    direction = eff_dir(m, direction);           // csc.rs:138-180: naive + guard on the scattered axis, two-pass on the major one
     if (direction == SRX_ROW) return row_stat(m, 1, out, nullptr);
     if (direction != SRX_COLUMN) return fail(m->ctx, SRX_E_ARG, "bad direction %d", direction);
     std::vector<double> var;
@@ -701,7 +710,7 @@ int32_t srx_compute_variance(srx_mat* m, int32_t direction, double* out) {
 
 int32_t srx_compute_std_dev(srx_mat* m, int32_t direction, double* out) {
     SRX_TRY(srx_compute_variance(m, direction, out));
-    uint64_t n = direction == SRX_ROW ? m->n_rows : m->n_cols;
+    uint64_t n = eff_dir(m, direction) == SRX_ROW ? m->n_rows : m->n_cols;
     for (uint64_t i = 0; i < n; ++i) out[i] = std::sqrt(out[i]);   // csr.rs:227
     return SRX_OK;
 }
@@ -712,6 +721,12 @@ int32_t srx_compute_qc_variables(srx_mat* m, uint32_t* num_per_cell, uint32_t* n
     if (!m) return fail(nullptr, SRX_E_ARG, "null matrix");
     srx_ctx* ctx = m->ctx;
     SRX_HIP(ctx, hipSetDevice(ctx->device));
+    if (m->csc) {                                // stored rows are genes: exchange the roles of the outputs
+        std::swap(num_per_cell, num_per_gene);
+        std::swap(expr_per_cell, expr_per_gene);
+        std::swap(variance_per_cell, variance_per_gene);
+        std::swap(std_dev_per_cell, std_dev_per_gene);
+    }
     // per cell: ONE row pass
     if (num_per_cell || expr_per_cell || variance_per_cell || std_dev_per_cell) {
         std::vector<double> var;
@@ -743,6 +758,7 @@ int32_t srx_compute_min_max(srx_mat* m, int32_t direction, double* mn, double* m
     if (!m || !mn || !mx) return fail(m ? m->ctx : nullptr, SRX_E_ARG, "null argument");
     srx_ctx* ctx = m->ctx;
     SRX_HIP(ctx, hipSetDevice(ctx->device));
+    direction = eff_dir(m, direction);           // csc.rs:186-212
     if (direction == SRX_ROW) return row_stat(m, 2, mn, mx);
     if (direction != SRX_COLUMN) return fail(ctx, SRX_E_ARG, "bad direction %d", direction);
     SRX_TRY(ensure_tiles(m));
@@ -776,6 +792,7 @@ int32_t srx_normalize_total_inplace(srx_mat* m, double target_sum, int32_t direc
     if (!m) return fail(nullptr, SRX_E_ARG, "null matrix");
     srx_ctx* ctx = m->ctx;
     SRX_HIP(ctx, hipSetDevice(ctx->device));
+    direction = eff_dir(m, direction);           // scale_row_csc / scale_col_csc, scale/mod.rs:25-57,104-139
     if (direction == SRX_ROW) return launch_normalize(m, target_sum, true, false);
     if (direction != SRX_COLUMN) return fail(ctx, SRX_E_ARG, "bad direction %d", direction);
     SRX_TRY(ensure_moments(m));
@@ -798,7 +815,12 @@ int32_t srx_select_hvg(srx_mat* m, uint64_t n, uint64_t* idx_out, uint64_t* n_ou
     if (!m || !n_out) return fail(m ? m->ctx : nullptr, SRX_E_ARG, "null argument");
     SRX_HIP(m->ctx, hipSetDevice(m->ctx->device));
     std::vector<double> var;
-    SRX_TRY(gene_variances(m, var));
+    if (m->csc) {                                // compute_variance(Column) of a CSC matrix: csc.rs:164-177 (NaN for an empty gene)
+        var.resize(m->n_rows);
+        SRX_TRY(row_stat(m, 1, var.data(), nullptr));
+    } else {
+        SRX_TRY(gene_variances(m, var));
+    }
     std::vector<uint64_t> sel;
     SRX_TRY(select_hvg_host(m->ctx, var, n, sel));
     if (idx_out) memcpy(idx_out, sel.data(), sel.size() * sizeof(uint64_t));

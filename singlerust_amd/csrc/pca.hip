@@ -2200,6 +2200,17 @@ static int32_t prepare_host_selection(srx_mat* m, const std::vector<uint64_t>& s
 static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const srx_pca_opts* opts, uint64_t hvg_n = 0) {
     srx_ctx* ctx = m->ctx;
     SRX_HIP(ctx, hipSetDevice(ctx->device));
+    if (m->csc) {
+        // compaction, Gram and SpMM walk cells: solve on the CSR of X (device transpose, csc.hip) and hand the
+        // result to the CSC handle (convert_to_array_f64_csc_selected, src/shared/mod.rs:261-290, builds the same
+        // dense matrix from either storage)
+        srx_mat* t = nullptr;
+        SRX_TRY(transpose_device(m, &t));
+        const int32_t rc = pca_device(t, sel, k64, opts, hvg_n);
+        std::swap(m->pca, t->pca);
+        srx_matrix_free(t);
+        return rc;
+    }
     srx_pca_state& st = m->pca;
     st.valid = false;
     const uint64_t G = m->n_cols;
@@ -2327,7 +2338,7 @@ int32_t srx_result_fetch(srx_mat* m, double* scores, double* components, double*
     SRX_HIP(ctx, hipSetDevice(ctx->device));
     if (components || evr || mean || std_ || hvg_idx) SRX_TRY(pca_materialize(m));
     const srx_pca_state& st = m->pca;
-    if (scores) SRX_TRY(d2h(ctx, scores, st.d_scores, m->n_rows * (size_t)st.n_pc * 8));
+    if (scores) SRX_TRY(d2h(ctx, scores, st.d_scores, (m->csc ? m->n_cols : m->n_rows) * (size_t)st.n_pc * 8));
     if (components) memcpy(components, st.components.data(), st.components.size() * 8);
     if (evr) memcpy(evr, st.evr.data(), st.evr.size() * 8);
     if (mean) memcpy(mean, st.mean.data(), st.mean.size() * 8);
@@ -2353,6 +2364,7 @@ int32_t srx_spmm(srx_mat* m, const uint64_t* sel, uint64_t k64, const double* pa
                  double* gram_out) {
     if (!m || !sel) return fail(m ? m->ctx : nullptr, SRX_E_ARG, "null argument");
     if ((y_out || t_out) && !panel) return fail(m->ctx, SRX_E_ARG, "srx_spmm: panel is required for y/t");
+    if (m->csc) return fail(m->ctx, SRX_E_FORMAT, "srx_spmm walks cells: convert the CSC matrix with srx_matrix_to_csr");
     srx_ctx* ctx = m->ctx;
     SRX_HIP(ctx, hipSetDevice(ctx->device));
     const int k = (int)k64;
@@ -2437,18 +2449,23 @@ int32_t srx_pipeline(srx_mat* m, double target_sum, uint64_t n_hvg, const srx_pc
     auto cleanup = [&]() { for (auto& e : ev) (void)hipEventDestroy(e); };
     int32_t rc = SRX_OK;
     (void)hipEventRecord(ev[0], ctx->stream);
-    // normalize_total_inplace(target, Row) + log1p_transform_inplace, fused
-    rc = launch_normalize(m, target_sum, true, true);
+    // normalize_total_inplace(target, Row) + log1p_transform_inplace, fused (CSC: the two calls, cells are columns)
+    rc = m->csc ? srx_normalize_log1p_inplace(m, target_sum, nullptr) : launch_normalize(m, target_sum, true, true);
     (void)hipEventRecord(ev[1], ctx->stream);
     // per-gene moments of the transformed values (one pass, all-reduced across shards)
-    if (rc == SRX_OK) rc = ensure_moments(m);
+    if (rc == SRX_OK && !m->csc) rc = ensure_moments(m);
     (void)hipEventRecord(ev[2], ctx->stream);
     // FeatureSelection::HighlyVariable(n_hvg): on the device, inside pca_device (the selection is fetched with the
     // other results once the solve is over); the host route only for shapes the device kernels do not take
     std::vector<uint64_t> sel;
     const uint64_t take = n_hvg < m->n_cols ? n_hvg : m->n_cols;
-    const bool dev_sel = n_hvg > 0 && take <= (uint64_t)kWave * KG && m->n_cols <= 65536;
-    if (rc == SRX_OK && !dev_sel) {
+    const bool dev_sel = !m->csc && n_hvg > 0 && take <= (uint64_t)kWave * KG && m->n_cols <= 65536;
+    if (rc == SRX_OK && m->csc) {                 // HighlyVariable(n) with the CSC variance (csc.rs:164-177)
+        uint64_t n_out = 0;
+        sel.resize(n_hvg < m->n_rows ? n_hvg : m->n_rows);
+        rc = srx_select_hvg(m, n_hvg, sel.data(), &n_out);
+        sel.resize(rc == SRX_OK ? n_out : 0);
+    } else if (rc == SRX_OK && !dev_sel) {
         std::vector<double> var;
         rc = gene_variances(m, var);
         if (rc == SRX_OK) rc = select_hvg_host(ctx, var, n_hvg, sel);

@@ -322,6 +322,11 @@ int32_t srx_log1p_inplace(srx_mat* m) {
 
 int32_t srx_normalize_log1p_inplace(srx_mat* m, double target_sum, double* row_sums_out) {
     if (!m) return fail(nullptr, SRX_E_ARG, "null matrix");
+    if (m->csc) {                                // cells are the stored columns: the two reference calls, one after the other
+        if (row_sums_out) SRX_TRY(srx_compute_sum(m, SRX_ROW, row_sums_out));
+        SRX_TRY(srx_normalize_total_inplace(m, target_sum, SRX_ROW));
+        return srx_log1p_inplace(m);
+    }
     SRX_TRY(launch_normalize(m, target_sum, true, true));
     if (row_sums_out) SRX_TRY(d2h(m->ctx, row_sums_out, m->d_row_sum, m->n_rows * sizeof(double)));
     return SRX_OK;

@@ -61,6 +61,12 @@ struct CsrMatrix {
     std::vector<std::uint64_t> row_offsets, col_indices;
     std::vector<T> values;
 };
+template <typename T>
+struct CscMatrix {                                               // nalgebra_sparse::CscMatrix<T>
+    std::size_t nrows = 0, ncols = 0;
+    std::vector<std::uint64_t> col_offsets, row_indices;
+    std::vector<T> values;
+};
 template <typename T> struct DTypeOf;
 template <> struct DTypeOf<std::int8_t> { static constexpr int v = SRX_I8; };
 template <> struct DTypeOf<std::int16_t> { static constexpr int v = SRX_I16; };
@@ -110,6 +116,25 @@ public:
         a.obs_names_ = std::move(obs_names);
         a.var_names_ = std::move(var_names);
         return a;
+    }
+    // X as ArrayData::CscMatrix: same entry points, the reference's CSC arithmetic (helper/csc.rs, scale_*_csc)
+    template <typename T>
+    static IMAnnData new_basic(Context& ctx, const CscMatrix<T>& x, std::vector<std::string> obs_names,
+                               std::vector<std::string> var_names, int store = SRX_STORE_AUTO) {
+        IMAnnData a(ctx);
+        srx_csr h{x.nrows, x.ncols, x.values.size(), x.col_offsets.data(), x.row_indices.data(),
+                  const_cast<T*>(x.values.data()), DTypeOf<T>::v};
+        ctx.check(srx_matrix_upload_csc(ctx.handle(), &h, store, &a.x_));
+        a.row_offsets_ = x.col_offsets;
+        a.col_indices_ = x.row_indices;
+        a.obs_names_ = std::move(obs_names);
+        a.var_names_ = std::move(var_names);
+        return a;
+    }
+    bool x_is_csc() const {
+        int32_t f = 0;
+        ctx_->check(srx_matrix_format(x_, &f));
+        return f == SRX_FORMAT_CSC;
     }
     IMAnnData(IMAnnData&& o) noexcept : ctx_(o.ctx_) { *this = std::move(o); }
     IMAnnData& operator=(IMAnnData&& o) noexcept {

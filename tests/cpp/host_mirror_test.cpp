@@ -192,6 +192,43 @@ static void test_backed(Context& ctx) {
     }
 }
 
+// ArrayData::CscMatrix: the same X as CSR and as CSC gives the same statistics and the same normalised row sums
+static void test_csc(Context& ctx) {
+    auto x = create_large_test_data(300, 40, 10.0, 29);
+    CscMatrix<double> c;
+    c.nrows = x.nrows;
+    c.ncols = x.ncols;
+    std::vector<std::vector<std::pair<std::uint64_t, double>>> cols(x.ncols);
+    for (std::size_t r = 0; r < x.nrows; ++r)
+        for (auto p = x.row_offsets[r]; p < x.row_offsets[r + 1]; ++p) cols[x.col_indices[p]].push_back({r, x.values[p]});
+    c.col_offsets.push_back(0);
+    for (auto& col : cols) {
+        for (auto& e : col) {
+            c.row_indices.push_back(e.first);
+            c.values.push_back(e.second);
+        }
+        c.col_offsets.push_back(c.row_indices.size());
+    }
+    IMAnnData a_csr = IMAnnData::new_basic(ctx, x, names("obs", 300), names("var", 40));
+    IMAnnData a_csc = IMAnnData::new_basic(ctx, c, names("obs", 300), names("var", 40));
+    EXPECT(a_csc.x_is_csc() && !a_csr.x_is_csc(), "storage format flags");
+    EXPECT(a_csc.n_obs() == 300 && a_csc.n_vars() == 40, "CSC shape %zu x %zu", a_csc.n_obs(), a_csc.n_vars());
+    for (Direction d : {Direction::Row, Direction::Column}) {
+        EXPECT(stats::compute_number(a_csc, d) == stats::compute_number(a_csr, d), "compute_number CSC vs CSR");
+        auto s1 = stats::compute_sum(a_csc, d), s0 = stats::compute_sum(a_csr, d);
+        for (std::size_t i = 0; i < s0.size(); ++i)
+            EXPECT(std::fabs(s1[i] - s0[i]) <= 1e-12 * std::fabs(s0[i]), "compute_sum CSC vs CSR at %zu", i);
+    }
+    proc::normalize_total_inplace(a_csc, 1e4, Direction::Row);          // scale_row_csc
+    auto sums = stats::compute_sum(a_csc, Direction::Row);
+    auto num = stats::compute_number(a_csc, Direction::Row);
+    for (std::size_t i = 0; i < sums.size(); ++i)
+        if (num[i]) EXPECT(std::fabs(sums[i] - 1e4) < 1e-6, "CSC row %zu sums to %.12g after normalize_total", i, sums[i]);
+    proc::log1p_transform_inplace(a_csc);
+    auto info = proc::dim_red::pca_inplace(a_csc, 5, {}, {}, {}, FeatureSelection::None());
+    EXPECT(info.n_pc == 5 && a_csc.obsm().at("X_pca").nrows == 300, "PCA from a CSC matrix");
+}
+
 static void test_errors(Context& ctx) {
     auto x = create_large_test_data(4, 6, 2.0, 3);
     IMAnnData tiny = IMAnnData::new_basic(ctx, x, names("obs", 4), names("var", 6));
@@ -211,6 +248,7 @@ int main() {
         test_path_end_to_end(ctx);
         test_filters(ctx);
         test_backed(ctx);
+        test_csc(ctx);
         test_errors(ctx);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "exception: %s\n", e.what());

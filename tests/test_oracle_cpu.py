@@ -193,3 +193,34 @@ def test_backed_oracle_chunked_equals_whole_and_flat_store_roundtrip(tmp_path):
         assert int(chunk.indptr[0]) == lo                  # a window of the row offsets, not rebased
         seen = end
     assert seen == 300
+
+
+def test_csc_oracle_is_the_csr_oracle_of_the_transpose():
+    """oracle/csc_oracle.py restates helper/csc.rs loop by loop; the product holds a CSC matrix as the CSR of X^T and
+    exchanges the direction.  That identity is pinned here on the two restatements: bit-identical number / sum /
+    variance / min-max (same accumulation orders), including NaN for an empty column (csc.rs:164-177 == csr.rs:158-171
+    on the transpose) and 0 for an empty row."""
+    import scipy.sparse as sp
+    from oracle import csc_oracle
+    rng = np.random.default_rng(0)
+    x = sp.random(200, 60, density=0.1, random_state=1, format="lil", data_rvs=lambda s: rng.uniform(0, 50, s))
+    x[:, 7] = 0
+    x[11, :] = 0
+    x = x.tocsc()
+    x.eliminate_zeros()
+    x.sort_indices()
+    m = csc_oracle.Csc.from_scipy(x)
+    t = Csr(60, 200, x.indptr, x.indices, x.data)                  # the CSR arrays of X^T are the CSC arrays of X
+    for d, fd in ((ROW, COLUMN), (COLUMN, ROW)):
+        assert np.array_equal(csc_oracle.compute_number(m, d), oracle.compute_number(t, fd))
+        assert np.array_equal(csc_oracle.compute_sum(m, d), oracle.compute_sum(t, fd))
+        assert np.array_equal(csc_oracle.compute_variance(m, d), oracle.compute_variance(t, fd), equal_nan=True)
+        a, b = csc_oracle.compute_min_max(m, d), oracle.compute_min_max(t, fd)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.isnan(csc_oracle.compute_variance(m, COLUMN)[7]) and csc_oracle.compute_variance(m, ROW)[11] == 0.0
+    # normalize_total on CSC == on the CSR of the same X (the reference's test_normalize_total bar: sums == target)
+    n = csc_oracle.normalize_total(m, 1e4, ROW)
+    s = csc_oracle.compute_sum(n, ROW)
+    assert np.all(np.abs(s[s > 0] - 1e4) < 1e-6)
+    dense = csc_oracle.densify_selected(m, [3, 1, 59])
+    assert np.array_equal(dense, x.toarray()[:, [3, 1, 59]])
