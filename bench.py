@@ -89,7 +89,7 @@ def parse():
     ap.add_argument("--target-sum", type=float, default=1e4)
     ap.add_argument("--solver", type=int, default=0, help="0 auto, 1 explicit Gram, 2 matrix-free SpMM iteration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-cells", type=int, default=12000)
+    ap.add_argument("--cpu-sample-cells", type=int, default=24000)
     ap.add_argument("--max-copies-gb", type=float, default=180.0)
     return ap.parse_args()
 

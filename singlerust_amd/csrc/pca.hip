@@ -263,7 +263,12 @@ __device__ __forceinline__ SelLds stage_selection(const uint32_t* __restrict__ g
     return SelLds{lds, lds + n_words};
 }
 
-constexpr int kCompactUnroll = 4;    // 64-entry chunks of a row in flight per wave
+constexpr int kFillUnroll = 4;       // 64-entry chunks of a row in flight per wave in k_tfill
+constexpr int kCompactRows = 8;      // consecutive rows per wave visit (one 64-byte line of 8-byte per-row counters)
+// rows r0*8 .. r0*8+7 of a wave's block, then the block n_waves further on
+__device__ __forceinline__ uint64_t next_compact_row(uint64_t r, uint64_t n_waves) {
+    return ((r + 1) % kCompactRows) ? r + 1 : r + 1 + (n_waves - 1) * kCompactRows;
+}
 
 template <typename I>
 __global__ __launch_bounds__(256) void k_tcount(const int64_t* __restrict__ indptr, const I* __restrict__ idx,
@@ -281,17 +286,25 @@ __global__ __launch_bounds__(256) void k_tcount(const int64_t* __restrict__ indp
     // present in the chunk (the loop made this pass VALU-bound: 1.04 ms for 2.2 GB of indices)
     uint32_t* tcnt = reinterpret_cast<uint32_t*>(lds_raw) + 2 * n_words + (threadIdx.x / kWave) * kWave;
     tcnt[lane] = 0u;
-    for (uint64_t r = wave; r < n_rows; r += n_waves) {
+    // A wave takes kCompactRows CONSECUTIVE rows at a time: the per-(tile, row) counters of 8 neighbouring rows share
+    // a 64-byte line, so the strided stores (and k_tfill's loads of counters and pointers) merge in L1 / L2.
+    // Lane l of a chunk takes entry l (2-byte loads): consecutive entries of a row are ~1 bitmask word apart, so
+    // the 64 lookups of a chunk fall into 64 different LDS banks — 8 consecutive entries per lane (16-byte loads)
+    // were tried and cost an 8-way bank conflict per lookup.  What this pass lacked was loads in flight: with 4
+    // chunks per iteration a ~840-entry row was 4 dependent round trips to HBM; kCountUnroll chunks (1024 entries)
+    // are issued together.
+    constexpr int kCountUnroll = 16;
+    for (uint64_t r = (wave * kCompactRows); r < n_rows; r = next_compact_row(r, n_waves)) {
         const int64_t lo = indptr[r], hi = indptr[r + 1];
-        for (int64_t base = lo; base < hi; base += kCompactUnroll * kWave) {
-            int32_t g[kCompactUnroll];
+        for (int64_t base = lo; base < hi; base += kCountUnroll * kWave) {
+            int32_t g[kCountUnroll];
 #pragma unroll
-            for (int u = 0; u < kCompactUnroll; ++u) {
+            for (int u = 0; u < kCountUnroll; ++u) {
                 const int64_t p = base + u * kWave + lane;
                 g[u] = p < hi ? (int32_t)idx[p] : -1;
             }
 #pragma unroll
-            for (int u = 0; u < kCompactUnroll; ++u) {
+            for (int u = 0; u < kCountUnroll; ++u) {
                 const int col = g[u] >= 0 ? sel.column(g[u]) : -1;             // -1 for dropped entries
                 if (col >= 0) __hip_atomic_fetch_add(&tcnt[col >> 7], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
@@ -319,7 +332,7 @@ __global__ __launch_bounds__(256) void k_tfill(const int64_t* __restrict__ indpt
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
-    for (uint64_t r = wave; r < n_rows; r += n_waves) {
+    for (uint64_t r = (wave * kCompactRows); r < n_rows; r = next_compact_row(r, n_waves)) {
         const int64_t lo = indptr[r], hi = indptr[r + 1];
         // lane t: kept entries before tile t in this row (exclusive prefix over the tile counters)
         const int c_t = lane < nt128 ? (int)cnt128[(uint64_t)lane * n_rows + r] : 0;
@@ -335,15 +348,18 @@ __global__ __launch_bounds__(256) void k_tfill(const int64_t* __restrict__ indpt
         const int64_t off128 = (lane < nt128 ? tptr128[(uint64_t)lane * n_rows + r] : 0) - before128;
         const int64_t off256 = (lane < nt256 ? tptr256[(uint64_t)lane * n_rows + r] : 0) - before256;
         int rank0 = 0;                                  // kept entries of the row before this chunk
-        for (int64_t base = lo; base < hi; base += kCompactUnroll * kWave) {
-            int32_t g[kCompactUnroll];
+        // (tried and slower at c3: 16 chunks in flight, 2.42 ms — the ballots / shuffles of the masked-out tail
+        //  chunks cost more than the loads gain; parking the kept entries in LDS and writing them out per row,
+        //  2.59 ms — the value gather then waits for the whole row and the stage halves the occupancy)
+        for (int64_t base = lo; base < hi; base += kFillUnroll * kWave) {
+            int32_t g[kFillUnroll];
 #pragma unroll
-            for (int u = 0; u < kCompactUnroll; ++u) {
+            for (int u = 0; u < kFillUnroll; ++u) {
                 const int64_t p = base + u * kWave + lane;
                 g[u] = p < hi ? (int32_t)idx[p] : -1;
             }
 #pragma unroll
-            for (int u = 0; u < kCompactUnroll; ++u) {
+            for (int u = 0; u < kFillUnroll; ++u) {
                 const int64_t p = base + u * kWave + lane;
                 const int32_t c = g[u] >= 0 ? sel.column(g[u]) : -1;
                 const unsigned long long mask = __ballot(c >= 0);
