@@ -283,39 +283,52 @@ __global__ __launch_bounds__(256) void k_tcount(const int64_t* __restrict__ indp
     const int lane = lane_id();
     // per-wave tile counters in LDS (after the selection table): a kept entry is one ds_add_u32 on its
     // tile's counter — ~5 active lanes per 64-entry chunk — instead of a ballot-match loop over the tiles
-    // present in the chunk (the loop made this pass VALU-bound: 1.04 ms for 2.2 GB of indices)
-    uint32_t* tcnt = reinterpret_cast<uint32_t*>(lds_raw) + 2 * n_words + (threadIdx.x / kWave) * kWave;
-    tcnt[lane] = 0u;
-    // A wave takes kCompactRows CONSECUTIVE rows at a time: the per-(tile, row) counters of 8 neighbouring rows share
-    // a 64-byte line, so the strided stores (and k_tfill's loads of counters and pointers) merge in L1 / L2.
+    // present in the chunk (the loop made this pass VALU-bound);
+    // one 64-counter row per row of the wave's current block of kCompactRows rows
+    uint32_t* tcnt = reinterpret_cast<uint32_t*>(lds_raw) + 2 * n_words + (threadIdx.x / kWave) * (kCompactRows * kWave);
+#pragma unroll
+    for (int i = 0; i < kCompactRows; ++i) tcnt[i * kWave + lane] = 0u;
+    // A wave takes kCompactRows CONSECUTIVE rows at a time and writes their counters out together: lane (tile, row)
+    // stores 8 bytes next to its 7 neighbours, i.e. one full 64-byte line per tile — stored row by row, the 24
+    // strided 8-byte counters of a row cost ~44 bytes of HBM write each (1.39 GB written for 0.25 GB of counters).
     // Lane l of a chunk takes entry l (2-byte loads): consecutive entries of a row are ~1 bitmask word apart, so
     // the 64 lookups of a chunk fall into 64 different LDS banks — 8 consecutive entries per lane (16-byte loads)
-    // were tried and cost an 8-way bank conflict per lookup.  What this pass lacked was loads in flight: with 4
-    // chunks per iteration a ~840-entry row was 4 dependent round trips to HBM; kCountUnroll chunks (1024 entries)
-    // are issued together.
+    // were tried and cost an 8-way bank conflict per lookup.  kCountUnroll chunks (1024 entries) are issued
+    // together: with 4 a ~840-entry row was 4 dependent round trips to HBM.
     constexpr int kCountUnroll = 16;
-    for (uint64_t r = (wave * kCompactRows); r < n_rows; r = next_compact_row(r, n_waves)) {
-        const int64_t lo = indptr[r], hi = indptr[r + 1];
-        for (int64_t base = lo; base < hi; base += kCountUnroll * kWave) {
-            int32_t g[kCountUnroll];
+    for (uint64_t r0 = wave * kCompactRows; r0 < n_rows; r0 += n_waves * kCompactRows) {
+        const int nr = (int)(n_rows - r0 < (uint64_t)kCompactRows ? n_rows - r0 : kCompactRows);
+        for (int i = 0; i < nr; ++i) {
+            const int64_t lo = indptr[r0 + i], hi = indptr[r0 + i + 1];
+            uint32_t* row_cnt = tcnt + i * kWave;
+            for (int64_t base = lo; base < hi; base += kCountUnroll * kWave) {
+                int32_t g[kCountUnroll];
 #pragma unroll
-            for (int u = 0; u < kCountUnroll; ++u) {
-                const int64_t p = base + u * kWave + lane;
-                g[u] = p < hi ? (int32_t)idx[p] : -1;
-            }
+                for (int u = 0; u < kCountUnroll; ++u) {
+                    const int64_t p = base + u * kWave + lane;
+                    g[u] = p < hi ? (int32_t)idx[p] : -1;
+                }
 #pragma unroll
-            for (int u = 0; u < kCountUnroll; ++u) {
-                const int col = g[u] >= 0 ? sel.column(g[u]) : -1;             // -1 for dropped entries
-                if (col >= 0) __hip_atomic_fetch_add(&tcnt[col >> 7], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                for (int u = 0; u < kCountUnroll; ++u) {
+                    const int col = g[u] >= 0 ? sel.column(g[u]) : -1;             // -1 for dropped entries
+                    if (col >= 0) __hip_atomic_fetch_add(&row_cnt[col >> 7], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const int cnt = (int)tcnt[lane];                // lane t: kept entries of this row in tile t
-        tcnt[lane] = 0u;
+        // lane q -> (tile q / 8, row q % 8)
+        for (int q = lane; q < nt128 * kCompactRows; q += kWave) {
+            const int t = q / kCompactRows, i = q % kCompactRows;
+            if (i < nr) cnt128[(uint64_t)t * n_rows + r0 + i] = (int64_t)tcnt[i * kWave + t];
+        }
+        for (int q = lane; q < nt256 * kCompactRows; q += kWave) {
+            const int t = q / kCompactRows, i = q % kCompactRows;
+            if (i < nr) cnt256[(uint64_t)t * n_rows + r0 + i] = (int64_t)(tcnt[i * kWave + 2 * t] + tcnt[i * kWave + 2 * t + 1]);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (lane < nt128) cnt128[(uint64_t)lane * n_rows + r] = cnt;
-        const int pair = cnt + __shfl_xor(cnt, 1, kWave);      // lanes 2T and 2T+1 both hold the 256-tile count
-        if (lane < 2 * nt256 && !(lane & 1)) cnt256[(uint64_t)(lane >> 1) * n_rows + r] = pair;
+#pragma unroll
+        for (int i = 0; i < kCompactRows; ++i) tcnt[i * kWave + lane] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 }
 
@@ -1547,7 +1560,7 @@ static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words,
     SRX_TRY(scratch(ctx, "pca_t256_ptr", (n256 + 1) * sizeof(int64_t), (void**)&t256.tptr));
     const double s_i = m->d_idx16 ? 2.0 : 4.0;          // bytes per column index streamed by the two passes
     ProfScope ps(ctx, SRX_K_COMPACT, (double)m->nnz * s_i * 2.0 + (double)m->nnz * val_bytes(m) + (double)(N + 1) * 8.0 * 2.0);
-    const size_t cnt_lds = sel_lds + 256 * sizeof(uint32_t);      // + one 64-counter row per wave
+    const size_t cnt_lds = sel_lds + 4 * (size_t)kCompactRows * kWave * sizeof(uint32_t);      // + 8 x 64 counters per wave
     if (m->d_idx16)
         hipLaunchKernelGGL((k_tcount<uint16_t>), dim3(grid_rows(ctx, N, 4)), dim3(256), cnt_lds, ctx->stream, m->d_indptr,
                            (const uint16_t*)m->d_idx16, d_sel, d_sel + n_words, n_words, N, nt128, nt256, cnt128, cnt256);
