@@ -88,6 +88,8 @@ def parse():
     ap.add_argument("--npc", type=int, default=50)
     ap.add_argument("--target-sum", type=float, default=1e4)
     ap.add_argument("--solver", type=int, default=0, help="0 auto, 1 explicit Gram, 2 matrix-free SpMM iteration")
+    ap.add_argument("--storage", default="f32", choices=("f32", "f64"),
+                    help="value storage in HBM: f32 (default; exact for count data, meets the 1e-5 bar) or f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=24000)
     ap.add_argument("--max-copies-gb", type=float, default=180.0)
@@ -146,7 +148,8 @@ def main():
     # and once it is imported into this process ncclCommInitRank of the system RCCL that
     # libsrx_hip.so uses fails; nothing on the data path needs torch.  Device synchronisation goes
     # through the library (hipStreamSynchronize on the stream every kernel of the path runs on).
-    ctx = sr.Context(local_rank)
+    # SRX_BENCH_DEVICE: development override (several ranks on one GPU to exercise the N > 1 path on a 1-GPU box)
+    ctx = sr.Context(int(os.environ.get("SRX_BENCH_DEVICE", local_rank)))
     from singlerust_amd.rendezvous import StarGroup
     launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # under torch.distributed.run
     group = StarGroup(rank, world)
@@ -175,13 +178,15 @@ def main():
 
     t_gen = time.perf_counter()
     h = C.c_void_p()
-    F.check(lib.srx_synth_generate(ctx.handle, C.byref(params), row0, row1, F.F32, F.STORE_F32, C.byref(h)), ctx.handle)
+    f64 = a.storage == "f64"
+    F.check(lib.srx_synth_generate(ctx.handle, C.byref(params), row0, row1, F.F64 if f64 else F.F32,
+                                   F.STORE_F64 if f64 else F.STORE_F32, C.byref(h)), ctx.handle)
     pristine = sr.DeviceCsr(ctx, h)
     pristine.prepare()          # pattern-only row/gene-tile cuts: part of the resident layout, like indptr
     info = pristine.info()
     nnz = int(info.nnz)
     t_gen = time.perf_counter() - t_gen
-    bytes_per_copy = nnz * 8 + (cells + 1) * 8
+    bytes_per_copy = nnz * (12 if f64 else 8) + (cells + 1) * 8
     n_steps_total = a.warmup + a.steps
     max_copies = max(1, int(a.max_copies_gb * 1e9 // bytes_per_copy) - 1)
     n_copies = min(n_steps_total, max_copies)
@@ -261,10 +266,10 @@ def main():
             "metric": "cells/sec end-to-end normalise->HVG->50-PC PCA; SpMM achieved HBM GB/s vs peak",
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling,
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": a.storage, "data": "synthetic",
             "config": {
                 "workload": f"{a.config}: {cells} cells/GPU x {genes} genes, density {density}, seed {seed}; "
-                            f"normalize_total(1e4,Row)+log1p+HVG({a.hvg})+{a.npc}-PC PCA; values f32 / indices i32 in HBM",
+                            f"normalize_total(1e4,Row)+log1p+HVG({a.hvg})+{a.npc}-PC PCA; values {a.storage} / indices i32 in HBM",
                 "cells_global": n_global, "genes": genes, "nnz_per_gpu": nnz, "hvg": a.hvg, "n_pc": a.npc,
                 "panel_width": 64, "parallelism": f"row-shard x{world}",
                 "nnz_hvg_compacted_per_gpu": int(res.pca.nnz_selected),

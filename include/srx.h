@@ -95,6 +95,12 @@ const char* srx_last_error(const srx_ctx* ctx);
 #define SRX_UNIQUE_ID_BYTES 128
 int32_t srx_comm_unique_id(void* id_out_128);
 int32_t srx_comm_init(srx_ctx* ctx, int32_t n_ranks, int32_t rank, const void* id_128);
+/* Alternative to srx_comm_init for hosts that already own a transport (MPI, sockets): every
+ * cross-rank sum of the path (3G+1 doubles of moments, the packed Gram tiles or the k x 64 block,
+ * 64 x 64 blocks) is handed to `fn` as a host buffer to be summed over all ranks IN PLACE
+ * (return 0 on success).  Collective calls must be made by all ranks in the same order. */
+typedef int32_t (*srx_host_allreduce_fn)(void* user, double* buf, uint64_t count);
+int32_t srx_comm_init_host(srx_ctx* ctx, int32_t n_ranks, int32_t rank, srx_host_allreduce_fn fn, void* user);
 int32_t srx_comm_destroy(srx_ctx* ctx);
 /* Contiguous nnz-balanced row ranges: cut[r]..cut[r+1] is rank r's rows (cut has
  * n_ranks+1 entries).  Pure host helper, no GPU needed. */

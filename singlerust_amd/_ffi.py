@@ -74,6 +74,7 @@ class Flex(C.Structure):            # srx_flex: FlexValue (src/shared/mod.rs:62-
     _fields_ = [("kind", C.c_int32), ("absolute", C.c_uint32), ("relative", C.c_double)]
 
 
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_double), C.c_uint64)
 FLEX_NONE, FLEX_ABSOLUTE, FLEX_RELATIVE = 0, 1, 2
 BACKED_NORMALIZE, BACKED_LOG1P = 1, 2
 P = C.c_void_p
@@ -87,6 +88,7 @@ _SIGS = {
     "srx_last_error": (C.c_char_p, [P]),
     "srx_comm_unique_id": (C.c_int32, [P]),
     "srx_comm_init": (C.c_int32, [P, C.c_int32, C.c_int32, P]),
+    "srx_comm_init_host": (C.c_int32, [P, C.c_int32, C.c_int32, C.c_void_p, P]),
     "srx_comm_destroy": (C.c_int32, [P]),
     "srx_partition_rows": (C.c_int32, [P, C.c_uint64, C.c_int32, P]),
     "srx_matrix_upload": (C.c_int32, [P, C.POINTER(Csr), C.c_int32, C.POINTER(P)]),

@@ -110,6 +110,18 @@ class Context:
         F.check(F.lib().srx_comm_init(self._h, n_ranks, rank, buf), self._h)
         self.n_ranks, self.rank = n_ranks, rank
 
+    def comm_init_host(self, n_ranks: int, rank: int, allreduce) -> None:
+        """srx_comm_init_host: ``allreduce(np.ndarray[f64])`` sums the array over all ranks in place."""
+        def _cb(_user, buf, count):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(int(count),)))
+                return 0
+            except Exception:            # never unwind through the C frames
+                return 1
+        self._host_cb = F.HOST_ALLREDUCE_FN(_cb)      # kept alive with the context
+        F.check(F.lib().srx_comm_init_host(self._h, n_ranks, rank, C.cast(self._host_cb, C.c_void_p), None), self._h)
+        self.n_ranks, self.rank = n_ranks, rank
+
     @staticmethod
     def comm_unique_id() -> bytes:
         buf = (C.c_char * F.UNIQUE_ID_BYTES)()
@@ -205,7 +217,10 @@ class DeviceCsr:
 
     def free(self) -> None:
         if self._h:
-            F.lib().srx_matrix_free(self._h)
+            # a matrix must not outlive its context (srx_matrix_free synchronises the context's stream): once the
+            # context is closed the device memory has gone with it and only the handle is dropped
+            if getattr(self.ctx, "_h", None):
+                F.lib().srx_matrix_free(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

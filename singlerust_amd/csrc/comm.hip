@@ -58,7 +58,16 @@ static const char* rccl_err(rcclResult r) {
 }
 
 int32_t allreduce_f64(srx_ctx* ctx, double* d_buf, size_t count) {
-    if (!ctx->comm || count == 0) return SRX_OK;
+    if (count == 0) return SRX_OK;
+    if (ctx->host_allreduce) {
+        // host transport: the buffer goes down, the caller sums it over the ranks in place, it comes back
+        std::vector<double> h(count);
+        SRX_TRY(d2h(ctx, h.data(), d_buf, count * sizeof(double)));
+        const int32_t rc = ctx->host_allreduce(ctx->host_allreduce_user, h.data(), (uint64_t)count);
+        if (rc != 0) return fail(ctx, SRX_E_RCCL, "host all-reduce callback failed (%d) on %zu doubles", rc, count);
+        return h2d(ctx, d_buf, h.data(), count * sizeof(double));
+    }
+    if (!ctx->comm) return SRX_OK;
     rcclResult r = g_rccl.AllReduce(d_buf, d_buf, count, rcclFloat64, rcclSum, ctx->comm, ctx->stream);
     if (r != 0) return fail(ctx, SRX_E_RCCL, "ncclAllReduce(f64, %zu) failed: %s", count, rccl_err(r));
     return SRX_OK;
@@ -103,8 +112,21 @@ int32_t srx_comm_init(srx_ctx* ctx, int32_t n_ranks, int32_t rank, const void* i
     return SRX_OK;
 }
 
+int32_t srx_comm_init_host(srx_ctx* ctx, int32_t n_ranks, int32_t rank, srx_host_allreduce_fn fn, void* user) {
+    if (!ctx || !fn || n_ranks < 1 || rank < 0 || rank >= n_ranks)
+        return fail(ctx, SRX_E_ARG, "srx_comm_init_host: bad arguments");
+    if (ctx->comm || ctx->host_allreduce) return fail(ctx, SRX_E_ARG, "communicator already initialised");
+    ctx->n_ranks = n_ranks;
+    ctx->rank = rank;
+    ctx->host_allreduce = fn;
+    ctx->host_allreduce_user = user;
+    return SRX_OK;
+}
+
 int32_t srx_comm_destroy(srx_ctx* ctx) {
     if (!ctx) return fail(nullptr, SRX_E_ARG, "null ctx");
+    ctx->host_allreduce = nullptr;
+    ctx->host_allreduce_user = nullptr;
     if (ctx->comm && g_rccl.CommDestroy) {
         (void)hipStreamSynchronize(ctx->stream);
         g_rccl.CommDestroy(ctx->comm);

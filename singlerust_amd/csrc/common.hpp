@@ -69,6 +69,11 @@ struct srx_ctx {
     // RCCL (one process per GPU)
     ncclComm* comm = nullptr;
     int n_ranks = 1, rank = 0;
+    // caller-supplied sum over ranks (srx_comm_init_host): an application that already has a transport (MPI, its
+    // own sockets) reduces the few small f64 buffers of the path itself; also how the sharded path is tested with
+    // several ranks on ONE GPU, where RCCL refuses duplicate devices
+    srx_host_allreduce_fn host_allreduce = nullptr;
+    void* host_allreduce_user = nullptr;
     // profiling
     uint32_t prof_mask = 0;
     srx::ProfAcc prof[SRX_K_COUNT_];

@@ -410,7 +410,7 @@ int32_t ensure_moments(srx_mat* m) {
     hipLaunchKernelGGL(k_moments_unpack, dim3((unsigned)((G + 255) / 256 + 1)), dim3(256), 0, ctx->stream, packed, G,
                        m->d_cnt, m->d_sum, m->d_sq);
     SRX_HIP(ctx, hipGetLastError());
-    if (ctx->comm) {
+    if (ctx->comm || ctx->host_allreduce) {
         double ng = 0.0;
         SRX_TRY(d2h(ctx, &ng, packed + 3 * G, sizeof(double)));
         m->n_rows_global = (uint64_t)ng;

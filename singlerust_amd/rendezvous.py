@@ -106,6 +106,22 @@ class StarGroup:
         self._up.sendall(struct.pack("<d", x))
         return struct.unpack("<d", self._recv(self._up, 8))[0]
 
+    def allreduce_sum_f64(self, a) -> None:
+        """In-place sum of a contiguous float64 numpy array over all ranks (rank order: ((r0 + r1) + r2) ...)."""
+        import numpy as np
+        if self.world <= 1:
+            return
+        n = a.size * 8
+        if self.rank == 0:
+            for p in self._peers:
+                a += np.frombuffer(self._recv(p, n), dtype=np.float64)
+            data = a.tobytes()
+            for p in self._peers:
+                p.sendall(data)
+        else:
+            self._up.sendall(a.tobytes())
+            a[:] = np.frombuffer(self._recv(self._up, n), dtype=np.float64)
+
     def barrier(self) -> None:
         self.allreduce_max(0.0)
 
