@@ -211,12 +211,26 @@ int32_t srx_backed_moments(srx_backed* b, uint64_t* cnt, double* sum, double* su
     return SRX_OK;
 }
 
+static int32_t backed_select_impl(srx_backed* b, uint64_t n_hvg, const uint64_t* sel, uint64_t n_sel, const srx_pca_opts* opts,
+                                  uint64_t* sel_out, uint64_t* n_out);
+
 int32_t srx_backed_select(srx_backed* b, uint64_t n_hvg, const uint64_t* sel, uint64_t n_sel, const srx_pca_opts* opts,
                           uint64_t* sel_out, uint64_t* n_out) {
     if (!b) return fail(nullptr, SRX_E_ARG, "null session");
     srx_ctx* ctx = b->ctx;
-    if (b->phase != 0) return fail(ctx, SRX_E_ARG, "backed: the selection was already made");
+    if (b->phase != 0) return fail(ctx, SRX_E_ARG, b->phase < 0 ? "backed: the session failed during the selection; start a new one"
+                                                                 : "backed: the selection was already made");
     if (b->store < 0) return fail(ctx, SRX_E_ARG, "backed: no tile was given to the statistics sweep");
+    // the moment accumulators are all-reduced in place: a selection that fails half-way cannot be repeated
+    b->phase = -1;
+    const int32_t rc = backed_select_impl(b, n_hvg, sel, n_sel, opts, sel_out, n_out);
+    if (rc == SRX_OK) b->phase = 1;
+    return rc;
+}
+
+static int32_t backed_select_impl(srx_backed* b, uint64_t n_hvg, const uint64_t* sel, uint64_t n_sel, const srx_pca_opts* opts,
+                                  uint64_t* sel_out, uint64_t* n_out) {
+    srx_ctx* ctx = b->ctx;
     SRX_HIP(ctx, hipSetDevice(ctx->device));
     backed_release_prev(b);
     srx_mat* acc = b->acc;
@@ -255,7 +269,6 @@ int32_t srx_backed_select(srx_backed* b, uint64_t n_hvg, const uint64_t* sel, ui
     b->n_packed = (size_t)(nt128 * (nt128 + 1) / 2) * KG * KG;
     SRX_HIP(ctx, hipMalloc((void**)&b->d_gram, b->n_packed * sizeof(double)));
     SRX_HIP(ctx, hipMemsetAsync(b->d_gram, 0, b->n_packed * sizeof(double), ctx->stream));
-    b->phase = 1;
     if (n_out) *n_out = (uint64_t)k;
     if (sel_out) {
         if (b->dev_sel) {
