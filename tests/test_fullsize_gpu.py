@@ -10,32 +10,38 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-N, G, DENSITY, SEED = 1_300_000, 28_000, 0.03, 3003
+# configs[2] (the metric's configuration) and configs[4] on ONE GPU: 10M cells x 30k genes, 2 % = 6.0e9 non-zeros, 48 GB
+# of CSR resident in HBM — the maximum size of the contract, with row offsets beyond 2^32
+CONFIGS = {"c3": (1_300_000, 28_000, 0.03, 3003), "c5": (10_000_000, 30_000, 0.02, 5005)}
 
 
-@pytest.fixture(scope="module")
-def c3(ctx):
+@pytest.fixture(scope="module", params=["c3", "c5"])
+def big(request, ctx):
     import singlerust_amd as sr
     from singlerust_amd import _ffi as F
     lib = F.lib()
+    n, g, density, seed = CONFIGS[request.param]
     p = F.SynthParams()
-    lib.srx_synth_defaults(C.byref(p), SEED, N, G, DENSITY)
+    lib.srx_synth_defaults(C.byref(p), seed, n, g, density)
     h = C.c_void_p()
-    F.check(lib.srx_synth_generate(ctx.handle, C.byref(p), 0, N, F.F32, F.STORE_F32, C.byref(h)), ctx.handle)
+    F.check(lib.srx_synth_generate(ctx.handle, C.byref(p), 0, n, F.F32, F.STORE_F32, C.byref(h)), ctx.handle)
     dev = sr.DeviceCsr(ctx, h)
     a = sr.IMAnnData(dev, None, None, [], [])          # pattern stays on the device at this size
-    yield a
+    yield a, n, g, density
     dev.free()
 
 
-def test_full_size_pipeline_properties(ctx, c3):
+def test_full_size_pipeline_properties(ctx, big):
     import singlerust_amd as sr
     from singlerust_amd import _ffi as F
     from singlerust_amd.memory import statistics
     lib = F.lib()
+    c3, N, G, DENSITY = big
     info = c3.x().info()
     nnz = int(info.nnz)
     assert info.n_rows == N and info.n_cols == G and 0.9 * N * G * DENSITY < nnz < 1.1 * N * G * DENSITY
+    if N >= 10_000_000:
+        assert nnz > 2 ** 32                             # 64-bit row offsets are exercised
 
     # --- raw counts: integer work is bit-exact, and the two directions agree on every checksum ---
     n_cell, n_gene = statistics.compute_number(c3, sr.Direction.Row), statistics.compute_number(c3, sr.Direction.Column)
