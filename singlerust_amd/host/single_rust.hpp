@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <map>
 #include <optional>
+#include <random>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -42,7 +43,9 @@ struct FeatureSelection {                                        // src/shared/m
     std::string col;
     std::size_t n = 0;
     double threshold = 0.0;
+    static FeatureSelection HighlyVariableCol(std::string c) { FeatureSelection f; f.kind = HighlyVariableColK; f.col = std::move(c); return f; }
     static FeatureSelection HighlyVariable(std::size_t n) { FeatureSelection f; f.kind = HighlyVariableK; f.n = n; return f; }
+    static FeatureSelection Randomized(std::size_t n) { FeatureSelection f; f.kind = RandomizedK; f.n = n; return f; }
     static FeatureSelection VarianceThreshold(double t) { FeatureSelection f; f.kind = VarianceThresholdK; f.threshold = t; return f; }
     static FeatureSelection None() { return FeatureSelection(); }
 };
@@ -145,6 +148,7 @@ public:
         var_names_ = std::move(o.var_names_);
         obsm_ = std::move(o.obsm_);
         varm_ = std::move(o.varm_);
+        var_bool_ = std::move(o.var_bool_);
         return *this;
     }
     ~IMAnnData() { srx_matrix_free(x_); }
@@ -180,6 +184,7 @@ public:
         c.var_names_ = var_names_;
         c.obsm_ = obsm_;
         c.varm_ = varm_;
+        c.var_bool_ = var_bool_;
         return c;
     }
     // a matrix the library produced (filter / subset): the host copy of the pattern is downloaded
@@ -197,6 +202,9 @@ public:
     }
     const std::vector<std::string>& obs_names() const { return obs_names_; }
     const std::vector<std::string>& var_names() const { return var_names_; }
+    // boolean columns of the `var` DataFrame (what FeatureSelection::HighlyVariableCol reads)
+    std::map<std::string, std::vector<bool>>& var_bool() { return var_bool_; }
+    const std::map<std::string, std::vector<bool>>& var_bool() const { return var_bool_; }
     std::map<std::string, Array2>& obsm() { return obsm_; }
     std::map<std::string, Array2>& varm() { return varm_; }
 
@@ -207,6 +215,7 @@ private:
     std::vector<std::uint64_t> row_offsets_, col_indices_;
     std::vector<std::string> obs_names_, var_names_;
     std::map<std::string, Array2> obsm_, varm_;
+    std::map<std::string, std::vector<bool>> var_bool_;
 };
 
 namespace memory {
@@ -315,8 +324,25 @@ inline std::vector<std::uint64_t> select_features(const IMAnnData& a, const Feat
             for (std::size_t i = 0; i < idx.size(); ++i) idx[i] = i;
             return idx;
         }
-        default: throw Error(SRX_E_ARG, "this FeatureSelection arm needs the var DataFrame (host-side only)");
+        case FeatureSelection::HighlyVariableColK: {                       // :125-134: indices where the bool column is true
+            auto it = a.var_bool().find(fs.col);
+            if (it == a.var_bool().end()) throw Error(SRX_E_ARG, "Error accessing column '" + fs.col + "' : not found");
+            std::vector<std::uint64_t> idx;
+            for (std::size_t i = 0; i < it->second.size(); ++i)
+                if (it->second[i]) idx.push_back(i);
+            return idx;
+        }
+        case FeatureSelection::RandomizedK: {                              // :141-146: shuffle of 0..n_vars, first n (thread_rng)
+            std::vector<std::uint64_t> idx(a.n_vars());
+            for (std::size_t i = 0; i < idx.size(); ++i) idx[i] = i;
+            std::random_device rd;
+            std::mt19937_64 rng(rd());
+            std::shuffle(idx.begin(), idx.end(), rng);
+            idx.resize(std::min<std::size_t>(fs.n, idx.size()));
+            return idx;
+        }
     }
+    throw Error(SRX_E_ARG, "unknown FeatureSelection");
 }
 // pca_inplace(anndata, n_components, center, scale, n_threads, feature_selection, svd_mode) (:24-94);
 // svd_mode (FaerSVD / LapackSVD marker) has no counterpart.  Stores obsm["X_pca"] (:105-106).

@@ -131,6 +131,21 @@ static void test_path_end_to_end(Context& ctx) {
         EXPECT(q <= prev * (1 + 1e-9), "PC variances not descending at %zu", c);
         prev = q;
     }
+    // the remaining FeatureSelection arms (dim_red/mod.rs:125-134, 141-153)
+    {
+        std::vector<bool> flag(100, false);
+        for (std::size_t i = 0; i < hv.size(); ++i) flag[hv[i]] = true;
+        adata.var_bool()["highly_variable"] = flag;
+        auto by_col = proc::dim_red::select_features(adata, FeatureSelection::HighlyVariableCol("highly_variable"));
+        auto sorted = hv;
+        std::sort(sorted.begin(), sorted.end());
+        EXPECT(by_col == sorted, "HighlyVariableCol returns the true entries in index order");
+        auto rnd = proc::dim_red::select_features(adata, FeatureSelection::Randomized(30));
+        std::sort(rnd.begin(), rnd.end());
+        EXPECT(rnd.size() == 30 && std::adjacent_find(rnd.begin(), rnd.end()) == rnd.end() && rnd.back() < 100, "Randomized(30)");
+        auto thr = proc::dim_red::select_features(adata, FeatureSelection::VarianceThreshold(var[hv[39]]));
+        EXPECT(thr.size() == 39, "VarianceThreshold keeps the %zu genes above the 40th variance", thr.size());
+    }
     // defaults: n_components None -> 2 (dim_red/mod.rs:52)
     IMAnnData again = adata.deep_clone();
     proc::dim_red::pca_inplace(again, {}, {}, {}, {}, FeatureSelection::None());
