@@ -235,7 +235,9 @@ typedef enum srx_pca_solver {
 } srx_pca_solver;
 
 typedef struct srx_pca_opts {
-    int32_t n_components;  /* < 0 = None -> 2        (dim_red/mod.rs:52)                  */
+    int32_t n_components;  /* < 0 = None -> 2        (dim_red/mod.rs:52); any value up to k
+                              with the Gram solver (beyond 56 the solve runs in deflation
+                              rounds of 48), up to 56 with the SpMM solver                */
     int32_t center;        /* < 0 = None -> true     (:55)                                */
     int32_t scale;         /* < 0 = None -> true     (:56)                                */
     int32_t n_threads;     /* accepted, ignored on GPU (:61)                              */

@@ -98,6 +98,7 @@ struct srx_ctx {
 struct srx_pca_state {           // what the last srx_pca / srx_pipeline left in HBM
     bool valid = false;
     uint32_t k = 0, n_pc = 0;
+    uint32_t rounds = 1;             // deflation rounds of the solve (n_pc > 56: kPcaPerRound components per round)
     double* d_scores = nullptr;      // n_rows x n_pc, row-major f64
     size_t scores_cap = 0;
     std::vector<double> components;  // k x n_pc (host copy; small)
@@ -107,7 +108,7 @@ struct srx_pca_state {           // what the last srx_pca / srx_pipeline left in
     // Deferred host copies ("results stay on the device until fetched"): the solve leaves its small results in
     // `d_small` (carved from the d_scores allocation) and the host vectors above are produced by the first
     // fetch — pca_materialize() in pca.hip.  Layout in doubles:
-    //   V k*64 | theta 64 | sgn 64 | mu k | sd k | trace 1 | pad 1 | sel_rank (int32) k
+    //   rounds x [ V k*64 | theta 64 | sgn 64 ] | mu k | sd k | trace 1 | pad 1 | sel_rank (int32) k
     double* d_small = nullptr;
     bool host_pending = false;
     bool dev_sel = false;            // mu / sd / trace / selection are in d_small (else in the pend_* fields)

@@ -524,7 +524,8 @@ template <typename VT, typename PT>
 __global__ __launch_bounds__(kFwdThreads, FwdCfg<PT>::kWavesPerSimd) void k_spmm_fwd(
     const int64_t* __restrict__ tptr, const GramPk<VT>* __restrict__ tpk, uint64_t n_rows,
     int nt, int k, const PT* __restrict__ P, const PT* __restrict__ cvec, PT* __restrict__ Y,
-    double* __restrict__ scores /* nullable: n_rows x n_pc row-major f64, written INSTEAD of Y */, int n_pc) {
+    double* __restrict__ scores /* nullable: n_rows x ld row-major f64 (first n_pc panel columns), written INSTEAD of Y */,
+    int n_pc, int ld) {
     constexpr int kRows = FwdCfg<PT>::kRows;            // rows per 16-lane group
     constexpr int kRowsPerWg = (kFwdThreads / 16) * kRows;
     constexpr int kStage = FwdCfg<PT>::kStage;          // rows whose (index, value) chunks are in flight together
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(kFwdThreads, FwdCfg<PT>::kWavesPerSimd) void k_spmm
                 if (scores) {            // the transform pass: obsm["X_pca"] layout directly (dim_red/mod.rs:105-106)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (4 * q + j < n_pc) scores[row * (uint64_t)n_pc + 4 * q + j] = (double)o[j];
+                        if (4 * q + j < n_pc) scores[row * (uint64_t)ld + 4 * q + j] = (double)o[j];
                 } else {
                     o.store(Y + row * L + 4 * q);
                 }
@@ -1627,7 +1628,7 @@ static int32_t build_tiled_fused(srx_mat* m, const std::vector<int32_t>& remap, 
 // ---- launches ---------------------------------------------------------------------------------
 template <typename VT, typename PT>
 static int32_t launch_fwd(srx_ctx* ctx, const Tiled& c, const PT* P, const PT* cvec, PT* Y, double* scores = nullptr,
-                          int n_pc = 0) {
+                          int n_pc = 0, int ld = 0) {
     // the output is either the N x 64 panel product (SpMM solver) or, for the transform, the N x n_pc f64 scores
     const double out_bytes = scores ? (double)c.n_rows * n_pc * 8.0 : (double)c.n_rows * L * sizeof(PT);
     const double bytes = (double)c.nnz * (4.0 + sizeof(VT)) + (double)((uint64_t)c.nt * c.n_rows + 1) * 8.0 + out_bytes +
@@ -1643,7 +1644,7 @@ static int32_t launch_fwd(srx_ctx* ctx, const Tiled& c, const PT* P, const PT* c
     SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_spmm_fwd<VT, PT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));
     hipLaunchKernelGGL((k_spmm_fwd<VT, PT>), dim3((unsigned)grid), dim3(kFwdThreads), lds, ctx->stream, c.tptr,
-                       (const GramPk<VT>*)c.tpk, c.n_rows, c.nt, c.k, P, cvec, Y, scores, n_pc);
+                       (const GramPk<VT>*)c.tpk, c.n_rows, c.nt, c.k, P, cvec, Y, scores, n_pc, ld ? ld : n_pc);
     SRX_HIP(ctx, hipGetLastError());
     return SRX_OK;
 }
@@ -2042,6 +2043,32 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     return SRX_OK;
 }
 
+// Components per deflation round when more than L - 8 are asked of a k > L problem (the block keeps 16 guard
+// columns), and the number of rounds; the last round takes everything that is left once <= L dimensions remain.
+constexpr int kPcaPerRound = 48;
+static int pca_rounds(int k, int n_pc) {
+    if (k <= L || n_pc <= L - 8) return 1;
+    int done = 0, r = 0;
+    while (done < n_pc) {
+        done += (k - done <= L) ? n_pc - done : std::min(kPcaPerRound, n_pc - done);
+        ++r;
+    }
+    return r;
+}
+
+// C -= V diag(theta) V^T over the first n columns of V (k x 64): the resolved eigenpairs leave the operator.
+// theta_c * (v_ic * v_jc) is symmetric in (i, j) to the last bit, so C stays exactly symmetric.
+__global__ void k_deflate(double* __restrict__ C, int k, const double* __restrict__ V, const double* __restrict__ theta, int n) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (uint64_t)k * k) return;
+    const int i = (int)(e / k), j = (int)(e % k);
+    const double* vi = V + (size_t)i * L;
+    const double* vj = V + (size_t)j * L;
+    double s = 0.0;
+    for (int c = 0; c < n; ++c) s += theta[c] * (vi[c] * vj[c]);
+    C[e] -= s;
+}
+
 template <typename VT, typename PT>
 static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tiled* t128p, double* gram_packed,
                        const Resolved& o, const std::vector<double>& mu, const std::vector<double>& dinv,
@@ -2075,6 +2102,44 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
     double resid = INFINITY;
     int iters = 0;
     bool converged = false;
+    // More than 56 components (k > 64): DEFLATION ROUNDS on the explicit C.  A round resolves the next kPcaPerRound
+    // eigenpairs with the 64-column block, writes their scores, and removes them from C (C -= V diag(theta) V^T),
+    // so that the next round's dominant subspace is the one after them.  One round is the whole solve otherwise.
+    const int n_pc = o.n_pc;
+    const int rounds = pca_rounds(k, n_pc);
+    st.rounds = (uint32_t)rounds;
+    // one allocation: the scores, then the block of small results (layout: srx_pca_state::d_small)
+    const size_t score_bytes = (cc.n_rows ? cc.n_rows : 1) * (size_t)n_pc * 8;
+    const size_t small_doubles = (size_t)rounds * (kl + 2 * L) + 2 * (size_t)k + 2 + ((size_t)k + 1) / 2;
+    const size_t need = score_bytes + small_doubles * 8;
+    if (st.scores_cap < need) {
+        if (st.d_scores) SRX_HIP(ctx, hipFree(st.d_scores));
+        st.d_scores = nullptr;
+        st.scores_cap = 0;
+        SRX_HIP(ctx, hipMalloc((void**)&st.d_scores, need));
+        st.scores_cap = need;
+    }
+    double* const d_small = st.d_scores + score_bytes / 8;
+    // A2 = W U are the Ritz vectors (ascending-gene row order); sign: largest-|.| entry positive.
+    // scores = Z V (transform, pca/mod.rs:156-185): one forward SpMM per row tile with the panel D V, the f64 scores
+    // written by the SpMM itself.  The Ritz vectors, values and signs move out of the (per-context) scratch into
+    // the matrix's own block; their host copies are made by the first fetch (pca_materialize).
+    auto finish_round = [&](int r, int col0, int n_r) -> int32_t {
+        hipLaunchKernelGGL(k_signs, dim3(1), dim3(L), 0, ctx->stream, w.dColmax, w.dSgn);
+        hipLaunchKernelGGL((k_make_panel<PT>), dim3(1), dim3(1024), 0, ctx->stream, w.A2, w.d, w.mu, (const double*)w.dSgn,
+                           k, o.center, P, cvec);
+        SRX_HIP(ctx, hipGetLastError());
+        uint64_t row0 = 0;
+        for (int i = 0; i < n_parts; ++i) {
+            SRX_TRY((launch_fwd<VT, PT>(ctx, parts[i], P, cvec, Y, st.d_scores + row0 * (size_t)n_pc + col0, n_r, n_pc)));
+            row0 += parts[i].n_rows;
+        }
+        double* blk = d_small + (size_t)r * (kl + 2 * L);
+        SRX_HIP(ctx, hipMemcpyAsync(blk, w.A2, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        SRX_HIP(ctx, hipMemcpyAsync(blk + kl, w.dTheta, L * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        SRX_HIP(ctx, hipMemcpyAsync(blk + kl + L, w.dSgn, L * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        return SRX_OK;
+    };
     if (o.solver == 1) {
         // explicit Gram: G = A^T A once (all-reduced), C = D (G - c N mu mu^T) D dense
         double* C;
@@ -2094,7 +2159,31 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
             SRX_HIP(ctx, hipGetLastError());
             return SRX_OK;
         };
-        SRX_TRY(subspace_iterate(ctx, w, k, l_act, o, apply, C, true, hv ? hv->d_status : nullptr, resid, iters, converged));
+        resid = 0.0;
+        converged = true;
+        int done = 0;
+        for (int r = 0; r < rounds; ++r) {
+            Resolved o_r = o;
+            const int left_dim = k - done;                            // dimension of what is still in C
+            const int l_r = rounds == 1 ? l_act : std::min(L, left_dim);
+            o_r.n_pc = rounds == 1 ? n_pc : (left_dim <= L ? n_pc - done : std::min(kPcaPerRound, n_pc - done));
+            o_r.seed = o.seed + (uint64_t)r;
+            double resid_r = INFINITY;
+            int iters_r = 0;
+            bool conv_r = false;
+            SRX_TRY(subspace_iterate(ctx, w, k, l_r, o_r, apply, C, true, hv ? hv->d_status : nullptr, resid_r, iters_r, conv_r));
+            SRX_TRY(finish_round(r, done, o_r.n_pc));
+            resid = std::max(resid, resid_r);
+            iters += iters_r + o.warm;
+            converged = converged && conv_r;
+            done += o_r.n_pc;
+            if (r + 1 < rounds) {
+                hipLaunchKernelGGL(k_deflate, dim3((unsigned)(((size_t)k * k + 255) / 256)), dim3(256), 0, ctx->stream, C, k,
+                                   (const double*)w.A2, (const double*)w.dTheta, o_r.n_pc);
+                SRX_HIP(ctx, hipGetLastError());
+            }
+        }
+        iters -= o.warm;                                              // st.info adds it back once below
     } else {
         if (n_parts != 1) return fail(ctx, SRX_E_ARG, "pca: the SpMM solver needs the matrix resident in one piece");
         auto apply = [&](const double* Win, double* Wout) -> int32_t {
@@ -2111,40 +2200,9 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
         };
         SRX_TRY(subspace_iterate(ctx, w, k, l_act, o, apply, nullptr, false, hv ? hv->d_status : nullptr, resid, iters,
                                  converged));
+        SRX_TRY(finish_round(0, 0, n_pc));
     }
-
-    // A2 = W U are the Ritz vectors (ascending-gene row order); sign: largest-|.| entry positive.
-    // scores = Z V (transform, pca/mod.rs:156-185): one forward SpMM with the panel D V.  Everything is
-    // enqueued first; the host copies of (theta, signs, V) are read afterwards, behind the kernels.
-    const int n_pc = o.n_pc;
-    hipLaunchKernelGGL(k_signs, dim3(1), dim3(L), 0, ctx->stream, w.dColmax, w.dSgn);
-    hipLaunchKernelGGL((k_make_panel<PT>), dim3(1), dim3(1024), 0, ctx->stream, w.A2, w.d, w.mu, (const double*)w.dSgn, k,
-                       o.center, P, cvec);
-    SRX_HIP(ctx, hipGetLastError());
-    // one allocation: the scores, then the block of small results (layout: srx_pca_state::d_small)
-    const size_t score_bytes = (cc.n_rows ? cc.n_rows : 1) * (size_t)n_pc * 8;
-    const size_t small_doubles = kl + 2 * L + 2 * (size_t)k + 2 + ((size_t)k + 1) / 2;
-    const size_t need = score_bytes + small_doubles * 8;
-    if (st.scores_cap < need) {
-        if (st.d_scores) SRX_HIP(ctx, hipFree(st.d_scores));
-        st.d_scores = nullptr;
-        st.scores_cap = 0;
-        SRX_HIP(ctx, hipMalloc((void**)&st.d_scores, need));
-        st.scores_cap = need;
-    }
-    st.d_small = st.d_scores + score_bytes / 8;
-    {
-        uint64_t row0 = 0;                                           // f64 scores written by the SpMM itself
-        for (int i = 0; i < n_parts; ++i) {
-            SRX_TRY((launch_fwd<VT, PT>(ctx, parts[i], P, cvec, Y, st.d_scores + row0 * (size_t)n_pc, n_pc)));
-            row0 += parts[i].n_rows;
-        }
-    }
-    // the Ritz vectors, values and signs move out of the (per-context) scratch into the matrix's own block;
-    // their host copies are made by the first fetch (pca_materialize)
-    SRX_HIP(ctx, hipMemcpyAsync(st.d_small, w.A2, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    SRX_HIP(ctx, hipMemcpyAsync(st.d_small + kl, w.dTheta, L * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    SRX_HIP(ctx, hipMemcpyAsync(st.d_small + kl + L, w.dSgn, L * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    st.d_small = d_small;
     st.info.n_iter = (uint32_t)(iters + o.warm);
     st.info.residual = resid;
     if (!converged)
@@ -2176,9 +2234,12 @@ static int32_t resolve_opts(srx_ctx* ctx, const srx_pca_opts* opts, int k, uint6
     if (o.n_pc < 1) return fail(ctx, SRX_E_ARG, "pca: n_components must be >= 1");
     if (opts && opts->block != 0 && opts->block != L) return fail(ctx, SRX_E_ARG, "pca: only block = %d is built", L);
     l_act = std::min(L, k);
-    if (o.n_pc > l_act || (k > L && o.n_pc > L - 8))
-        return fail(ctx, SRX_E_ARG, "pca: n_components %d exceeds what the %d-column block resolves (max %d)", o.n_pc, L,
-                    k > L ? L - 8 : l_act);
+    if (o.n_pc > l_act && o.solver != 1)
+        return fail(ctx, SRX_E_ARG, "pca: n_components %d exceeds what the %d-column block resolves (max %d)", o.n_pc, L, l_act);
+    // beyond L - 8 components the Gram solver runs deflation rounds on the explicit k x k matrix; the matrix-free
+    // solver has nothing to deflate
+    if (k > L && o.n_pc > L - 8 && o.solver != 1)
+        return fail(ctx, SRX_E_ARG, "pca: n_components %d > %d needs the Gram solver (k <= 16384, opts.solver = 1)", o.n_pc, L - 8);
     return SRX_OK;
 }
 
@@ -2188,13 +2249,13 @@ static int32_t stash_results(srx_ctx* ctx, srx_pca_state& st, int k, int n_pc, c
                              const std::vector<uint64_t>& selv) {
     // Everything the host side of the result needs stays on the device until the first fetch.
     const size_t kl = (size_t)k * L;
-    double* sm = st.d_small;
+    double* sm = st.d_small + (size_t)st.rounds * (kl + 2 * L);      // behind the per-round blocks
     st.dev_sel = hv != nullptr;
     if (hv) {
-        SRX_HIP(ctx, hipMemcpyAsync(sm + kl + 2 * L, hv->d_mu, (size_t)k * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        SRX_HIP(ctx, hipMemcpyAsync(sm + kl + 2 * L + k, hv->d_sd, (size_t)k * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        SRX_HIP(ctx, hipMemcpyAsync(sm + kl + 2 * L + 2 * (size_t)k, hv->d_trace, 8, hipMemcpyDeviceToDevice, ctx->stream));
-        SRX_HIP(ctx, hipMemcpyAsync(sm + kl + 2 * L + 2 * (size_t)k + 2, hv->d_sel_rank, (size_t)k * sizeof(int32_t),
+        SRX_HIP(ctx, hipMemcpyAsync(sm, hv->d_mu, (size_t)k * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        SRX_HIP(ctx, hipMemcpyAsync(sm + k, hv->d_sd, (size_t)k * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        SRX_HIP(ctx, hipMemcpyAsync(sm + 2 * (size_t)k, hv->d_trace, 8, hipMemcpyDeviceToDevice, ctx->stream));
+        SRX_HIP(ctx, hipMemcpyAsync(sm + 2 * (size_t)k + 2, hv->d_sel_rank, (size_t)k * sizeof(int32_t),
                                     hipMemcpyDeviceToDevice, ctx->stream));
         st.sel.clear();
     } else {
@@ -2342,19 +2403,27 @@ static int32_t pca_materialize(srx_mat* m) {
     srx_ctx* ctx = m->ctx;
     const int k = (int)st.k, n_pc = (int)st.n_pc;
     const size_t kl = (size_t)k * L;
-    const size_t small_doubles = kl + 2 * L + 2 * (size_t)k + 2 + ((size_t)k + 1) / 2;
+    const int rounds = (int)st.rounds;
+    const size_t rblk = kl + 2 * L;
+    const size_t small_doubles = (size_t)rounds * rblk + 2 * (size_t)k + 2 + ((size_t)k + 1) / 2;
     std::vector<double> blk(small_doubles);
     SRX_TRY(d2h(ctx, blk.data(), st.d_small, small_doubles * 8));
-    const double* hV = blk.data();
-    const double* theta = hV + kl;
-    const double* sgn = theta + L;
+    const double* tail = blk.data() + (size_t)rounds * rblk;
+    // component p lives in round p / kPcaPerRound (the last round may hold more), column p - first component of it
+    auto locate = [&](int p, const double*& hV, const double*& theta, const double*& sgn, int& c) {
+        int r = rounds == 1 ? 0 : std::min(p / kPcaPerRound, rounds - 1);
+        c = p - r * (rounds == 1 ? 0 : kPcaPerRound);
+        hV = blk.data() + (size_t)r * rblk;
+        theta = hV + kl;
+        sgn = theta + L;
+    };
     std::vector<double> mu, sd;
     double trace;
     if (st.dev_sel) {
-        mu.assign(sgn + L, sgn + L + k);
-        sd.assign(sgn + L + k, sgn + L + 2 * (size_t)k);
-        trace = sgn[L + 2 * (size_t)k];
-        const int32_t* hsel = reinterpret_cast<const int32_t*>(sgn + L + 2 * (size_t)k + 2);
+        mu.assign(tail, tail + k);
+        sd.assign(tail + k, tail + 2 * (size_t)k);
+        trace = tail[2 * (size_t)k];
+        const int32_t* hsel = reinterpret_cast<const int32_t*>(tail + 2 * (size_t)k + 2);
         st.sel.resize(k);
         for (int i = 0; i < k; ++i) st.sel[i] = (uint64_t)hsel[i];
     } else {
@@ -2372,12 +2441,22 @@ static int32_t pca_materialize(srx_mat* m) {
     st.std_.resize(k);
     for (int i = 0; i < k; ++i) {
         const int sl = slot_of_sel[i];
-        for (int p = 0; p < n_pc; ++p) st.components[(size_t)i * n_pc + p] = hV[(size_t)sl * L + p] * sgn[p];
+        for (int p = 0; p < n_pc; ++p) {
+            const double *hV, *theta, *sgn;
+            int c;
+            locate(p, hV, theta, sgn, c);
+            st.components[(size_t)i * n_pc + p] = hV[(size_t)sl * L + c] * sgn[c];
+        }
         st.mean[i] = mu[sl];
         st.std_[i] = sd[sl];
     }
     st.evr.resize(n_pc);
-    for (int p = 0; p < n_pc; ++p) st.evr[p] = trace > 0 ? theta[p] / trace : 0.0;
+    for (int p = 0; p < n_pc; ++p) {
+        const double *hV, *theta, *sgn;
+        int c;
+        locate(p, hV, theta, sgn, c);
+        st.evr[p] = trace > 0 ? theta[c] / trace : 0.0;
+    }
     st.host_pending = false;
     return SRX_OK;
 }

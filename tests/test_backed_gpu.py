@@ -116,10 +116,14 @@ def test_backed_pipeline_explicit_selection_and_errors(ctx, tmp_path):
     rng = np.random.default_rng(1)
     sel = rng.permutation(300)[:90].astype(np.uint64)
     r = backed.processing.pca_pipeline(ad, 333, 1e4, 0, 8, selected=sel)
+    r80 = backed.processing.pca_pipeline(ad, 500, 1e4, 0, 80, selected=np.arange(300, dtype=np.uint64))   # two deflation rounds over row tiles
     assert np.array_equal(r.selected, sel)
     lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
     want, wc, *_ = pca_oracle.pca_inplace(lg, 8, None, None, sel)
     assert col_err(r.x_pca, want) < TOL and col_err(r.components, wc) < TOL
+    want80, wc80, *_ = pca_oracle.pca_inplace(lg, 80, None, None, np.arange(300))
+    assert r80.x_pca.shape == (2000, 80) and np.abs(wc80 @ (wc80.T @ r80.components) - r80.components).max() < 1e-4
+    assert col_err(r80.x_pca[:, :20], want80[:, :20]) < TOL
     # FeatureSelection::None
     r2 = backed.processing.pca_pipeline(ad, 1000, 1e4, 0, 5)
     want2, wc2, *_ = pca_oracle.pca_inplace(lg, 5, None, None, np.arange(300))
