@@ -47,7 +47,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc, *FLAGS, "-c", s, "-o", o]
+            cmd = [hipcc, *FLAGS, *os.environ.get("SRX_EXTRA_FLAGS", "").split(), "-c", s, "-o", o]   # (experiments: -D switches)
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
