@@ -92,6 +92,14 @@ struct srx_ctx {
     bool graphs_off = false;                 // capture failed once (or SRX_NO_GRAPH): plain launches from then on
     bool capturing = false;                  // ProfScope and friends stay out of a capture
     double* pin_async = nullptr;             // kAsyncSlots x 4 doubles, pinned
+    // H2D workers of srx_matrix_upload / the backed sessions (ctx.hip): each owns a stream, two pinned staging
+    // buffers and two events, and moves its own contiguous share of an array
+    struct UpWorker {
+        hipStream_t stream = nullptr;
+        void* pin[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+    };
+    std::vector<UpWorker> up_workers;
     hipEvent_t async_ev[kAsyncSlots] = {nullptr, nullptr, nullptr, nullptr};
 };
 

@@ -6,6 +6,9 @@
 // (nalgebra_sparse::CsrMatrix) happens once, here.
 #include "common.hpp"
 
+#include <algorithm>
+#include <thread>
+
 namespace srx {
 
 thread_local std::string g_tls_err;
@@ -206,6 +209,90 @@ __global__ void k_rebase_indptr(int64_t* __restrict__ indptr, uint64_t n, int64_
     if (i < n) indptr[i] -= base;
 }
 
+// ---- host -> device in parallel ----------------------------------------------------------------------------
+// A pageable hipMemcpy moves ~26-31 GB/s on this box: one thread copies into the runtime's staging buffer while the
+// DMA engine waits.  Here kUpWorkers (8; SRX_UP_WORKERS) threads each take a contiguous share of the array and run their own two-buffer
+// pipeline (fill a pinned buffer — narrowing u64 indices to i32 and bounds-checking them on the way, so only half
+// the index bytes cross PCIe — then hipMemcpyAsync on the worker's stream while the other buffer is being filled).
+static const int kUpWorkers = [] {
+    const char* e = getenv("SRX_UP_WORKERS");          // tuning switch
+    const int v = e ? atoi(e) : 8;                   // 4: 40, 8: 55, 16: 39-50, 32: 33 GB/s of host data (400k x 20k matrix)
+    return v < 1 ? 1 : v > 64 ? 64 : v;
+}();
+constexpr size_t kUpChunkBytes = 4u << 20;          // per staging buffer (pinned: workers x 2 x 4 MiB)
+
+static int32_t ensure_up_workers(srx_ctx* ctx) {
+    if (!ctx->up_workers.empty()) return SRX_OK;
+    std::vector<srx_ctx::UpWorker> ws(kUpWorkers);
+    for (auto& w : ws) {
+        SRX_HIP(ctx, hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+            SRX_HIP(ctx, hipHostMalloc(&w.pin[b], kUpChunkBytes, hipHostMallocDefault));
+            SRX_HIP(ctx, hipEventCreateWithFlags(&w.ev[b], hipEventDisableTiming));
+        }
+    }
+    ctx->up_workers = std::move(ws);
+    return SRX_OK;
+}
+
+// `n` elements from host `src` to device `dst`.  narrow: src is u64[n], dst i32[n], values >= n_cols set *bad;
+// otherwise a plain copy of n * elem_bytes bytes.
+static int32_t parallel_h2d(srx_ctx* ctx, const void* src, void* dst, uint64_t n, bool narrow, size_t elem_bytes,
+                            uint64_t n_cols, bool* bad) {
+    if (n == 0) return SRX_OK;
+    SRX_TRY(ensure_up_workers(ctx));
+    const int device = ctx->device;
+    const uint64_t per_chunk = kUpChunkBytes / elem_bytes;
+    // small arrays: fewer workers (a share should be worth a thread)
+    int nw = (int)std::min<uint64_t>(kUpWorkers, (n + per_chunk - 1) / per_chunk);
+    if (nw < 1) nw = 1;
+    const uint64_t share = ((n + nw - 1) / nw + 15) & ~(uint64_t)15;
+    std::vector<hipError_t> err(nw, hipSuccess);
+    std::vector<int> oob(nw, 0);
+    auto run = [&](int t) {
+        srx_ctx::UpWorker& w = ctx->up_workers[t];
+        hipError_t e = hipSetDevice(device);
+        const uint64_t e0 = std::min<uint64_t>(n, (uint64_t)t * share), e1 = std::min<uint64_t>(n, e0 + share);
+        int buf = 0;
+        bool used[2] = {false, false};
+        int bad_local = 0;
+        for (uint64_t off = e0; off < e1 && e == hipSuccess; off += per_chunk, buf ^= 1) {
+            const uint64_t cnt = std::min<uint64_t>(per_chunk, e1 - off);
+            if (used[buf]) e = hipEventSynchronize(w.ev[buf]);          // the DMA out of this buffer has finished
+            if (e != hipSuccess) break;
+            if (narrow) {
+                const uint64_t* s = static_cast<const uint64_t*>(src) + off;
+                int32_t* d = static_cast<int32_t*>(w.pin[buf]);
+                uint64_t over = 0;
+                for (uint64_t i = 0; i < cnt; ++i) {
+                    const uint64_t v = s[i];
+                    over |= (uint64_t)(v >= n_cols);
+                    d[i] = (int32_t)v;
+                }
+                bad_local |= (int)over;
+            } else {
+                memcpy(w.pin[buf], static_cast<const char*>(src) + off * elem_bytes, cnt * elem_bytes);
+            }
+            e = hipMemcpyAsync(static_cast<char*>(dst) + off * elem_bytes, w.pin[buf], cnt * elem_bytes, hipMemcpyHostToDevice,
+                               w.stream);
+            if (e == hipSuccess) e = hipEventRecord(w.ev[buf], w.stream);
+            used[buf] = true;
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(w.stream);
+        err[t] = e;
+        oob[t] = bad_local;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nw; ++t) th.emplace_back(run, t);
+    run(0);
+    for (auto& x : th) x.join();
+    for (int t = 0; t < nw; ++t) {
+        if (err[t] != hipSuccess) return fail(ctx, SRX_E_HIP, "H2D worker %d: %s", t, hipGetErrorString(err[t]));
+        if (bad && oob[t]) *bad = true;
+    }
+    return SRX_OK;
+}
+
 // H2D of a host CSR slice with the u64 -> i32 index narrowing, the value conversion and the canonical-CSR
 // validation, every kernel on `stream`.  `h->indptr` may be a window of a larger row-offset array (a row tile of
 // a backed matrix: indptr[0] != 0, indices / values pointing at the tile's first entry) — it is rebased on the
@@ -232,29 +319,23 @@ int32_t upload_on(srx_ctx* ctx, const srx_csr* h, int32_t store, hipStream_t str
     if (rc) return bail(rc);
     (void)hipMemsetAsync(d_flag, 0, sizeof(int), stream);
 
-    // indices: u64 -> i32 through a staging chunk
-    {
-        const uint64_t chunk = 32ull << 20;
-        void* d_tmp;
-        uint64_t c0 = h->nnz < chunk ? h->nnz : chunk;
-        rc = scratch(ctx, tmp_tag, (c0 ? c0 : 1) * sizeof(uint64_t) + 16, &d_tmp);
+    // indices (u64 -> i32 on the way into the pinned staging buffers: 4 of the 8 bytes cross PCIe) and, when the
+    // dtype is the storage type, the values: the H2D workers
+    bool f32 = is_f32(m);
+    const bool plain_values = (h->dtype == SRX_F32 && f32) || (h->dtype == SRX_F64 && !f32);
+    if (h->nnz) {
+        bool bad_col = false;
+        rc = parallel_h2d(ctx, h->indices, m->d_indices, h->nnz, true, sizeof(int32_t), h->n_cols, &bad_col);
         if (rc) return bail(rc);
-        for (uint64_t off = 0; off < h->nnz; off += chunk) {
-            uint64_t cnt = h->nnz - off < chunk ? h->nnz - off : chunk;
-            e = hipMemcpy(d_tmp, h->indices + off, cnt * sizeof(uint64_t), hipMemcpyHostToDevice);
-            if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "H2D indices: %s", hipGetErrorString(e)));
-            hipLaunchKernelGGL(k_narrow_indices, dim3(grid_for(cnt, 256, 4096)), dim3(256), 0, stream,
-                               (const uint64_t*)d_tmp, m->d_indices + off, cnt, h->n_cols, d_flag);
-            e = hipStreamSynchronize(stream);
-            if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "narrow indices: %s", hipGetErrorString(e)));
+        if (bad_col) return bail(fail(ctx, SRX_E_BOUNDS, "column index out of bounds (>= n_cols = %llu)",
+                                      (unsigned long long)h->n_cols));
+        if (plain_values) {
+            rc = parallel_h2d(ctx, h->values, m->d_values, h->nnz, false, val_bytes(m), 0, nullptr);
+            if (rc) return bail(rc);
         }
     }
-    // values
-    bool f32 = is_f32(m);
-    if ((h->dtype == SRX_F32 && f32) || (h->dtype == SRX_F64 && !f32)) {
-        e = hipMemcpy(m->d_values, h->values, h->nnz * val_bytes(m), hipMemcpyHostToDevice);
-        if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "H2D values: %s", hipGetErrorString(e)));
-    } else if (h->nnz) {
+    (void)tmp_tag;
+    if (!plain_values && h->nnz) {
         switch (h->dtype) {
             case SRX_I8:  rc = convert_chunked<int8_t>(ctx, stream, tmp_tag, h->values, m->d_values, h->nnz, f32); break;
             case SRX_I16: rc = convert_chunked<int16_t>(ctx, stream, tmp_tag, h->values, m->d_values, h->nnz, f32); break;
@@ -338,6 +419,13 @@ void srx_ctx_destroy(srx_ctx* ctx) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
     if (ctx->pin_async) (void)hipHostFree(ctx->pin_async);
+    for (auto& uw : ctx->up_workers) {
+        for (int b = 0; b < 2; ++b) {
+            if (uw.pin[b]) (void)hipHostFree(uw.pin[b]);
+            if (uw.ev[b]) (void)hipEventDestroy(uw.ev[b]);
+        }
+        if (uw.stream) (void)hipStreamDestroy(uw.stream);
+    }
     for (auto e : ctx->async_ev)
         if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
