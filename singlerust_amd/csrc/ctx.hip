@@ -40,8 +40,13 @@ int32_t pinned(srx_ctx* ctx, size_t bytes, void** out) {
     return SRX_OK;
 }
 
+static int32_t parallel_h2d(srx_ctx* ctx, const void* src, void* dst, uint64_t n, bool narrow, size_t elem_bytes,
+                            uint64_t n_cols, bool* bad);
+static int32_t parallel_d2h(srx_ctx* ctx, void* dst, const void* src, size_t bytes);
+
 // Small/medium blocks go through the pinned staging buffer so the copy is a true async DMA
-// ordered on the ctx stream; large blocks (values of the whole matrix) go direct.
+// ordered on the ctx stream; large blocks (values of the whole matrix, the score matrix) go through the
+// transfer workers (several pinned double-buffer pipelines side by side).
 int32_t d2h(srx_ctx* ctx, void* host, const void* dev, size_t bytes) {
     if (bytes == 0) return SRX_OK;
     if (bytes <= (64u << 20)) {
@@ -52,7 +57,7 @@ int32_t d2h(srx_ctx* ctx, void* host, const void* dev, size_t bytes) {
         memcpy(host, p, bytes);
     } else {
         SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        SRX_HIP(ctx, hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+        SRX_TRY(parallel_d2h(ctx, host, dev, bytes));
     }
     return SRX_OK;
 }
@@ -68,7 +73,7 @@ int32_t h2d(srx_ctx* ctx, void* dev, const void* host, size_t bytes) {
         SRX_HIP(ctx, hipMemcpyAsync(dev, p, bytes, hipMemcpyHostToDevice, ctx->stream));
     } else {
         SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        SRX_HIP(ctx, hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
+        SRX_TRY(parallel_h2d(ctx, host, dev, bytes, false, 1, 0, nullptr));
     }
     return SRX_OK;
 }
@@ -290,6 +295,48 @@ static int32_t parallel_h2d(srx_ctx* ctx, const void* src, void* dst, uint64_t n
         if (err[t] != hipSuccess) return fail(ctx, SRX_E_HIP, "H2D worker %d: %s", t, hipGetErrorString(err[t]));
         if (bad && oob[t]) *bad = true;
     }
+    return SRX_OK;
+}
+
+// the same in the other direction: DMA into a pinned buffer, then a memcpy out of it while the next DMA runs
+static int32_t parallel_d2h(srx_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return SRX_OK;
+    SRX_TRY(ensure_up_workers(ctx));
+    const int device = ctx->device;
+    int nw = (int)std::min<uint64_t>(kUpWorkers, (bytes + kUpChunkBytes - 1) / kUpChunkBytes);
+    if (nw < 1) nw = 1;
+    const uint64_t share = ((bytes + nw - 1) / nw + 255) & ~(uint64_t)255;
+    std::vector<hipError_t> err(nw, hipSuccess);
+    auto run = [&](int t) {
+        srx_ctx::UpWorker& w = ctx->up_workers[t];
+        hipError_t e = hipSetDevice(device);
+        const uint64_t b0 = std::min<uint64_t>(bytes, (uint64_t)t * share), b1 = std::min<uint64_t>(bytes, b0 + share);
+        // chunk c is DMAed into buffer c & 1 while chunk c - 1 is copied out of the other one
+        uint64_t prev_off = 0, prev_cnt = 0;
+        int buf = 0;
+        for (uint64_t off = b0; off < b1 && e == hipSuccess; off += kUpChunkBytes, buf ^= 1) {
+            const uint64_t cnt = std::min<uint64_t>(kUpChunkBytes, b1 - off);
+            e = hipMemcpyAsync(w.pin[buf], static_cast<const char*>(src) + off, cnt, hipMemcpyDeviceToHost, w.stream);
+            if (e == hipSuccess) e = hipEventRecord(w.ev[buf], w.stream);
+            if (prev_cnt && e == hipSuccess) {
+                e = hipEventSynchronize(w.ev[buf ^ 1]);
+                if (e == hipSuccess) memcpy(static_cast<char*>(dst) + prev_off, w.pin[buf ^ 1], prev_cnt);
+            }
+            prev_off = off;
+            prev_cnt = cnt;
+        }
+        if (prev_cnt && e == hipSuccess) {
+            e = hipEventSynchronize(w.ev[buf ^ 1]);
+            if (e == hipSuccess) memcpy(static_cast<char*>(dst) + prev_off, w.pin[buf ^ 1], prev_cnt);
+        }
+        err[t] = e;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nw; ++t) th.emplace_back(run, t);
+    run(0);
+    for (auto& x : th) x.join();
+    for (int t = 0; t < nw; ++t)
+        if (err[t] != hipSuccess) return fail(ctx, SRX_E_HIP, "D2H worker %d: %s", t, hipGetErrorString(err[t]));
     return SRX_OK;
 }
 
