@@ -711,7 +711,7 @@ __device__ __forceinline__ double gram_product(float a, float b) { return (doubl
 __device__ __forceinline__ double gram_product(double a, double b) { return a * b; }
 template <typename VT> struct GramCfg;
 template <> struct GramCfg<float> { static constexpr int kWavesPerWg = 16; };    // 16 x 2048 B of staging
-template <> struct GramCfg<double> { static constexpr int kWavesPerWg = 7; };    //  7 x 4096 B
+template <> struct GramCfg<double> { static constexpr int kWavesPerWg = 8; };    //  8 x 4096 B: the LDS is full to the byte
 constexpr int kGramRows = 32;          // cells per batch (lane l < 32 holds cell l's extents)
 constexpr int kGramCap = 128;          // staged entries per side (a cell holds <= 128 entries of a tile)
 
