@@ -1,0 +1,93 @@
+"""GPU parity tests (-m gpu) on BASELINE.json's configs[0] and configs[1] shapes, end to end against the oracle.
+
+configs[0]: 2.7k cells x 32k genes, ~7 % (the reference's CPU-runnable case): every stage against the C oracle and the
+            exact-SVD oracle.
+configs[1]: 100k cells x 20k genes, 5 % (1.0e8 non-zeros): normalise / log1p / gene variance / HVG against the C oracle
+            (serial loops, a few seconds); the PCA against an f64 covariance-eigendecomposition restatement
+            (scipy sparse Z^T Z of the 2000 selected genes + numpy eigh — mathematically the oracle's SVD, and the only
+            exact reference that fits a test at this size)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import COLUMN, ROW, pca_oracle
+from test_pca_gpu import TOL, adata_of, col_err, synth_host
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def pipeline(ctx, m, store, n_hvg, n_pc):
+    from singlerust_amd import _ffi as F
+    a = adata_of(m, ctx, store)
+    opts = F.PcaOpts(n_pc, -1, -1, -1, 0, 0, 0, 0.0, 0)
+    res = F.PipelineResult()
+    F.check(F.lib().srx_pipeline(a.x().handle, 1e4, n_hvg, C.byref(opts), C.byref(res)), ctx.handle)
+    k = int(res.pca.k)
+    scores, comps = np.zeros((m.n_rows, n_pc)), np.zeros((k, n_pc))
+    evr, mean, std, hv = np.zeros(n_pc), np.zeros(k), np.zeros(k), np.zeros(k, np.uint64)
+    F.check(F.lib().srx_result_fetch(a.x().handle, F.ptr(scores), F.ptr(comps), F.ptr(evr), F.ptr(mean), F.ptr(std), F.ptr(hv)),
+            ctx.handle)
+    return a, scores, comps, evr, mean, std, hv
+
+
+@pytest.mark.parametrize("store,vtol", [(1, 1e-6), (2, 4e-16)])
+def test_config0_shape_every_stage_against_the_oracle(ctx, store, vtol):
+    import singlerust_amd as sr
+    from singlerust_amd.memory import statistics as st
+    m, _ = synth_host(1001, 2700, 32000, 0.07)
+    raw = adata_of(m, ctx, store)
+    assert np.array_equal(st.compute_number(raw, sr.Direction.Row), oracle.compute_number(m, ROW))        # bit-exact
+    assert np.array_equal(st.compute_number(raw, sr.Direction.Column), oracle.compute_number(m, COLUMN))
+    assert np.array_equal(st.compute_sum(raw, sr.Direction.Row), oracle.compute_sum(m, ROW))              # integer counts
+    assert np.array_equal(st.compute_sum(raw, sr.Direction.Column), oracle.compute_sum(m, COLUMN))
+    a, scores, comps, evr, mean, std, hv = pipeline(ctx, m, store, 2000, 50)
+    lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
+    assert rel_err(a.x_values(np.float64), lg.values.astype(np.float64)) <= vtol
+    want_var = oracle.compute_variance(lg, COLUMN)
+    got_var = st.compute_variance(a, sr.Direction.Column)
+    assert np.allclose(got_var, want_var, rtol=1e-4 if store == 1 else 1e-11, atol=1e-12)
+    if store == 2:
+        assert np.array_equal(hv, oracle.select_hvg(want_var, 2000))            # identical set and order
+    want, wc, wevr, wmean, wstd = pca_oracle.pca_inplace(lg, 50, None, None, hv)
+    assert np.allclose(evr, wevr, rtol=1e-5) and np.allclose(mean, wmean, rtol=1e-5, atol=1e-7) and np.allclose(std, wstd, rtol=1e-5)
+    gaps = np.minimum(np.abs(np.diff(wevr, prepend=np.inf)), np.abs(np.diff(wevr, append=0.0))) / wevr
+    iso = gaps > 1e-3                                                           # N = 2700: the tail eigenvalues crowd
+    assert iso[:10].all()
+    assert col_err(scores[:, iso], want[:, iso]) < 20 * TOL and col_err(comps[:, iso], wc[:, iso]) < 20 * TOL
+    assert np.abs(wc @ (wc.T @ comps) - comps).max() < 1e-4
+
+
+def test_config1_shape_against_the_oracle(ctx):
+    import scipy.sparse as sp
+    import singlerust_amd as sr
+    from singlerust_amd.memory import statistics as st
+    n, g = 100_000, 20_000
+    m, _ = synth_host(2002, n, g, 0.05)
+    assert 0.9e8 < len(m.values) < 1.1e8
+    a, scores, comps, evr, mean, std, hv = pipeline(ctx, m, 1, 2000, 50)
+    lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))            # serial C loops over 1e8 non-zeros
+    assert rel_err(a.x_values(np.float64), lg.values.astype(np.float64)) <= 1e-6
+    want_var = oracle.compute_variance(lg, COLUMN)
+    assert np.allclose(st.compute_variance(a, sr.Direction.Column), want_var, rtol=1e-4, atol=1e-12)
+    want_sel = oracle.select_hvg(want_var, 2000)
+    # f32 storage rounds log1p differently from the f64 oracle: near-ties may swap, the sets must agree almost entirely
+    assert len(set(hv.tolist()) & set(want_sel.tolist())) >= 1995
+    # PCA of the GPU's own selection: covariance eigendecomposition in f64
+    x = sp.csr_matrix((lg.values.astype(np.float64), lg.indices.astype(np.int64), lg.indptr.astype(np.int64)), shape=(n, g))
+    xs = x[:, hv.astype(np.int64)].tocsc()
+    mu = np.asarray(xs.mean(axis=0)).ravel()
+    ex2 = np.asarray(xs.multiply(xs).mean(axis=0)).ravel()
+    sd = np.sqrt(ex2 - mu * mu)
+    gram = (xs.T @ xs).toarray()
+    cov = (gram - n * np.outer(mu, mu)) / np.outer(sd, sd)                      # Z^T Z
+    w, v = np.linalg.eigh(cov)
+    order = np.argsort(w)[::-1][:50]
+    wv, vv = w[order], v[:, order]
+    assert np.allclose(mean, mu, rtol=1e-5, atol=1e-7) and np.allclose(std, sd, rtol=1e-5)
+    assert np.allclose(evr, wv / np.trace(cov), rtol=1e-5)
+    assert col_err(comps, vv) < 10 * TOL
+    want_scores = (xs @ (vv / sd[:, None])) - (mu / sd) @ vv
+    assert col_err(scores, np.asarray(want_scores)) < 10 * TOL
