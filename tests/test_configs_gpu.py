@@ -91,3 +91,38 @@ def test_config1_shape_against_the_oracle(ctx):
     assert col_err(comps, vv) < 10 * TOL
     want_scores = (xs @ (vv / sd[:, None])) - (mu / sd) @ vv
     assert col_err(scores, np.asarray(want_scores)) < 10 * TOL
+
+
+def test_wide_matrix_without_the_16bit_index_mirror(ctx, tmp_path):
+    """More than 65 536 genes: no 16-bit index mirror (the 32-bit paths of the moments and compaction passes), HVG
+    selection on the host; resident pipeline, backed session and CSC handle against the oracle."""
+    import scipy.sparse as sp
+    import singlerust_amd as sr
+    from oracle import csc_oracle
+    from singlerust_amd import backed
+    from singlerust_amd.memory import statistics as st
+    n, g = 3000, 70_000
+    m, _ = synth_host(606, n, g, 0.01)
+    a, scores, comps, evr, mean, std, hv = pipeline(ctx, m, 2, 500, 10)
+    lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
+    assert rel_err(a.x_values(np.float64), lg.values.astype(np.float64)) <= 4e-16
+    want_var = oracle.compute_variance(lg, COLUMN)
+    assert np.allclose(st.compute_variance(a, sr.Direction.Column), want_var, rtol=1e-11, atol=1e-13)
+    assert np.array_equal(st.compute_number(a, sr.Direction.Column), oracle.compute_number(m, COLUMN))
+    assert np.array_equal(hv, oracle.select_hvg(want_var, 500))
+    want, wc, wevr, *_ = pca_oracle.pca_inplace(lg, 10, None, None, hv)
+    assert np.allclose(evr, wevr, rtol=1e-6) and col_err(scores, want) < 1e-6 and col_err(comps, wc) < 1e-6
+    # backed session over 7 row tiles
+    p = str(tmp_path / "wide")
+    backed.BackedCsr.write(p, m.indptr, m.indices, m.values, g)
+    r = backed.processing.pca_pipeline(backed.BackedAnnData.open(p, ctx), 450, 1e4, 500, 10, store=2)
+    assert np.array_equal(r.selected, hv) and col_err(r.x_pca, want) < 1e-6
+    # the same X as a CSC handle: statistics and the transpose with 70k stored rows
+    x = sp.csr_matrix((m.values, m.indices.astype(np.int64), m.indptr.astype(np.int64)), shape=(n, g)).tocsc()
+    x.sort_indices()
+    c = sr.IMAnnData.new_basic(x, ctx=ctx, store=2)
+    mc = csc_oracle.Csc.from_scipy(x)
+    assert np.array_equal(st.compute_number(c, sr.Direction.Column), csc_oracle.compute_number(mc, COLUMN))
+    assert np.array_equal(st.compute_sum(c, sr.Direction.Row), csc_oracle.compute_sum(mc, ROW))
+    back = c.x().to_csr()
+    assert np.array_equal(back.values(np.float64), m.values.astype(np.float64))
