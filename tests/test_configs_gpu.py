@@ -126,3 +126,25 @@ def test_wide_matrix_without_the_16bit_index_mirror(ctx, tmp_path):
     assert np.array_equal(st.compute_sum(c, sr.Direction.Row), csc_oracle.compute_sum(mc, ROW))
     back = c.x().to_csr()
     assert np.array_equal(back.values(np.float64), m.values.astype(np.float64))
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+def test_more_than_8192_selected_features(ctx, solver):
+    """FeatureSelection::None on 9000 genes: past the 64 tile counters of the fused compaction (general route: row-major
+    compaction, then re-tiling) and, with solver auto, past the Gram solver's default range (matrix-free SpMM solver)."""
+    import singlerust_amd as sr
+    from singlerust_amd.memory import processing
+    from singlerust_amd.memory.processing import dim_red
+    m, _ = synth_host(909, 1500, 9000, 0.02)
+    a = adata_of(m, ctx, 2)
+    processing.normalize_total_inplace(a, 1e4, sr.Direction.Row)
+    processing.log1p_transform_inplace(a)
+    # VarianceThreshold(0): the genes whose non-zeros differ (std > 0 — the reference divides by the std) — still > 8192
+    lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
+    info = dim_red.pca_inplace(a, 6, None, None, None, sr.FeatureSelection.VarianceThreshold(0.0), None, solver=solver)
+    sel = a.uns["pca"]["selected_features"]
+    assert np.array_equal(sel, np.flatnonzero(oracle.compute_variance(lg, COLUMN) > 0.0))
+    assert info.k == len(sel) > 8192 and info.solver == (2 if solver == 0 else 1)
+    want, wc, wevr, *_ = pca_oracle.pca_inplace(lg, 6, None, None, sel)
+    assert np.allclose(a.uns["pca"]["explained_variance_ratio"], wevr, rtol=1e-6)
+    assert col_err(a.obsm["X_pca"], want) < 1e-6 and col_err(a.uns["pca"]["components"], wc) < 1e-6
