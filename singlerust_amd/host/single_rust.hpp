@@ -149,6 +149,8 @@ public:
         obsm_ = std::move(o.obsm_);
         varm_ = std::move(o.varm_);
         var_bool_ = std::move(o.var_bool_);
+        obs_cols_ = std::move(o.obs_cols_);
+        var_cols_ = std::move(o.var_cols_);
         return *this;
     }
     ~IMAnnData() { srx_matrix_free(x_); }
@@ -185,6 +187,8 @@ public:
         c.obsm_ = obsm_;
         c.varm_ = varm_;
         c.var_bool_ = var_bool_;
+        c.obs_cols_ = obs_cols_;
+        c.var_cols_ = var_cols_;
         return c;
     }
     // a matrix the library produced (filter / subset): the host copy of the pattern is downloaded
@@ -202,6 +206,9 @@ public:
     }
     const std::vector<std::string>& obs_names() const { return obs_names_; }
     const std::vector<std::string>& var_names() const { return var_names_; }
+    // numeric columns of the `obs` / `var` DataFrames (what qc_vars_inplace writes)
+    std::map<std::string, std::vector<double>>& obs_columns() { return obs_cols_; }
+    std::map<std::string, std::vector<double>>& var_columns() { return var_cols_; }
     // boolean columns of the `var` DataFrame (what FeatureSelection::HighlyVariableCol reads)
     std::map<std::string, std::vector<bool>>& var_bool() { return var_bool_; }
     const std::map<std::string, std::vector<bool>>& var_bool() const { return var_bool_; }
@@ -216,6 +223,7 @@ private:
     std::vector<std::string> obs_names_, var_names_;
     std::map<std::string, Array2> obsm_, varm_;
     std::map<std::string, std::vector<bool>> var_bool_;
+    std::map<std::string, std::vector<double>> obs_cols_, var_cols_;
 };
 
 namespace memory {
@@ -264,6 +272,20 @@ inline StatisticsContainer compute_qc_variables(const IMAnnData& a) {
                                            c.expr_per_cell.data(), c.variance_per_gene.data(), c.variance_per_cell.data(),
                                            c.std_dev_per_cell.data(), c.std_dev_per_gene.data()));
     return c;
+}
+// qc_vars_inplace (src/memory/statistics/mod.rs:74-103): the eight vectors become columns of obs / var under the
+// reference's names (counts are widened to f64: the mirror's DataFrames hold f64 columns)
+inline void qc_vars_inplace(IMAnnData& a) {
+    const StatisticsContainer d = compute_qc_variables(a);
+    auto widen = [](const std::vector<std::uint32_t>& v) { return std::vector<double>(v.begin(), v.end()); };
+    a.obs_columns()["num_genes_per_cell"] = widen(d.num_per_cell);
+    a.obs_columns()["sum_expr_per_cell"] = d.expr_per_cell;
+    a.obs_columns()["var_expr_per_cell"] = d.variance_per_cell;
+    a.obs_columns()["std_dev_per_cell"] = d.std_dev_per_cell;
+    a.var_columns()["num_cells_per_gene"] = widen(d.num_per_gene);
+    a.var_columns()["sum_expr_per_gene"] = d.expr_per_gene;
+    a.var_columns()["var_expr_per_gene"] = d.variance_per_gene;
+    a.var_columns()["std_dev_per_gene"] = d.std_dev_per_gene;
 }
 }  // namespace statistics
 

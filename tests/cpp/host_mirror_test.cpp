@@ -131,6 +131,17 @@ static void test_path_end_to_end(Context& ctx) {
         EXPECT(q <= prev * (1 + 1e-9), "PC variances not descending at %zu", c);
         prev = q;
     }
+    // qc_vars_inplace (statistics/mod.rs:74-103): the eight columns under the reference's names
+    {
+        IMAnnData q = adata.deep_clone();
+        stats::qc_vars_inplace(q);
+        EXPECT(q.obs_columns().size() == 4 && q.var_columns().size() == 4, "qc_vars_inplace column counts");
+        EXPECT(q.obs_columns().at("num_genes_per_cell").size() == 1000 && q.var_columns().at("std_dev_per_gene").size() == 100,
+               "qc_vars_inplace column lengths");
+        auto n = stats::compute_number(q, Direction::Column);
+        for (std::size_t j = 0; j < n.size(); ++j)
+            EXPECT(q.var_columns().at("num_cells_per_gene")[j] == (double)n[j], "num_cells_per_gene[%zu]", j);
+    }
     // the remaining FeatureSelection arms (dim_red/mod.rs:125-134, 141-153)
     {
         std::vector<bool> flag(100, false);
