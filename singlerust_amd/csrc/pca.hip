@@ -1254,7 +1254,7 @@ __device__ __forceinline__ void jacobi_pair(int m, int r, int& p, int& q) {
     }
 }
 __global__ __launch_bounds__(1024) void k_jacobi_eig(const double* __restrict__ H, int n, double* __restrict__ U,
-                                                     double* __restrict__ theta, int* __restrict__ status) {
+                                                     double* __restrict__ theta, int* __restrict__ status, double off_tol2) {
     static_assert(L == 64, "the block mapping below is written for l = 64");
     extern __shared__ double lds_raw[];
     double (*A)[L + 1] = reinterpret_cast<double (*)[L + 1]>(lds_raw);
@@ -1292,7 +1292,7 @@ __global__ __launch_bounds__(1024) void k_jacobi_eig(const double* __restrict__ 
             dg += red[1][w];
         }
         __syncthreads();
-        if (!(off > 1e-30 * dg)) {            // also leaves on NaN (reported through the residual)
+        if (!(off > off_tol2 * dg)) {         // also leaves on NaN (reported through the residual)
             done = true;
             break;
         }
@@ -1875,11 +1875,16 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     };
     // one Rayleigh–Ritz step on span(W): Wp = C W, H = W^T Wp = U diag(theta) U^T, Ritz vectors
     // A2 = W U, residuals || C v_i - theta_i v_i || in f64; slot <- (residual, status)
-    auto ritz_kernels = [&](int slot) -> int32_t {
+    // `loose`: the step after the warm-up.  Its residuals are O(1e-2) whatever the eigen-solver does (it only feeds the
+    // filter's bounds and the rotated start), and the tail of the 64-column block holds clustered Ritz values that cost
+    // the cyclic Jacobi two slow sweeps: it may stop at an off-diagonal norm of 1e-5 of the diagonal (7 -> 5 sweeps).  The
+    // residuals are measured on the vectors actually formed, so a loosely rotated basis is judged as what it is: at the
+    // default tolerances (1e-7 / 1e-9) such a step is never accepted as converged — the next, exact one decides.
+    auto ritz_kernels = [&](int slot, bool loose = false) -> int32_t {
         SRX_TRY(apply(w.W, w.Wp));
         SRX_TRY(gram2(ctx, w, w.W, w.Wp, k));
         hipLaunchKernelGGL(k_jacobi_eig, dim3(1), dim3(1024), kJacobiLds, ctx->stream, w.dHG, l_act, w.dM2, w.dTheta,
-                           d_status);
+                           d_status, loose ? 1e-10 : 1e-30);
         hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.Wp, w.dM2, k, w.A1);
         hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.W, w.dM2, k, w.A2);
         hipLaunchKernelGGL(k_col_resid, dim3(1), dim3(1024), 0, ctx->stream, w.A1, w.A2, w.dTheta, k, w.dRho, w.dColmax);
@@ -1932,7 +1937,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         SRX_TRY(orth(w.Wp));
         SRX_TRY(orth(w.W));            // CholeskyQR2 on the random start
         for (int sweep = 0; sweep < o.warm; ++sweep) SRX_TRY(plain_sweep());
-        return ritz_kernels(0);
+        return ritz_kernels(0, true);
     };
     // Chebyshev filter after the first Ritz step (Gram solver: w.T is free and `apply` has no collective).
     // Speculative part: Y1 and Z = C Y1 (needed whatever the degree turns out to be, d >= 2).
