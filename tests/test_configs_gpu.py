@@ -148,3 +148,31 @@ def test_more_than_8192_selected_features(ctx, solver):
     want, wc, wevr, *_ = pca_oracle.pca_inplace(lg, 6, None, None, sel)
     assert np.allclose(a.uns["pca"]["explained_variance_ratio"], wevr, rtol=1e-6)
     assert col_err(a.obsm["X_pca"], want) < 1e-6 and col_err(a.uns["pca"]["components"], wc) < 1e-6
+
+
+def test_reference_integration_flow(ctx):
+    """tests/test_basic_load.rs:108-230 of the reference (load_file_with_test_plot_small_faer / _lapack), on a synthetic
+    matrix instead of the h5ad file it reads: filter_cells_inplace(Absolute(200), None) -> filter_genes_inplace(
+    Absolute(3), None) -> pca_inplace(Some(5), None, Some(true), Some(32), HighlyVariable(25), FaerSVD) — on RAW counts,
+    as the reference's test does — against the oracle's filters and exact SVD."""
+    import singlerust_amd as sr
+    from oracle import filter_oracle as fo
+    from singlerust_amd.memory import processing
+    from singlerust_amd.memory.processing import dim_red
+    m, _ = synth_host(4242, 3000, 2500, 0.1)
+    a = adata_of(m, ctx, 0)
+    n_cells_before, n_genes_before = a.n_obs(), a.n_vars()
+    processing.filter_cells_inplace(a, sr.FlexValue.Absolute(200), sr.FlexValue.NoLimit())
+    processing.filter_genes_inplace(a, sr.FlexValue.Absolute(3), sr.FlexValue.NoLimit())
+    want, _ = fo.filter_cells(m, fo.absolute(200), fo.NONE)
+    want, _ = fo.filter_genes(want, fo.absolute(3), fo.NONE)
+    assert (a.n_obs(), a.n_vars()) == (want.n_rows, want.n_cols)
+    assert 0 < a.n_obs() < n_cells_before and 0 < a.n_vars() <= n_genes_before
+    assert np.array_equal(a.x_values(np.float64), want.values.astype(np.float64))
+    info = dim_red.pca_inplace(a, 5, None, True, 32, sr.FeatureSelection.HighlyVariable(25), None)
+    assert info.n_pc == 5 and info.k == 25 and a.obsm["X_pca"].shape == (want.n_rows, 5)
+    sel = a.uns["pca"]["selected_features"]
+    assert np.array_equal(sel, oracle.select_hvg(oracle.compute_variance(want, COLUMN), 25))
+    ws, wc, wevr, *_ = pca_oracle.pca_inplace(want, 5, None, True, sel)
+    assert np.allclose(a.uns["pca"]["explained_variance_ratio"], wevr, rtol=1e-6)
+    assert col_err(a.obsm["X_pca"], ws) < TOL and col_err(a.uns["pca"]["components"], wc) < TOL
