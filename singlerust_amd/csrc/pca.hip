@@ -2230,12 +2230,15 @@ static int32_t resolve_opts(srx_ctx* ctx, const srx_pca_opts* opts, int k, uint6
     o.seed = opts ? opts->seed : 0;
     o.solver = opts ? opts->solver : 0;
     if (o.solver < 0 || o.solver > 2) return fail(ctx, SRX_E_ARG, "pca: solver must be 0 (auto), 1 (gram) or 2 (spmm)");
-    if (o.solver == 0) o.solver = k <= 4096 ? 1 : 2;
+    // auto: the explicit Gram matrix as long as the fused compaction takes the selection (k <= 64 tiles of 128): at
+    // c2's size k = 6000 / 8000 cost 13.6 / 20.5 ms per pipeline, a fraction of what the matrix-free iteration needs
+    if (o.solver == 0) o.solver = k <= kWave * KG ? 1 : 2;
     o.power = o.solver == 1 ? 3 : 1;
     o.warm = o.solver == 1 ? 2 : 0;
     if (o.solver == 1 && k > 16384) return fail(ctx, SRX_E_ARG, "pca: the Gram solver holds a k x k f64 matrix; k=%d is too large", k);
     // default tolerance on the relative Ritz residual: what the arithmetic of the solver supports
-    if (o.tol == 0.0) o.tol = f32 ? 1e-7 : 1e-9;
+    // (the matrix-free solver forms its products in f32 with f32 storage: its residuals level off at ~1.3e-7)
+    if (o.tol == 0.0) o.tol = f32 ? (o.solver == 2 ? 5e-7 : 1e-7) : 1e-9;
     if (o.n_pc < 1) return fail(ctx, SRX_E_ARG, "pca: n_components must be >= 1");
     if (opts && opts->block != 0 && opts->block != L) return fail(ctx, SRX_E_ARG, "pca: only block = %d is built", L);
     l_act = std::min(L, k);
