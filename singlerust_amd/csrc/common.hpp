@@ -91,7 +91,7 @@ struct srx_ctx {
     std::map<std::string, hipGraphExec_t> graphs;
     bool graphs_off = false;                 // capture failed once (or SRX_NO_GRAPH): plain launches from then on
     bool capturing = false;                  // ProfScope and friends stay out of a capture
-    double* pin_async = nullptr;             // kAsyncSlots x 4 doubles, pinned
+    double* pin_async = nullptr;             // kAsyncSlots x 8 doubles, pinned
     // H2D workers of srx_matrix_upload / the backed sessions (ctx.hip): each owns a stream, two pinned staging
     // buffers and two events, and moves its own contiguous share of an array
     struct UpWorker {
@@ -106,7 +106,8 @@ struct srx_ctx {
 struct srx_pca_state {           // what the last srx_pca / srx_pipeline left in HBM
     bool valid = false;
     uint32_t k = 0, n_pc = 0;
-    uint32_t rounds = 1;             // deflation rounds of the solve (n_pc > 56: kPcaPerRound components per round)
+    uint32_t rounds = 1;             // deflation rounds of the solve
+    std::vector<int> round_counts;   // components resolved by each round (sums to n_pc)
     double* d_scores = nullptr;      // n_rows x n_pc, row-major f64
     size_t scores_cap = 0;
     std::vector<double> components;  // k x n_pc (host copy; small)

@@ -1425,6 +1425,7 @@ __global__ void k_resid_scalar(const double* __restrict__ rho, const double* __r
     out[1] = (double)*status;
     out[2] = theta[n_pc - 1] > 0 ? theta[l_act - 1] / theta[n_pc - 1] : 1.0;
     out[3] = status_sel ? (double)*status_sel : 0.0;      // device-side feature selection: bit 0 = NaN variance
+    out[4] = theta[l_act - 1] > 0 ? theta[0] / theta[l_act - 1] : 1.0;      // spread of the block: bounds the filter degree
 }
 
 
@@ -1830,7 +1831,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     const size_t kl = (size_t)k * L;
     const bool use_graph = graphable && !getenv("SRX_NO_GRAPH");
     const bool use_cheb = l_act > o.n_pc && !getenv("SRX_NO_CHEB");      // both solvers: the filter only needs `apply`
-    constexpr int kSlots = srx_ctx::kAsyncSlots, kSlotDoubles = 4;
+    constexpr int kSlots = srx_ctx::kAsyncSlots, kSlotDoubles = 8;
     if (!ctx->pin_async) {
         SRX_HIP(ctx, hipHostMalloc((void**)&ctx->pin_async, kSlots * kSlotDoubles * sizeof(double), hipHostMallocDefault));
         for (auto& e : ctx->async_ev) SRX_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1909,11 +1910,13 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         SRX_TRY(apply_n(w.A1, o.power - 1, &res));
         return orth(res);
     };
+    double spread = 1.0;               // theta_1 / theta_l of the last collected Ritz step
     auto collect = [&](int slot, double& r, double& ratio) -> int32_t {
         SRX_HIP(ctx, hipEventSynchronize(ctx->async_ev[slot]));
         r = ctx->pin_async[kSlotDoubles * slot];
         const int st = (int)ctx->pin_async[kSlotDoubles * slot + 1];
         ratio = ctx->pin_async[kSlotDoubles * slot + 2];
+        spread = ctx->pin_async[kSlotDoubles * slot + 4];
         if ((int)ctx->pin_async[kSlotDoubles * slot + 3] & 1)
             return fail(ctx, SRX_E_NAN, "NaN gene variance: called `Option::unwrap()` on a `None` value (partial_cmp)");
         if (st & kStatChol) return fail(ctx, SRX_E_NOCONV, "pca: block lost rank (Cholesky pivot <= 0)");
@@ -2009,6 +2012,16 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
             // that had seen ONE application (SpMM solver, no warm-up) collapsed it ("block lost rank").
             if (d > q_applied) d = q_applied;
             if (d > 12) d = 12;                // T_12 of the largest t stays far inside f64; harder spectra take more rounds
+            // The filter multiplies the component of every column along the leading eigenvector by T_d(t_1), t_1 =
+            // 2 theta_1 / theta_l - 1, and the guard columns' own components by ~1: whatever rounding-level trace of v_1
+            // a guard column carries (1e-16) must stay small against the column itself, or the block collapses onto the
+            // leading directions and the next CholeskyQR finds a pivot <= 0.  T_d(t_1) <= 1e14 <=> d <= 32.9 / acosh(t_1):
+            // no limit in practice when the block's spectrum spans less than 5x, 6 at 30x, 5 at 100x.
+            {
+                const double t1 = 2.0 * (spread > 1.0 ? spread : 1.0) - 1.0;
+                const int d_safe = t1 > 1.0 + 1e-9 ? (int)std::floor(32.9 / std::acosh(t1)) : 12;
+                if (d > d_safe) d = d_safe;
+            }
             if (d < 2) d = 2;
             q_applied += d;                    // d - 1 applications in the filter + the one of the Ritz step
             iters += (d + o.power - 1) / o.power;      // counted in sweep equivalents (max_iter bounds applications of C)
@@ -2051,14 +2064,21 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
 // Components per deflation round when more than L - 8 are asked of a k > L problem (the block keeps 16 guard
 // columns), and the number of rounds; the last round takes everything that is left once <= L dimensions remain.
 constexpr int kPcaPerRound = 48;
-static int pca_rounds(int k, int n_pc) {
-    if (k <= L || n_pc <= L - 8) return 1;
-    int done = 0, r = 0;
-    while (done < n_pc) {
-        done += (k - done <= L) ? n_pc - done : std::min(kPcaPerRound, n_pc - done);
-        ++r;
+constexpr int kPcaPerRoundSafe = 16;       // the fallback plan: 48 guard columns per round
+// Components per round when at most `per` are asked of one round.
+static std::vector<int> plan_rounds(int k, int n_pc, int per) {
+    std::vector<int> counts;
+    if (k <= L) {                            // the block spans the whole space: one exact round
+        counts.push_back(n_pc);
+        return counts;
     }
-    return r;
+    int done = 0;
+    while (done < n_pc) {
+        const int take = (k - done <= L) ? n_pc - done : std::min(per, n_pc - done);
+        counts.push_back(take);
+        done += take;
+    }
+    return counts;
 }
 
 // C -= V diag(theta) V^T over the first n columns of V (k x 64): the resolved eigenpairs leave the operator.
@@ -2107,15 +2127,25 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
     double resid = INFINITY;
     int iters = 0;
     bool converged = false;
-    // More than 56 components (k > 64): DEFLATION ROUNDS on the explicit C.  A round resolves the next kPcaPerRound
-    // eigenpairs with the 64-column block, writes their scores, and removes them from C (C -= V diag(theta) V^T),
-    // so that the next round's dominant subspace is the one after them.  One round is the whole solve otherwise.
+    // DEFLATION ROUNDS on the explicit C (Gram solver).  A round resolves the next eigenpairs with the 64-column block,
+    // writes their scores, and removes them from C (C -= V diag(theta) V^T), so that the next round's dominant
+    // subspace is the one after them.
+    //   plan A: everything in one round up to 56 components (48 per round beyond) — two Ritz steps when the spectrum
+    //           decays across the block, the normal case;
+    //   plan B: rounds of <= 16 components with 48 guard columns each.  Taken when plan A breaks down or stalls: a flat
+    //           tail (theta_64 / theta_50 -> 1) needs Chebyshev filters of high total degree, and with the dominant
+    //           eigenvalues still in the operator (theta_1 / theta_64 ~ 20-100) a degree-12 filter amplifies the leading
+    //           directions by T_12(t_1) ~ 1e20 over the guard columns — the block collapses onto them ("Cholesky pivot
+    //           <= 0").  Once a round has deflated the leading eigenpairs the remaining spectrum is narrow and the same
+    //           filters are harmless.
     const int n_pc = o.n_pc;
-    const int rounds = pca_rounds(k, n_pc);
-    st.rounds = (uint32_t)rounds;
+    const std::vector<int> plan_a = plan_rounds(k, n_pc, n_pc <= L - 8 ? n_pc : kPcaPerRound);
+    const int n_b = (n_pc + kPcaPerRoundSafe - 1) / kPcaPerRoundSafe;
+    const std::vector<int> plan_b = plan_rounds(k, n_pc, (n_pc + n_b - 1) / n_b);
+    const int rounds_cap = (int)std::max(plan_a.size(), plan_b.size());
     // one allocation: the scores, then the block of small results (layout: srx_pca_state::d_small)
     const size_t score_bytes = (cc.n_rows ? cc.n_rows : 1) * (size_t)n_pc * 8;
-    const size_t small_doubles = (size_t)rounds * (kl + 2 * L) + 2 * (size_t)k + 2 + ((size_t)k + 1) / 2;
+    const size_t small_doubles = (size_t)rounds_cap * (kl + 2 * L) + 2 * (size_t)k + 2 + ((size_t)k + 1) / 2;
     const size_t need = score_bytes + small_doubles * 8;
     if (st.scores_cap < need) {
         if (st.d_scores) SRX_HIP(ctx, hipFree(st.d_scores));
@@ -2154,9 +2184,12 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
         size_t n_packed = (size_t)(nt128 * (nt128 + 1) / 2) * KG * KG;
         if (!Pk) SRX_TRY(launch_gram<VT>(ctx, *t128p, &Pk, &n_packed));
         SRX_TRY(allreduce_f64(ctx, Pk, n_packed));                // the one exchange of this solver: upper tiles only
-        hipLaunchKernelGGL(k_gram_expand, dim3((unsigned)(((size_t)k * k + 255) / 256)), dim3(256), 0, ctx->stream, Pk,
-                           nt128, k, (const double*)w.d, (const double*)w.mu, o.center, n_cells, C);
-        SRX_HIP(ctx, hipGetLastError());
+        auto build_c = [&]() -> int32_t {
+            hipLaunchKernelGGL(k_gram_expand, dim3((unsigned)(((size_t)k * k + 255) / 256)), dim3(256), 0, ctx->stream, Pk,
+                               nt128, k, (const double*)w.d, (const double*)w.mu, o.center, n_cells, C);
+            SRX_HIP(ctx, hipGetLastError());
+            return SRX_OK;
+        };
         auto apply = [&](const double* Win, double* Wout) -> int32_t {
             ProfScope ps(ctx, SRX_K_DENSE, (double)k * k * 8.0 + 2.0 * k * L * 8.0);
             SRX_HIP(ctx, hipMemsetAsync(Wout, 0, kl * 8, ctx->stream));
@@ -2164,30 +2197,55 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
             SRX_HIP(ctx, hipGetLastError());
             return SRX_OK;
         };
-        resid = 0.0;
-        converged = true;
-        int done = 0;
-        for (int r = 0; r < rounds; ++r) {
-            Resolved o_r = o;
-            const int left_dim = k - done;                            // dimension of what is still in C
-            const int l_r = rounds == 1 ? l_act : std::min(L, left_dim);
-            o_r.n_pc = rounds == 1 ? n_pc : (left_dim <= L ? n_pc - done : std::min(kPcaPerRound, n_pc - done));
-            o_r.seed = o.seed + (uint64_t)r;
-            double resid_r = INFINITY;
-            int iters_r = 0;
-            bool conv_r = false;
-            SRX_TRY(subspace_iterate(ctx, w, k, l_r, o_r, apply, C, true, hv ? hv->d_status : nullptr, resid_r, iters_r, conv_r));
-            SRX_TRY(finish_round(r, done, o_r.n_pc));
-            resid = std::max(resid, resid_r);
-            iters += iters_r + o.warm;
-            converged = converged && conv_r;
-            done += o_r.n_pc;
-            if (r + 1 < rounds) {
-                hipLaunchKernelGGL(k_deflate, dim3((unsigned)(((size_t)k * k + 255) / 256)), dim3(256), 0, ctx->stream, C, k,
-                                   (const double*)w.A2, (const double*)w.dTheta, o_r.n_pc);
-                SRX_HIP(ctx, hipGetLastError());
+        // runs a plan; SRX_E_NOCONV (breakdown) or converged == false (budget spent) leave the decision to the caller
+        auto run_plan = [&](const std::vector<int>& plan, int budget) -> int32_t {
+            SRX_TRY(build_c());
+            resid = 0.0;
+            converged = true;
+            iters = 0;
+            int done = 0;
+            const int rounds = (int)plan.size();
+            for (int r = 0; r < rounds; ++r) {
+                Resolved o_r = o;
+                o_r.n_pc = plan[r];
+                o_r.max_iter = budget;
+                o_r.seed = o.seed + (uint64_t)r;
+                const int l_r = rounds == 1 ? l_act : std::min(L, k - done);      // k - done: what is still in C
+                double resid_r = INFINITY;
+                int iters_r = 0;
+                bool conv_r = false;
+                SRX_TRY(subspace_iterate(ctx, w, k, l_r, o_r, apply, C, true, hv ? hv->d_status : nullptr, resid_r, iters_r, conv_r));
+                resid = std::max(resid, resid_r);
+                iters += iters_r + o.warm;
+                if (!conv_r) {
+                    converged = false;
+                    return SRX_OK;
+                }
+                SRX_TRY(finish_round(r, done, o_r.n_pc));
+                done += o_r.n_pc;
+                if (r + 1 < rounds) {
+                    hipLaunchKernelGGL(k_deflate, dim3((unsigned)(((size_t)k * k + 255) / 256)), dim3(256), 0, ctx->stream, C, k,
+                                       (const double*)w.A2, (const double*)w.dTheta, o_r.n_pc);
+                    SRX_HIP(ctx, hipGetLastError());
+                }
             }
+            st.rounds = (uint32_t)rounds;
+            st.round_counts = plan;
+            return SRX_OK;
+        };
+        const bool have_b = plan_b.size() > plan_a.size();
+        // one round for everything gets a short budget before the safe plan takes over; a plan A that already
+        // deflates (n_pc > 56) keeps the full one
+        int32_t rc = run_plan(plan_a, have_b && plan_a.size() == 1 ? std::min(o.max_iter, 40) : o.max_iter);
+        if (have_b && (rc == SRX_E_NOCONV || (rc == SRX_OK && !converged))) {
+            if (getenv("SRX_PCA_TRACE"))
+                fprintf(stderr, "[srx pca] plan A (%zu round(s)) %s at residual %.3e: rounds of <= %d components instead\n",
+                        plan_a.size(), rc == SRX_OK ? "stalled" : "broke down", resid, plan_b[0]);
+            const int spent = iters;
+            rc = run_plan(plan_b, o.max_iter);
+            iters += spent;
         }
+        SRX_TRY(rc);
         iters -= o.warm;                                              // st.info adds it back once below
     } else {
         if (n_parts != 1) return fail(ctx, SRX_E_ARG, "pca: the SpMM solver needs the matrix resident in one piece");
@@ -2206,6 +2264,8 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
         SRX_TRY(subspace_iterate(ctx, w, k, l_act, o, apply, nullptr, false, hv ? hv->d_status : nullptr, resid, iters,
                                  converged));
         SRX_TRY(finish_round(0, 0, n_pc));
+        st.rounds = 1;
+        st.round_counts.assign(1, n_pc);
     }
     st.d_small = d_small;
     st.info.n_iter = (uint32_t)(iters + o.warm);
@@ -2417,10 +2477,13 @@ static int32_t pca_materialize(srx_mat* m) {
     std::vector<double> blk(small_doubles);
     SRX_TRY(d2h(ctx, blk.data(), st.d_small, small_doubles * 8));
     const double* tail = blk.data() + (size_t)rounds * rblk;
-    // component p lives in round p / kPcaPerRound (the last round may hold more), column p - first component of it
+    // component p lives in the round whose range of components holds it, at column p - first component of that round
+    std::vector<int> first(rounds + 1, 0);
+    for (int r = 0; r < rounds; ++r) first[r + 1] = first[r] + (r < (int)st.round_counts.size() ? st.round_counts[r] : 0);
     auto locate = [&](int p, const double*& hV, const double*& theta, const double*& sgn, int& c) {
-        int r = rounds == 1 ? 0 : std::min(p / kPcaPerRound, rounds - 1);
-        c = p - r * (rounds == 1 ? 0 : kPcaPerRound);
+        int r = 0;
+        while (r + 1 < rounds && p >= first[r + 1]) ++r;
+        c = p - first[r];
         hV = blk.data() + (size_t)r * rblk;
         theta = hV + kl;
         sgn = theta + L;

@@ -410,3 +410,67 @@ def test_more_components_than_one_block_resolves(ctx, store, tol, k, n_pc):
     assert col_err(got[:, iso], want[:, iso]) < 20 * tol and col_err(comps[:, iso], wc[:, iso]) < 20 * tol
     proj = wc @ (wc.T @ comps)                                       # the oracle's subspace contains ours
     assert np.abs(proj - comps).max() < 1e-4
+
+
+@pytest.mark.parametrize("n,g,density,n_pc", [(4000, 800, 0.1, 50), (3000, 300, 0.15, 30), (5000, 1200, 0.05, 56)])
+def test_flat_spectrum_does_not_break_the_block(ctx, n, g, density, n_pc):
+    """Structureless data: the eigenvalues form a nearly flat bulk (theta_64 / theta_50 -> 1), the case where the block
+    needs Chebyshev filters of high total degree.  A degree-12 filter with the leading eigenvalues still in the operator
+    used to collapse the guard columns ("block lost rank").  The degree is now bounded by the block's spectral spread
+    and rounds of <= 16 components take over when one round stalls.  Eigenvalues against the exact SVD; the vectors of
+    a nearly degenerate bulk are not individually determined, so they are checked through their own residuals."""
+    import scipy.sparse as sp
+    import singlerust_amd as sr
+    from singlerust_amd.memory.processing import dim_red
+    rng = np.random.default_rng(n + g)
+    x = sp.random(n, g, density=density, random_state=rng.integers(1 << 30), format="csr",
+                  data_rvs=lambda s: rng.integers(1, 6, s).astype(np.float64), dtype=np.float64)
+    x.sort_indices()
+    keep = np.flatnonzero(np.asarray((x != 0).sum(axis=0)).ravel() > 1)
+    x = x[:, keep].tocsr()
+    x.sort_indices()
+    m = oracle.Csr(n, x.shape[1], x.indptr, x.indices, x.data)
+    a = adata_of(m, ctx, 2)
+    info = dim_red.pca_inplace(a, n_pc, None, None, None, sr.FeatureSelection.None_, None)
+    assert info.n_pc == n_pc and info.residual <= 1e-9
+    dense = x.toarray()
+    z = (dense - dense.mean(axis=0)) / dense.std(axis=0)
+    s = np.linalg.svd(z, compute_uv=False)
+    want_evr = (s * s)[:n_pc] / (s * s).sum()
+    assert np.allclose(a.uns["pca"]["explained_variance_ratio"], want_evr, rtol=1e-8)
+    v = a.uns["pca"]["components"]
+    assert np.abs(v.T @ v - np.eye(n_pc)).max() < 1e-8
+    cv = z.T @ (z @ v)
+    theta = (s * s)[:n_pc]
+    res = np.linalg.norm(cv - v * theta, axis=0) / theta
+    assert res.max() < 1e-7
+    assert col_err(a.obsm["X_pca"], z @ v) < 1e-9                  # scores belong to the returned vectors
+
+
+def test_dominant_structure_with_flat_tail(ctx):
+    """The configuration that ended in "block lost rank" before the degree bound and the safe plan: 20k cells x 20k genes
+    of the bench generator, 1000 HVGs, 50 components — a few strong components (theta_1 / theta_64 ~ 30) over a flat
+    bulk (theta_64 / theta_50 = 0.97-0.99).  The run has to converge, with the exact SVD's eigenvalues, vectors that
+    satisfy their own eigen-equation, and scores that belong to them."""
+    from singlerust_amd import _ffi
+    m, _ = synth_host(2002, 20000, 20000, 0.05)
+    a = adata_of(m, ctx, 1)
+    opts = _ffi.PcaOpts(50, -1, -1, -1, 0, 0, 0, 0.0, 0)
+    res = _ffi.PipelineResult()
+    _ffi.check(_ffi.lib().srx_pipeline(a.x().handle, 1e4, 1000, C.byref(opts), C.byref(res)), ctx.handle)
+    assert res.pca.residual <= 1e-7 and res.pca.n_pc == 50
+    scores, comps = np.zeros((20000, 50)), np.zeros((1000, 50))
+    evr, hv = np.zeros(50), np.zeros(1000, np.uint64)
+    _ffi.check(_ffi.lib().srx_result_fetch(a.x().handle, _ffi.ptr(scores), _ffi.ptr(comps), _ffi.ptr(evr), None, None,
+                                           _ffi.ptr(hv)), ctx.handle)
+    lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
+    dense = oracle.densify_selected(lg, hv)
+    z = (dense - dense.mean(axis=0)) / dense.std(axis=0)
+    s = np.linalg.svd(z, compute_uv=False)
+    theta = (s * s)[:50]
+    assert theta[0] / (s * s)[63] > 10 and (s * s)[63] / theta[49] > 0.9          # the spectrum this test is about
+    assert np.allclose(evr, theta / (s * s).sum(), rtol=1e-5)
+    assert np.abs(comps.T @ comps - np.eye(50)).max() < 1e-6
+    cv = z.T @ (z @ comps)
+    assert (np.linalg.norm(cv - comps * theta, axis=0) / theta).max() < 1e-5
+    assert col_err(scores, z @ comps) < TOL
