@@ -244,10 +244,10 @@ typedef struct srx_pca_opts {
     int32_t block;         /* panel width l; 0 -> default (64)                            */
     int32_t max_iter;      /* bound on the sweeps (one sweep = power applications of C:
                               3 in the Gram solver, 1 in the SpMM solver) after the
-                              warm-up; 0 -> default 200                                   */
-    int32_t solver;        /* srx_pca_solver; 0 = auto (Gram when k <= 8192)              */
+                              warm-up; 0 -> default 200 (Gram) / 600 (SpMM)               */
+    int32_t solver;        /* srx_pca_solver; 0 = auto (Gram when k <= 16384)             */
     double  tol;           /* relative Ritz-residual tolerance; 0 -> default (1e-7 with
-                              f32 storage — 5e-7 in the SpMM solver —, 1e-9 with f64)     */
+                              f32 storage, 1e-9 with f64 storage)                         */
     uint64_t seed;         /* start panel seed (the reference has no randomness here)     */
 } srx_pca_opts;
 

@@ -17,8 +17,6 @@ run --config c2 --hvg 2000 --npc 50 --storage f64
 run --config c2 --hvg 6000 --npc 50 --storage f64
 run --config c2 --hvg 10000 --npc 20
 run --config c2 --hvg 10000 --npc 20 --solver 1
-run --config c1 --hvg 2000 --npc 50
-run --config c1 --hvg 2000 --npc 50 --storage f64
 run --config c3 --hvg 500 --npc 10
 run --config c3 --hvg 4000 --npc 50
 run --config c3 --cells 50000 --hvg 2000 --npc 50

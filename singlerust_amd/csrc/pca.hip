@@ -2081,6 +2081,25 @@ static std::vector<int> plan_rounds(int k, int n_pc, int per) {
     return counts;
 }
 
+// M (64 x 64, row-major) <- diag(s) M: row r scaled by s[r]
+__global__ void k_scale_rows(double* __restrict__ M, const double* __restrict__ s) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < L * L) M[e] *= s[e / L];
+}
+__global__ void k_sub_inplace(double* __restrict__ a, const double* __restrict__ b, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] -= b[i];
+}
+// columns [at, at + n) of the locked block <- the leading n Ritz vectors / values of a finished round
+__global__ void k_lock_columns(double* __restrict__ Vl, double* __restrict__ thl, const double* __restrict__ V,
+                               const double* __restrict__ theta, int k, int at, int n) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)k * n) return;
+    const int i = (int)(e / n), c = (int)(e % n);
+    Vl[(size_t)i * L + at + c] = V[(size_t)i * L + c];
+    if (i == 0) thl[at + c] = theta[c];
+}
+
 // C -= V diag(theta) V^T over the first n columns of V (k x 64): the resolved eigenpairs leave the operator.
 // theta_c * (v_ic * v_jc) is symmetric in (i, j) to the last bit, so C stays exactly symmetric.
 __global__ void k_deflate(double* __restrict__ C, int k, const double* __restrict__ V, const double* __restrict__ theta, int n) {
@@ -2175,6 +2194,60 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
         SRX_HIP(ctx, hipMemcpyAsync(blk + kl + L, w.dSgn, L * 8, hipMemcpyDeviceToDevice, ctx->stream));
         return SRX_OK;
     };
+    // Runs a plan of deflation rounds with the solver's `apply`; `reset` restores the undeflated operator, `deflate`
+    // removes the eigenpairs a round has resolved (w.A2 / w.dTheta, leading n columns).  SRX_E_NOCONV (breakdown) or
+    // converged == false (budget spent) leave the decision to the caller.
+    auto run_plan = [&](const std::vector<int>& plan, int budget, auto& apply, const void* apply_id, bool graphable, auto& reset,
+                        auto& deflate) -> int32_t {
+        SRX_TRY(reset());
+        resid = 0.0;
+        converged = true;
+        iters = 0;
+        int done = 0;
+        const int rounds = (int)plan.size();
+        for (int r = 0; r < rounds; ++r) {
+            Resolved o_r = o;
+            o_r.n_pc = plan[r];
+            o_r.max_iter = budget;
+            o_r.seed = o.seed + (uint64_t)r;
+            const int l_r = rounds == 1 ? l_act : std::min(L, k - done);          // k - done: what is still in the operator
+            double resid_r = INFINITY;
+            int iters_r = 0;
+            bool conv_r = false;
+            SRX_TRY(subspace_iterate(ctx, w, k, l_r, o_r, apply, apply_id, graphable, hv ? hv->d_status : nullptr, resid_r,
+                                     iters_r, conv_r));
+            resid = std::max(resid, resid_r);
+            iters += iters_r + o.warm;
+            if (!conv_r) {
+                converged = false;
+                return SRX_OK;
+            }
+            SRX_TRY(finish_round(r, done, o_r.n_pc));
+            if (r + 1 < rounds) SRX_TRY(deflate(done, o_r.n_pc));
+            done += o_r.n_pc;
+        }
+        st.rounds = (uint32_t)rounds;
+        st.round_counts = plan;
+        return SRX_OK;
+    };
+    // plan A, then plan B if it stalled or broke down.  One round for everything gets a short budget before the safe
+    // plan takes over; a plan A that already deflates (n_pc > 56) keeps the full one.
+    auto solve = [&](auto& apply, const void* apply_id, bool graphable, auto& reset, auto& deflate) -> int32_t {
+        const bool have_b = plan_b.size() > plan_a.size();
+        int32_t rc = run_plan(plan_a, have_b && plan_a.size() == 1 ? std::min(o.max_iter, 40) : o.max_iter, apply, apply_id,
+                              graphable, reset, deflate);
+        if (have_b && (rc == SRX_E_NOCONV || (rc == SRX_OK && !converged))) {
+            if (getenv("SRX_PCA_TRACE"))
+                fprintf(stderr, "[srx pca] plan A (%zu round(s)) %s at residual %.3e: rounds of <= %d components instead\n",
+                        plan_a.size(), rc == SRX_OK ? "stalled" : "broke down", resid, plan_b[0]);
+            const int spent = iters;
+            rc = run_plan(plan_b, o.max_iter, apply, apply_id, graphable, reset, deflate);
+            iters += spent;
+        }
+        SRX_TRY(rc);
+        iters -= o.warm;                                              // st.info adds it back once below
+        return SRX_OK;
+    };
     if (o.solver == 1) {
         // explicit Gram: G = A^T A once (all-reduced), C = D (G - c N mu mu^T) D dense
         double* C;
@@ -2184,7 +2257,7 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
         size_t n_packed = (size_t)(nt128 * (nt128 + 1) / 2) * KG * KG;
         if (!Pk) SRX_TRY(launch_gram<VT>(ctx, *t128p, &Pk, &n_packed));
         SRX_TRY(allreduce_f64(ctx, Pk, n_packed));                // the one exchange of this solver: upper tiles only
-        auto build_c = [&]() -> int32_t {
+        auto reset = [&]() -> int32_t {
             hipLaunchKernelGGL(k_gram_expand, dim3((unsigned)(((size_t)k * k + 255) / 256)), dim3(256), 0, ctx->stream, Pk,
                                nt128, k, (const double*)w.d, (const double*)w.mu, o.center, n_cells, C);
             SRX_HIP(ctx, hipGetLastError());
@@ -2197,58 +2270,26 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
             SRX_HIP(ctx, hipGetLastError());
             return SRX_OK;
         };
-        // runs a plan; SRX_E_NOCONV (breakdown) or converged == false (budget spent) leave the decision to the caller
-        auto run_plan = [&](const std::vector<int>& plan, int budget) -> int32_t {
-            SRX_TRY(build_c());
-            resid = 0.0;
-            converged = true;
-            iters = 0;
-            int done = 0;
-            const int rounds = (int)plan.size();
-            for (int r = 0; r < rounds; ++r) {
-                Resolved o_r = o;
-                o_r.n_pc = plan[r];
-                o_r.max_iter = budget;
-                o_r.seed = o.seed + (uint64_t)r;
-                const int l_r = rounds == 1 ? l_act : std::min(L, k - done);      // k - done: what is still in C
-                double resid_r = INFINITY;
-                int iters_r = 0;
-                bool conv_r = false;
-                SRX_TRY(subspace_iterate(ctx, w, k, l_r, o_r, apply, C, true, hv ? hv->d_status : nullptr, resid_r, iters_r, conv_r));
-                resid = std::max(resid, resid_r);
-                iters += iters_r + o.warm;
-                if (!conv_r) {
-                    converged = false;
-                    return SRX_OK;
-                }
-                SRX_TRY(finish_round(r, done, o_r.n_pc));
-                done += o_r.n_pc;
-                if (r + 1 < rounds) {
-                    hipLaunchKernelGGL(k_deflate, dim3((unsigned)(((size_t)k * k + 255) / 256)), dim3(256), 0, ctx->stream, C, k,
-                                       (const double*)w.A2, (const double*)w.dTheta, o_r.n_pc);
-                    SRX_HIP(ctx, hipGetLastError());
-                }
-            }
-            st.rounds = (uint32_t)rounds;
-            st.round_counts = plan;
+        auto deflate = [&](int, int n_r) -> int32_t {                  // C -= V diag(theta) V^T
+            hipLaunchKernelGGL(k_deflate, dim3((unsigned)(((size_t)k * k + 255) / 256)), dim3(256), 0, ctx->stream, C, k,
+                               (const double*)w.A2, (const double*)w.dTheta, n_r);
+            SRX_HIP(ctx, hipGetLastError());
             return SRX_OK;
         };
-        const bool have_b = plan_b.size() > plan_a.size();
-        // one round for everything gets a short budget before the safe plan takes over; a plan A that already
-        // deflates (n_pc > 56) keeps the full one
-        int32_t rc = run_plan(plan_a, have_b && plan_a.size() == 1 ? std::min(o.max_iter, 40) : o.max_iter);
-        if (have_b && (rc == SRX_E_NOCONV || (rc == SRX_OK && !converged))) {
-            if (getenv("SRX_PCA_TRACE"))
-                fprintf(stderr, "[srx pca] plan A (%zu round(s)) %s at residual %.3e: rounds of <= %d components instead\n",
-                        plan_a.size(), rc == SRX_OK ? "stalled" : "broke down", resid, plan_b[0]);
-            const int spent = iters;
-            rc = run_plan(plan_b, o.max_iter);
-            iters += spent;
-        }
-        SRX_TRY(rc);
-        iters -= o.warm;                                              // st.info adds it back once below
+        SRX_TRY(solve(apply, C, true, reset, deflate));
     } else {
         if (n_parts != 1) return fail(ctx, SRX_E_ARG, "pca: the SpMM solver needs the matrix resident in one piece");
+        // matrix-free: Z^T (Z W) by a forward and a transposed SpMM; resolved eigenpairs are deflated IMPLICITLY,
+        // W' -= V_lock (theta_lock * (V_lock^T W)) with the locked vectors in a k x 64 block (plan B locks <= 48)
+        double* v_lock;
+        SRX_TRY(scratch(ctx, "pca_lock", (kl + L) * 8, (void**)&v_lock));
+        double* th_lock = v_lock + kl;
+        int n_lock = 0;
+        auto reset = [&]() -> int32_t {
+            n_lock = 0;
+            SRX_HIP(ctx, hipMemsetAsync(v_lock, 0, (kl + L) * 8, ctx->stream));
+            return SRX_OK;
+        };
         auto apply = [&](const double* Win, double* Wout) -> int32_t {
             hipLaunchKernelGGL((k_make_panel<PT>), dim3(1), dim3(1024), 0, ctx->stream, Win, w.d, w.mu,
                                (const double*)nullptr, k, o.center, P, cvec);
@@ -2259,13 +2300,24 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
             hipLaunchKernelGGL(k_finish_t, dim3((unsigned)((kl + 255) / 256)), dim3(256), 0, ctx->stream, w.T, w.d, w.mu,
                                k, o.center, Wout);
             SRX_HIP(ctx, hipGetLastError());
+            if (n_lock > 0) {
+                SRX_TRY(gram2(ctx, w, v_lock, Win, k));                               // dHG <- V_lock^T W (64 x 64)
+                hipLaunchKernelGGL(k_scale_rows, dim3((L * L + 255) / 256), dim3(256), 0, ctx->stream, w.dHG, (const double*)th_lock);
+                hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, (const double*)v_lock, (const double*)w.dHG, k, w.T);
+                hipLaunchKernelGGL(k_sub_inplace, dim3((unsigned)((kl + 255) / 256)), dim3(256), 0, ctx->stream, Wout, (const double*)w.T, kl);
+                SRX_HIP(ctx, hipGetLastError());
+            }
             return SRX_OK;
         };
-        SRX_TRY(subspace_iterate(ctx, w, k, l_act, o, apply, nullptr, false, hv ? hv->d_status : nullptr, resid, iters,
-                                 converged));
-        SRX_TRY(finish_round(0, 0, n_pc));
-        st.rounds = 1;
-        st.round_counts.assign(1, n_pc);
+        auto deflate = [&](int, int n_r) -> int32_t {                  // the round's vectors join the locked block
+            if (n_lock + n_r > L) return fail(ctx, SRX_E_ARG, "pca: more than %d locked vectors in the matrix-free solver", L);
+            hipLaunchKernelGGL(k_lock_columns, dim3((unsigned)(((size_t)k * n_r + 255) / 256)), dim3(256), 0, ctx->stream, v_lock,
+                               th_lock, (const double*)w.A2, (const double*)w.dTheta, k, n_lock, n_r);
+            SRX_HIP(ctx, hipGetLastError());
+            n_lock += n_r;
+            return SRX_OK;
+        };
+        SRX_TRY(solve(apply, nullptr, false, reset, deflate));
     }
     st.d_small = d_small;
     st.info.n_iter = (uint32_t)(iters + o.warm);
@@ -2285,20 +2337,22 @@ static int32_t resolve_opts(srx_ctx* ctx, const srx_pca_opts* opts, int k, uint6
     o.n_pc = std::min(want, k);
     o.center = (!opts || opts->center < 0) ? 1 : (opts->center != 0);           // :55
     o.scale = (!opts || opts->scale < 0) ? 1 : (opts->scale != 0);              // :56
-    o.max_iter = (opts && opts->max_iter > 0) ? opts->max_iter : 200;
+    o.max_iter = (opts && opts->max_iter > 0) ? opts->max_iter : 0;          // default set below, once the solver is known
     o.tol = (opts && opts->tol > 0) ? opts->tol : 0.0;
     o.seed = opts ? opts->seed : 0;
     o.solver = opts ? opts->solver : 0;
     if (o.solver < 0 || o.solver > 2) return fail(ctx, SRX_E_ARG, "pca: solver must be 0 (auto), 1 (gram) or 2 (spmm)");
-    // auto: the explicit Gram matrix as long as the fused compaction takes the selection (k <= 64 tiles of 128): at
-    // c2's size k = 6000 / 8000 cost 13.6 / 20.5 ms per pipeline, a fraction of what the matrix-free iteration needs
-    if (o.solver == 0) o.solver = k <= kWave * KG ? 1 : 2;
+    // auto: the explicit Gram matrix as long as it fits (k <= 16384: 2 GB of f64).  At c2's size k = 6000 / 8000 cost
+    // 13.6 / 20.5 ms per pipeline against 23.7 / 30 of the matrix-free iteration, and on a flat-tailed spectrum at
+    // k = 9000 (general compaction route) 105 ms against 297
+    if (o.solver == 0) o.solver = k <= 16384 ? 1 : 2;
+    // a sweep is `power` applications of C: the same default budget of 600 applications for both solvers
+    if (o.max_iter == 0) o.max_iter = o.solver == 1 ? 200 : 600;
     o.power = o.solver == 1 ? 3 : 1;
     o.warm = o.solver == 1 ? 2 : 0;
     if (o.solver == 1 && k > 16384) return fail(ctx, SRX_E_ARG, "pca: the Gram solver holds a k x k f64 matrix; k=%d is too large", k);
     // default tolerance on the relative Ritz residual: what the arithmetic of the solver supports
-    // (the matrix-free solver forms its products in f32 with f32 storage: its residuals level off at ~1.3e-7)
-    if (o.tol == 0.0) o.tol = f32 ? (o.solver == 2 ? 5e-7 : 1e-7) : 1e-9;
+    if (o.tol == 0.0) o.tol = f32 ? 1e-7 : 1e-9;
     if (o.n_pc < 1) return fail(ctx, SRX_E_ARG, "pca: n_components must be >= 1");
     if (opts && opts->block != 0 && opts->block != L) return fail(ctx, SRX_E_ARG, "pca: only block = %d is built", L);
     l_act = std::min(L, k);
@@ -2455,7 +2509,12 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     st.info.solver = (uint32_t)o.solver;
     int32_t rc;
     const HvgDev* hvp = dev_sel ? &hv : nullptr;
-    if (is_f32(m)) rc = run_pca<float, float>(ctx, &t256, 1, need128 ? &t128 : nullptr, nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
+    // f32 storage: f32 panels and products for the one transform of the Gram route; the matrix-free iteration runs its
+    // panels in f64 (f32 products of Z W level the residuals of the small components off at ~1e-7 theta_1 / theta_i:
+    // 6.6e-5 at k = 9000 on a flat-tailed matrix, however many sweeps)
+    if (is_f32(m) && o.solver == 2)
+        rc = run_pca<float, double>(ctx, &t256, 1, need128 ? &t128 : nullptr, nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
+    else if (is_f32(m)) rc = run_pca<float, float>(ctx, &t256, 1, need128 ? &t128 : nullptr, nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
     else rc = run_pca<double, double>(ctx, &t256, 1, need128 ? &t128 : nullptr, nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
     if ((rc != SRX_OK && rc != SRX_E_NOCONV) || !st.d_small) return rc;      // d_small unset: the solve broke down early
     SRX_TRY(stash_results(ctx, st, k, o.n_pc, dev_sel ? &hv : nullptr, mu, sd, trace, selv));

@@ -128,10 +128,10 @@ def test_wide_matrix_without_the_16bit_index_mirror(ctx, tmp_path):
     assert np.array_equal(back.values(np.float64), m.values.astype(np.float64))
 
 
-@pytest.mark.parametrize("solver", [0, 1])
+@pytest.mark.parametrize("solver", [0, 2])
 def test_more_than_8192_selected_features(ctx, solver):
     """FeatureSelection::None on 9000 genes: past the 64 tile counters of the fused compaction (general route: row-major
-    compaction, then re-tiling) and, with solver auto, past the Gram solver's default range (matrix-free SpMM solver)."""
+    compaction, then re-tiling), with the Gram solver (auto up to k = 16384) and the matrix-free SpMM solver."""
     import singlerust_amd as sr
     from singlerust_amd.memory import processing
     from singlerust_amd.memory.processing import dim_red
@@ -144,7 +144,7 @@ def test_more_than_8192_selected_features(ctx, solver):
     info = dim_red.pca_inplace(a, 6, None, None, None, sr.FeatureSelection.VarianceThreshold(0.0), None, solver=solver)
     sel = a.uns["pca"]["selected_features"]
     assert np.array_equal(sel, np.flatnonzero(oracle.compute_variance(lg, COLUMN) > 0.0))
-    assert info.k == len(sel) > 8192 and info.solver == (2 if solver == 0 else 1)
+    assert info.k == len(sel) > 8192 and info.solver == (1 if solver == 0 else 2)
     want, wc, wevr, *_ = pca_oracle.pca_inplace(lg, 6, None, None, sel)
     assert np.allclose(a.uns["pca"]["explained_variance_ratio"], wevr, rtol=1e-6)
     assert col_err(a.obsm["X_pca"], want) < 1e-6 and col_err(a.uns["pca"]["components"], wc) < 1e-6
