@@ -2066,9 +2066,9 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
 constexpr int kPcaPerRound = 48;
 constexpr int kPcaPerRoundSafe = 16;       // the fallback plan: 48 guard columns per round
 // Components per round when at most `per` are asked of one round.
-static std::vector<int> plan_rounds(int k, int n_pc, int per) {
+static std::vector<int> plan_rounds(int k /* dimension of the operator's range */, int n_pc, int per) {
     std::vector<int> counts;
-    if (k <= L) {                            // the block spans the whole space: one exact round
+    if (k <= L) {                            // the block spans the whole range: one exact round
         counts.push_back(n_pc);
         return counts;
     }
@@ -2158,9 +2158,11 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
     //           <= 0").  Once a round has deflated the leading eigenpairs the remaining spectrum is narrow and the same
     //           filters are harmless.
     const int n_pc = o.n_pc;
-    const std::vector<int> plan_a = plan_rounds(k, n_pc, n_pc <= L - 8 ? n_pc : kPcaPerRound);
+    // dimension of the operator's range: min(k, N - 1) (N when not centred); a block as wide as that is exact
+    const int dim = (int)std::min<double>((double)k, n_cells - (o.center ? 1.0 : 0.0));
+    const std::vector<int> plan_a = plan_rounds(dim, n_pc, n_pc <= L - 8 ? n_pc : kPcaPerRound);
     const int n_b = (n_pc + kPcaPerRoundSafe - 1) / kPcaPerRoundSafe;
-    const std::vector<int> plan_b = plan_rounds(k, n_pc, (n_pc + n_b - 1) / n_b);
+    const std::vector<int> plan_b = plan_rounds(dim, n_pc, (n_pc + n_b - 1) / n_b);
     const int rounds_cap = (int)std::max(plan_a.size(), plan_b.size());
     // one allocation: the scores, then the block of small results (layout: srx_pca_state::d_small)
     const size_t score_bytes = (cc.n_rows ? cc.n_rows : 1) * (size_t)n_pc * 8;
@@ -2210,7 +2212,7 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
             o_r.n_pc = plan[r];
             o_r.max_iter = budget;
             o_r.seed = o.seed + (uint64_t)r;
-            const int l_r = rounds == 1 ? l_act : std::min(L, k - done);          // k - done: what is still in the operator
+            const int l_r = rounds == 1 ? l_act : std::min(L, dim - done);        // dim - done: what is still in the operator
             double resid_r = INFINITY;
             int iters_r = 0;
             bool conv_r = false;
@@ -2355,12 +2357,17 @@ static int32_t resolve_opts(srx_ctx* ctx, const srx_pca_opts* opts, int k, uint6
     if (o.tol == 0.0) o.tol = f32 ? 1e-7 : 1e-9;
     if (o.n_pc < 1) return fail(ctx, SRX_E_ARG, "pca: n_components must be >= 1");
     if (opts && opts->block != 0 && opts->block != L) return fail(ctx, SRX_E_ARG, "pca: only block = %d is built", L);
-    l_act = std::min(L, k);
+    // Z has rank <= min(k, N - 1) (N when not centred): a block wider than that cannot stay independent under C
+    const uint64_t rank_bound = std::min<uint64_t>((uint64_t)k, Ng - (o.center ? 1 : 0));
+    if ((uint64_t)o.n_pc > rank_bound)
+        return fail(ctx, SRX_E_ARG, "pca: n_components %d exceeds the rank of the data (min(k, N%s) = %llu)", o.n_pc,
+                    o.center ? " - 1" : "", (unsigned long long)rank_bound);
+    l_act = (int)std::min<uint64_t>((uint64_t)L, rank_bound);
     if (o.n_pc > l_act && o.solver != 1)
         return fail(ctx, SRX_E_ARG, "pca: n_components %d exceeds what the %d-column block resolves (max %d)", o.n_pc, L, l_act);
     // beyond L - 8 components the Gram solver runs deflation rounds on the explicit k x k matrix; the matrix-free
     // solver has nothing to deflate
-    if (k > L && o.n_pc > L - 8 && o.solver != 1)
+    if (rank_bound > (uint64_t)L && o.n_pc > L - 8 && o.solver != 1)
         return fail(ctx, SRX_E_ARG, "pca: n_components %d > %d needs the Gram solver (k <= 16384, opts.solver = 1)", o.n_pc, L - 8);
     return SRX_OK;
 }

@@ -473,3 +473,28 @@ def test_dominant_structure_with_flat_tail(ctx):
     cv = z.T @ (z @ comps)
     assert (np.linalg.norm(cv - comps * theta, axis=0) / theta).max() < 1e-5
     assert col_err(scores, z @ comps) < TOL
+
+
+@pytest.mark.parametrize("n,k,n_pc", [(60, 300, 50), (40, 200, 39), (64, 500, 10), (65, 500, 56)])
+def test_fewer_cells_than_the_block_is_wide(ctx, n, k, n_pc):
+    """N - 1 < 64 <= k: the centred matrix has rank N - 1, the 64-column block must be narrowed to it (it used to lose
+    rank in the first CholeskyQR); asking for more components than the rank is refused."""
+    import singlerust_amd as sr
+    from singlerust_amd import _ffi
+    from singlerust_amd.memory import processing
+    from singlerust_amd.memory.processing import dim_red
+    m, _ = synth_host(900 + n, n, 1500, 0.2)
+    a = adata_of(m, ctx, 2)
+    processing.normalize_total_inplace(a, 1e4, sr.Direction.Row)
+    processing.log1p_transform_inplace(a)
+    info = dim_red.pca_inplace(a, n_pc, None, None, None, sr.FeatureSelection.HighlyVariable(k), None)
+    lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
+    sel = a.uns["pca"]["selected_features"]
+    dense = oracle.densify_selected(lg, sel)
+    live = dense.std(axis=0) > 0                                   # zero-variance columns: std treated as 1, nothing to compare
+    want, wc, wevr, *_ = pca_oracle.pca_inplace(lg, n_pc, None, None, sel[live])
+    assert info.n_pc == n_pc
+    assert col_err(a.obsm["X_pca"], want) < 1e-7 and col_err(a.uns["pca"]["components"][live], wc) < 1e-7
+    with pytest.raises(_ffi.SrxError) as e:
+        dim_red.pca_inplace(a, n, None, None, None, sr.FeatureSelection.HighlyVariable(k), None)     # rank is N - 1
+    assert e.value.code == _ffi.E_ARG
