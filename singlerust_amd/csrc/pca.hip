@@ -1170,18 +1170,29 @@ __global__ void k_init_block(uint64_t seed, int k, int l_act, double* __restrict
 // k_chol_factor: one workgroup, right-looking: at step j every thread subtracts a_jr a_jc / a_jj from the
 // trailing elements it owns (one barrier per step).  Rout (L x L, row-major) receives R, zero outside
 // the upper triangle of the leading block; dinv[j] = 1 / R[j][j] (0 for j >= n).
+// `shifted` (the robust mode of the driver): a pivot that has fallen below 1e-13 of the largest diagonal entry of G is
+// held at that floor instead of being reported — the factor then belongs to a slightly shifted G, W = Wp R^-1 stays
+// bounded and of full rank, and a second plain pass (CholeskyQR2) makes it orthonormal (shifted CholeskyQR3 idea).
 __global__ __launch_bounds__(1024) void k_chol_factor(const double* __restrict__ G, int n, double* __restrict__ Rout,
-                                                      double* __restrict__ dinv, int* __restrict__ status) {
+                                                      double* __restrict__ dinv, int* __restrict__ status, int shifted) {
     __shared__ double A[L][L + 1];
+    __shared__ double s_floor;
     const int tid = threadIdx.x;
     for (int e = tid; e < L * L; e += 1024) {
         const int r = e >> 6, c = e & 63;
         A[r][c] = (r < n && c < n) ? G[(size_t)r * L + c] : 0.0;
     }
     __syncthreads();
+    if (tid == 0) {
+        double mx = 0.0;
+        for (int j = 0; j < n; ++j) mx = A[j][j] > mx ? A[j][j] : mx;
+        s_floor = shifted ? 1e-13 * mx : 0.0;
+    }
+    __syncthreads();
     bool bad = false;
     for (int j = 0; j < n; ++j) {
-        const double d = A[j][j];
+        double d = A[j][j];
+        if (shifted && !(d > s_floor)) d = s_floor;          // (a zero matrix keeps its zero pivot: reported below)
         if (!(d > 0.0)) bad = true;
         const double inv = rsqrt(d), inv2 = inv * inv;
         if (tid < L) {
@@ -1733,6 +1744,8 @@ static int32_t launch_gram(srx_ctx* ctx, const Tiled& g, double** packed_out, si
 // ---- the driver ---------------------------------------------------------------------------------
 struct Resolved {
     int n_pc, center, scale, max_iter, solver;
+    bool robust = false;     // last resort after a breakdown: CholeskyQR after every application of C, shifted
+                             // CholeskyQR3, plain sweeps instead of Chebyshev filters
     int power = 1;           // applications of C per Rayleigh–Ritz step
     int warm = 0;            // leading sweeps of `power` applications + CholeskyQR WITHOUT a Rayleigh–Ritz step
     double tol;
@@ -1830,7 +1843,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
                                 bool& converged) {
     const size_t kl = (size_t)k * L;
     const bool use_graph = graphable && !getenv("SRX_NO_GRAPH");
-    const bool use_cheb = l_act > o.n_pc && !getenv("SRX_NO_CHEB");      // both solvers: the filter only needs `apply`
+    const bool use_cheb = l_act > o.n_pc && !o.robust && !getenv("SRX_NO_CHEB");      // both solvers: the filter only needs `apply`
     constexpr int kSlots = srx_ctx::kAsyncSlots, kSlotDoubles = 8;
     if (!ctx->pin_async) {
         SRX_HIP(ctx, hipHostMalloc((void**)&ctx->pin_async, kSlots * kSlotDoubles * sizeof(double), hipHostMallocDefault));
@@ -1844,7 +1857,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
                                      (int)kJacobiLds));
     // what a captured segment depends on besides its own schedule: shapes, options, every buffer it touches
     char key0[256];
-    snprintf(key0, sizeof key0, "k%d l%d p%d w%d n%d s%llu|%p %p %p %p %p %p %p %p %p", k, l_act, o.power, o.warm, o.n_pc,
+    snprintf(key0, sizeof key0, "k%d l%d p%d w%d r%d n%d s%llu|%p %p %p %p %p %p %p %p %p", k, l_act, o.power, o.warm, o.robust ? 1 : 0, o.n_pc,
              (unsigned long long)o.seed, apply_id, (void*)w.W, (void*)w.Wp, (void*)w.A1, (void*)w.A2, (void*)w.small,
              (void*)w.gpart, (void*)d_status, (void*)d_status_sel);
     const std::string key_base(key0);
@@ -1857,9 +1870,16 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     // thread of the substitution owns one row); G lands in dHG + L*L
     auto orth = [&](const double* src) -> int32_t {
         SRX_TRY(gram2(ctx, w, src, src, k));
-        hipLaunchKernelGGL(k_chol_factor, dim3(1), dim3(1024), 0, ctx->stream, w.dHG + L * L, l_act, w.dM, w.dDinv, d_status);
+        hipLaunchKernelGGL(k_chol_factor, dim3(1), dim3(1024), 0, ctx->stream, w.dHG + L * L, l_act, w.dM, w.dDinv, d_status,
+                           o.robust ? 1 : 0);
         hipLaunchKernelGGL(k_trsm_rows, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, src, w.dM, w.dDinv, k, w.W);
         SRX_HIP(ctx, hipGetLastError());
+        if (o.robust) {                         // second pass: the first one may have run on a shifted Gram matrix
+            SRX_TRY(gram2(ctx, w, w.W, w.W, k));
+            hipLaunchKernelGGL(k_chol_factor, dim3(1), dim3(1024), 0, ctx->stream, w.dHG + L * L, l_act, w.dM, w.dDinv, d_status, 1);
+            hipLaunchKernelGGL(k_trsm_rows, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, (const double*)w.W, w.dM, w.dDinv, k, w.W);
+            SRX_HIP(ctx, hipGetLastError());
+        }
         return SRX_OK;
     };
     // `n` applications of C starting from `src`, ping-ponging between Wp and A1 (no copies); returns where
@@ -2199,8 +2219,8 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
     // Runs a plan of deflation rounds with the solver's `apply`; `reset` restores the undeflated operator, `deflate`
     // removes the eigenpairs a round has resolved (w.A2 / w.dTheta, leading n columns).  SRX_E_NOCONV (breakdown) or
     // converged == false (budget spent) leave the decision to the caller.
-    auto run_plan = [&](const std::vector<int>& plan, int budget, auto& apply, const void* apply_id, bool graphable, auto& reset,
-                        auto& deflate) -> int32_t {
+    auto run_plan = [&](const std::vector<int>& plan, int budget, bool robust, auto& apply, const void* apply_id, bool graphable,
+                        auto& reset, auto& deflate) -> int32_t {
         SRX_TRY(reset());
         resid = 0.0;
         converged = true;
@@ -2212,6 +2232,12 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
             o_r.n_pc = plan[r];
             o_r.max_iter = budget;
             o_r.seed = o.seed + (uint64_t)r;
+            if (robust) {                       // CholeskyQR after every application, the same number of applications up front
+                o_r.robust = true;
+                o_r.warm = o.warm * o.power;
+                o_r.power = 1;
+                o_r.max_iter = budget * o.power;
+            }
             const int l_r = rounds == 1 ? l_act : std::min(L, dim - done);        // dim - done: what is still in the operator
             double resid_r = INFINITY;
             int iters_r = 0;
@@ -2236,14 +2262,27 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
     // plan takes over; a plan A that already deflates (n_pc > 56) keeps the full one.
     auto solve = [&](auto& apply, const void* apply_id, bool graphable, auto& reset, auto& deflate) -> int32_t {
         const bool have_b = plan_b.size() > plan_a.size();
-        int32_t rc = run_plan(plan_a, have_b && plan_a.size() == 1 ? std::min(o.max_iter, 40) : o.max_iter, apply, apply_id,
+        if (getenv("SRX_PCA_ROBUST")) {                               // test switch: the last-resort mode from the start
+            SRX_TRY(run_plan(have_b ? plan_b : plan_a, o.max_iter, true, apply, apply_id, graphable, reset, deflate));
+            iters -= o.warm;
+            return SRX_OK;
+        }
+        int32_t rc = run_plan(plan_a, have_b && plan_a.size() == 1 ? std::min(o.max_iter, 40) : o.max_iter, false, apply, apply_id,
                               graphable, reset, deflate);
         if (have_b && (rc == SRX_E_NOCONV || (rc == SRX_OK && !converged))) {
             if (getenv("SRX_PCA_TRACE"))
                 fprintf(stderr, "[srx pca] plan A (%zu round(s)) %s at residual %.3e: rounds of <= %d components instead\n",
                         plan_a.size(), rc == SRX_OK ? "stalled" : "broke down", resid, plan_b[0]);
             const int spent = iters;
-            rc = run_plan(plan_b, o.max_iter, apply, apply_id, graphable, reset, deflate);
+            rc = run_plan(plan_b, o.max_iter, false, apply, apply_id, graphable, reset, deflate);
+            iters += spent;
+        }
+        if (rc == SRX_E_NOCONV) {
+            // last resort: a block whose spectrum spans more than ~1e8 between two CholeskyQRs (small exact-rank
+            // problems: k = 10 features of 6 cells have theta_1 / theta_5 ~ 1e3 and a sweep is three applications)
+            if (getenv("SRX_PCA_TRACE")) fprintf(stderr, "[srx pca] breakdown again: robust mode (CholeskyQR3 after every application)\n");
+            const int spent = iters;
+            rc = run_plan(have_b ? plan_b : plan_a, o.max_iter, true, apply, apply_id, graphable, reset, deflate);
             iters += spent;
         }
         SRX_TRY(rc);

@@ -498,3 +498,50 @@ def test_fewer_cells_than_the_block_is_wide(ctx, n, k, n_pc):
     with pytest.raises(_ffi.SrxError) as e:
         dim_red.pca_inplace(a, n, None, None, None, sr.FeatureSelection.HighlyVariable(k), None)     # rank is N - 1
     assert e.value.code == _ffi.E_ARG
+
+
+def test_tiny_exact_rank_problem_is_reliable(ctx):
+    """6 cells (one of them empty) x 40 genes, 10 HVGs, 3 components: the block is as wide as the rank (5) and its
+    spectrum spans ~1e3, so a sweep of three applications squares to a Gram matrix beyond what one CholeskyQR takes —
+    the run used to fail or succeed depending on the summation order of the atomics.  The last-resort mode (shifted
+    CholeskyQR3 after every application) makes it reliable: ten runs, ten results equal to the exact SVD."""
+    import scipy.sparse as sp
+    from singlerust_amd import _ffi
+    rng = np.random.default_rng(3)
+    x = sp.random(6, 40, density=0.4, random_state=2, data_rvs=lambda s: rng.integers(1, 9, s).astype(np.float64), dtype=np.float64,
+                  format="csr")
+    x = sp.vstack([x[:1], sp.csr_matrix((1, 40)), x[2:]]).tocsr()
+    x.sort_indices()
+    m = oracle.Csr(6, 40, x.indptr, x.indices, x.data)
+    lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
+    for _ in range(10):
+        a = adata_of(m, ctx, 2)
+        opts = _ffi.PcaOpts(3, -1, -1, -1, 0, 0, 0, 0.0, 5)
+        res = _ffi.PipelineResult()
+        _ffi.check(_ffi.lib().srx_pipeline(a.x().handle, 1e4, 10, C.byref(opts), C.byref(res)), ctx.handle)
+        scores, comps, hv = np.zeros((6, 3)), np.zeros((10, 3)), np.zeros(10, np.uint64)
+        _ffi.check(_ffi.lib().srx_result_fetch(a.x().handle, _ffi.ptr(scores), _ffi.ptr(comps), None, None, None, _ffi.ptr(hv)),
+                   ctx.handle)
+        dense = oracle.densify_selected(lg, hv)
+        live = dense.std(axis=0) > 0
+        want, wc, *_ = pca_oracle.pca_inplace(lg, 3, None, None, hv[live])
+        assert col_err(scores, want) < 1e-7 and col_err(comps[live], wc) < 1e-7
+
+
+def test_robust_mode_gives_the_same_answers(ctx, monkeypatch):
+    """SRX_PCA_ROBUST=1 runs the last-resort mode from the start (CholeskyQR3 after every application of C, plain sweeps):
+    the planted golden case and a deflation-round case against the oracle."""
+    import singlerust_amd as sr
+    from singlerust_amd.memory import processing
+    from singlerust_amd.memory.processing import dim_red
+    monkeypatch.setenv("SRX_PCA_ROBUST", "1")
+    m, _ = synth_host(77 + 130, 6000, 900, 0.08)
+    a = adata_of(m, ctx, 2)
+    processing.normalize_total_inplace(a, 1e4, sr.Direction.Row)
+    processing.log1p_transform_inplace(a)
+    dim_red.pca_inplace(a, 57, None, None, None, sr.FeatureSelection.HighlyVariable(130), None)
+    lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
+    want, wc, wevr, *_ = pca_oracle.pca_inplace(lg, 57, None, None, a.uns["pca"]["selected_features"])
+    assert np.allclose(a.uns["pca"]["explained_variance_ratio"], wevr, rtol=1e-6)
+    comps = a.uns["pca"]["components"]
+    assert np.abs(wc @ (wc.T @ comps) - comps).max() < 1e-4 and col_err(a.obsm["X_pca"][:, :10], want[:, :10]) < 1e-6
