@@ -1744,6 +1744,8 @@ static int32_t launch_gram(srx_ctx* ctx, const Tiled& g, double** packed_out, si
 // ---- the driver ---------------------------------------------------------------------------------
 struct Resolved {
     int n_pc, center, scale, max_iter, solver;
+    double bail_ratio = 0.0; // > 0: give the round up after its first Ritz step when theta_l / theta_npc exceeds this (the
+                             // caller has a plan with more guard columns per round)
     bool robust = false;     // last resort after a breakdown: CholeskyQR after every application of C, shifted
                              // CholeskyQR3, plain sweeps instead of Chebyshev filters
     int power = 1;           // applications of C per Rayleigh–Ritz step
@@ -2021,6 +2023,10 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
             break;
         }
         if (iters >= o.max_iter) break;
+        if (first && o.bail_ratio > 0.0 && ratio > o.bail_ratio) {
+            if (getenv("SRX_PCA_TRACE")) fprintf(stderr, "[srx pca] flat tail (theta_l / theta_npc = %.3f): leaving the round to the safe plan\n", ratio);
+            break;                                 // converged stays false
+        }
         if (cheb) {
             // degree: T_d(t_a) >= 4 r / tol with t_a = (2 theta_npc - b) / b = 2 / ratio - 1
             const double ta = ratio > 0 && ratio < 1 ? 2.0 / ratio - 1.0 : 1.0;
@@ -2220,7 +2226,7 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
     // removes the eigenpairs a round has resolved (w.A2 / w.dTheta, leading n columns).  SRX_E_NOCONV (breakdown) or
     // converged == false (budget spent) leave the decision to the caller.
     auto run_plan = [&](const std::vector<int>& plan, int budget, bool robust, auto& apply, const void* apply_id, bool graphable,
-                        auto& reset, auto& deflate) -> int32_t {
+                        auto& reset, auto& deflate, double bail = 0.0) -> int32_t {
         SRX_TRY(reset());
         resid = 0.0;
         converged = true;
@@ -2232,6 +2238,7 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
             o_r.n_pc = plan[r];
             o_r.max_iter = budget;
             o_r.seed = o.seed + (uint64_t)r;
+            o_r.bail_ratio = bail;
             if (robust) {                       // CholeskyQR after every application, the same number of applications up front
                 o_r.robust = true;
                 o_r.warm = o.warm * o.power;
@@ -2267,8 +2274,10 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
             iters -= o.warm;
             return SRX_OK;
         }
+        // (a one-round plan A is also given up at once when its first Ritz step shows a flat tail, theta_64 / theta_npc >
+        //  0.93: such a round needs a total filter degree of 45+ and plan B gets there sooner)
         int32_t rc = run_plan(plan_a, have_b && plan_a.size() == 1 ? std::min(o.max_iter, 40) : o.max_iter, false, apply, apply_id,
-                              graphable, reset, deflate);
+                              graphable, reset, deflate, have_b && plan_a.size() == 1 ? 0.93 : 0.0);
         if (have_b && (rc == SRX_E_NOCONV || (rc == SRX_OK && !converged))) {
             if (getenv("SRX_PCA_TRACE"))
                 fprintf(stderr, "[srx pca] plan A (%zu round(s)) %s at residual %.3e: rounds of <= %d components instead\n",
