@@ -2090,7 +2090,8 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
 // Components per deflation round when more than L - 8 are asked of a k > L problem (the block keeps 16 guard
 // columns), and the number of rounds; the last round takes everything that is left once <= L dimensions remain.
 constexpr int kPcaPerRound = 48;
-constexpr int kPcaPerRoundSafe = 16;       // the fallback plan: 48 guard columns per round
+constexpr int kPcaPerRoundSafe = 32;       // the fallback plan: >= 32 guard columns per round (c2, 1000 HVGs, 50 components:
+                                           // 12 -> 19.6 ms, 16 -> 16.3, 24 -> 15.5, 32 -> 10.7)
 // Components per round when at most `per` are asked of one round.
 static std::vector<int> plan_rounds(int k /* dimension of the operator's range */, int n_pc, int per) {
     std::vector<int> counts;
@@ -2177,7 +2178,7 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
     // subspace is the one after them.
     //   plan A: everything in one round up to 56 components (48 per round beyond) — two Ritz steps when the spectrum
     //           decays across the block, the normal case;
-    //   plan B: rounds of <= 16 components with 48 guard columns each.  Taken when plan A breaks down or stalls: a flat
+    //   plan B: rounds of <= 32 components with 32+ guard columns each.  Taken when plan A breaks down or stalls: a flat
     //           tail (theta_64 / theta_50 -> 1) needs Chebyshev filters of high total degree, and with the dominant
     //           eigenvalues still in the operator (theta_1 / theta_64 ~ 20-100) a degree-12 filter amplifies the leading
     //           directions by T_12(t_1) ~ 1e20 over the guard columns — the block collapses onto them ("Cholesky pivot
