@@ -14,7 +14,7 @@ ctx = sr.Context.default()
 fails = 0
 t0 = time.time()
 cases = []
-for n_types, markers, density, hvg, npc, store in itertools.product((1, 40), (400,), (0.06,), (1000,), (50,), (F.STORE_F32,)):
+for n_types, markers, density, hvg, npc, store in itertools.product((1, 4, 30), (20, 300), (0.01, 0.06), (200, 1000, 3000), (10, 50), (F.STORE_F32, F.STORE_F64)):
     cases.append((30000, 12000, n_types, markers, density, hvg, npc, store, 0))
 cases += [(30000, 12000, 8, 100, 0.05, 1000, 50, F.STORE_F32, 2), (30000, 12000, 8, 100, 0.05, 9000, 30, F.STORE_F32, 0),
           (30000, 12000, 8, 100, 0.05, 9000, 30, F.STORE_F32, 1), (2000, 12000, 8, 100, 0.05, 1000, 50, F.STORE_F32, 0),
@@ -36,7 +36,7 @@ for (n, g, n_types, markers, density, hvg, npc, store, solver) in cases:
     msg = "" if rc == 0 else (lib.srx_last_error(ctx.handle) or b"").decode()[:90]
     if rc != 0:
         fails += 1
-    if rc != 0 or res.pca.n_iter > 60:
+    if rc != 0 or res.pca.n_iter > 150:
         print(f"n={n} types={n_types} markers={markers} dens={density} hvg={hvg} npc={npc} store={store} solver={solver}: rc={rc} "
               f"iters={res.pca.n_iter} resid={res.pca.residual:.2e} {ms:.1f} ms {msg}", flush=True)
     lib.srx_matrix_free(h)
