@@ -227,7 +227,11 @@ int32_t srx_select_hvg(srx_mat* m, uint64_t n, uint64_t* idx_out, uint64_t* n_ou
  * accumulated once from the sparse rows; never densifies X.  Between Rayleigh–Ritz steps the
  * block is advanced by Chebyshev filters of C = Z^T Z (plain powers during the warm-up); the
  * whole iteration runs on the device (SRX_NO_GRAPH=1 / SRX_NO_CHEB=1 / SRX_PCA_TRACE=1 in the
- * environment: no hipGraph replay / plain sweeps instead of filters / residual trace on stderr). */
+ * environment: no hipGraph replay / plain sweeps instead of filters / residual trace on stderr).
+ * Hard spectra (a few strong components over a flat bulk) are handled by bounding the filter
+ * degree, by deflation rounds of <= 32 components when one round stalls, and by a last-resort
+ * mode (CholeskyQR3 after every application of C; SRX_PCA_ROBUST=1 forces it): SRX_E_NOCONV is
+ * left for a zero matrix, NaN input or an exhausted max_iter. */
 typedef enum srx_pca_solver {
     SRX_SOLVER_AUTO = 0,
     SRX_SOLVER_GRAM = 1,   /* explicit sparse Gram X_sel^T X_sel once, dense k x k iteration  */
