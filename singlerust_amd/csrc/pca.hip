@@ -1149,6 +1149,10 @@ __device__ __forceinline__ uint64_t dmix64(uint64_t x) {
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
 }
+__global__ void k_identity_block(int k, double* __restrict__ W) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < k * L) W[e] = (e / L == e % L) ? 1.0 : 0.0;
+}
 __global__ void k_init_block(uint64_t seed, int k, int l_act, double* __restrict__ Wp) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= k * L) return;
@@ -1429,7 +1433,10 @@ __global__ void k_resid_scalar(const double* __restrict__ rho, const double* __r
     if (threadIdx.x != 0) return;
     double resid = 0.0;
     for (int i = 0; i < n_pc; ++i) {
-        const double r = theta[i] > 0 ? rho[i] / theta[i] : rho[i];
+        // relative to the pair's own eigenvalue, but not to less than 1e-7 of the largest one: pairs of a numerically
+        // zero eigenvalue (more components asked than the data have rank) are judged on the scale of the problem
+        const double den = theta[i] > 1e-7 * theta[0] ? theta[i] : 1e-7 * theta[0];
+        const double r = den > 0 ? rho[i] / den : rho[i];
         if (!(r <= resid)) resid = r;
     }
     out[0] = resid;
@@ -1746,6 +1753,7 @@ struct Resolved {
     int n_pc, center, scale, max_iter, solver;
     double bail_ratio = 0.0; // > 0: give the round up after its first Ritz step when theta_l / theta_npc exceeds this (the
                              // caller has a plan with more guard columns per round)
+    bool direct = false;     // k <= 64 with the explicit matrix: the block is the identity, one exact eigen-solve of C
     bool robust = false;     // last resort after a breakdown: CholeskyQR after every application of C, shifted
                              // CholeskyQR3, plain sweeps instead of Chebyshev filters
     int power = 1;           // applications of C per Rayleigh–Ritz step
@@ -1845,7 +1853,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
                                 bool& converged) {
     const size_t kl = (size_t)k * L;
     const bool use_graph = graphable && !getenv("SRX_NO_GRAPH");
-    const bool use_cheb = l_act > o.n_pc && !o.robust && !getenv("SRX_NO_CHEB");      // both solvers: the filter only needs `apply`
+    const bool use_cheb = l_act > o.n_pc && !o.robust && !o.direct && !getenv("SRX_NO_CHEB");      // both solvers: the filter only needs `apply`
     constexpr int kSlots = srx_ctx::kAsyncSlots, kSlotDoubles = 8;
     if (!ctx->pin_async) {
         SRX_HIP(ctx, hipHostMalloc((void**)&ctx->pin_async, kSlots * kSlotDoubles * sizeof(double), hipHostMallocDefault));
@@ -1859,7 +1867,8 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
                                      (int)kJacobiLds));
     // what a captured segment depends on besides its own schedule: shapes, options, every buffer it touches
     char key0[256];
-    snprintf(key0, sizeof key0, "k%d l%d p%d w%d r%d n%d s%llu|%p %p %p %p %p %p %p %p %p", k, l_act, o.power, o.warm, o.robust ? 1 : 0, o.n_pc,
+    snprintf(key0, sizeof key0, "k%d l%d p%d w%d r%d n%d s%llu|%p %p %p %p %p %p %p %p %p", k, l_act, o.power, o.warm,
+             (o.robust ? 1 : 0) + (o.direct ? 2 : 0), o.n_pc,
              (unsigned long long)o.seed, apply_id, (void*)w.W, (void*)w.Wp, (void*)w.A1, (void*)w.A2, (void*)w.small,
              (void*)w.gpart, (void*)d_status, (void*)d_status_sel);
     const std::string key_base(key0);
@@ -1957,6 +1966,11 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     // happens — no Rayleigh–Ritz step to learn that), first Ritz step
     auto seg_start = [&]() -> int32_t {
         SRX_HIP(ctx, hipMemsetAsync(d_status, 0, 256, ctx->stream));
+        if (o.direct) {                    // W = I (k x k, k = l_act): H = C itself, Ritz pairs = eigenpairs whatever the rank
+            hipLaunchKernelGGL(k_identity_block, dim3((unsigned)((kl + 255) / 256)), dim3(256), 0, ctx->stream, k, w.W);
+            SRX_HIP(ctx, hipGetLastError());
+            return ritz_kernels(0, false);
+        }
         hipLaunchKernelGGL(k_init_block, dim3((unsigned)((kl + 255) / 256)), dim3(256), 0, ctx->stream, o.seed, k, l_act,
                            w.Wp);
         SRX_TRY(orth(w.Wp));
@@ -2011,7 +2025,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         const bool first = n_ritz == 1;
         const bool cheb = use_cheb;
         if (cheb && first) SRX_TRY(graphed(ctx, use_graph, key_base + "|cheb0", cheb_spec));   // speculative: Y1, C Y1
-        else if (first) SRX_TRY(graphed(ctx, use_graph, key_base + "|adv", advance));          // speculative: completes this sweep
+        else if (first && !o.direct) SRX_TRY(graphed(ctx, use_graph, key_base + "|adv", advance));   // speculative: completes this sweep
         double r, ratio;
         SRX_TRY(collect(slot, r, ratio));
         resid = r;
@@ -2186,7 +2200,7 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
     //           filters are harmless.
     const int n_pc = o.n_pc;
     // dimension of the operator's range: min(k, N - 1) (N when not centred); a block as wide as that is exact
-    const int dim = (int)std::min<double>((double)k, n_cells - (o.center ? 1.0 : 0.0));
+    const int dim = o.direct ? k : (int)std::min<double>((double)k, n_cells - (o.center ? 1.0 : 0.0));
     const std::vector<int> plan_a = plan_rounds(dim, n_pc, n_pc <= L - 8 ? n_pc : kPcaPerRound);
     const int n_b = (n_pc + kPcaPerRoundSafe - 1) / kPcaPerRoundSafe;
     const std::vector<int> plan_b = plan_rounds(dim, n_pc, (n_pc + n_b - 1) / n_b);
@@ -2408,10 +2422,15 @@ static int32_t resolve_opts(srx_ctx* ctx, const srx_pca_opts* opts, int k, uint6
     if (opts && opts->block != 0 && opts->block != L) return fail(ctx, SRX_E_ARG, "pca: only block = %d is built", L);
     // Z has rank <= min(k, N - 1) (N when not centred): a block wider than that cannot stay independent under C
     const uint64_t rank_bound = std::min<uint64_t>((uint64_t)k, Ng - (o.center ? 1 : 0));
-    if ((uint64_t)o.n_pc > rank_bound)
+    if ((uint64_t)o.n_pc > rank_bound && !(k <= L && o.solver == 1))
         return fail(ctx, SRX_E_ARG, "pca: n_components %d exceeds the rank of the data (min(k, N%s) = %llu)", o.n_pc,
                     o.center ? " - 1" : "", (unsigned long long)rank_bound);
     l_act = (int)std::min<uint64_t>((uint64_t)L, rank_bound);
+    // k <= 64 with the explicit matrix: the k x k matrix goes straight to the eigen-solver (exact for any rank)
+    if (k <= L && o.solver == 1) {
+        o.direct = true;
+        l_act = k;
+    }
     if (o.n_pc > l_act && o.solver != 1)
         return fail(ctx, SRX_E_ARG, "pca: n_components %d exceeds what the %d-column block resolves (max %d)", o.n_pc, L, l_act);
     // beyond L - 8 components the Gram solver runs deflation rounds on the explicit k x k matrix; the matrix-free
