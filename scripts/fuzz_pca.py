@@ -14,7 +14,7 @@ from singlerust_amd import _ffi as F
 
 ctx = sr.Context.default()
 lib = F.lib()
-rng = np.random.default_rng(2024)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 2024)
 bad = skipped = 0
 for it in range(160):
     n = int(rng.choice([5, 6, 9, 33, 64, 65, 200, 1500, 4000]))

@@ -1433,9 +1433,10 @@ __global__ void k_resid_scalar(const double* __restrict__ rho, const double* __r
     if (threadIdx.x != 0) return;
     double resid = 0.0;
     for (int i = 0; i < n_pc; ++i) {
-        // relative to the pair's own eigenvalue, but not to less than 1e-7 of the largest one: pairs of a numerically
+        // relative to the pair's own eigenvalue, but not to less than 1e-5 of the largest one: pairs of a numerically
         // zero eigenvalue (more components asked than the data have rank) are judged on the scale of the problem
-        const double den = theta[i] > 1e-7 * theta[0] ? theta[i] : 1e-7 * theta[0];
+        // (their absolute residual is ~1e-16 theta_1: 1e-11 on this scale)
+        const double den = theta[i] > 1e-5 * theta[0] ? theta[i] : 1e-5 * theta[0];
         const double r = den > 0 ? rho[i] / den : rho[i];
         if (!(r <= resid)) resid = r;
     }

@@ -545,3 +545,41 @@ def test_robust_mode_gives_the_same_answers(ctx, monkeypatch):
     assert np.allclose(a.uns["pca"]["explained_variance_ratio"], wevr, rtol=1e-6)
     comps = a.uns["pca"]["components"]
     assert np.abs(wc @ (wc.T @ comps) - comps).max() < 1e-4 and col_err(a.obsm["X_pca"][:, :10], want[:, :10]) < 1e-6
+
+
+@pytest.mark.parametrize("n,g,density,n_pc,center,scale", [(64, 64, 0.02, 63, True, False), (33, 17, 0.05, 17, True, True),
+                                                          (64, 2500, 0.02, 64, False, True), (9, 3, 0.5, 3, True, True)])
+def test_small_k_goes_straight_to_the_eigensolver(ctx, n, g, density, n_pc, center, scale):
+    """k <= 64: the k x k matrix itself is diagonalised (the block is the identity) — exact whatever the rank, so nearly
+    empty matrices whose rank is far below min(k, N - 1) and n_components up to k (the reference's limit) are served:
+    eigenvalues of the exact SVD, vectors that satisfy the eigen-equation, scores that belong to them."""
+    import scipy.sparse as sp
+    from singlerust_amd import _ffi
+    rng = np.random.default_rng(n * 1000 + g)
+    x = sp.random(n, g, density=density, random_state=int(rng.integers(1 << 30)), format="csr",
+                  data_rvs=lambda s: rng.integers(1, 30, s).astype(np.float64), dtype=np.float64)
+    x.sort_indices()
+    m = oracle.Csr(n, g, x.indptr, x.indices, x.data)
+    a = adata_of(m, ctx, 2)
+    opts = _ffi.PcaOpts(n_pc, int(center), int(scale), -1, 0, 0, 0, 0.0, 1)
+    res = _ffi.PipelineResult()
+    _ffi.check(_ffi.lib().srx_pipeline(a.x().handle, 1e4, 64, C.byref(opts), C.byref(res)), ctx.handle)
+    k = int(res.pca.k)
+    assert k == min(64, g) and res.pca.n_pc == n_pc
+    scores, comps, evr, hv = np.zeros((n, n_pc)), np.zeros((k, n_pc)), np.zeros(n_pc), np.zeros(k, np.uint64)
+    _ffi.check(_ffi.lib().srx_result_fetch(a.x().handle, _ffi.ptr(scores), _ffi.ptr(comps), _ffi.ptr(evr), None, None,
+                                           _ffi.ptr(hv)), ctx.handle)
+    lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
+    dense = oracle.densify_selected(lg, hv)
+    sd = dense.std(axis=0)
+    z = dense - (dense.mean(axis=0) if center else 0.0)
+    if scale:
+        z = z / np.where(sd > 0, sd, 1.0)
+    s = np.linalg.svd(z, compute_uv=False)
+    s2 = np.zeros(k)
+    s2[:len(s)] = s * s
+    th = s2[:n_pc]
+    assert np.allclose(evr, th / s2.sum(), rtol=1e-9, atol=1e-14)
+    assert np.abs(comps.T @ comps - np.eye(n_pc)).max() < 1e-10
+    assert np.abs(z.T @ (z @ comps) - comps * th).max() < 1e-9 * max(th[0], 1.0)
+    assert np.abs(scores - z @ comps).max() < 1e-9 * max(np.abs(scores).max(), 1.0)
