@@ -159,9 +159,32 @@ def main():
         sys.stdout.flush()
         saved = os.dup(1)
         os.dup2(2, 1)
+        collective, comm_err = "rccl", ""
         try:
-            uid = group.broadcast_bytes(sr.Context.comm_unique_id() if rank == 0 else None, F.UNIQUE_ID_BYTES)
-            ctx.comm_init(world, rank, uid)
+            # every rank goes through the same sequence whatever fails where (a rank that raised early
+            # would leave the others waiting in the star): id (zeros = rank 0 could not make one) ->
+            # init -> agreement on the outcome
+            uid = None
+            if rank == 0:
+                try:
+                    uid = sr.Context.comm_unique_id()
+                except Exception as e:          # noqa: BLE001
+                    uid, comm_err = bytes(F.UNIQUE_ID_BYTES), str(e)
+            uid = group.broadcast_bytes(uid, F.UNIQUE_ID_BYTES)
+            ok = uid != bytes(F.UNIQUE_ID_BYTES) and os.environ.get("SRX_BENCH_COLLECTIVE", "rccl") == "rccl"
+            if ok:
+                try:
+                    ctx.comm_init(world, rank, uid)
+                except Exception as e:          # noqa: BLE001
+                    ok, comm_err = False, str(e)
+            if group.allreduce_max(0.0 if ok else 1.0) > 0.0:
+                # RCCL could not be brought up on some rank (or SRX_BENCH_COLLECTIVE=host): the sums over ranks
+                # go through the host transport hook of the C-ABI (srx_comm_init_host) over the rendezvous
+                # sockets instead.  Same arithmetic, slower exchange; the JSON line says which one ran.
+                F.check(lib.srx_comm_destroy(ctx.handle), ctx.handle)
+                ctx.comm_init_host(world, rank, group.allreduce_sum_f64)
+                collective = "host-star"
+                print(f"[bench rank {rank}] RCCL unavailable ({comm_err or 'see other ranks'}): host all-reduce", file=sys.stderr)
         finally:
             os.dup2(saved, 1)
             os.close(saved)
@@ -272,6 +295,7 @@ def main():
                             f"normalize_total(1e4,Row)+log1p+HVG({a.hvg})+{a.npc}-PC PCA; values {a.storage} / indices i32 in HBM",
                 "cells_global": n_global, "genes": genes, "nnz_per_gpu": nnz, "hvg": a.hvg, "n_pc": a.npc,
                 "panel_width": 64, "parallelism": f"row-shard x{world}",
+                **({"collective": collective} if dist is not None else {}),
                 "nnz_hvg_compacted_per_gpu": int(res.pca.nnz_selected),
                 "subspace_iterations": iters, "pca_residual": float(res.pca.residual),
                 "pca_solver": {1: "gram", 2: "spmm"}.get(int(res.pca.solver), "?"),
