@@ -1,0 +1,37 @@
+"""GPU test (-m gpu) of bench.py's N > 1 launch path: two ranks with the environment torch.distributed.run gives them
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), both on GPU 0 (SRX_BENCH_DEVICE), the sums over ranks
+through the host all-reduce hook (SRX_BENCH_COLLECTIVE=host — RCCL refuses two ranks on one device).  Rank 0 must
+print exactly one JSON line describing the whole job."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_bench_line():
+    world, cells = 2, 60000
+    env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(20000 + os.getpid() % 20000),
+               SRX_BENCH_DEVICE="0", SRX_BENCH_COLLECTIVE="host", TORCHELASTIC_RUN_ID=f"t{os.getpid()}")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--cells", str(cells), "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline"]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              cwd=ROOT) for r in range(world)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e.decode()[-3000:]
+    lines0 = [ln for ln in outs[0][0].decode().splitlines() if ln.strip()]
+    assert len(lines0) == 1, lines0                        # one JSON line, nothing else on rank 0's stdout
+    assert not outs[1][0].decode().strip()                 # and nothing at all on the other rank's
+    d = json.loads(lines0[0])
+    assert d["n_gpus"] == world and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["unit"] == "cells/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    c = d["config"]
+    assert c["cells_global"] == world * cells and c["parallelism"] == f"row-shard x{world}" and c["collective"] == "host-star"
+    # whole-job value: all ranks' cells over the max-over-ranks time of the timed steps
+    assert abs(d["value"] - world * cells / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert c["pca_residual"] < 1e-6 and d["roofline"]["frac"] > 0 and d["roofline"]["bound"] == "hbm"
