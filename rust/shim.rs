@@ -1,0 +1,291 @@
+// rust/shim.rs — the module a SingleRust maintainer adds as `src/gpu/mod.rs` (cargo feature `hip`), next to the
+// generated `src/gpu/ffi.rs` (= rust/srx_sys.rs).  It keeps the reference's public signatures and replaces the bodies
+// listed in SURVEY.md §8(b) by calls into libsrx_hip.so.  NOT compile-checked: the build image has no rustc / cargo.
+// The same call sequences are exercised through ctypes (singlerust_amd/_ffi.py) and through the C++ mirror
+// (singlerust_amd/host/single_rust.hpp, tests/cpp/host_mirror_test.cpp), which this file follows function by function.
+//
+// Replaced bodies (reference file:line):
+//   memory::statistics::{compute_number, compute_sum, compute_variance, compute_std_dev, compute_min_max}
+//       src/memory/statistics/mod.rs:10-46   -> src/shared/statistics/helper/csr.rs:16-38,81-102,149-228
+//   memory::statistics::compute_qc_variables          src/memory/statistics/mod.rs:48-72
+//   memory::processing::normalize_total_inplace       src/memory/processing/mod.rs:303-312 -> scale/mod.rs:7-173
+//   memory::processing::log1p_transform_inplace       src/memory/processing/mod.rs:324-326 -> transform/mod.rs:36-57
+//   memory::processing::dim_red::select_features      src/memory/processing/dim_red/mod.rs:123-156 (HighlyVariable arm)
+//   memory::processing::dim_red::pca_inplace          src/memory/processing/dim_red/mod.rs:24-94
+//   memory::processing::filter_cells / filter_genes   src/memory/processing/mod.rs:86-146,245-299
+mod ffi;                                   // rust/srx_sys.rs
+use ffi::*;
+
+use std::ffi::CStr;
+use std::ops::Deref;
+use std::os::raw::c_void;
+use std::ptr::{null, null_mut};
+
+use anndata::data::{ArrayData, DynCscMatrix, DynCsrMatrix};
+use anndata_memory::IMAnnData;
+use anyhow::{anyhow, bail, Result};
+
+use crate::shared::{Direction, FeatureSelection, FlexValue};
+
+// ---- handles --------------------------------------------------------------------------------------------------
+/// One GPU + stream (+ optional communicator).  Not `Sync`: one context per thread, as include/srx.h requires.
+pub struct Ctx(*mut SrxCtx);
+
+impl Ctx {
+    pub fn new(device_id: i32) -> Result<Self> {
+        let mut p = null_mut();
+        let rc = unsafe { srx_ctx_create(device_id, &mut p) };
+        if rc != SRX_OK {
+            return Err(anyhow!(last_error(null())));        // "no HIP device" when the library cannot see a GPU: no CPU fallback
+        }
+        Ok(Ctx(p))
+    }
+    fn check(&self, rc: i32) -> Result<()> {
+        if rc == SRX_OK { Ok(()) } else { Err(anyhow!(last_error(self.0))) }
+    }
+}
+impl Drop for Ctx {
+    fn drop(&mut self) { unsafe { srx_ctx_destroy(self.0) } }
+}
+
+fn last_error(ctx: *const SrxCtx) -> String {
+    unsafe { CStr::from_ptr(srx_last_error(ctx)) }.to_string_lossy().into_owned()
+}
+
+/// Device-resident X of one IMAnnData.  Upload once; every call of the path then works on the handle.
+pub struct DeviceX<'c> { ctx: &'c Ctx, mat: *mut SrxMat, n_obs: usize, n_vars: usize }
+
+impl Drop for DeviceX<'_> {
+    fn drop(&mut self) { unsafe { srx_matrix_free(self.mat) } }
+}
+
+macro_rules! csr_descriptor {
+    ($m:expr, $code:expr) => {
+        SrxCsr {
+            n_rows: $m.nrows() as u64, n_cols: $m.ncols() as u64, nnz: $m.nnz() as u64,
+            indptr: $m.row_offsets().as_ptr() as *const u64,       // usize == u64 on x86-64
+            indices: $m.col_indices().as_ptr() as *const u64,
+            values: $m.values().as_ptr() as *mut c_void,
+            dtype: $code,
+        }
+    };
+}
+macro_rules! csc_descriptor {
+    ($m:expr, $code:expr) => {
+        SrxCsr {
+            n_rows: $m.nrows() as u64, n_cols: $m.ncols() as u64, nnz: $m.nnz() as u64,
+            indptr: $m.col_offsets().as_ptr() as *const u64,
+            indices: $m.row_indices().as_ptr() as *const u64,
+            values: $m.values().as_ptr() as *mut c_void,
+            dtype: $code,
+        }
+    };
+}
+
+impl<'c> DeviceX<'c> {
+    /// Takes the same read guard the reference takes (statistics/mod.rs:11-13) for the duration of the copy.
+    pub fn upload(ctx: &'c Ctx, adata: &IMAnnData) -> Result<Self> {
+        let x = adata.x();
+        let guard = x.0.read_inner();
+        let mut mat = null_mut();
+        macro_rules! up { ($d:expr, $f:ident) => {{ let h = $d; ctx.check(unsafe { $f(ctx.0, &h, SRX_STORE_AUTO, &mut mat) })?; }}; }
+        match guard.deref() {
+            // dtype set of match_dyn_csr_matrix! (src/shared/mod.rs:110-129); anything else stays the reference's panic
+            ArrayData::CsrMatrix(d) => match d {
+                DynCsrMatrix::I8(m) => up!(csr_descriptor!(m, SRX_I8), srx_matrix_upload),
+                DynCsrMatrix::I16(m) => up!(csr_descriptor!(m, SRX_I16), srx_matrix_upload),
+                DynCsrMatrix::I32(m) => up!(csr_descriptor!(m, SRX_I32), srx_matrix_upload),
+                DynCsrMatrix::U8(m) => up!(csr_descriptor!(m, SRX_U8), srx_matrix_upload),
+                DynCsrMatrix::U16(m) => up!(csr_descriptor!(m, SRX_U16), srx_matrix_upload),
+                DynCsrMatrix::U32(m) => up!(csr_descriptor!(m, SRX_U32), srx_matrix_upload),
+                DynCsrMatrix::F32(m) => up!(csr_descriptor!(m, SRX_F32), srx_matrix_upload),
+                DynCsrMatrix::F64(m) => up!(csr_descriptor!(m, SRX_F64), srx_matrix_upload),
+                _ => panic!("CSR matrices of this dtype are not supported for this operation"),
+            },
+            ArrayData::CscMatrix(d) => match d {
+                DynCscMatrix::I8(m) => up!(csc_descriptor!(m, SRX_I8), srx_matrix_upload_csc),
+                DynCscMatrix::I16(m) => up!(csc_descriptor!(m, SRX_I16), srx_matrix_upload_csc),
+                DynCscMatrix::I32(m) => up!(csc_descriptor!(m, SRX_I32), srx_matrix_upload_csc),
+                DynCscMatrix::U8(m) => up!(csc_descriptor!(m, SRX_U8), srx_matrix_upload_csc),
+                DynCscMatrix::U16(m) => up!(csc_descriptor!(m, SRX_U16), srx_matrix_upload_csc),
+                DynCscMatrix::U32(m) => up!(csc_descriptor!(m, SRX_U32), srx_matrix_upload_csc),
+                DynCscMatrix::F32(m) => up!(csc_descriptor!(m, SRX_F32), srx_matrix_upload_csc),
+                DynCscMatrix::F64(m) => up!(csc_descriptor!(m, SRX_F64), srx_matrix_upload_csc),
+                _ => panic!("CSC matrices of this dtype are not supported for this operation"),
+            },
+            _ => bail!("X is neither a CSC nor a CSR matrix"),
+        }
+        Ok(DeviceX { ctx, mat, n_obs: adata.n_obs(), n_vars: adata.n_vars() })
+    }
+    fn len(&self, d: &Direction) -> usize { if d.is_row() { self.n_obs } else { self.n_vars } }
+    fn dir(d: &Direction) -> i32 { if d.is_row() { SRX_ROW } else { SRX_COLUMN } }
+
+    // ---- memory::statistics ----------------------------------------------------------------------------------
+    pub fn compute_number(&self, direction: Direction) -> Result<Vec<u32>> {
+        let mut v = vec![0u32; self.len(&direction)];
+        self.ctx.check(unsafe { srx_compute_number(self.mat, Self::dir(&direction), v.as_mut_ptr()) })?;
+        Ok(v)
+    }
+    pub fn compute_sum(&self, direction: Direction) -> Result<Vec<f64>> {
+        let mut v = vec![0f64; self.len(&direction)];
+        self.ctx.check(unsafe { srx_compute_sum(self.mat, Self::dir(&direction), v.as_mut_ptr()) })?;
+        Ok(v)
+    }
+    pub fn compute_variance(&self, direction: Direction) -> Result<Vec<f64>> {
+        let mut v = vec![0f64; self.len(&direction)];
+        self.ctx.check(unsafe { srx_compute_variance(self.mat, Self::dir(&direction), v.as_mut_ptr()) })?;
+        Ok(v)
+    }
+    pub fn compute_std_dev(&self, direction: Direction) -> Result<Vec<f64>> {
+        let mut v = vec![0f64; self.len(&direction)];
+        self.ctx.check(unsafe { srx_compute_std_dev(self.mat, Self::dir(&direction), v.as_mut_ptr()) })?;
+        Ok(v)
+    }
+    pub fn compute_min_max(&self, direction: Direction) -> Result<(Vec<f64>, Vec<f64>)> {
+        let n = self.len(&direction);
+        let (mut mn, mut mx) = (vec![0f64; n], vec![0f64; n]);
+        self.ctx.check(unsafe { srx_compute_min_max(self.mat, Self::dir(&direction), mn.as_mut_ptr(), mx.as_mut_ptr()) })?;
+        Ok((mn, mx))
+    }
+    /// The eight vectors of `StatisticsContainer` (statistics/mod.rs:48-72) from one row pass + one column pass.
+    #[allow(clippy::type_complexity)]
+    pub fn compute_qc_variables(&self) -> Result<(Vec<u32>, Vec<u32>, Vec<f64>, Vec<f64>, Vec<f64>, Vec<f64>, Vec<f64>, Vec<f64>)> {
+        let (c, g) = (self.n_obs, self.n_vars);
+        let (mut num_cell, mut num_gene) = (vec![0u32; c], vec![0u32; g]);
+        let (mut expr_gene, mut expr_cell) = (vec![0f64; g], vec![0f64; c]);
+        let (mut var_gene, mut var_cell, mut sd_cell, mut sd_gene) = (vec![0f64; g], vec![0f64; c], vec![0f64; c], vec![0f64; g]);
+        self.ctx.check(unsafe {
+            srx_compute_qc_variables(self.mat, num_cell.as_mut_ptr(), num_gene.as_mut_ptr(), expr_gene.as_mut_ptr(),
+                                     expr_cell.as_mut_ptr(), var_gene.as_mut_ptr(), var_cell.as_mut_ptr(),
+                                     sd_cell.as_mut_ptr(), sd_gene.as_mut_ptr())
+        })?;
+        Ok((num_cell, num_gene, expr_gene, expr_cell, var_gene, var_cell, sd_cell, sd_gene))
+    }
+
+    // ---- memory::processing ----------------------------------------------------------------------------------
+    /// scale/mod.rs:7-23: `scale = if sum == 0 { 0 } else { target / sum }`, `v * scale`; the logical dtype becomes F64.
+    pub fn normalize_total_inplace(&mut self, target_sum: f64, direction: Direction) -> Result<()> {
+        self.ctx.check(unsafe { srx_normalize_total_inplace(self.mat, target_sum, Self::dir(&direction)) })
+    }
+    /// transform/mod.rs:36-57: F32 stays F32, everything else becomes F64.
+    pub fn log1p_transform_inplace(&mut self) -> Result<()> {
+        self.ctx.check(unsafe { srx_log1p_inplace(self.mat) })
+    }
+    /// Values back into a host `Vec<f64>` for `*csr_matrix = DynCsrMatrix::F64(..)` (scale/mod.rs:82) — only when the
+    /// host copy is needed; the pipeline itself never leaves the device.
+    pub fn download_values_f64(&self, nnz: usize) -> Result<Vec<f64>> {
+        let mut v = vec![0f64; nnz];
+        self.ctx.check(unsafe { srx_matrix_download_values(self.mat, v.as_mut_ptr() as *mut c_void, SRX_F64) })?;
+        Ok(v)
+    }
+
+    fn flex(v: &FlexValue) -> SrxFlex {          // src/shared/mod.rs:62-66
+        match v {
+            FlexValue::Absolute(a) => SrxFlex { kind: SRX_FLEX_ABSOLUTE, absolute: *a, relative: 0.0 },
+            FlexValue::Relative(p) => SrxFlex { kind: SRX_FLEX_RELATIVE, absolute: 0, relative: *p },
+            FlexValue::None => SrxFlex { kind: SRX_FLEX_NONE, absolute: 0, relative: 0.0 },
+        }
+    }
+    /// processing/mod.rs:86-146: returns the filtered matrix and the keep-mask that drives the `obs` subset.
+    pub fn filter_cells(&self, lower: &FlexValue, upper: &FlexValue) -> Result<(DeviceX<'c>, Vec<bool>)> {
+        let mut out = null_mut();
+        let mut mask = vec![0u8; self.n_obs];
+        self.ctx.check(unsafe { srx_filter_cells(self.mat, Self::flex(lower), Self::flex(upper), &mut out, mask.as_mut_ptr()) })?;
+        let keep: Vec<bool> = mask.iter().map(|&b| b != 0).collect();
+        let n_obs = keep.iter().filter(|&&k| k).count();
+        Ok((DeviceX { ctx: self.ctx, mat: out, n_obs, n_vars: self.n_vars }, keep))
+    }
+    /// processing/mod.rs:245-299.
+    pub fn filter_genes(&self, lower: &FlexValue, upper: &FlexValue) -> Result<(DeviceX<'c>, Vec<bool>)> {
+        let mut out = null_mut();
+        let mut mask = vec![0u8; self.n_vars];
+        self.ctx.check(unsafe { srx_filter_genes(self.mat, Self::flex(lower), Self::flex(upper), &mut out, mask.as_mut_ptr()) })?;
+        let keep: Vec<bool> = mask.iter().map(|&b| b != 0).collect();
+        let n_vars = keep.iter().filter(|&&k| k).count();
+        Ok((DeviceX { ctx: self.ctx, mat: out, n_obs: self.n_obs, n_vars }, keep))
+    }
+
+    // ---- memory::processing::dim_red ---------------------------------------------------------------------------
+    /// dim_red/mod.rs:123-156.  `HighlyVariable(n)`: stable descending sort of the non-zero-only gene variance, the
+    /// first n indices in rank order (:135-140) — computed on the device; the other arms are host-side index lists.
+    pub fn select_features(&self, fs: &FeatureSelection) -> Result<Option<Vec<u64>>> {
+        match fs {
+            FeatureSelection::HighlyVariable(n) => {
+                let mut idx = vec![0u64; (*n).min(self.n_vars)];
+                let mut n_out = 0u64;
+                self.ctx.check(unsafe { srx_select_hvg(self.mat, *n as u64, idx.as_mut_ptr(), &mut n_out) })?;
+                idx.truncate(n_out as usize);
+                Ok(Some(idx))
+            }
+            FeatureSelection::None => Ok(None),      // all genes: `sel = NULL`
+            // HighlyVariableCol / Randomized / VarianceThreshold keep the reference's host code (:125-134,141-153): it
+            // builds the index list from a var column, an RNG or `compute_variance` (replaced above); hand that list
+            // to `pca_with_selection`
+            _ => bail!("feature selection arm handled on the host: pass its index list to pca_with_selection"),
+        }
+    }
+
+    /// dim_red/mod.rs:24-94 without the dense N x k matrix: returns (scores N x n_pc row-major, explained variance
+    /// ratio, selected features) — exactly what `attach_pca_results` (:96-121) takes; `n_threads` is accepted and ignored,
+    /// the `svd_mode` marker has no counterpart.
+    pub fn pca(&self, n_components: Option<usize>, center: Option<bool>, scale: Option<bool>, _n_threads: Option<usize>,
+               feature_selection: &FeatureSelection) -> Result<(Vec<f64>, Vec<f64>, Vec<usize>, usize)> {
+        let sel = self.select_features(feature_selection)?;
+        self.pca_with_selection(n_components, center, scale, sel)
+    }
+
+    /// `sel`: feature indices in selection order (`None` = all genes, FeatureSelection::None).
+    pub fn pca_with_selection(&self, n_components: Option<usize>, center: Option<bool>, scale: Option<bool>,
+                              sel: Option<Vec<u64>>) -> Result<(Vec<f64>, Vec<f64>, Vec<usize>, usize)> {
+        let k = sel.as_ref().map_or(self.n_vars, |s| s.len());
+        let n_pc = n_components.unwrap_or(2).min(k);                                      // :52
+        let opt = |o: Option<bool>| o.map_or(-1, |b| b as i32);                            // None -> library default (true, :55-56)
+        let opts = SrxPcaOpts { n_components: n_pc as i32, center: opt(center), scale: opt(scale), n_threads: -1,
+                                block: 0, max_iter: 0, solver: SRX_SOLVER_AUTO, tol: 0.0, seed: 0 };
+        let mut scores = vec![0f64; self.n_obs * n_pc];
+        let mut evr = vec![0f64; n_pc];
+        let mut info: SrxPcaInfo = unsafe { std::mem::zeroed() };
+        self.ctx.check(unsafe {
+            srx_pca(self.mat, sel.as_ref().map_or(null(), |s| s.as_ptr()), k as u64, &opts, scores.as_mut_ptr(),
+                    null_mut(), evr.as_mut_ptr(), null_mut(), null_mut(), &mut info)
+        })?;
+        let selected: Vec<usize> = sel.map_or_else(|| (0..self.n_vars).collect(), |s| s.into_iter().map(|i| i as usize).collect());
+        Ok((scores, evr, selected, n_pc))
+    }
+}
+
+// ---- the reference's public functions, bodies replaced ----------------------------------------------------------
+// (each takes the thread's context; a real integration keeps one `Ctx` + `DeviceX` alive next to the IMAnnData so that
+//  the five calls of the canonical pipeline — SURVEY.md §3.6 — share one upload)
+pub fn compute_number(ctx: &Ctx, adata: &IMAnnData, direction: Direction) -> Result<Vec<u32>> {
+    DeviceX::upload(ctx, adata)?.compute_number(direction)
+}
+pub fn compute_sum(ctx: &Ctx, adata: &IMAnnData, direction: Direction) -> Result<Vec<f64>> {
+    DeviceX::upload(ctx, adata)?.compute_sum(direction)
+}
+pub fn compute_variance(ctx: &Ctx, adata: &IMAnnData, direction: Direction) -> Result<Vec<f64>> {
+    DeviceX::upload(ctx, adata)?.compute_variance(direction)
+}
+pub fn compute_std_dev(ctx: &Ctx, adata: &IMAnnData, direction: Direction) -> Result<Vec<f64>> {
+    DeviceX::upload(ctx, adata)?.compute_std_dev(direction)
+}
+pub fn compute_min_max(ctx: &Ctx, adata: &IMAnnData, direction: Direction) -> Result<(Vec<f64>, Vec<f64>)> {
+    DeviceX::upload(ctx, adata)?.compute_min_max(direction)
+}
+
+/// normalize_total_inplace -> log1p_transform_inplace -> pca_inplace(.., HighlyVariable(n_hvg)) in ONE library call with
+/// every intermediate in HBM (`srx_pipeline`); scores / ratio come back through `srx_result_fetch`.
+pub fn pipeline(ctx: &Ctx, adata: &mut IMAnnData, target_sum: f64, n_hvg: usize, n_components: usize)
+                -> Result<(Vec<f64>, Vec<f64>, Vec<usize>)> {
+    let x = DeviceX::upload(ctx, adata)?;
+    let opts = SrxPcaOpts { n_components: n_components as i32, center: -1, scale: -1, n_threads: -1, block: 0, max_iter: 0,
+                            solver: SRX_SOLVER_AUTO, tol: 0.0, seed: 0 };
+    let mut res: SrxPipelineResult = unsafe { std::mem::zeroed() };
+    ctx.check(unsafe { srx_pipeline(x.mat, target_sum, n_hvg as u64, &opts, &mut res) })?;
+    let (k, n_pc) = (res.pca.k as usize, res.pca.n_pc as usize);
+    let (mut scores, mut evr, mut hvg) = (vec![0f64; x.n_obs * n_pc], vec![0f64; n_pc], vec![0u64; k]);
+    ctx.check(unsafe {
+        srx_result_fetch(x.mat, scores.as_mut_ptr(), null_mut(), evr.as_mut_ptr(), null_mut(), null_mut(), hvg.as_mut_ptr())
+    })?;
+    Ok((scores, evr, hvg.into_iter().map(|i| i as usize).collect()))
+}

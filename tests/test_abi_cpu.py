@@ -37,6 +37,39 @@ def test_library_exports_every_declared_symbol(lib):
     assert set(decl) == set(_ffi.EXPORTS)
 
 
+def test_rust_bindings_follow_the_header():
+    """rust/srx_sys.rs (the `extern "C"` module of INTEGRATION.md) is generated from include/srx.h: the committed
+    file must be what the generator produces now, and declare every function of that header with its arity."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("gen_rust_bindings", os.path.join(ROOT, "scripts", "gen_rust_bindings.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    text = open(os.path.join(ROOT, "rust", "srx_sys.rs")).read()
+    assert text == gen.render(), "rust/srx_sys.rs is stale: run python scripts/gen_rust_bindings.py"
+    header = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", "srx.h")).read(), flags=re.S)
+    in_header = {m.group(1): m.group(2) for m in re.finditer(r"\b(srx_\w+)\s*\(([^()]*)\)\s*;", header)}
+    in_header = {k: v for k, v in in_header.items() if not k.endswith("_fn")}
+    in_rust = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (srx_\w+)\((.*?)\)(?: -> [^;]+)?;", text, flags=re.S)}
+    assert set(in_rust) == set(in_header) and len(in_rust) >= 50
+
+    def arity(params, sep_depth_char="("):
+        params = params.strip()
+        if not params or params == "void":
+            return 0
+        depth, n = 0, 1
+        for ch in params:
+            depth += ch == "("
+            depth -= ch == ")"
+            n += ch == "," and depth == 0
+        return n
+    for name in in_header:
+        assert arity(in_header[name]) == arity(in_rust[name]), name
+    # the hand-written shim only calls functions the generated module declares
+    shim = open(os.path.join(ROOT, "rust", "shim.rs")).read()
+    assert set(re.findall(r"\b(srx_\w+)\(", shim)) <= set(in_rust)
+
+
 def test_abi_version(lib):
     assert lib.srx_abi_version() == 1
 
