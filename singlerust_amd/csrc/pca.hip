@@ -873,6 +873,41 @@ __global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
             // together and unconditionally (a lane past np reads some record at or past the staging area —
             // LDS reads beyond the allocation return 0 — and drops it), so a wave has two independent
             // read -> multiply -> atomic chains behind each wait
+            if (!__any(np > 16)) {
+                // all four cells of the pass have <= 16 products (45 % of the cells at c3, sorted to the front of the
+                // batch): one slice each, and the NEXT pass rides along when it is of the same kind — eight cells
+                // per trip, two independent read -> multiply -> atomic chains as in the general loop
+                const unsigned info2 = (unsigned)__shfl(packed, (row + 4) & 63, kWave);
+                const int lb2 = info2 >> 24;
+                const int np2 = (int)((info2 >> 16) & 0xff) * lb2;
+                const bool pair2 = !__any(np2 > 16);
+                const int ia0 = (int)(pf * rcp);
+                const int ib0 = q - __mul24(ia0, lbR);
+                const Entry xa0 = *reinterpret_cast<const Entry*>(base_a + ia0 * (int)sizeof(Entry));
+                const Entry xb0 = *reinterpret_cast<const Entry*>(base_b + ib0 * (int)sizeof(Entry));
+                if (pair2) {
+                    const char* base_a2 = sa_bytes + (info2 & 0xff) * (int)sizeof(Entry);
+                    const char* base_b2 = sb_bytes + ((info2 >> 8) & 0xff) * (int)sizeof(Entry);
+                    const float rcp2 = __builtin_amdgcn_rcpf((float)(lb2 > 0 ? lb2 : 1));
+                    const int ia1 = (int)(pf * rcp2);
+                    const int ib1 = q - __mul24(ia1, lb2);
+                    const Entry xa1 = *reinterpret_cast<const Entry*>(base_a2 + ia1 * (int)sizeof(Entry));
+                    const Entry xb1 = *reinterpret_cast<const Entry*>(base_b2 + ib1 * (int)sizeof(Entry));
+                    if (q < np) {
+                        double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa0.j ^ xb0.j));
+                        __hip_atomic_fetch_add(dst, gram_product(xa0.v, xb0.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    if (q < np2) {
+                        double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa1.j ^ xb1.j));
+                        __hip_atomic_fetch_add(dst, gram_product(xa1.v, xb1.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    ++rsub;
+                } else if (q < np) {
+                    double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa0.j ^ xb0.j));
+                    __hip_atomic_fetch_add(dst, gram_product(xa0.v, xb0.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                continue;
+            }
             for (int p = q; __any(p < np); p += 32, pf += 32.0f) {
                 const int ia0 = (int)(pf * rcp), ia1 = (int)((pf + 16.0f) * rcp);          // p / lbR
                 const int ib0 = p - __mul24(ia0, lbR), ib1 = p + 16 - __mul24(ia1, lbR);   // full-rate 24-bit multiply
