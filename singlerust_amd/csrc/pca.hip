@@ -703,6 +703,10 @@ __global__ void k_t_reduce(const AT* __restrict__ part, const double* __restrict
 // ran 17.5 ms against 10.7), and two independent cells per pass so that a wave keeps two chains in
 // the LDS queue.  [Flattening the products of the whole batch over the lanes costs ~117 VALU
 // instructions per 64 products for the per-product cell search — profiles/r01_pmc_gram_flattened.md.]
+// The cells of a batch are sorted by product count first (ballots + one ds_permute): cells without a
+// product are dropped, cells with <= 8 products run eight to a pass in 8-lane groups, passes of cells
+// with <= 16 products take ONE slice per cell and two passes per trip, the rest the general two-slice
+// loop (c3: 7.9 -> 7.6 ms; at c5's density, where most cells are small, 8.5 -> 6.7 ms).
 // Diagonal pairs compute the full tile.  Per-(row block, pair) partial tiles are summed in fixed
 // order by k_gram_reduce.
 // f32 storage: the product is formed in f32 (one rounding of 2^-24, the precision the stored values
@@ -840,27 +844,72 @@ __global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
         // the diet below, 32 before): no 64-bit arithmetic, no clamps, one multiply in storage precision.
         const int packed_cell = (cur.startA & 0xff) | ((cur.startB & 0xff) << 8) | (cur.la << 16) | (cur.lb << 24);
         // A pass runs as long as its LONGEST cell needs, so the cells of the batch are first grouped by
-        // product count (<= 16: one atomic slice; <= 32: two; more) with three ballots and one ds_permute:
-        // a pass then holds four cells of the same class and its lanes stay busy (21.6 -> ~16 slices per
-        // batch of 32 cells on the bench matrix).  Order inside a class is the original one.
-        int packed;
+        // product count with ballots and one ds_permute: a pass then holds cells of the same class and its
+        // lanes stay busy (21.6 -> ~16 slices per batch of 32 cells on the bench matrix with three classes).
+        // Order inside a class is the original one.
+        int packed, n_tiny, n_live;
         {
             const int npl = cur.la * cur.lb;                         // 0 for lanes past the batch
             const bool valid = lane < cur.nr;
-            const int cls = !valid ? 3 : npl <= 16 ? 0 : npl <= 32 ? 1 : 2;
-            const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
+            // classes: 1..8 products (eight cells per pass, 8-lane groups), <= 16, <= 32, more; cells without a
+            // product (an empty segment on either side) go behind the live ones and are never visited
+            const int cls = !valid ? 5 : npl == 0 ? 4 : npl <= 8 ? 0 : npl <= 16 ? 1 : npl <= 32 ? 2 : 3;
+            const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2),
+                                     m3 = __ballot(cls == 3), mz = __ballot(cls == 4);
             const unsigned long long below = (1ull << lane) - 1ull;
-            const int n0 = __popcll(m0), n1 = __popcll(m1);
+            const int n0 = __popcll(m0), n1 = n0 + __popcll(m1), n2 = n1 + __popcll(m2), n3 = n2 + __popcll(m3);
             const int pos = cls == 0 ? __popcll(m0 & below)
                           : cls == 1 ? n0 + __popcll(m1 & below)
-                          : cls == 2 ? n0 + n1 + __popcll(m2 & below)
+                          : cls == 2 ? n1 + __popcll(m2 & below)
+                          : cls == 3 ? n2 + __popcll(m3 & below)
+                          : cls == 4 ? n3 + __popcll(mz & below)
                                      : lane;                          // lanes >= nr keep their place (they are >= nr)
-            packed = __builtin_amdgcn_ds_permute(pos << 2, valid ? packed_cell : 0);
+            packed = __builtin_amdgcn_ds_permute(pos << 2, (valid && npl > 0) ? packed_cell : 0);
+            n_tiny = n0;
+            n_live = n3;
         }
         const char* sa_bytes = reinterpret_cast<const char*>(s_a);
         const char* sb_bytes = reinterpret_cast<const char*>(s_b);
-        for (int rsub = 0; rsub * 4 < cur.nr; ++rsub) {
-            const int row = grp + 4 * rsub;                          // group-uniform, < 32
+        int row0 = 0;
+        {
+            // cells with <= 8 products: 8-lane groups, eight cells per pass and two passes per trip
+            const int g8 = lane >> 3, q8 = lane & 7;
+            const float pf8 = (float)q8 + 0.5f;
+            auto fetch8 = [&](int cell, Entry& xa, Entry& xb, int& np8) {
+                const unsigned info = (unsigned)__shfl(packed, cell & 63, kWave);
+                const int lb8 = info >> 24;
+                np8 = (int)((info >> 16) & 0xff) * lb8;
+                const float rcp8 = __builtin_amdgcn_rcpf((float)(lb8 > 0 ? lb8 : 1));
+                const int ia = (int)(pf8 * rcp8);
+                const int ib = q8 - __mul24(ia, lb8);
+                xa = *reinterpret_cast<const Entry*>(sa_bytes + ((int)(info & 0xff) + ia) * (int)sizeof(Entry));
+                xb = *reinterpret_cast<const Entry*>(sb_bytes + ((int)((info >> 8) & 0xff) + ib) * (int)sizeof(Entry));
+            };
+            auto add8 = [&](const Entry& xa, const Entry& xb, int np8) {
+                if (q8 < np8) {
+                    double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa.j ^ xb.j));
+                    __hip_atomic_fetch_add(dst, gram_product(xa.v, xb.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            };
+            for (; row0 + 16 <= n_tiny; row0 += 16) {
+                Entry xa0, xb0, xa1, xb1;
+                int np0, np1;
+                fetch8(row0 + g8, xa0, xb0, np0);
+                fetch8(row0 + 8 + g8, xa1, xb1, np1);
+                add8(xa0, xb0, np0);
+                add8(xa1, xb1, np1);
+            }
+            if (row0 + 8 <= n_tiny) {
+                Entry xa0, xb0;
+                int np0;
+                fetch8(row0 + g8, xa0, xb0, np0);
+                add8(xa0, xb0, np0);
+                row0 += 8;
+            }
+        }
+        for (int rsub = 0; row0 + rsub * 4 < n_live; ++rsub) {
+            const int row = row0 + grp + 4 * rsub;                   // group-uniform, < 64
+
             const unsigned info = (unsigned)__shfl(packed, row, kWave);   // every lane active
             const int lbR = info >> 24;
             const int np = (int)((info >> 16) & 0xff) * lbR;         // 0 for cells past the batch
