@@ -705,8 +705,10 @@ __global__ void k_t_reduce(const AT* __restrict__ part, const double* __restrict
 // instructions per 64 products for the per-product cell search — profiles/r01_pmc_gram_flattened.md.]
 // The cells of a batch are sorted by product count first (ballots + one ds_permute): cells without a
 // product are dropped, cells with <= 8 products run eight to a pass in 8-lane groups, passes of cells
-// with <= 16 products take ONE slice per cell and two passes per trip, the rest the general two-slice
-// loop (c3: 7.9 -> 7.6 ms; at c5's density, where most cells are small, 8.5 -> 6.7 ms).
+// with <= 16 products take ONE slice per cell and two passes per trip, cells with <= 32 the two-slice
+// loop (one trip), and a cell with more than 32 products gets the WHOLE wave (64-product slices, its
+// extents in scalars; two single-slice cells go out together): c3 7.9 -> 7.4 ms; c5's density, where
+// most cells are small, 8.5 -> 6.7 ms; c2's, where they are large, 1.60 -> 1.40 ms.
 // Diagonal pairs compute the full tile.  Per-(row block, pair) partial tiles are summed in fixed
 // order by k_gram_reduce.
 // f32 storage: the product is formed in f32 (one rounding of 2^-24, the precision the stored values
@@ -847,7 +849,7 @@ __global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
         // product count with ballots and one ds_permute: a pass then holds cells of the same class and its
         // lanes stay busy (21.6 -> ~16 slices per batch of 32 cells on the bench matrix with three classes).
         // Order inside a class is the original one.
-        int packed, n_tiny, n_live;
+        int packed, n_tiny, n_mid, n_live;
         {
             const int npl = cur.la * cur.lb;                         // 0 for lanes past the batch
             const bool valid = lane < cur.nr;
@@ -866,6 +868,7 @@ __global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
                                      : lane;                          // lanes >= nr keep their place (they are >= nr)
             packed = __builtin_amdgcn_ds_permute(pos << 2, (valid && npl > 0) ? packed_cell : 0);
             n_tiny = n0;
+            n_mid = n2;
             n_live = n3;
         }
         const char* sa_bytes = reinterpret_cast<const char*>(s_a);
@@ -907,12 +910,11 @@ __global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
                 row0 += 8;
             }
         }
-        for (int rsub = 0; row0 + rsub * 4 < n_live; ++rsub) {
+        for (int rsub = 0; row0 + rsub * 4 < n_mid; ++rsub) {
             const int row = row0 + grp + 4 * rsub;                   // group-uniform, < 64
-
             const unsigned info = (unsigned)__shfl(packed, row, kWave);   // every lane active
             const int lbR = info >> 24;
-            const int np = (int)((info >> 16) & 0xff) * lbR;         // 0 for cells past the batch
+            const int np = row < n_mid ? (int)((info >> 16) & 0xff) * lbR : 0;   // the larger cells come after this loop
             const char* base_a = sa_bytes + (info & 0xff) * (int)sizeof(Entry);
             const char* base_b = sb_bytes + ((info >> 8) & 0xff) * (int)sizeof(Entry);
             // 1-ulp reciprocal: (p + 0.5) / lb stays >= 0.5 / 128 away from an integer, p < 2^14
@@ -928,7 +930,7 @@ __global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
                 // per trip, two independent read -> multiply -> atomic chains as in the general loop
                 const unsigned info2 = (unsigned)__shfl(packed, (row + 4) & 63, kWave);
                 const int lb2 = info2 >> 24;
-                const int np2 = (int)((info2 >> 16) & 0xff) * lb2;
+                const int np2 = row + 4 < n_mid ? (int)((info2 >> 16) & 0xff) * lb2 : 0;
                 const bool pair2 = !__any(np2 > 16);
                 const int ia0 = (int)(pf * rcp);
                 const int ib0 = q - __mul24(ia0, lbR);
@@ -969,6 +971,62 @@ __global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
                     __hip_atomic_fetch_add(dst, gram_product(xa0.v, xb0.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 if (p + 16 < np) {
+                    double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa1.j ^ xb1.j));
+                    __hip_atomic_fetch_add(dst, gram_product(xa1.v, xb1.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        // cells with more than 32 products: the WHOLE wave per cell, 64 products per slice and two slices per trip.
+        // What the kernel pays for is the number of wave-level atomic instructions (~9 clk each plus 0.26 per lane,
+        // in a dependent chain), and four such cells side by side run as long as the largest of them.  The cell is
+        // wave-uniform here: its extents are scalars.
+        for (int c = n_mid; c < n_live; ++c) {
+            const unsigned info = (unsigned)__builtin_amdgcn_readlane(packed, c);
+            const int lbR = (int)(info >> 24);
+            const int np = (int)((info >> 16) & 0xff) * lbR;
+            const char* base_a = sa_bytes + (info & 0xff) * (int)sizeof(Entry);
+            const char* base_b = sb_bytes + ((info >> 8) & 0xff) * (int)sizeof(Entry);
+            const float rcp = __builtin_amdgcn_rcpf((float)lbR);
+            float pf = (float)lane + 0.5f;
+            if (np <= 64 && c + 1 < n_live) {
+                // two cells of one slice each: their reads go out together (two independent chains)
+                const unsigned info1 = (unsigned)__builtin_amdgcn_readlane(packed, c + 1);
+                const int lb1 = (int)(info1 >> 24);
+                const int np1 = (int)((info1 >> 16) & 0xff) * lb1;
+                if (np1 <= 64) {
+                    const char* base_a1 = sa_bytes + (info1 & 0xff) * (int)sizeof(Entry);
+                    const char* base_b1 = sb_bytes + ((info1 >> 8) & 0xff) * (int)sizeof(Entry);
+                    const float rcp1 = __builtin_amdgcn_rcpf((float)lb1);
+                    const int ia0 = (int)(pf * rcp), ia1 = (int)(pf * rcp1);
+                    const int ib0 = lane - __mul24(ia0, lbR), ib1 = lane - __mul24(ia1, lb1);
+                    const Entry xa0 = *reinterpret_cast<const Entry*>(base_a + ia0 * (int)sizeof(Entry));
+                    const Entry xb0 = *reinterpret_cast<const Entry*>(base_b + ib0 * (int)sizeof(Entry));
+                    const Entry xa1 = *reinterpret_cast<const Entry*>(base_a1 + ia1 * (int)sizeof(Entry));
+                    const Entry xb1 = *reinterpret_cast<const Entry*>(base_b1 + ib1 * (int)sizeof(Entry));
+                    if (lane < np) {
+                        double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa0.j ^ xb0.j));
+                        __hip_atomic_fetch_add(dst, gram_product(xa0.v, xb0.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    if (lane < np1) {
+                        double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa1.j ^ xb1.j));
+                        __hip_atomic_fetch_add(dst, gram_product(xa1.v, xb1.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    ++c;
+                    continue;
+                }
+            }
+            for (int p = lane; p - lane < np; p += 128, pf += 128.0f) {
+                const int ia0 = (int)(pf * rcp), ia1 = (int)((pf + 64.0f) * rcp);
+                const int ib0 = p - __mul24(ia0, lbR), ib1 = p + 64 - __mul24(ia1, lbR);
+                const Entry xa0 = *reinterpret_cast<const Entry*>(base_a + ia0 * (int)sizeof(Entry));
+                const Entry xb0 = *reinterpret_cast<const Entry*>(base_b + ib0 * (int)sizeof(Entry));
+                const Entry xa1 = *reinterpret_cast<const Entry*>(base_a + ia1 * (int)sizeof(Entry));
+                const Entry xb1 = *reinterpret_cast<const Entry*>(base_b + ib1 * (int)sizeof(Entry));
+                if (p < np) {
+                    double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa0.j ^ xb0.j));
+                    __hip_atomic_fetch_add(dst, gram_product(xa0.v, xb0.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (p + 64 < np) {
                     double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa1.j ^ xb1.j));
                     __hip_atomic_fetch_add(dst, gram_product(xa1.v, xb1.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
