@@ -231,7 +231,12 @@ int32_t srx_select_hvg(srx_mat* m, uint64_t n, uint64_t* idx_out, uint64_t* n_ou
  * Hard spectra (a few strong components over a flat bulk) are handled by bounding the filter
  * degree, by deflation rounds of <= 32 components when one round stalls, and by a last-resort
  * mode (CholeskyQR3 after every application of C; SRX_PCA_ROBUST=1 forces it): SRX_E_NOCONV is
- * left for a zero matrix, NaN input or an exhausted max_iter. */
+ * left for a zero matrix, NaN input or an exhausted max_iter.  n_components beyond the structural
+ * rank bound min(k, N - centred) is SRX_E_ARG (k <= 64 excepted: the exact eigen-solver takes any
+ * rank); components beyond the NUMERICAL rank of the selected columns (a handful of cells, most
+ * selected columns empty) come back with explained variance 0 and a zero vector (k > 64) or an
+ * arbitrary unit vector of the null space (k <= 64) — the reference returns whatever its SVD
+ * makes of a zero singular value. */
 typedef enum srx_pca_solver {
     SRX_SOLVER_AUTO = 0,
     SRX_SOLVER_GRAM = 1,   /* explicit sparse Gram X_sel^T X_sel once, dense k x k iteration  */

@@ -44,7 +44,15 @@ for it in range(160):
             continue
         m = oracle.Csr(n, g, x.indptr, x.indices, x.data)
         lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
-        d = lg.values
+        if "block lost rank" in msg:
+            # more components asked for than the selected columns have numerical rank, with k > 64 (k <= 64 goes to the
+            # exact eigen-solver and takes any rank): documented refusal (include/srx.h, srx_pca)
+            sel = oracle.select_hvg(oracle.compute_variance(lg, 1), hvg)
+            zz = oracle.densify_selected(lg, sel)
+            zz = zz - (zz.mean(axis=0) if cen else 0.0)
+            if len(sel) > 64 and np.linalg.matrix_rank(zz) < npc:
+                skipped += 1
+                continue
         print("FAIL", tag, rc, msg[:90]); bad += 1
         continue
     kk = int(res.pca.k)

@@ -717,15 +717,16 @@ __device__ __forceinline__ double gram_product(float a, float b) { return (doubl
 __device__ __forceinline__ double gram_product(double a, double b) { return a * b; }
 template <typename VT> struct GramCfg;
 // kRows: cells per batch (lane l holds the start of cell l: kRows + 1 <= 64 pointers); kCap: staged entries per side
-// (a cell holds <= 128 entries of a tile)
+// (a cell holds <= 128 entries of a tile); kPaths: size-class paths in use (1: 8-lane groups for <= 8 products, 2: whole
+// wave for > 32, 4: one slice per cell for <= 16; SRX_GRAM_PATHS overrides); kFineSort: five-way ranking of a batch
 // (8 waves x 63 cells x 256 entries — half the batches, half the waves: 9.5 ms against 7.3 at c3)
-template <> struct GramCfg<float> { static constexpr int kWavesPerWg = 16, kRows = 32, kCap = 128; };    // 16 x 2048 B of staging
-template <> struct GramCfg<double> { static constexpr int kWavesPerWg = 8, kRows = 32, kCap = 128; };    //  8 x 4096 B: the LDS is full to the byte
+template <> struct GramCfg<float> { static constexpr int kWavesPerWg = 16, kRows = 32, kCap = 128, kPaths = 7; static constexpr bool kFineSort = true; };    // 16 x 2048 B of staging
+template <> struct GramCfg<double> { static constexpr int kWavesPerWg = 8, kRows = 32, kCap = 128, kPaths = 6; static constexpr bool kFineSort = false; };    //  8 x 4096 B: the LDS is full to the byte
 
 template <typename VT>
 __global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
     const int64_t* __restrict__ tptr, const GramPk<VT>* __restrict__ tpk, uint64_t n_rows, int ntg,
-    uint64_t rows_per_block, int n_pairs, double* __restrict__ part, const int* __restrict__ pair_order) {
+    uint64_t rows_per_block, int n_pairs, double* __restrict__ part, const int* __restrict__ pair_order, int paths) {
     constexpr int kWaves = GramCfg<VT>::kWavesPerWg, kRows = GramCfg<VT>::kRows, kCap = GramCfg<VT>::kCap;
     constexpr int kThreads = kWaves * kWave;
     using Entry = GramPk<VT>;
@@ -851,7 +852,7 @@ __global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
         // lanes stay busy (21.6 -> ~16 slices per batch of 32 cells on the bench matrix with three classes).
         // Order inside a class is the original one.
         int packed, n_tiny, n_mid, n_live;
-        {
+        if constexpr (GramCfg<VT>::kFineSort) {
             const int npl = cur.la * cur.lb;                         // 0 for lanes past the batch
             const bool valid = lane < cur.nr;
             // classes: 1..8 products (eight cells per pass, 8-lane groups), <= 16, <= 32, more; cells without a
@@ -868,9 +869,26 @@ __global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
                           : cls == 4 ? n3 + __popcll(mz & below)
                                      : lane;                          // lanes >= nr keep their place (they are >= nr)
             packed = __builtin_amdgcn_ds_permute(pos << 2, (valid && npl > 0) ? packed_cell : 0);
-            n_tiny = n0;
-            n_mid = n2;
+            n_tiny = (paths & 1) ? n0 : 0;           // bit 0: the 8-lane path for cells with <= 8 products
+            n_mid = (paths & 2) ? n2 : n3;           // bit 1: the whole-wave path for cells with > 32 products
             n_live = n3;
+        } else {
+            // three classes (<= 16, <= 32, more), nothing dropped: with 8 waves per workgroup (f64 records) the longer
+            // ranking chain of the five-way split costs more than its passes save (18.4 -> 20 ms per launch at c3)
+            const int npl = cur.la * cur.lb;
+            const bool valid = lane < cur.nr;
+            const int cls = !valid ? 3 : npl <= 16 ? 0 : npl <= 32 ? 1 : 2;
+            const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const int n0 = __popcll(m0), n1 = __popcll(m1);
+            const int pos = cls == 0 ? __popcll(m0 & below)
+                          : cls == 1 ? n0 + __popcll(m1 & below)
+                          : cls == 2 ? n0 + n1 + __popcll(m2 & below)
+                                     : lane;
+            packed = __builtin_amdgcn_ds_permute(pos << 2, valid ? packed_cell : 0);
+            n_tiny = 0;
+            n_live = cur.nr;
+            n_mid = (paths & 2) ? n0 + n1 : n_live;
         }
         const char* sa_bytes = reinterpret_cast<const char*>(s_a);
         const char* sb_bytes = reinterpret_cast<const char*>(s_b);
@@ -925,7 +943,7 @@ __global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
             // together and unconditionally (a lane past np reads some record at or past the staging area —
             // LDS reads beyond the allocation return 0 — and drops it), so a wave has two independent
             // read -> multiply -> atomic chains behind each wait
-            if (!__any(np > 16)) {
+            if ((paths & 4) && !__any(np > 16)) {
                 // all four cells of the pass have <= 16 products (45 % of the cells at c3, sorted to the front of the
                 // batch): one slice each, and the NEXT pass rides along when it is of the same kind — eight cells
                 // per trip, two independent read -> multiply -> atomic chains as in the general loop
@@ -1323,13 +1341,14 @@ __global__ void k_init_block(uint64_t seed, int k, int l_act, double* __restrict
 __global__ __launch_bounds__(1024) void k_chol_factor(const double* __restrict__ G, int n, double* __restrict__ Rout,
                                                       double* __restrict__ dinv, int* __restrict__ status, int shifted) {
     __shared__ double A[L][L + 1];
-    __shared__ double s_floor;
+    __shared__ double s_floor, s_diag[L];
     const int tid = threadIdx.x;
     for (int e = tid; e < L * L; e += 1024) {
         const int r = e >> 6, c = e & 63;
         A[r][c] = (r < n && c < n) ? G[(size_t)r * L + c] : 0.0;
     }
     __syncthreads();
+    if (tid < L) s_diag[tid] = A[tid][tid];
     if (tid == 0) {
         double mx = 0.0;
         for (int j = 0; j < n; ++j) mx = A[j][j] > mx ? A[j][j] : mx;
@@ -1339,11 +1358,18 @@ __global__ __launch_bounds__(1024) void k_chol_factor(const double* __restrict__
     bool bad = false;
     for (int j = 0; j < n; ++j) {
         double d = A[j][j];
-        if (shifted && !(d > s_floor)) d = s_floor;          // (a zero matrix keeps its zero pivot: reported below)
-        if (!(d > 0.0)) bad = true;
-        const double inv = rsqrt(d), inv2 = inv * inv;
+        // shifted (last-resort) mode: a pivot below 1e-13 of the largest diagonal entry means the column depends on the
+        // ones before it — the block is wider than the numerical rank of the data (a handful of cells, most selected
+        // columns empty).  The column is DROPPED (zero in Q: dinv = 0, empty row of R) instead of being scaled up from
+        // rounding noise; it stays zero under C, and its Ritz pair comes out as (0, 0).  "Dependent" = the pivot is
+        // below 1e-13 of the column's OWN squared norm (s_diag, taken before the elimination).  (A zero or NaN matrix
+        // keeps its non-positive pivot: reported below.)
+        const bool drop = shifted && s_floor > 0.0 && d == d && !(d > 1e-13 * s_diag[j]);
+        if (!drop && shifted && !(d > s_floor)) d = s_floor;   // independent but tiny next to the others: lifted as before
+        if (!drop && !(d > 0.0)) bad = true;
+        const double inv = drop ? 0.0 : rsqrt(d), inv2 = inv * inv;
         if (tid < L) {
-            Rout[(size_t)j * L + tid] = (tid >= j && tid < n) ? A[j][tid] * inv : 0.0;
+            Rout[(size_t)j * L + tid] = (tid >= j && tid < n) ? (drop ? (tid == j ? 1.0 : 0.0) : A[j][tid] * inv) : 0.0;
             if (tid == j) dinv[j] = inv;
         }
 #pragma unroll
@@ -1874,6 +1900,7 @@ static int32_t launch_gram(srx_ctx* ctx, const Tiled& g, double** packed_out, si
     double* part;
     SRX_TRY(scratch(ctx, "pca_gpart", n_rb * (size_t)n_pairs * KG * KG * sizeof(double), (void**)&part));
     constexpr int kGramWaves = GramCfg<VT>::kWavesPerWg;
+    static const int paths = getenv("SRX_GRAM_PATHS") ? atoi(getenv("SRX_GRAM_PATHS")) : GramCfg<VT>::kPaths;
     const size_t lds = (size_t)KG * KG * sizeof(double) + (size_t)kGramWaves * (2 * GramCfg<VT>::kCap * sizeof(GramPk<VT>));
     // algorithmic bytes: the compacted matrix (8-byte entries + per-tile row pointers) read ONCE and G written
     // once.  The kernel re-reads every 128-tile once per tile pair it belongs to (n_t + 1 times, from L2 /
@@ -1882,7 +1909,7 @@ static int32_t launch_gram(srx_ctx* ctx, const Tiled& g, double** packed_out, si
                                       (double)g.k * g.k * 8.0);
     SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_sparse<VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_gram_sparse<VT>), dim3((unsigned)(n_rb * n_pairs)), dim3(kGramWaves * kWave), lds, ctx->stream, g.tptr,
-                       (const GramPk<VT>*)g.tpk, g.n_rows, ntg, rpb, n_pairs, part, (const int*)d_order);
+                       (const GramPk<VT>*)g.tpk, g.n_rows, ntg, rpb, n_pairs, part, (const int*)d_order, paths);
     double* P;
     SRX_TRY(scratch(ctx, "pca_gpacked", (size_t)n_pairs * KG * KG * sizeof(double), (void**)&P));
     hipLaunchKernelGGL(k_gram_reduce, dim3((KG * KG + 255) / 256, n_pairs), dim3(256), 0, ctx->stream, part, n_rb, n_pairs, P);

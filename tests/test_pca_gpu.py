@@ -583,3 +583,35 @@ def test_small_k_goes_straight_to_the_eigensolver(ctx, n, g, density, n_pc, cent
     assert np.abs(comps.T @ comps - np.eye(n_pc)).max() < 1e-10
     assert np.abs(z.T @ (z @ comps) - comps * th).max() < 1e-9 * max(th[0], 1.0)
     assert np.abs(scores - z @ comps).max() < 1e-9 * max(np.abs(scores).max(), 1.0)
+
+
+@pytest.mark.parametrize("seed", [3, 11, 29])
+def test_block_wider_than_numerical_rank(ctx, seed):
+    """Five cells, 130 genes, ~13 counts, HVG(65) without centring or scaling: k = 65 > 64 takes the iterative solver with a
+    block as wide as the structural rank bound (5), but most selected columns are empty and the numerical rank can be
+    lower.  The last-resort mode drops the dependent columns (fuzz_pca.py seed 83): the pairs of the non-zero eigenvalues
+    must be exact, the others come back as (0, zero vector)."""
+    import ctypes as C
+    import scipy.sparse as sp
+    import singlerust_amd as sr
+    from singlerust_amd import _ffi as F
+    rng = np.random.default_rng(seed)
+    x = sp.random(5, 130, density=0.02, random_state=seed, format="csr",
+                  data_rvs=lambda s: rng.integers(1, 30, s).astype(np.float64), dtype=np.float64)
+    x.sort_indices()
+    a = sr.IMAnnData.new_basic(x, ctx=ctx, store=2)
+    opts = F.PcaOpts(5, 0, 0, -1, 0, 0, 0, 0.0, 1)
+    res = F.PipelineResult()
+    F.check(F.lib().srx_pipeline(a.x().handle, 1e4, 65, C.byref(opts), C.byref(res)), ctx.handle)
+    k = int(res.pca.k)
+    scores, comps, evr, hv = np.zeros((5, 5)), np.zeros((k, 5)), np.zeros(5), np.zeros(k, np.uint64)
+    F.check(F.lib().srx_result_fetch(a.x().handle, F.ptr(scores), F.ptr(comps), F.ptr(evr), None, None, F.ptr(hv)), ctx.handle)
+    m = oracle.Csr(5, 130, x.indptr.astype(np.uint64), x.indices.astype(np.uint64), x.data)
+    z = oracle.densify_selected(oracle.log1p_transform(oracle.normalize_total(m, 1e4, 0)), hv)
+    s2 = np.linalg.svd(z, compute_uv=False) ** 2
+    live = s2 > 1e-9 * s2[0]
+    assert np.isfinite(comps).all() and np.isfinite(scores).all()
+    assert np.allclose(evr[live], s2[live] / s2.sum(), rtol=1e-7)
+    cv = z.T @ (z @ comps)
+    assert (np.linalg.norm(cv[:, live] - comps[:, live] * s2[live], axis=0) / s2[live]).max() < 1e-7
+    assert np.abs(evr[~live]).max(initial=0.0) < 1e-9 and np.abs(scores - z @ comps).max() < 1e-7 * max(1.0, np.abs(scores).max())
