@@ -154,6 +154,7 @@ def main():
     launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # under torch.distributed.run
     group = StarGroup(rank, world)
     dist = group if (world > 1 or launched) else None
+    json_fd = None
     if dist is not None:
         # RCCL prints a version banner on stdout at init: keep stdout clean for the one JSON line
         sys.stdout.flush()
@@ -186,8 +187,9 @@ def main():
                 collective = "host-star"
                 print(f"[bench rank {rank}] RCCL unavailable ({comm_err or 'see other ranks'}): host all-reduce", file=sys.stderr)
         finally:
-            os.dup2(saved, 1)
-            os.close(saved)
+            # fd 1 stays on stderr for the rest of a multi-rank run (RCCL may warn on stdout at any collective); the one
+            # JSON line goes to the saved descriptor at the end
+            json_fd = saved
 
     cells, genes, density, seed = CONFIGS[a.config]
     if a.cells:
@@ -319,7 +321,11 @@ def main():
             except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
                 out["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}
-        print(json.dumps(out), flush=True)
+        if json_fd is not None:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+        else:
+            print(json.dumps(out), flush=True)
 
     for c in copies:
         c.free()
