@@ -208,6 +208,7 @@ def main():
                                    F.STORE_F64 if f64 else F.STORE_F32, C.byref(h)), ctx.handle)
     pristine = sr.DeviceCsr(ctx, h)
     pristine.prepare()          # pattern-only row/gene-tile cuts: part of the resident layout, like indptr
+    pristine.reserve_results(a.hvg, a.npc)      # output block (scores + small results): clones get their own, before the clock
     info = pristine.info()
     nnz = int(info.nnz)
     t_gen = time.perf_counter() - t_gen
@@ -250,7 +251,11 @@ def main():
         sync_all()
         t0 = time.perf_counter()
         for _ in range(chunk):
+            ts = time.perf_counter()
             step(copies[used]); used += 1
+            if os.environ.get("SRX_BENCH_TRACE"):
+                print(f"[bench] step {done} copy {used - 1}: {(time.perf_counter() - ts) * 1e3:.2f} ms host, pca stage {res.ms_pca:.2f} ms",
+                      file=sys.stderr)
             stage["normalize"] += res.ms_normalize; stage["moments"] += res.ms_moments
             stage["select"] += res.ms_select; stage["pca"] += res.ms_pca
             iters.append(int(res.pca.n_iter))

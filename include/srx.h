@@ -152,6 +152,10 @@ int32_t srx_matrix_download_values(srx_mat* m, void* values_out, int32_t dtype_o
  * row used by the per-gene passes) instead of lazily at first use; clones inherit them.  They
  * depend on indptr/indices only, never on the values. */
 int32_t srx_matrix_prepare(srx_mat* m);
+/* Allocate the handle's result block now (N x n_components f64 scores + the small results of a PCA over
+ * n_selected features) instead of inside the first srx_pca / srx_pipeline on it: a pipeline step on a prepared
+ * and reserved matrix makes no device allocation.  Clones inherit the reservation (each gets its own block). */
+int32_t srx_matrix_reserve_results(srx_mat* m, uint64_t n_selected, int32_t n_components);
 /* Deep copy on device (normalize_total / log1p_transform, the copying forms,
  * processing/mod.rs:314-322,329-332, deep_clone X). */
 int32_t srx_matrix_clone(srx_mat* m, srx_mat** out);

@@ -153,6 +153,7 @@ extern "C" {
     pub fn srx_matrix_set_shard(m: *mut SrxMat, row_offset: u64) -> i32;
     pub fn srx_matrix_download_values(m: *mut SrxMat, values_out: *mut c_void, dtype_out: i32) -> i32;
     pub fn srx_matrix_prepare(m: *mut SrxMat) -> i32;
+    pub fn srx_matrix_reserve_results(m: *mut SrxMat, n_selected: u64, n_components: i32) -> i32;
     pub fn srx_matrix_clone(m: *mut SrxMat, out: *mut *mut SrxMat) -> i32;
     pub fn srx_matrix_copy_values(dst: *mut SrxMat, src: *const SrxMat) -> i32;
     pub fn srx_matrix_free(m: *mut SrxMat);

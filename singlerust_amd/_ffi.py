@@ -102,6 +102,7 @@ _SIGS = {
     "srx_matrix_set_shard": (C.c_int32, [P, C.c_uint64]),
     "srx_matrix_download_values": (C.c_int32, [P, P, C.c_int32]),
     "srx_matrix_prepare": (C.c_int32, [P]),
+    "srx_matrix_reserve_results": (C.c_int32, [P, C.c_uint64, C.c_int32]),
     "srx_matrix_clone": (C.c_int32, [P, C.POINTER(P)]),
     "srx_matrix_copy_values": (C.c_int32, [P, P]),
     "srx_matrix_free": (None, [P]),

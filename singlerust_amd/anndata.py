@@ -207,6 +207,10 @@ class DeviceCsr:
         """Build the pattern-only index structures of the device layout now (clones inherit them)."""
         F.check(F.lib().srx_matrix_prepare(self._h), self.ctx.handle)
 
+    def reserve_results(self, n_selected: int, n_components: int) -> None:
+        """Allocate the result block (scores + small PCA results) ahead of the first solve; clones inherit it."""
+        F.check(F.lib().srx_matrix_reserve_results(self._h, n_selected, n_components), self.ctx.handle)
+
     def clone(self) -> "DeviceCsr":
         h = C.c_void_p()
         F.check(F.lib().srx_matrix_clone(self._h, C.byref(h)), self.ctx.handle)

@@ -631,6 +631,11 @@ int32_t srx_matrix_clone(srx_mat* m, srx_mat** out) {
             if (e == hipSuccess) e = hipMemcpyAsync(c->d_idx16, m->d_idx16, ib, hipMemcpyDeviceToDevice, ctx->stream);
         }
     }
+    // a reserved result block (srx_matrix_reserve_results) is part of the handle's layout: the clone gets its own
+    if (e == hipSuccess && m->pca.scores_cap > 0) {
+        e = hipMalloc((void**)&c->pca.d_scores, m->pca.scores_cap);
+        if (e == hipSuccess) c->pca.scores_cap = m->pca.scores_cap;
+    }
     if (e != hipSuccess) {
         srx_matrix_free(c);
         return fail(ctx, SRX_E_HIP, "clone D2D: %s", hipGetErrorString(e));

@@ -2325,6 +2325,31 @@ __global__ void k_deflate(double* __restrict__ C, int k, const double* __restric
     C[e] -= s;
 }
 
+// Size of a matrix's result allocation: the N x n_pc f64 scores followed by the block of small results
+// (layout: srx_pca_state::d_small) for the most rounds either plan can take.
+static void result_layout(uint64_t n_rows, int k, int n_pc, int dim, size_t& score_bytes, size_t& small_doubles,
+                          std::vector<int>* plan_a_out = nullptr, std::vector<int>* plan_b_out = nullptr) {
+    const size_t kl = (size_t)k * L;
+    const std::vector<int> pa = plan_rounds(dim, n_pc, n_pc <= L - 8 ? n_pc : kPcaPerRound);
+    const int n_b = (n_pc + kPcaPerRoundSafe - 1) / kPcaPerRoundSafe;
+    const std::vector<int> pb = plan_rounds(dim, n_pc, (n_pc + n_b - 1) / n_b);
+    const int rounds_cap = (int)std::max(pa.size(), pb.size());
+    score_bytes = (n_rows ? n_rows : 1) * (size_t)n_pc * 8;
+    small_doubles = (size_t)rounds_cap * (kl + 2 * L) + 2 * (size_t)k + 2 + ((size_t)k + 1) / 2;
+    if (plan_a_out) *plan_a_out = pa;
+    if (plan_b_out) *plan_b_out = pb;
+}
+static int32_t ensure_result_capacity(srx_ctx* ctx, srx_pca_state& st, size_t need) {
+    if (st.scores_cap < need) {
+        if (st.d_scores) SRX_HIP(ctx, hipFree(st.d_scores));
+        st.d_scores = nullptr;
+        st.scores_cap = 0;
+        SRX_HIP(ctx, hipMalloc((void**)&st.d_scores, need));
+        st.scores_cap = need;
+    }
+    return SRX_OK;
+}
+
 template <typename VT, typename PT>
 static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tiled* t128p, double* gram_packed,
                        const Resolved& o, const std::vector<double>& mu, const std::vector<double>& dinv,
@@ -2372,21 +2397,11 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
     const int n_pc = o.n_pc;
     // dimension of the operator's range: min(k, N - 1) (N when not centred); a block as wide as that is exact
     const int dim = o.direct ? k : (int)std::min<double>((double)k, n_cells - (o.center ? 1.0 : 0.0));
-    const std::vector<int> plan_a = plan_rounds(dim, n_pc, n_pc <= L - 8 ? n_pc : kPcaPerRound);
-    const int n_b = (n_pc + kPcaPerRoundSafe - 1) / kPcaPerRoundSafe;
-    const std::vector<int> plan_b = plan_rounds(dim, n_pc, (n_pc + n_b - 1) / n_b);
-    const int rounds_cap = (int)std::max(plan_a.size(), plan_b.size());
-    // one allocation: the scores, then the block of small results (layout: srx_pca_state::d_small)
-    const size_t score_bytes = (cc.n_rows ? cc.n_rows : 1) * (size_t)n_pc * 8;
-    const size_t small_doubles = (size_t)rounds_cap * (kl + 2 * L) + 2 * (size_t)k + 2 + ((size_t)k + 1) / 2;
-    const size_t need = score_bytes + small_doubles * 8;
-    if (st.scores_cap < need) {
-        if (st.d_scores) SRX_HIP(ctx, hipFree(st.d_scores));
-        st.d_scores = nullptr;
-        st.scores_cap = 0;
-        SRX_HIP(ctx, hipMalloc((void**)&st.d_scores, need));
-        st.scores_cap = need;
-    }
+    std::vector<int> plan_a, plan_b;
+    size_t score_bytes, small_doubles;
+    result_layout(cc.n_rows, k, n_pc, dim, score_bytes, small_doubles, &plan_a, &plan_b);
+    // one allocation: the scores, then the block of small results (srx_matrix_reserve_results makes it ahead of time)
+    SRX_TRY(ensure_result_capacity(ctx, st, score_bytes + small_doubles * 8));
     double* const d_small = st.d_scores + score_bytes / 8;
     // A2 = W U are the Ritz vectors (ascending-gene row order); sign: largest-|.| entry positive.
     // scores = Z V (transform, pca/mod.rs:156-185): one forward SpMM per row tile with the panel D V, the f64 scores
@@ -2860,6 +2875,20 @@ int32_t srx_result_fetch(srx_mat* m, double* scores, double* components, double*
     if (std_) memcpy(std_, st.std_.data(), st.std_.size() * 8);
     if (hvg_idx) memcpy(hvg_idx, st.sel.data(), st.sel.size() * 8);
     return SRX_OK;
+}
+
+int32_t srx_matrix_reserve_results(srx_mat* m, uint64_t n_selected, int32_t n_components) {
+    if (!m) return fail(nullptr, SRX_E_ARG, "null matrix");
+    srx_ctx* ctx = m->ctx;
+    if (n_components < 1 || n_selected < 1) return fail(ctx, SRX_E_ARG, "reserve_results: need n_selected >= 1 and n_components >= 1");
+    SRX_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n_cells = m->csc ? m->n_cols : m->n_rows, n_genes = m->csc ? m->n_rows : m->n_cols;
+    const int k = (int)std::min<uint64_t>(n_selected, n_genes);
+    const int n_pc = std::min(n_components, k);
+    size_t score_bytes, small_doubles;
+    // dim = k bounds the number of rounds from above (fewer dimensions never take more rounds)
+    result_layout(n_cells, k, n_pc, k, score_bytes, small_doubles);
+    return ensure_result_capacity(ctx, m->pca, score_bytes + small_doubles * 8);
 }
 
 int32_t srx_pca(srx_mat* m, const uint64_t* sel, uint64_t k, const srx_pca_opts* opts, double* scores,
