@@ -1,0 +1,15 @@
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out/r2
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|rror" | tail -4
+B="python bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline"
+for v in "SRX_X=0" "SRX_GRAM_RBLK=256 SRX_GRAM_CHUNK=64" "SRX_GRAM_RBLK=1024 SRX_GRAM_CHUNK=16"; do
+env $v $B 2>&1 | python -c "
+import json,sys
+t=sys.stdin.read().strip().splitlines()
+d=json.loads(t[-1]); print('$v','ms/step', round(d['ms_per_step'],3), d['stage_ms_per_step'], {k:round(v['avg_ms'],3) for k,v in d['kernels'].items()})"
+done
+rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o g -- $B > /dev/null 2>&1
+python - <<'PY'
+import csv,sys
+rows=list(csv.DictReader(open('/tmp/kt/g_kernel_stats.csv')))
+for r in rows[:10]: print(r['Name'][:60], r['Calls'], round(float(r['AverageNs'])/1e3,1),'us')
+PY

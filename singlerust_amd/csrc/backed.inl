@@ -94,15 +94,11 @@ static void free_parts(srx_backed* b) {
 template <typename VT>
 static int32_t backed_gram_tile(srx_backed* b, srx_mat* m) {
     srx_ctx* ctx = b->ctx;
-    Tiled t128, t256;
-    if (b->dev_sel) SRX_TRY(build_tiled_fused(m, b->hv.d_bits, b->hv.n_words, b->k, t128, t256));
-    else SRX_TRY(build_tiled_fused(m, b->remap, b->k, t128, t256));
-    double* Pk;
-    size_t n_packed;
-    SRX_TRY(launch_gram<VT>(ctx, t128, &Pk, &n_packed));
-    hipLaunchKernelGGL(k_acc_f64, dim3((unsigned)((n_packed + 255) / 256)), dim3(256), 0, ctx->stream, b->d_gram, Pk,
-                       (uint64_t)n_packed);
-    SRX_HIP(ctx, hipGetLastError());
+    Tiled t256;
+    RowMajor rm;
+    if (b->dev_sel) SRX_TRY(build_tiled_fused(m, b->hv.d_bits, b->hv.n_words, b->k, rm, t256));
+    else SRX_TRY(build_tiled_fused(m, b->remap, b->k, rm, t256));
+    SRX_TRY(launch_gram<VT>(ctx, rm, b->d_gram));            // accumulates into the session's packed matrix
     // keep the 256-tiled view of this tile: exact-size copies out of the scratch buffers
     Tiled keep = t256;
     keep.tptr = nullptr;
@@ -265,8 +261,7 @@ static int32_t backed_select_impl(srx_backed* b, uint64_t n_hvg, const uint64_t*
         std::vector<int> order(k), slot_of_sel(k);
         SRX_TRY(prepare_host_selection(acc, b->selv, b->o, order, slot_of_sel, b->remap, b->mu, b->sd, b->dinv, b->trace));
     }
-    const int nt128 = (k + KG - 1) / KG;
-    b->n_packed = (size_t)(nt128 * (nt128 + 1) / 2) * KG * KG;
+    b->n_packed = gram_packed_count(k);
     SRX_HIP(ctx, hipMalloc((void**)&b->d_gram, b->n_packed * sizeof(double)));
     SRX_HIP(ctx, hipMemsetAsync(b->d_gram, 0, b->n_packed * sizeof(double), ctx->stream));
     if (n_out) *n_out = (uint64_t)k;

@@ -244,6 +244,17 @@ __global__ __launch_bounds__(256) void k_retile(const int64_t* __restrict__ indp
 // non-zero drags a 64-byte line each: 70 GB of L2 traffic at c3): the selection is a bitmask
 // (G/32 words) plus the number of selected genes before each word, both staged in LDS (7 KB at
 // G = 28k); column = prefix[w] + popcount(bits[w] below the gene's bit).
+// ---- owner buckets of the Gram kernel (k_gram_stripes, below) -----------------------------------------
+constexpr int kGramWaves = 16;            // waves per Gram workgroup
+constexpr int kGramUnroll = 8;            // suffix loads in flight per wave
+
+struct GramRec { uint32_t pos, len; };    // entry position relative to its block's first entry; entries from it to the row's end
+
+__device__ __forceinline__ int gram_owner(int c, int sr_shift, int n_wg, int n_stripes) {
+    const int s = c >> sr_shift;
+    return s < n_wg ? s : n_stripes - 1 - s;
+}
+
 struct SelLds {
     const uint32_t* bits;
     const uint32_t* prefix;
@@ -274,7 +285,7 @@ template <typename I>
 __global__ __launch_bounds__(256) void k_tcount(const int64_t* __restrict__ indptr, const I* __restrict__ idx,
                                                 const uint32_t* __restrict__ g_bits,
                                                 const uint32_t* __restrict__ g_prefix, int n_words, uint64_t n_rows,
-                                                int nt128, int nt256, int64_t* __restrict__ cnt128,
+                                                int nt128, int nt256, int k, int64_t* __restrict__ cntrow,
                                                 int64_t* __restrict__ cnt256) {
     extern __shared__ double lds_raw[];
     const SelLds sel = stage_selection(g_bits, g_prefix, n_words, reinterpret_cast<uint32_t*>(lds_raw));
@@ -310,16 +321,18 @@ __global__ __launch_bounds__(256) void k_tcount(const int64_t* __restrict__ indp
                 }
 #pragma unroll
                 for (int u = 0; u < kCountUnroll; ++u) {
-                    const int col = g[u] >= 0 ? sel.column(g[u]) : -1;             // -1 for dropped entries
+                    int col = g[u] >= 0 ? sel.column(g[u]) : -1;             // -1 for dropped entries
+                    if (col >= k) col = -1;          // only a broken selection (NaN variances) has such columns: dropped
                     if (col >= 0) __hip_atomic_fetch_add(&row_cnt[col >> 7], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // lane q -> (tile q / 8, row q % 8)
-        for (int q = lane; q < nt128 * kCompactRows; q += kWave) {
-            const int t = q / kCompactRows, i = q % kCompactRows;
-            if (i < nr) cnt128[(uint64_t)t * n_rows + r0 + i] = (int64_t)tcnt[i * kWave + t];
+        if (lane < nr) {                                   // kept entries of row r0 + lane (the row-major layout's row length)
+            uint32_t tot = 0;
+            for (int t = 0; t < nt128; ++t) tot += tcnt[lane * kWave + t];
+            cntrow[r0 + lane] = (int64_t)tot;
         }
         for (int q = lane; q < nt256 * kCompactRows; q += kWave) {
             const int t = q / kCompactRows, i = q % kCompactRows;
@@ -336,9 +349,9 @@ template <typename T, typename I>
 __global__ __launch_bounds__(256) void k_tfill(const int64_t* __restrict__ indptr, const I* __restrict__ idx,
                                                const T* __restrict__ vals, const uint32_t* __restrict__ g_bits,
                                                const uint32_t* __restrict__ g_prefix, int n_words, uint64_t n_rows,
-                                               int nt128, int nt256, const int64_t* __restrict__ cnt128,
-                                               const int64_t* __restrict__ tptr128,
-                                               const int64_t* __restrict__ tptr256, GramPk<T>* __restrict__ pk128,
+                                               int nt256, int k, const int64_t* __restrict__ cnt256,
+                                               const int64_t* __restrict__ rm_ptr,
+                                               const int64_t* __restrict__ tptr256, GramPk<T>* __restrict__ rm,
                                                GramPk<T>* __restrict__ pk256) {
     extern __shared__ double lds_raw[];
     const SelLds sel = stage_selection(g_bits, g_prefix, n_words, reinterpret_cast<uint32_t*>(lds_raw));
@@ -347,23 +360,23 @@ __global__ __launch_bounds__(256) void k_tfill(const int64_t* __restrict__ indpt
     const int lane = lane_id();
     for (uint64_t r = (wave * kCompactRows); r < n_rows; r = next_compact_row(r, n_waves)) {
         const int64_t lo = indptr[r], hi = indptr[r + 1];
-        // lane t: kept entries before tile t in this row (exclusive prefix over the tile counters)
-        const int c_t = lane < nt128 ? (int)cnt128[(uint64_t)lane * n_rows + r] : 0;
+        // lane t: kept entries before 256-tile t in this row (exclusive prefix over the tile counters)
+        const int c_t = lane < nt256 ? (int)cnt256[(uint64_t)lane * n_rows + r] : 0;
         int inc = c_t;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
             const int o = __shfl_up(inc, off, kWave);
             if (lane >= off) inc += o;
         }
-        const int before128 = inc - c_t;
-        const int before256 = __shfl(before128, (2 * lane) & 63, kWave);     // lane T: before 256-tile T
+        const int before256 = inc - c_t;
         // destination bias of each tile: tptr - (kept entries before the tile)
-        const int64_t off128 = (lane < nt128 ? tptr128[(uint64_t)lane * n_rows + r] : 0) - before128;
         const int64_t off256 = (lane < nt256 ? tptr256[(uint64_t)lane * n_rows + r] : 0) - before256;
+        const int64_t row_base = rm_ptr[r];
         int rank0 = 0;                                  // kept entries of the row before this chunk
         // (tried and slower at c3: 16 chunks in flight, 2.42 ms — the ballots / shuffles of the masked-out tail
         //  chunks cost more than the loads gain; parking the kept entries in LDS and writing them out per row,
-        //  2.59 ms — the value gather then waits for the whole row and the stage halves the occupancy)
+        //  2.59 ms — the value gather then waits for the whole row and the stage halves the occupancy; bucketing the
+        //  entries by Gram owner here, one workgroup per row block: 2.65 ms against 1.3 + a separate 0.4 ms pass)
         for (int64_t base = lo; base < hi; base += kFillUnroll * kWave) {
             int32_t g[kFillUnroll];
 #pragma unroll
@@ -374,18 +387,18 @@ __global__ __launch_bounds__(256) void k_tfill(const int64_t* __restrict__ indpt
 #pragma unroll
             for (int u = 0; u < kFillUnroll; ++u) {
                 const int64_t p = base + u * kWave + lane;
-                const int32_t c = g[u] >= 0 ? sel.column(g[u]) : -1;
+                int32_t c = g[u] >= 0 ? sel.column(g[u]) : -1;
+                if (c >= k) c = -1;
                 const unsigned long long mask = __ballot(c >= 0);
                 const int cc = c >= 0 ? c : 0;
-                const int64_t o128 = __shfl(off128, cc >> 7, kWave);   // shuffles run with all lanes active
-                const int64_t o256 = __shfl(off256, cc >> 8, kWave);
+                const int64_t o256 = __shfl(off256, cc >> 8, kWave);   // shuffles run with all lanes active
                 if (c >= 0) {
                     const int rank = rank0 + __popcll(mask & ((1ull << lane) - 1ull));
                     const T v = vals[p];
                     GramPk<T> e{};
-                    e.j = c & 127;
+                    e.j = c;
                     e.v = v;
-                    pk128[o128 + rank] = e;
+                    rm[row_base + rank] = e;
                     e.j = c & 255;
                     pk256[o256 + rank] = e;
                 }
@@ -686,415 +699,321 @@ __global__ void k_t_reduce(const AT* __restrict__ part, const double* __restrict
     }
 }
 
-// ---- explicit sparse Gram: G = A^T A, one 128 x 128 f64 tile per workgroup --------------------------
-// Workgroup = (gene-tile pair (a <= b), row block); LDS holds the 128 x 128 f64 tile (128 KiB,
-// column index XOR-swizzled by the row so that products sharing jb spread over the banks) and a
-// small staging area per wave.  A wave walks its contiguous share of the row block in batches of
-// up to 32 cells whose tile-a and tile-b entries fit the staging area (two contiguous ranges of
-// packed 8-byte (column, value) records: coalesced loads -> LDS).  Each 16-lane group then takes
-// TWO cells at a time and spreads each cell's la*lb products over its lanes: (ia, ib) = divmod(p, lb)
-// with a group-uniform lb, two staged reads, one LDS f64 atomic at (ja, jb) per product.
+// ---- explicit sparse Gram: G = A^T A from the ROW-MAJOR compacted matrix ----------------------------
+// Round 2 design.  The work is N m(m+1)/2 scalar products (m = kept entries of a cell), each ending in an
+// f64 LDS atomic; what the round-1 kernel paid on top of that was two staged LDS reads and ~17 VALU
+// instructions of index arithmetic per product slice, with 22-30 of 64 lanes busy per atomic
+// (profiles/r01_pmc_gram_v6.md).  Here ONE wave instruction is one (cell, entry): the entry (ja, va) and the
+// SUFFIX of its row — the entries with column >= ja, contiguous in the row-major layout — so that lane q
+// holds (jb_q, vb_q) straight from a coalesced global load and adds va * vb_q to G[ja][jb_q].  No staging,
+// no per-product index arithmetic, every cell's upper-triangle products exactly once.
 //
-// What bounds it (bench_micro/lds_atomic_banks.hip, MI355X): an LDS f64 atomic instruction costs
-// ~9 clk + ~0.26 clk per active lane on random addresses (25 clk for 64 lanes, 10 clk for 8), a
-// staged ds_read_b64 ~4 clk, and every wave-level operation queues behind those of the other 15
-// waves, so one product pass has ~1000 clk of latency.  Hence: full instructions (16-lane groups,
-// not lane-per-entry: 19 % utilisation), entries fetched from LDS not L1 (a global-load variant
-// ran 17.5 ms against 10.7), and two independent cells per pass so that a wave keeps two chains in
-// the LDS queue.  [Flattening the products of the whole batch over the lanes costs ~117 VALU
-// instructions per 64 products for the per-product cell search — profiles/r01_pmc_gram_flattened.md.]
-// The cells of a batch are sorted by product count first (ballots + one ds_permute): cells without a
-// product are dropped, cells with <= 8 products run eight to a pass in 8-lane groups, passes of cells
-// with <= 16 products take ONE slice per cell and two passes per trip, cells with <= 32 the two-slice
-// loop (one trip), and a cell with more than 32 products gets the WHOLE wave (64-product slices, its
-// extents in scalars; two single-slice cells go out together): c3 7.9 -> 7.4 ms; c5's density, where
-// most cells are small, 8.5 -> 6.7 ms; c2's, where they are large, 1.60 -> 1.40 ms.
-// Diagonal pairs compute the full tile.  Per-(row block, pair) partial tiles are summed in fixed
-// order by k_gram_reduce.
-// f32 storage: the product is formed in f32 (one rounding of 2^-24, the precision the stored values
-// have anyway) and widened once; f64 storage multiplies in f64.
+// Ownership: G's upper triangle is cut into STRIPES of SR rows; workgroup w owns stripes w and
+// n_stripes - 1 - w (long rows at the top, short ones at the bottom: SR (k + SR) doubles of LDS per
+// workgroup whatever w — 64 KiB at k = 2000, SR = 4, two workgroups per CU).  The entries a workgroup needs
+// are those whose column lies in its two stripes: k_bucket sorts the entries of every block of kBucketRows
+// cells by owner, so that a wave fetches its share of a block as one contiguous run of 8-byte records
+// (position of the entry relative to the block, suffix length).  All workgroups walk the row blocks in the
+// same order at about the same pace, so the row-major matrix streams through L2 / Infinity Cache once per
+// XCD while every cell is visited by the ~m workgroups that own one of its entries.
+template <typename VT> struct GramPk;
 __device__ __forceinline__ double gram_product(float a, float b) { return (double)(a * b); }
 __device__ __forceinline__ double gram_product(double a, double b) { return a * b; }
-template <typename VT> struct GramCfg;
-// kRows: cells per batch (lane l holds the start of cell l: kRows + 1 <= 64 pointers); kCap: staged entries per side
-// (a cell holds <= 128 entries of a tile); kPaths: size-class paths in use (1: 8-lane groups for <= 8 products, 2: whole
-// wave for > 32, 4: one slice per cell for <= 16; SRX_GRAM_PATHS overrides); kFineSort: five-way ranking of a batch
-// (8 waves x 63 cells x 256 entries — half the batches, half the waves: 9.5 ms against 7.3 at c3)
-template <> struct GramCfg<float> { static constexpr int kWavesPerWg = 16, kRows = 32, kCap = 128, kPaths = 7; static constexpr bool kFineSort = true; };    // 16 x 2048 B of staging
-template <> struct GramCfg<double> { static constexpr int kWavesPerWg = 8, kRows = 32, kCap = 128, kPaths = 6; static constexpr bool kFineSort = false; };    //  8 x 4096 B: the LDS is full to the byte
 
+// Entries of a block of kBucketRows cells, grouped by owning workgroup (counting sort in LDS; the order inside
+// a group is whatever the LDS atomics make it — the Gram sums are order-dependent in their last bits anyway).
+// boff[rb][w] .. boff[rb][w + 1]: records of owner w, relative to the block's first entry.
+constexpr int kBucketThreads = 1024;
+constexpr int kBucketUnroll = 4;          // entries in flight per thread
 template <typename VT>
-__global__ __launch_bounds__(GramCfg<VT>::kWavesPerWg * 64) void k_gram_sparse(
-    const int64_t* __restrict__ tptr, const GramPk<VT>* __restrict__ tpk, uint64_t n_rows, int ntg,
-    uint64_t rows_per_block, int n_pairs, double* __restrict__ part, const int* __restrict__ pair_order, int paths) {
-    constexpr int kWaves = GramCfg<VT>::kWavesPerWg, kRows = GramCfg<VT>::kRows, kCap = GramCfg<VT>::kCap;
-    constexpr int kThreads = kWaves * kWave;
-    using Entry = GramPk<VT>;
-    constexpr int kStageBytes = 2 * kCap * (int)sizeof(Entry);
-    static_assert(KG * KG * 8 + kWaves * kStageBytes <= 163840, "LDS budget");
+__global__ __launch_bounds__(kBucketThreads) void k_bucket(const int64_t* __restrict__ rm_ptr, const GramPk<VT>* __restrict__ rm,
+                                                           uint64_t n_rows, uint32_t rblk, int sr_shift, int n_wg, int n_stripes,
+                                                           uint32_t* __restrict__ boff, GramRec* __restrict__ recs) {
     extern __shared__ double lds_raw[];
-    double* acc = lds_raw;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(lds_raw);        // n_wg + 1 counters, then rblk + 1 row ends
+    uint32_t* rptr = hist + n_wg + 1;                             // row starts of the block, relative to its first entry
+    const uint64_t rb = blockIdx.x;
+    const uint64_t r0 = rb * rblk;
+    const uint64_t r1 = r0 + rblk < n_rows ? r0 + rblk : n_rows;
+    const int nr = (int)(r1 - r0);
+    const int lane = lane_id(), wave = threadIdx.x / kWave;
+    const int64_t base = rm_ptr[r0];
+    for (int e = threadIdx.x; e <= n_wg; e += kBucketThreads) hist[e] = 0u;
+    for (int e = threadIdx.x; e <= nr; e += kBucketThreads) rptr[e] = (uint32_t)(rm_ptr[r0 + e] - base);
+    __syncthreads();
+    // the block's entries are ONE contiguous run of the row-major array: walk it flat (coalesced, no pointer chase),
+    // kBucketUnroll column loads in flight per thread
+    const uint32_t total = rptr[nr];
+    const GramPk<VT>* rmb = rm + base;
+    constexpr uint32_t kStep = kBucketThreads * kBucketUnroll;
+    for (uint32_t p0 = threadIdx.x; p0 < total; p0 += kStep) {
+        int c[kBucketUnroll];
+#pragma unroll
+        for (int u = 0; u < kBucketUnroll; ++u) {
+            const uint32_t p = p0 + u * kBucketThreads;
+            c[u] = p < total ? rmb[p].j : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kBucketUnroll; ++u)
+            if (c[u] >= 0)
+                __hip_atomic_fetch_add(&hist[gram_owner(c[u], sr_shift, n_wg, n_stripes)], 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    // exclusive scan of the n_wg counters by wave 0, 64 at a time
+    if (wave == 0) {
+        uint32_t carry = 0;
+        for (int c0 = 0; c0 < n_wg; c0 += kWave) {
+            const int i = c0 + lane;
+            const uint32_t v = i < n_wg ? hist[i] : 0u;
+            uint32_t inc = v;
+#pragma unroll
+            for (int off = 1; off < kWave; off <<= 1) {
+                const uint32_t o = __shfl_up(inc, off, kWave);
+                if (lane >= off) inc += o;
+            }
+            if (i < n_wg) {
+                hist[i] = carry + inc - v;
+                boff[rb * (uint64_t)(n_wg + 1) + i] = carry + inc - v;
+            }
+            carry += __shfl(inc, kWave - 1, kWave);
+        }
+        if (lane == 0) boff[rb * (uint64_t)(n_wg + 1) + n_wg] = carry;
+    }
+    __syncthreads();
+    GramRec* rcb = recs + base;
+    int r = 0;                                     // row of entry p: p moves forward, so does r
+    for (uint32_t p0 = threadIdx.x; p0 < total; p0 += kStep) {
+        int c[kBucketUnroll];
+#pragma unroll
+        for (int u = 0; u < kBucketUnroll; ++u) {
+            const uint32_t p = p0 + u * kBucketThreads;
+            c[u] = p < total ? rmb[p].j : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kBucketUnroll; ++u) {
+            const uint32_t p = p0 + u * kBucketThreads;
+            if (c[u] >= 0) {
+                while (rptr[r + 1] <= p) ++r;
+                const uint32_t slot = __hip_atomic_fetch_add(&hist[gram_owner(c[u], sr_shift, n_wg, n_stripes)], 1u,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                rcb[slot] = GramRec{p, rptr[r + 1] - p};
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float readfirst_v(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+__device__ __forceinline__ double readfirst_v(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// index of (i, j), i <= j, in the packed upper triangle (row-major, row i holds columns i .. k - 1)
+__host__ __device__ __forceinline__ size_t tri_index(int i, int j, int k) {
+    return (size_t)i * (size_t)k - (size_t)i * (size_t)(i - 1) / 2 + (size_t)(j - i);
+}
+
+template <typename VT, bool kCoop>
+__global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
+    const int64_t* __restrict__ rm_ptr, const GramPk<VT>* __restrict__ rm, const uint32_t* __restrict__ boff,
+    const GramRec* __restrict__ recs, uint64_t n_rblk, uint32_t rblk, int k, int sr_shift, int n_wg, int n_stripes, int n_z,
+    int* __restrict__ pace /* one arrival counter per window, zeroed; nullptr = free-running */, int lag, uint32_t n_chunk,
+    double* __restrict__ Gp /* packed upper triangle, ACCUMULATED into (global f64 atomics) */) {
+    using Entry = GramPk<VT>;
+    extern __shared__ double acc[];
+    const int w = blockIdx.x % n_wg, z = blockIdx.x / n_wg;
+    const int SR = 1 << sr_shift;
+    const int a0 = w * SR, b0 = (n_stripes - 1 - w) * SR;
+    const int WA = k - a0, WB = k - b0 > 0 ? k - b0 : 0;
+    const int n_acc = SR * (WA + WB);
+    for (int e = threadIdx.x; e < n_acc; e += blockDim.x) acc[e] = 0.0;
+    __syncthreads();
     const int lane = lane_id();
-    const int wave = threadIdx.x / kWave;
-    char* stage = reinterpret_cast<char*>(lds_raw + KG * KG) + wave * kStageBytes;
-    Entry* s_a = reinterpret_cast<Entry*>(stage);
-    Entry* s_b = s_a + kCap;
-    for (int e = threadIdx.x; e < KG * KG; e += kThreads) acc[e] = 0.0;
-    __syncthreads();
-    int pair;
-    uint64_t rb;
-    if (pair_order) {
-        // XCD-aware placement (workgroups go round-robin over the 8 XCDs, each with its own L2): XCD x owns the row
-        // blocks = x (mod 8) and walks their tile pairs in `pair_order` — square groups of pairs that share tiles —
-        // so that the workgroups resident on an XCD at the same time read the same tile rows at about the same
-        // time and the re-reads of a tile (17 pairs use it) have a chance to hit in that XCD's L2
-        const unsigned xcd = blockIdx.x & 7u, i = blockIdx.x >> 3;
-        pair = pair_order[i % n_pairs];
-        rb = (uint64_t)(i / n_pairs) * 8u + xcd;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int a_end = a0 + SR;
+    // accumulator of (ja, jb): stripe A rows are WA wide and start at column a0, stripe B rows WB wide from b0
+    auto row_base = [&](int ja) { return ja < a_end ? (ja - a0) * WA - a0 : SR * WA + (ja - b0) * WB - b0; };
+    // kGramUnroll records (lanes u0 .. of `rec`; records past the run have len 0): their suffix loads go out together,
+    // then one masked LDS atomic instruction per record
+    auto batch = [&](const Entry* __restrict__ rmb, const GramRec& rec, int u0) {
+        Entry e[kGramUnroll];
+        uint32_t pos[kGramUnroll], len[kGramUnroll];
+#pragma unroll
+        for (int u = 0; u < kGramUnroll; ++u) {
+            pos[u] = (uint32_t)__builtin_amdgcn_readlane((int)rec.pos, u0 + u);
+            len[u] = (uint32_t)__builtin_amdgcn_readlane((int)rec.len, u0 + u);
+            e[u] = rmb[pos[u] + lane];       // unconditional (the array is padded by a wave of records): no branch
+        }                                    // around the loads, and the waits below count them
+#pragma unroll
+        for (int u = 0; u < kGramUnroll; ++u) {
+            const int ja = __builtin_amdgcn_readfirstlane(e[u].j);      // lane 0 holds the entry itself
+            const VT va = readfirst_v(e[u].v);
+            const int rbase = row_base(ja);
+            if ((uint32_t)lane < len[u])
+                __hip_atomic_fetch_add(&acc[rbase + e[u].j], gram_product(va, e[u].v), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (len[u] > (uint32_t)kWave)
+                for (uint32_t o = kWave; o < len[u]; o += kWave) {          // suffixes longer than a wave: rare
+                    if (o + lane < len[u]) {
+                        const Entry x = rmb[pos[u] + o + lane];
+                        __hip_atomic_fetch_add(&acc[rbase + x.j], gram_product(va, x.v), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+        }
+    };
+    if constexpr (kCoop) {
+        // All waves of the workgroup are in the SAME row block, a wave taking every kGramWaves-th batch of the block's
+        // run, and all workgroups stay within `lag` windows of each other (window j = row blocks j n_z .. j n_z + n_z - 1):
+        // the rows of a window are then fetched into each XCD's L2 once and hit by the ~60 workgroups of that XCD — left
+        // to themselves the workgroups drift tens of blocks apart (their shares differ by a few per cent) and every
+        // suffix read goes out to the Infinity Cache (L2 hit rate 12 %, 50 GB of fabric reads per launch at c3).
+        // The pacing is a HINT: a wave waits a bounded time for the slowest workgroup, then goes on regardless.
+        __shared__ int s_arrive[8];
+        if (threadIdx.x < 8) s_arrive[threadIdx.x] = 0;
+        __syncthreads();
+        const int n_total = n_wg * n_z;
+        int j = 0;
+        for (uint64_t rb = (uint64_t)z; rb < n_rblk; rb += (uint64_t)n_z, ++j) {
+            if (pace && j >= lag) {
+                const int* flag = pace + (j - lag);
+                for (int it = 0; it < 1024 && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_total; ++it)
+                    __builtin_amdgcn_s_sleep(4);
+            }
+            const uint32_t* bo = boff + rb * (uint64_t)(n_wg + 1) + w;
+            const uint32_t o0 = bo[0], o1 = bo[1];
+            const int64_t base = rm_ptr[rb * rblk];
+            const Entry* rmb = rm + base;
+            const GramRec* rc = recs + base;
+            for (uint32_t i0 = o0 + (uint32_t)wave * kGramUnroll; i0 < o1; i0 += kGramWaves * kGramUnroll) {
+                GramRec rec{0u, 0u};
+                if (lane < kGramUnroll && i0 + lane < o1) rec = rc[i0 + lane];
+                batch(rmb, rec, 0);
+            }
+            if (pace && lane == 0) {
+                // the last wave of the workgroup to finish window j reports it
+                const int seen = __hip_atomic_fetch_add(&s_arrive[j & 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (seen == kGramWaves - 1) {
+                    __hip_atomic_store(&s_arrive[j & 7], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(pace + j, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
     } else {
-        pair = blockIdx.x % n_pairs;
-        rb = blockIdx.x / n_pairs;
-    }
-    int a = 0, rem = pair;
-    while (rem >= ntg - a) { rem -= ntg - a; ++a; }
-    const int b = a + rem;
-    const uint64_t r0 = rb * rows_per_block;
-    const uint64_t r1 = r0 + rows_per_block < n_rows ? r0 + rows_per_block : n_rows;
-    const int64_t* pa = tptr + (uint64_t)a * n_rows;
-    const int64_t* pb = tptr + (uint64_t)b * n_rows;
-    const uint64_t per_wave = r1 > r0 ? (r1 - r0 + kWaves - 1) / kWaves : 0;
-    const uint64_t w0 = r0 + (uint64_t)wave * per_wave < r1 ? r0 + (uint64_t)wave * per_wave : r1;
-    const uint64_t w1 = w0 + per_wave < r1 ? w0 + per_wave : r1;
-    const int grp = lane >> 4, q = lane & 15;
-    // Two-deep software pipeline on the global side: while batch n is staged and multiplied out of
-    // LDS, the entry loads of batch n+1 and the row pointers of batch n+2 are in flight.
-    struct Ext {                    // extents of a batch, from its row pointers
-        int64_t a0, b0;
-        int startA, startB, la, lb, nr, nA, nB;
-    };
-    auto load_ptrs = [&](uint64_t rr, int64_t& pal, int64_t& pbl) {
-        const uint64_t at = rr < w1 ? rr : w1;
-        const uint64_t left = w1 - at;
-        const int nbmax = (int)(left < (uint64_t)kRows ? left : (uint64_t)kRows);
-        const int li = lane < nbmax ? lane : nbmax;
-        pal = pa[at + li];
-        pbl = pb[at + li];
-    };
-    auto extents = [&](uint64_t rr, int64_t pal, int64_t pbl) -> Ext {
-        Ext x;
-        const uint64_t at = rr < w1 ? rr : w1;
-        const int nbmax = (int)(w1 - at < (uint64_t)kRows ? w1 - at : (uint64_t)kRows);
-        x.a0 = readlane64(pal, 0);
-        x.b0 = readlane64(pbl, 0);
-        const int nxt = lane + 1 < kWave ? lane + 1 : kWave - 1;
-        x.startA = (int)(pal - x.a0);
-        x.startB = (int)(pbl - x.b0);
-        const int endA = (int)(__shfl(pal, nxt, kWave) - x.a0);      // end of row `lane` (valid for lane < nbmax)
-        const int endB = (int)(__shfl(pbl, nxt, kWave) - x.b0);
-        // rows of the batch: the longest prefix whose entries fit the staging area on both sides
-        // (one row holds <= 128 entries of a tile, so nr >= 1 whenever rows are left)
-        const unsigned long long fit = __ballot(lane < nbmax && endA <= kCap && endB <= kCap);
-        x.nr = __popcll(fit);
-        const int last = x.nr > 0 ? x.nr - 1 : 0;
-        x.nA = x.nr > 0 ? __builtin_amdgcn_readlane(endA, last) : 0;
-        x.nB = x.nr > 0 ? __builtin_amdgcn_readlane(endB, last) : 0;
-        x.la = lane < x.nr ? endA - x.startA : 0;
-        x.lb = lane < x.nr ? endB - x.startB : 0;
-        return x;
-    };
-    auto load_entries = [&](const Ext& x, Entry (&ea)[kCap / kWave], Entry (&eb)[kCap / kWave]) {
+        // A wave owns a row block at a time and streams its run of records through a two-deep software pipeline: the
+        // suffix loads of batch b + 1 are in flight while the atomics of batch b issue, and the next slab of 64 records
+        // is fetched a slab ahead — a wave that waits for every batch's loads before it issues the next ones moves
+        // kGramUnroll records per memory round trip (~2 us under load), which bounded the first version at 7.3 ms.
+        struct Buf {
+            Entry e[kGramUnroll];
+            uint32_t pos[kGramUnroll], len[kGramUnroll];
+        };
+        auto issue = [&](Buf& bf, const Entry* __restrict__ rmb, const GramRec& rec, int u0) {
 #pragma unroll
-        for (int u = 0; u < kCap / kWave; ++u) {
-            const int c = u * kWave + lane;
-            ea[u] = tpk[x.a0 + (c < x.nA ? c : 0)];
-            eb[u] = tpk[x.b0 + (c < x.nB ? c : 0)];
-        }
-    };
-    int64_t pal = 0, pbl = 0;
-    Ext cur{};
-    Entry ea[kCap / kWave], eb[kCap / kWave];
-    uint64_t rr = w0;
-    if (w0 < w1) {
-        load_ptrs(rr, pal, pbl);
-        cur = extents(rr, pal, pbl);
-        load_entries(cur, ea, eb);
-        load_ptrs(rr + (uint64_t)cur.nr, pal, pbl);              // row pointers of batch 1
-    }
-    while (rr < w1) {
-        // extents + entry loads of the NEXT batch, row pointers of the one after
-        const uint64_t rr_n = rr + (uint64_t)cur.nr;
-        const Ext nxt_x = extents(rr_n, pal, pbl);
-        Entry ea_n[kCap / kWave], eb_n[kCap / kWave];
-        load_entries(nxt_x, ea_n, eb_n);
-        load_ptrs(rr_n + (uint64_t)nxt_x.nr, pal, pbl);
-        // stage the current batch with the address arithmetic done ONCE per entry instead of once per
-        // product: the accumulator of (ja, jb) lives at byte  ja*1024 + ((jb ^ (ja & 31)) * 8)  =  P ^ (jb*8)
-        // with P = (ja << 10) | ((ja & 31) << 3)  (the two terms of P and jb*8 < 1024 never carry).
-        // a-side records hold P, b-side records hold jb*8: one XOR per product.
+            for (int u = 0; u < kGramUnroll; ++u) {
+                bf.pos[u] = (uint32_t)__builtin_amdgcn_readlane((int)rec.pos, u0 + u);
+                bf.len[u] = (uint32_t)__builtin_amdgcn_readlane((int)rec.len, u0 + u);
+                bf.e[u] = rmb[bf.pos[u] + lane];
+            }
+        };
+        auto process = [&](const Buf& bf, const Entry* __restrict__ rmb) {
 #pragma unroll
-        for (int u = 0; u < kCap / kWave; ++u) {
-            const int c = u * kWave + lane;
-            Entry xa = ea[u], xb = eb[u];
-            xa.j = (xa.j << 10) | ((xa.j & 31) << 3);
-            xb.j = xb.j << 3;
-            if (c < cur.nA) s_a[c] = xa;
-            if (c < cur.nB) s_b[c] = xb;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // group g takes cells g, g+4, g+8, ... of the batch.  A cell's four extents travel in ONE
-        // shuffle: startA (8 bits) | startB (8) | la (8) | lb (8), each <= 128 by construction.
-        // The product loop is VALU-issue bound as much as LDS bound (~17 instructions per pass after
-        // the diet below, 32 before): no 64-bit arithmetic, no clamps, one multiply in storage precision.
-        const int packed_cell = (cur.startA & 0xff) | ((cur.startB & 0xff) << 8) | (cur.la << 16) | (cur.lb << 24);
-        // A pass runs as long as its LONGEST cell needs, so the cells of the batch are first grouped by
-        // product count with ballots and one ds_permute: a pass then holds cells of the same class and its
-        // lanes stay busy (21.6 -> ~16 slices per batch of 32 cells on the bench matrix with three classes).
-        // Order inside a class is the original one.
-        int packed, n_tiny, n_mid, n_live;
-        if constexpr (GramCfg<VT>::kFineSort) {
-            const int npl = cur.la * cur.lb;                         // 0 for lanes past the batch
-            const bool valid = lane < cur.nr;
-            // classes: 1..8 products (eight cells per pass, 8-lane groups), <= 16, <= 32, more; cells without a
-            // product (an empty segment on either side) go behind the live ones and are never visited
-            const int cls = !valid ? 5 : npl == 0 ? 4 : npl <= 8 ? 0 : npl <= 16 ? 1 : npl <= 32 ? 2 : 3;
-            const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2),
-                                     m3 = __ballot(cls == 3), mz = __ballot(cls == 4);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            const int n0 = __popcll(m0), n1 = n0 + __popcll(m1), n2 = n1 + __popcll(m2), n3 = n2 + __popcll(m3);
-            const int pos = cls == 0 ? __popcll(m0 & below)
-                          : cls == 1 ? n0 + __popcll(m1 & below)
-                          : cls == 2 ? n1 + __popcll(m2 & below)
-                          : cls == 3 ? n2 + __popcll(m3 & below)
-                          : cls == 4 ? n3 + __popcll(mz & below)
-                                     : lane;                          // lanes >= nr keep their place (they are >= nr)
-            packed = __builtin_amdgcn_ds_permute(pos << 2, (valid && npl > 0) ? packed_cell : 0);
-            n_tiny = (paths & 1) ? n0 : 0;           // bit 0: the 8-lane path for cells with <= 8 products
-            n_mid = (paths & 2) ? n2 : n3;           // bit 1: the whole-wave path for cells with > 32 products
-            n_live = n3;
-        } else {
-            // three classes (<= 16, <= 32, more), nothing dropped: with 8 waves per workgroup (f64 records) the longer
-            // ranking chain of the five-way split costs more than its passes save (18.4 -> 20 ms per launch at c3)
-            const int npl = cur.la * cur.lb;
-            const bool valid = lane < cur.nr;
-            const int cls = !valid ? 3 : npl <= 16 ? 0 : npl <= 32 ? 1 : 2;
-            const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            const int n0 = __popcll(m0), n1 = __popcll(m1);
-            const int pos = cls == 0 ? __popcll(m0 & below)
-                          : cls == 1 ? n0 + __popcll(m1 & below)
-                          : cls == 2 ? n0 + n1 + __popcll(m2 & below)
-                                     : lane;
-            packed = __builtin_amdgcn_ds_permute(pos << 2, valid ? packed_cell : 0);
-            n_tiny = 0;
-            n_live = cur.nr;
-            n_mid = (paths & 2) ? n0 + n1 : n_live;
-        }
-        const char* sa_bytes = reinterpret_cast<const char*>(s_a);
-        const char* sb_bytes = reinterpret_cast<const char*>(s_b);
-        int row0 = 0;
-        {
-            // cells with <= 8 products: 8-lane groups, eight cells per pass and two passes per trip
-            const int g8 = lane >> 3, q8 = lane & 7;
-            const float pf8 = (float)q8 + 0.5f;
-            auto fetch8 = [&](int cell, Entry& xa, Entry& xb, int& np8) {
-                const unsigned info = (unsigned)__shfl(packed, cell & 63, kWave);
-                const int lb8 = info >> 24;
-                np8 = (int)((info >> 16) & 0xff) * lb8;
-                const float rcp8 = __builtin_amdgcn_rcpf((float)(lb8 > 0 ? lb8 : 1));
-                const int ia = (int)(pf8 * rcp8);
-                const int ib = q8 - __mul24(ia, lb8);
-                xa = *reinterpret_cast<const Entry*>(sa_bytes + ((int)(info & 0xff) + ia) * (int)sizeof(Entry));
-                xb = *reinterpret_cast<const Entry*>(sb_bytes + ((int)((info >> 8) & 0xff) + ib) * (int)sizeof(Entry));
-            };
-            auto add8 = [&](const Entry& xa, const Entry& xb, int np8) {
-                if (q8 < np8) {
-                    double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa.j ^ xb.j));
-                    __hip_atomic_fetch_add(dst, gram_product(xa.v, xb.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            };
-            for (; row0 + 16 <= n_tiny; row0 += 16) {
-                Entry xa0, xb0, xa1, xb1;
-                int np0, np1;
-                fetch8(row0 + g8, xa0, xb0, np0);
-                fetch8(row0 + 8 + g8, xa1, xb1, np1);
-                add8(xa0, xb0, np0);
-                add8(xa1, xb1, np1);
-            }
-            if (row0 + 8 <= n_tiny) {
-                Entry xa0, xb0;
-                int np0;
-                fetch8(row0 + g8, xa0, xb0, np0);
-                add8(xa0, xb0, np0);
-                row0 += 8;
-            }
-        }
-        for (int rsub = 0; row0 + rsub * 4 < n_mid; ++rsub) {
-            const int row = row0 + grp + 4 * rsub;                   // group-uniform, < 64
-            const unsigned info = (unsigned)__shfl(packed, row, kWave);   // every lane active
-            const int lbR = info >> 24;
-            const int np = row < n_mid ? (int)((info >> 16) & 0xff) * lbR : 0;   // the larger cells come after this loop
-            const char* base_a = sa_bytes + (info & 0xff) * (int)sizeof(Entry);
-            const char* base_b = sb_bytes + ((info >> 8) & 0xff) * (int)sizeof(Entry);
-            // 1-ulp reciprocal: (p + 0.5) / lb stays >= 0.5 / 128 away from an integer, p < 2^14
-            const float rcp = __builtin_amdgcn_rcpf((float)(lbR > 0 ? lbR : 1));
-            float pf = (float)q + 0.5f;
-            // two product slices (p and p + 16) per pass of the loop: their four staged reads are issued
-            // together and unconditionally (a lane past np reads some record at or past the staging area —
-            // LDS reads beyond the allocation return 0 — and drops it), so a wave has two independent
-            // read -> multiply -> atomic chains behind each wait
-            if ((paths & 4) && !__any(np > 16)) {
-                // all four cells of the pass have <= 16 products (45 % of the cells at c3, sorted to the front of the
-                // batch): one slice each, and the NEXT pass rides along when it is of the same kind — eight cells
-                // per trip, two independent read -> multiply -> atomic chains as in the general loop
-                const unsigned info2 = (unsigned)__shfl(packed, (row + 4) & 63, kWave);
-                const int lb2 = info2 >> 24;
-                const int np2 = row + 4 < n_mid ? (int)((info2 >> 16) & 0xff) * lb2 : 0;
-                const bool pair2 = !__any(np2 > 16);
-                const int ia0 = (int)(pf * rcp);
-                const int ib0 = q - __mul24(ia0, lbR);
-                const Entry xa0 = *reinterpret_cast<const Entry*>(base_a + ia0 * (int)sizeof(Entry));
-                const Entry xb0 = *reinterpret_cast<const Entry*>(base_b + ib0 * (int)sizeof(Entry));
-                if (pair2) {
-                    const char* base_a2 = sa_bytes + (info2 & 0xff) * (int)sizeof(Entry);
-                    const char* base_b2 = sb_bytes + ((info2 >> 8) & 0xff) * (int)sizeof(Entry);
-                    const float rcp2 = __builtin_amdgcn_rcpf((float)(lb2 > 0 ? lb2 : 1));
-                    const int ia1 = (int)(pf * rcp2);
-                    const int ib1 = q - __mul24(ia1, lb2);
-                    const Entry xa1 = *reinterpret_cast<const Entry*>(base_a2 + ia1 * (int)sizeof(Entry));
-                    const Entry xb1 = *reinterpret_cast<const Entry*>(base_b2 + ib1 * (int)sizeof(Entry));
-                    if (q < np) {
-                        double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa0.j ^ xb0.j));
-                        __hip_atomic_fetch_add(dst, gram_product(xa0.v, xb0.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int u = 0; u < kGramUnroll; ++u) {
+                const int ja = __builtin_amdgcn_readfirstlane(bf.e[u].j);
+                const VT va = readfirst_v(bf.e[u].v);
+                const int rbase = row_base(ja);
+                if ((uint32_t)lane < bf.len[u])
+                    __hip_atomic_fetch_add(&acc[rbase + bf.e[u].j], gram_product(va, bf.e[u].v), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (bf.len[u] > (uint32_t)kWave)
+                    for (uint32_t o = kWave; o < bf.len[u]; o += kWave) {
+                        if (o + lane < bf.len[u]) {
+                            const Entry x = rmb[bf.pos[u] + o + lane];
+                            __hip_atomic_fetch_add(&acc[rbase + x.j], gram_product(va, x.v), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
                     }
-                    if (q < np2) {
-                        double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa1.j ^ xb1.j));
-                        __hip_atomic_fetch_add(dst, gram_product(xa1.v, xb1.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    ++rsub;
-                } else if (q < np) {
-                    double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa0.j ^ xb0.j));
-                    __hip_atomic_fetch_add(dst, gram_product(xa0.v, xb0.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                continue;
             }
-            for (int p = q; __any(p < np); p += 32, pf += 32.0f) {
-                const int ia0 = (int)(pf * rcp), ia1 = (int)((pf + 16.0f) * rcp);          // p / lbR
-                const int ib0 = p - __mul24(ia0, lbR), ib1 = p + 16 - __mul24(ia1, lbR);   // full-rate 24-bit multiply
-                const Entry xa0 = *reinterpret_cast<const Entry*>(base_a + ia0 * (int)sizeof(Entry));
-                const Entry xb0 = *reinterpret_cast<const Entry*>(base_b + ib0 * (int)sizeof(Entry));
-                const Entry xa1 = *reinterpret_cast<const Entry*>(base_a + ia1 * (int)sizeof(Entry));
-                const Entry xb1 = *reinterpret_cast<const Entry*>(base_b + ib1 * (int)sizeof(Entry));
-                if (p < np) {
-                    double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa0.j ^ xb0.j));
-                    __hip_atomic_fetch_add(dst, gram_product(xa0.v, xb0.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                if (p + 16 < np) {
-                    double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa1.j ^ xb1.j));
-                    __hip_atomic_fetch_add(dst, gram_product(xa1.v, xb1.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+        };
+        // Workgroup = (owner w, chunk z of n_chunk consecutive row blocks); blockIdx = z * n_wg + w, so the dispatcher starts
+        // all owners of a chunk together and they walk its rows in the same order: what one workgroup pulls into its
+        // XCD's L2 the ~60 others on that XCD hit (free-running persistent workgroups drift tens of MB apart: L2 hit rate
+        // 12 %, 50 GB of fabric reads per launch at c3).  Wave v takes blocks v, v + 16, ... of the chunk; the offsets and
+        // the record slab of its NEXT block are fetched while the current one is multiplied.
+        struct Blk {
+            uint32_t n;
+            const Entry* rmb;
+            const GramRec* rc;
+        };
+        const uint64_t rb0 = (uint64_t)z * n_chunk, rb1 = rb0 + n_chunk < n_rblk ? rb0 + n_chunk : n_rblk;
+        auto scalars = [&](uint64_t rb) -> Blk {
+            Blk k_{0u, rm, recs};
+            if (rb < rb1) {
+                const uint32_t* bo = boff + rb * (uint64_t)(n_wg + 1) + w;
+                const uint32_t o0 = bo[0], o1 = bo[1];
+                const int64_t base = rm_ptr[rb * rblk];
+                k_.n = o1 - o0;
+                k_.rmb = rm + base;
+                k_.rc = recs + base + o0;
             }
-        }
-        // cells with more than 32 products: the WHOLE wave per cell, 64 products per slice and two slices per trip.
-        // What the kernel pays for is the number of wave-level atomic instructions (~9 clk each plus 0.26 per lane,
-        // in a dependent chain), and four such cells side by side run as long as the largest of them.  The cell is
-        // wave-uniform here: its extents are scalars.
-        for (int c = n_mid; c < n_live; ++c) {
-            const unsigned info = (unsigned)__builtin_amdgcn_readlane(packed, c);
-            const int lbR = (int)(info >> 24);
-            const int np = (int)((info >> 16) & 0xff) * lbR;
-            const char* base_a = sa_bytes + (info & 0xff) * (int)sizeof(Entry);
-            const char* base_b = sb_bytes + ((info >> 8) & 0xff) * (int)sizeof(Entry);
-            const float rcp = __builtin_amdgcn_rcpf((float)lbR);
-            float pf = (float)lane + 0.5f;
-            if (np <= 64 && c + 1 < n_live) {
-                // two cells of one slice each: their reads go out together (two independent chains)
-                const unsigned info1 = (unsigned)__builtin_amdgcn_readlane(packed, c + 1);
-                const int lb1 = (int)(info1 >> 24);
-                const int np1 = (int)((info1 >> 16) & 0xff) * lb1;
-                if (np1 <= 64) {
-                    const char* base_a1 = sa_bytes + (info1 & 0xff) * (int)sizeof(Entry);
-                    const char* base_b1 = sb_bytes + ((info1 >> 8) & 0xff) * (int)sizeof(Entry);
-                    const float rcp1 = __builtin_amdgcn_rcpf((float)lb1);
-                    const int ia0 = (int)(pf * rcp), ia1 = (int)(pf * rcp1);
-                    const int ib0 = lane - __mul24(ia0, lbR), ib1 = lane - __mul24(ia1, lb1);
-                    const Entry xa0 = *reinterpret_cast<const Entry*>(base_a + ia0 * (int)sizeof(Entry));
-                    const Entry xb0 = *reinterpret_cast<const Entry*>(base_b + ib0 * (int)sizeof(Entry));
-                    const Entry xa1 = *reinterpret_cast<const Entry*>(base_a1 + ia1 * (int)sizeof(Entry));
-                    const Entry xb1 = *reinterpret_cast<const Entry*>(base_b1 + ib1 * (int)sizeof(Entry));
-                    if (lane < np) {
-                        double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa0.j ^ xb0.j));
-                        __hip_atomic_fetch_add(dst, gram_product(xa0.v, xb0.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    if (lane < np1) {
-                        double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa1.j ^ xb1.j));
-                        __hip_atomic_fetch_add(dst, gram_product(xa1.v, xb1.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                    ++c;
-                    continue;
+            return k_;
+        };
+        auto slab = [&](const Blk& k_, uint32_t i0) {
+            GramRec r{0u, 0u};
+            if (i0 + lane < k_.n) r = k_.rc[i0 + lane];
+            return r;
+        };
+        uint64_t rb = rb0 + wave;
+        Blk cur = scalars(rb), nxt = scalars(rb + kGramWaves);
+        GramRec rec = slab(cur, 0);
+        while (rb < rb1) {
+            const GramRec rec_nxt = slab(nxt, 0);                  // next block's first slab: in flight during this block
+            const Blk nxt2 = scalars(rb + 2 * kGramWaves);
+            for (uint32_t i0 = 0; i0 < cur.n; i0 += kWave) {
+                if (i0 > 0) rec = slab(cur, i0);                   // blocks with more than 64 records of this owner: rare
+                const int n = (int)(cur.n - i0 < (uint32_t)kWave ? cur.n - i0 : (uint32_t)kWave);
+                for (int u0 = 0; u0 < n; u0 += 2 * kGramUnroll) {
+                    Buf A, B;
+                    issue(A, cur.rmb, rec, u0);
+                    if (u0 + kGramUnroll < n) issue(B, cur.rmb, rec, u0 + kGramUnroll);
+                    process(A, cur.rmb);
+                    if (u0 + kGramUnroll < n) process(B, cur.rmb);
                 }
             }
-            for (int p = lane; p - lane < np; p += 128, pf += 128.0f) {
-                const int ia0 = (int)(pf * rcp), ia1 = (int)((pf + 64.0f) * rcp);
-                const int ib0 = p - __mul24(ia0, lbR), ib1 = p + 64 - __mul24(ia1, lbR);
-                const Entry xa0 = *reinterpret_cast<const Entry*>(base_a + ia0 * (int)sizeof(Entry));
-                const Entry xb0 = *reinterpret_cast<const Entry*>(base_b + ib0 * (int)sizeof(Entry));
-                const Entry xa1 = *reinterpret_cast<const Entry*>(base_a + ia1 * (int)sizeof(Entry));
-                const Entry xb1 = *reinterpret_cast<const Entry*>(base_b + ib1 * (int)sizeof(Entry));
-                if (p < np) {
-                    double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa0.j ^ xb0.j));
-                    __hip_atomic_fetch_add(dst, gram_product(xa0.v, xb0.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                if (p + 64 < np) {
-                    double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + (xa1.j ^ xb1.j));
-                    __hip_atomic_fetch_add(dst, gram_product(xa1.v, xb1.v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        rr = rr_n;
-        cur = nxt_x;
-#pragma unroll
-        for (int u = 0; u < kCap / kWave; ++u) {
-            ea[u] = ea_n[u];
-            eb[u] = eb_n[u];
+            rb += kGramWaves;
+            cur = nxt;
+            nxt = nxt2;
+            rec = rec_nxt;
         }
     }
     __syncthreads();
-    double* out = part + (rb * (uint64_t)n_pairs + pair) * (uint64_t)(KG * KG);
-    for (int e = threadIdx.x; e < KG * KG; e += kThreads) {
-        const int ja = e / KG, jb = e % KG;
-        out[e] = acc[ja * KG + (jb ^ (ja & 31))];
+    // flush: the upper-triangle part of both stripes, added to the packed matrix (row splits and, in backed
+    // mode, earlier row tiles have been there before)
+    for (int e = threadIdx.x; e < SR * WA; e += blockDim.x) {
+        const int r = e / WA, c = a0 + e % WA, row = a0 + r;
+        const double v = acc[e];
+        if (row < k && c >= row && v != 0.0) atomicAdd(&Gp[tri_index(row, c, k)], v);
+    }
+    for (int e = threadIdx.x; e < SR * WB; e += blockDim.x) {
+        const int r = e / WB, c = b0 + e % WB, row = b0 + r;
+        const double v = acc[SR * WA + e];
+        if (row < k && c >= row && v != 0.0) atomicAdd(&Gp[tri_index(row, c, k)], v);
     }
 }
 
-// Packed Gram: P[pair][128 x 128] = sum over row blocks of the partial tiles (fixed order), pairs (a <= b)
-// a-major.  Only these n_t (n_t + 1) / 2 tiles cross the xGMI links when the rows are sharded (17.8 MB instead
-// of the 32 MB of the full k x k matrix at k = 2000).
-__global__ void k_gram_reduce(const double* __restrict__ part, uint64_t n_rb, int n_pairs, double* __restrict__ P) {
-    const int pair = blockIdx.y;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= KG * KG) return;
-    double s = 0.0;
-    for (uint64_t r = 0; r < n_rb; ++r) s += part[(r * (uint64_t)n_pairs + pair) * (uint64_t)(KG * KG) + e];
-    P[(size_t)pair * (KG * KG) + e] = s;
-}
-
-// C (k x k, both triangles) from the packed tiles: entry (i, j) with i <= j in tile order comes from pair
-// (a, b) = (i / 128, j / 128) — diagonal tiles hold their upper triangle — and (j, i) mirrors it, so C is
+// C (k x k, both triangles) from the packed upper triangle: (i, j) and (j, i) read the same entry, so C is
 // EXACTLY symmetric (k_dense_apply reads it transposed).  With d != nullptr: C = D (G - cen N mu mu^T) D.
-__global__ void k_gram_expand(const double* __restrict__ P, int ntg, int k, const double* __restrict__ d,
+__global__ void k_gram_expand(const double* __restrict__ P, int k, const double* __restrict__ d,
                               const double* __restrict__ mu, int cen, double n_cells, double* __restrict__ C) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (uint64_t)k * k) return;
     const int i = (int)(e / k), j = (int)(e % k);
     const int lo = i < j ? i : j, hi = i < j ? j : i;
-    const int a = lo / KG, b = hi / KG;                     // a <= b
-    int ra = lo % KG, rb = hi % KG;
-    if (a == b && rb < ra) { const int t = ra; ra = rb; rb = t; }     // same tile: upper triangle
-    const int pair = a * ntg - a * (a - 1) / 2 + (b - a);
-    double g = P[(size_t)pair * (KG * KG) + ra * KG + rb];
+    double g = P[tri_index(lo, hi, k)];
     if (d) {
         if (cen) g -= n_cells * (mu[i] * mu[j]);            // (mu_i mu_j) first: symmetric to the last bit
         g = d[i] * d[j] * g;
@@ -1617,7 +1536,7 @@ __global__ void k_resid_scalar(const double* __restrict__ rho, const double* __r
 }
 
 
-// ---- compacted matrix: row-major CSR first, then tile-major views of it ----------------------------
+// ---- compacted matrix: row-major records + the tile-major view of the forward SpMM ------------------
 struct CompactCsr {
     uint64_t n_rows = 0, nnz = 0;
     int k = 0;
@@ -1631,7 +1550,76 @@ struct Tiled {
     int64_t* tptr = nullptr;   // nt * n_rows + 1
     void* tpk = nullptr;       // GramPk<VT> records: (local column within the tile, value)
 };
+// How G's upper triangle is cut into stripes of SR rows and paired into workgroups (k_gram_stripes)
+struct GramPlan {
+    int k = 0, sr_shift = 0, n_stripes = 0, n_wg = 0, n_z = 1;
+    bool coop = true;          // all waves of a workgroup share a row block (else: a row block per wave)
+    uint32_t rblk = 1024;      // cells per bucket block
+    uint32_t n_chunk = 0;      // chunked mode: consecutive row blocks per workgroup
+    uint64_t n_rblk = 0;
+    size_t lds_bytes = 0;
+};
+struct Buckets {
+    uint32_t* off = nullptr;   // n_rblk x (n_wg + 1)
+    GramRec* recs = nullptr;   // nnz
+};
 
+// X[:, sel] row by row: GramPk<VT> records (compacted column in [0, k), value), columns ascending within a row —
+// what the Gram kernel walks (a suffix of a row is one contiguous run)
+struct RowMajor {
+    uint64_t n_rows = 0, nnz = 0;
+    int k = 0;
+    int64_t* ptr = nullptr;    // n_rows + 1
+    void* pk = nullptr;
+    GramPlan plan;             // how the Gram kernel will cut G (fixed by k and n_rows)
+    Buckets bk;                // owner buckets of the entries, if the compaction made them (else launch_gram does)
+    bool has_buckets = false;
+};
+static int32_t gram_plan(srx_ctx* ctx, int k, uint64_t n_rows, GramPlan& g) {
+    g.k = k;
+    // the largest stripe height whose two stripes fit 64 KiB (two workgroups per CU); one row per stripe up to 160 KiB
+    static const int force_sr = getenv("SRX_GRAM_SR") ? atoi(getenv("SRX_GRAM_SR")) : 0;
+    int sr = 8;
+    while (sr > 1 && (size_t)sr * (size_t)(k + sr) * 8 > 65536) sr >>= 1;
+    if (force_sr == 1 || force_sr == 2 || force_sr == 4 || force_sr == 8) sr = force_sr;
+    g.sr_shift = sr == 8 ? 3 : sr == 4 ? 2 : sr == 2 ? 1 : 0;
+    g.n_stripes = (k + sr - 1) / sr;
+    g.n_stripes += g.n_stripes & 1;
+    g.n_wg = g.n_stripes / 2;
+    size_t widest = 0;
+    for (int w = 0; w < g.n_wg; ++w) {
+        const int a0 = w * sr, b0 = (g.n_stripes - 1 - w) * sr;
+        const size_t wd = (size_t)(k - a0) + (size_t)(k - b0 > 0 ? k - b0 : 0);
+        widest = std::max(widest, wd);
+    }
+    g.lds_bytes = (size_t)sr * widest * 8;
+    if (g.lds_bytes > 163840) return fail(ctx, SRX_E_ARG, "pca: %d selected features exceed the Gram kernel's LDS stripes", k);
+    static const int force_coop = getenv("SRX_GRAM_COOP") ? atoi(getenv("SRX_GRAM_COOP")) : 0;
+    static const int force_rblk = getenv("SRX_GRAM_RBLK") ? atoi(getenv("SRX_GRAM_RBLK")) : 0;
+    g.coop = force_coop != 0;
+    g.rblk = force_rblk > 0 ? (uint32_t)force_rblk : 1024u;
+    g.n_rblk = (n_rows + g.rblk - 1) / g.rblk;
+    static const int force_z = getenv("SRX_GRAM_Z") ? atoi(getenv("SRX_GRAM_Z")) : 0;
+    const int per_cu = g.lds_bytes <= 65536 ? 2 : 1;
+    int z;
+    if (g.coop) {
+        // row splits: enough workgroups for two per CU (when they fit)
+        z = (ctx->n_cus * per_cu + g.n_wg - 1) / g.n_wg;
+        if (force_z > 0) z = force_z;
+        if ((uint64_t)z > g.n_rblk) z = (int)g.n_rblk;
+    } else {
+        // chunks of consecutive row blocks: ~16k cells each, at least one block per wave, and enough chunks to fill the device
+        static const int force_chunk = getenv("SRX_GRAM_CHUNK") ? atoi(getenv("SRX_GRAM_CHUNK")) : 0;
+        uint64_t chunk = force_chunk > 0 ? (uint64_t)force_chunk : std::max<uint64_t>(16384 / g.rblk, kGramWaves);      // c3: 4.5 ms with 16k-cell chunks, 5.2 with 32k, 5.0 with 8k
+        const uint64_t want_wgs = (uint64_t)ctx->n_cus * per_cu;
+        while (chunk > kGramWaves && ((g.n_rblk + chunk - 1) / chunk) * (uint64_t)g.n_wg < want_wgs) chunk /= 2;
+        g.n_chunk = (uint32_t)chunk;
+        z = (int)((g.n_rblk + chunk - 1) / chunk);
+    }
+    if (z < 1) z = 1;
+    g.n_z = z;
+    return SRX_OK;
+}
 static int grid_rows(const srx_ctx* ctx, uint64_t n_rows, int rows_per_block) {
     uint64_t want = (n_rows + rows_per_block - 1) / rows_per_block;
     uint64_t cap = (uint64_t)ctx->n_cus * 8;
@@ -1655,8 +1643,23 @@ int32_t scan_exclusive(srx_ctx* ctx, const int64_t* d_in, uint64_t n, int64_t* d
     return SRX_OK;
 }
 
-// X[:, sel] -> row-major compacted CSR (count, scan, fill); columns renumbered by `remap`.
-static int32_t build_compact(srx_mat* m, const std::vector<int32_t>& remap, int k, CompactCsr& c) {
+// (idx, vals) of a compacted CSR -> packed row-major records
+template <typename T>
+__global__ void k_pack_records(const int32_t* __restrict__ idx, const T* __restrict__ vals, uint64_t n,
+                               GramPk<T>* __restrict__ out) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; e < n; e += stride) {
+        GramPk<T> r{};
+        r.j = idx[e];
+        r.v = vals[e];
+        out[e] = r;
+    }
+}
+
+// X[:, sel] -> row-major compacted CSR (count, scan, fill); columns renumbered by `remap`.  General route
+// (more than 8192 selected features); `rm` receives the packed-record view of it.
+static int32_t build_compact(srx_mat* m, const std::vector<int32_t>& remap, int k, CompactCsr& c, RowMajor& rm) {
     srx_ctx* ctx = m->ctx;
     const uint64_t N = m->n_rows;
     int32_t* d_remap;
@@ -1664,7 +1667,7 @@ static int32_t build_compact(srx_mat* m, const std::vector<int32_t>& remap, int 
     SRX_TRY(scratch(ctx, "pca_remap", (remap.size() ? remap.size() : 1) * sizeof(int32_t), (void**)&d_remap));
     SRX_TRY(h2d(ctx, d_remap, remap.data(), remap.size() * sizeof(int32_t)));
     SRX_TRY(scratch(ctx, "pca_counts", (N ? N : 1) * sizeof(int64_t), (void**)&d_counts));
-    SRX_TRY(scratch(ctx, "pca_cindptr", (N + 1) * sizeof(int64_t), (void**)&c.indptr));
+    SRX_TRY(scratch(ctx, "pca_rm_ptr", (N + 1) * sizeof(int64_t), (void**)&c.indptr));
     const double in_bytes = (double)m->nnz * 4.0 * 2.0 + (double)(N + 1) * 8.0 * 2.0;   // idx read by count + fill
     ProfScope ps(ctx, SRX_K_COMPACT, in_bytes);
     hipLaunchKernelGGL(k_compact_count, dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream, m->d_indptr,
@@ -1678,15 +1681,27 @@ static int32_t build_compact(srx_mat* m, const std::vector<int32_t>& remap, int 
     const size_t vb = val_bytes(m);
     SRX_TRY(scratch(ctx, "pca_cidx", (c.nnz ? c.nnz : 1) * sizeof(int32_t), (void**)&c.idx));
     SRX_TRY(scratch(ctx, "pca_cvals", (c.nnz ? c.nnz : 1) * vb, &c.vals));
-    if (is_f32(m))
+    const size_t pb = vb == 4 ? sizeof(GramPk<float>) : sizeof(GramPk<double>);
+    SRX_TRY(scratch(ctx, "pca_rm_pk", (c.nnz + 64) * pb, &rm.pk));
+    const unsigned pg = (unsigned)std::min<uint64_t>((c.nnz + 255) / 256 + 1, 65536);
+    if (is_f32(m)) {
         hipLaunchKernelGGL((k_compact_fill<float>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream, m->d_indptr,
                            m->d_indices, (const float*)m->d_values, d_remap, N, c.indptr, c.idx, (float*)c.vals);
-    else
+        hipLaunchKernelGGL((k_pack_records<float>), dim3(pg), dim3(256), 0, ctx->stream, c.idx, (const float*)c.vals, c.nnz,
+                           (GramPk<float>*)rm.pk);
+    } else {
         hipLaunchKernelGGL((k_compact_fill<double>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream,
                            m->d_indptr, m->d_indices, (const double*)m->d_values, d_remap, N, c.indptr, c.idx,
                            (double*)c.vals);
+        hipLaunchKernelGGL((k_pack_records<double>), dim3(pg), dim3(256), 0, ctx->stream, c.idx, (const double*)c.vals, c.nnz,
+                           (GramPk<double>*)rm.pk);
+    }
     SRX_HIP(ctx, hipGetLastError());
-    if (ctx->prof_mask & (1u << SRX_K_COMPACT)) ctx->prof[SRX_K_COMPACT].bytes += (double)c.nnz * (4.0 + vb);
+    rm.n_rows = N;
+    rm.nnz = c.nnz;
+    rm.k = k;
+    rm.ptr = c.indptr;
+    if (ctx->prof_mask & (1u << SRX_K_COMPACT)) ctx->prof[SRX_K_COMPACT].bytes += (double)c.nnz * (4.0 + vb) * 3.0;
     return SRX_OK;
 }
 
@@ -1729,8 +1744,8 @@ static int32_t retile(srx_mat* m, const CompactCsr& c, int kt, Tiled& t) {
     return SRX_OK;
 }
 
-// Fast path: both tile-major layouts straight from X (count, two scans, fill); needs <= 64 tiles
-// of 128 columns (k <= 8192) because lane t of a wave is the counter of tile t.
+// Fast path: the 256-tiled layout and the row-major records straight from X (count, two scans, fill); needs
+// <= 64 tiles of 128 columns (k <= 8192) because lane t of a wave is the counter of tile t.
 static int32_t alloc_tiled(srx_mat* m, uint64_t N, uint64_t nnz, int k, int kt, Tiled& t) {
     srx_ctx* ctx = m->ctx;
     const size_t vb = val_bytes(m);
@@ -1748,47 +1763,51 @@ static int32_t alloc_tiled(srx_mat* m, uint64_t N, uint64_t nnz, int k, int kt, 
 
 // `d_sel`: n_words selection bits followed by n_words prefix counts, on the device (the compacted column of a
 // gene is its rank among the selected genes in ascending gene order)
-static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words, int k, Tiled& t128, Tiled& t256) {
+static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words, int k, RowMajor& rm, Tiled& t256) {
     srx_ctx* ctx = m->ctx;
     const uint64_t N = m->n_rows;
     const int nt128 = (k + KG - 1) / KG, nt256 = (k + KT - 1) / KT;
-    int64_t *cnt128, *cnt256, *d_total;
+    int64_t *cntrow, *cnt256, *d_total;
     const size_t sel_lds = 2 * (size_t)n_words * sizeof(uint32_t);
     if (sel_lds > 60000) return fail(ctx, SRX_E_ARG, "pca: %llu genes exceed the LDS selection table", (unsigned long long)m->n_cols);
-    const uint64_t n128 = (uint64_t)nt128 * N, n256 = (uint64_t)nt256 * N;
-    SRX_TRY(scratch(ctx, "pca_cnt128", (n128 ? n128 : 1) * sizeof(int64_t), (void**)&cnt128));
+    const uint64_t n256 = (uint64_t)nt256 * N;
+    SRX_TRY(scratch(ctx, "pca_cntrow", (N ? N : 1) * sizeof(int64_t), (void**)&cntrow));
     SRX_TRY(scratch(ctx, "pca_cnt256", (n256 ? n256 : 1) * sizeof(int64_t), (void**)&cnt256));
-    SRX_TRY(scratch(ctx, "pca_t128_ptr", (n128 + 1) * sizeof(int64_t), (void**)&t128.tptr));
+    SRX_TRY(scratch(ctx, "pca_rm_ptr", (N + 1) * sizeof(int64_t), (void**)&rm.ptr));
     SRX_TRY(scratch(ctx, "pca_t256_ptr", (n256 + 1) * sizeof(int64_t), (void**)&t256.tptr));
     const double s_i = m->d_idx16 ? 2.0 : 4.0;          // bytes per column index streamed by the two passes
     ProfScope ps(ctx, SRX_K_COMPACT, (double)m->nnz * s_i * 2.0 + (double)m->nnz * val_bytes(m) + (double)(N + 1) * 8.0 * 2.0);
     const size_t cnt_lds = sel_lds + 4 * (size_t)kCompactRows * kWave * sizeof(uint32_t);      // + 8 x 64 counters per wave
     if (m->d_idx16)
         hipLaunchKernelGGL((k_tcount<uint16_t>), dim3(grid_rows(ctx, N, 4)), dim3(256), cnt_lds, ctx->stream, m->d_indptr,
-                           (const uint16_t*)m->d_idx16, d_sel, d_sel + n_words, n_words, N, nt128, nt256, cnt128, cnt256);
+                           (const uint16_t*)m->d_idx16, d_sel, d_sel + n_words, n_words, N, nt128, nt256, k, cntrow, cnt256);
     else
         hipLaunchKernelGGL((k_tcount<int32_t>), dim3(grid_rows(ctx, N, 4)), dim3(256), cnt_lds, ctx->stream, m->d_indptr,
-                           (const int32_t*)m->d_indices, d_sel, d_sel + n_words, n_words, N, nt128, nt256, cnt128, cnt256);
-    SRX_TRY(scan_exclusive(ctx, cnt128, n128, t128.tptr, &d_total));
+                           (const int32_t*)m->d_indices, d_sel, d_sel + n_words, n_words, N, nt128, nt256, k, cntrow, cnt256);
+    SRX_TRY(scan_exclusive(ctx, cntrow, N, rm.ptr, &d_total));
     int64_t total = 0;
     SRX_TRY(d2h(ctx, &total, d_total, sizeof(int64_t)));
     SRX_TRY(scan_exclusive(ctx, cnt256, n256, t256.tptr, nullptr));
-    SRX_TRY(alloc_tiled(m, N, (uint64_t)total, k, KG, t128));
     SRX_TRY(alloc_tiled(m, N, (uint64_t)total, k, KT, t256));
-    auto fill = [&](auto kern, const auto* idxp, const auto* valp, auto* pk128, auto* pk256) {
+    const size_t pb = is_f32(m) ? sizeof(GramPk<float>) : sizeof(GramPk<double>);
+    SRX_TRY(scratch(ctx, "pca_rm_pk", ((size_t)total + 64) * pb, &rm.pk));
+    rm.n_rows = N;
+    rm.nnz = (uint64_t)total;
+    rm.k = k;
+    auto fill = [&](auto kern, const auto* idxp, const auto* valp, auto* rmp, auto* pk256) {
         hipLaunchKernelGGL(kern, dim3(grid_rows(ctx, N, 4)), dim3(256), sel_lds, ctx->stream, m->d_indptr, idxp, valp, d_sel,
-                           d_sel + n_words, n_words, N, nt128, nt256, cnt128, t128.tptr, t256.tptr, pk128, pk256);
+                           d_sel + n_words, n_words, N, nt256, k, cnt256, rm.ptr, t256.tptr, rmp, pk256);
     };
     if (is_f32(m)) {
         if (m->d_idx16) fill(k_tfill<float, uint16_t>, (const uint16_t*)m->d_idx16, (const float*)m->d_values,
-                             (GramPk<float>*)t128.tpk, (GramPk<float>*)t256.tpk);
+                             (GramPk<float>*)rm.pk, (GramPk<float>*)t256.tpk);
         else fill(k_tfill<float, int32_t>, (const int32_t*)m->d_indices, (const float*)m->d_values,
-                  (GramPk<float>*)t128.tpk, (GramPk<float>*)t256.tpk);
+                  (GramPk<float>*)rm.pk, (GramPk<float>*)t256.tpk);
     } else {
         if (m->d_idx16) fill(k_tfill<double, uint16_t>, (const uint16_t*)m->d_idx16, (const double*)m->d_values,
-                             (GramPk<double>*)t128.tpk, (GramPk<double>*)t256.tpk);
+                             (GramPk<double>*)rm.pk, (GramPk<double>*)t256.tpk);
         else fill(k_tfill<double, int32_t>, (const int32_t*)m->d_indices, (const double*)m->d_values,
-                  (GramPk<double>*)t128.tpk, (GramPk<double>*)t256.tpk);
+                  (GramPk<double>*)rm.pk, (GramPk<double>*)t256.tpk);
     }
     SRX_HIP(ctx, hipGetLastError());
     if (ctx->prof_mask & (1u << SRX_K_COMPACT))
@@ -1797,7 +1816,7 @@ static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words,
 }
 
 // host-side selection (srx_pca with an explicit feature list): bitmask + prefix counts from the remap table
-static int32_t build_tiled_fused(srx_mat* m, const std::vector<int32_t>& remap, int k, Tiled& t128, Tiled& t256) {
+static int32_t build_tiled_fused(srx_mat* m, const std::vector<int32_t>& remap, int k, RowMajor& rm, Tiled& t256) {
     srx_ctx* ctx = m->ctx;
     const int n_words = (int)((remap.size() + 31) / 32);
     std::vector<uint32_t> hsel(2 * (size_t)n_words, 0u);
@@ -1811,7 +1830,7 @@ static int32_t build_tiled_fused(srx_mat* m, const std::vector<int32_t>& remap, 
     uint32_t* d_sel;
     SRX_TRY(scratch(ctx, "pca_selbits", (hsel.size() ? hsel.size() : 1) * sizeof(uint32_t), (void**)&d_sel));
     SRX_TRY(h2d(ctx, d_sel, hsel.data(), hsel.size() * sizeof(uint32_t)));
-    return build_tiled_fused(m, d_sel, n_words, k, t128, t256);
+    return build_tiled_fused(m, d_sel, n_words, k, rm, t256);
 }
 
 // ---- launches ---------------------------------------------------------------------------------
@@ -1866,58 +1885,46 @@ static int32_t launch_t(srx_ctx* ctx, const Tiled& c, const YT* Y, double* T /* 
     return SRX_OK;
 }
 
-// G (k x k, raw A^T A summed over ranks) from the 128-tiled matrix.
+// G += A^T A of the row-major compacted matrix, into the packed upper triangle `Gp` (k (k + 1) / 2 doubles; the
+// caller zeroes it for a fresh sum): owner buckets, then the stripe kernel.
 template <typename VT>
-static int32_t launch_gram(srx_ctx* ctx, const Tiled& g, double** packed_out, size_t* packed_count) {
-    const int ntg = g.nt;
-    const int n_pairs = ntg * (ntg + 1) / 2;
-    const uint64_t per_cu = 16;      // 4: 9.58 ms, 8: 8.90, 12: 8.76, 16: 8.69, 24: 8.68 at c3 (shorter tail of the last round)
-    uint64_t n_rb = ((uint64_t)ctx->n_cus * per_cu + n_pairs - 1) / n_pairs;      // workgroups per CU in total
-    uint64_t by_rows = (g.n_rows + 1023) / 1024;
-    if (by_rows < 1) by_rows = 1;
-    if (n_rb > by_rows) n_rb = by_rows;
-    if (n_rb < 1) n_rb = 1;
-    // XCD-aware placement (needs a multiple of 8 row blocks): at c3 the L2 misses of the kernel drop from 12.3 to
-    // 8.0 GB per launch and the kernel from 8.0 to 7.8 ms — the tile re-reads are not what bounds it.
-    // SRX_GRAM_MAP = group size in tiles (default 8), 0 = plain (pair, row block) order.
-    static const int map_mode = getenv("SRX_GRAM_MAP") ? atoi(getenv("SRX_GRAM_MAP")) : 8;
-    int* d_order = nullptr;
-    if (map_mode > 0 && n_rb >= 8) {
-        n_rb = (n_rb + 7) / 8 * 8;
-        // pairs in square groups of `gsz` tiles: all pairs (a, b) with a in group A, b in group B, a <= b
-        const int gsz = map_mode;
-        std::vector<int> order;
-        const int ngrp = (ntg + gsz - 1) / gsz;
-        auto pair_id = [&](int a, int b) { return a * ntg - a * (a - 1) / 2 + (b - a); };
-        for (int A = 0; A < ngrp; ++A)
-            for (int B = A; B < ngrp; ++B)
-                for (int a = A * gsz; a < std::min(ntg, (A + 1) * gsz); ++a)
-                    for (int b = std::max(a, B * gsz); b < std::min(ntg, (B + 1) * gsz); ++b) order.push_back(pair_id(a, b));
-        SRX_TRY(scratch(ctx, "pca_gorder", order.size() * sizeof(int), (void**)&d_order));
-        SRX_TRY(h2d(ctx, d_order, order.data(), order.size() * sizeof(int)));
+static int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp) {
+    GramPlan g = rm.plan;
+    Buckets b = rm.bk;
+    if (!rm.has_buckets) SRX_TRY(gram_plan(ctx, rm.k, rm.n_rows, g));
+    if (rm.n_rows == 0) return SRX_OK;
+    // algorithmic bytes: the compacted matrix and the owner records read once, G written once.  Every row suffix is read
+    // once per kept entry of its row (from L2 / Infinity Cache): that shows up in the PMC traffic, not here.
+    ProfScope ps(ctx, SRX_K_GRAM, (double)rm.nnz * (sizeof(GramPk<VT>) + sizeof(GramRec)) +
+                                      (double)(rm.n_rows + 1) * 8.0 + (double)rm.k * (rm.k + 1) / 2 * 8.0);
+    if (!rm.has_buckets) {           // general compaction route: a separate bucket pass over the row-major records
+        SRX_TRY(scratch(ctx, "pca_boff", g.n_rblk * (size_t)(g.n_wg + 1) * sizeof(uint32_t), (void**)&b.off));
+        SRX_TRY(scratch(ctx, "pca_brecs", (rm.nnz ? rm.nnz : 1) * sizeof(GramRec), (void**)&b.recs));
+        hipLaunchKernelGGL((k_bucket<VT>), dim3((unsigned)g.n_rblk), dim3(kBucketThreads), (size_t)(g.n_wg + 1 + g.rblk + 1) * sizeof(uint32_t), ctx->stream,
+                           rm.ptr, (const GramPk<VT>*)rm.pk, rm.n_rows, g.rblk, g.sr_shift, g.n_wg, g.n_stripes, b.off, b.recs);
     }
-    const uint64_t rpb = (g.n_rows + n_rb - 1) / n_rb > 0 ? (g.n_rows + n_rb - 1) / n_rb : 1;
-    double* part;
-    SRX_TRY(scratch(ctx, "pca_gpart", n_rb * (size_t)n_pairs * KG * KG * sizeof(double), (void**)&part));
-    constexpr int kGramWaves = GramCfg<VT>::kWavesPerWg;
-    static const int paths = getenv("SRX_GRAM_PATHS") ? atoi(getenv("SRX_GRAM_PATHS")) : GramCfg<VT>::kPaths;
-    const size_t lds = (size_t)KG * KG * sizeof(double) + (size_t)kGramWaves * (2 * GramCfg<VT>::kCap * sizeof(GramPk<VT>));
-    // algorithmic bytes: the compacted matrix (8-byte entries + per-tile row pointers) read ONCE and G written
-    // once.  The kernel re-reads every 128-tile once per tile pair it belongs to (n_t + 1 times, from L2 /
-    // Infinity Cache for the most part): that shows up in the PMC traffic, not here.
-    ProfScope ps(ctx, SRX_K_GRAM, (double)g.nnz * sizeof(GramPk<VT>) + (double)ntg * g.n_rows * 8.0 +
-                                      (double)g.k * g.k * 8.0);
-    SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_sparse<VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_gram_sparse<VT>), dim3((unsigned)(n_rb * n_pairs)), dim3(kGramWaves * kWave), lds, ctx->stream, g.tptr,
-                       (const GramPk<VT>*)g.tpk, g.n_rows, ntg, rpb, n_pairs, part, (const int*)d_order, paths);
-    double* P;
-    SRX_TRY(scratch(ctx, "pca_gpacked", (size_t)n_pairs * KG * KG * sizeof(double), (void**)&P));
-    hipLaunchKernelGGL(k_gram_reduce, dim3((KG * KG + 255) / 256, n_pairs), dim3(256), 0, ctx->stream, part, n_rb, n_pairs, P);
-    SRX_HIP(ctx, hipGetLastError());
-    *packed_out = P;
-    *packed_count = (size_t)n_pairs * KG * KG;
+    // pacing of the workgroups (cooperative mode): only when every workgroup is resident at once
+    static const int lag = getenv("SRX_GRAM_LAG") ? atoi(getenv("SRX_GRAM_LAG")) : 1;
+    int* d_pace = nullptr;
+    const int per_cu = g.lds_bytes <= 65536 ? 2 : 1;
+    if (g.coop && lag > 0 && g.n_wg * g.n_z <= ctx->n_cus * per_cu) {
+        const size_t n_win = (size_t)((g.n_rblk + g.n_z - 1) / g.n_z);
+        SRX_TRY(scratch(ctx, "pca_gpace", (n_win + 1) * sizeof(int), (void**)&d_pace));
+        SRX_HIP(ctx, hipMemsetAsync(d_pace, 0, (n_win + 1) * sizeof(int), ctx->stream));
+    }
+    auto go = [&](auto kern) -> int32_t {
+        SRX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
+        hipLaunchKernelGGL(kern, dim3((unsigned)(g.n_wg * g.n_z)), dim3(kGramWaves * kWave), g.lds_bytes, ctx->stream,
+                           rm.ptr, (const GramPk<VT>*)rm.pk, b.off, b.recs, g.n_rblk, g.rblk, rm.k, g.sr_shift, g.n_wg, g.n_stripes,
+                           g.n_z, d_pace, lag, g.n_chunk, Gp);
+        SRX_HIP(ctx, hipGetLastError());
+        return SRX_OK;
+    };
+    if (g.coop) SRX_TRY(go(k_gram_stripes<VT, true>));
+    else SRX_TRY(go(k_gram_stripes<VT, false>));
     return SRX_OK;
 }
+static size_t gram_packed_count(int k) { return (size_t)k * (size_t)(k + 1) / 2; }
 
 // ---- the driver ---------------------------------------------------------------------------------
 struct Resolved {
@@ -2351,11 +2358,11 @@ static int32_t ensure_result_capacity(srx_ctx* ctx, srx_pca_state& st, size_t ne
 }
 
 template <typename VT, typename PT>
-static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tiled* t128p, double* gram_packed,
+static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const RowMajor* rmp, double* gram_packed,
                        const Resolved& o, const std::vector<double>& mu, const std::vector<double>& dinv,
                        const HvgDev* hv, int l_act, double n_cells, srx_pca_state& st) {
     // `parts`: the 256-tiled views of this rank's rows — one for a resident matrix, one per row tile in backed
-    // mode (then `gram_packed` holds the Gram tiles already summed over the row tiles and `t128p` is null)
+    // mode (then `gram_packed` holds the packed Gram matrix already summed over the row tiles and `rmp` is null)
     const Tiled& t256 = parts[0];
     const int k = t256.k;
     struct { uint64_t n_rows, max_rows; } cc{0, 0};
@@ -2503,14 +2510,17 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const Tile
         // explicit Gram: G = A^T A once (all-reduced), C = D (G - c N mu mu^T) D dense
         double* C;
         SRX_TRY(scratch(ctx, "pca_C", (size_t)k * k * 8, (void**)&C));
-        const int nt128 = (k + KG - 1) / KG;
         double* Pk = gram_packed;
-        size_t n_packed = (size_t)(nt128 * (nt128 + 1) / 2) * KG * KG;
-        if (!Pk) SRX_TRY(launch_gram<VT>(ctx, *t128p, &Pk, &n_packed));
-        SRX_TRY(allreduce_f64(ctx, Pk, n_packed));                // the one exchange of this solver: upper tiles only
+        const size_t n_packed = gram_packed_count(k);
+        if (!Pk) {
+            SRX_TRY(scratch(ctx, "pca_gpacked", n_packed * sizeof(double), (void**)&Pk));
+            SRX_HIP(ctx, hipMemsetAsync(Pk, 0, n_packed * sizeof(double), ctx->stream));
+            SRX_TRY(launch_gram<VT>(ctx, *rmp, Pk));
+        }
+        SRX_TRY(allreduce_f64(ctx, Pk, n_packed));                // the one exchange of this solver: the packed upper triangle
         auto reset = [&]() -> int32_t {
             hipLaunchKernelGGL(k_gram_expand, dim3((unsigned)(((size_t)k * k + 255) / 256)), dim3(256), 0, ctx->stream, Pk,
-                               nt128, k, (const double*)w.d, (const double*)w.mu, o.center, n_cells, C);
+                               k, (const double*)w.d, (const double*)w.mu, o.center, n_cells, C);
             SRX_HIP(ctx, hipGetLastError());
             return SRX_OK;
         };
@@ -2747,19 +2757,16 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
 
     // tile-major views of X[:, sel]: fused count/fill when the tile counters fit a wave, else the
     // general route through a row-major compacted CSR
-    Tiled t256, t128;
-    const bool need128 = o.solver == 1;
+    Tiled t256;
+    RowMajor rm;
     if (dev_sel) {
-        SRX_TRY(build_tiled_fused(m, hv.d_bits, hv.n_words, k, t128, t256));
+        SRX_TRY(build_tiled_fused(m, hv.d_bits, hv.n_words, k, rm, t256));
     } else if ((k + KG - 1) / KG <= kWave) {
-        SRX_TRY(build_tiled_fused(m, remap, k, t128, t256));
+        SRX_TRY(build_tiled_fused(m, remap, k, rm, t256));
     } else {
         CompactCsr cc;
-        SRX_TRY(build_compact(m, remap, k, cc));
+        SRX_TRY(build_compact(m, remap, k, cc, rm));
         SRX_TRY(retile(m, cc, KT, t256));
-        if (need128) {
-            SRX_TRY(retile(m, cc, KG, t128));
-        }
     }
     st.info = srx_pca_info{};
     st.info.n_cells_global = Ng;
@@ -2774,9 +2781,9 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     // panels in f64 (f32 products of Z W level the residuals of the small components off at ~1e-7 theta_1 / theta_i:
     // 6.6e-5 at k = 9000 on a flat-tailed matrix, however many sweeps)
     if (is_f32(m) && o.solver == 2)
-        rc = run_pca<float, double>(ctx, &t256, 1, need128 ? &t128 : nullptr, nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
-    else if (is_f32(m)) rc = run_pca<float, float>(ctx, &t256, 1, need128 ? &t128 : nullptr, nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
-    else rc = run_pca<double, double>(ctx, &t256, 1, need128 ? &t128 : nullptr, nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
+        rc = run_pca<float, double>(ctx, &t256, 1, &rm, nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
+    else if (is_f32(m)) rc = run_pca<float, float>(ctx, &t256, 1, &rm, nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
+    else rc = run_pca<double, double>(ctx, &t256, 1, &rm, nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
     if ((rc != SRX_OK && rc != SRX_E_NOCONV) || !st.d_small) return rc;      // d_small unset: the solve broke down early
     SRX_TRY(stash_results(ctx, st, k, o.n_pc, dev_sel ? &hv : nullptr, mu, sd, trace, selv));
     return rc;
@@ -2919,14 +2926,14 @@ int32_t srx_spmm(srx_mat* m, const uint64_t* sel, uint64_t k64, const double* pa
         if (s > 0 && sel[s] <= sel[s - 1]) return fail(ctx, SRX_E_ARG, "srx_spmm: sel must be strictly ascending");
         remap[sel[s]] = s;
     }
-    Tiled c256, c128;
+    Tiled c256;
+    RowMajor crm;
     if ((k + KG - 1) / KG <= kWave) {
-        SRX_TRY(build_tiled_fused(m, remap, k, c128, c256));
+        SRX_TRY(build_tiled_fused(m, remap, k, crm, c256));
     } else {
         CompactCsr cc;
-        SRX_TRY(build_compact(m, remap, k, cc));
+        SRX_TRY(build_compact(m, remap, k, cc, crm));
         SRX_TRY(retile(m, cc, KT, c256));
-        SRX_TRY(retile(m, cc, KG, c128));
     }
     const size_t kl = (size_t)k * L;
     double* T;
@@ -2954,14 +2961,13 @@ int32_t srx_spmm(srx_mat* m, const uint64_t* sel, uint64_t k64, const double* pa
             }
         }
         if (gram_out) {
-            const Tiled& g = c128;
-            double* C;
+            double *C, *Pk;
             SRX_TRY(scratch(ctx, "pca_C", (size_t)k * k * 8, (void**)&C));
-            double* Pk;
-            size_t n_packed;
-            SRX_TRY(launch_gram<VT>(ctx, g, &Pk, &n_packed));
+            SRX_TRY(scratch(ctx, "pca_gpacked", gram_packed_count(k) * sizeof(double), (void**)&Pk));
+            SRX_HIP(ctx, hipMemsetAsync(Pk, 0, gram_packed_count(k) * sizeof(double), ctx->stream));
+            SRX_TRY(launch_gram<VT>(ctx, crm, Pk));
             hipLaunchKernelGGL(k_gram_expand, dim3((unsigned)(((size_t)k * k + 255) / 256)), dim3(256), 0, ctx->stream, Pk,
-                               g.nt, k, (const double*)nullptr, (const double*)nullptr, 0, 0.0, C);
+                               k, (const double*)nullptr, (const double*)nullptr, 0, 0.0, C);
             SRX_HIP(ctx, hipGetLastError());
             SRX_TRY(d2h(ctx, gram_out, C, (size_t)k * k * 8));
         }
