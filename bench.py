@@ -235,7 +235,7 @@ def main():
     for _ in range(a.warmup):
         step(copies[used]); used += 1
     # timed: chunks of fresh copies; restoring copies from the pristine matrix is outside the clock
-    prof_mask = sum(1 << c for c in (F.K_NORMALIZE, F.K_MOMENTS, F.K_COMPACT, F.K_SPMM_FWD, F.K_SPMM_T, F.K_GRAM, F.K_DENSE))
+    prof_mask = sum(1 << c for c in (F.K_NORMALIZE, F.K_MOMENTS, F.K_COMPACT, F.K_SPMM_FWD, F.K_SPMM_T, F.K_GRAM, F.K_DENSE, F.K_ROWSUM))
     ctx.prof_enable(prof_mask)
     ctx.prof_reset()
     elapsed = 0.0
@@ -267,7 +267,8 @@ def main():
 
     prof = {}
     names = {F.K_NORMALIZE: "normalize_log1p", F.K_MOMENTS: "gene_moments", F.K_COMPACT: "hvg_compact",
-             F.K_SPMM_FWD: "spmm_fwd", F.K_SPMM_T: "spmm_t", F.K_GRAM: "gram_sparse", F.K_DENSE: "dense_apply"}
+             F.K_SPMM_FWD: "spmm_fwd", F.K_SPMM_T: "spmm_t", F.K_GRAM: "gram_sparse", F.K_DENSE: "dense_apply",
+             F.K_ROWSUM: "row_sums"}
     for cls_, name in names.items():
         ms, n, b = ctx.prof_get(cls_)
         if n:

@@ -367,7 +367,8 @@ typedef enum srx_kernel_class {
     SRX_K_SPMM_T = 4,      /* T = X_sel^T Y                                               */
     SRX_K_GRAM = 5,        /* G = X_sel^T X_sel (sparse outer products into LDS tiles)     */
     SRX_K_DENSE = 6,       /* dense k x k times k x 64 products of the Gram solver        */
-    SRX_K_COUNT_ = 7
+    SRX_K_ROWSUM = 7,      /* per-cell sums of the raw values (first pass of srx_pipeline)  */
+    SRX_K_COUNT_ = 8
 } srx_kernel_class;
 int32_t srx_prof_enable(srx_ctx* ctx, uint32_t class_mask);
 int32_t srx_prof_reset(srx_ctx* ctx);

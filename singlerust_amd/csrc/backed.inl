@@ -77,9 +77,18 @@ static int32_t backed_upload(srx_backed* b, const srx_csr* tile, srx_mat** out) 
     return SRX_OK;
 }
 
-static int32_t backed_transform(srx_mat* m, double target_sum, int32_t transform) {
+// normalize_total(Row) + log1p together are applied ON THE FLY by the passes that read the tile (RowXf: f64-accurate
+// values from the raw ones, nothing written back — the tile is dropped afterwards); either one alone is done in place.
+static int32_t backed_transform(srx_mat* m, double target_sum, int32_t transform, RowXf& xf) {
     const bool do_norm = (transform & SRX_BACKED_NORMALIZE) != 0, do_log = (transform & SRX_BACKED_LOG1P) != 0;
+    xf = RowXf{};
     if (!do_norm && !do_log) return SRX_OK;
+    if (do_norm && do_log) {
+        SRX_TRY(launch_row_sums(m));
+        xf.row_sum = m->d_row_sum;
+        xf.target = target_sum;
+        return SRX_OK;
+    }
     return launch_normalize(m, target_sum, do_norm, do_log);
 }
 
@@ -92,12 +101,12 @@ static void free_parts(srx_backed* b) {
 }
 
 template <typename VT>
-static int32_t backed_gram_tile(srx_backed* b, srx_mat* m) {
+static int32_t backed_gram_tile(srx_backed* b, srx_mat* m, RowXf xf) {
     srx_ctx* ctx = b->ctx;
     Tiled t256;
     RowMajor rm;
-    if (b->dev_sel) SRX_TRY(build_tiled_fused(m, b->hv.d_bits, b->hv.n_words, b->k, rm, t256));
-    else SRX_TRY(build_tiled_fused(m, b->remap, b->k, rm, t256));
+    if (b->dev_sel) SRX_TRY(build_tiled_fused(m, b->hv.d_bits, b->hv.n_words, b->k, rm, t256, xf));
+    else SRX_TRY(build_tiled_fused(m, b->remap, b->k, rm, t256, xf));
     SRX_TRY(launch_gram<VT>(ctx, rm, b->d_gram));            // accumulates into the session's packed matrix
     // keep the 256-tiled view of this tile: exact-size copies out of the scratch buffers
     Tiled keep = t256;
@@ -179,8 +188,9 @@ int32_t srx_backed_stats_tile(srx_backed* b, const srx_csr* tile, double target_
     // Direction::Row statistics of the RAW values belong to the tile alone: written at the caller's offset
     if (row_number_out) SRX_TRY(row_number(m, row_number_out));
     if (row_sum_out) SRX_TRY(row_stat(m, 0, row_sum_out, nullptr));
-    SRX_TRY(backed_transform(m, target_sum, transform));
-    SRX_TRY(moments_accumulate(m, b->d_packed));
+    RowXf xf;
+    SRX_TRY(backed_transform(m, target_sum, transform, xf));
+    SRX_TRY(moments_accumulate(m, b->d_packed, xf));
     b->rows1 += m->n_rows;
     b->nnz1 += m->nnz;
     return SRX_OK;
@@ -290,9 +300,10 @@ int32_t srx_backed_gram_tile(srx_backed* b, const srx_csr* tile, double target_s
     b->prev = m;
     if (m->store != b->store) return fail(ctx, SRX_E_DTYPE, "backed: tile storage differs from the first tile's");
     if (m->n_rows == 0) return SRX_OK;
-    SRX_TRY(backed_transform(m, target_sum, transform));
-    if (is_f32(m)) SRX_TRY(backed_gram_tile<float>(b, m));
-    else SRX_TRY(backed_gram_tile<double>(b, m));
+    RowXf xf;
+    SRX_TRY(backed_transform(m, target_sum, transform, xf));
+    if (is_f32(m)) SRX_TRY(backed_gram_tile<float>(b, m, xf));
+    else SRX_TRY(backed_gram_tile<double>(b, m, xf));
     b->rows2 += m->n_rows;
     return SRX_OK;
 }

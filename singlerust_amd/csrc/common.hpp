@@ -65,6 +65,11 @@ struct srx_ctx {
     int device = 0;
     int n_cus = 256;
     hipStream_t stream = nullptr;
+    // side stream of the pipeline: the in-place write-back of the normalised values runs beside the Gram kernel
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
+    bool side_busy = false;
+    struct srx_mat* wb_after_gram = nullptr;      // pipeline: matrix whose write-back run_pca queues behind the Gram kernel
     std::string err;
     // RCCL (one process per GPU)
     ncclComm* comm = nullptr;
@@ -130,6 +135,8 @@ struct srx_mat {
     uint64_t n_rows = 0, n_cols = 0, nnz = 0;
     int32_t dtype = SRX_F32;   // logical dtype (DynCsrMatrix variant)
     int32_t store = SRX_STORE_F32;
+    bool store_auto = false;   // SRX_STORE_AUTO at creation: normalize_total / log1p promote f32 storage to f64 where the
+                               // reference's DynCsrMatrix variant becomes F64 (scale/mod.rs:74-83, transform/mod.rs:48-55)
     int64_t* d_indptr = nullptr;
     int32_t* d_indices = nullptr;
     void* d_values = nullptr;
@@ -142,6 +149,10 @@ struct srx_mat {
     // the three passes that stream the column indices of the WHOLE matrix (gene moments, HVG count / fill)
     // read 2 bytes per non-zero instead of 4
     uint16_t* d_idx16 = nullptr;
+    // per-gene non-zero counts of THIS shard: pattern-only (built by the first moments pass or srx_matrix_prepare,
+    // inherited by clones); with them the moments passes drop the count atomic
+    uint32_t* d_cnt_pat = nullptr;
+    bool cnt_pat_valid = false;
     // per-gene moment cache, keyed by the value version
     uint64_t version = 1;
     uint64_t moments_version = 0;
@@ -150,6 +161,9 @@ struct srx_mat {
     double* d_sq = nullptr;
     uint64_t n_rows_global = 0;     // valid with moments
     double* d_row_sum = nullptr;    // n_rows f64, filled by the normalise pass
+    // pipeline: the matrix is still RAW and the in-place normalise(lazy_target) + log1p is owed (launch_writeback, pca.hip)
+    bool lazy_pending = false;
+    double lazy_target = 0.0;
     // CSC storage (DynCscMatrix): the arrays above are the CSR of X^T (n_rows = n_vars, n_cols = n_obs) and the
     // entry points exchange Row and Column (csc.hip)
     bool csc = false;
@@ -197,8 +211,9 @@ int32_t h2d(srx_ctx* ctx, void* dev, const void* host, size_t bytes);
 struct ProfScope {
     srx_ctx* ctx;
     int cls;
+    hipStream_t stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    ProfScope(srx_ctx* c, int cls_, double alg_bytes);
+    ProfScope(srx_ctx* c, int cls_, double alg_bytes, hipStream_t stream_ = nullptr);
     ~ProfScope();
 };
 
@@ -207,8 +222,16 @@ struct ProfScope {
 int32_t allreduce_f64(srx_ctx* ctx, double* d_buf, size_t count);
 
 // ---- internal entry points shared between translation units -----------------------------------
+// The fused normalise + log1p transform applied ON THE FLY by a pass that reads raw values: y = ln_1p(f64(v) * scale_r),
+// scale_r = (s_r == 0) ? 0 : target / s_r from the row sums (scale/mod.rs:9-15).  `row_sum` null = identity.
+struct RowXf {
+    const double* row_sum = nullptr;
+    double target = 0.0;
+};
 int32_t upload_on(srx_ctx* ctx, const srx_csr* h, int32_t store, hipStream_t stream, srx_mat** out);   // ctx.hip
 int32_t ensure_tiles(srx_mat* m);
+int32_t promote_to_f64(srx_mat* m);                   // ctx.hip: f32 storage -> f64 storage, values unchanged
+int32_t ensure_pattern_counts(srx_mat* m);            // genes.hip
 // device-resident result of FeatureSelection::HighlyVariable(n) (genes.hip), consumed by the PCA driver
 struct HvgDev {
     int k = 0, n_words = 0;
@@ -219,9 +242,12 @@ struct HvgDev {
 };
 int32_t select_hvg_device(srx_mat* m, uint64_t n, int center, int scale, HvgDev& out);
 int32_t ensure_moments(srx_mat* m);   // fills d_cnt/d_sum/d_sq (global) for the current values
-int32_t moments_accumulate(srx_mat* m, double* d_acc);     // backed mode: this tile's (cnt,sum,sumsq,N) += into d_acc
+int32_t moments_accumulate(srx_mat* m, double* d_acc, RowXf xf);     // backed mode: this tile's (cnt,sum,sumsq,N) += into d_acc
 int32_t moments_install(srx_mat* m, double* d_packed);     // all-reduce d_packed and make it m's global moments
-int32_t launch_normalize(srx_mat* m, double target, bool do_norm, bool do_log);
+int32_t launch_normalize(srx_mat* m, double target, bool do_norm, bool do_log, hipStream_t stream = nullptr,
+                         bool precise = false, int wgs_per_cu = 0);
+int32_t launch_row_sums(srx_mat* m);
+int32_t ensure_moments_xf(srx_mat* m, RowXf xf);      // moments of the TRANSFORMED values from the raw matrix
 inline void touch(srx_mat* m) { m->version++; m->pca.valid = false; }
 
 inline bool is_f32(const srx_mat* m) { return m->store == SRX_STORE_F32; }

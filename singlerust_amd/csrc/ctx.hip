@@ -90,23 +90,24 @@ static hipEvent_t take_event(srx_ctx* ctx) {
     return e;
 }
 
-ProfScope::ProfScope(srx_ctx* c, int cls_, double alg_bytes) : ctx(c), cls(cls_) {
+ProfScope::ProfScope(srx_ctx* c, int cls_, double alg_bytes, hipStream_t stream_) : ctx(c), cls(cls_), stream(stream_ ? stream_ : c->stream) {
     if (!(ctx->prof_mask & (1u << cls)) || ctx->capturing) return;      // no event nodes inside a captured graph
     e0 = take_event(ctx);
     e1 = take_event(ctx);
     if (!e0 || !e1) { e0 = e1 = nullptr; return; }
     ctx->prof[cls].bytes += alg_bytes;
     ctx->prof[cls].launches += 1;
-    (void)hipEventRecord(e0, ctx->stream);
+    (void)hipEventRecord(e0, stream);
 }
 ProfScope::~ProfScope() {
     if (!e0) return;
-    (void)hipEventRecord(e1, ctx->stream);
+    (void)hipEventRecord(e1, stream);
     ctx->prof[cls].pending.emplace_back(e0, e1);
 }
 
 static int32_t prof_drain(srx_ctx* ctx) {
     SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->side_stream) SRX_HIP(ctx, hipStreamSynchronize(ctx->side_stream));
     for (int c = 0; c < SRX_K_COUNT_; ++c) {
         for (auto& pr : ctx->prof[c].pending) {
             float ms = 0.f;
@@ -194,6 +195,7 @@ static void free_mat_buffers(srx_mat* m) {
     (void)hipFree(m->d_tile_ptr);
     (void)hipFree(m->d_idx16);
     (void)hipFree(m->d_cnt);
+    (void)hipFree(m->d_cnt_pat);
     (void)hipFree(m->d_sum);
     (void)hipFree(m->d_sq);
     (void)hipFree(m->d_row_sum);
@@ -475,6 +477,9 @@ void srx_ctx_destroy(srx_ctx* ctx) {
     }
     for (auto e : ctx->async_ev)
         if (e) (void)hipEventDestroy(e);
+    if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
+    if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -524,6 +529,7 @@ int32_t srx_matrix_alloc(srx_ctx* ctx, uint64_t n_rows, uint64_t n_cols, uint64_
     m->n_rows = n_rows; m->n_cols = n_cols; m->nnz = nnz;
     m->dtype = dtype;
     m->store = resolve_store(dtype, store);
+    m->store_auto = store == SRX_STORE_AUTO;
     m->n_rows_global = n_rows;
     hipError_t e;
     e = hipMalloc((void**)&m->d_indptr, (n_rows + 1) * sizeof(int64_t));
@@ -562,6 +568,7 @@ int32_t srx_matrix_device_ptrs(srx_mat* m, void** indptr, void** indices, void**
     if (m->d_tile_ptr) { (void)hipFree(m->d_tile_ptr); m->d_tile_ptr = nullptr; }
     if (m->d_idx16) { (void)hipFree(m->d_idx16); m->d_idx16 = nullptr; }
     m->n_tiles = 0;
+    m->cnt_pat_valid = false;
     return SRX_OK;
 }
 
@@ -603,6 +610,33 @@ int32_t srx_matrix_download_values(srx_mat* m, void* out, int32_t dtype_out) {
     return d2h(ctx, out, d_tmp, m->nnz * ob);
 }
 
+}  // extern "C"
+
+namespace srx {
+// Storage follows the reference's variant change: a matrix created with SRX_STORE_AUTO and held in f32 moves to f64 when
+// an operation makes X a DynCsrMatrix::F64 (normalize_total on anything, log1p on a non-F32 matrix).  The values are
+// widened exactly; everything derived from them stays valid.
+int32_t promote_to_f64(srx_mat* m) {
+    if (!m->store_auto || !is_f32(m)) return SRX_OK;
+    srx_ctx* ctx = m->ctx;
+    void* d_new = nullptr;
+    SRX_HIP(ctx, hipMalloc(&d_new, (m->nnz + 16) * sizeof(double)));
+    const unsigned g = (unsigned)std::min<uint64_t>((m->nnz + 16 + 255) / 256, 65535);
+    hipLaunchKernelGGL((k_convert_values<float, double>), dim3(g ? g : 1), dim3(256), 0, ctx->stream, (const float*)m->d_values,
+                       (double*)d_new, m->nnz + 16);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        (void)hipFree(d_new);
+        return fail(ctx, SRX_E_HIP, "promote_to_f64: conversion failed");
+    }
+    (void)hipFree(m->d_values);
+    m->d_values = d_new;
+    m->store = SRX_STORE_F64;
+    return SRX_OK;
+}
+}  // namespace srx
+
+extern "C" {
+
 int32_t srx_matrix_clone(srx_mat* m, srx_mat** out) {
     if (!m || !out) return fail(m ? m->ctx : nullptr, SRX_E_ARG, "null argument");
     srx_ctx* ctx = m->ctx;
@@ -610,6 +644,7 @@ int32_t srx_matrix_clone(srx_mat* m, srx_mat** out) {
     SRX_TRY(srx_matrix_alloc(ctx, m->n_rows, m->n_cols, m->nnz, m->dtype, m->store, &c));
     c->row_offset = m->row_offset;
     c->csc = m->csc;
+    c->store_auto = m->store_auto;
     hipError_t e = hipMemcpyAsync(c->d_indptr, m->d_indptr, (m->n_rows + 1) * sizeof(int64_t),
                                   hipMemcpyDeviceToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c->d_indices, m->d_indices, m->nnz * sizeof(int32_t),
@@ -631,6 +666,12 @@ int32_t srx_matrix_clone(srx_mat* m, srx_mat** out) {
             if (e == hipSuccess) e = hipMemcpyAsync(c->d_idx16, m->d_idx16, ib, hipMemcpyDeviceToDevice, ctx->stream);
         }
     }
+    if (e == hipSuccess && m->cnt_pat_valid && m->d_cnt_pat) {          // pattern-only per-gene counts
+        const size_t cb = (m->n_cols ? m->n_cols : 1) * sizeof(uint32_t);
+        e = hipMalloc((void**)&c->d_cnt_pat, cb);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->d_cnt_pat, m->d_cnt_pat, cb, hipMemcpyDeviceToDevice, ctx->stream);
+        c->cnt_pat_valid = e == hipSuccess;
+    }
     // a reserved result block (srx_matrix_reserve_results) is part of the handle's layout: the clone gets its own
     if (e == hipSuccess && m->pca.scores_cap > 0) {
         e = hipMalloc((void**)&c->pca.d_scores, m->pca.scores_cap);
@@ -647,7 +688,8 @@ int32_t srx_matrix_clone(srx_mat* m, srx_mat** out) {
 int32_t srx_matrix_prepare(srx_mat* m) {
     if (!m) return fail(nullptr, SRX_E_ARG, "null matrix");
     SRX_HIP(m->ctx, hipSetDevice(m->ctx->device));
-    return ensure_tiles(m);
+    SRX_TRY(ensure_tiles(m));
+    return m->csc ? SRX_OK : ensure_pattern_counts(m);
 }
 
 int32_t srx_matrix_copy_values(srx_mat* dst, const srx_mat* src) {

@@ -14,6 +14,7 @@
 //
 // Algorithmic bytes: nnz*(4 + s_v) + (N+1)*8 + G*24.
 #include "common.hpp"
+#include "log1p64.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -50,16 +51,24 @@ __device__ __forceinline__ void seg_bounds(const int64_t* __restrict__ indptr, c
 
 // The three column passes of the reference — histogram (csr.rs:29-36), scatter-add of x
 // (csr.rs:94-100) and of x^2 (csr.rs:175-178) — in ONE walk.
-template <typename T, typename I>
+// XF: the values are the RAW matrix and x = ln_1p(f64(v) * scale_row) is formed on the fly in f64 (RowXf, common.hpp):
+// the moments of the normalised + log1p'd matrix to f64 accuracy whatever the storage type, before (and without) the
+// in-place write-back.  COUNT = false: the per-gene counts are pattern-only and already cached on the matrix — one
+// LDS atomic per non-zero less.
+template <typename T, typename I, bool XF, bool COUNT>
 __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     const int64_t* __restrict__ indptr, const int64_t* __restrict__ tp, const I* __restrict__ idx,
     const T* __restrict__ vals, uint64_t n_rows, uint64_t n_cols, int n_tiles, int tile_genes,
-    uint64_t rows_per_block, uint32_t* __restrict__ part_cnt, double* __restrict__ part_sum,
-    double* __restrict__ part_sq) {
+    uint64_t rows_per_block, const double* __restrict__ row_sum, double target, double fx_sum, double fx_sq,
+    uint32_t* __restrict__ poison, uint32_t* __restrict__ part_cnt, double* __restrict__ part_sum, double* __restrict__ part_sq) {
     extern __shared__ double lds[];
     double* s_sum = lds;
     double* s_sq = lds + tile_genes;
     uint32_t* s_cnt = reinterpret_cast<uint32_t*>(lds + 2 * tile_genes);
+    // behind the accumulators (tile_genes * 20 B, rounded up to 16): the log1p table
+    // (the table from global memory instead — 2 KB, L1-resident, one vector load per value — was tried: 5.7 ms against 3.5)
+    const Log1pTabEntry* s_tab = reinterpret_cast<const Log1pTabEntry*>(reinterpret_cast<char*>(lds) + (((size_t)tile_genes * 20 + 15) & ~(size_t)15));
+    if constexpr (XF) stage_log1p_table(const_cast<Log1pTabEntry*>(s_tab));
     for (int g = threadIdx.x; g < tile_genes; g += kMomThreads) { s_sum[g] = 0.0; s_sq[g] = 0.0; s_cnt[g] = 0u; }
     __syncthreads();
 
@@ -102,14 +111,33 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
             c.v[0] = a2.x; c.v[1] = a2.y; c.v[2] = b2.x; c.v[3] = b2.y;
         }
     };
-    auto add_chunk = [&](int64_t e0, int64_t lo, int64_t hi, const Chunk& c) {
+    // XF: the sums are kept in FIXED POINT (2^-sum_shift, 2^-sq_shift; 64-bit integer LDS atomics): integer addition is
+    // associative, so the moments do not depend on the order the atomics land in — two genes with identical columns get
+    // identical sums, as in the reference's sequential loops (HighlyVariable(n) breaks exact ties by gene index), and the
+    // run is reproducible to the bit.  [Raw f32 values widened to f64 sum exactly anyway: the plain path keeps f64 adds.]
+    auto add_chunk = [&](int64_t e0, int64_t lo, int64_t hi, const Chunk& c, double scale) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t pos = e0 + j;
             if (pos >= lo && pos < hi) {
                 const int32_t g0 = c.gg[j] - gbase;
-                const double x0 = (double)c.v[j];
-                __hip_atomic_fetch_add(&s_cnt[g0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                double x0 = (double)c.v[j];
+                if constexpr (XF) {
+                    x0 = sizeof(T) == 4 ? log1p_f64_lite(x0 * scale, s_tab) : log1p_f64_fast(x0 * scale, s_tab);
+                    if (!(fabs(x0) < 64.0)) {          // NaN, infinite, or outside the fixed-point range: the gene's moments are NaN
+                        poison[(uint64_t)gbase + g0] = 1u;
+                        continue;
+                    }
+                    // round-to-nearest integer of x * 2^shift through the 1.5 * 2^52 trick (|x * 2^shift| < 2^51)
+                    const double kMagic = 6755399441055744.0;
+                    const long long is = __double_as_longlong(__builtin_fma(x0, fx_sum, kMagic)) - __double_as_longlong(kMagic);
+                    const long long iq = __double_as_longlong(__builtin_fma(x0 * x0, fx_sq, kMagic)) - __double_as_longlong(kMagic);
+                    if constexpr (COUNT) __hip_atomic_fetch_add(&s_cnt[g0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&s_sum[g0]), (unsigned long long)is, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&s_sq[g0]), (unsigned long long)iq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    continue;
+                }
+                if constexpr (COUNT) __hip_atomic_fetch_add(&s_cnt[g0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&s_sum[g0], x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&s_sq[g0], x0 * x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -117,11 +145,18 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     };
     for (uint64_t rbase = r0 + wave; rbase < r1; rbase += (uint64_t)kWaves * kMomRows) {
         int64_t lo[kMomRows], hi[kMomRows];
+        double scale[kMomRows];
 #pragma unroll
         for (int u = 0; u < kMomRows; ++u) {
             const uint64_t r = rbase + (uint64_t)u * kWaves;
-            if (r < r1) seg_bounds(indptr, tp, n_rows, n_tiles, tile, r, lo[u], hi[u]);
-            else lo[u] = hi[u] = 0;
+            scale[u] = 1.0;
+            if (r < r1) {
+                seg_bounds(indptr, tp, n_rows, n_tiles, tile, r, lo[u], hi[u]);
+                if constexpr (XF) {
+                    const double sr = row_sum[r];
+                    scale[u] = sr == 0.0 ? 0.0 : target / sr;            // scale/mod.rs:9-15
+                }
+            } else lo[u] = hi[u] = 0;
         }
         Chunk c[kMomRows];
 #pragma unroll
@@ -132,12 +167,12 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
 #pragma unroll
         for (int u = 0; u < kMomRows; ++u) {
             const int64_t e0 = (lo[u] & ~(int64_t)3) + 4 * lane;
-            if (e0 < hi[u]) add_chunk(e0, lo[u], hi[u], c[u]);
+            if (e0 < hi[u]) add_chunk(e0, lo[u], hi[u], c[u], scale[u]);
             // segments longer than 256 entries: the rest, one chunk at a time
             for (int64_t e1 = e0 + 4 * kWave; e1 < hi[u]; e1 += 4 * kWave) {
                 Chunk cc;
                 load_chunk(e1, cc);
-                add_chunk(e1, lo[u], hi[u], cc);
+                add_chunk(e1, lo[u], hi[u], cc, scale[u]);
             }
         }
     }
@@ -145,7 +180,7 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     for (int g = threadIdx.x; g < tile_genes; g += kMomThreads) {
         uint64_t gene = (uint64_t)gbase + g;
         if (gene < n_cols) {
-            part_cnt[rb * n_cols + gene] = s_cnt[g];
+            if constexpr (COUNT) part_cnt[rb * n_cols + gene] = s_cnt[g];
             part_sum[rb * n_cols + gene] = s_sum[g];
             part_sq[rb * n_cols + gene] = s_sq[g];
         }
@@ -153,19 +188,36 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
 }
 
 // Fixed-order sum of the per-row-block partials -> packed f64 [cnt | sum | sq | n_rows].
+// `cnt_cached` (nullable): this shard's per-gene counts, known from an earlier pass over the same sparsity pattern;
+// `cnt_store` (nullable): where to keep the counts summed here for the next time.
 __global__ void k_moments_reduce(const uint32_t* __restrict__ part_cnt, const double* __restrict__ part_sum,
                                  const double* __restrict__ part_sq, uint64_t n_cols, uint64_t n_blocks,
-                                 uint64_t n_rows, double* __restrict__ packed) {
+                                 uint64_t n_rows, const uint32_t* __restrict__ cnt_cached, uint32_t* __restrict__ cnt_store,
+                                 double inv_fx_sum, double inv_fx_sq, const uint32_t* __restrict__ poison,
+                                 double* __restrict__ packed) {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j == 0) packed[3 * n_cols] = (double)n_rows;
     if (j >= n_cols) return;
     uint64_t c = 0;
     double s = 0.0, q = 0.0;
+    if (inv_fx_sum != 0.0) {                 // fixed-point partials (transformed values): exact integer sums
+        long long is = 0, iq = 0;
+        for (uint64_t b = 0; b < n_blocks; ++b) {
+            if (!cnt_cached) c += part_cnt[b * n_cols + j];
+            is += __double_as_longlong(part_sum[b * n_cols + j]);
+            iq += __double_as_longlong(part_sq[b * n_cols + j]);
+        }
+        s = (double)is * inv_fx_sum;
+        q = (double)iq * inv_fx_sq;
+        if (poison[j]) s = q = __builtin_nan("");
+    } else
     for (uint64_t b = 0; b < n_blocks; ++b) {
-        c += part_cnt[b * n_cols + j];
+        if (!cnt_cached) c += part_cnt[b * n_cols + j];
         s += part_sum[b * n_cols + j];
         q += part_sq[b * n_cols + j];
     }
+    if (cnt_cached) c = cnt_cached[j];
+    else if (cnt_store) cnt_store[j] = (uint32_t)c;
     packed[j] = (double)c;
     packed[n_cols + j] = s;
     packed[2 * n_cols + j] = q;
@@ -312,7 +364,8 @@ static void block_geometry(const srx_mat* m, uint64_t& n_blocks, uint64_t& rows_
 }
 
 // This shard's (cnt, sum, sumsq) per gene and its row count, packed as 3G+1 doubles in a scratch buffer.
-static int32_t local_moments(srx_mat* m, double** packed_out) {
+// `xf`: moments of the transformed values ln_1p(v * scale_row) formed on the fly from the raw matrix.
+static int32_t local_moments(srx_mat* m, double** packed_out, RowXf xf = RowXf{}) {
     srx_ctx* ctx = m->ctx;
     SRX_TRY(ensure_tiles(m));
     const uint64_t G = m->n_cols;
@@ -324,32 +377,66 @@ static int32_t local_moments(srx_mat* m, double** packed_out) {
     SRX_TRY(scratch(ctx, "mom_part_sum", nb * (G ? G : 1) * sizeof(double), (void**)&p_sum));
     SRX_TRY(scratch(ctx, "mom_part_sq", nb * (G ? G : 1) * sizeof(double), (void**)&p_sq));
     SRX_TRY(scratch(ctx, "mom_packed", (3 * G + 1) * sizeof(double), (void**)&packed));
-    const size_t lds = (size_t)m->tile_genes * 20;
+    // the per-gene counts depend on the sparsity pattern only: computed by the first pass over a pattern, kept on the
+    // matrix (clones inherit them), and the count atomic is left out of every later pass
+    const bool have_cnt = m->cnt_pat_valid && m->d_cnt_pat;
+    if (!m->d_cnt_pat) SRX_HIP(ctx, hipMalloc((void**)&m->d_cnt_pat, (G ? G : 1) * sizeof(uint32_t)));
+    const size_t lds = (((size_t)m->tile_genes * 20 + 15) & ~(size_t)15) + (xf.row_sum ? (size_t)kLog1pTabBytes : 0);
     // s_i = 2 when the 16-bit index mirror exists (n_cols <= 65536), 4 otherwise
     const double bytes = (double)m->nnz * ((m->n_cols <= 65536 ? 2.0 : 4.0) + val_bytes(m)) + (double)(m->n_rows + 1) * 8.0 +
-                         (double)G * 24.0;
+                         (double)G * 24.0 + (xf.row_sum ? (double)m->n_rows * 8.0 : 0.0);
+    // fixed-point scales of the transformed sums: 62 bits hold n_rows values of magnitude < 2^6 (ln_1p(x) < 64, any
+    // x < 6e27) resp. their squares
+    double fx_sum = 0.0, fx_sq = 0.0;
+    if (xf.row_sum) {
+        int lg = 0;
+        while ((1ull << lg) < (m->n_rows ? m->n_rows : 1)) ++lg;
+        fx_sum = std::ldexp(1.0, std::min(62 - 6 - lg, 44));
+        fx_sq = std::ldexp(1.0, std::min(62 - 12 - lg, 38));
+    }
+    uint32_t* d_poison = nullptr;
+    if (xf.row_sum) {
+        SRX_TRY(scratch(ctx, "mom_poison", (G ? G : 1) * sizeof(uint32_t), (void**)&d_poison));
+        SRX_HIP(ctx, hipMemsetAsync(d_poison, 0, (G ? G : 1) * sizeof(uint32_t), ctx->stream));
+    }
     {
         ProfScope ps(ctx, SRX_K_MOMENTS, bytes);
         dim3 grid((unsigned)(nb * m->n_tiles));
         auto launch = [&](auto kern, const auto* idxp, const auto* valp) -> int32_t {
             SRX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, grid, dim3(kMomThreads), lds, ctx->stream, m->d_indptr, m->d_tile_ptr, idxp, valp,
-                               m->n_rows, G, m->n_tiles, m->tile_genes, rpb, p_cnt, p_sum, p_sq);
+                               m->n_rows, G, m->n_tiles, m->tile_genes, rpb, xf.row_sum, xf.target, fx_sum, fx_sq, d_poison, p_cnt, p_sum, p_sq);
             return SRX_OK;
         };
+        auto pick = [&](auto tval, auto tidx, const auto* idxp, const auto* valp) -> int32_t {
+            using T = decltype(tval);
+            using I = decltype(tidx);
+            if (xf.row_sum) return have_cnt ? launch(k_gene_moments<T, I, true, false>, idxp, valp) : launch(k_gene_moments<T, I, true, true>, idxp, valp);
+            return have_cnt ? launch(k_gene_moments<T, I, false, false>, idxp, valp) : launch(k_gene_moments<T, I, false, true>, idxp, valp);
+        };
         if (is_f32(m)) {
-            if (m->d_idx16) SRX_TRY(launch(k_gene_moments<float, uint16_t>, (const uint16_t*)m->d_idx16, (const float*)m->d_values));
-            else SRX_TRY(launch(k_gene_moments<float, int32_t>, (const int32_t*)m->d_indices, (const float*)m->d_values));
+            if (m->d_idx16) SRX_TRY(pick(float{}, uint16_t{}, (const uint16_t*)m->d_idx16, (const float*)m->d_values));
+            else SRX_TRY(pick(float{}, int32_t{}, (const int32_t*)m->d_indices, (const float*)m->d_values));
         } else {
-            if (m->d_idx16) SRX_TRY(launch(k_gene_moments<double, uint16_t>, (const uint16_t*)m->d_idx16, (const double*)m->d_values));
-            else SRX_TRY(launch(k_gene_moments<double, int32_t>, (const int32_t*)m->d_indices, (const double*)m->d_values));
+            if (m->d_idx16) SRX_TRY(pick(double{}, uint16_t{}, (const uint16_t*)m->d_idx16, (const double*)m->d_values));
+            else SRX_TRY(pick(double{}, int32_t{}, (const int32_t*)m->d_indices, (const double*)m->d_values));
         }
         hipLaunchKernelGGL(k_moments_reduce, dim3((unsigned)((G + 255) / 256 + 1)), dim3(256), 0, ctx->stream, p_cnt,
-                           p_sum, p_sq, G, nb, m->n_rows, packed);
+                           p_sum, p_sq, G, nb, m->n_rows, have_cnt ? (const uint32_t*)m->d_cnt_pat : (const uint32_t*)nullptr,
+                           have_cnt ? (uint32_t*)nullptr : m->d_cnt_pat, fx_sum != 0.0 ? 1.0 / fx_sum : 0.0,
+                           fx_sq != 0.0 ? 1.0 / fx_sq : 0.0, (const uint32_t*)d_poison, packed);
     }
     SRX_HIP(ctx, hipGetLastError());
+    m->cnt_pat_valid = true;
     *packed_out = packed;
     return SRX_OK;
+}
+
+// srx_matrix_prepare: the pattern-only per-gene counts now (one pass), so that clones inherit them
+int32_t ensure_pattern_counts(srx_mat* m) {
+    if (m->cnt_pat_valid) return SRX_OK;
+    double* packed;
+    return local_moments(m, &packed);
 }
 
 __global__ void k_add_f64(double* __restrict__ acc, const double* __restrict__ x, uint64_t n) {
@@ -358,11 +445,11 @@ __global__ void k_add_f64(double* __restrict__ acc, const double* __restrict__ x
 }
 
 // Backed mode: the moments of one row tile ADDED to `d_acc` (3G+1 doubles; counts stay exact below 2^53).
-int32_t moments_accumulate(srx_mat* m, double* d_acc) {
+int32_t moments_accumulate(srx_mat* m, double* d_acc, RowXf xf) {
     srx_ctx* ctx = m->ctx;
     SRX_HIP(ctx, hipSetDevice(ctx->device));
     double* packed;
-    SRX_TRY(local_moments(m, &packed));
+    SRX_TRY(local_moments(m, &packed, xf));
     const uint64_t n = 3 * m->n_cols + 1;
     hipLaunchKernelGGL(k_add_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_acc, packed, n);
     SRX_HIP(ctx, hipGetLastError());
@@ -418,6 +505,29 @@ int32_t ensure_moments(srx_mat* m) {
         m->n_rows_global = m->n_rows;
     }
     m->moments_version = m->version;
+    return SRX_OK;
+}
+
+// Moments of the transformed values y = ln_1p(v * scale_row), computed from the RAW matrix (pipeline): installed as the
+// moments of the version the in-place write-back is about to create (the caller bumps the version right after).
+int32_t ensure_moments_xf(srx_mat* m, RowXf xf) {
+    srx_ctx* ctx = m->ctx;
+    SRX_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t G = m->n_cols;
+    SRX_TRY(alloc_moments(m));
+    double* packed;
+    SRX_TRY(local_moments(m, &packed, xf));
+    SRX_TRY(allreduce_f64(ctx, packed, 3 * G + 1));
+    hipLaunchKernelGGL(k_moments_unpack, dim3((unsigned)((G + 255) / 256 + 1)), dim3(256), 0, ctx->stream, packed, G,
+                       m->d_cnt, m->d_sum, m->d_sq);
+    SRX_HIP(ctx, hipGetLastError());
+    if (ctx->comm || ctx->host_allreduce) {
+        double ng = 0.0;
+        SRX_TRY(d2h(ctx, &ng, packed + 3 * G, sizeof(double)));
+        m->n_rows_global = (uint64_t)ng;
+    } else {
+        m->n_rows_global = m->n_rows;
+    }
     return SRX_OK;
 }
 
@@ -793,6 +903,7 @@ int32_t srx_normalize_total_inplace(srx_mat* m, double target_sum, int32_t direc
     srx_ctx* ctx = m->ctx;
     SRX_HIP(ctx, hipSetDevice(ctx->device));
     direction = eff_dir(m, direction);           // scale_row_csc / scale_col_csc, scale/mod.rs:25-57,104-139
+    SRX_TRY(promote_to_f64(m));                  // X becomes DynCsrMatrix::F64 (scale/mod.rs:74-83)
     if (direction == SRX_ROW) return launch_normalize(m, target_sum, true, false);
     if (direction != SRX_COLUMN) return fail(ctx, SRX_E_ARG, "bad direction %d", direction);
     SRX_TRY(ensure_moments(m));

@@ -36,6 +36,7 @@
 #include <numeric>
 
 #include "common.hpp"
+#include "log1p64.hpp"
 
 namespace srx {
 
@@ -345,15 +346,18 @@ __global__ __launch_bounds__(256) void k_tcount(const int64_t* __restrict__ indp
     }
 }
 
-template <typename T, typename I>
+// XF: `vals` are the raw values and the kept entries are stored as ln_1p(f64(v) * scale_row), rounded once (RowXf).
+template <typename T, typename I, bool XF>
 __global__ __launch_bounds__(256) void k_tfill(const int64_t* __restrict__ indptr, const I* __restrict__ idx,
                                                const T* __restrict__ vals, const uint32_t* __restrict__ g_bits,
                                                const uint32_t* __restrict__ g_prefix, int n_words, uint64_t n_rows,
                                                int nt256, int k, const int64_t* __restrict__ cnt256,
                                                const int64_t* __restrict__ rm_ptr,
-                                               const int64_t* __restrict__ tptr256, GramPk<T>* __restrict__ rm,
-                                               GramPk<T>* __restrict__ pk256) {
+                                               const int64_t* __restrict__ tptr256, const double* __restrict__ row_sum,
+                                               double target, GramPk<T>* __restrict__ rm, GramPk<T>* __restrict__ pk256) {
     extern __shared__ double lds_raw[];
+    __shared__ Log1pTabEntry s_tab[XF ? 128 : 1];
+    if constexpr (XF) stage_log1p_table(s_tab);
     const SelLds sel = stage_selection(g_bits, g_prefix, n_words, reinterpret_cast<uint32_t*>(lds_raw));
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
@@ -372,6 +376,12 @@ __global__ __launch_bounds__(256) void k_tfill(const int64_t* __restrict__ indpt
         // destination bias of each tile: tptr - (kept entries before the tile)
         const int64_t off256 = (lane < nt256 ? tptr256[(uint64_t)lane * n_rows + r] : 0) - before256;
         const int64_t row_base = rm_ptr[r];
+        double scale = 1.0, row_table = 0.0;
+        if constexpr (XF) {
+            const double sr = row_sum[r];
+            scale = sr == 0.0 ? 0.0 : target / sr;      // scale/mod.rs:9-15
+        }
+        (void)row_table;
         int rank0 = 0;                                  // kept entries of the row before this chunk
         // (tried and slower at c3: 16 chunks in flight, 2.42 ms — the ballots / shuffles of the masked-out tail
         //  chunks cost more than the loads gain; parking the kept entries in LDS and writing them out per row,
@@ -394,7 +404,8 @@ __global__ __launch_bounds__(256) void k_tfill(const int64_t* __restrict__ indpt
                 const int64_t o256 = __shfl(off256, cc >> 8, kWave);   // shuffles run with all lanes active
                 if (c >= 0) {
                     const int rank = rank0 + __popcll(mask & ((1ull << lane) - 1ull));
-                    const T v = vals[p];
+                    T v = vals[p];
+                    if constexpr (XF) v = xf_stored(v, scale, s_tab);         // the value the write-back stores in X
                     GramPk<T> e{};
                     e.j = c;
                     e.v = v;
@@ -1763,7 +1774,7 @@ static int32_t alloc_tiled(srx_mat* m, uint64_t N, uint64_t nnz, int k, int kt, 
 
 // `d_sel`: n_words selection bits followed by n_words prefix counts, on the device (the compacted column of a
 // gene is its rank among the selected genes in ascending gene order)
-static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words, int k, RowMajor& rm, Tiled& t256) {
+static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words, int k, RowMajor& rm, Tiled& t256, RowXf xf = RowXf{}) {
     srx_ctx* ctx = m->ctx;
     const uint64_t N = m->n_rows;
     const int nt128 = (k + KG - 1) / KG, nt256 = (k + KT - 1) / KT;
@@ -1796,19 +1807,23 @@ static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words,
     rm.k = k;
     auto fill = [&](auto kern, const auto* idxp, const auto* valp, auto* rmp, auto* pk256) {
         hipLaunchKernelGGL(kern, dim3(grid_rows(ctx, N, 4)), dim3(256), sel_lds, ctx->stream, m->d_indptr, idxp, valp, d_sel,
-                           d_sel + n_words, n_words, N, nt256, k, cnt256, rm.ptr, t256.tptr, rmp, pk256);
+                           d_sel + n_words, n_words, N, nt256, k, cnt256, rm.ptr, t256.tptr, xf.row_sum, xf.target, rmp, pk256);
     };
-    if (is_f32(m)) {
-        if (m->d_idx16) fill(k_tfill<float, uint16_t>, (const uint16_t*)m->d_idx16, (const float*)m->d_values,
-                             (GramPk<float>*)rm.pk, (GramPk<float>*)t256.tpk);
-        else fill(k_tfill<float, int32_t>, (const int32_t*)m->d_indices, (const float*)m->d_values,
-                  (GramPk<float>*)rm.pk, (GramPk<float>*)t256.tpk);
-    } else {
-        if (m->d_idx16) fill(k_tfill<double, uint16_t>, (const uint16_t*)m->d_idx16, (const double*)m->d_values,
-                             (GramPk<double>*)rm.pk, (GramPk<double>*)t256.tpk);
-        else fill(k_tfill<double, int32_t>, (const int32_t*)m->d_indices, (const double*)m->d_values,
-                  (GramPk<double>*)rm.pk, (GramPk<double>*)t256.tpk);
-    }
+    auto fill_t = [&](auto tval, auto* rmp, auto* pk256) {
+        using T = decltype(tval);
+        const T* valp = (const T*)m->d_values;
+        if (m->d_idx16) {
+            const uint16_t* ip = (const uint16_t*)m->d_idx16;
+            if (xf.row_sum) fill(k_tfill<T, uint16_t, true>, ip, valp, rmp, pk256);
+            else fill(k_tfill<T, uint16_t, false>, ip, valp, rmp, pk256);
+        } else {
+            const int32_t* ip = (const int32_t*)m->d_indices;
+            if (xf.row_sum) fill(k_tfill<T, int32_t, true>, ip, valp, rmp, pk256);
+            else fill(k_tfill<T, int32_t, false>, ip, valp, rmp, pk256);
+        }
+    };
+    if (is_f32(m)) fill_t(float{}, (GramPk<float>*)rm.pk, (GramPk<float>*)t256.tpk);
+    else fill_t(double{}, (GramPk<double>*)rm.pk, (GramPk<double>*)t256.tpk);
     SRX_HIP(ctx, hipGetLastError());
     if (ctx->prof_mask & (1u << SRX_K_COMPACT))
         ctx->prof[SRX_K_COMPACT].bytes += (double)total * (4.0 + val_bytes(m)) * 3.0;   // read once, written twice
@@ -1816,7 +1831,7 @@ static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words,
 }
 
 // host-side selection (srx_pca with an explicit feature list): bitmask + prefix counts from the remap table
-static int32_t build_tiled_fused(srx_mat* m, const std::vector<int32_t>& remap, int k, RowMajor& rm, Tiled& t256) {
+static int32_t build_tiled_fused(srx_mat* m, const std::vector<int32_t>& remap, int k, RowMajor& rm, Tiled& t256, RowXf xf = RowXf{}) {
     srx_ctx* ctx = m->ctx;
     const int n_words = (int)((remap.size() + 31) / 32);
     std::vector<uint32_t> hsel(2 * (size_t)n_words, 0u);
@@ -1830,7 +1845,7 @@ static int32_t build_tiled_fused(srx_mat* m, const std::vector<int32_t>& remap, 
     uint32_t* d_sel;
     SRX_TRY(scratch(ctx, "pca_selbits", (hsel.size() ? hsel.size() : 1) * sizeof(uint32_t), (void**)&d_sel));
     SRX_TRY(h2d(ctx, d_sel, hsel.data(), hsel.size() * sizeof(uint32_t)));
-    return build_tiled_fused(m, d_sel, n_words, k, rm, t256);
+    return build_tiled_fused(m, d_sel, n_words, k, rm, t256, xf);
 }
 
 // ---- launches ---------------------------------------------------------------------------------
@@ -2357,6 +2372,8 @@ static int32_t ensure_result_capacity(srx_ctx* ctx, srx_pca_state& st, size_t ne
     return SRX_OK;
 }
 
+static int32_t launch_writeback(srx_mat* m);
+
 template <typename VT, typename PT>
 static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const RowMajor* rmp, double* gram_packed,
                        const Resolved& o, const std::vector<double>& mu, const std::vector<double>& dinv,
@@ -2518,6 +2535,11 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const RowM
             SRX_TRY(launch_gram<VT>(ctx, *rmp, Pk));
         }
         SRX_TRY(allreduce_f64(ctx, Pk, n_packed));                // the one exchange of this solver: the packed upper triangle
+        if (ctx->wb_after_gram) {
+            srx_mat* wm = ctx->wb_after_gram;
+            ctx->wb_after_gram = nullptr;
+            SRX_TRY(launch_writeback(wm));
+        }
         auto reset = [&]() -> int32_t {
             hipLaunchKernelGGL(k_gram_expand, dim3((unsigned)(((size_t)k * k + 255) / 256)), dim3(256), 0, ctx->stream, Pk,
                                k, (const double*)w.d, (const double*)w.mu, o.center, n_cells, C);
@@ -2540,6 +2562,11 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const RowM
         SRX_TRY(solve(apply, C, true, reset, deflate));
     } else {
         if (n_parts != 1) return fail(ctx, SRX_E_ARG, "pca: the SpMM solver needs the matrix resident in one piece");
+        if (ctx->wb_after_gram) {
+            srx_mat* wm = ctx->wb_after_gram;
+            ctx->wb_after_gram = nullptr;
+            SRX_TRY(launch_writeback(wm));
+        }
         // matrix-free: Z^T (Z W) by a forward and a transposed SpMM; resolved eigenpairs are deflated IMPLICITLY,
         // W' -= V_lock (theta_lock * (V_lock^T W)) with the locked vectors in a k x 64 block (plan B locks <= 48)
         double* v_lock;
@@ -2711,7 +2738,53 @@ static int32_t prepare_host_selection(srx_mat* m, const std::vector<uint64_t>& s
 // Everything up to and including the scores, left in m->pca (device scores + small host vectors).
 // `hvg_n` > 0: FeatureSelection::HighlyVariable(hvg_n) made on the device (the pipeline's route: no host round
 // trip between the moments pass and the compaction); otherwise `sel` (nullptr = all features).
-static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const srx_pca_opts* opts, uint64_t hvg_n = 0) {
+// The in-place normalise + log1p of a matrix whose pipeline has been reading it raw (RowXf), on the context's side
+// stream: it runs beside the bucket / Gram kernels, which do not touch X.  The caller joins before it returns.
+static int32_t launch_writeback(srx_mat* m) {
+    srx_ctx* ctx = m->ctx;
+    if (!m->lazy_pending) return SRX_OK;
+    if (!ctx->side_stream) {
+        // The side stream is kept off a few CUs (CU mask): the write-back's waves hold ~100 VGPRs each, and with them on
+        // every CU a 1024-thread workgroup of the iteration (k_gram2_part, the Cholesky / Jacobi kernels) found no CU
+        // with room until the write-back had finished — the two streams ran one after the other (profiles/r02 timeline).
+        static const int free_cus = getenv("SRX_WB_FREE_CUS") ? atoi(getenv("SRX_WB_FREE_CUS")) : 32;
+        uint32_t mask[8];
+        const int n_cus = ctx->n_cus > 256 ? 256 : ctx->n_cus;
+        for (int w = 0; w < 8; ++w) mask[w] = 0u;
+        for (int c = (free_cus < n_cus ? free_cus : 0); c < n_cus; ++c) mask[c >> 5] |= 1u << (c & 31);
+        if (free_cus <= 0 || free_cus >= n_cus ||
+            hipExtStreamCreateWithCUMask(&ctx->side_stream, (uint32_t)((n_cus + 31) / 32), mask) != hipSuccess) {
+            (void)hipGetLastError();
+            SRX_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        }
+        SRX_HIP(ctx, hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+        SRX_HIP(ctx, hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
+    }
+    static const bool serial = getenv("SRX_NO_OVERLAP") != nullptr;           // A/B switch: write back on the main stream
+    hipStream_t st = serial ? ctx->stream : ctx->side_stream;
+    if (!serial) {
+        SRX_HIP(ctx, hipEventRecord(ctx->side_fork, ctx->stream));
+        SRX_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+    }
+    m->lazy_pending = false;
+    SRX_TRY(launch_normalize(m, m->lazy_target, true, true, st, !is_f32(m), 0));      // bumps the version; 3 workgroups per CU: room for the iteration's kernels
+    // (the moments cached on the matrix are those of the f64 transform, not of the values as stored: the version bump
+    //  above retires them — a later compute_variance sees what X holds)
+    if (!serial) {
+        SRX_HIP(ctx, hipEventRecord(ctx->side_join, ctx->side_stream));
+        ctx->side_busy = true;
+    }
+    return SRX_OK;
+}
+static int32_t join_side(srx_ctx* ctx) {
+    if (!ctx->side_busy) return SRX_OK;
+    ctx->side_busy = false;
+    SRX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_join, 0));
+    return SRX_OK;
+}
+
+static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const srx_pca_opts* opts, uint64_t hvg_n = 0,
+                          RowXf xf = RowXf{}) {
     srx_ctx* ctx = m->ctx;
     SRX_HIP(ctx, hipSetDevice(ctx->device));
     if (m->csc) {
@@ -2720,7 +2793,7 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
         // dense matrix from either storage)
         srx_mat* t = nullptr;
         SRX_TRY(transpose_device(m, &t));
-        const int32_t rc = pca_device(t, sel, k64, opts, hvg_n);
+        const int32_t rc = pca_device(t, sel, k64, opts, hvg_n, RowXf{});
         std::swap(m->pca, t->pca);
         srx_matrix_free(t);
         return rc;
@@ -2760,14 +2833,23 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     Tiled t256;
     RowMajor rm;
     if (dev_sel) {
-        SRX_TRY(build_tiled_fused(m, hv.d_bits, hv.n_words, k, rm, t256));
+        SRX_TRY(build_tiled_fused(m, hv.d_bits, hv.n_words, k, rm, t256, xf));
     } else if ((k + KG - 1) / KG <= kWave) {
-        SRX_TRY(build_tiled_fused(m, remap, k, rm, t256));
+        SRX_TRY(build_tiled_fused(m, remap, k, rm, t256, xf));
     } else {
+        // the general route reads stored values: the matrix is transformed in place first
+        if (xf.row_sum) {
+            SRX_TRY(launch_writeback(m));
+            SRX_TRY(join_side(ctx));
+        }
         CompactCsr cc;
         SRX_TRY(build_compact(m, remap, k, cc, rm));
         SRX_TRY(retile(m, cc, KT, t256));
     }
+    // nothing below reads X.  The in-place write-back of the transformed values is queued on the side stream once the
+    // Gram kernel is (run_pca): it then runs beside the k x 64 iteration — ~100 small launches that leave HBM idle —
+    // instead of beside the Gram kernel, whose suffix gathers the streaming pass slowed by 3 ms when the two overlapped.
+    ctx->wb_after_gram = xf.row_sum ? m : nullptr;
     st.info = srx_pca_info{};
     st.info.n_cells_global = Ng;
     st.info.k = (uint32_t)k;
@@ -2999,16 +3081,34 @@ int32_t srx_pipeline(srx_mat* m, double target_sum, uint64_t n_hvg, const srx_pc
     auto cleanup = [&]() { for (auto& e : ev) (void)hipEventDestroy(e); };
     int32_t rc = SRX_OK;
     (void)hipEventRecord(ev[0], ctx->stream);
-    // normalize_total_inplace(target, Row) + log1p_transform_inplace, fused (CSC: the two calls, cells are columns)
-    rc = m->csc ? srx_normalize_log1p_inplace(m, target_sum, nullptr) : launch_normalize(m, target_sum, true, true);
+    // normalize_total_inplace(target, Row) + log1p_transform_inplace.  CSR: the passes that follow read the RAW matrix
+    // and form y = ln_1p(v * scale_row) on the fly in f64 (RowXf) — so the per-gene moments behind HighlyVariable(n)
+    // are those of the reference's f64 values whatever the storage type — and the in-place write-back of y runs on the
+    // side stream beside the Gram kernel.  CSC (cells are columns): the two calls, then the stored values.
+    const uint64_t take = n_hvg < m->n_cols ? n_hvg : m->n_cols;
+    const bool lazy = !m->csc && !getenv("SRX_NO_LAZY");
+    RowXf xf;
+    if (m->csc) rc = srx_normalize_log1p_inplace(m, target_sum, nullptr);
+    else if (!lazy) rc = launch_normalize(m, target_sum, true, true);
+    else {
+        rc = launch_row_sums(m);
+        xf.row_sum = m->d_row_sum;
+        xf.target = target_sum;
+        m->lazy_pending = true;
+        m->lazy_target = target_sum;
+    }
     (void)hipEventRecord(ev[1], ctx->stream);
     // per-gene moments of the transformed values (one pass, all-reduced across shards)
-    if (rc == SRX_OK && !m->csc) rc = ensure_moments(m);
+    if (rc == SRX_OK && !m->csc) {
+        if (lazy) {
+            rc = ensure_moments_xf(m, xf);
+            m->moments_version = m->version;          // what pca_device's ensure_moments looks at
+        } else rc = ensure_moments(m);
+    }
     (void)hipEventRecord(ev[2], ctx->stream);
     // FeatureSelection::HighlyVariable(n_hvg): on the device, inside pca_device (the selection is fetched with the
     // other results once the solve is over); the host route only for shapes the device kernels do not take
     std::vector<uint64_t> sel;
-    const uint64_t take = n_hvg < m->n_cols ? n_hvg : m->n_cols;
     const bool dev_sel = !m->csc && n_hvg > 0 && take <= (uint64_t)kWave * KG && m->n_cols <= 65536;
     if (rc == SRX_OK && m->csc) {                 // HighlyVariable(n) with the CSC variance (csc.rs:164-177)
         uint64_t n_out = 0;
@@ -3021,7 +3121,14 @@ int32_t srx_pipeline(srx_mat* m, double target_sum, uint64_t n_hvg, const srx_pc
         if (rc == SRX_OK) rc = select_hvg_host(ctx, var, n_hvg, sel);
     }
     (void)hipEventRecord(ev[3], ctx->stream);
-    if (rc == SRX_OK) rc = dev_sel ? pca_device(m, nullptr, 0, opts, n_hvg) : pca_device(m, sel.data(), sel.size(), opts);
+    if (rc == SRX_OK) rc = dev_sel ? pca_device(m, nullptr, 0, opts, n_hvg, xf) : pca_device(m, sel.data(), sel.size(), opts, 0, xf);
+    // whatever happened above, X ends up normalised and log1p'd (the two in-place calls come first in the reference)
+    ctx->wb_after_gram = nullptr;
+    if (m->lazy_pending) {
+        const int32_t rc_wb = launch_writeback(m);
+        if (rc == SRX_OK) rc = rc_wb;
+    }
+    (void)join_side(ctx);
     (void)hipEventRecord(ev[4], ctx->stream);
     (void)hipStreamSynchronize(ctx->stream);
     if (res) {

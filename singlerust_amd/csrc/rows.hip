@@ -8,28 +8,12 @@
 //
 // Algorithmic bytes: fused normalise+log1p = nnz*2*s_v + (N+1)*8.
 #include "common.hpp"
+#include "log1p64.hpp"
 
 namespace srx {
 
 constexpr int kRowCache = 32;  // values per lane kept in registers: rows up to 2048 nnz are read from HBM once
                                // (16 left 26 % of the c3 rows — log-normal sizes, mean 840 — in the scalar tail loop)
-
-template <typename T>
-__device__ __forceinline__ T apply_log1p(T x);
-// f32 ln(1+x) in ~10 instructions (ocml's log1pf is ~100 and made the fused pass VALU-bound):
-// u = fl(1 + x); ln(1+x) = ln(u) * x / (u - 1) compensates the rounding of u (Goldberg / Kahan),
-// with ln(u) = v_log_f32(u) * ln 2 (1 ulp hardware log2).  Measured <= 3e-7 relative against f64
-// log1p over 1e-30 .. 1e30 (tests/test_stats_gpu.py::test_log1p_f32_accuracy).
-template <>
-__device__ __forceinline__ float apply_log1p<float>(float x) {
-    const float u = 1.0f + x;
-    const float d = u - 1.0f;
-    const float lg = __builtin_amdgcn_logf(u) * 0.693147180559945309f;
-    const float q = x >= 16777216.0f ? 1.0f : x * __builtin_amdgcn_rcpf(d);   // u == x there; rcp would flush
-    return (d == 0.0f || !(u < INFINITY)) ? (d == 0.0f ? x : u) : lg * q;
-}
-template <>
-__device__ __forceinline__ double apply_log1p<double>(double x) { return log1p(x); }
 
 // 16-byte vector of row values: 4 x f32 or 2 x f64.
 template <typename T>
@@ -44,10 +28,18 @@ struct alignas(16) RowVec {
 // its first entry (elements outside [lo, hi) are masked; the arrays are padded by 16 entries),
 // 16 values per lane stay in registers between the reduction and the write-back, so a row is
 // read from HBM exactly once; interior vectors are written back with 16-byte stores.
-template <typename T, bool NORM, bool LOG>
+// PRECISE (with NORM and LOG): y = ln_1p(f64(v) * scale) evaluated in f64 and rounded ONCE to the storage type — the
+// value the reference's two calls produce (scale/mod.rs:66-83 promotes to f64, transform/mod.rs:38-42), and the value
+// the pipeline's moments / compaction passes computed on the fly from the raw matrix before this write-back.
+template <typename T, bool NORM, bool LOG, bool PRECISE = false>
 __global__ __launch_bounds__(256) void k_row_pass(const int64_t* __restrict__ indptr, T* __restrict__ vals,
                                                   uint64_t n_rows, double target,
                                                   double* __restrict__ row_sum_out) {
+    __shared__ Log1pTabEntry s_tab[PRECISE ? 128 : 1];
+    if constexpr (PRECISE) {
+        stage_log1p_table(s_tab);
+        __syncthreads();
+    }
     constexpr int V = 16 / sizeof(T);
     constexpr int NV = kRowCache / V;
     using Vec = RowVec<T>;
@@ -84,17 +76,28 @@ __global__ __launch_bounds__(256) void k_row_pass(const int64_t* __restrict__ in
             if (row_sum_out && lane == 0) row_sum_out[r] = s;
         }
         const double scale = NORM ? (s == 0.0 ? 0.0 : target / s) : 1.0;
+        double row_table = 0.0;
+        if constexpr (PRECISE) row_table = xf_row_table(scale, s_tab);
         auto f = [&](T v) -> T {
+            if constexpr (PRECISE) return (T)xf_apply<T>(v, scale, row_table, s_tab);      // every lane active (shuffle)
             T x = NORM ? (T)((double)v * scale) : v;
             return LOG ? apply_log1p<T>(x) : x;
         };
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
             const int64_t e0 = base + ((int64_t)t * kWave + lane) * V;
-            if (e0 < hi && e0 + V > lo) {
-                Vec o;
+            Vec o;
+            if constexpr (PRECISE) {                       // outside the lane predicate: f() shuffles
+                if (__any(e0 < hi)) {
 #pragma unroll
-                for (int j = 0; j < V; ++j) o.x[j] = f(c[t].x[j]);
+                    for (int j = 0; j < V; ++j) o.x[j] = f(c[t].x[j]);
+                }
+            }
+            if (e0 < hi && e0 + V > lo) {
+                if constexpr (!PRECISE) {
+#pragma unroll
+                    for (int j = 0; j < V; ++j) o.x[j] = f(c[t].x[j]);
+                }
                 if (e0 >= lo && e0 + V <= hi) {
                     *reinterpret_cast<Vec*>(vals + e0) = o;
                 } else {
@@ -106,7 +109,15 @@ __global__ __launch_bounds__(256) void k_row_pass(const int64_t* __restrict__ in
                 }
             }
         }
-        for (int64_t p = tail + lane; p < hi; p += kWave) vals[p] = f(vals[p]);
+        if constexpr (PRECISE) {
+            for (int64_t p0 = tail; p0 < hi; p0 += kWave) {
+                const int64_t p = p0 + lane;
+                const T y = f(p < hi ? vals[p] : T(0));
+                if (p < hi) vals[p] = y;
+            }
+        } else {
+            for (int64_t p = tail + lane; p < hi; p += kWave) vals[p] = f(vals[p]);
+        }
     }
 }
 
@@ -257,25 +268,30 @@ static int row_grid(const srx_mat* m) {
     return (int)(want < cap ? want : cap);
 }
 
-int32_t launch_normalize(srx_mat* m, double target, bool do_norm, bool do_log) {
+// `stream` / `precise`: the pipeline's write-back (k_row_pass<.., PRECISE>) runs on the context's side stream
+int32_t launch_normalize(srx_mat* m, double target, bool do_norm, bool do_log, hipStream_t stream, bool precise, int wgs_per_cu) {
     srx_ctx* ctx = m->ctx;
     SRX_HIP(ctx, hipSetDevice(ctx->device));
+    if (!stream) stream = ctx->stream;
     if (do_norm && !m->d_row_sum) SRX_HIP(ctx, hipMalloc((void**)&m->d_row_sum, (m->n_rows ? m->n_rows : 1) * sizeof(double)));
-    const int g = row_grid(m);
+    int g = row_grid(m);
+    if (wgs_per_cu > 0 && g > ctx->n_cus * wgs_per_cu) g = ctx->n_cus * wgs_per_cu;
     const double bytes = (double)m->nnz * 2.0 * val_bytes(m) + (double)(m->n_rows + 1) * 8.0;
     {
-        ProfScope ps(ctx, SRX_K_NORMALIZE, bytes);
-#define SRX_LAUNCH_ROW(T, N, L)                                                                    \
-    hipLaunchKernelGGL((k_row_pass<T, N, L>), dim3(g), dim3(256), 0, ctx->stream, m->d_indptr,      \
+        ProfScope ps(ctx, SRX_K_NORMALIZE, bytes, stream);
+#define SRX_LAUNCH_ROW(T, N, L, P)                                                                  \
+    hipLaunchKernelGGL((k_row_pass<T, N, L, P>), dim3(g), dim3(256), 0, stream, m->d_indptr,         \
                        (T*)m->d_values, m->n_rows, target, (N) ? m->d_row_sum : (double*)nullptr)
         if (is_f32(m)) {
-            if (do_norm && do_log) SRX_LAUNCH_ROW(float, true, true);
-            else if (do_norm) SRX_LAUNCH_ROW(float, true, false);
-            else if (do_log) SRX_LAUNCH_ROW(float, false, true);
+            if (do_norm && do_log && precise) SRX_LAUNCH_ROW(float, true, true, true);
+            else if (do_norm && do_log) SRX_LAUNCH_ROW(float, true, true, false);
+            else if (do_norm) SRX_LAUNCH_ROW(float, true, false, false);
+            else if (do_log) SRX_LAUNCH_ROW(float, false, true, false);
         } else {
-            if (do_norm && do_log) SRX_LAUNCH_ROW(double, true, true);
-            else if (do_norm) SRX_LAUNCH_ROW(double, true, false);
-            else if (do_log) SRX_LAUNCH_ROW(double, false, true);
+            if (do_norm && do_log && precise) SRX_LAUNCH_ROW(double, true, true, true);
+            else if (do_norm && do_log) SRX_LAUNCH_ROW(double, true, true, false);
+            else if (do_norm) SRX_LAUNCH_ROW(double, true, false, false);
+            else if (do_log) SRX_LAUNCH_ROW(double, false, true, false);
         }
 #undef SRX_LAUNCH_ROW
     }
@@ -284,6 +300,24 @@ int32_t launch_normalize(srx_mat* m, double target, bool do_norm, bool do_log) {
     if (do_norm) m->dtype = SRX_F64;
     if (do_log && m->dtype != SRX_F32) m->dtype = SRX_F64;
     touch(m);
+    return SRX_OK;
+}
+
+// Row sums of the current values into m->d_row_sum (the first step of the pipeline: the per-gene passes apply the
+// normalise + log1p transform on the fly from them, the in-place write-back follows on the side stream).
+int32_t launch_row_sums(srx_mat* m) {
+    srx_ctx* ctx = m->ctx;
+    SRX_HIP(ctx, hipSetDevice(ctx->device));
+    if (!m->d_row_sum) SRX_HIP(ctx, hipMalloc((void**)&m->d_row_sum, (m->n_rows ? m->n_rows : 1) * sizeof(double)));
+    const int g = row_grid(m);
+    ProfScope ps(ctx, SRX_K_ROWSUM, (double)m->nnz * val_bytes(m) + (double)(m->n_rows + 1) * 8.0 + (double)m->n_rows * 8.0);
+    if (is_f32(m))
+        hipLaunchKernelGGL((k_row_sum<float>), dim3(g), dim3(256), 0, ctx->stream, m->d_indptr, (const float*)m->d_values,
+                           m->n_rows, m->d_row_sum);
+    else
+        hipLaunchKernelGGL((k_row_sum<double>), dim3(g), dim3(256), 0, ctx->stream, m->d_indptr, (const double*)m->d_values,
+                           m->n_rows, m->d_row_sum);
+    SRX_HIP(ctx, hipGetLastError());
     return SRX_OK;
 }
 
@@ -317,6 +351,7 @@ extern "C" {
 
 int32_t srx_log1p_inplace(srx_mat* m) {
     if (!m) return fail(nullptr, SRX_E_ARG, "null matrix");
+    if (m->dtype != SRX_F32) SRX_TRY(promote_to_f64(m));      // transform/mod.rs:43-55: F32 stays F32, anything else -> F64
     return launch_normalize(m, 0.0, false, true);
 }
 
@@ -327,6 +362,7 @@ int32_t srx_normalize_log1p_inplace(srx_mat* m, double target_sum, double* row_s
         SRX_TRY(srx_normalize_total_inplace(m, target_sum, SRX_ROW));
         return srx_log1p_inplace(m);
     }
+    SRX_TRY(promote_to_f64(m));
     SRX_TRY(launch_normalize(m, target_sum, true, true));
     if (row_sums_out) SRX_TRY(d2h(m->ctx, row_sums_out, m->d_row_sum, m->n_rows * sizeof(double)));
     return SRX_OK;

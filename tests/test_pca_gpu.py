@@ -100,7 +100,9 @@ def test_hvg_pipeline_vs_oracle(ctx, store, tol, solver):
     if store == 2:
         assert np.array_equal(sel, want_sel)
     else:
-        assert len(set(sel.tolist()) ^ set(want_sel.tolist())) <= 2      # f32 rounding may swap a near-tie at the cut
+        # EXPLICIT f32 storage and the three separate calls: HighlyVariable(n) ranks what X holds, f32-rounded values (a
+        # matrix created with SRX_STORE_AUTO moves to f64 at normalize_total, like the reference's variant, and is exact)
+        assert len(set(sel.tolist()) ^ set(want_sel.tolist())) <= 2
     scores, comps, evr, mean, std = pca_oracle.pca_inplace(lg, n_pc, None, None, sel)
     assert col_err(a.obsm["X_pca"], scores) < tol
     assert col_err(a.uns["pca"]["components"], comps) < tol
@@ -195,7 +197,9 @@ def test_fused_pipeline_equals_separate_calls(ctx):
     hv = np.zeros(400, np.uint64)
     _ffi.check(_ffi.lib().srx_result_fetch(b.x().handle, _ffi.ptr(scores), _ffi.ptr(comps), None, None, None, _ffi.ptr(hv)), ctx.handle)
     assert np.array_equal(hv, a.uns["pca"]["selected_features"])
-    assert np.array_equal(a.x_values(), b.x_values())
+    # the pipeline rounds ln_1p(f64(v) * scale) ONCE to the f32 storage; the two separate calls round the scaled value and
+    # the logarithm in turn
+    assert np.max(np.abs(a.x_values() - b.x_values()) / np.maximum(np.abs(b.x_values()), 1e-30)) < 1e-6
     # LDS atomics accumulate in a run-dependent order: equal to rounding, not bit-equal
     assert col_err(scores, a.obsm["X_pca"]) < TOL
     assert col_err(comps, a.uns["pca"]["components"]) < TOL
@@ -278,9 +282,10 @@ def test_pipeline_device_selection_ties_and_results(ctx):
     dim_red.pca_inplace(a, 10, None, None, None, sr.FeatureSelection.HighlyVariable(n_hvg), None, seed=3)
     ref = a.uns["pca"]
     assert np.array_equal(hv, ref["selected_features"])
-    np.testing.assert_allclose(mean, ref["mean"], rtol=1e-12, atol=1e-14)
-    np.testing.assert_allclose(std, ref["std"], rtol=1e-12, atol=1e-14)
-    np.testing.assert_allclose(evr, ref["explained_variance_ratio"], rtol=1e-6)
+    # (the pipeline's moments are those of the f64 transform, the three-call route's those of the f32 values X holds)
+    np.testing.assert_allclose(mean, ref["mean"], rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(std, ref["std"], rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(evr, ref["explained_variance_ratio"], rtol=1e-5)
     # duplicated genes make C rank-deficient but the leading subspace is well defined: compare projectors
     q1, _ = np.linalg.qr(comps[:, :5]); q2, _ = np.linalg.qr(ref["components"][:, :5])
     assert np.linalg.norm(q1 @ q1.T - q2 @ q2.T) < 1e-4
@@ -329,10 +334,7 @@ def test_fused_pipeline_odd_shapes(ctx, n, g, hvg, npc, store):
                                            _ffi.ptr(hv)), ctx.handle)
     lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
     want_sel = pca_oracle.select_features_hvg(lg, hvg)
-    if store == 2:
-        assert np.array_equal(hv, want_sel)
-    else:
-        assert len(set(hv.tolist()) ^ set(want_sel.tolist())) <= 2
+    assert np.array_equal(hv, want_sel)               # srx_pipeline: f64 moments at either storage
     # zero-variance selected genes (n_hvg >= n_vars picks the empty ones): the reference divides by std = 0 there;
     # compare on the columns with a positive std, as test_defaults_and_small_k does
     dense = oracle.densify_selected(lg, hv)
@@ -365,7 +367,7 @@ def test_pipeline_medium_scale_vs_oracle(ctx):
                                            _ffi.ptr(hv)), ctx.handle)
     lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
     want_sel = pca_oracle.select_features_hvg(lg, hvg)
-    assert len(set(hv.tolist()) ^ set(want_sel.tolist())) <= 4
+    assert np.array_equal(hv, want_sel)
     want_scores, want_comps, want_evr, *_ = pca_oracle.pca_inplace(lg, npc, None, None, hv)
     # components inside a cluster of close eigenvalues may rotate among themselves: compare the well separated ones
     # column by column and everything through the projector
