@@ -91,7 +91,10 @@ const char* srx_last_error(const srx_ctx* ctx);
  * means (torch.distributed / MPI / a file), every rank calls srx_comm_init.  Afterwards
  * every per-gene reduction (moments, Z^T Y blocks, Gram matrices, the global cell count)
  * is summed across ranks with ONE ncclAllReduce(f64, sum) each over xGMI; per-cell results
- * stay local to the rank that owns the rows. */
+ * stay local to the rank that owns the rows.  Entry points whose answer would be the shard's own
+ * rather than the matrix's refuse a sharded context with SRX_E_ARG: srx_filter_cells /
+ * srx_filter_genes with a FlexValue::Relative limit (a quantile of all cells' / genes' sums) and
+ * srx_compute_min_max(Column); CSC handles are single-rank. */
 #define SRX_UNIQUE_ID_BYTES 128
 int32_t srx_comm_unique_id(void* id_out_128);
 int32_t srx_comm_init(srx_ctx* ctx, int32_t n_ranks, int32_t rank, const void* id_128);

@@ -217,6 +217,15 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// ---- roctx ranges (rocprofiler-sdk-roctx, dlopen()ed on first use; a no-op when the library is absent) --------------
+// One range per pipeline stage, so that a `rocprofv3 --marker-trace` timeline shows normalise / moments / select /
+// compact / gram / iterate / transform beside the kernels.
+struct Range {
+    bool on;
+    explicit Range(const char* name);
+    ~Range();
+};
+
 // ---- cross-rank sum (RCCL) --------------------------------------------------------------------
 // In-place f64 sum over all ranks on ctx->stream; no-op for a single rank.
 int32_t allreduce_f64(srx_ctx* ctx, double* d_buf, size_t count);

@@ -6,6 +6,8 @@
 // (nalgebra_sparse::CsrMatrix) happens once, here.
 #include "common.hpp"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <thread>
 
@@ -76,6 +78,42 @@ int32_t h2d(srx_ctx* ctx, void* dev, const void* host, size_t bytes) {
         SRX_TRY(parallel_h2d(ctx, host, dev, bytes, false, 1, 0, nullptr));
     }
     return SRX_OK;
+}
+
+// ---- roctx ---------------------------------------------------------------------------------------
+namespace {
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)(void);
+struct Roctx {
+    roctx_push_fn push = nullptr;
+    roctx_pop_fn pop = nullptr;
+    Roctx() {
+        if (getenv("SRX_NO_ROCTX")) return;
+        void* h = nullptr;
+        for (const char* n : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
+        if (!h) return;
+        push = (roctx_push_fn)dlsym(h, "roctxRangePushA");
+        pop = (roctx_pop_fn)dlsym(h, "roctxRangePop");
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+Roctx& roctx() {
+    static Roctx r;
+    return r;
+}
+}  // namespace
+Range::Range(const char* name) : on(false) {
+    Roctx& r = roctx();
+    if (r.push) {
+        r.push(name);
+        on = true;
+    }
+}
+Range::~Range() {
+    if (on) roctx().pop();
 }
 
 // ---- profiling -------------------------------------------------------------------------------
@@ -444,11 +482,15 @@ int32_t srx_ctx_create(int32_t device_id, srx_ctx** out) {
         return fail(nullptr, SRX_E_ARG, "device_id %d out of range [0,%d)", device_id, n);
     srx_ctx* ctx = new srx_ctx();
     ctx->device = device_id;
-    SRX_HIP(ctx, hipSetDevice(device_id));
     hipDeviceProp_t prop;
-    SRX_HIP(ctx, hipGetDeviceProperties(&prop, device_id));
+    e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;                                  // nothing else is owned yet
+        return fail(nullptr, SRX_E_HIP, "srx_ctx_create: %s", hipGetErrorString(e));
+    }
     ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    SRX_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     *out = ctx;
     return SRX_OK;
 }

@@ -144,6 +144,10 @@ static int32_t quantile_linear(srx_ctx* ctx, std::vector<double> v, double q, do
     const size_t n = v.size();
     if (n == 0) return fail(ctx, SRX_E_ARG, "Error calculating percentile: empty input");
     if (!(q >= 0.0 && q <= 1.0)) return fail(ctx, SRX_E_ARG, "Error calculating percentile: quantile %g outside [0, 1]", q);
+    // the reference wraps the sums in noisy_float's n64(), which panics on NaN (mod.rs:152-158); a NaN would also break
+    // the strict weak ordering nth_element relies on
+    for (double x : v)
+        if (x != x) return fail(ctx, SRX_E_NAN, "Error calculating percentile: NaN among the sums (n64() panics in the reference)");
     const double idx = q * (double)(n - 1);
     const size_t lo = (size_t)std::floor(idx), hi = (size_t)std::ceil(idx);
     std::nth_element(v.begin(), v.begin() + lo, v.end());
@@ -161,6 +165,11 @@ static int32_t filter_mask(srx_ctx* ctx, uint64_t n, const std::vector<uint32_t>
         return fail(ctx, SRX_E_ARG, "bad FlexValue kind");
     // calculate_percentiles (mod.rs:148-174): f64::MIN / f64::MAX when the limit is not Relative
     double lp = -std::numeric_limits<double>::max(), up = std::numeric_limits<double>::max();
+    // a quantile is a property of ALL cells / genes: on a row shard it would be the shard's own, a different threshold on
+    // every rank
+    if (ctx->n_ranks > 1 && (lower.kind == SRX_FLEX_RELATIVE || upper.kind == SRX_FLEX_RELATIVE))
+        return fail(ctx, SRX_E_ARG, "FlexValue::Relative needs the sums of the whole matrix: filter before sharding the rows "
+                                    "(or use Absolute limits) — this context holds rank %d of %d", ctx->rank, ctx->n_ranks);
     if (lower.kind == SRX_FLEX_RELATIVE) SRX_TRY(quantile_linear(ctx, sums, lower.relative, &lp));
     if (upper.kind == SRX_FLEX_RELATIVE) SRX_TRY(quantile_linear(ctx, sums, upper.relative, &up));
     mask.assign(n, 1);

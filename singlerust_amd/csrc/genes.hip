@@ -871,6 +871,11 @@ int32_t srx_compute_min_max(srx_mat* m, int32_t direction, double* mn, double* m
     direction = eff_dir(m, direction);           // csc.rs:186-212
     if (direction == SRX_ROW) return row_stat(m, 2, mn, mx);
     if (direction != SRX_COLUMN) return fail(ctx, SRX_E_ARG, "bad direction %d", direction);
+    // per-gene extrema of a row shard are the shard's own (the path has sum all-reduces only): refuse rather than
+    // return a different answer on every rank
+    if (ctx->n_ranks > 1)
+        return fail(ctx, SRX_E_ARG, "compute_min_max(Column) on a row-sharded context is shard-local: reduce the per-rank "
+                                    "results on the host (min of mins, max of maxs) — rank %d of %d", ctx->rank, ctx->n_ranks);
     SRX_TRY(ensure_tiles(m));
     const uint64_t G = m->n_cols;
     unsigned long long* d;

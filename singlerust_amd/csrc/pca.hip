@@ -2530,6 +2530,7 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const RowM
         double* Pk = gram_packed;
         const size_t n_packed = gram_packed_count(k);
         if (!Pk) {
+            Range r_("srx:gram");
             SRX_TRY(scratch(ctx, "pca_gpacked", n_packed * sizeof(double), (void**)&Pk));
             SRX_HIP(ctx, hipMemsetAsync(Pk, 0, n_packed * sizeof(double), ctx->stream));
             SRX_TRY(launch_gram<VT>(ctx, *rmp, Pk));
@@ -2559,6 +2560,7 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const RowM
             SRX_HIP(ctx, hipGetLastError());
             return SRX_OK;
         };
+        Range r_("srx:iterate");
         SRX_TRY(solve(apply, C, true, reset, deflate));
     } else {
         if (n_parts != 1) return fail(ctx, SRX_E_ARG, "pca: the SpMM solver needs the matrix resident in one piece");
@@ -2821,6 +2823,7 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     const double Nd = (double)Ng;
     HvgDev hv;
     if (dev_sel) {
+        Range r_("srx:select_hvg");
         SRX_TRY(select_hvg_device(m, hvg_n, o.center, o.scale, hv));
     } else {
         SRX_TRY(prepare_host_selection(m, selv, o, order, slot_of_sel, remap, mu, sd, dinv, trace));
@@ -2832,6 +2835,7 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     // general route through a row-major compacted CSR
     Tiled t256;
     RowMajor rm;
+    Range r_compact("srx:compact");
     if (dev_sel) {
         SRX_TRY(build_tiled_fused(m, hv.d_bits, hv.n_words, k, rm, t256, xf));
     } else if ((k + KG - 1) / KG <= kWave) {
@@ -3076,9 +3080,13 @@ int32_t srx_pipeline(srx_mat* m, double target_sum, uint64_t n_hvg, const srx_pc
     if (!m) return fail(nullptr, SRX_E_ARG, "null matrix");
     srx_ctx* ctx = m->ctx;
     SRX_HIP(ctx, hipSetDevice(ctx->device));
-    hipEvent_t ev[5];
-    for (auto& e : ev) SRX_HIP(ctx, hipEventCreate(&e));
-    auto cleanup = [&]() { for (auto& e : ev) (void)hipEventDestroy(e); };
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    auto cleanup = [&]() { for (auto& e : ev) if (e) (void)hipEventDestroy(e); };
+    for (auto& e : ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            cleanup();
+            return fail(ctx, SRX_E_HIP, "srx_pipeline: hipEventCreate failed");
+        }
     int32_t rc = SRX_OK;
     (void)hipEventRecord(ev[0], ctx->stream);
     // normalize_total_inplace(target, Row) + log1p_transform_inplace.  CSR: the passes that follow read the RAW matrix
@@ -3088,6 +3096,8 @@ int32_t srx_pipeline(srx_mat* m, double target_sum, uint64_t n_hvg, const srx_pc
     const uint64_t take = n_hvg < m->n_cols ? n_hvg : m->n_cols;
     const bool lazy = !m->csc && !getenv("SRX_NO_LAZY");
     RowXf xf;
+    {
+    Range r_("srx:normalize");
     if (m->csc) rc = srx_normalize_log1p_inplace(m, target_sum, nullptr);
     else if (!lazy) rc = launch_normalize(m, target_sum, true, true);
     else {
@@ -3097,9 +3107,11 @@ int32_t srx_pipeline(srx_mat* m, double target_sum, uint64_t n_hvg, const srx_pc
         m->lazy_pending = true;
         m->lazy_target = target_sum;
     }
+    }
     (void)hipEventRecord(ev[1], ctx->stream);
     // per-gene moments of the transformed values (one pass, all-reduced across shards)
     if (rc == SRX_OK && !m->csc) {
+        Range r_("srx:gene_moments");
         if (lazy) {
             rc = ensure_moments_xf(m, xf);
             m->moments_version = m->version;          // what pca_device's ensure_moments looks at
@@ -3121,7 +3133,10 @@ int32_t srx_pipeline(srx_mat* m, double target_sum, uint64_t n_hvg, const srx_pc
         if (rc == SRX_OK) rc = select_hvg_host(ctx, var, n_hvg, sel);
     }
     (void)hipEventRecord(ev[3], ctx->stream);
-    if (rc == SRX_OK) rc = dev_sel ? pca_device(m, nullptr, 0, opts, n_hvg, xf) : pca_device(m, sel.data(), sel.size(), opts, 0, xf);
+    if (rc == SRX_OK) {
+        Range r_("srx:pca");
+        rc = dev_sel ? pca_device(m, nullptr, 0, opts, n_hvg, xf) : pca_device(m, sel.data(), sel.size(), opts, 0, xf);
+    }
     // whatever happened above, X ends up normalised and log1p'd (the two in-place calls come first in the reference)
     ctx->wb_after_gram = nullptr;
     if (m->lazy_pending) {

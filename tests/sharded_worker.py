@@ -38,6 +38,14 @@ def main():
         res["num_col"] = st.compute_number(a, sr.Direction.Column)
         res["sum_col"] = st.compute_sum(a, sr.Direction.Column)
         res["sum_row"] = st.compute_sum(a, sr.Direction.Row)
+        # entry points whose answer would be this shard's own refuse a sharded context (srx.h, "row sharding")
+        shard_local = []
+        mn, mx = np.zeros(g), np.zeros(g)
+        shard_local.append(lib.srx_compute_min_max(a.x().handle, 1, F.ptr(mn), F.ptr(mx)))
+        out_h = C.c_void_p()
+        shard_local.append(lib.srx_filter_cells(a.x().handle, F.Flex(F.FLEX_RELATIVE, 0, 0.1), F.Flex(F.FLEX_NONE, 0, 0.0),
+                                                C.byref(out_h), None))
+        res["shard_local_rc"] = np.array(shard_local)
         pr = F.PipelineResult()
         F.check(lib.srx_pipeline(a.x().handle, 1e4, n_hvg, C.byref(opts), C.byref(pr)), ctx.handle)
         k = int(pr.pca.k)

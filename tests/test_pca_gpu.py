@@ -617,3 +617,30 @@ def test_block_wider_than_numerical_rank(ctx, seed):
     cv = z.T @ (z @ comps)
     assert (np.linalg.norm(cv[:, live] - comps[:, live] * s2[live], axis=0) / s2[live]).max() < 1e-7
     assert np.abs(evr[~live]).max(initial=0.0) < 1e-9 and np.abs(scores - z @ comps).max() < 1e-7 * max(1.0, np.abs(scores).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("store", [1, 2])
+def test_run_to_run_determinism_of_integer_and_index_outputs(ctx, store):
+    """LDS atomics reorder floating-point sums, so the integer outputs (nnz counts, integer row / column sums
+    of counts) and everything the feature selection depends on must not depend on the order: two pipeline runs on the
+    same input give bit-equal counts, sums, per-gene moments (fixed-point sums), HVG list, mean and std."""
+    import singlerust_amd as sr
+    from singlerust_amd import _ffi
+    from singlerust_amd.memory import statistics as st
+    m, _ = synth_host(91, 9000, 5000, 0.05)
+    outs = []
+    for _ in range(3):
+        a = adata_of(m, ctx, store)
+        num = (st.compute_number(a, sr.Direction.Row), st.compute_number(a, sr.Direction.Column))
+        sums = (st.compute_sum(a, sr.Direction.Row), st.compute_sum(a, sr.Direction.Column))
+        opts = _ffi.PcaOpts(10, -1, -1, -1, 0, 0, 0, 0.0, 3)
+        res = _ffi.PipelineResult()
+        _ffi.check(_ffi.lib().srx_pipeline(a.x().handle, 1e4, 500, C.byref(opts), C.byref(res)), ctx.handle)
+        mean, std, hv = np.zeros(500), np.zeros(500), np.zeros(500, np.uint64)
+        _ffi.check(_ffi.lib().srx_result_fetch(a.x().handle, None, None, None, _ffi.ptr(mean), _ffi.ptr(std), _ffi.ptr(hv)),
+                   ctx.handle)
+        outs.append((num[0], num[1], sums[0], sums[1], hv, mean, std, a.x_values()))
+    for o in outs[1:]:
+        for x, y in zip(outs[0], o):
+            assert np.array_equal(x, y)

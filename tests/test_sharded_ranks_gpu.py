@@ -60,6 +60,8 @@ def test_row_sharded_ranks_match_single_rank(ctx, tmp_path, world, solver):
             assert col_err(r["comps"], comps) < TOL
             if mode == "resident":
                 assert np.array_equal(r["num_col"], num_col) and np.array_equal(r["sum_col"], sum_col)
+                # compute_min_max(Column) and a Relative filter would be the shard's own answer: refused
+                assert list(r["shard_local_rc"]) == [F.E_ARG, F.E_ARG]
         assert np.array_equal(np.concatenate([r["sum_row"] for r in rs]), sum_row)
         got = np.concatenate([r["scores"] for r in rs], axis=0)     # per-cell quantities: the rank's own rows
         # every rank fixes the sign of a component the same way (it is decided on the replicated k x 64 block)
