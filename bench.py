@@ -5,12 +5,20 @@ HVG(2000) -> 50-PC PCA  on synthetic CSR resident in HBM, plus the SpMM's achiev
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one srx_pipeline() call over one fresh copy of the raw count matrix (the pipeline
-normalises X in place, so every step gets its own copy, cloned before the timed region).
-Workload at N=1: BASELINE.json configs[2], the configuration the north_star targets are
-quoted on (1.3M x 28k, ~3 % nnz — it fits one GPU); N>1: weak scaling, every rank owns a
-1.3M-cell row shard of an (N x 1.3M)-cell matrix, gene moments and the k x l blocks are
-all-reduced over RCCL.  One JSON line on rank 0.
+A "step" is one srx_pipeline() call over one fresh copy of the raw count matrix (the pipeline normalises X in place,
+so every step gets its own copy, cloned — with its pattern-only index structures and its reserved result block —
+before the timed region: a step makes no device allocation).
+
+N = 1: BASELINE.json configs[2], the configuration the north_star targets are quoted on (1.3M x 28k, ~3 % nnz; it
+fits one GPU).  N > 1: configs[3] read literally — the SAME 1.3M cells row-sharded over the N GPUs (strong scaling,
+nnz-balanced shards, RCCL all-reduce of the gene moments and of the packed Gram triangle); a `weak` block (1.3M cells
+per GPU) is measured after it with fewer steps.
+
+One JSON line on rank 0.  Besides the contract's fields it carries (N = 1 only, each a short bounded run after the
+timed region): the f64-storage pipeline (`f64_storage`), the matrix-free solver's SpMM kernels (`roofline_spmm_iter`),
+a skewed-gene matrix (`skewed_genes`), a hard spectrum (`hard_spectrum`), the rate including the upload of a host CSR
+and the download of the scores (`incl_h2d`), and two CPU baselines timed on this box (`cpu_baseline`: the
+reference-faithful serial restatement; `cpu_baseline_threaded`: the OpenMP variant with the cheaper k x k PCA).
 """
 from __future__ import annotations
 
@@ -25,53 +33,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CONFIGS = {
-    # name: (cells per GPU, genes, density, seed)       SURVEY.md §8 table
+    # name: (cells, genes, density, seed)       SURVEY.md §8 table
     "c2": (100_000, 20_000, 0.05, 2002),
     "c3": (1_300_000, 28_000, 0.03, 3003),
-    # config 5's total size on ONE GPU (48 GB of CSR in HBM: no out-of-core tiling needed on 288 GB); a
-    # large-offset (nnz > 2^32) correctness / scale check, not the headline
+    # config 5's total size on ONE GPU (48 GB of CSR in HBM: no out-of-core tiling needed on 288 GB); `--backed`
+    # streams it as row tiles from pinned host memory instead (configs[4] as specified)
     "c5": (10_000_000, 30_000, 0.02, 5005),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
-
-KERNEL_SYMBOL = {"normalize_log1p": "k_row_pass<float,NORM,LOG>", "gene_moments": "k_gene_moments<float>",
+KERNEL_SYMBOL = {"normalize_log1p": "k_row_pass<float,NORM,LOG> (in-place write-back, side stream)",
+                 "row_sums": "k_row_sum<float>", "gene_moments": "k_gene_moments<float,u16,XF>",
+                 "select": "k_gene_var + k_hvg_rank + k_hvg_take + k_sel_finish",
                  "hvg_compact": "k_tcount + k_tfill (+ scans)", "spmm_fwd": "k_spmm_fwd (CSR x 64-col panel)",
-                 "spmm_t": "k_spmm_t", "gram_sparse": "k_gram_sparse<float> (+ k_gram_reduce)",
-                 "dense_apply": "k_dense_apply"}
+                 "spmm_t": "k_spmm_t", "gram_sparse": "k_gram_stripes<float> (+ k_bucket)",
+                 "iterate": "k x 64 subspace iteration (hipGraph replays)", "dense_apply": "k_dense_apply"}
 ROOF_NOTE = {
-    "gram_sparse": "algorithmic bytes = HVG-compacted matrix (8-byte records + tile row pointers) read once + G "
-                   "written once. Not an HBM-bound kernel: one f64 LDS atomic per product (3.4e9 per launch at c3) "
-                   "plus two staged LDS reads and ~16 VALU instructions per 64-lane pass; the LDS pipe and VALU issue "
-                   "are each 50-65 % busy (profiles/r01_pmc_gram_v3.md), random-address f64 LDS atomics alone would "
-                   "take 2.2 ms at the 2.5 lanes/clk/CU measured by bench_micro/lds_atomic_banks.hip",
+    "gram_sparse": "algorithmic bytes = the row-major HVG-compacted matrix (8-byte records) and the 8-byte owner records read "
+                   "once + the packed upper triangle of G written once.  Not an HBM-bound kernel: N m(m+1)/2 = 3.4e9 scalar "
+                   "products per launch at c3, each one lane of an f64 LDS atomic (LDS pipe 59 % busy, 14 clk per 36-lane "
+                   "instruction) fed by one gathered 8-byte operand (every row suffix is re-read once per kept entry of its "
+                   "row: 27 GB of L2 requests, 58 % L2 hits with the chunked dispatch order) — profiles/r02_pmc_gram.md",
     "spmm_fwd": "algorithmic bytes per SURVEY.md 8(d): nnz_w*(4+4) + (n_t*N+1)*8 + k*64*4 + the output, which for this "
                 "launch (the transform) is the N x n_pc f64 score matrix written by the SpMM itself",
 }
-
-
-def load_traffic(config):
-    """HBM bytes per pipeline step from the committed PMC passes (profiles/make_traffic.py), per bench kernel class."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_traffic_{config}.json")
-    try:
-        with open(path) as fh:
-            t = json.load(fh)["kernels"]
-    except (OSError, ValueError, KeyError):
-        return {}
-    cls = {"normalize_log1p": ("k_row_pass",), "gene_moments": ("k_gene_moments",), "spmm_fwd": ("k_spmm_fwd",),
-           "spmm_t": ("k_spmm_t",), "gram_sparse": ("k_gram_sparse", "k_gram_reduce"),
-           "dense_apply": ("k_dense_apply",),
-           "hvg_compact": ("k_tcount", "k_tfill", "k_scan_block_sums", "k_scan_serial", "k_scan_apply", "k_seglen")}
-    out = {}
-    for name, subs in cls.items():
-        tot, hit = 0.0, False
-        for sym, d in t.items():
-            if any(sym.startswith(s_) or (" " + s_) in sym or ("srx::" + s_) in sym for s_ in subs):
-                tot += d["hbm_bytes"] * d["launches_per_step"]      # bytes per pipeline step
-                hit = True
-        if hit:
-            out[name] = tot
-    return out
 
 
 def parse():
@@ -80,91 +65,111 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-    ap.add_argument("--cells", type=int, default=0, help="override cells per GPU")
-    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
-                    help="weak (default): the config's cell count PER GPU; strong: the config's cell count in total, "
-                         "row-sharded over the GPUs (BASELINE.json configs[3] read literally)")
+    ap.add_argument("--cells", type=int, default=0, help="override the config's cell count")
+    ap.add_argument("--scaling", default="auto", choices=("auto", "weak", "strong"),
+                    help="N > 1: strong (default; the config's cells in total, row-sharded = BASELINE.json configs[3]) "
+                         "or weak (the config's cells PER GPU)")
     ap.add_argument("--hvg", type=int, default=2000)
     ap.add_argument("--npc", type=int, default=50)
     ap.add_argument("--target-sum", type=float, default=1e4)
     ap.add_argument("--solver", type=int, default=0, help="0 auto, 1 explicit Gram, 2 matrix-free SpMM iteration")
     ap.add_argument("--storage", default="f32", choices=("f32", "f64"),
-                    help="value storage in HBM: f32 (default; exact for count data, meets the 1e-5 bar) or f64")
+                    help="value storage in HBM of the headline run: f32 (default; exact for count data, HighlyVariable(n) "
+                         "ranked on f64 moments) or f64")
+    ap.add_argument("--skew", type=int, default=0, help="1: the quadratic gene-density map of the generator (srx_synth.h)")
+    ap.add_argument("--backed", action="store_true",
+                    help="out-of-core form (configs[4]): the matrix stays in pinned host memory and is streamed as row tiles "
+                         "through the srx_backed_* session, two sweeps; reports H2D-bound cells/s")
+    ap.add_argument("--tile-rows", type=int, default=250_000, help="--backed: cells per streamed tile")
+    ap.add_argument("--lean", action="store_true", help="only the headline measurement (no extra blocks, no CPU baselines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-cells", type=int, default=24000)
+    ap.add_argument("--cpu-sample-cells", type=int, default=24000, help="reference-faithful CPU baseline: cells of the sample")
+    ap.add_argument("--host-sample-cells", type=int, default=100_000,
+                    help="cells of the host-side sample (incl_h2d block, threaded CPU baseline)")
     ap.add_argument("--max-copies-gb", type=float, default=180.0)
     return ap.parse_args()
 
 
-def cpu_baseline(F, params, genes, n_cells, hvg, npc, target):
-    """The oracle (a port of the reference's serial loops + exact-SVD PCA) timed on this box's
-    host cores over a bounded sample of the SAME synthetic workload (first n_cells rows)."""
-    import numpy as np
-    import oracle
-    from oracle import pca_oracle
-    lib = F.lib()
-    ip = np.zeros(n_cells + 1, dtype=np.uint64)
-    lib.srx_synth_indptr(C.byref(params), 0, n_cells, F.ptr(ip))
-    idx = np.zeros(int(ip[-1]), np.uint64)
-    val = np.zeros(int(ip[-1]), np.float32)
-    lib.srx_synth_fill_host(C.byref(params), 0, n_cells, F.ptr(ip), F.ptr(idx), F.ptr(val))
-    m = oracle.Csr(n_cells, genes, ip, idx, val)
-    oracle.lib()
-    t0 = time.perf_counter()
-    n = oracle.normalize_total(m, target, oracle.ROW)
-    lg = oracle.log1p_transform(n)
-    t1 = time.perf_counter()
-    sel = pca_oracle.select_features_hvg(lg, hvg)
-    t2 = time.perf_counter()
-    pca_oracle.pca_inplace(lg, npc, None, None, sel)
-    t3 = time.perf_counter()
-    total = t3 - t0
-    return {
-        "value": n_cells / total, "unit": "cells/s", "cores": os.cpu_count(), "kind": "port",
-        "sample": f"first {n_cells} cells of the same synthetic matrix ({int(ip[-1])} nnz): serial C restatement of "
-                  f"normalize_total+log1p ({t1 - t0:.2f}s) and nz-variance HVG({hvg}) ({t2 - t1:.2f}s) on 1 core, "
-                  f"densify + full-SVD PCA via numpy/LAPACK on all cores ({t3 - t2:.2f}s); "
-                  "exact-SVD cost is linear in cells at fixed k, so cells/s carries to the full size",
-        "seconds": total,
-    }
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N with N > 1 must be launched through torch.distributed.run (one rank per GPU)")
-        a.gpus = world
-    import numpy as np
-    import singlerust_amd as sr
-    from singlerust_amd import _ffi as F
-    lib = F.lib()
+def usable_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
 
-    # One process per GPU.  The handshake (128-byte RCCL id, barriers, max over ranks) uses a
-    # stdlib socket star, not torch.distributed: the torch wheel bundles its own HIP runtime and RCCL,
-    # and once it is imported into this process ncclCommInitRank of the system RCCL that
-    # libsrx_hip.so uses fails; nothing on the data path needs torch.  Device synchronisation goes
-    # through the library (hipStreamSynchronize on the stream every kernel of the path runs on).
-    # SRX_BENCH_DEVICE: development override (several ranks on one GPU to exercise the N > 1 path on a 1-GPU box)
-    ctx = sr.Context(int(os.environ.get("SRX_BENCH_DEVICE", local_rank)))
-    from singlerust_amd.rendezvous import StarGroup
-    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # under torch.distributed.run
-    group = StarGroup(rank, world)
-    dist = group if (world > 1 or launched) else None
-    json_fd = None
-    if dist is not None:
+
+def load_traffic(config):
+    """HBM bytes per pipeline step from the committed PMC passes (profiles/make_traffic.py), per bench kernel class."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{config}.json")
+        try:
+            with open(path) as fh:
+                t = json.load(fh)["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+        cls = {"normalize_log1p": ("k_row_pass",), "row_sums": ("k_row_sum",), "gene_moments": ("k_gene_moments",),
+               "spmm_fwd": ("k_spmm_fwd",), "spmm_t": ("k_spmm_t",),
+               "gram_sparse": ("k_gram_stripes", "k_bucket", "k_gram_sparse", "k_gram_reduce"),
+               "dense_apply": ("k_dense_apply",),
+               "hvg_compact": ("k_tcount", "k_tfill", "k_scan_block_sums", "k_scan_serial", "k_scan_apply", "k_seglen")}
+        out = {}
+        for name, subs in cls.items():
+            tot, hit = 0.0, False
+            for sym, d in t.items():
+                if any(sym.startswith(s_) or (" " + s_) in sym or ("srx::" + s_) in sym for s_ in subs):
+                    tot += d["hbm_bytes"] * d["launches_per_step"]      # bytes per pipeline step
+                    hit = True
+            if hit:
+                out[name] = tot
+        return out, rnd
+    return {}, None
+
+
+class Bench:
+    """One context, its rendezvous group, and the workload runner."""
+
+    def __init__(self, a):
+        import singlerust_amd as sr
+        from singlerust_amd import _ffi as F
+        self.a, self.sr, self.F = a, sr, F
+        self.lib = F.lib()
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        # One process per GPU.  The handshake (128-byte RCCL id, barriers, max over ranks) uses a stdlib socket star,
+        # not torch.distributed: the torch wheel bundles its own HIP runtime and RCCL, and once it is imported into
+        # this process ncclCommInitRank of the system RCCL that libsrx_hip.so uses fails; nothing on the data path
+        # needs torch.  SRX_BENCH_DEVICE: development override (several ranks on one GPU)
+        self.ctx = sr.Context(int(os.environ.get("SRX_BENCH_DEVICE", self.local_rank)))
+        from singlerust_amd.rendezvous import StarGroup
+        launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # under torch.distributed.run
+        self.group = StarGroup(self.rank, self.world)
+        self.dist = self.group if (self.world > 1 or launched) else None
+        self.json_fd = None
+        self.collective = None
+        if self.dist is not None:
+            self._comm_init()
+
+    def _comm_init(self):
+        F, sr, group, ctx, rank, world = self.F, self.sr, self.group, self.ctx, self.rank, self.world
         # RCCL prints a version banner on stdout at init: keep stdout clean for the one JSON line
         sys.stdout.flush()
         saved = os.dup(1)
         os.dup2(2, 1)
         collective, comm_err = "rccl", ""
         try:
-            # every rank goes through the same sequence whatever fails where (a rank that raised early
-            # would leave the others waiting in the star): id (zeros = rank 0 could not make one) ->
-            # init -> agreement on the outcome
+            # every rank goes through the same sequence whatever fails where (a rank that raised early would leave the
+            # others waiting in the star): id (zeros = rank 0 could not make one) -> init -> agreement on the outcome
             uid = None
             if rank == 0:
                 try:
@@ -179,167 +184,507 @@ def main():
                 except Exception as e:          # noqa: BLE001
                     ok, comm_err = False, str(e)
             if group.allreduce_max(0.0 if ok else 1.0) > 0.0:
-                # RCCL could not be brought up on some rank (or SRX_BENCH_COLLECTIVE=host): the sums over ranks
-                # go through the host transport hook of the C-ABI (srx_comm_init_host) over the rendezvous
-                # sockets instead.  Same arithmetic, slower exchange; the JSON line says which one ran.
-                F.check(lib.srx_comm_destroy(ctx.handle), ctx.handle)
+                # RCCL could not be brought up on some rank (or SRX_BENCH_COLLECTIVE=host): the sums over ranks go
+                # through the host transport hook of the C-ABI (srx_comm_init_host) over the rendezvous sockets.
+                # Same arithmetic, slower exchange; the JSON line says which one ran.
+                F.check(self.lib.srx_comm_destroy(ctx.handle), ctx.handle)
                 ctx.comm_init_host(world, rank, group.allreduce_sum_f64)
                 collective = "host-star"
                 print(f"[bench rank {rank}] RCCL unavailable ({comm_err or 'see other ranks'}): host all-reduce", file=sys.stderr)
         finally:
             # fd 1 stays on stderr for the rest of a multi-rank run (RCCL may warn on stdout at any collective); the one
             # JSON line goes to the saved descriptor at the end
-            json_fd = saved
+            self.json_fd = saved
+        self.collective = collective
 
-    cells, genes, density, seed = CONFIGS[a.config]
-    if a.cells:
-        cells = a.cells
-    if a.scaling == "strong":
-        cells = (cells + world - 1) // world
-    n_global = cells * world
-    params = F.SynthParams()
-    lib.srx_synth_defaults(C.byref(params), seed, n_global, genes, density)
-    row0, row1 = rank * cells, (rank + 1) * cells
+    def sync_all(self):
+        self.ctx.synchronize()               # every kernel of the path runs on this context's streams (the pipeline joins them)
+        if self.dist is not None:
+            self.dist.barrier()
 
-    t_gen = time.perf_counter()
-    h = C.c_void_p()
-    f64 = a.storage == "f64"
-    F.check(lib.srx_synth_generate(ctx.handle, C.byref(params), row0, row1, F.F64 if f64 else F.F32,
-                                   F.STORE_F64 if f64 else F.STORE_F32, C.byref(h)), ctx.handle)
-    pristine = sr.DeviceCsr(ctx, h)
-    pristine.prepare()          # pattern-only row/gene-tile cuts: part of the resident layout, like indptr
-    pristine.reserve_results(a.hvg, a.npc)      # output block (scores + small results): clones get their own, before the clock
-    info = pristine.info()
-    nnz = int(info.nnz)
-    t_gen = time.perf_counter() - t_gen
-    bytes_per_copy = nnz * (12 if f64 else 8) + (cells + 1) * 8
-    n_steps_total = a.warmup + a.steps
-    max_copies = max(1, int(a.max_copies_gb * 1e9 // bytes_per_copy) - 1)
-    n_copies = min(n_steps_total, max_copies)
-    copies = [pristine.clone() for _ in range(n_copies)]
-    ctx.synchronize()
+    def params(self, config, n_global, skew=0):
+        _, genes, density, seed = CONFIGS[config]
+        p = self.F.SynthParams()
+        self.lib.srx_synth_defaults(C.byref(p), seed, n_global, genes, density)
+        p.skew = skew
+        return p
 
-    opts = F.PcaOpts(a.npc, -1, -1, -1, 0, 0, a.solver, 0.0, 12345)
-    res = F.PipelineResult()
+    def shard(self, p, n_global):
+        """This rank's row range: nnz-balanced contiguous cut of the global matrix (srx_partition_rows on the generator's
+        row offsets — 8 bytes per cell on the host, no values)."""
+        import numpy as np
+        if self.world == 1:
+            return 0, n_global
+        ip = np.zeros(n_global + 1, dtype=np.uint64)
+        self.lib.srx_synth_indptr(C.byref(p), 0, n_global, self.F.ptr(ip))
+        cut = np.zeros(self.world + 1, dtype=np.uint64)
+        self.F.check(self.lib.srx_partition_rows(self.F.ptr(ip), n_global, self.world, self.F.ptr(cut)))
+        return int(cut[self.rank]), int(cut[self.rank + 1])
 
-    def step(mat):
-        F.check(lib.srx_pipeline(mat.handle, a.target_sum, a.hvg, C.byref(opts), C.byref(res)), ctx.handle)
+    def run(self, config, n_global, row0, row1, storage, steps, warmup, solver=0, hvg=None, skew=0, tolerate_noconv=False):
+        """K timed pipeline steps on rows [row0, row1) of the synthetic matrix; returns the measurements of this rank
+        (times already maxed over ranks)."""
+        a, F, sr, lib, ctx = self.a, self.F, self.sr, self.lib, self.ctx
+        hvg = hvg or a.hvg
+        p = self.params(config, n_global, skew)
+        f64 = storage == "f64"
+        t_gen = time.perf_counter()
+        h = C.c_void_p()
+        F.check(lib.srx_synth_generate(ctx.handle, C.byref(p), row0, row1, F.F64 if f64 else F.F32,
+                                       F.STORE_F64 if f64 else F.STORE_F32, C.byref(h)), ctx.handle)
+        pristine = sr.DeviceCsr(ctx, h)
+        pristine.prepare()          # pattern-only structures (gene-tile cuts, 16-bit index mirror, per-gene counts): part of the resident layout
+        pristine.reserve_results(hvg, a.npc)      # output block (scores + small results): clones get their own, before the clock
+        info = pristine.info()
+        nnz = int(info.nnz)
+        ctx.synchronize()
+        t_gen = time.perf_counter() - t_gen
+        bytes_per_copy = nnz * (12 if f64 else 8) + (row1 - row0 + 1) * 8 + (row1 - row0) * a.npc * 8
+        n_total = warmup + steps
+        max_copies = max(1, int(a.max_copies_gb * 1e9 // max(bytes_per_copy, 1)) - 1)
+        n_copies = min(n_total, max_copies)
+        copies = [pristine.clone() for _ in range(n_copies)]
+        ctx.synchronize()
+        opts = F.PcaOpts(a.npc, -1, -1, -1, 0, 0, solver, 0.0, 12345)
+        res = F.PipelineResult()
+        failures = []
 
-    def sync_all():
-        ctx.synchronize()               # every kernel of the path runs on this context's stream
-        if dist is not None:
-            dist.barrier()
+        def step(mat):
+            rc = lib.srx_pipeline(mat.handle, a.target_sum, hvg, C.byref(opts), C.byref(res))
+            if rc == F.E_NOCONV and tolerate_noconv:
+                failures.append(rc)
+                return
+            F.check(rc, ctx.handle)
 
-    # warmup (untimed)
-    used = 0
-    for _ in range(a.warmup):
-        step(copies[used]); used += 1
-    # timed: chunks of fresh copies; restoring copies from the pristine matrix is outside the clock
-    prof_mask = sum(1 << c for c in (F.K_NORMALIZE, F.K_MOMENTS, F.K_COMPACT, F.K_SPMM_FWD, F.K_SPMM_T, F.K_GRAM, F.K_DENSE, F.K_ROWSUM))
-    ctx.prof_enable(prof_mask)
-    ctx.prof_reset()
-    elapsed = 0.0
-    done = 0
-    stage = {"normalize": 0.0, "moments": 0.0, "select": 0.0, "pca": 0.0}
-    iters = []
-    while done < a.steps:
+        used = 0
+        for _ in range(warmup):
+            step(copies[used % n_copies]); used += 1
+            if used % n_copies == 0 and used < warmup:
+                for c in copies:
+                    c.copy_values_from(pristine)
         if used >= n_copies:
             for c in copies:
                 c.copy_values_from(pristine)
             used = 0
-        chunk = min(a.steps - done, n_copies - used)
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(chunk):
-            ts = time.perf_counter()
-            step(copies[used]); used += 1
-            if os.environ.get("SRX_BENCH_TRACE"):
-                print(f"[bench] step {done} copy {used - 1}: {(time.perf_counter() - ts) * 1e3:.2f} ms host, pca stage {res.ms_pca:.2f} ms",
-                      file=sys.stderr)
-            stage["normalize"] += res.ms_normalize; stage["moments"] += res.ms_moments
-            stage["select"] += res.ms_select; stage["pca"] += res.ms_pca
-            iters.append(int(res.pca.n_iter))
-        sync_all()
-        elapsed += time.perf_counter() - t0
-        done += chunk
-    if dist is not None:
-        elapsed = dist.allreduce_max(elapsed)
+        classes = {F.K_NORMALIZE: "normalize_log1p", F.K_ROWSUM: "row_sums", F.K_MOMENTS: "gene_moments", F.K_SELECT: "select",
+                   F.K_COMPACT: "hvg_compact", F.K_GRAM: "gram_sparse", F.K_ITERATE: "iterate", F.K_DENSE: "dense_apply",
+                   F.K_SPMM_FWD: "spmm_fwd", F.K_SPMM_T: "spmm_t"}
+        ctx.prof_enable(sum(1 << c for c in classes))
+        ctx.prof_reset()
+        elapsed, done = 0.0, 0
+        stage = {"normalize": 0.0, "moments": 0.0, "select": 0.0, "pca": 0.0}
+        iters = []
+        while done < steps:
+            if used >= n_copies:            # restoring copies from the pristine matrix is outside the clock
+                for c in copies:
+                    c.copy_values_from(pristine)
+                used = 0
+            chunk = min(steps - done, n_copies - used)
+            self.sync_all()
+            t0 = time.perf_counter()
+            for _ in range(chunk):
+                ts = time.perf_counter()
+                step(copies[used]); used += 1
+                if os.environ.get("SRX_BENCH_TRACE"):
+                    print(f"[bench] step {done} copy {used - 1}: {(time.perf_counter() - ts) * 1e3:.2f} ms host, "
+                          f"pca stage {res.ms_pca:.2f} ms", file=sys.stderr)
+                stage["normalize"] += res.ms_normalize; stage["moments"] += res.ms_moments
+                stage["select"] += res.ms_select; stage["pca"] += res.ms_pca
+                iters.append(int(res.pca.n_iter))
+            self.sync_all()
+            elapsed += time.perf_counter() - t0
+            done += chunk
+        if self.dist is not None:
+            elapsed = self.dist.allreduce_max(elapsed)
+        prof = {}
+        for cls_, name in classes.items():
+            ms, n, b = ctx.prof_get(cls_)
+            if n:
+                prof[name] = {"launches": n, "avg_ms": ms / n, "alg_bytes_per_launch": b / n,
+                              "GBps": (b / n) / (ms / n * 1e-3) / 1e9 if ms > 0 else None,
+                              "frac_of_peak": (b / n) / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None}
+        ctx.prof_enable(0)
+        out = {"elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "nnz": nnz, "prof": prof,
+               "stage_ms_per_step": {k_: v / steps for k_, v in stage.items()}, "iters": iters,
+               "residual": float(res.pca.residual), "nnz_selected": int(res.pca.nnz_selected),
+               "solver": {1: "gram", 2: "spmm"}.get(int(res.pca.solver), "?"), "generate_s": t_gen, "copies": n_copies,
+               "noconv_steps": len(failures), "genes": int(info.n_cols)}
+        for c in copies:
+            c.free()
+        pristine.free()
+        return out
 
-    prof = {}
-    names = {F.K_NORMALIZE: "normalize_log1p", F.K_MOMENTS: "gene_moments", F.K_COMPACT: "hvg_compact",
-             F.K_SPMM_FWD: "spmm_fwd", F.K_SPMM_T: "spmm_t", F.K_GRAM: "gram_sparse", F.K_DENSE: "dense_apply",
-             F.K_ROWSUM: "row_sums"}
-    for cls_, name in names.items():
-        ms, n, b = ctx.prof_get(cls_)
-        if n:
-            prof[name] = {"launches": n, "avg_ms": ms / n, "alg_bytes_per_launch": b / n,
-                          "GBps": (b / n) / (ms / n * 1e-3) / 1e9 if ms > 0 else None,
-                          "frac_of_peak": (b / n) / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None}
-    ctx.prof_enable(0)
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.close()
+        self.ctx.close()
+
+
+def attributed(prof, steps):
+    """ms per step inside the bracketed kernel classes that are NOT overlapped (the in-place write-back runs on the side
+    stream beside the iteration: reported, not added; dense_apply sits inside `iterate`)."""
+    per = {k_: v["avg_ms"] * v["launches"] / steps for k_, v in prof.items()}
+    serial = sum(per.get(k_, 0.0) for k_ in ("row_sums", "gene_moments", "select", "hvg_compact", "gram_sparse", "iterate", "spmm_fwd", "spmm_t"))
+    return per, serial
+
+
+def roof(d, kernel, note):
+    return {"bound": "hbm", "kernel": kernel, "achieved": d.get("GBps"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": d.get("frac_of_peak"), "traffic": d.get("hbm_traffic_per_launch"), "launches": d.get("launches"),
+            "avg_ms": d.get("avg_ms"), "alg_bytes_per_launch": d.get("alg_bytes_per_launch"), "note": note}
+
+
+def host_sample(B, config, n_cells):
+    """First n_cells rows of the synthetic matrix in the REFERENCE layout on the host (u64 offsets / indices, f32 values)."""
+    import numpy as np
+    F, lib = B.F, B.lib
+    cells, genes, _, _ = CONFIGS[config]
+    p = B.params(config, B.a.cells or cells)
+    ip = np.zeros(n_cells + 1, dtype=np.uint64)
+    lib.srx_synth_indptr(C.byref(p), 0, n_cells, F.ptr(ip))
+    idx = np.zeros(int(ip[-1]), np.uint64)
+    val = np.zeros(int(ip[-1]), np.float32)
+    lib.srx_synth_fill_host(C.byref(p), 0, n_cells, F.ptr(ip), F.ptr(idx), F.ptr(val))
+    return ip, idx, val, genes
+
+
+def incl_h2d(B, ip, idx, val, genes):
+    """The rate a caller sees who hands over HOST buffers for every pipeline: upload of the reference-layout CSR (u64
+    indices narrowed on the way), the pipeline, download of the f64 scores."""
+    import numpy as np
+    a, F, sr, lib, ctx = B.a, B.F, B.sr, B.lib, B.ctx
+    n = len(ip) - 1
+    opts = F.PcaOpts(a.npc, -1, -1, -1, 0, 0, 0, 0.0, 12345)
+    res = F.PipelineResult()
+    scores = np.zeros((n, a.npc))
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        m = sr.DeviceCsr.upload(ctx, n, genes, ip, idx, val, F.STORE_F32)
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        F.check(lib.srx_pipeline(m.handle, a.target_sum, a.hvg, C.byref(opts), C.byref(res)), ctx.handle)
+        ctx.synchronize()
+        t2 = time.perf_counter()
+        F.check(lib.srx_result_fetch(m.handle, F.ptr(scores), None, None, None, None, None), ctx.handle)
+        t3 = time.perf_counter()
+        m.free()
+        cur = (t3 - t0, t1 - t0, t2 - t1, t3 - t2)
+        if best is None or cur[0] < best[0]:
+            best = cur
+    host_bytes = ip.nbytes + idx.nbytes + val.nbytes
+    return {"cells": n, "host_bytes": host_bytes, "upload_s": best[1], "pipeline_s": best[2], "d2h_scores_s": best[3],
+            "value": n / best[0], "unit": "cells/s", "upload_GBps_of_host_bytes": host_bytes / best[1] / 1e9,
+            "note": "best of 3: srx_matrix_upload of the reference-layout host CSR (u64 offsets / indices, f32 values; pageable "
+                    "memory, 8 H2D workers) + srx_pipeline (first call on the handle: it also builds the pattern-only "
+                    "structures and allocates the result block) + srx_result_fetch of the f64 scores; the upload dominates — "
+                    "the drop-in uploads once and runs the whole path on the handle, a matrix larger than HBM goes through "
+                    "the backed session (--backed)"}
+
+
+def cpu_baselines(B, ip, idx, val, genes):
+    import numpy as np
+    import oracle
+    from oracle import pca_oracle
+    a = B.a
+    oracle.lib()
+    out = {}
+    model, cores = cpu_model(), usable_cores()
+    # (i) reference-faithful: the serial loops + densify + full-SVD PCA (numpy / LAPACK, all cores) on a bounded sample
+    n1 = min(a.cpu_sample_cells, len(ip) - 1)
+    e1 = int(ip[n1])
+    m1 = oracle.Csr(n1, genes, ip[:n1 + 1], idx[:e1], val[:e1])
+    t0 = time.perf_counter()
+    lg = oracle.log1p_transform(oracle.normalize_total(m1, a.target_sum, oracle.ROW))
+    t1 = time.perf_counter()
+    sel = pca_oracle.select_features_hvg(lg, a.hvg)
+    t2 = time.perf_counter()
+    pca_oracle.pca_inplace(lg, a.npc, None, None, sel)
+    t3 = time.perf_counter()
+    out["cpu_baseline"] = {
+        "value": n1 / (t3 - t0), "unit": "cells/s", "cores": cores, "kind": "port", "cpu_model": model,
+        "sample": f"first {n1} cells of the same synthetic matrix ({e1} nnz): serial C restatement of normalize_total + log1p "
+                  f"({t1 - t0:.2f} s) and nz-variance HVG({a.hvg}) ({t2 - t1:.2f} s) on 1 thread — the reference's loops are "
+                  f"serial —, densify + full-SVD PCA via numpy / LAPACK on the box's {cores} usable cores ({t3 - t2:.2f} s); "
+                  "the exact SVD is linear in cells at fixed k, so cells/s carries to the full size",
+        "seconds": t3 - t0}
+    # (ii) threaded: OpenMP over every loop + k x k covariance and a symmetric eigen-solve instead of the full SVD
+    n2 = len(ip) - 1
+    threads = max(1, min(cores, 64))
+    m2 = oracle.Csr(n2, genes, ip, idx, val)
+    t0 = time.perf_counter()
+    vals, hv, order, cov, mean, sd, secs = oracle.omp_pipeline(m2, a.target_sum, a.hvg, threads)
+    t1 = time.perf_counter()
+    import scipy.linalg as sla
+    k = cov.shape[0]
+    w, v = sla.eigh(cov, subset_by_index=[max(0, k - a.npc), k - 1])
+    t2 = time.perf_counter()
+    # scores = Z V for the sample: sparse x dense through scipy (threaded BLAS does not apply; counted as is)
+    import scipy.sparse as sp
+    x = sp.csr_matrix((vals, idx.astype(np.int64), ip.astype(np.int64)), shape=(n2, genes))[:, order.astype(np.int64)]
+    pv = v / sd[:, None]
+    _ = x @ pv - (mean / sd) @ v
+    t3 = time.perf_counter()
+    out["cpu_baseline_threaded"] = {
+        "value": n2 / (t3 - t0), "unit": "cells/s", "cores": threads, "kind": "port", "cpu_model": model,
+        "sample": f"first {n2} cells ({len(val)} nnz): oracle/omp_baseline.c on {threads} OpenMP threads — normalise + log1p "
+                  f"{secs[0]:.2f} s, moments + HVG {secs[1]:.2f} s, k x k Gram {secs[2]:.2f} s — then LAPACK eigh of the "
+                  f"{k} x {k} covariance (top {a.npc}) {t2 - t1:.2f} s and the scores {t3 - t2:.2f} s; SURVEY.md 8(d) variant "
+                  "(ii): algorithmically cheaper than the reference's full SVD, i.e. a baseline that favours the CPU",
+        "seconds": t3 - t0}
+    return out
+
+
+def backed_run(B):
+    """configs[4] as specified, on one GPU: the matrix lives in pinned host memory and goes through the backed session as
+    row tiles (two sweeps: statistics, then compaction + Gram), H2D overlapped with the kernels of the previous tile."""
+    import numpy as np
+    a, F, lib, ctx = B.a, B.F, B.lib, B.ctx
+    cells, genes, density, seed = CONFIGS[a.config]
+    if a.cells:
+        cells = a.cells
+    p = B.params(a.config, cells)
+    tile = a.tile_rows
+    t_gen = time.perf_counter()
+    ip = np.zeros(cells + 1, dtype=np.uint64)
+    lib.srx_synth_indptr(C.byref(p), 0, cells, F.ptr(ip))
+    nnz = int(ip[-1])
+    # pinned host memory for the two big arrays (the session's H2D workers copy straight out of it)
+    hidx, hval = C.c_void_p(), C.c_void_p()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+    pinned = hip.hipHostMalloc(C.byref(hidx), nnz * 8, 0) == 0 and hip.hipHostMalloc(C.byref(hval), nnz * 4, 0) == 0
+    if pinned:
+        idx = np.ctypeslib.as_array(C.cast(hidx, C.POINTER(C.c_uint64)), shape=(nnz,))
+        val = np.ctypeslib.as_array(C.cast(hval, C.POINTER(C.c_float)), shape=(nnz,))
+    else:
+        idx, val = np.zeros(nnz, np.uint64), np.zeros(nnz, np.float32)
+    # fill tile by tile (the host generator is serial per call: keep the calls bounded)
+    for r0 in range(0, cells, tile):
+        r1 = min(cells, r0 + tile)
+        e0, e1 = int(ip[r0]), int(ip[r1])
+        sub = (ip[r0:r1 + 1] - ip[r0]).astype(np.uint64)
+        lib.srx_synth_fill_host(C.byref(p), r0, r1, F.ptr(sub), F.ptr(idx[e0:e1]), F.ptr(val[e0:e1]))
+    t_gen = time.perf_counter() - t_gen
+    host_bytes = ip.nbytes + idx.nbytes + val.nbytes
+    opts = F.PcaOpts(a.npc, -1, -1, -1, 0, 0, 1, 0.0, 12345)
+    xf = F.BACKED_NORMALIZE | F.BACKED_LOG1P
+
+    def tiles():
+        for r0 in range(0, cells, tile):
+            r1 = min(cells, r0 + tile)
+            e0 = int(ip[r0])
+            yield F.Csr(r1 - r0, genes, int(ip[r1]) - e0, ip[r0:].ctypes.data, idx[e0:].ctypes.data, val[e0:].ctypes.data, F.F32)
+
+    runs = []
+    for _ in range(max(1, a.steps)):
+        h = C.c_void_p()
+        F.check(lib.srx_backed_create(ctx.handle, genes, F.STORE_F32, C.byref(h)), ctx.handle)
+        t0 = time.perf_counter()
+        for t in tiles():
+            F.check(lib.srx_backed_stats_tile(h, C.byref(t), a.target_sum, xf, None, None), ctx.handle)
+        t1 = time.perf_counter()
+        n_out = C.c_uint64()
+        sel = np.zeros(a.hvg, np.uint64)
+        F.check(lib.srx_backed_select(h, a.hvg, None, 0, C.byref(opts), F.ptr(sel), C.byref(n_out)), ctx.handle)
+        t2 = time.perf_counter()
+        for t in tiles():
+            F.check(lib.srx_backed_gram_tile(h, C.byref(t), a.target_sum, xf), ctx.handle)
+        t3 = time.perf_counter()
+        info = F.PcaInfo()
+        F.check(lib.srx_backed_solve(h, C.byref(info)), ctx.handle)
+        ctx.synchronize()
+        t4 = time.perf_counter()
+        lib.srx_backed_destroy(h)
+        runs.append({"total_s": t4 - t0, "sweep1_s": t1 - t0, "select_s": t2 - t1, "sweep2_s": t3 - t2, "solve_s": t4 - t3,
+                     "residual": float(info.residual), "iterations": int(info.n_iter)})
+    best = min(runs, key=lambda r: r["total_s"])
+    out = {
+        "metric": "cells/sec end-to-end normalise->HVG->50-PC PCA; SpMM achieved HBM GB/s vs peak",
+        "value": cells / best["total_s"], "unit": "cells/s", "n_gpus": 1, "steps": len(runs), "warmup": 0,
+        "ms_per_step": best["total_s"] * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{a.config} OUT OF CORE: {cells} cells x {genes} genes, density {density}, seed {seed}; the CSR "
+                               f"({host_bytes / 1e9:.1f} GB: u64 offsets / indices + f32 values) stays in "
+                               f"{'pinned' if pinned else 'pageable'} host memory and is streamed as {tile}-cell tiles "
+                               "through srx_backed_* (sweep 1: statistics; select; sweep 2: compaction + Gram; solve)",
+                   "cells_global": cells, "genes": genes, "nnz": nnz, "hvg": a.hvg, "n_pc": a.npc, "tile_rows": tile},
+        "h2d": {"host_bytes_per_sweep": host_bytes, "GBps_sweep1": host_bytes / best["sweep1_s"] / 1e9,
+                "GBps_sweep2": host_bytes / best["sweep2_s"] / 1e9,
+                "note": "both sweeps cross PCIe (u64 indices narrowed to i32 on the host side of the link); upload-bound: the "
+                        "kernels of a tile run under the upload of the next one"},
+        "runs": runs, "setup": {"host_generate_s": t_gen},
+    }
+    print(json.dumps(out), flush=True)
+    if pinned:
+        hip.hipHostFree.argtypes = [C.c_void_p]
+        hip.hipHostFree(hidx); hip.hipHostFree(hval)
+
+
+def main():
+    a = parse()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != a.gpus:
+        if world_env == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+        a.gpus = world_env
+    B = Bench(a)
+    rank, world = B.rank, B.world
+    if a.backed:
+        if world != 1:
+            sys.exit("--backed is a single-GPU measurement")
+        backed_run(B)
+        B.close()
+        return
+    cells, genes, density, seed = CONFIGS[a.config]
+    if a.cells:
+        cells = a.cells
+    scaling = a.scaling if a.scaling != "auto" else ("strong" if world > 1 else "weak")
+    n_global = cells if scaling == "strong" or world == 1 else cells * world
+    p = B.params(a.config, n_global, a.skew)
+    row0, row1 = B.shard(p, n_global)
+    main_ = B.run(a.config, n_global, row0, row1, a.storage, a.steps, a.warmup, solver=a.solver, skew=a.skew)
+    weak = None
+    if world > 1 and scaling == "strong" and not a.lean:
+        # the other reading of the scaling question: per-GPU work fixed (the config's cells on EVERY GPU)
+        ng = cells * world
+        pw = B.params(a.config, ng, a.skew)
+        w0, w1 = B.shard(pw, ng)
+        wk = min(a.steps, 5)
+        w = B.run(a.config, ng, w0, w1, a.storage, wk, min(a.warmup, 2), solver=a.solver, skew=a.skew)
+        weak = {"scaling": "weak", "cells_global": ng, "steps": wk, "ms_per_step": w["ms_per_step"],
+                "value": ng * wk / w["elapsed"], "unit": "cells/s", "subspace_iterations": w["iters"]}
+
+    extra = {}
+    if rank == 0 and world == 1 and not a.lean:
+        def attempt(name, fn):
+            try:
+                extra[name] = fn()
+            except Exception as e:      # an extra block is never a reason to lose the headline line
+                extra[name] = {"failed": repr(e)}
+        k5 = min(a.steps, 5)
+        other = "f64" if a.storage == "f32" else "f32"
+
+        def f_other():
+            r = B.run(a.config, n_global, 0, n_global, other, k5, 1, solver=a.solver)
+            per, serial = attributed(r["prof"], k5)
+            return {"storage": other, "steps": k5, "ms_per_step": r["ms_per_step"], "value": n_global * k5 / r["elapsed"],
+                    "unit": "cells/s", "pca_residual": r["residual"], "subspace_iterations": r["iters"],
+                    "kernel_ms_per_step": per,
+                    "note": "the same pipeline with f64 value storage (12 B per non-zero, 16-byte compacted records): the "
+                            "reference's f64 arithmetic to ~1e-15; HighlyVariable(n) is the reference's at either storage"}
+        attempt("f64_storage" if other == "f64" else "f32_storage", f_other)
+
+        def f_fast():
+            os.environ["SRX_NO_LAZY"] = "1"
+            try:
+                r = B.run(a.config, n_global, 0, n_global, a.storage, k5, 1, solver=a.solver)
+            finally:
+                del os.environ["SRX_NO_LAZY"]
+            return {"steps": k5, "ms_per_step": r["ms_per_step"], "value": n_global * k5 / r["elapsed"], "unit": "cells/s",
+                    "note": "SRX_NO_LAZY=1: in-place normalise + log1p first, moments of the f32-rounded stored values (round-1 "
+                            "order; near-ties of HighlyVariable(n) may swap against the reference) — what the exact selection costs"}
+        attempt("approximate_selection", f_fast)
+
+        def f_iter():
+            r = B.run(a.config, n_global, 0, n_global, a.storage, 2, 1, solver=2)
+            fw, tr = r["prof"].get("spmm_fwd", {}), r["prof"].get("spmm_t", {})
+            return {"steps": 2, "ms_per_step": r["ms_per_step"], "subspace_iterations": r["iters"], "pca_residual": r["residual"],
+                    "spmm_fwd": roof(fw, KERNEL_SYMBOL["spmm_fwd"], "f64 panels (the matrix-free iteration runs its products in f64)"),
+                    "spmm_t": roof(tr, KERNEL_SYMBOL["spmm_t"], "N m 64 f64 LDS lane-atomics per launch: LDS-atomic bound"),
+                    "note": "--solver 2: the matrix-free subspace iteration, one forward and one transposed SpMM per application of "
+                            "C — the kernels BASELINE.json's second metric means; the default Gram solver runs the forward "
+                            "SpMM once per solve (roofline_spmm)"}
+        attempt("roofline_spmm_iter", f_iter)
+
+        def f_skew():
+            r = B.run(a.config, n_global, 0, n_global, a.storage, 3, 1, solver=a.solver, skew=1 - a.skew, tolerate_noconv=True)
+            per, _ = attributed(r["prof"], 3)
+            return {"skew": 1 - a.skew, "steps": 3, "ms_per_step": r["ms_per_step"], "kernel_ms_per_step": per,
+                    "nnz_hvg_compacted": r["nnz_selected"], "noconv_steps": r["noconv_steps"],
+                    "note": "srx_synth skew = 1: gene density ~ 1/sqrt(gene index) (7x between the first and the last genes): "
+                            "contention on the per-gene LDS accumulators of the moments pass, owners of very different weight "
+                            "in the Gram kernel (stripes are cut by row count, not by measured work)"}
+        attempt("skewed_genes", f_skew)
+
+        def f_hard():
+            c2 = CONFIGS["c2"]
+            r = B.run("c2", c2[0], 0, c2[0], a.storage, 3, 1, hvg=1000, tolerate_noconv=True)
+            return {"workload": "c2 (100k x 20k, 5 %), HighlyVariable(1000): theta_64 / theta_50 = 0.97-0.99 (flat tail)",
+                    "steps": 3, "ms_per_step": r["ms_per_step"], "subspace_iterations": r["iters"], "pca_residual": r["residual"],
+                    "noconv_steps": r["noconv_steps"]}
+        attempt("hard_spectrum", f_hard)
+
+        if not a.no_cpu_baseline:
+            try:
+                ns = min(a.host_sample_cells, n_global)
+                hs = host_sample(B, a.config, ns)
+                attempt("incl_h2d", lambda: incl_h2d(B, *hs))
+                try:
+                    extra.update(cpu_baselines(B, *hs))
+                except Exception as e:      # the baseline is a reported number, never a reason to lose the GPU line
+                    extra["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": usable_cores(), "kind": "port",
+                                             "sample": f"failed: {e!r}"}
+            except Exception as e:
+                extra["incl_h2d"] = {"failed": repr(e)}
 
     if rank == 0:
-        value = n_global * a.steps / elapsed
-        fwd = prof.get("spmm_fwd", {})
-        traffic = load_traffic(a.config)
+        prof = main_["prof"]
+        value = n_global * a.steps / main_["elapsed"]
+        traffic, traffic_round = load_traffic(a.config)
         for name, d in prof.items():
             per_step = traffic.get(name)
             d["hbm_traffic_per_launch"] = per_step / (d["launches"] / a.steps) if per_step else None
-        dom_name = max(prof, key=lambda k: prof[k]["avg_ms"] * prof[k]["launches"]) if prof else None
+        per, serial = attributed(prof, a.steps)
+        cand = {k_: v for k_, v in per.items() if k_ not in ("iterate", "dense_apply", "select")}
+        dom_name = max(cand, key=cand.get) if cand else None
         dom = prof.get(dom_name, {})
-
-        def roof(name, d, kernel, note):
-            return {"bound": "hbm", "kernel": kernel, "achieved": d.get("GBps"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": d.get("frac_of_peak"), "traffic": d.get("hbm_traffic_per_launch"),
-                    "launches": d.get("launches"), "avg_ms": d.get("avg_ms"),
-                    "alg_bytes_per_launch": d.get("alg_bytes_per_launch"), "note": note}
-
         out = {
             "metric": "cells/sec end-to-end normalise->HVG->50-PC PCA; SpMM achieved HBM GB/s vs peak",
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling,
+            "ms_per_step": main_["ms_per_step"], "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": a.storage, "data": "synthetic",
             "config": {
-                "workload": f"{a.config}: {cells} cells/GPU x {genes} genes, density {density}, seed {seed}; "
-                            f"normalize_total(1e4,Row)+log1p+HVG({a.hvg})+{a.npc}-PC PCA; values {a.storage} / indices i32 in HBM",
-                "cells_global": n_global, "genes": genes, "nnz_per_gpu": nnz, "hvg": a.hvg, "n_pc": a.npc,
-                "panel_width": 64, "parallelism": f"row-shard x{world}",
-                **({"collective": collective} if dist is not None else {}),
-                "nnz_hvg_compacted_per_gpu": int(res.pca.nnz_selected),
-                "subspace_iterations": iters, "pca_residual": float(res.pca.residual),
-                "pca_solver": {1: "gram", 2: "spmm"}.get(int(res.pca.solver), "?"),
+                "workload": f"{a.config}: {n_global} cells x {genes} genes, density {density}, seed {seed}"
+                            f"{', skewed gene densities' if a.skew else ''}; normalize_total(1e4,Row)+log1p+HVG({a.hvg})+"
+                            f"{a.npc}-PC PCA; values {a.storage} / indices i32 in HBM; rows {row0}..{row1} on rank 0",
+                "cells_global": n_global, "genes": genes, "nnz_rank0": main_["nnz"], "hvg": a.hvg, "n_pc": a.npc,
+                "panel_width": 64, "parallelism": f"row-shard x{world} (nnz-balanced)",
+                **({"collective": B.collective} if B.dist is not None else {}),
+                "nnz_hvg_compacted_rank0": main_["nnz_selected"],
+                "subspace_iterations": main_["iters"], "pca_residual": main_["residual"], "pca_solver": main_["solver"],
+                "hvg_selection": "f64 moments of ln_1p(v * scale) from the raw matrix: identical to the reference's at f32 storage",
                 # the ~80 small launches of the subspace iteration are replayed from captured hipGraphs (three
-                # segments per solve); their kernels are therefore not bracketed by per-class events
-                "pca_iteration_hip_graphs": int(res.pca.solver) == 1 and not os.environ.get("SRX_NO_GRAPH"),
+                # segments per solve); they are bracketed as ONE class (`iterate`)
+                "pca_iteration_hip_graphs": main_["solver"] == "gram" and not os.environ.get("SRX_NO_GRAPH"),
             },
-            # the kernel with the largest share of the step (live HIP-event timing on the ctx stream)
-            "roofline": roof(dom_name, dom, KERNEL_SYMBOL.get(dom_name, dom_name), ROOF_NOTE.get(dom_name, "")),
+            # the kernel class with the largest share of the step (live HIP-event timing on the stream it runs on)
+            "roofline": roof(dom, KERNEL_SYMBOL.get(dom_name, dom_name), ROOF_NOTE.get(dom_name, "")),
             # BASELINE.json's second metric: the CSR x 64-column-panel SpMM against the HBM peak
-            "roofline_spmm": roof("spmm_fwd", fwd, KERNEL_SYMBOL["spmm_fwd"], ROOF_NOTE["spmm_fwd"]),
+            "roofline_spmm": roof(prof.get("spmm_fwd", {}), KERNEL_SYMBOL["spmm_fwd"], ROOF_NOTE["spmm_fwd"]),
             "kernels": prof,
-            "stage_ms_per_step": {k: v / a.steps for k, v in stage.items()},
-            "setup": {"generate_s": t_gen, "copies": n_copies},
+            "kernel_ms_per_step": per,
+            # step time outside every bracketed class (launch gaps, host waits, scans, small copies)
+            "unattributed_ms_per_step": main_["ms_per_step"] - serial,
+            "writeback_overlapped_ms_per_step": per.get("normalize_log1p"),
+            "stage_ms_per_step": main_["stage_ms_per_step"],
+            "traffic_source": f"profiles/{traffic_round}_traffic_{a.config}.json" if traffic_round else None,
+            "setup": {"generate_s": main_["generate_s"], "copies": main_["copies"]},
         }
-        if world == 1 and not a.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(F, params, genes, min(a.cpu_sample_cells, cells), a.hvg, a.npc,
-                                                   a.target_sum)
-                out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-            except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
-                out["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": os.cpu_count(), "kind": "port",
-                                       "sample": f"failed: {e!r}"}
-        if json_fd is not None:
+        if weak:
+            out["weak"] = weak
+        out.update(extra)
+        if "cpu_baseline" in out and out["cpu_baseline"].get("value"):
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if "cpu_baseline_threaded" in out and out["cpu_baseline_threaded"].get("value"):
+            out["gpu_over_cpu_threaded"] = value / out["cpu_baseline_threaded"]["value"]
+        if B.json_fd is not None:
             sys.stdout.flush()
-            os.write(json_fd, (json.dumps(out) + "\n").encode())
+            os.write(B.json_fd, (json.dumps(out) + "\n").encode())
         else:
             print(json.dumps(out), flush=True)
-
-    for c in copies:
-        c.free()
-    pristine.free()
-    if dist is not None:
-        dist.barrier()
-        dist.close()
-    ctx.close()
+    B.close()
 
 
 if __name__ == "__main__":

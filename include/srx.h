@@ -371,7 +371,10 @@ typedef enum srx_kernel_class {
     SRX_K_GRAM = 5,        /* G = X_sel^T X_sel (sparse outer products into LDS tiles)     */
     SRX_K_DENSE = 6,       /* dense k x k times k x 64 products of the Gram solver        */
     SRX_K_ROWSUM = 7,      /* per-cell sums of the raw values (first pass of srx_pipeline)  */
-    SRX_K_COUNT_ = 8
+    SRX_K_ITERATE = 8,     /* the k x 64 subspace iteration as a whole (graph replays + the
+                              launches between them); contains the SRX_K_DENSE launches     */
+    SRX_K_SELECT = 9,      /* device-side HighlyVariable(n): variances, ranks, selection    */
+    SRX_K_COUNT_ = 10
 } srx_kernel_class;
 int32_t srx_prof_enable(srx_ctx* ctx, uint32_t class_mask);
 int32_t srx_prof_reset(srx_ctx* ctx);

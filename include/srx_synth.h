@@ -43,6 +43,12 @@ typedef struct srx_synth_params {
     uint32_t marker_genes;   /* M; n_types * M <= n_cols                                   */
     uint32_t expr_boost;     /* B >= 1                                                     */
     uint32_t value_boost;    /* VB >= 1                                                    */
+    uint32_t skew;           /* 0: strata of equal width (uniform gene densities); 1: stratum s of a
+                                row with r entries starts at (Gv - r B) (s/r)^2 + s B — the quadratic map of
+                                SURVEY.md 8(d): gene density ~ 1 / sqrt(gene index), the first genes are
+                                present in almost every cell (per-gene atomic contention, Gram owners
+                                of very different weight)                                        */
+    uint32_t reserved_;
 } srx_synth_params;
 
 /* Fill the defaults used by bench.py for a given shape. */

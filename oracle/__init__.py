@@ -32,12 +32,40 @@ NP_DTYPES = {
 DTYPE_CODE = {np.dtype(v): k for k, v in NP_DTYPES.items()}
 
 
+_OMP_PATH = os.path.join(_HERE, "liborc_omp.so")
+
+
 def build(force: bool = False) -> str:
-    """Compile liborc.so with gcc (recipe: oracle/Makefile)."""
-    src = os.path.join(_HERE, "srx_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "liborc.so"], stdout=subprocess.DEVNULL)
+    """Compile liborc.so (and the threaded bench baseline liborc_omp.so) with gcc (recipe: oracle/Makefile)."""
+    for target, srcname in (("liborc.so", "srx_oracle.c"), ("liborc_omp.so", "omp_baseline.c")):
+        path, src = os.path.join(_HERE, target), os.path.join(_HERE, srcname)
+        if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-B", target], stdout=subprocess.DEVNULL)
     return _LIB_PATH
+
+
+def omp_pipeline(m, target_sum: float, n_hvg: int, n_threads: int):
+    """Threaded CPU baseline (omp_baseline.c; SURVEY.md 8(d) variant (ii)): normalise + log1p, per-gene moments,
+    HighlyVariable(n_hvg), k x k standardised covariance of the selection.  Returns (values_f64, hvg (rank order),
+    order (ascending genes), cov, mean, sd, seconds[3])."""
+    build()
+    lo = ctypes.CDLL(_OMP_PATH)
+    k = min(n_hvg, m.n_cols)
+    vals = np.ascontiguousarray(m.values, dtype=np.float32)
+    out = np.empty(len(vals), np.float64)
+    hv, order = np.zeros(k, np.uint64), np.zeros(k, np.uint64)
+    cov, mean, sd, secs = np.zeros((k, k)), np.zeros(k), np.zeros(k), np.zeros(4)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lo.orc_omp_pipeline.restype = ctypes.c_int
+    lo.orc_omp_pipeline.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_double, ctypes.c_uint64, ctypes.c_int] + [ctypes.c_void_p] * 7
+    ip = np.ascontiguousarray(m.indptr, dtype=np.uint64)
+    ix = np.ascontiguousarray(m.indices, dtype=np.uint64)
+    rc = lo.orc_omp_pipeline(m.n_rows, m.n_cols, vp(ip), vp(ix), vp(vals), target_sum, n_hvg, n_threads, vp(out), vp(hv),
+                             vp(order), vp(cov), vp(mean), vp(sd), vp(secs))
+    if rc != 0:
+        raise MemoryError("orc_omp_pipeline: out of memory")
+    return out, hv, order, cov, mean, sd, secs
 
 
 class _Csr(ctypes.Structure):

@@ -49,7 +49,9 @@ pub const SRX_K_SPMM_T: i32 = 4;
 pub const SRX_K_GRAM: i32 = 5;
 pub const SRX_K_DENSE: i32 = 6;
 pub const SRX_K_ROWSUM: i32 = 7;
-pub const SRX_K_COUNT_: i32 = 8;
+pub const SRX_K_ITERATE: i32 = 8;
+pub const SRX_K_SELECT: i32 = 9;
+pub const SRX_K_COUNT_: i32 = 10;
 
 #[repr(C)] pub struct SrxCtx { _private: [u8; 0] }      // opaque `srx_ctx`
 #[repr(C)] pub struct SrxMat { _private: [u8; 0] }      // opaque `srx_mat`

@@ -22,7 +22,7 @@ STATUS_NAMES = {0: "SRX_OK", -1: "SRX_E_ARG", -2: "SRX_E_DTYPE", -3: "SRX_E_FORM
 I8, I16, I32, U8, U16, U32, F32, F64 = range(8)
 ROW, COLUMN = 0, 1
 STORE_AUTO, STORE_F32, STORE_F64 = 0, 1, 2
-K_NORMALIZE, K_MOMENTS, K_COMPACT, K_SPMM_FWD, K_SPMM_T, K_GRAM, K_DENSE, K_ROWSUM = range(8)
+K_NORMALIZE, K_MOMENTS, K_COMPACT, K_SPMM_FWD, K_SPMM_T, K_GRAM, K_DENSE, K_ROWSUM, K_ITERATE, K_SELECT = range(10)
 SOLVER_AUTO, SOLVER_GRAM, SOLVER_SPMM = 0, 1, 2
 UNIQUE_ID_BYTES = 128
 
@@ -67,7 +67,7 @@ class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_rows_global", C.c_uint64), ("n_cols", C.c_uint64),
                 ("density", C.c_double), ("lib_sigma", C.c_double), ("type_decay", C.c_double),
                 ("n_types", C.c_uint32), ("marker_genes", C.c_uint32), ("expr_boost", C.c_uint32),
-                ("value_boost", C.c_uint32)]
+                ("value_boost", C.c_uint32), ("skew", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 class Flex(C.Structure):            # srx_flex: FlexValue (src/shared/mod.rs:62-66)

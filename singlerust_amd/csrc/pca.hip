@@ -2474,8 +2474,11 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const RowM
             double resid_r = INFINITY;
             int iters_r = 0;
             bool conv_r = false;
-            SRX_TRY(subspace_iterate(ctx, w, k, l_r, o_r, apply, apply_id, graphable, hv ? hv->d_status : nullptr, resid_r,
-                                     iters_r, conv_r));
+            {
+                ProfScope ps_it(ctx, SRX_K_ITERATE, (double)k * k * 8.0);
+                SRX_TRY(subspace_iterate(ctx, w, k, l_r, o_r, apply, apply_id, graphable, hv ? hv->d_status : nullptr, resid_r,
+                                         iters_r, conv_r));
+            }
             resid = std::max(resid, resid_r);
             iters += iters_r + o.warm;
             if (!conv_r) {
@@ -2824,6 +2827,7 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     HvgDev hv;
     if (dev_sel) {
         Range r_("srx:select_hvg");
+        ProfScope ps_sel(ctx, SRX_K_SELECT, (double)G * 24.0);
         SRX_TRY(select_hvg_device(m, hvg_n, o.center, o.scale, hv));
     } else {
         SRX_TRY(prepare_host_selection(m, selv, o, order, slot_of_sel, remap, mu, sd, dinv, trace));

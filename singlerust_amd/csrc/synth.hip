@@ -11,7 +11,7 @@ namespace srx {
 struct SynthConst {
     uint64_t seed;
     uint64_t G, Gv;          // real / virtual gene axis length
-    uint32_t T, M, B, VB;
+    uint32_t T, M, B, VB, skew;
     uint32_t thr[SRX_SYNTH_MAX_TYPES];   // cumulative type thresholds on a 32-bit uniform
 };
 
@@ -44,8 +44,16 @@ __host__ __device__ __forceinline__ uint64_t vmap(const SynthConst& c, uint32_t 
 
 __host__ __device__ __forceinline__ void synth_entry(const SynthConst& c, uint64_t row, uint32_t t, uint64_t r,
                                                      uint64_t s, uint64_t& col, uint32_t& val) {
-    uint64_t g0 = vmap(c, t, (s * c.Gv) / r);
-    uint64_t g1 = vmap(c, t, ((s + 1) * c.Gv) / r);
+    uint64_t b0 = (s * c.Gv) / r, b1 = ((s + 1) * c.Gv) / r;
+    if (c.skew) {
+        // quadratic strata: (Gv - r B) (s/r)^2 + s B — strictly increasing, every stratum >= B virtual slots wide (so it
+        // holds a whole gene after vmap, like the uniform strata), the last one ends at Gv
+        const uint64_t span = c.Gv - r * c.B;
+        b0 = (span * s * s) / (r * r) + s * c.B;
+        b1 = (span * (s + 1) * (s + 1)) / (r * r) + (s + 1) * c.B;
+    }
+    uint64_t g0 = vmap(c, t, b0);
+    uint64_t g1 = vmap(c, t, b1);
     uint64_t h = hash2(c.seed, row, s);
     col = g0 + (h >> 32) % (g1 - g0);
     uint32_t low = (uint32_t)(h & 0xFFFFu) | 0x8000u;
@@ -69,6 +77,7 @@ static int32_t make_const(const srx_synth_params* p, SynthConst& c) {
     c.M = p->n_types > 1 ? p->marker_genes : 0;
     c.B = p->n_types > 1 ? p->expr_boost : 1;
     c.VB = p->value_boost;
+    c.skew = p->skew ? 1u : 0u;
     c.Gv = c.G + (uint64_t)(c.B - 1) * c.M;
     double tot = 0.0, w = 1.0;
     for (uint32_t t = 0; t < c.T; ++t) { tot += w; w *= p->type_decay; }
@@ -143,6 +152,8 @@ void srx_synth_defaults(srx_synth_params* p, uint64_t seed, uint64_t n_rows_glob
     p->marker_genes = 40;
     p->expr_boost = 12;
     p->value_boost = 8;
+    p->skew = 0;
+    p->reserved_ = 0;
     // small matrices: shrink the planted structure to fit
     while ((uint64_t)p->n_types * p->marker_genes * 4 > n_cols && p->marker_genes > 4) p->marker_genes /= 2;
     while ((uint64_t)p->n_types * p->marker_genes * 4 > n_cols && p->n_types > 2) p->n_types /= 2;

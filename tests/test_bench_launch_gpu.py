@@ -28,10 +28,16 @@ def test_two_rank_bench_line():
     assert len(lines0) == 1, lines0                        # one JSON line, nothing else on rank 0's stdout
     assert not outs[1][0].decode().strip()                 # and nothing at all on the other rank's
     d = json.loads(lines0[0])
-    assert d["n_gpus"] == world and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    # N > 1 defaults to STRONG scaling (BASELINE.json configs[3]: the same cells row-sharded over the GPUs) and carries a
+    # `weak` block measured after it
+    assert d["n_gpus"] == world and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong"
     assert d["unit"] == "cells/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
     c = d["config"]
-    assert c["cells_global"] == world * cells and c["parallelism"] == f"row-shard x{world}" and c["collective"] == "host-star"
+    assert c["cells_global"] == cells and c["parallelism"].startswith(f"row-shard x{world}") and c["collective"] == "host-star"
     # whole-job value: all ranks' cells over the max-over-ranks time of the timed steps
-    assert abs(d["value"] - world * cells / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert abs(d["value"] - cells / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    w = d["weak"]
+    assert w["scaling"] == "weak" and w["cells_global"] == world * cells
+    assert abs(w["value"] - world * cells / (w["ms_per_step"] * 1e-3)) <= 1e-6 * w["value"]
+    assert d["unattributed_ms_per_step"] is not None
     assert c["pca_residual"] < 1e-6 and d["roofline"]["frac"] > 0 and d["roofline"]["bound"] == "hbm"
