@@ -460,12 +460,16 @@ def backed_run(B):
         val = np.ctypeslib.as_array(C.cast(hval, C.POINTER(C.c_float)), shape=(nnz,))
     else:
         idx, val = np.zeros(nnz, np.uint64), np.zeros(nnz, np.float32)
-    # fill tile by tile (the host generator is serial per call: keep the calls bounded)
-    for r0 in range(0, cells, tile):
+    # fill tile by tile on a thread pool (the host generator is serial per call; ctypes releases the GIL)
+    import concurrent.futures as cf
+
+    def fill(r0):
         r1 = min(cells, r0 + tile)
         e0, e1 = int(ip[r0]), int(ip[r1])
         sub = (ip[r0:r1 + 1] - ip[r0]).astype(np.uint64)
         lib.srx_synth_fill_host(C.byref(p), r0, r1, F.ptr(sub), F.ptr(idx[e0:e1]), F.ptr(val[e0:e1]))
+    with cf.ThreadPoolExecutor(max_workers=max(1, min(usable_cores(), 64))) as ex:
+        list(ex.map(fill, range(0, cells, tile)))
     t_gen = time.perf_counter() - t_gen
     host_bytes = ip.nbytes + idx.nbytes + val.nbytes
     opts = F.PcaOpts(a.npc, -1, -1, -1, 0, 0, 1, 0.0, 12345)

@@ -289,3 +289,175 @@ pub fn pipeline(ctx: &Ctx, adata: &mut IMAnnData, target_sum: f64, n_hvg: usize,
     })?;
     Ok((scores, evr, hvg.into_iter().map(|i| i as usize).collect()))
 }
+
+// ================================================================================================================
+// The reference's FREE FUNCTIONS with their exact signatures (no context argument): what `src/memory/statistics/mod.rs`,
+// `src/memory/processing/mod.rs` and `src/memory/processing/dim_red/mod.rs` export today, bodies replaced.  A caller of
+// SingleRust recompiles against the `hip` feature and changes nothing.  The context lives in a `thread_local!` (one per
+// thread, as include/srx.h requires); every call uploads X under the reference's own guard, works on the handle and — for
+// the in-place operations — writes the result back into the IMAnnData, INCLUDING the variant change to
+// `DynCsrMatrix::F64` that `scale_row_csr` performs (scale/mod.rs:74-83).  Callers that run the whole path should use
+// `pipeline()` above (one upload, nothing copied back but the scores).
+// ================================================================================================================
+use std::cell::OnceCell;
+use std::ops::DerefMut;
+
+use anndata::data::array::ArrayData as AD;
+use anndata_memory::IMArrayElement;
+use nalgebra_sparse::{CscMatrix, CsrMatrix};
+use ndarray::Array2;
+use single_algebra::svd::SVDImplementation;            // the marker trait of pca_inplace's last argument (dim_red/mod.rs:12)
+
+thread_local! {
+    static CTX: OnceCell<Ctx> = const { OnceCell::new() };
+}
+/// The thread's context: device `SRX_DEVICE` (default 0), created on first use.
+fn with_ctx<R>(f: impl FnOnce(&Ctx) -> Result<R>) -> Result<R> {
+    CTX.with(|cell| {
+        if cell.get().is_none() {
+            let dev = std::env::var("SRX_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
+            let _ = cell.set(Ctx::new(dev)?);
+        }
+        f(cell.get().expect("context"))
+    })
+}
+
+pub mod statistics_free {
+    //! src/memory/statistics/mod.rs:10-46, signatures unchanged.
+    use super::*;
+    pub fn compute_number(adata: &IMAnnData, direction: Direction) -> anyhow::Result<Vec<u32>> {
+        with_ctx(|c| DeviceX::upload(c, adata)?.compute_number(direction))
+    }
+    pub fn compute_sum(adata: &IMAnnData, direction: Direction) -> anyhow::Result<Vec<f64>> {
+        with_ctx(|c| DeviceX::upload(c, adata)?.compute_sum(direction))
+    }
+    pub fn compute_variance(adata: &IMAnnData, direction: Direction) -> anyhow::Result<Vec<f64>> {
+        with_ctx(|c| DeviceX::upload(c, adata)?.compute_variance(direction))
+    }
+    pub fn compute_min_max(adata: &IMAnnData, direction: Direction) -> anyhow::Result<(Vec<f64>, Vec<f64>)> {
+        with_ctx(|c| DeviceX::upload(c, adata)?.compute_min_max(direction))
+    }
+    pub fn compute_std_dev(adata: &IMAnnData, direction: Direction) -> anyhow::Result<Vec<f64>> {
+        with_ctx(|c| DeviceX::upload(c, adata)?.compute_std_dev(direction))
+    }
+}
+
+/// What `scale_row_csr` / `scale_col_csr` / `log1p_data` leave in X (scale/mod.rs:59-89,141-173, transform/mod.rs:8-62):
+/// the values come back from the device and, unless the matrix already is F64 (or F32 under log1p), X is REPLACED by the
+/// F64 variant built on the unchanged sparsity pattern — `*csr_matrix = DynCsrMatrix::F64(float_matrix)` (scale/mod.rs:82).
+fn write_back(adata: &mut IMAnnData, x: &DeviceX, keep_f32: bool) -> Result<()> {
+    let xe = adata.x();
+    let mut guard = xe.0.write_inner();
+    match guard.deref_mut() {
+        AD::CsrMatrix(csr) => {
+            let nnz = match csr { DynCsrMatrix::F64(m) => m.nnz(), DynCsrMatrix::F32(m) => m.nnz(), other => other.nnz() };
+            match csr {
+                DynCsrMatrix::F64(m) => {                                               // in place (:66-73)
+                    x.ctx.check(unsafe { srx_matrix_download_values(x.mat, m.values_mut().as_mut_ptr() as *mut c_void, SRX_F64) })
+                }
+                DynCsrMatrix::F32(m) if keep_f32 => {                                    // f32::ln_1p in place (transform/mod.rs:43-47)
+                    x.ctx.check(unsafe { srx_matrix_download_values(x.mat, m.values_mut().as_mut_ptr() as *mut c_void, SRX_F32) })
+                }
+                other => {                                                              // clone -> f64 -> replace (:74-83)
+                    let values = x.download_values_f64(nnz)?;
+                    let float_matrix: CsrMatrix<f64> = other.clone().try_into()?;       // the pattern, as the reference obtains it
+                    let (offsets, indices, _) = float_matrix.disassemble();
+                    *other = DynCsrMatrix::F64(CsrMatrix::try_from_csr_data(x.n_obs, x.n_vars, offsets, indices, values)
+                        .map_err(|e| anyhow!("{e}"))?);
+                    Ok(())
+                }
+            }
+        }
+        AD::CscMatrix(csc) => {                                                          // scale_row_csc / scale_col_csc (:25-57,104-139)
+            let nnz = csc.nnz();
+            match csc {
+                DynCscMatrix::F64(m) => x.ctx.check(unsafe { srx_matrix_download_values(x.mat, m.values_mut().as_mut_ptr() as *mut c_void, SRX_F64) }),
+                DynCscMatrix::F32(m) if keep_f32 => x.ctx.check(unsafe { srx_matrix_download_values(x.mat, m.values_mut().as_mut_ptr() as *mut c_void, SRX_F32) }),
+                other => {
+                    let values = x.download_values_f64(nnz)?;
+                    let float_matrix: CscMatrix<f64> = other.clone().try_into()?;
+                    let (offsets, indices, _) = float_matrix.disassemble();
+                    *other = DynCscMatrix::F64(CscMatrix::try_from_csc_data(x.n_obs, x.n_vars, offsets, indices, values)
+                        .map_err(|e| anyhow!("{e}"))?);
+                    Ok(())
+                }
+            }
+        }
+        _ => bail!("X is neither a CSC nor a CSR matrix"),                               // transform/mod.rs:58
+    }
+}
+
+pub mod processing_free {
+    //! src/memory/processing/mod.rs:303-332, signatures unchanged.
+    use super::*;
+    pub fn normalize_total_inplace(adata: &mut IMAnnData, target_sum: f64, direction: Direction) -> anyhow::Result<()> {
+        with_ctx(|c| {
+            let mut x = DeviceX::upload(c, adata)?;
+            x.normalize_total_inplace(target_sum, direction)?;
+            write_back(adata, &x, false)                    // X becomes DynCsrMatrix::F64 whatever it was
+        })
+    }
+    pub fn normalize_total(adata: &IMAnnData, target_sum: f64, direction: Direction) -> anyhow::Result<IMAnnData> {
+        let mut new_data = adata.deep_clone();              // :319, as in the reference
+        normalize_total_inplace(&mut new_data, target_sum, direction)?;
+        Ok(new_data)
+    }
+    pub fn log1p_transform_inplace(adata: &mut IMAnnData) -> anyhow::Result<()> {
+        with_ctx(|c| {
+            let mut x = DeviceX::upload(c, adata)?;
+            x.log1p_transform_inplace()?;
+            write_back(adata, &x, true)                     // F32 stays F32, every other dtype becomes F64
+        })
+    }
+    pub fn log1p_transform(adata: &IMAnnData) -> anyhow::Result<IMAnnData> {
+        let mut new_data = adata.deep_clone();
+        log1p_transform_inplace(&mut new_data)?;
+        Ok(new_data)
+    }
+
+    pub mod dim_red {
+        //! src/memory/processing/dim_red/mod.rs:24-121.
+        use super::super::*;
+        /// dim_red/mod.rs:24-94, signature unchanged.  `svd_mode` selects single_algebra's SVD backend in the reference; the
+        /// device solver has none to choose: accepted and ignored, like `n_threads`.
+        pub fn pca_inplace<S: SVDImplementation>(anndata: &mut IMAnnData, n_components: Option<usize>, center: Option<bool>,
+                                                 scale: Option<bool>, n_threads: Option<usize>,
+                                                 feature_selection: &FeatureSelection, _svd_mode: S) -> anyhow::Result<()> {
+            // HighlyVariableCol / Randomized / VarianceThreshold: the reference's own host code makes the index list
+            // (dim_red/mod.rs:125-134,141-153); HighlyVariable(n) and None go to the device
+            let (scores, evr, selected, n_pc) = with_ctx(|c| {
+                let x = DeviceX::upload(c, anndata)?;
+                match feature_selection {
+                    FeatureSelection::HighlyVariable(_) | FeatureSelection::None => x.pca(n_components, center, scale, n_threads, feature_selection),
+                    other => {
+                        let sel: Vec<u64> = crate::memory::processing::dim_red::select_features(anndata, other)?
+                            .into_iter().map(|i| i as u64).collect();
+                        x.pca_with_selection(n_components, center, scale, Some(sel))
+                    }
+                }
+            })?;
+            let transformed = Array2::from_shape_vec((anndata.n_obs(), n_pc), scores)?;      // N x n_pc row-major, as pca.transform returns
+            attach_pca_results(anndata, transformed, None, Some(evr), selected, n_pc)
+        }
+
+        /// dim_red/mod.rs:96-121, UNCHANGED (copied call for call so that the module is self-contained): obsm["X_pca"] and,
+        /// when loadings are given, varm["PCA_loadings"] with row selected[i] <- loadings row i.
+        fn attach_pca_results(anndata: &mut IMAnnData, transformed: Array2<f64>, loadings: Option<Array2<f64>>,
+                              _explained_variance_ratio: Option<Vec<f64>>, selected_features: Vec<usize>,
+                              n_components: usize) -> anyhow::Result<()> {
+            let obsm = anndata.obsm();
+            obsm.add_array("X_pca".to_string(), IMArrayElement::new(AD::from(transformed)))?;
+            if let Some(loadings) = loadings {
+                let varm = anndata.varm();
+                let mut full_loadings = Array2::zeros((anndata.n_vars(), n_components));
+                for (i, &feature_idx) in selected_features.iter().enumerate() {
+                    if i < loadings.nrows() {
+                        full_loadings.row_mut(feature_idx).assign(&loadings.row(i));
+                    }
+                }
+                varm.add_array("PCA_loadings".to_string(), IMArrayElement::new(AD::from(full_loadings)))?;
+            }
+            Ok(())
+        }
+    }
+}

@@ -366,11 +366,17 @@ inline std::vector<std::uint64_t> select_features(const IMAnnData& a, const Feat
     }
     throw Error(SRX_E_ARG, "unknown FeatureSelection");
 }
-// pca_inplace(anndata, n_components, center, scale, n_threads, feature_selection, svd_mode) (:24-94);
-// svd_mode (FaerSVD / LapackSVD marker) has no counterpart.  Stores obsm["X_pca"] (:105-106).
+// single_algebra's SVDImplementation markers (dim_red/mod.rs:12,24): accepted, as in the reference's signature, and
+// ignored — the device solver has no SVD backend to choose.
+struct FaerSVD {};
+struct LapackSVD {};
+// pca_inplace<S: SVDImplementation>(anndata, n_components, center, scale, n_threads, feature_selection, svd_mode)
+// (:24-94), argument for argument.  Stores obsm["X_pca"] (:105-106) like attach_pca_results; returns the solver's info
+// (the reference returns Ok(())).
+template <typename S = FaerSVD>
 inline srx_pca_info pca_inplace(IMAnnData& a, std::optional<std::size_t> n_components, std::optional<bool> center,
                                 std::optional<bool> scale, std::optional<std::size_t> n_threads,
-                                const FeatureSelection& fs) {
+                                const FeatureSelection& fs, S /*svd_mode*/ = S{}) {
     auto sel = select_features(a, fs);
     srx_pca_opts o{};
     o.n_components = n_components ? (int)*n_components : -1;

@@ -116,7 +116,8 @@ static void test_path_end_to_end(Context& ctx) {
         EXPECT(var[hv[i - 1]] > var[hv[i]] || (var[hv[i - 1]] == var[hv[i]] && hv[i - 1] < hv[i]),
                "HVG order broken at %zu", i);
 
-    auto info = proc::dim_red::pca_inplace(adata, 10, {}, {}, {}, FeatureSelection::HighlyVariable(40));
+    // the reference's call, argument for argument: pca_inplace(&mut adata, Some(10), None, None, None, &HighlyVariable(40), FaerSVD)
+    auto info = proc::dim_red::pca_inplace(adata, 10, {}, {}, {}, FeatureSelection::HighlyVariable(40), single_rust::memory::processing::dim_red::FaerSVD{});
     const Array2& pcs = adata.obsm().at("X_pca");
     EXPECT(pcs.nrows == 1000 && pcs.ncols == 10, "X_pca shape %zu x %zu", pcs.nrows, pcs.ncols);
     EXPECT(info.n_pc == 10 && info.k == 40, "pca info n_pc=%d k=%llu", info.n_pc, (unsigned long long)info.k);
