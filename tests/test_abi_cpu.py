@@ -154,3 +154,23 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt.lower().replace("no cpu oracle", ""), f"{f} mentions the oracle"
+
+
+def test_integration_excerpts_are_the_shim():
+    """INTEGRATION.md shows excerpts of rust/shim.rs, not a second version of it: every fenced rust block whose first
+    line is `// rust/shim.rs ...` must appear verbatim (after that line) in the file."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    shim = open(os.path.join(ROOT, "rust", "shim.rs")).read()
+    blocks = re.findall(r"```rust\n// rust/shim\.rs[^\n]*\n(.*?)```", doc, flags=re.S)
+    assert len(blocks) >= 5
+    for b in blocks:
+        assert b.rstrip("\n") in shim, b[:200]
+    # and the free functions carry the reference's signatures (src/memory/processing/mod.rs:303-332, dim_red/mod.rs:24)
+    for sig in ("pub fn normalize_total_inplace(adata: &mut IMAnnData, target_sum: f64, direction: Direction) -> anyhow::Result<()>",
+                "pub fn normalize_total(adata: &IMAnnData, target_sum: f64, direction: Direction) -> anyhow::Result<IMAnnData>",
+                "pub fn log1p_transform_inplace(adata: &mut IMAnnData) -> anyhow::Result<()>",
+                "pub fn log1p_transform(adata: &IMAnnData) -> anyhow::Result<IMAnnData>",
+                "pub fn compute_number(adata: &IMAnnData, direction: Direction) -> anyhow::Result<Vec<u32>>",
+                "pub fn compute_variance(adata: &IMAnnData, direction: Direction) -> anyhow::Result<Vec<f64>>",
+                "pub fn pca_inplace<S: SVDImplementation>(anndata: &mut IMAnnData, n_components: Option<usize>, center: Option<bool>,"):
+        assert sig in shim, sig
