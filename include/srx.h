@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SRX_ABI_VERSION 1
+#define SRX_ABI_VERSION 2      /* 2: srx_matrix_reserve_results, kernel classes 7-9, srx_synth_params.skew */
 
 typedef struct srx_ctx srx_ctx;   /* one GPU + stream + (optional) RCCL communicator      */
 typedef struct srx_mat srx_mat;   /* device-resident CSR (the `X` of an IMAnnData)        */

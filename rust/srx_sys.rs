@@ -5,7 +5,7 @@
 #![allow(non_camel_case_types, dead_code)]
 use std::os::raw::{c_char, c_void};
 
-pub const SRX_ABI_VERSION: i32 = 1;
+pub const SRX_ABI_VERSION: i32 = 2;
 pub const SRX_UNIQUE_ID_BYTES: usize = 128;
 pub const SRX_OK: i32 = 0;
 pub const SRX_E_ARG: i32 = -1;

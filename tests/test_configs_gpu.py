@@ -13,7 +13,7 @@ import pytest
 
 import oracle
 from oracle import COLUMN, ROW, pca_oracle
-from test_pca_gpu import TOL, adata_of, col_err, synth_host
+from test_pca_gpu import TOL, adata_of, assert_components_within_conditioning, col_err, synth_host
 from util import rel_err
 
 pytestmark = pytest.mark.gpu
@@ -53,10 +53,11 @@ def test_config0_shape_every_stage_against_the_oracle(ctx, store, vtol):
     assert np.array_equal(hv, oracle.select_hvg(want_var, 2000))
     want, wc, wevr, wmean, wstd = pca_oracle.pca_inplace(lg, 50, None, None, hv)
     assert np.allclose(evr, wevr, rtol=1e-5) and np.allclose(mean, wmean, rtol=1e-5, atol=1e-7) and np.allclose(std, wstd, rtol=1e-5)
-    gaps = np.minimum(np.abs(np.diff(wevr, prepend=np.inf)), np.abs(np.diff(wevr, append=0.0))) / wevr
-    iso = gaps > 1e-3                                                           # N = 2700: the tail eigenvalues crowd
-    assert iso[:10].all()
-    assert col_err(scores[:, iso], want[:, iso]) < 20 * TOL and col_err(comps[:, iso], wc[:, iso]) < 20 * TOL
+    # 1e-5 per component wherever the eigengap supports it (N = 2700: the tail eigenvalues crowd), the perturbation bound
+    # of the storage precision elsewhere — no blanket factor
+    gaps = assert_components_within_conditioning(scores, want, wevr, store, "score")
+    assert_components_within_conditioning(comps, wc, wevr, store, "loading")
+    assert (gaps[:10] > 1e-3).all()
     assert np.abs(wc @ (wc.T @ comps) - comps).max() < 1e-4
 
 
@@ -88,9 +89,9 @@ def test_config1_shape_against_the_oracle(ctx):
     wv, vv = w[order], v[:, order]
     assert np.allclose(mean, mu, rtol=1e-5, atol=1e-7) and np.allclose(std, sd, rtol=1e-5)
     assert np.allclose(evr, wv / np.trace(cov), rtol=1e-5)
-    assert col_err(comps, vv) < 10 * TOL
+    assert_components_within_conditioning(comps, vv, wv, 1, "loading")
     want_scores = (xs @ (vv / sd[:, None])) - (mu / sd) @ vv
-    assert col_err(scores, np.asarray(want_scores)) < 10 * TOL
+    assert_components_within_conditioning(scores, np.asarray(want_scores), wv, 1, "score")
 
 
 def test_wide_matrix_without_the_16bit_index_mirror(ctx, tmp_path):

@@ -32,6 +32,26 @@ def col_err(got, ref):
     return worst
 
 
+def assert_components_within_conditioning(got, ref, eigvals, store, what, tol=TOL):
+    """The north_star's 1e-5 bar per component, as far as the problem's conditioning allows (per-component
+    comparison up to sign, near-degenerate pairs judged by what their eigengap supports).  An eigenvector moves by
+    ~ ||dC|| / gap under a perturbation dC of the matrix; the inputs of the f32-storage path are the f64 oracle's values
+    rounded to f32 (2^-24 relative), those of the f64 path differ at 2^-53.  So component c must agree to
+        max(tol, 8 * eps_store / relgap_c),    relgap_c = distance to the nearest other eigenvalue / eigenvalue
+    — 1e-5 for every component whose gap exceeds 5e-2 (f32) / 1e-10 (f64), and the perturbation bound for the crowded tail."""
+    ev = np.asarray(eigvals, dtype=np.float64)
+    gap = np.minimum(np.abs(np.diff(ev, prepend=np.inf)), np.abs(np.diff(ev, append=0.0))) / ev
+    if len(ev) > 1:                                  # the eigenvalue below the last one is not known: take the gap above it
+        gap[-1] = abs(ev[-2] - ev[-1]) / ev[-1]
+    eps = 2.0 ** -24 if store == 1 else 2.0 ** -53
+    for c in range(ref.shape[1]):
+        sgn = 1.0 if np.dot(got[:, c], ref[:, c]) >= 0 else -1.0
+        e = np.linalg.norm(got[:, c] - sgn * ref[:, c]) / np.linalg.norm(ref[:, c])
+        bound = max(tol, 8.0 * eps / gap[c])
+        assert np.isfinite(e) and e < bound, f"{what} component {c}: error {e:.3e} > {bound:.3e} (relative eigengap {gap[c]:.2e})"
+    return gap
+
+
 def adata_of(m, ctx, store=0):
     import singlerust_amd as sr
     return sr.IMAnnData.new_basic((m.n_rows, m.n_cols, m.indptr, m.indices, m.values), ctx=ctx, store=store)
