@@ -42,7 +42,7 @@ struct srx_backed {
     std::vector<double> mu, sd, dinv;
     double trace = 0.0;
     // sweep 2
-    std::vector<srx::Tiled> parts;      // owned copies of the 256-tiled views
+    std::vector<srx::RowMajor> parts;   // owned copies of the row-major compacted rows of every tile (the transform walks them)
     double* d_gram = nullptr;
     size_t n_packed = 0;
 };
@@ -94,8 +94,9 @@ static int32_t backed_transform(srx_mat* m, double target_sum, int32_t transform
 
 static void free_parts(srx_backed* b) {
     for (auto& t : b->parts) {
-        (void)hipFree(t.tptr);
-        (void)hipFree(t.tpk);
+        (void)hipFree(t.ptr);
+        (void)hipFree(t.pk);
+        (void)hipFree(t.perm);
     }
     b->parts.clear();
 }
@@ -103,27 +104,35 @@ static void free_parts(srx_backed* b) {
 template <typename VT>
 static int32_t backed_gram_tile(srx_backed* b, srx_mat* m, RowXf xf) {
     srx_ctx* ctx = b->ctx;
-    Tiled t256;
     RowMajor rm;
-    if (b->dev_sel) SRX_TRY(build_tiled_fused(m, b->hv.d_bits, b->hv.n_words, b->k, rm, t256, xf));
-    else SRX_TRY(build_tiled_fused(m, b->remap, b->k, rm, t256, xf));
+    if (b->dev_sel) SRX_TRY(build_tiled_fused(m, b->hv.d_bits, b->hv.n_words, b->k, rm, nullptr, xf));
+    else SRX_TRY(build_tiled_fused(m, b->remap, b->k, rm, nullptr, xf));
     SRX_TRY(launch_gram<VT>(ctx, rm, b->d_gram));            // accumulates into the session's packed matrix
-    // keep the 256-tiled view of this tile: exact-size copies out of the scratch buffers
-    Tiled keep = t256;
-    keep.tptr = nullptr;
-    keep.tpk = nullptr;
-    const size_t ptr_bytes = ((size_t)t256.nt * t256.n_rows + 1) * sizeof(int64_t);
-    const size_t pk_bytes = (t256.nnz + 64) * sizeof(GramPk<VT>);
-    SRX_HIP(ctx, hipMalloc((void**)&keep.tptr, ptr_bytes));
-    hipError_t e = hipMalloc(&keep.tpk, pk_bytes);
+    SRX_TRY(build_row_order(ctx, rm));
+    // keep the row-major records of this tile for the transform: exact-size copies out of the scratch buffers
+    RowMajor keep = rm;
+    keep.ptr = nullptr;
+    keep.pk = nullptr;
+    keep.perm = nullptr;
+    keep.has_buckets = false;
+    const size_t ptr_bytes = (rm.n_rows + 1) * sizeof(int64_t);
+    const size_t pk_bytes = (rm.nnz + 64) * sizeof(GramPk<VT>);
+    const size_t perm_bytes = (rm.n_rows ? rm.n_rows : 1) * sizeof(uint32_t);
+    hipError_t e = hipMalloc((void**)&keep.ptr, ptr_bytes);
+    if (e == hipSuccess) e = hipMalloc(&keep.pk, pk_bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&keep.perm, perm_bytes);
     if (e != hipSuccess) {
-        (void)hipFree(keep.tptr);
+        (void)hipFree(keep.ptr);
+        (void)hipFree(keep.pk);
+        (void)hipFree(keep.perm);
         return fail(ctx, SRX_E_OOM, "backed: keeping a compacted tile: %s", hipGetErrorString(e));
     }
     b->parts.push_back(keep);
-    SRX_HIP(ctx, hipMemcpyAsync(keep.tptr, t256.tptr, ptr_bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    SRX_HIP(ctx, hipMemcpyAsync(keep.tpk, t256.tpk, pk_bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    b->nnz_sel += t256.nnz;
+    SRX_HIP(ctx, hipMemcpyAsync(keep.ptr, rm.ptr, ptr_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    SRX_HIP(ctx, hipMemcpyAsync(keep.pk, rm.pk, pk_bytes - 64 * sizeof(GramPk<VT>), hipMemcpyDeviceToDevice, ctx->stream));
+    SRX_HIP(ctx, hipMemsetAsync((char*)keep.pk + pk_bytes - 64 * sizeof(GramPk<VT>), 0, 64 * sizeof(GramPk<VT>), ctx->stream));
+    SRX_HIP(ctx, hipMemcpyAsync(keep.perm, rm.perm, perm_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    b->nnz_sel += rm.nnz;
     return SRX_OK;
 }
 
@@ -260,6 +269,10 @@ static int32_t backed_select_impl(srx_backed* b, uint64_t n_hvg, const uint64_t*
     b->k = k;
     if ((k + KG - 1) / KG > kWave)
         return fail(ctx, SRX_E_ARG, "backed: %d selected features exceed the %d the fused compaction takes", k, kWave * KG);
+    // the scores are written by the row-major forward kernel, whose panel slice (4 columns of all k genes per lane) must fit the LDS
+    if (!(b->store == SRX_STORE_F64 ? fwd_rows_fits<double, double>(k) : fwd_rows_fits<float, float>(k)))
+        return fail(ctx, SRX_E_ARG, "backed: %d selected features exceed the forward kernel's LDS panel slice (%s storage)", k,
+                    b->store == SRX_STORE_F64 ? "f64: 5119" : "f32: 10239");
     SRX_TRY(resolve_opts(ctx, opts, k, acc->n_rows_global, b->store == SRX_STORE_F32, b->o, b->l_act));
     if (opts && opts->solver == 2) return fail(ctx, SRX_E_ARG, "backed: only the Gram solver works on row tiles");
     if (b->o.solver != 1) { b->o.solver = 1; b->o.power = 3; b->o.warm = 2; }

@@ -34,6 +34,7 @@
 #include <algorithm>
 #include <cmath>
 #include <numeric>
+#include <type_traits>
 
 #include "common.hpp"
 #include "log1p64.hpp"
@@ -410,8 +411,10 @@ __global__ __launch_bounds__(256) void k_tfill(const int64_t* __restrict__ indpt
                     e.j = c;
                     e.v = v;
                     rm[row_base + rank] = e;
-                    e.j = c & 255;
-                    pk256[o256 + rank] = e;
+                    if (nt256 > 0) {
+                        e.j = c & 255;
+                        pk256[o256 + rank] = e;
+                    }
                 }
                 rank0 += __popcll(mask);
             }
@@ -611,6 +614,174 @@ __global__ __launch_bounds__(kFwdThreads, FwdCfg<PT>::kWavesPerSimd) void k_spmm
                     o.store(Y + row * L + 4 * q);
                 }
             }
+        }
+    }
+}
+
+// ---- forward SpMM from the ROW-MAJOR records: Y[:, slice] = A P[:, slice] - 1 c^T (round 2) -------------------------
+// The tile-major kernel above cuts the gene axis into 256-column tiles because a 64-column panel does not fit the LDS
+// (2000 x 64 x 4 B = 512 KB); a row then falls into ~8 segments of ~9 entries, visited in 16-slot chunks: 56 % of the
+// rotation steps carry a zero.  Here the PANEL COLUMNS are cut instead: a workgroup holds C = 4 Q columns of ALL k genes
+// (k x C x sizeof(PT): 128 KB at k = 2000 with C = 16 floats / 8 doubles) and walks whole rows; the n_pc / C column
+// slices of the same rows run on neighbouring workgroups (blockIdx = row group x n_slices + slice), so the matrix comes
+// out of L2 for all but the first of them.  A row is taken by Q adjacent lanes (lane q owns columns 4q .. 4q+3 of the
+// slice): they load Q consecutive records per step and broadcast them to each other in order (DPP quad_perm), one
+// ds_read_b128 of the panel row + 4 FMAs per record and lane — chunks of Q instead of 16: no padding worth mentioning.
+constexpr int kFwdRowsThreads = 1024;
+
+template <int Q>
+__device__ __forceinline__ int quad_bcast(int x, int s) {
+    if constexpr (Q == 1) {
+        return x;                                               // one lane per row: nothing to broadcast
+    } else if constexpr (Q == 4) {
+        switch (s) {                                            // v_mov_b32_dpp quad_perm:[s,s,s,s]
+            case 0: return __builtin_amdgcn_update_dpp(0, x, 0x00, 0xf, 0xf, false);
+            case 1: return __builtin_amdgcn_update_dpp(0, x, 0x55, 0xf, 0xf, false);
+            case 2: return __builtin_amdgcn_update_dpp(0, x, 0xaa, 0xf, 0xf, false);
+            default: return __builtin_amdgcn_update_dpp(0, x, 0xff, 0xf, 0xf, false);
+        }
+    } else {                                                    // pairs: lanes (2i, 2i+1) of every quad
+        return s == 0 ? __builtin_amdgcn_update_dpp(0, x, 0xa0, 0xf, 0xf, false)      // [0,0,2,2]
+                      : __builtin_amdgcn_update_dpp(0, x, 0xf5, 0xf, 0xf, false);     // [1,1,3,3]
+    }
+}
+template <int Q>
+__device__ __forceinline__ float quad_bcast_v(float x, int s) {
+    return __builtin_bit_cast(float, quad_bcast<Q>(__builtin_bit_cast(int, x), s));
+}
+template <int Q>
+__device__ __forceinline__ double quad_bcast_v(double x, int s) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = quad_bcast<Q>((int)(b & 0xffffffffll), s), hi = quad_bcast<Q>((int)(b >> 32), s);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Rows ordered by their number of kept entries (counting sort on the length, `perm`): the Q-lane groups of a wave then
+// hold rows of (nearly) equal length and the record loop is wave-uniform — with rows in natural order a wave runs as long as
+// the longest of its 16 rows (+30 %), and walking several rows per group as one stream instead puts a row-boundary test
+// into every step of 16 independent streams (that version: 1.44 ms against the tile-major kernel's 1.22).
+constexpr int kLenBins = 512;
+constexpr int kLenRowsPerWg = 4096;
+__global__ __launch_bounds__(256) void k_len_hist(const int64_t* __restrict__ rm_ptr, uint64_t n_rows,
+                                                  uint32_t* __restrict__ hist /* kLenBins, zeroed */) {
+    __shared__ uint32_t s[kLenBins];
+    for (int e = threadIdx.x; e < kLenBins; e += blockDim.x) s[e] = 0u;
+    __syncthreads();
+    const uint64_t r0 = (uint64_t)blockIdx.x * kLenRowsPerWg, r1 = r0 + kLenRowsPerWg < n_rows ? r0 + kLenRowsPerWg : n_rows;
+    for (uint64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+        const int64_t n = rm_ptr[r + 1] - rm_ptr[r];
+        atomicAdd(&s[n < kLenBins - 1 ? (int)n : kLenBins - 1], 1u);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < kLenBins; e += blockDim.x)
+        if (s[e]) atomicAdd(&hist[e], s[e]);
+}
+__global__ void k_len_scan(uint32_t* __restrict__ hist /* kLenBins counts -> exclusive offsets */) {
+    __shared__ uint32_t s[kLenBins];
+    const int t = threadIdx.x;
+    s[t] = hist[t];
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < kLenBins; ++i) { const uint32_t c = s[i]; s[i] = run; run += c; }
+    }
+    __syncthreads();
+    hist[t] = s[t];
+}
+// a workgroup reserves, per length, a run for its rows with ONE global atomic and fills it through LDS cursors
+__global__ __launch_bounds__(256) void k_len_scatter(const int64_t* __restrict__ rm_ptr, uint64_t n_rows,
+                                                     uint32_t* __restrict__ cursor, uint32_t* __restrict__ perm) {
+    __shared__ uint32_t s[kLenBins];
+    for (int e = threadIdx.x; e < kLenBins; e += blockDim.x) s[e] = 0u;
+    __syncthreads();
+    const uint64_t r0 = (uint64_t)blockIdx.x * kLenRowsPerWg, r1 = r0 + kLenRowsPerWg < n_rows ? r0 + kLenRowsPerWg : n_rows;
+    for (uint64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+        const int64_t n = rm_ptr[r + 1] - rm_ptr[r];
+        atomicAdd(&s[n < kLenBins - 1 ? (int)n : kLenBins - 1], 1u);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < kLenBins; e += blockDim.x) {
+        const uint32_t c = s[e];
+        s[e] = c ? atomicAdd(&cursor[e], c) : 0u;
+    }
+    __syncthreads();
+    for (uint64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+        const int64_t n = rm_ptr[r + 1] - rm_ptr[r];
+        perm[atomicAdd(&s[n < kLenBins - 1 ? (int)n : kLenBins - 1], 1u)] = (uint32_t)r;
+    }
+}
+
+template <typename VT, typename PT, int Q>
+__global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
+    const int64_t* __restrict__ rm_ptr, const GramPk<VT>* __restrict__ rm, const uint32_t* __restrict__ perm /* nullable */,
+    uint64_t n_rows, int k, const PT* __restrict__ P /* k x 64 */, const PT* __restrict__ cvec /* 64 */,
+    int n_cols /* panel columns wanted */, double* __restrict__ scores /* n_rows x ld f64 (nullable) */,
+    PT* __restrict__ Y /* n_rows x 64 (nullable) */, int ld) {
+    constexpr int C = 4 * Q;
+    extern __shared__ double lds_raw[];
+    PT* panel = reinterpret_cast<PT*>(lds_raw);                 // k x C
+    const int n_slices = (n_cols + C - 1) / C;
+    const int slice = blockIdx.x % n_slices;
+    const uint64_t wg = blockIdx.x / n_slices, n_wg = gridDim.x / n_slices;
+    for (int e = threadIdx.x; e < k * Q; e += kFwdRowsThreads) {
+        const int j = e / Q, cq = e % Q;
+        Vec4<PT> v;
+        v.load(P + (size_t)j * L + slice * C + cq * 4);
+        v.store(panel + (size_t)j * C + cq * 4);
+    }
+    __syncthreads();
+    const int ql = threadIdx.x % Q;                             // lane within the row's lane group
+    constexpr uint64_t kGroups = kFwdRowsThreads / Q;
+    const int col0 = slice * C + ql * 4;
+    Vec4<PT> cv4;
+    cv4.load(cvec + col0);
+    const PT* panel_q = panel + ql * 4;
+    // sorted position i -> row perm[i]; a wave's groups take consecutive positions (equal lengths), the workgroups
+    // interleave so that the long rows at the end are spread over all of them
+    for (uint64_t i = wg * kGroups + threadIdx.x / Q; i < n_rows; i += n_wg * kGroups) {
+        const uint64_t row = perm ? perm[i] : i;
+        const int64_t lo = rm_ptr[row];
+        const int n = (int)(rm_ptr[row + 1] - lo);
+        const GramPk<VT>* rr = rm + lo;
+        PT a0 = PT(0), a1 = PT(0), a2 = PT(0), a3 = PT(0);
+        // a chunk = 4 Q consecutive records of the row: lane ql holds records 4 ql .. 4 ql + 3 (one 32- / 64-byte load per
+        // lane), and the next chunk's load is in flight while this one's 4 Q records are broadcast and multiplied — with one
+        // Q-record step per load the loop ran at one memory round trip per step
+        struct Chunk { GramPk<VT> r[4]; };
+        auto load_chunk = [&](int at) {
+            Chunk c;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c.r[u] = rr[at + ql * 4 + u];        // (the array is padded by a wave of records)
+            return c;
+        };
+        Chunk cur = load_chunk(0);
+        for (int st = 0; st < n; st += 4 * Q) {
+            const Chunk nxt = load_chunk(st + 4 * Q);
+#pragma unroll
+            for (int s_ = 0; s_ < 4 * Q; ++s_) {
+                const int j = quad_bcast<Q>(cur.r[s_ & 3].j, s_ >> 2);
+                PT v = (PT)quad_bcast_v<Q>(cur.r[s_ & 3].v, s_ >> 2);
+                if (st + s_ >= n) v = PT(0);                    // past the row's end (j is then a valid column of a later row)
+                Vec4<PT> pv;
+                pv.load(panel_q + (size_t)j * C);
+                a0 += v * pv[0];
+                a1 += v * pv[1];
+                a2 += v * pv[2];
+                a3 += v * pv[3];
+            }
+            cur = nxt;
+        }
+        const PT o0 = a0 - cv4[0], o1 = a1 - cv4[1], o2 = a2 - cv4[2], o3 = a3 - cv4[3];
+        if (scores) {
+            double* dst = scores + row * (uint64_t)ld + col0;
+            if (col0 + 0 < n_cols) dst[0] = (double)o0;
+            if (col0 + 1 < n_cols) dst[1] = (double)o1;
+            if (col0 + 2 < n_cols) dst[2] = (double)o2;
+            if (col0 + 3 < n_cols) dst[3] = (double)o3;
+        } else {
+            Vec4<PT> o;
+            o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
+            o.store(Y + row * L + col0);
         }
     }
 }
@@ -1582,6 +1753,7 @@ struct RowMajor {
     int k = 0;
     int64_t* ptr = nullptr;    // n_rows + 1
     void* pk = nullptr;
+    uint32_t* perm = nullptr;  // rows ordered by their number of kept entries (forward SpMM), or null
     GramPlan plan;             // how the Gram kernel will cut G (fixed by k and n_rows)
     Buckets bk;                // owner buckets of the entries, if the compaction made them (else launch_gram does)
     bool has_buckets = false;
@@ -1774,10 +1946,12 @@ static int32_t alloc_tiled(srx_mat* m, uint64_t N, uint64_t nnz, int k, int kt, 
 
 // `d_sel`: n_words selection bits followed by n_words prefix counts, on the device (the compacted column of a
 // gene is its rank among the selected genes in ascending gene order)
-static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words, int k, RowMajor& rm, Tiled& t256, RowXf xf = RowXf{}) {
+static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words, int k, RowMajor& rm, Tiled* t256p, RowXf xf = RowXf{}) {
+    Tiled t256_dummy;
+    Tiled& t256 = t256p ? *t256p : t256_dummy;          // the 256-tiled view is only made for the matrix-free solver
     srx_ctx* ctx = m->ctx;
     const uint64_t N = m->n_rows;
-    const int nt128 = (k + KG - 1) / KG, nt256 = (k + KT - 1) / KT;
+    const int nt128 = (k + KG - 1) / KG, nt256 = t256p ? (k + KT - 1) / KT : 0;
     int64_t *cntrow, *cnt256, *d_total;
     const size_t sel_lds = 2 * (size_t)n_words * sizeof(uint32_t);
     if (sel_lds > 60000) return fail(ctx, SRX_E_ARG, "pca: %llu genes exceed the LDS selection table", (unsigned long long)m->n_cols);
@@ -1798,8 +1972,10 @@ static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words,
     SRX_TRY(scan_exclusive(ctx, cntrow, N, rm.ptr, &d_total));
     int64_t total = 0;
     SRX_TRY(d2h(ctx, &total, d_total, sizeof(int64_t)));
-    SRX_TRY(scan_exclusive(ctx, cnt256, n256, t256.tptr, nullptr));
-    SRX_TRY(alloc_tiled(m, N, (uint64_t)total, k, KT, t256));
+    if (t256p) {
+        SRX_TRY(scan_exclusive(ctx, cnt256, n256, t256.tptr, nullptr));
+        SRX_TRY(alloc_tiled(m, N, (uint64_t)total, k, KT, t256));
+    }
     const size_t pb = is_f32(m) ? sizeof(GramPk<float>) : sizeof(GramPk<double>);
     SRX_TRY(scratch(ctx, "pca_rm_pk", ((size_t)total + 64) * pb, &rm.pk));
     rm.n_rows = N;
@@ -1826,12 +2002,12 @@ static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words,
     else fill_t(double{}, (GramPk<double>*)rm.pk, (GramPk<double>*)t256.tpk);
     SRX_HIP(ctx, hipGetLastError());
     if (ctx->prof_mask & (1u << SRX_K_COMPACT))
-        ctx->prof[SRX_K_COMPACT].bytes += (double)total * (4.0 + val_bytes(m)) * 3.0;   // read once, written twice
+        ctx->prof[SRX_K_COMPACT].bytes += (double)total * (4.0 + val_bytes(m)) * (t256p ? 3.0 : 2.0);   // read once, written once or twice
     return SRX_OK;
 }
 
 // host-side selection (srx_pca with an explicit feature list): bitmask + prefix counts from the remap table
-static int32_t build_tiled_fused(srx_mat* m, const std::vector<int32_t>& remap, int k, RowMajor& rm, Tiled& t256, RowXf xf = RowXf{}) {
+static int32_t build_tiled_fused(srx_mat* m, const std::vector<int32_t>& remap, int k, RowMajor& rm, Tiled* t256, RowXf xf = RowXf{}) {
     srx_ctx* ctx = m->ctx;
     const int n_words = (int)((remap.size() + 31) / 32);
     std::vector<uint32_t> hsel(2 * (size_t)n_words, 0u);
@@ -1868,6 +2044,65 @@ static int32_t launch_fwd(srx_ctx* ctx, const Tiled& c, const PT* P, const PT* c
                                      (int)lds));
     hipLaunchKernelGGL((k_spmm_fwd<VT, PT>), dim3((unsigned)grid), dim3(kFwdThreads), lds, ctx->stream, c.tptr,
                        (const GramPk<VT>*)c.tpk, c.n_rows, c.nt, c.k, P, cvec, Y, scores, n_pc, ld ? ld : n_pc);
+    SRX_HIP(ctx, hipGetLastError());
+    return SRX_OK;
+}
+
+// Forward product from the row-major records (k_spmm_rows); false when the panel slice does not fit the LDS (the caller
+// falls back on the tile-major kernel).
+// Lanes per row of the row-major forward kernel: the widest panel slice (4 Q columns of all k genes) that fits the LDS;
+// 0 when even one lane's four columns do not (the caller falls back on the tile-major kernel).
+template <typename PT>
+static int fwd_rows_q(int k) {
+    const size_t budget = 163840 - 64;
+    for (int q = sizeof(PT) == 4 ? 4 : 2; q >= 1; q >>= 1)
+        if ((size_t)k * 4 * q * sizeof(PT) <= budget) return q;
+    return 0;
+}
+template <typename VT, typename PT>
+static bool fwd_rows_fits(int k) { return fwd_rows_q<PT>(k) > 0; }
+template <typename VT, typename PT>
+static int32_t launch_fwd_rows(srx_ctx* ctx, const RowMajor& r, const PT* P, const PT* cvec, int n_cols, double* scores, PT* Y,
+                               int ld) {
+    const int Qr = fwd_rows_q<PT>(r.k);
+    if (Qr == 0) return fail(ctx, SRX_E_ARG, "pca: %d selected features exceed the LDS panel slice of the row-major forward kernel", r.k);
+    auto go = [&](auto qtag) -> int32_t {
+        constexpr int Q = decltype(qtag)::value;
+        constexpr int C = 4 * Q;
+        const int n_slices = (n_cols + C - 1) / C;
+        const size_t lds = (size_t)r.k * C * sizeof(PT);
+        const uint64_t groups = kFwdRowsThreads / Q;
+        uint64_t n_wg = (r.n_rows + groups - 1) / groups;
+        const uint64_t cap = std::max<uint64_t>(1, (uint64_t)ctx->n_cus / n_slices);      // one workgroup per CU
+        if (n_wg > cap) n_wg = cap;
+        if (n_wg < 1) n_wg = 1;
+        const double out_bytes = scores ? (double)r.n_rows * n_cols * 8.0 : (double)r.n_rows * L * sizeof(PT);
+        ProfScope ps(ctx, SRX_K_SPMM_FWD, (double)r.nnz * sizeof(GramPk<VT>) + (double)(r.n_rows + 1) * 8.0 + out_bytes +
+                                              (double)r.k * L * sizeof(PT) + (r.perm ? (double)r.n_rows * 4.0 : 0.0));
+        SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_spmm_rows<VT, PT, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_spmm_rows<VT, PT, Q>), dim3((unsigned)(n_wg * n_slices)), dim3(kFwdRowsThreads), lds, ctx->stream, r.ptr,
+                           (const GramPk<VT>*)r.pk, (const uint32_t*)r.perm, r.n_rows, r.k, P, cvec, n_cols, scores, Y, ld);
+        SRX_HIP(ctx, hipGetLastError());
+        return SRX_OK;
+    };
+    if (Qr == 4) {
+        if constexpr (sizeof(PT) == 4) return go(std::integral_constant<int, 4>{});
+        else return SRX_E_ARG;
+    }
+    if (Qr == 2) return go(std::integral_constant<int, 2>{});
+    return go(std::integral_constant<int, 1>{});
+}
+
+// rows ordered by their number of kept entries (k_spmm_rows); r.ptr must be complete
+static int32_t build_row_order(srx_ctx* ctx, RowMajor& r) {
+    uint32_t* hist;
+    SRX_TRY(scratch(ctx, "pca_rm_lenhist", kLenBins * sizeof(uint32_t), (void**)&hist));
+    SRX_TRY(scratch(ctx, "pca_rm_perm", (r.n_rows ? r.n_rows : 1) * sizeof(uint32_t), (void**)&r.perm));
+    SRX_HIP(ctx, hipMemsetAsync(hist, 0, kLenBins * sizeof(uint32_t), ctx->stream));
+    const unsigned g = (unsigned)((r.n_rows + kLenRowsPerWg - 1) / kLenRowsPerWg + (r.n_rows ? 0 : 1));
+    hipLaunchKernelGGL(k_len_hist, dim3(g), dim3(256), 0, ctx->stream, r.ptr, r.n_rows, hist);
+    hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(kLenBins), 0, ctx->stream, hist);
+    hipLaunchKernelGGL(k_len_scatter, dim3(g), dim3(256), 0, ctx->stream, r.ptr, r.n_rows, hist, r.perm);
     SRX_HIP(ctx, hipGetLastError());
     return SRX_OK;
 }
@@ -2375,13 +2610,14 @@ static int32_t ensure_result_capacity(srx_ctx* ctx, srx_pca_state& st, size_t ne
 static int32_t launch_writeback(srx_mat* m);
 
 template <typename VT, typename PT>
-static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const RowMajor* rmp, double* gram_packed,
+static int32_t run_pca(srx_ctx* ctx, const RowMajor* parts, int n_parts, const Tiled* t256p, double* gram_packed,
                        const Resolved& o, const std::vector<double>& mu, const std::vector<double>& dinv,
                        const HvgDev* hv, int l_act, double n_cells, srx_pca_state& st) {
-    // `parts`: the 256-tiled views of this rank's rows — one for a resident matrix, one per row tile in backed
-    // mode (then `gram_packed` holds the packed Gram matrix already summed over the row tiles and `rmp` is null)
-    const Tiled& t256 = parts[0];
-    const int k = t256.k;
+    // `parts`: the row-major compacted rows of this rank — one for a resident matrix, one per row tile in backed mode (then
+    // `gram_packed` holds the packed Gram matrix already summed over the row tiles); `t256p`: the 256-tiled view, made for
+    // the matrix-free solver and for selections too wide for the row kernel's LDS panel slice
+    const RowMajor* rmp = n_parts == 1 ? &parts[0] : nullptr;
+    const int k = parts[0].k;
     struct { uint64_t n_rows, max_rows; } cc{0, 0};
     for (int i = 0; i < n_parts; ++i) {
         cc.n_rows += parts[i].n_rows;
@@ -2436,10 +2672,16 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const RowM
         hipLaunchKernelGGL((k_make_panel<PT>), dim3(1), dim3(1024), 0, ctx->stream, w.A2, w.d, w.mu, (const double*)w.dSgn,
                            k, o.center, P, cvec);
         SRX_HIP(ctx, hipGetLastError());
+        // scores = Z V: the transform from the row-major records, one launch per row tile (the tile-major kernel — 1.22 ms
+        // at c3 against 0.84 — when its view was made: matrix-free solver, panel slice larger than the LDS, SRX_FWD_TILED)
         uint64_t row0 = 0;
-        for (int i = 0; i < n_parts; ++i) {
-            SRX_TRY((launch_fwd<VT, PT>(ctx, parts[i], P, cvec, Y, st.d_scores + row0 * (size_t)n_pc + col0, n_r, n_pc)));
-            row0 += parts[i].n_rows;
+        if (t256p) {
+            SRX_TRY((launch_fwd<VT, PT>(ctx, *t256p, P, cvec, Y, st.d_scores + col0, n_r, n_pc)));
+        } else {
+            for (int i = 0; i < n_parts; ++i) {
+                SRX_TRY((launch_fwd_rows<VT, PT>(ctx, parts[i], P, cvec, n_r, st.d_scores + row0 * (size_t)n_pc + col0, (PT*)nullptr, n_pc)));
+                row0 += parts[i].n_rows;
+            }
         }
         double* blk = d_small + (size_t)r * (kl + 2 * L);
         SRX_HIP(ctx, hipMemcpyAsync(blk, w.A2, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -2566,7 +2808,8 @@ static int32_t run_pca(srx_ctx* ctx, const Tiled* parts, int n_parts, const RowM
         Range r_("srx:iterate");
         SRX_TRY(solve(apply, C, true, reset, deflate));
     } else {
-        if (n_parts != 1) return fail(ctx, SRX_E_ARG, "pca: the SpMM solver needs the matrix resident in one piece");
+        if (n_parts != 1 || !t256p) return fail(ctx, SRX_E_ARG, "pca: the SpMM solver needs the matrix resident in one piece");
+        const Tiled& t256 = *t256p;
         if (ctx->wb_after_gram) {
             srx_mat* wm = ctx->wb_after_gram;
             ctx->wb_after_gram = nullptr;
@@ -2840,10 +3083,13 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     Tiled t256;
     RowMajor rm;
     Range r_compact("srx:compact");
+    // the 256-tiled view only where something reads it
+    const bool fits_rows = is_f32(m) ? fwd_rows_fits<float, float>(k) : fwd_rows_fits<double, double>(k);
+    const bool need_t256 = o.solver == 2 || !fits_rows || getenv("SRX_FWD_TILED") != nullptr;
     if (dev_sel) {
-        SRX_TRY(build_tiled_fused(m, hv.d_bits, hv.n_words, k, rm, t256, xf));
+        SRX_TRY(build_tiled_fused(m, hv.d_bits, hv.n_words, k, rm, need_t256 ? &t256 : nullptr, xf));
     } else if ((k + KG - 1) / KG <= kWave) {
-        SRX_TRY(build_tiled_fused(m, remap, k, rm, t256, xf));
+        SRX_TRY(build_tiled_fused(m, remap, k, rm, need_t256 ? &t256 : nullptr, xf));
     } else {
         // the general route reads stored values: the matrix is transformed in place first
         if (xf.row_sum) {
@@ -2852,8 +3098,9 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
         }
         CompactCsr cc;
         SRX_TRY(build_compact(m, remap, k, cc, rm));
-        SRX_TRY(retile(m, cc, KT, t256));
+        if (need_t256) SRX_TRY(retile(m, cc, KT, t256));
     }
+    if (!need_t256) SRX_TRY(build_row_order(ctx, rm));      // the transform walks rows by length
     // nothing below reads X.  The in-place write-back of the transformed values is queued on the side stream once the
     // Gram kernel is (run_pca): it then runs beside the k x 64 iteration — ~100 small launches that leave HBM idle —
     // instead of beside the Gram kernel, whose suffix gathers the streaming pass slowed by 3 ms when the two overlapped.
@@ -2863,7 +3110,7 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     st.info.k = (uint32_t)k;
     st.info.n_pc = (uint32_t)o.n_pc;
     st.info.block = L;
-    st.info.nnz_selected = t256.nnz;
+    st.info.nnz_selected = rm.nnz;
     st.info.solver = (uint32_t)o.solver;
     int32_t rc;
     const HvgDev* hvp = dev_sel ? &hv : nullptr;
@@ -2871,9 +3118,9 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     // panels in f64 (f32 products of Z W level the residuals of the small components off at ~1e-7 theta_1 / theta_i:
     // 6.6e-5 at k = 9000 on a flat-tailed matrix, however many sweeps)
     if (is_f32(m) && o.solver == 2)
-        rc = run_pca<float, double>(ctx, &t256, 1, &rm, nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
-    else if (is_f32(m)) rc = run_pca<float, float>(ctx, &t256, 1, &rm, nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
-    else rc = run_pca<double, double>(ctx, &t256, 1, &rm, nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
+        rc = run_pca<float, double>(ctx, &rm, 1, need_t256 ? &t256 : nullptr, nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
+    else if (is_f32(m)) rc = run_pca<float, float>(ctx, &rm, 1, need_t256 ? &t256 : nullptr, nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
+    else rc = run_pca<double, double>(ctx, &rm, 1, need_t256 ? &t256 : nullptr, nullptr, o, mu_eff, dinv, hvp, l_act, Nd, st);
     if ((rc != SRX_OK && rc != SRX_E_NOCONV) || !st.d_small) return rc;      // d_small unset: the solve broke down early
     SRX_TRY(stash_results(ctx, st, k, o.n_pc, dev_sel ? &hv : nullptr, mu, sd, trace, selv));
     return rc;
@@ -3019,7 +3266,7 @@ int32_t srx_spmm(srx_mat* m, const uint64_t* sel, uint64_t k64, const double* pa
     Tiled c256;
     RowMajor crm;
     if ((k + KG - 1) / KG <= kWave) {
-        SRX_TRY(build_tiled_fused(m, remap, k, crm, c256));
+        SRX_TRY(build_tiled_fused(m, remap, k, crm, &c256));
     } else {
         CompactCsr cc;
         SRX_TRY(build_compact(m, remap, k, cc, crm));
