@@ -115,26 +115,32 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     // associative, so the moments do not depend on the order the atomics land in — two genes with identical columns get
     // identical sums, as in the reference's sequential loops (HighlyVariable(n) breaks exact ties by gene index), and the
     // run is reproducible to the bit.  [Raw f32 values widened to f64 sum exactly anyway: the plain path keeps f64 adds.]
+    // The magic constant's bit pattern is NOT subtracted per value: the accumulators sum bits(1.5 * 2^52 + x * 2^shift) =
+    // bits(1.5 * 2^52) + round(x * 2^shift) in wrapping 64-bit arithmetic and k_moments_reduce takes count x bits(1.5 * 2^52)
+    // off again (the per-gene counts are known).  Positions are tested as 32-bit offsets from the segment start.
     auto add_chunk = [&](int64_t e0, int64_t lo, int64_t hi, const Chunk& c, double scale) {
+        const int rel = (int)(e0 - lo);                    // >= -3
+        const unsigned len = (unsigned)(hi - lo);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int64_t pos = e0 + j;
-            if (pos >= lo && pos < hi) {
+            if ((unsigned)(rel + j) < len) {
                 const int32_t g0 = c.gg[j] - gbase;
                 double x0 = (double)c.v[j];
                 if constexpr (XF) {
-                    x0 = sizeof(T) == 4 ? log1p_f64_lite(x0 * scale, s_tab) : log1p_f64_fast(x0 * scale, s_tab);
-                    if (!(fabs(x0) < 64.0)) {          // NaN, infinite, or outside the fixed-point range: the gene's moments are NaN
+                    x0 = sizeof(T) == 4 ? log1p_f64_moment(x0 * scale, s_tab) : log1p_f64_fast(x0 * scale, s_tab);
+                    if (__builtin_expect(!(fabs(x0) < 64.0), 0)) {     // NaN, infinite, or outside the fixed-point range: the gene's moments are NaN
                         poison[(uint64_t)gbase + g0] = 1u;
                         continue;
                     }
                     // round-to-nearest integer of x * 2^shift through the 1.5 * 2^52 trick (|x * 2^shift| < 2^51)
                     const double kMagic = 6755399441055744.0;
-                    const long long is = __double_as_longlong(__builtin_fma(x0, fx_sum, kMagic)) - __double_as_longlong(kMagic);
-                    const long long iq = __double_as_longlong(__builtin_fma(x0 * x0, fx_sq, kMagic)) - __double_as_longlong(kMagic);
+                    const unsigned long long is = (unsigned long long)__double_as_longlong(__builtin_fma(x0, fx_sum, kMagic));
+                    const unsigned long long iq = (unsigned long long)__double_as_longlong(__builtin_fma(x0 * x0, fx_sq, kMagic));
+                    // (a poisoned value adds nothing while the reduction still takes its magic bits off: the gene's sums are
+                    //  replaced by NaN anyway)
                     if constexpr (COUNT) __hip_atomic_fetch_add(&s_cnt[g0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&s_sum[g0]), (unsigned long long)is, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&s_sq[g0]), (unsigned long long)iq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&s_sum[g0]), is, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&s_sq[g0]), iq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     continue;
                 }
                 if constexpr (COUNT) __hip_atomic_fetch_add(&s_cnt[g0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -204,9 +210,14 @@ __global__ void k_moments_reduce(const uint32_t* __restrict__ part_cnt, const do
         long long is = 0, iq = 0;
         for (uint64_t b = 0; b < n_blocks; ++b) {
             if (!cnt_cached) c += part_cnt[b * n_cols + j];
-            is += __double_as_longlong(part_sum[b * n_cols + j]);
-            iq += __double_as_longlong(part_sq[b * n_cols + j]);
+            is = (long long)((unsigned long long)is + (unsigned long long)__double_as_longlong(part_sum[b * n_cols + j]));
+            iq = (long long)((unsigned long long)iq + (unsigned long long)__double_as_longlong(part_sq[b * n_cols + j]));
         }
+        // every contribution carried the bit pattern of the 1.5 * 2^52 rounding constant along (k_gene_moments): off again
+        const unsigned long long cn = cnt_cached ? (unsigned long long)cnt_cached[j] : (unsigned long long)c;
+        const unsigned long long magic_bits = (unsigned long long)__double_as_longlong(6755399441055744.0);
+        is = (long long)((unsigned long long)is - cn * magic_bits);
+        iq = (long long)((unsigned long long)iq - cn * magic_bits);
         s = (double)is * inv_fx_sum;
         q = (double)iq * inv_fx_sq;
         if (poison[j]) s = q = __builtin_nan("");

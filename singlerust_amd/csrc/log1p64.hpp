@@ -212,6 +212,32 @@ __device__ __forceinline__ float apply_log1p<float>(float x) {
 template <>
 __device__ __forceinline__ double apply_log1p<double>(double x) { return log1p(x); }
 
+// out-of-line: the rare arguments of the routine below (keeps the hot loop's code and register footprint small)
+static __device__ __attribute__((noinline)) double log1p_f64_rare(double x, const Log1pTabEntry* tab) {
+    return x == 0.0 ? 0.0 : log1p_f64_fast(x, tab);
+}
+
+// ln_1p for the per-gene moments of the pipeline, written for the instruction count: the argument's class is read off the
+// high word of x (one unsigned compare: 2^-10 <= x < inf), exponent / table index / mantissa come from the high word of
+// u = 1 + x with 32-bit operations, degree-5 polynomial (same arithmetic as log1p_f64_lite: <= 2e-13 for those arguments);
+// everything else (x < 2^-10, negative, NaN, inf) takes the full routine.
+__device__ __forceinline__ double log1p_f64_moment(double x, const Log1pTabEntry* __restrict__ tab) {
+    const unsigned xh = (unsigned)__double2hiint(x);
+    if (__builtin_expect(xh - 0x3f500000u >= 0x7ff00000u - 0x3f500000u, 0)) return log1p_f64_rare(x, tab);
+    const double u = 1.0 + x;
+    const int uh = __double2hiint(u);
+    const int e = (uh >> 20) - 1023;
+    const int i = (uh >> 13) & 127;
+    const double m = __hiloint2double((uh & 0x000fffff) | 0x3ff00000, __double2loint(u));
+    const Log1pTabEntry t = tab[i];
+    const double r = __builtin_fma(m, t.inv, -1.0);
+    double p = __builtin_fma(r, 1.0 / 5, -1.0 / 4);
+    p = __builtin_fma(r, p, 1.0 / 3);
+    p = __builtin_fma(r, p, -0.5);
+    const double lr = __builtin_fma(r * r, p, r);
+    return __builtin_fma((double)e, 0x1.62e42fefa39efp-1, t.lg) + lr;
+}
+
 // The transform of one value of a row whose scale is `scale`: y = ln_1p(f64(v) * scale).  Count data takes few distinct
 // values per cell, so every wave that works on a row first builds the row's table y(c) = ln_1p(c * scale) for c = 0 .. 63
 // (ONE evaluation per lane: `xf_row_table`), and a value that is a small non-negative integer fetches its result from
