@@ -114,7 +114,6 @@ static int32_t backed_gram_tile(srx_backed* b, srx_mat* m, RowXf xf) {
     keep.ptr = nullptr;
     keep.pk = nullptr;
     keep.perm = nullptr;
-    keep.has_buckets = false;
     const size_t ptr_bytes = (rm.n_rows + 1) * sizeof(int64_t);
     const size_t pk_bytes = (rm.nnz + 64) * sizeof(GramPk<VT>);
     const size_t perm_bytes = (rm.n_rows ? rm.n_rows : 1) * sizeof(uint32_t);

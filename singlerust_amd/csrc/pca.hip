@@ -250,11 +250,30 @@ __global__ __launch_bounds__(256) void k_retile(const int64_t* __restrict__ indp
 constexpr int kGramWaves = 16;            // waves per Gram workgroup
 constexpr int kGramUnroll = 8;            // suffix loads in flight per wave
 
-struct GramRec { uint32_t pos, len; };    // entry position relative to its block's first entry; entries from it to the row's end
+// One unit of Gram work: entry (ja, va) times up to 64 consecutive entries of its row's suffix (the suffix starts at the
+// entry itself — the diagonal product — and a suffix longer than a wave is cut into several records).
+// pos: first suffix entry of this record, relative to its block's first entry; lenrb = lanes | rbase << 8, where
+// rbase + jb is the index of G[ja][jb] among the owner's LDS accumulators (gram_row_base: may be negative, jb >= ja).
+template <typename VT> struct GramRec { uint32_t pos, lenrb; VT va; };
+// records of a row with n kept entries: sum over suffix lengths L = 1 .. n of ceil(L / 64)
+__host__ __device__ __forceinline__ uint64_t gram_row_records(uint64_t n) {
+    const uint64_t q = n >> 6, r = n & 63;
+    return 32 * q * (q + 1) + r * (q + 1);
+}
 
 __device__ __forceinline__ int gram_owner(int c, int sr_shift, int n_wg, int n_stripes) {
     const int s = c >> sr_shift;
     return s < n_wg ? s : n_stripes - 1 - s;
+}
+
+// accumulator layout of an owner: stripe A (rows a0 .. a0 + SR - 1, WA = k - a0 columns from a0), then stripe B (rows from
+// b0 = the mirrored stripe, WB = k - b0 columns): the offset to which a column index jb >= ja is added
+__device__ __forceinline__ int gram_row_base(int ja, int k, int sr_shift, int n_wg, int n_stripes) {
+    const int s = ja >> sr_shift, SR = 1 << sr_shift;
+    const int s0 = s << sr_shift;                       // first row of ja's stripe
+    if (s < n_wg) return (ja - s0) * (k - s0) - s0;
+    const int a0 = (n_stripes - 1 - s) << sr_shift;     // the owner's stripe A
+    return SR * (k - a0) + (ja - s0) * (k - s0) - s0;
 }
 
 struct SelLds {
@@ -902,15 +921,59 @@ template <typename VT> struct GramPk;
 __device__ __forceinline__ double gram_product(float a, float b) { return (double)(a * b); }
 __device__ __forceinline__ double gram_product(double a, double b) { return a * b; }
 
-// Entries of a block of kBucketRows cells, grouped by owning workgroup (counting sort in LDS; the order inside
-// a group is whatever the LDS atomics make it — the Gram sums are order-dependent in their last bits anyway).
-// boff[rb][w] .. boff[rb][w + 1]: records of owner w, relative to the block's first entry.
+// Records of a block of `rblk` cells, grouped by owning workgroup (counting sort in LDS; the order inside a group is
+// whatever the LDS atomics make it — the Gram sums are order-dependent in their last bits anyway).
+// boff[rb][w] .. boff[rb][w + 1]: records of owner w, relative to the block's first record (rec_base[rb]).
 constexpr int kBucketThreads = 1024;
-constexpr int kBucketUnroll = 4;          // entries in flight per thread
+constexpr int kBucketGroup = 4;           // consecutive rows a wave walks as one flat run
+constexpr int kBucketUnroll = 4;          // 64-entry chunks of the run in flight
+
+// per-block record totals (k_bucket's layout needs their prefix sums before it runs)
+__global__ __launch_bounds__(256) void k_rec_count(const int64_t* __restrict__ rm_ptr, uint64_t n_rows, uint32_t rblk,
+                                                   int64_t* __restrict__ blk_total) {
+    const uint64_t r0 = (uint64_t)blockIdx.x * rblk;
+    const uint64_t r1 = r0 + rblk < n_rows ? r0 + rblk : n_rows;
+    uint64_t acc = 0;
+    for (uint64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) acc += gram_row_records((uint64_t)(rm_ptr[r + 1] - rm_ptr[r]));
+    acc = wave_sum(acc);
+    __shared__ uint64_t part[4];
+    if (lane_id() == 0) part[threadIdx.x / kWave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) blk_total[blockIdx.x] = (int64_t)(part[0] + part[1] + part[2] + part[3]);
+}
+// exclusive scan of the block totals by one workgroup: base[0 .. n], base[n] = all records
+__global__ __launch_bounds__(1024) void k_rec_scan(const int64_t* __restrict__ blk_total, uint64_t n, int64_t* __restrict__ base) {
+    __shared__ int64_t wsum[16];
+    __shared__ int64_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = lane_id(), wave = threadIdx.x / kWave;
+    for (uint64_t i0 = 0; i0 < n; i0 += 1024) {
+        const uint64_t i = i0 + threadIdx.x;
+        const int64_t v = i < n ? blk_total[i] : 0;
+        int64_t inc = v;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const int64_t o = __shfl_up(inc, off, kWave);
+            if (lane >= off) inc += o;
+        }
+        if (lane == kWave - 1) wsum[wave] = inc;
+        __syncthreads();
+        int64_t before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (i < n) base[i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) base[n] = carry_s;
+}
+
 template <typename VT>
 __global__ __launch_bounds__(kBucketThreads) void k_bucket(const int64_t* __restrict__ rm_ptr, const GramPk<VT>* __restrict__ rm,
-                                                           uint64_t n_rows, uint32_t rblk, int sr_shift, int n_wg, int n_stripes,
-                                                           uint32_t* __restrict__ boff, GramRec* __restrict__ recs) {
+                                                           uint64_t n_rows, uint32_t rblk, int k, int sr_shift, int n_wg, int n_stripes,
+                                                           const int64_t* __restrict__ rec_base, uint32_t* __restrict__ boff,
+                                                           GramRec<VT>* __restrict__ recs) {
     extern __shared__ double lds_raw[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(lds_raw);        // n_wg + 1 counters, then rblk + 1 row ends
     uint32_t* rptr = hist + n_wg + 1;                             // row starts of the block, relative to its first entry
@@ -921,26 +984,42 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket(const int64_t* __rest
     const int lane = lane_id(), wave = threadIdx.x / kWave;
     const int64_t base = rm_ptr[r0];
     for (int e = threadIdx.x; e <= n_wg; e += kBucketThreads) hist[e] = 0u;
-    for (int e = threadIdx.x; e <= nr; e += kBucketThreads) rptr[e] = (uint32_t)(rm_ptr[r0 + e] - base);
+    for (int e = threadIdx.x; e <= nr + kBucketGroup; e += kBucketThreads)
+        rptr[e] = (uint32_t)(rm_ptr[r0 + (e < nr ? e : nr)] - base);          // padded by a group of empty rows
     __syncthreads();
-    // the block's entries are ONE contiguous run of the row-major array: walk it flat (coalesced, no pointer chase),
-    // kBucketUnroll column loads in flight per thread
-    const uint32_t total = rptr[nr];
     const GramPk<VT>* rmb = rm + base;
-    constexpr uint32_t kStep = kBucketThreads * kBucketUnroll;
-    for (uint32_t p0 = threadIdx.x; p0 < total; p0 += kStep) {
-        int c[kBucketUnroll];
+    // A wave takes kBucketGroup consecutive rows at a time: their entries are one contiguous run, walked flat 64 at a time
+    // (coalesced), and the row of an entry is found by comparing with the group's three inner row starts — the suffix
+    // length of an entry (its record count) needs the row's end.  `visit(p, j, v, row_end)` for every entry of the block.
+    auto walk = [&](auto visit) {
+        for (int g0 = wave * kBucketGroup; g0 < nr; g0 += (kBucketThreads / kWave) * kBucketGroup) {
+            uint32_t b[kBucketGroup + 1];
 #pragma unroll
-        for (int u = 0; u < kBucketUnroll; ++u) {
-            const uint32_t p = p0 + u * kBucketThreads;
-            c[u] = p < total ? rmb[p].j : -1;
+            for (int i = 0; i <= kBucketGroup; ++i) b[i] = rptr[g0 + i];
+            for (uint32_t p0 = b[0]; p0 < b[kBucketGroup]; p0 += kBucketUnroll * kWave) {
+                GramPk<VT> x[kBucketUnroll];
+#pragma unroll
+                for (int u = 0; u < kBucketUnroll; ++u) {
+                    const uint32_t p = p0 + u * kWave + lane;
+                    x[u].j = -1;
+                    if (p < b[kBucketGroup]) x[u] = rmb[p];
+                }
+#pragma unroll
+                for (int u = 0; u < kBucketUnroll; ++u) {
+                    const uint32_t p = p0 + u * kWave + lane;
+                    if (x[u].j < 0) continue;
+                    uint32_t end = b[1];
+#pragma unroll
+                    for (int i = 1; i < kBucketGroup; ++i) end = p >= b[i] ? b[i + 1] : end;
+                    visit(p, x[u].j, x[u].v, end);
+                }
+            }
         }
-#pragma unroll
-        for (int u = 0; u < kBucketUnroll; ++u)
-            if (c[u] >= 0)
-                __hip_atomic_fetch_add(&hist[gram_owner(c[u], sr_shift, n_wg, n_stripes)], 1u, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    };
+    walk([&](uint32_t p, int j, VT, uint32_t end) {
+        __hip_atomic_fetch_add(&hist[gram_owner(j, sr_shift, n_wg, n_stripes)], (end - p + 63u) >> 6, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+    });
     __syncthreads();
     // exclusive scan of the n_wg counters by wave 0, 64 at a time
     if (wave == 0) {
@@ -963,26 +1042,15 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket(const int64_t* __rest
         if (lane == 0) boff[rb * (uint64_t)(n_wg + 1) + n_wg] = carry;
     }
     __syncthreads();
-    GramRec* rcb = recs + base;
-    int r = 0;                                     // row of entry p: p moves forward, so does r
-    for (uint32_t p0 = threadIdx.x; p0 < total; p0 += kStep) {
-        int c[kBucketUnroll];
-#pragma unroll
-        for (int u = 0; u < kBucketUnroll; ++u) {
-            const uint32_t p = p0 + u * kBucketThreads;
-            c[u] = p < total ? rmb[p].j : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < kBucketUnroll; ++u) {
-            const uint32_t p = p0 + u * kBucketThreads;
-            if (c[u] >= 0) {
-                while (rptr[r + 1] <= p) ++r;
-                const uint32_t slot = __hip_atomic_fetch_add(&hist[gram_owner(c[u], sr_shift, n_wg, n_stripes)], 1u,
-                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                rcb[slot] = GramRec{p, rptr[r + 1] - p};
-            }
-        }
-    }
+    GramRec<VT>* rcb = recs + rec_base[rb];
+    walk([&](uint32_t p, int j, VT v, uint32_t end) {
+        const uint32_t len = end - p, nch = (len + 63u) >> 6;
+        uint32_t slot = __hip_atomic_fetch_add(&hist[gram_owner(j, sr_shift, n_wg, n_stripes)], nch, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t rb8 = (uint32_t)gram_row_base(j, k, sr_shift, n_wg, n_stripes) << 8;
+        for (uint32_t o = 0; o < len; o += kWave, ++slot)
+            rcb[slot] = GramRec<VT>{p + o, (len - o < (uint32_t)kWave ? len - o : (uint32_t)kWave) | rb8, v};
+    });
 }
 
 __device__ __forceinline__ float readfirst_v(float x) {
@@ -994,18 +1062,35 @@ __device__ __forceinline__ double readfirst_v(double x) {
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
+// entries [0, len) of `base`, lane l taking entry l; lanes >= len return zeros without touching memory
+__device__ __forceinline__ GramPk<float> suffix_load(const GramPk<float>* base, uint32_t len, int lane) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<GramPk<float>*>(base), (short)0, (int)(len * 8u), 0x00020000);
+    const auto x = __builtin_amdgcn_raw_buffer_load_b64(rs, lane * 8, 0, 0);
+    return GramPk<float>{(int)x[0], __builtin_bit_cast(float, (unsigned)x[1])};
+}
+__device__ __forceinline__ GramPk<double> suffix_load(const GramPk<double>* base, uint32_t len, int lane) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<GramPk<double>*>(base), (short)0, (int)(len * 16u), 0x00020000);
+    const auto x = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, 0, 0);
+    GramPk<double> e;
+    e.j = (int)x[0];
+    e.pad_ = 0;
+    e.v = __builtin_bit_cast(double, ((unsigned long long)(unsigned)x[3] << 32) | (unsigned)x[2]);
+    return e;
+}
+
 // index of (i, j), i <= j, in the packed upper triangle (row-major, row i holds columns i .. k - 1)
 __host__ __device__ __forceinline__ size_t tri_index(int i, int j, int k) {
     return (size_t)i * (size_t)k - (size_t)i * (size_t)(i - 1) / 2 + (size_t)(j - i);
 }
 
-template <typename VT, bool kCoop>
+template <typename VT>
 __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     const int64_t* __restrict__ rm_ptr, const GramPk<VT>* __restrict__ rm, const uint32_t* __restrict__ boff,
-    const GramRec* __restrict__ recs, uint64_t n_rblk, uint32_t rblk, int k, int sr_shift, int n_wg, int n_stripes, int n_z,
-    int* __restrict__ pace /* one arrival counter per window, zeroed; nullptr = free-running */, int lag, uint32_t n_chunk,
+    const int64_t* __restrict__ rec_base, const GramRec<VT>* __restrict__ recs, uint64_t n_rblk, uint32_t rblk, int k,
+    int sr_shift, int n_wg, int n_stripes, uint32_t n_chunk,
     double* __restrict__ Gp /* packed upper triangle, ACCUMULATED into (global f64 atomics) */) {
     using Entry = GramPk<VT>;
+    using Rec = GramRec<VT>;
     extern __shared__ double acc[];
     const int w = blockIdx.x % n_wg, z = blockIdx.x / n_wg;
     const int SR = 1 << sr_shift;
@@ -1016,160 +1101,114 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     __syncthreads();
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const int a_end = a0 + SR;
-    // accumulator of (ja, jb): stripe A rows are WA wide and start at column a0, stripe B rows WB wide from b0
-    auto row_base = [&](int ja) { return ja < a_end ? (ja - a0) * WA - a0 : SR * WA + (ja - b0) * WB - b0; };
-    // kGramUnroll records (lanes u0 .. of `rec`; records past the run have len 0): their suffix loads go out together,
-    // then one masked LDS atomic instruction per record
-    auto batch = [&](const Entry* __restrict__ rmb, const GramRec& rec, int u0) {
-        Entry e[kGramUnroll];
-        uint32_t pos[kGramUnroll], len[kGramUnroll];
-#pragma unroll
-        for (int u = 0; u < kGramUnroll; ++u) {
-            pos[u] = (uint32_t)__builtin_amdgcn_readlane((int)rec.pos, u0 + u);
-            len[u] = (uint32_t)__builtin_amdgcn_readlane((int)rec.len, u0 + u);
-            e[u] = rmb[pos[u] + lane];       // unconditional (the array is padded by a wave of records): no branch
-        }                                    // around the loads, and the waits below count them
-#pragma unroll
-        for (int u = 0; u < kGramUnroll; ++u) {
-            const int ja = __builtin_amdgcn_readfirstlane(e[u].j);      // lane 0 holds the entry itself
-            const VT va = readfirst_v(e[u].v);
-            const int rbase = row_base(ja);
-            if ((uint32_t)lane < len[u])
-                __hip_atomic_fetch_add(&acc[rbase + e[u].j], gram_product(va, e[u].v), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (len[u] > (uint32_t)kWave)
-                for (uint32_t o = kWave; o < len[u]; o += kWave) {          // suffixes longer than a wave: rare
-                    if (o + lane < len[u]) {
-                        const Entry x = rmb[pos[u] + o + lane];
-                        __hip_atomic_fetch_add(&acc[rbase + x.j], gram_product(va, x.v), __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                }
-        }
+    // Workgroup = (owner w, chunk z of n_chunk consecutive row blocks); blockIdx = z * n_wg + w, so the dispatcher starts
+    // all owners of a chunk together and they walk its rows in the same order: what one workgroup pulls into its
+    // XCD's L2 the ~60 others on that XCD hit (free-running persistent workgroups drift tens of MB apart: L2 hit rate
+    // 12 %, 50 GB of fabric reads per launch at c3).  Wave v takes blocks v, v + 16, ... of the chunk.
+    //
+    // A wave reads its records 64 at a time (one 12-byte vector load per lane, the slab after this one in flight while this
+    // one is worked through) and hands them out kGramUnroll at a time: v_readlane makes (pos, len, rbase, va) of a record
+    // wave-uniform, the suffix load takes (scalar base, 32-bit lane offset), and what is left per record is lane < len, the
+    // product, its conversion and the LDS address.  Two batches are in flight: one being fetched, one being added.
+    // (Records fetched by scalar loads, one batch ahead: the stream alone cost 3.1 ms — every batch a dependent round trip
+    // through the scalar cache; slabs fetched only when the previous one was used up: 4 of 5 slab loads exposed.)
+    struct Blk {
+        uint32_t n;
+        const Entry* rmb;
+        const Rec* rc;
     };
-    if constexpr (kCoop) {
-        // All waves of the workgroup are in the SAME row block, a wave taking every kGramWaves-th batch of the block's
-        // run, and all workgroups stay within `lag` windows of each other (window j = row blocks j n_z .. j n_z + n_z - 1):
-        // the rows of a window are then fetched into each XCD's L2 once and hit by the ~60 workgroups of that XCD — left
-        // to themselves the workgroups drift tens of blocks apart (their shares differ by a few per cent) and every
-        // suffix read goes out to the Infinity Cache (L2 hit rate 12 %, 50 GB of fabric reads per launch at c3).
-        // The pacing is a HINT: a wave waits a bounded time for the slowest workgroup, then goes on regardless.
-        __shared__ int s_arrive[8];
-        if (threadIdx.x < 8) s_arrive[threadIdx.x] = 0;
-        __syncthreads();
-        const int n_total = n_wg * n_z;
-        int j = 0;
-        for (uint64_t rb = (uint64_t)z; rb < n_rblk; rb += (uint64_t)n_z, ++j) {
-            if (pace && j >= lag) {
-                const int* flag = pace + (j - lag);
-                for (int it = 0; it < 1024 && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_total; ++it)
-                    __builtin_amdgcn_s_sleep(4);
-            }
+    const uint64_t rb0 = (uint64_t)z * n_chunk, rb1 = rb0 + n_chunk < n_rblk ? rb0 + n_chunk : n_rblk;
+    auto scalars = [&](uint64_t rb) -> Blk {
+        Blk k_{0u, rm, recs};
+        if (rb < rb1) {
             const uint32_t* bo = boff + rb * (uint64_t)(n_wg + 1) + w;
             const uint32_t o0 = bo[0], o1 = bo[1];
-            const int64_t base = rm_ptr[rb * rblk];
-            const Entry* rmb = rm + base;
-            const GramRec* rc = recs + base;
-            for (uint32_t i0 = o0 + (uint32_t)wave * kGramUnroll; i0 < o1; i0 += kGramWaves * kGramUnroll) {
-                GramRec rec{0u, 0u};
-                if (lane < kGramUnroll && i0 + lane < o1) rec = rc[i0 + lane];
-                batch(rmb, rec, 0);
-            }
-            if (pace && lane == 0) {
-                // the last wave of the workgroup to finish window j reports it
-                const int seen = __hip_atomic_fetch_add(&s_arrive[j & 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (seen == kGramWaves - 1) {
-                    __hip_atomic_store(&s_arrive[j & 7], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(pace + j, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
+            k_.n = o1 - o0;
+            k_.rmb = rm + rm_ptr[rb * rblk];
+            k_.rc = recs + rec_base[rb] + o0;
         }
-    } else {
-        // A wave owns a row block at a time and streams its run of records through a two-deep software pipeline: the
-        // suffix loads of batch b + 1 are in flight while the atomics of batch b issue, and the next slab of 64 records
-        // is fetched a slab ahead — a wave that waits for every batch's loads before it issues the next ones moves
-        // kGramUnroll records per memory round trip (~2 us under load), which bounded the first version at 7.3 ms.
-        struct Buf {
-            Entry e[kGramUnroll];
-            uint32_t pos[kGramUnroll], len[kGramUnroll];
-        };
-        auto issue = [&](Buf& bf, const Entry* __restrict__ rmb, const GramRec& rec, int u0) {
-#pragma unroll
-            for (int u = 0; u < kGramUnroll; ++u) {
-                bf.pos[u] = (uint32_t)__builtin_amdgcn_readlane((int)rec.pos, u0 + u);
-                bf.len[u] = (uint32_t)__builtin_amdgcn_readlane((int)rec.len, u0 + u);
-                bf.e[u] = rmb[bf.pos[u] + lane];
-            }
-        };
-        auto process = [&](const Buf& bf, const Entry* __restrict__ rmb) {
-#pragma unroll
-            for (int u = 0; u < kGramUnroll; ++u) {
-                const int ja = __builtin_amdgcn_readfirstlane(bf.e[u].j);
-                const VT va = readfirst_v(bf.e[u].v);
-                const int rbase = row_base(ja);
-                if ((uint32_t)lane < bf.len[u])
-                    __hip_atomic_fetch_add(&acc[rbase + bf.e[u].j], gram_product(va, bf.e[u].v), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (bf.len[u] > (uint32_t)kWave)
-                    for (uint32_t o = kWave; o < bf.len[u]; o += kWave) {
-                        if (o + lane < bf.len[u]) {
-                            const Entry x = rmb[bf.pos[u] + o + lane];
-                            __hip_atomic_fetch_add(&acc[rbase + x.j], gram_product(va, x.v), __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                    }
-            }
-        };
-        // Workgroup = (owner w, chunk z of n_chunk consecutive row blocks); blockIdx = z * n_wg + w, so the dispatcher starts
-        // all owners of a chunk together and they walk its rows in the same order: what one workgroup pulls into its
-        // XCD's L2 the ~60 others on that XCD hit (free-running persistent workgroups drift tens of MB apart: L2 hit rate
-        // 12 %, 50 GB of fabric reads per launch at c3).  Wave v takes blocks v, v + 16, ... of the chunk; the offsets and
-        // the record slab of its NEXT block are fetched while the current one is multiplied.
-        struct Blk {
-            uint32_t n;
-            const Entry* rmb;
-            const GramRec* rc;
-        };
-        const uint64_t rb0 = (uint64_t)z * n_chunk, rb1 = rb0 + n_chunk < n_rblk ? rb0 + n_chunk : n_rblk;
-        auto scalars = [&](uint64_t rb) -> Blk {
-            Blk k_{0u, rm, recs};
-            if (rb < rb1) {
-                const uint32_t* bo = boff + rb * (uint64_t)(n_wg + 1) + w;
-                const uint32_t o0 = bo[0], o1 = bo[1];
-                const int64_t base = rm_ptr[rb * rblk];
-                k_.n = o1 - o0;
-                k_.rmb = rm + base;
-                k_.rc = recs + base + o0;
-            }
-            return k_;
-        };
-        auto slab = [&](const Blk& k_, uint32_t i0) {
-            GramRec r{0u, 0u};
-            if (i0 + lane < k_.n) r = k_.rc[i0 + lane];
-            return r;
-        };
-        uint64_t rb = rb0 + wave;
-        Blk cur = scalars(rb), nxt = scalars(rb + kGramWaves);
-        GramRec rec = slab(cur, 0);
-        while (rb < rb1) {
-            const GramRec rec_nxt = slab(nxt, 0);                  // next block's first slab: in flight during this block
-            const Blk nxt2 = scalars(rb + 2 * kGramWaves);
-            for (uint32_t i0 = 0; i0 < cur.n; i0 += kWave) {
-                if (i0 > 0) rec = slab(cur, i0);                   // blocks with more than 64 records of this owner: rare
-                const int n = (int)(cur.n - i0 < (uint32_t)kWave ? cur.n - i0 : (uint32_t)kWave);
-                for (int u0 = 0; u0 < n; u0 += 2 * kGramUnroll) {
-                    Buf A, B;
-                    issue(A, cur.rmb, rec, u0);
-                    if (u0 + kGramUnroll < n) issue(B, cur.rmb, rec, u0 + kGramUnroll);
-                    process(A, cur.rmb);
-                    if (u0 + kGramUnroll < n) process(B, cur.rmb);
-                }
-            }
+        return k_;
+    };
+    uint64_t rb = rb0 + wave;
+    uint32_t i0 = 0;
+    Blk cur = scalars(rb), nxt = scalars(rb + kGramWaves);
+    struct Slab {                         // up to 64 records of one block, lane l holding record l
+        Rec r;
+        uint32_t n;
+        const Entry* rmb;
+    };
+    auto next_slab = [&]() -> Slab {
+        while (i0 >= cur.n && rb < rb1) {
             rb += kGramWaves;
             cur = nxt;
-            nxt = nxt2;
-            rec = rec_nxt;
+            nxt = scalars(rb + kGramWaves);
+            i0 = 0;
+        }
+        Slab sl;
+        sl.rmb = cur.rmb;
+        sl.n = i0 < cur.n ? (cur.n - i0 < (uint32_t)kWave ? cur.n - i0 : (uint32_t)kWave) : 0u;
+        sl.r = Rec{0u, 0u, (VT)0};
+        if ((uint32_t)lane < sl.n) sl.r = cur.rc[i0 + lane];
+        i0 += kWave;
+        return sl;
+    };
+    struct Loaded {                       // a batch of records with their suffix entries on the way
+        Entry e[kGramUnroll];
+        uint32_t lenrb[kGramUnroll];
+        VT va[kGramUnroll];
+    };
+    auto batch = [&](const Slab& sl, int u0) -> Loaded {
+        Loaded l;
+#pragma unroll
+        for (int u = 0; u < kGramUnroll; ++u) {       // lanes past sl.n hold empty records: len 0, pos 0
+            const uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.pos, u0 + u);
+            l.lenrb[u] = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.lenrb, u0 + u);
+            l.va[u] = readlane_v(sl.r.va, u0 + u);
+            // a buffer load whose range is the suffix itself: lanes past `len` are out of range and fetch nothing (the L1
+            // works through a wave's load 64 bytes at a time — reading all 64 lanes of every ~36-entry suffix was 2 of the
+            // kernel's 4.2 ms), the address is (scalar base, constant lane offset), and there is no branch or exec mask
+            // around the load for the compiler's wait counting to trip over
+            l.e[u] = suffix_load(sl.rmb + pos, l.lenrb[u] & 0xffu, lane);
+        }
+        return l;
+    };
+    auto process = [&](const Loaded& l) {
+#pragma unroll
+        for (int u = 0; u < kGramUnroll; ++u) {
+            const int rbase = (int)l.lenrb[u] >> 8;
+            const uint32_t len = l.lenrb[u] & 0xffu;
+            if ((uint32_t)lane < len)
+                __hip_atomic_fetch_add(&acc[rbase + l.e[u].j], gram_product(l.va[u], l.e[u].v), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    // All batches of slab `sl`, two in flight (ping-pong between two register sets: a `now = next` copy makes the compiler
+    // wait for next's loads).  The OTHER slab (used up before this one) is refilled right after this slab's first batch has
+    // gone out: when its records are first read, a slab later, every load issued after it has long been waited for — the
+    // compiler waits for ALL outstanding loads at that point (vmcnt is in order and it cannot count across the loop), so a
+    // refill issued last would be a full round trip exposed per slab.
+    auto consume = [&](const Slab& sl, Slab& other) {
+        const int n = (int)sl.n;
+        Loaded A = batch(sl, 0), B;
+        other = next_slab();
+#pragma unroll
+        for (int u0 = 0; u0 < kWave; u0 += 2 * kGramUnroll) {
+            // no branch around a batch's loads (slots past n are empty records, their loads hit the block's first line):
+            // after a conditional load the compiler's wait for A's entries also waits for B's
+            B = batch(sl, u0 + kGramUnroll);
+            process(A);
+            if (u0 + 2 * kGramUnroll < kWave) A = batch(sl, u0 + 2 * kGramUnroll);
+            process(B);
+            if (u0 + 2 * kGramUnroll >= n) break;
+        }
+    };
+    {
+        Slab S = next_slab(), T;
+        T.n = 0;
+        while (S.n > 0) {
+            consume(S, T);
+            if (T.n == 0) break;
+            consume(T, S);
         }
     }
     __syncthreads();
@@ -1734,18 +1773,13 @@ struct Tiled {
 };
 // How G's upper triangle is cut into stripes of SR rows and paired into workgroups (k_gram_stripes)
 struct GramPlan {
-    int k = 0, sr_shift = 0, n_stripes = 0, n_wg = 0, n_z = 1;
-    bool coop = true;          // all waves of a workgroup share a row block (else: a row block per wave)
+    int k = 0, sr_shift = 0, n_stripes = 0, n_wg = 0;
+    int n_z = 1;               // chunks: the grid is n_wg x n_z workgroups
     uint32_t rblk = 1024;      // cells per bucket block
-    uint32_t n_chunk = 0;      // chunked mode: consecutive row blocks per workgroup
+    uint32_t n_chunk = 0;      // consecutive row blocks per workgroup
     uint64_t n_rblk = 0;
     size_t lds_bytes = 0;
 };
-struct Buckets {
-    uint32_t* off = nullptr;   // n_rblk x (n_wg + 1)
-    GramRec* recs = nullptr;   // nnz
-};
-
 // X[:, sel] row by row: GramPk<VT> records (compacted column in [0, k), value), columns ascending within a row —
 // what the Gram kernel walks (a suffix of a row is one contiguous run)
 struct RowMajor {
@@ -1754,9 +1788,6 @@ struct RowMajor {
     int64_t* ptr = nullptr;    // n_rows + 1
     void* pk = nullptr;
     uint32_t* perm = nullptr;  // rows ordered by their number of kept entries (forward SpMM), or null
-    GramPlan plan;             // how the Gram kernel will cut G (fixed by k and n_rows)
-    Buckets bk;                // owner buckets of the entries, if the compaction made them (else launch_gram does)
-    bool has_buckets = false;
 };
 static int32_t gram_plan(srx_ctx* ctx, int k, uint64_t n_rows, GramPlan& g) {
     g.k = k;
@@ -1777,28 +1808,17 @@ static int32_t gram_plan(srx_ctx* ctx, int k, uint64_t n_rows, GramPlan& g) {
     }
     g.lds_bytes = (size_t)sr * widest * 8;
     if (g.lds_bytes > 163840) return fail(ctx, SRX_E_ARG, "pca: %d selected features exceed the Gram kernel's LDS stripes", k);
-    static const int force_coop = getenv("SRX_GRAM_COOP") ? atoi(getenv("SRX_GRAM_COOP")) : 0;
     static const int force_rblk = getenv("SRX_GRAM_RBLK") ? atoi(getenv("SRX_GRAM_RBLK")) : 0;
-    g.coop = force_coop != 0;
     g.rblk = force_rblk > 0 ? (uint32_t)force_rblk : 1024u;
     g.n_rblk = (n_rows + g.rblk - 1) / g.rblk;
-    static const int force_z = getenv("SRX_GRAM_Z") ? atoi(getenv("SRX_GRAM_Z")) : 0;
     const int per_cu = g.lds_bytes <= 65536 ? 2 : 1;
-    int z;
-    if (g.coop) {
-        // row splits: enough workgroups for two per CU (when they fit)
-        z = (ctx->n_cus * per_cu + g.n_wg - 1) / g.n_wg;
-        if (force_z > 0) z = force_z;
-        if ((uint64_t)z > g.n_rblk) z = (int)g.n_rblk;
-    } else {
-        // chunks of consecutive row blocks: ~16k cells each, at least one block per wave, and enough chunks to fill the device
-        static const int force_chunk = getenv("SRX_GRAM_CHUNK") ? atoi(getenv("SRX_GRAM_CHUNK")) : 0;
-        uint64_t chunk = force_chunk > 0 ? (uint64_t)force_chunk : std::max<uint64_t>(16384 / g.rblk, kGramWaves);      // c3: 4.5 ms with 16k-cell chunks, 5.2 with 32k, 5.0 with 8k
-        const uint64_t want_wgs = (uint64_t)ctx->n_cus * per_cu;
-        while (chunk > kGramWaves && ((g.n_rblk + chunk - 1) / chunk) * (uint64_t)g.n_wg < want_wgs) chunk /= 2;
-        g.n_chunk = (uint32_t)chunk;
-        z = (int)((g.n_rblk + chunk - 1) / chunk);
-    }
+    // chunks of consecutive row blocks: ~16k cells each, at least one block per wave, and enough chunks to fill the device
+    static const int force_chunk = getenv("SRX_GRAM_CHUNK") ? atoi(getenv("SRX_GRAM_CHUNK")) : 0;
+    uint64_t chunk = force_chunk > 0 ? (uint64_t)force_chunk : std::max<uint64_t>(16384 / g.rblk, kGramWaves);      // c3: 4.5 ms with 16k-cell chunks, 5.2 with 32k, 5.0 with 8k
+    const uint64_t want_wgs = (uint64_t)ctx->n_cus * per_cu;
+    while (chunk > kGramWaves && ((g.n_rblk + chunk - 1) / chunk) * (uint64_t)g.n_wg < want_wgs) chunk /= 2;
+    g.n_chunk = (uint32_t)chunk;
+    int z = (int)((g.n_rblk + chunk - 1) / chunk);
     if (z < 1) z = 1;
     g.n_z = z;
     return SRX_OK;
@@ -2139,39 +2159,39 @@ static int32_t launch_t(srx_ctx* ctx, const Tiled& c, const YT* Y, double* T /* 
 // caller zeroes it for a fresh sum): owner buckets, then the stripe kernel.
 template <typename VT>
 static int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp) {
-    GramPlan g = rm.plan;
-    Buckets b = rm.bk;
-    if (!rm.has_buckets) SRX_TRY(gram_plan(ctx, rm.k, rm.n_rows, g));
     if (rm.n_rows == 0) return SRX_OK;
-    // algorithmic bytes: the compacted matrix and the owner records read once, G written once.  Every row suffix is read
-    // once per kept entry of its row (from L2 / Infinity Cache): that shows up in the PMC traffic, not here.
-    ProfScope ps(ctx, SRX_K_GRAM, (double)rm.nnz * (sizeof(GramPk<VT>) + sizeof(GramRec)) +
-                                      (double)(rm.n_rows + 1) * 8.0 + (double)rm.k * (rm.k + 1) / 2 * 8.0);
-    if (!rm.has_buckets) {           // general compaction route: a separate bucket pass over the row-major records
-        SRX_TRY(scratch(ctx, "pca_boff", g.n_rblk * (size_t)(g.n_wg + 1) * sizeof(uint32_t), (void**)&b.off));
-        SRX_TRY(scratch(ctx, "pca_brecs", (rm.nnz ? rm.nnz : 1) * sizeof(GramRec), (void**)&b.recs));
-        hipLaunchKernelGGL((k_bucket<VT>), dim3((unsigned)g.n_rblk), dim3(kBucketThreads), (size_t)(g.n_wg + 1 + g.rblk + 1) * sizeof(uint32_t), ctx->stream,
-                           rm.ptr, (const GramPk<VT>*)rm.pk, rm.n_rows, g.rblk, g.sr_shift, g.n_wg, g.n_stripes, b.off, b.recs);
-    }
-    // pacing of the workgroups (cooperative mode): only when every workgroup is resident at once
-    static const int lag = getenv("SRX_GRAM_LAG") ? atoi(getenv("SRX_GRAM_LAG")) : 1;
-    int* d_pace = nullptr;
-    const int per_cu = g.lds_bytes <= 65536 ? 2 : 1;
-    if (g.coop && lag > 0 && g.n_wg * g.n_z <= ctx->n_cus * per_cu) {
-        const size_t n_win = (size_t)((g.n_rblk + g.n_z - 1) / g.n_z);
-        SRX_TRY(scratch(ctx, "pca_gpace", (n_win + 1) * sizeof(int), (void**)&d_pace));
-        SRX_HIP(ctx, hipMemsetAsync(d_pace, 0, (n_win + 1) * sizeof(int), ctx->stream));
-    }
-    auto go = [&](auto kern) -> int32_t {
-        SRX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
-        hipLaunchKernelGGL(kern, dim3((unsigned)(g.n_wg * g.n_z)), dim3(kGramWaves * kWave), g.lds_bytes, ctx->stream,
-                           rm.ptr, (const GramPk<VT>*)rm.pk, b.off, b.recs, g.n_rblk, g.rblk, rm.k, g.sr_shift, g.n_wg, g.n_stripes,
-                           g.n_z, d_pace, lag, g.n_chunk, Gp);
+    GramPlan g;
+    SRX_TRY(gram_plan(ctx, rm.k, rm.n_rows, g));
+    uint32_t* boff;
+    int64_t *blk_total, *rec_base;
+    GramRec<VT>* recs;
+    SRX_TRY(scratch(ctx, "pca_boff", g.n_rblk * (size_t)(g.n_wg + 1) * sizeof(uint32_t), (void**)&boff));
+    SRX_TRY(scratch(ctx, "pca_brtot", g.n_rblk * sizeof(int64_t), (void**)&blk_total));
+    SRX_TRY(scratch(ctx, "pca_brbase", (g.n_rblk + 1) * sizeof(int64_t), (void**)&rec_base));
+    int64_t n_recs = 0;
+    {
+        // how many records each block makes (a suffix longer than a wave is several), and where its records start
+        ProfScope ps(ctx, SRX_K_GRAM, (double)(rm.n_rows + 1) * 8.0);
+        hipLaunchKernelGGL(k_rec_count, dim3((unsigned)g.n_rblk), dim3(256), 0, ctx->stream, rm.ptr, rm.n_rows, g.rblk, blk_total);
+        hipLaunchKernelGGL(k_rec_scan, dim3(1), dim3(1024), 0, ctx->stream, blk_total, g.n_rblk, rec_base);
         SRX_HIP(ctx, hipGetLastError());
-        return SRX_OK;
-    };
-    if (g.coop) SRX_TRY(go(k_gram_stripes<VT, true>));
-    else SRX_TRY(go(k_gram_stripes<VT, false>));
+    }
+    SRX_TRY(d2h(ctx, &n_recs, rec_base + g.n_rblk, sizeof(int64_t)));
+    SRX_TRY(scratch(ctx, "pca_brecs", ((size_t)n_recs + kGramUnroll) * sizeof(GramRec<VT>), (void**)&recs));
+    // algorithmic bytes: the compacted matrix read twice (bucket pass, stripe kernel), the records written and read once,
+    // G written once.  Every row suffix is read once per kept entry of its row (from L2 / Infinity Cache): that shows up in
+    // the PMC traffic, not here.
+    ProfScope ps(ctx, SRX_K_GRAM, (double)rm.nnz * 2.0 * sizeof(GramPk<VT>) + (double)n_recs * 2.0 * sizeof(GramRec<VT>) +
+                                      (double)(rm.n_rows + 1) * 8.0 + (double)rm.k * (rm.k + 1) / 2 * 8.0);
+    SRX_HIP(ctx, hipMemsetAsync(recs + n_recs, 0, kGramUnroll * sizeof(GramRec<VT>), ctx->stream));
+    hipLaunchKernelGGL((k_bucket<VT>), dim3((unsigned)g.n_rblk), dim3(kBucketThreads),
+                       (size_t)(g.n_wg + 1 + g.rblk + 1 + kBucketGroup) * sizeof(uint32_t), ctx->stream, rm.ptr,
+                       (const GramPk<VT>*)rm.pk, rm.n_rows, g.rblk, rm.k, g.sr_shift, g.n_wg, g.n_stripes, rec_base, boff, recs);
+    SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_stripes<VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
+    hipLaunchKernelGGL((k_gram_stripes<VT>), dim3((unsigned)(g.n_wg * g.n_z)), dim3(kGramWaves * kWave), g.lds_bytes, ctx->stream,
+                       rm.ptr, (const GramPk<VT>*)rm.pk, boff, rec_base, recs, g.n_rblk, g.rblk, rm.k, g.sr_shift, g.n_wg,
+                       g.n_stripes, g.n_chunk, Gp);
+    SRX_HIP(ctx, hipGetLastError());
     return SRX_OK;
 }
 static size_t gram_packed_count(int k) { return (size_t)k * (size_t)(k + 1) / 2; }
