@@ -654,8 +654,8 @@ __global__ void k_hvg_take(const uint32_t* __restrict__ rank, uint32_t G, uint32
 // (pca/mod.rs:87-91: mean = sum/N, var = sumsq/N - mean^2, ddof 0); trace = sum_s dinv_s^2 ss_s, summed in a
 // fixed tree.  n_words <= 2048 (G <= 65536).
 __global__ __launch_bounds__(1024) void k_sel_finish(const uint8_t* __restrict__ flag, const double* __restrict__ sum,
-                                                     const double* __restrict__ sq, uint32_t G, int n_words, double n_cells,
-                                                     int center, int scale, uint32_t* __restrict__ bits,
+                                                     const double* __restrict__ sq, uint32_t G, uint32_t take, int n_words,
+                                                     double n_cells, int center, int scale, uint32_t* __restrict__ bits,
                                                      uint32_t* __restrict__ prefix, double* __restrict__ mu,
                                                      double* __restrict__ sd, double* __restrict__ dinv,
                                                      double* __restrict__ trace) {
@@ -700,6 +700,15 @@ __global__ __launch_bounds__(1024) void k_sel_finish(const uint8_t* __restrict__
     const uint32_t excl = before + inc - (c0 + c1);
     if (2 * t < n_words) s_pre[2 * t] = excl;
     if (2 * t + 1 < n_words) s_pre[2 * t + 1] = excl + c0;
+    __syncthreads();
+    // never more than `take` selected genes, whatever the flags say (a ranking broken by NaN variances can flag more): the
+    // passes over the matrix test the bit alone and the compacted columns must stay below `take`
+    for (int w = t; w < n_words; w += 1024) {
+        uint32_t b_ = s_bits[w];
+        const uint32_t e = s_pre[w], room = e < take ? take - e : 0u;
+        while ((uint32_t)__popc(b_) > room) b_ &= ~(1u << (31 - __clz((int)b_)));
+        s_bits[w] = b_;
+    }
     __syncthreads();
     for (int w = t; w < n_words; w += 1024) {
         bits[w] = s_bits[w];
@@ -763,7 +772,7 @@ int32_t select_hvg_device(srx_mat* m, uint64_t n, int center, int scale, HvgDev&
     hipLaunchKernelGGL(k_hvg_rank, dim3(gb, gy), dim3(256), 0, ctx->stream, d_var, (uint32_t)G, d_rank);
     hipLaunchKernelGGL(k_hvg_take, dim3(gb), dim3(256), 0, ctx->stream, d_rank, (uint32_t)G, (uint32_t)take, out.d_sel_rank,
                        d_flag);
-    hipLaunchKernelGGL(k_sel_finish, dim3(1), dim3(1024), 0, ctx->stream, d_flag, m->d_sum, m->d_sq, (uint32_t)G, n_words,
+    hipLaunchKernelGGL(k_sel_finish, dim3(1), dim3(1024), 0, ctx->stream, d_flag, m->d_sum, m->d_sq, (uint32_t)G, (uint32_t)take, n_words,
                        (double)m->n_rows_global, center, scale, out.d_bits, out.d_bits + n_words, out.d_mu, out.d_sd,
                        out.d_dinv, out.d_trace);
     SRX_HIP(ctx, hipGetLastError());

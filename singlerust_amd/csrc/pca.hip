@@ -302,6 +302,45 @@ __device__ __forceinline__ uint64_t next_compact_row(uint64_t r, uint64_t n_wave
     return ((r + 1) % kCompactRows) ? r + 1 : r + 1 + (n_waves - 1) * kCompactRows;
 }
 
+// Kept entries per row, nothing else (the row-major layout's row lengths; the tile counters of k_tcount are only wanted by
+// the matrix-free solver's 256-tiled view): the bit of the gene in the selection mask is the whole test — one LDS read per
+// entry, no prefix lookup, no LDS atomic.  The mask holds at most k bits (k_sel_finish / the host route make sure).
+template <typename I>
+__global__ __launch_bounds__(256) void k_rowcount(const int64_t* __restrict__ indptr, const I* __restrict__ idx,
+                                                  const uint32_t* __restrict__ g_bits, int n_words, uint64_t n_rows,
+                                                  int64_t* __restrict__ cntrow) {
+    extern __shared__ double lds_raw[];
+    uint32_t* bits = reinterpret_cast<uint32_t*>(lds_raw);
+    for (int e = threadIdx.x; e < n_words; e += blockDim.x) bits[e] = g_bits[e];
+    __syncthreads();
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
+    const int lane = lane_id();
+    constexpr int kCountUnroll = 16;          // 1024 entries in flight: a ~840-entry row is one round trip
+    for (uint64_t r0 = wave * kCompactRows; r0 < n_rows; r0 += n_waves * kCompactRows) {
+        const int nr = (int)(n_rows - r0 < (uint64_t)kCompactRows ? n_rows - r0 : kCompactRows);
+        uint32_t mine = 0;                    // lane i: row r0 + i
+        for (int i = 0; i < nr; ++i) {
+            const int64_t lo = indptr[r0 + i], hi = indptr[r0 + i + 1];
+            uint32_t c = 0;
+            for (int64_t base = lo; base < hi; base += kCountUnroll * kWave) {
+                int32_t g[kCountUnroll];
+#pragma unroll
+                for (int u = 0; u < kCountUnroll; ++u) {
+                    const int64_t p = base + u * kWave + lane;
+                    g[u] = p < hi ? (int32_t)idx[p] : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < kCountUnroll; ++u)
+                    if (g[u] >= 0) c += (bits[g[u] >> 5] >> (g[u] & 31)) & 1u;
+            }
+            c = wave_sum(c);
+            if (lane == i) mine = c;
+        }
+        if (lane < nr) cntrow[r0 + lane] = (int64_t)mine;     // 8 counters = one 64-byte line
+    }
+}
+
 template <typename I>
 __global__ __launch_bounds__(256) void k_tcount(const int64_t* __restrict__ indptr, const I* __restrict__ idx,
                                                 const uint32_t* __restrict__ g_bits,
@@ -1983,7 +2022,15 @@ static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words,
     const double s_i = m->d_idx16 ? 2.0 : 4.0;          // bytes per column index streamed by the two passes
     ProfScope ps(ctx, SRX_K_COMPACT, (double)m->nnz * s_i * 2.0 + (double)m->nnz * val_bytes(m) + (double)(N + 1) * 8.0 * 2.0);
     const size_t cnt_lds = sel_lds + 4 * (size_t)kCompactRows * kWave * sizeof(uint32_t);      // + 8 x 64 counters per wave
-    if (m->d_idx16)
+    if (!t256p) {
+        const size_t bits_lds = (size_t)n_words * sizeof(uint32_t);
+        if (m->d_idx16)
+            hipLaunchKernelGGL((k_rowcount<uint16_t>), dim3(grid_rows(ctx, N, 4)), dim3(256), bits_lds, ctx->stream, m->d_indptr,
+                               (const uint16_t*)m->d_idx16, d_sel, n_words, N, cntrow);
+        else
+            hipLaunchKernelGGL((k_rowcount<int32_t>), dim3(grid_rows(ctx, N, 4)), dim3(256), bits_lds, ctx->stream, m->d_indptr,
+                               (const int32_t*)m->d_indices, d_sel, n_words, N, cntrow);
+    } else if (m->d_idx16)
         hipLaunchKernelGGL((k_tcount<uint16_t>), dim3(grid_rows(ctx, N, 4)), dim3(256), cnt_lds, ctx->stream, m->d_indptr,
                            (const uint16_t*)m->d_idx16, d_sel, d_sel + n_words, n_words, N, nt128, nt256, k, cntrow, cnt256);
     else
