@@ -3059,10 +3059,12 @@ static int32_t launch_writeback(srx_mat* m) {
     srx_ctx* ctx = m->ctx;
     if (!m->lazy_pending) return SRX_OK;
     if (!ctx->side_stream) {
-        // The side stream is kept off a few CUs (CU mask): the write-back's waves hold ~100 VGPRs each, and with them on
-        // every CU a 1024-thread workgroup of the iteration (k_gram2_part, the Cholesky / Jacobi kernels) found no CU
-        // with room until the write-back had finished — the two streams ran one after the other (profiles/r02 timeline).
-        static const int free_cus = getenv("SRX_WB_FREE_CUS") ? atoi(getenv("SRX_WB_FREE_CUS")) : 32;
+        // The side stream is kept off some of the CUs (CU mask): with the write-back's waves on every CU a 1024-thread
+        // workgroup of the iteration (k_gram2_part, the Cholesky / Jacobi kernels) found no CU with room until the
+        // write-back had finished — the two streams ran one after the other (profiles/r02 timeline).  The f32 write-back
+        // (k_row_apply_f32) is bandwidth-bound from ~160 CUs up: 2.2 ms on 224, 2.3 on 160, 2.6 on 128, 4.3 on 64; the
+        // iteration beside it takes 3.2 / 2.85 / 2.9 ms (2.2 alone: what is left is contention for the fabric).
+        static const int free_cus = getenv("SRX_WB_FREE_CUS") ? atoi(getenv("SRX_WB_FREE_CUS")) : 96;
         uint32_t mask[8];
         const int n_cus = ctx->n_cus > 256 ? 256 : ctx->n_cus;
         for (int w = 0; w < 8; ++w) mask[w] = 0u;
@@ -3082,7 +3084,9 @@ static int32_t launch_writeback(srx_mat* m) {
         SRX_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
     }
     m->lazy_pending = false;
-    SRX_TRY(launch_normalize(m, m->lazy_target, true, true, st, !is_f32(m), 0));      // bumps the version; 3 workgroups per CU: room for the iteration's kernels
+    static const bool old_wb = getenv("SRX_WB_RESUM") != nullptr;
+    if (is_f32(m) && !old_wb) SRX_TRY(launch_row_apply(m, m->lazy_target, st));       // bumps the version
+    else SRX_TRY(launch_normalize(m, m->lazy_target, true, true, st, !is_f32(m), 0));
     // (the moments cached on the matrix are those of the f64 transform, not of the values as stored: the version bump
     //  above retires them — a later compute_variance sees what X holds)
     if (!serial) {
