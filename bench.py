@@ -42,20 +42,23 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
-KERNEL_SYMBOL = {"normalize_log1p": "k_row_pass<float,NORM,LOG> (in-place write-back, side stream)",
+KERNEL_SYMBOL = {"normalize_log1p": "k_row_apply_f32 (in-place write-back from the row sums, side stream; f64 storage: k_row_pass)",
                  "row_sums": "k_row_sum<float>", "gene_moments": "k_gene_moments<float,u16,XF>",
                  "select": "k_gene_var + k_hvg_rank + k_hvg_take + k_sel_finish",
-                 "hvg_compact": "k_tcount + k_tfill (+ scans)", "spmm_fwd": "k_spmm_fwd (CSR x 64-col panel)",
-                 "spmm_t": "k_spmm_t", "gram_sparse": "k_gram_stripes<float> (+ k_bucket)",
+                 "hvg_compact": "k_rowcount + k_tfill (+ scan)", "spmm_fwd": "k_spmm_rows (row-major records x 64-col panel)",
+                 "spmm_t": "k_spmm_t", "gram_sparse": "k_gram_stripes<float>",
+                 "gram_bucket": "k_rec_count + k_rec_scan + k_bucket (owner records of the Gram kernel)",
                  "iterate": "k x 64 subspace iteration (hipGraph replays)", "dense_apply": "k_dense_apply"}
 ROOF_NOTE = {
-    "gram_sparse": "algorithmic bytes = the row-major HVG-compacted matrix (8-byte records) and the 8-byte owner records read "
+    "gram_sparse": "algorithmic bytes = the row-major HVG-compacted matrix (8-byte entries) and the 12-byte owner records read "
                    "once + the packed upper triangle of G written once.  Not an HBM-bound kernel: N m(m+1)/2 = 3.4e9 scalar "
-                   "products per launch at c3, each one lane of an f64 LDS atomic (LDS pipe 59 % busy, 14 clk per 36-lane "
+                   "products per launch at c3, each one lane of an f64 LDS atomic (LDS pipe 66 % busy, 14 clk per 36-lane "
                    "instruction) fed by one gathered 8-byte operand (every row suffix is re-read once per kept entry of its "
-                   "row: 27 GB of L2 requests, 58 % L2 hits with the chunked dispatch order) — profiles/r02_pmc_gram.md",
-    "spmm_fwd": "algorithmic bytes per SURVEY.md 8(d): nnz_w*(4+4) + (n_t*N+1)*8 + k*64*4 + the output, which for this "
-                "launch (the transform) is the N x n_pc f64 score matrix written by the SpMM itself",
+                   "row: 19 GB through the fabric per launch) — profiles/r02_pmc_gram.md",
+    "spmm_fwd": "algorithmic bytes: the row-major compacted matrix (nnz_w * 8) + row pointers and row order (N * 12) + the "
+                "k x 64 f32 panel once per workgroup column slice + the output, which for this launch (the transform) is the "
+                "N x n_pc f64 score matrix written by the SpMM itself.  Not HBM-bound either: 64 multiply-adds per kept "
+                "entry from an LDS-resident panel slice (DESIGN.md section 3)",
 }
 
 
@@ -117,11 +120,12 @@ def load_traffic(config):
                 t = json.load(fh)["kernels"]
         except (OSError, ValueError, KeyError):
             continue
-        cls = {"normalize_log1p": ("k_row_pass",), "row_sums": ("k_row_sum",), "gene_moments": ("k_gene_moments",),
-               "spmm_fwd": ("k_spmm_fwd",), "spmm_t": ("k_spmm_t",),
-               "gram_sparse": ("k_gram_stripes", "k_bucket", "k_gram_sparse", "k_gram_reduce"),
+        cls = {"normalize_log1p": ("k_row_pass", "k_row_apply"), "row_sums": ("k_row_sum",), "gene_moments": ("k_gene_moments",),
+               "spmm_fwd": ("k_spmm_fwd", "k_spmm_rows"), "spmm_t": ("k_spmm_t",),
+               "gram_sparse": ("k_gram_stripes", "k_gram_sparse", "k_gram_reduce"),
+               "gram_bucket": ("k_bucket", "k_rec_count", "k_rec_scan"),
                "dense_apply": ("k_dense_apply",),
-               "hvg_compact": ("k_tcount", "k_tfill", "k_scan_block_sums", "k_scan_serial", "k_scan_apply", "k_seglen")}
+               "hvg_compact": ("k_tcount", "k_rowcount", "k_tfill", "k_scan_block_sums", "k_scan_serial", "k_scan_apply", "k_seglen")}
         out = {}
         for name, subs in cls.items():
             tot, hit = 0.0, False
@@ -267,7 +271,8 @@ class Bench:
                 c.copy_values_from(pristine)
             used = 0
         classes = {F.K_NORMALIZE: "normalize_log1p", F.K_ROWSUM: "row_sums", F.K_MOMENTS: "gene_moments", F.K_SELECT: "select",
-                   F.K_COMPACT: "hvg_compact", F.K_GRAM: "gram_sparse", F.K_ITERATE: "iterate", F.K_DENSE: "dense_apply",
+                   F.K_COMPACT: "hvg_compact", F.K_GRAM: "gram_sparse", F.K_BUCKET: "gram_bucket", F.K_ITERATE: "iterate",
+                   F.K_DENSE: "dense_apply",
                    F.K_SPMM_FWD: "spmm_fwd", F.K_SPMM_T: "spmm_t"}
         ctx.prof_enable(sum(1 << c for c in classes))
         ctx.prof_reset()
@@ -325,7 +330,7 @@ def attributed(prof, steps):
     """ms per step inside the bracketed kernel classes that are NOT overlapped (the in-place write-back runs on the side
     stream beside the iteration: reported, not added; dense_apply sits inside `iterate`)."""
     per = {k_: v["avg_ms"] * v["launches"] / steps for k_, v in prof.items()}
-    serial = sum(per.get(k_, 0.0) for k_ in ("row_sums", "gene_moments", "select", "hvg_compact", "gram_sparse", "iterate", "spmm_fwd", "spmm_t"))
+    serial = sum(per.get(k_, 0.0) for k_ in ("row_sums", "gene_moments", "select", "hvg_compact", "gram_bucket", "gram_sparse", "iterate", "spmm_fwd", "spmm_t"))
     return per, serial
 
 

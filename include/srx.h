@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SRX_ABI_VERSION 2      /* 2: srx_matrix_reserve_results, kernel classes 7-9, srx_synth_params.skew */
+#define SRX_ABI_VERSION 3      /* 2: srx_matrix_reserve_results, kernel classes 7-9, srx_synth_params.skew; 3: kernel class 10 */
 
 typedef struct srx_ctx srx_ctx;   /* one GPU + stream + (optional) RCCL communicator      */
 typedef struct srx_mat srx_mat;   /* device-resident CSR (the `X` of an IMAnnData)        */
@@ -374,7 +374,9 @@ typedef enum srx_kernel_class {
     SRX_K_ITERATE = 8,     /* the k x 64 subspace iteration as a whole (graph replays + the
                               launches between them); contains the SRX_K_DENSE launches     */
     SRX_K_SELECT = 9,      /* device-side HighlyVariable(n): variances, ranks, selection    */
-    SRX_K_COUNT_ = 10
+    SRX_K_BUCKET = 10,     /* the Gram kernel's owner records: counts, their read-back, bucket pass;
+                              SRX_K_GRAM is the stripe kernel alone                         */
+    SRX_K_COUNT_ = 11
 } srx_kernel_class;
 int32_t srx_prof_enable(srx_ctx* ctx, uint32_t class_mask);
 int32_t srx_prof_reset(srx_ctx* ctx);

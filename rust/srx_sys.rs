@@ -5,7 +5,7 @@
 #![allow(non_camel_case_types, dead_code)]
 use std::os::raw::{c_char, c_void};
 
-pub const SRX_ABI_VERSION: i32 = 2;
+pub const SRX_ABI_VERSION: i32 = 3;
 pub const SRX_UNIQUE_ID_BYTES: usize = 128;
 pub const SRX_OK: i32 = 0;
 pub const SRX_E_ARG: i32 = -1;
@@ -51,7 +51,8 @@ pub const SRX_K_DENSE: i32 = 6;
 pub const SRX_K_ROWSUM: i32 = 7;
 pub const SRX_K_ITERATE: i32 = 8;
 pub const SRX_K_SELECT: i32 = 9;
-pub const SRX_K_COUNT_: i32 = 10;
+pub const SRX_K_BUCKET: i32 = 10;
+pub const SRX_K_COUNT_: i32 = 11;
 
 #[repr(C)] pub struct SrxCtx { _private: [u8; 0] }      // opaque `srx_ctx`
 #[repr(C)] pub struct SrxMat { _private: [u8; 0] }      // opaque `srx_mat`

@@ -22,7 +22,7 @@ STATUS_NAMES = {0: "SRX_OK", -1: "SRX_E_ARG", -2: "SRX_E_DTYPE", -3: "SRX_E_FORM
 I8, I16, I32, U8, U16, U32, F32, F64 = range(8)
 ROW, COLUMN = 0, 1
 STORE_AUTO, STORE_F32, STORE_F64 = 0, 1, 2
-K_NORMALIZE, K_MOMENTS, K_COMPACT, K_SPMM_FWD, K_SPMM_T, K_GRAM, K_DENSE, K_ROWSUM, K_ITERATE, K_SELECT = range(10)
+K_NORMALIZE, K_MOMENTS, K_COMPACT, K_SPMM_FWD, K_SPMM_T, K_GRAM, K_DENSE, K_ROWSUM, K_ITERATE, K_SELECT, K_BUCKET = range(11)
 SOLVER_AUTO, SOLVER_GRAM, SOLVER_SPMM = 0, 1, 2
 UNIQUE_ID_BYTES = 128
 

@@ -2217,23 +2217,27 @@ static int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp) {
     SRX_TRY(scratch(ctx, "pca_brbase", (g.n_rblk + 1) * sizeof(int64_t), (void**)&rec_base));
     int64_t n_recs = 0;
     {
+        // SRX_K_BUCKET: record counts, their read-back, the bucket pass — the compacted matrix read once (twice through L2),
+        // the records written once
+        ProfScope ps(ctx, SRX_K_BUCKET, (double)rm.nnz * sizeof(GramPk<VT>) + (double)(rm.n_rows + 1) * 8.0 * 2.0);
         // how many records each block makes (a suffix longer than a wave is several), and where its records start
-        ProfScope ps(ctx, SRX_K_GRAM, (double)(rm.n_rows + 1) * 8.0);
         hipLaunchKernelGGL(k_rec_count, dim3((unsigned)g.n_rblk), dim3(256), 0, ctx->stream, rm.ptr, rm.n_rows, g.rblk, blk_total);
         hipLaunchKernelGGL(k_rec_scan, dim3(1), dim3(1024), 0, ctx->stream, blk_total, g.n_rblk, rec_base);
         SRX_HIP(ctx, hipGetLastError());
+        SRX_TRY(d2h(ctx, &n_recs, rec_base + g.n_rblk, sizeof(int64_t)));
+        SRX_TRY(scratch(ctx, "pca_brecs", ((size_t)n_recs + kGramUnroll) * sizeof(GramRec<VT>), (void**)&recs));
+        if (ctx->prof_mask & (1u << SRX_K_BUCKET)) ctx->prof[SRX_K_BUCKET].bytes += (double)n_recs * sizeof(GramRec<VT>);
+        SRX_HIP(ctx, hipMemsetAsync(recs + n_recs, 0, kGramUnroll * sizeof(GramRec<VT>), ctx->stream));
+        hipLaunchKernelGGL((k_bucket<VT>), dim3((unsigned)g.n_rblk), dim3(kBucketThreads),
+                           (size_t)(g.n_wg + 1 + g.rblk + 1 + kBucketGroup) * sizeof(uint32_t), ctx->stream, rm.ptr,
+                           (const GramPk<VT>*)rm.pk, rm.n_rows, g.rblk, rm.k, g.sr_shift, g.n_wg, g.n_stripes, rec_base, boff, recs);
+        SRX_HIP(ctx, hipGetLastError());
     }
-    SRX_TRY(d2h(ctx, &n_recs, rec_base + g.n_rblk, sizeof(int64_t)));
-    SRX_TRY(scratch(ctx, "pca_brecs", ((size_t)n_recs + kGramUnroll) * sizeof(GramRec<VT>), (void**)&recs));
-    // algorithmic bytes: the compacted matrix read twice (bucket pass, stripe kernel), the records written and read once,
-    // G written once.  Every row suffix is read once per kept entry of its row (from L2 / Infinity Cache): that shows up in
-    // the PMC traffic, not here.
-    ProfScope ps(ctx, SRX_K_GRAM, (double)rm.nnz * 2.0 * sizeof(GramPk<VT>) + (double)n_recs * 2.0 * sizeof(GramRec<VT>) +
-                                      (double)(rm.n_rows + 1) * 8.0 + (double)rm.k * (rm.k + 1) / 2 * 8.0);
-    SRX_HIP(ctx, hipMemsetAsync(recs + n_recs, 0, kGramUnroll * sizeof(GramRec<VT>), ctx->stream));
-    hipLaunchKernelGGL((k_bucket<VT>), dim3((unsigned)g.n_rblk), dim3(kBucketThreads),
-                       (size_t)(g.n_wg + 1 + g.rblk + 1 + kBucketGroup) * sizeof(uint32_t), ctx->stream, rm.ptr,
-                       (const GramPk<VT>*)rm.pk, rm.n_rows, g.rblk, rm.k, g.sr_shift, g.n_wg, g.n_stripes, rec_base, boff, recs);
+    // SRX_K_GRAM: the stripe kernel alone.  Algorithmic bytes: the compacted matrix and the records read once, the block
+    // offsets, G written once.  Every row suffix is read once per kept entry of its row (from L2 / Infinity Cache): that shows
+    // up in the PMC traffic, not here.
+    ProfScope ps(ctx, SRX_K_GRAM, (double)rm.nnz * sizeof(GramPk<VT>) + (double)n_recs * sizeof(GramRec<VT>) +
+                                      (double)g.n_rblk * (g.n_wg + 1) * 4.0 + (double)rm.k * (rm.k + 1) / 2 * 8.0);
     SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_stripes<VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
     hipLaunchKernelGGL((k_gram_stripes<VT>), dim3((unsigned)(g.n_wg * g.n_z)), dim3(kGramWaves * kWave), g.lds_bytes, ctx->stream,
                        rm.ptr, (const GramPk<VT>*)rm.pk, boff, rec_base, recs, g.n_rblk, g.rblk, rm.k, g.sr_shift, g.n_wg,
