@@ -964,8 +964,8 @@ __device__ __forceinline__ double gram_product(double a, double b) { return a * 
 // whatever the LDS atomics make it — the Gram sums are order-dependent in their last bits anyway).
 // boff[rb][w] .. boff[rb][w + 1]: records of owner w, relative to the block's first record (rec_base[rb]).
 constexpr int kBucketThreads = 1024;
-constexpr int kBucketGroup = 4;           // consecutive rows a wave walks as one flat run
-constexpr int kBucketUnroll = 4;          // 64-entry chunks of the run in flight
+constexpr int kBucketGroup = 8;           // consecutive rows a wave walks as one flat run
+constexpr int kBucketUnroll = 8;          // 64-entry chunks of the run in flight
 
 // per-block record totals (k_bucket's layout needs their prefix sums before it runs)
 __global__ __launch_bounds__(256) void k_rec_count(const int64_t* __restrict__ rm_ptr, uint64_t n_rows, uint32_t rblk,
