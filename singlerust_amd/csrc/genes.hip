@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     const uint64_t r0 = rb * rows_per_block;
     const uint64_t r1 = r0 + rows_per_block < n_rows ? r0 + rows_per_block : n_rows;
     const int lane = lane_id();
-    const int wave = threadIdx.x / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);      // row bounds and scales are then scalars
     constexpr int kWaves = kMomThreads / kWave;
 
     // 4 consecutive entries per lane: one 16-byte (8-byte for 16-bit indices) load of the indices and one
@@ -121,13 +121,37 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     auto add_chunk = [&](int64_t e0, int64_t lo, int64_t hi, const Chunk& c, double scale) {
         const int rel = (int)(e0 - lo);                    // >= -3
         const unsigned len = (unsigned)(hi - lo);
+        // XF: the four logarithms first, as independent straight-line chains the compiler can interleave (the accumulators
+        // leave room for 4 waves per SIMD: a wave has to bring its own instruction-level parallelism); the rare argument
+        // classes are patched afterwards (entries outside the segment hold padding values: evaluated, never used)
+        double y4[4] = {0.0, 0.0, 0.0, 0.0};
+        if constexpr (XF) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double x = (double)c.v[j] * scale;
+                if constexpr (sizeof(T) == 4) y4[j] = log1p_f64_moment_common(x, s_tab);
+                else y4[j] = log1p_f64_fast(x, s_tab);
+            }
+            if constexpr (sizeof(T) == 4) {
+                bool any_rare = false;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) any_rare |= log1p_f64_moment_is_rare((double)c.v[j] * scale);
+                if (__builtin_expect(any_rare, 0)) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const double x = (double)c.v[j] * scale;
+                        if (log1p_f64_moment_is_rare(x)) y4[j] = log1p_f64_rare(x, s_tab);
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if ((unsigned)(rel + j) < len) {
                 const int32_t g0 = c.gg[j] - gbase;
                 double x0 = (double)c.v[j];
                 if constexpr (XF) {
-                    x0 = sizeof(T) == 4 ? log1p_f64_moment(x0 * scale, s_tab) : log1p_f64_fast(x0 * scale, s_tab);
+                    x0 = y4[j];
                     if (__builtin_expect(!(fabs(x0) < 64.0), 0)) {     // NaN, infinite, or outside the fixed-point range: the gene's moments are NaN
                         poison[(uint64_t)gbase + g0] = 1u;
                         continue;
@@ -274,7 +298,7 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_minmax(
     const uint64_t r0 = rb * rows_per_block;
     const uint64_t r1 = r0 + rows_per_block < n_rows ? r0 + rows_per_block : n_rows;
     const int lane = lane_id();
-    const int wave = threadIdx.x / kWave;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);      // row bounds and scales are then scalars
     constexpr int kWaves = kMomThreads / kWave;
     for (uint64_t r = r0 + wave; r < r1; r += kWaves) {
         int64_t lo, hi;

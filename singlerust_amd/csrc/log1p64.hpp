@@ -221,6 +221,27 @@ static __device__ __attribute__((noinline)) double log1p_f64_rare(double x, cons
 // high word of x (one unsigned compare: 2^-10 <= x < inf), exponent / table index / mantissa come from the high word of
 // u = 1 + x with 32-bit operations, degree-5 polynomial (same arithmetic as log1p_f64_lite: <= 2e-13 for those arguments);
 // everything else (x < 2^-10, negative, NaN, inf) takes the full routine.
+// the class test and the straight-line part on their own: a caller with several independent arguments evaluates the
+// straight-line part for all of them (garbage, but no trap, for the rare classes) and patches the rare ones afterwards,
+// which leaves the compiler free to interleave the chains
+__device__ __forceinline__ bool log1p_f64_moment_is_rare(double x) {
+    const unsigned xh = (unsigned)__double2hiint(x);
+    return xh - 0x3f500000u >= 0x7ff00000u - 0x3f500000u;
+}
+__device__ __forceinline__ double log1p_f64_moment_common(double x, const Log1pTabEntry* __restrict__ tab) {
+    const double u = 1.0 + x;
+    const int uh = __double2hiint(u);
+    const int e = (uh >> 20) - 1023;
+    const int i = (uh >> 13) & 127;
+    const double m = __hiloint2double((uh & 0x000fffff) | 0x3ff00000, __double2loint(u));
+    const Log1pTabEntry t = tab[i];
+    const double r = __builtin_fma(m, t.inv, -1.0);
+    double p = __builtin_fma(r, 1.0 / 5, -1.0 / 4);
+    p = __builtin_fma(r, p, 1.0 / 3);
+    p = __builtin_fma(r, p, -0.5);
+    const double lr = __builtin_fma(r * r, p, r);
+    return __builtin_fma((double)e, 0x1.62e42fefa39efp-1, t.lg) + lr;
+}
 __device__ __forceinline__ double log1p_f64_moment(double x, const Log1pTabEntry* __restrict__ tab) {
     const unsigned xh = (unsigned)__double2hiint(x);
     if (__builtin_expect(xh - 0x3f500000u >= 0x7ff00000u - 0x3f500000u, 0)) return log1p_f64_rare(x, tab);
