@@ -24,6 +24,11 @@ constexpr int kWave = 64;
 
 // ---- device-side helpers -----------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+// index of this wave in the grid, as a wave-uniform value the compiler KNOWS is uniform: what is derived from it (row
+// numbers, row pointers, row scales) lives in SGPRs and comes in by scalar loads instead of 64 identical vector loads
+__device__ __forceinline__ uint64_t global_wave_id() {
+    return (uint64_t)blockIdx.x * (blockDim.x / kWave) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+}
 
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {

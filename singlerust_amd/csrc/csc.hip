@@ -38,7 +38,7 @@ template <typename T>
 __global__ void k_scatter(const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx, const T* __restrict__ vals,
                           uint64_t n_rows, const int64_t* __restrict__ out_ptr, unsigned long long* __restrict__ cursor,
                           int32_t* __restrict__ out_idx, T* __restrict__ out_vals) {
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t wave = global_wave_id();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
     for (uint64_t r = wave; r < n_rows; r += n_waves) {

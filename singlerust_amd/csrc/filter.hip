@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void k_subset_count(const int64_t* __restrict_
                                                       const uint8_t* __restrict__ rowmask,
                                                       const int32_t* __restrict__ colmap, uint64_t n_rows,
                                                       int64_t* __restrict__ counts) {
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t wave = global_wave_id();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
     for (uint64_t r = wave; r < n_rows; r += n_waves) {
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_subset_fill(const int64_t* __restrict__
                                                      const int64_t* __restrict__ new_id /* n_rows + 1 */,
                                                      int64_t* __restrict__ out_ptr, int32_t* __restrict__ out_idx,
                                                      T* __restrict__ out_vals) {
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t wave = global_wave_id();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
     if (wave == 0 && lane == 0) out_ptr[new_id[n_rows]] = off_old[n_rows];       // the closing pointer

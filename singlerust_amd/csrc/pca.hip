@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_compact_count(const int64_t* __restrict
                                                        const int32_t* __restrict__ idx,
                                                        const int32_t* __restrict__ remap, uint64_t n_rows,
                                                        int64_t* __restrict__ counts) {
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t wave = global_wave_id();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
     for (uint64_t r = wave; r < n_rows; r += n_waves) {
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_compact_fill(const int64_t* __restrict_
                                                       const int32_t* __restrict__ remap, uint64_t n_rows,
                                                       const int64_t* __restrict__ out_ptr,
                                                       int32_t* __restrict__ out_idx, T* __restrict__ out_vals) {
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t wave = global_wave_id();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
     for (uint64_t r = wave; r < n_rows; r += n_waves) {
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void k_retile(const int64_t* __restrict__ indp
                                                 const int32_t* __restrict__ idx, const T* __restrict__ vals,
                                                 uint64_t n_rows, int nt, int kt, const int64_t* __restrict__ tptr,
                                                 GramPk<T>* __restrict__ tpk) {
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t wave = global_wave_id();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
     for (uint64_t r = wave; r < n_rows; r += n_waves) {
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void k_rowcount(const int64_t* __restrict__ in
     uint32_t* bits = reinterpret_cast<uint32_t*>(lds_raw);
     for (int e = threadIdx.x; e < n_words; e += blockDim.x) bits[e] = g_bits[e];
     __syncthreads();
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t wave = global_wave_id();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
     constexpr int kCountUnroll = 16;          // 1024 entries in flight: a ~840-entry row is one round trip
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void k_tcount(const int64_t* __restrict__ indp
                                                 int64_t* __restrict__ cnt256) {
     extern __shared__ double lds_raw[];
     const SelLds sel = stage_selection(g_bits, g_prefix, n_words, reinterpret_cast<uint32_t*>(lds_raw));
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t wave = global_wave_id();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
     // per-wave tile counters in LDS (after the selection table): a kept entry is one ds_add_u32 on its
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void k_tfill(const int64_t* __restrict__ indpt
     __shared__ Log1pTabEntry s_tab[XF ? 128 : 1];
     if constexpr (XF) stage_log1p_table(s_tab);
     const SelLds sel = stage_selection(g_bits, g_prefix, n_words, reinterpret_cast<uint32_t*>(lds_raw));
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t wave = global_wave_id();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
     for (uint64_t r = (wave * kCompactRows); r < n_rows; r = next_compact_row(r, n_waves)) {

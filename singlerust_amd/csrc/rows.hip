@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void k_row_pass(const int64_t* __restrict__ in
     constexpr int V = 16 / sizeof(T);
     constexpr int NV = kRowCache / V;
     using Vec = RowVec<T>;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t wave = global_wave_id();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
     for (uint64_t r = wave; r < n_rows; r += n_waves) {
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_row_pass(const int64_t* __restrict__ in
 template <typename T>
 __global__ __launch_bounds__(256) void k_row_sum(const int64_t* __restrict__ indptr, const T* __restrict__ vals,
                                                  uint64_t n_rows, double* __restrict__ out) {
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t wave = global_wave_id();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
     for (uint64_t r = wave; r < n_rows; r += n_waves) {
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void k_row_sum(const int64_t* __restrict__ ind
 template <typename T>
 __global__ __launch_bounds__(256) void k_row_var(const int64_t* __restrict__ indptr, const T* __restrict__ vals,
                                                  uint64_t n_rows, double* __restrict__ out) {
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t wave = global_wave_id();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
     for (uint64_t r = wave; r < n_rows; r += n_waves) {
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_row_qc(const int64_t* __restrict__ indp
     constexpr int V = 16 / sizeof(T);
     constexpr int NV = kRowCache / V;
     using Vec = RowVec<T>;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t wave = global_wave_id();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
     for (uint64_t r = wave; r < n_rows; r += n_waves) {
@@ -237,7 +237,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_row_minmax(const int64_t* __restrict__ indptr, const T* __restrict__ vals,
                                                     uint64_t n_rows, double* __restrict__ mn,
                                                     double* __restrict__ mx) {
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t wave = global_wave_id();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
     for (uint64_t r = wave; r < n_rows; r += n_waves) {
@@ -270,7 +270,7 @@ constexpr int kApplyUnroll = 4;
 __global__ __launch_bounds__(256) void k_row_apply_f32(const int64_t* __restrict__ indptr, float* __restrict__ vals, uint64_t n_rows,
                                                        double target, const double* __restrict__ row_sum) {
     using Vec = RowVec<float>;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t wave = global_wave_id();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
     for (uint64_t r = wave; r < n_rows; r += n_waves) {

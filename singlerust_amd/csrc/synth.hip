@@ -114,7 +114,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_synth_fill(SynthConst c, uint64_t row_begin, uint64_t n_rows,
                                                     const int64_t* __restrict__ indptr, int32_t* __restrict__ idx,
                                                     T* __restrict__ vals) {
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint64_t wave = global_wave_id();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
     for (uint64_t lr = wave; lr < n_rows; lr += n_waves) {
