@@ -1,6 +1,6 @@
-# A/B a list of env settings on the lean bench line: scripts/r2_ab.sh "A=1" "B=2 C=3" ...
+# A/B a list of env settings on the lean bench line: scripts/r2_ab.sh "A=1" "B=2 C=3" ...   (BENCH_ARGS adds bench flags)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-B="python bench.py --gpus 1 --steps 8 --warmup 2 --lean"
+B="python bench.py --gpus 1 --steps 8 --warmup 2 --lean $BENCH_ARGS"
 for v in "$@"; do
   env $v $B 2>/dev/null | python -c "
 import json,sys

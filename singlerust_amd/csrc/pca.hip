@@ -1130,6 +1130,8 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     double* __restrict__ Gp /* packed upper triangle, ACCUMULATED into (global f64 atomics) */) {
     using Entry = GramPk<VT>;
     using Rec = GramRec<VT>;
+    // suffix loads in flight per batch: 16-byte f64 entries take twice the registers (8 of them spilled)
+    constexpr int kUnroll = sizeof(VT) == 8 ? kGramUnroll / 2 : kGramUnroll;
     extern __shared__ double acc[];
     const int w = blockIdx.x % n_wg, z = blockIdx.x / n_wg;
     const int SR = 1 << sr_shift;
@@ -1146,7 +1148,7 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     // 12 %, 50 GB of fabric reads per launch at c3).  Wave v takes blocks v, v + 16, ... of the chunk.
     //
     // A wave reads its records 64 at a time (one 12-byte vector load per lane, the slab after this one in flight while this
-    // one is worked through) and hands them out kGramUnroll at a time: v_readlane makes (pos, len, rbase, va) of a record
+    // one is worked through) and hands them out kUnroll at a time: v_readlane makes (pos, len, rbase, va) of a record
     // wave-uniform, the suffix load takes (scalar base, 32-bit lane offset), and what is left per record is lane < len, the
     // product, its conversion and the LDS address.  Two batches are in flight: one being fetched, one being added.
     // (Records fetched by scalar loads, one batch ahead: the stream alone cost 3.1 ms — every batch a dependent round trip
@@ -1192,14 +1194,14 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
         return sl;
     };
     struct Loaded {                       // a batch of records with their suffix entries on the way
-        Entry e[kGramUnroll];
-        uint32_t lenrb[kGramUnroll];
-        VT va[kGramUnroll];
+        Entry e[kUnroll];
+        uint32_t lenrb[kUnroll];
+        VT va[kUnroll];
     };
     auto batch = [&](const Slab& sl, int u0) -> Loaded {
         Loaded l;
 #pragma unroll
-        for (int u = 0; u < kGramUnroll; ++u) {       // lanes past sl.n hold empty records: len 0, pos 0
+        for (int u = 0; u < kUnroll; ++u) {       // lanes past sl.n hold empty records: len 0, pos 0
             const uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.pos, u0 + u);
             l.lenrb[u] = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.lenrb, u0 + u);
             l.va[u] = readlane_v(sl.r.va, u0 + u);
@@ -1213,7 +1215,7 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     };
     auto process = [&](const Loaded& l) {
 #pragma unroll
-        for (int u = 0; u < kGramUnroll; ++u) {
+        for (int u = 0; u < kUnroll; ++u) {
             const int rbase = (int)l.lenrb[u] >> 8;
             const uint32_t len = l.lenrb[u] & 0xffu;
             if ((uint32_t)lane < len)
@@ -1231,14 +1233,14 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
         Loaded A = batch(sl, 0), B;
         other = next_slab();
 #pragma unroll
-        for (int u0 = 0; u0 < kWave; u0 += 2 * kGramUnroll) {
+        for (int u0 = 0; u0 < kWave; u0 += 2 * kUnroll) {
             // no branch around a batch's loads (slots past n are empty records, their loads hit the block's first line):
             // after a conditional load the compiler's wait for A's entries also waits for B's
-            B = batch(sl, u0 + kGramUnroll);
+            B = batch(sl, u0 + kUnroll);
             process(A);
-            if (u0 + 2 * kGramUnroll < kWave) A = batch(sl, u0 + 2 * kGramUnroll);
+            if (u0 + 2 * kUnroll < kWave) A = batch(sl, u0 + 2 * kUnroll);
             process(B);
-            if (u0 + 2 * kGramUnroll >= n) break;
+            if (u0 + 2 * kUnroll >= n) break;
         }
     };
     {
