@@ -42,7 +42,7 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
-KERNEL_SYMBOL = {"normalize_log1p": "k_row_apply_f32 (in-place write-back from the row sums, side stream; f64 storage: k_row_pass)",
+KERNEL_SYMBOL = {"normalize_log1p": "k_row_apply<T> (in-place write-back from the row sums, side stream)",
                  "row_sums": "k_row_sum<float>", "gene_moments": "k_gene_moments<float,u16,XF>",
                  "select": "k_gene_var + k_hvg_rank + k_hvg_take + k_sel_finish",
                  "hvg_compact": "k_rowcount + k_tfill (+ scan)", "spmm_fwd": "k_spmm_rows (row-major records x 64-col panel)",

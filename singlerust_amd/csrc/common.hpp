@@ -258,7 +258,7 @@ int32_t select_hvg_device(srx_mat* m, uint64_t n, int center, int scale, HvgDev&
 int32_t ensure_moments(srx_mat* m);   // fills d_cnt/d_sum/d_sq (global) for the current values
 int32_t moments_accumulate(srx_mat* m, double* d_acc, RowXf xf);     // backed mode: this tile's (cnt,sum,sumsq,N) += into d_acc
 int32_t moments_install(srx_mat* m, double* d_packed);     // all-reduce d_packed and make it m's global moments
-int32_t launch_row_apply(srx_mat* m, double target, hipStream_t stream);   // f32 write-back from the row sums in m->d_row_sum
+int32_t launch_row_apply(srx_mat* m, double target, hipStream_t stream);   // in-place write-back from the row sums in m->d_row_sum
 int32_t launch_normalize(srx_mat* m, double target, bool do_norm, bool do_log, hipStream_t stream = nullptr,
                          bool precise = false, int wgs_per_cu = 0);
 int32_t launch_row_sums(srx_mat* m);

@@ -3068,7 +3068,7 @@ static int32_t launch_writeback(srx_mat* m) {
         // The side stream is kept off some of the CUs (CU mask): with the write-back's waves on every CU a 1024-thread
         // workgroup of the iteration (k_gram2_part, the Cholesky / Jacobi kernels) found no CU with room until the
         // write-back had finished — the two streams ran one after the other (profiles/r02 timeline).  The f32 write-back
-        // (k_row_apply_f32) is bandwidth-bound from ~160 CUs up: 2.2 ms on 224, 2.3 on 160, 2.6 on 128, 4.3 on 64; the
+        // (k_row_apply<T>) is bandwidth-bound from ~160 CUs up: 2.2 ms on 224, 2.3 on 160, 2.6 on 128, 4.3 on 64; the
         // iteration beside it takes 3.2 / 2.85 / 2.9 ms (2.2 alone: what is left is contention for the fabric).
         static const int free_cus = getenv("SRX_WB_FREE_CUS") ? atoi(getenv("SRX_WB_FREE_CUS")) : 96;
         uint32_t mask[8];
@@ -3091,7 +3091,7 @@ static int32_t launch_writeback(srx_mat* m) {
     }
     m->lazy_pending = false;
     static const bool old_wb = getenv("SRX_WB_RESUM") != nullptr;
-    if (is_f32(m) && !old_wb) SRX_TRY(launch_row_apply(m, m->lazy_target, st));       // bumps the version
+    if (!old_wb) SRX_TRY(launch_row_apply(m, m->lazy_target, st));       // bumps the version
     else SRX_TRY(launch_normalize(m, m->lazy_target, true, true, st, !is_f32(m), 0));
     // (the moments cached on the matrix are those of the f64 transform, not of the values as stored: the version bump
     //  above retires them — a later compute_variance sees what X holds)

@@ -261,15 +261,23 @@ __global__ void k_row_number(const int64_t* __restrict__ indptr, uint64_t n_rows
     for (; i < n_rows; i += stride) out[i] = (uint32_t)(indptr[i + 1] - indptr[i]);
 }
 
-// The pipeline's in-place write-back for f32 storage: x <- ln_1p(f32(f64(x) * target / row_sum)) with the row sums the
-// pipeline's first pass left in `row_sum` (the moments and the compaction formed their values from the same sums, so what
-// lands in X is exactly what they used).  No reduction, so nothing makes a wave wait for a whole row: 16-byte loads, four
-// in flight per lane, transformed and stored as they arrive.  (k_row_pass<float, true, true> re-sums every row first: 13 GB/s
-// per CU, its time proportional to the CUs it was given — 3.0 ms beside the iteration on 224 CUs.)
+// The pipeline's in-place write-back: x <- ln_1p(x * target / row_sum) at the storage precision (f32: the product rounded
+// to f32, then the f32 logarithm; f64: the table-driven f64 logarithm) with the row sums the pipeline's first pass left in
+// `row_sum` — the moments and the compaction formed their values from the same sums through the same functions, so what
+// lands in X is exactly what they used.  No reduction, so nothing makes a wave wait for a whole row: 16-byte loads, four
+// in flight per lane, transformed and stored as they arrive.  (k_row_pass<T, true, true> re-sums every row first: 13 GB/s
+// per CU at f32, its time proportional to the CUs it was given — 3.0 ms beside the iteration on 224 CUs.)
 constexpr int kApplyUnroll = 4;
-__global__ __launch_bounds__(256) void k_row_apply_f32(const int64_t* __restrict__ indptr, float* __restrict__ vals, uint64_t n_rows,
-                                                       double target, const double* __restrict__ row_sum) {
-    using Vec = RowVec<float>;
+template <typename T>
+__global__ __launch_bounds__(256) void k_row_apply(const int64_t* __restrict__ indptr, T* __restrict__ vals, uint64_t n_rows,
+                                                   double target, const double* __restrict__ row_sum) {
+    using Vec = RowVec<T>;
+    constexpr int V = 16 / sizeof(T);
+    __shared__ Log1pTabEntry s_tab[sizeof(T) == 8 ? 128 : 1];
+    if constexpr (sizeof(T) == 8) {
+        stage_log1p_table(s_tab);
+        __syncthreads();
+    }
     const uint64_t wave = global_wave_id();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
@@ -277,25 +285,25 @@ __global__ __launch_bounds__(256) void k_row_apply_f32(const int64_t* __restrict
         const int64_t lo = indptr[r], hi = indptr[r + 1];
         const double s = row_sum[r];
         const double scale = s == 0.0 ? 0.0 : target / s;           // scale/mod.rs:9-15
-        for (int64_t b0 = (lo & ~(int64_t)3) + 4 * lane; b0 < hi; b0 += (int64_t)kApplyUnroll * kWave * 4) {
+        for (int64_t b0 = (lo & ~(int64_t)(V - 1)) + V * lane; b0 < hi; b0 += (int64_t)kApplyUnroll * kWave * V) {
             Vec c[kApplyUnroll];
 #pragma unroll
             for (int t = 0; t < kApplyUnroll; ++t) {
-                const int64_t e0 = b0 + (int64_t)t * kWave * 4;
+                const int64_t e0 = b0 + (int64_t)t * kWave * V;
                 if (e0 < hi) c[t] = *reinterpret_cast<const Vec*>(vals + e0);       // the array is padded: a vector may start before lo or end past hi
             }
 #pragma unroll
             for (int t = 0; t < kApplyUnroll; ++t) {
-                const int64_t e0 = b0 + (int64_t)t * kWave * 4;
+                const int64_t e0 = b0 + (int64_t)t * kWave * V;
                 if (e0 >= hi) continue;
                 Vec o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o.x[j] = apply_log1p<float>((float)((double)c[t].x[j] * scale));
-                if (e0 >= lo && e0 + 4 <= hi) {
+                for (int j = 0; j < V; ++j) o.x[j] = xf_stored(c[t].x[j], scale, s_tab);
+                if (e0 >= lo && e0 + V <= hi) {
                     *reinterpret_cast<Vec*>(vals + e0) = o;
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < V; ++j)
                         if (e0 + j >= lo && e0 + j < hi) vals[e0 + j] = o.x[j];
                 }
             }
@@ -348,12 +356,16 @@ int32_t launch_normalize(srx_mat* m, double target, bool do_norm, bool do_log, h
 int32_t launch_row_apply(srx_mat* m, double target, hipStream_t stream) {
     srx_ctx* ctx = m->ctx;
     SRX_HIP(ctx, hipSetDevice(ctx->device));
-    if (!is_f32(m) || !m->d_row_sum) return fail(ctx, SRX_E_ARG, "row write-back: f32 storage with row sums only");
+    if (!m->d_row_sum) return fail(ctx, SRX_E_ARG, "row write-back without row sums");
     if (!stream) stream = ctx->stream;
     {
         ProfScope ps(ctx, SRX_K_NORMALIZE, (double)m->nnz * 2.0 * val_bytes(m) + (double)(m->n_rows + 1) * 8.0 + (double)m->n_rows * 8.0, stream);
-        hipLaunchKernelGGL(k_row_apply_f32, dim3(row_grid(m)), dim3(256), 0, stream, m->d_indptr, (float*)m->d_values, m->n_rows,
-                           target, m->d_row_sum);
+        if (is_f32(m))
+            hipLaunchKernelGGL((k_row_apply<float>), dim3(row_grid(m)), dim3(256), 0, stream, m->d_indptr, (float*)m->d_values,
+                               m->n_rows, target, m->d_row_sum);
+        else
+            hipLaunchKernelGGL((k_row_apply<double>), dim3(row_grid(m)), dim3(256), 0, stream, m->d_indptr, (double*)m->d_values,
+                               m->n_rows, target, m->d_row_sum);
     }
     SRX_HIP(ctx, hipGetLastError());
     m->dtype = SRX_F64;       // logical dtype bookkeeping as in launch_normalize: scale/mod.rs:74-83 (-> F64), transform/mod.rs:43-55
