@@ -779,8 +779,19 @@ __global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
     extern __shared__ double lds_raw[];
     PT* panel = reinterpret_cast<PT*>(lds_raw);                 // k x C
     const int n_slices = (n_cols + C - 1) / C;
-    const int slice = blockIdx.x % n_slices;
-    const uint64_t wg = blockIdx.x / n_slices, n_wg = gridDim.x / n_slices;
+    // the column slices of one row range sit on the SAME XCD (consecutive workgroup ids go round the 8 XCDs): they walk the
+    // same rows at the same pace, so the entries come out of that XCD's L2 for all but the first of them
+    const uint64_t n_wg = gridDim.x / n_slices;
+    int slice;
+    uint64_t wg;
+    if (n_wg % 8 == 0) {
+        const uint64_t t = blockIdx.x / 8;
+        slice = (int)(t % n_slices);
+        wg = (t / n_slices) * 8 + blockIdx.x % 8;
+    } else {
+        slice = blockIdx.x % n_slices;
+        wg = blockIdx.x / n_slices;
+    }
     for (int e = threadIdx.x; e < k * Q; e += kFwdRowsThreads) {
         const int j = e / Q, cq = e % Q;
         Vec4<PT> v;
