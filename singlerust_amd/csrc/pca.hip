@@ -807,11 +807,25 @@ __global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
     const PT* panel_q = panel + ql * 4;
     // sorted position i -> row perm[i]; a wave's groups take consecutive positions (equal lengths), the workgroups
     // interleave so that the long rows at the end are spread over all of them
-    for (uint64_t i = wg * kGroups + threadIdx.x / Q; i < n_rows; i += n_wg * kGroups) {
-        const uint64_t row = perm ? perm[i] : i;
-        const int64_t lo = rm_ptr[row];
-        const int n = (int)(rm_ptr[row + 1] - lo);
+    // position -> row -> row pointers -> entries is three dependent loads: the row of the position after next and the pointers
+    // of the next row are fetched while this row is multiplied (positions past the end are clamped: loaded, never used)
+    const uint64_t stride = n_wg * kGroups, i_first = wg * kGroups + threadIdx.x / Q, last = n_rows ? n_rows - 1 : 0;
+    auto row_at = [&](uint64_t i) -> uint64_t {
+        const uint64_t c = i < n_rows ? i : last;
+        return perm ? (uint64_t)perm[c] : c;
+    };
+    uint64_t row = row_at(i_first), row_n = row_at(i_first + stride);
+    int64_t lo = n_rows ? rm_ptr[row] : 0, hi = n_rows ? rm_ptr[row + 1] : 0;
+    for (uint64_t i = i_first; i < n_rows; i += stride) {
+        const int64_t lo_n = rm_ptr[row_n], hi_n = rm_ptr[row_n + 1];
+        const uint64_t row_nn = row_at(i + 2 * stride);
+        const int n = (int)(hi - lo);
         const GramPk<VT>* rr = rm + lo;
+        const uint64_t row_c = row;
+        row = row_n;
+        row_n = row_nn;
+        lo = lo_n;
+        hi = hi_n;
         PT a0 = PT(0), a1 = PT(0), a2 = PT(0), a3 = PT(0);
         // a chunk = 4 Q consecutive records of the row: lane ql holds records 4 ql .. 4 ql + 3 (one 32- / 64-byte load per
         // lane), and the next chunk's load is in flight while this one's 4 Q records are broadcast and multiplied — with one
@@ -842,7 +856,7 @@ __global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
         }
         const PT o0 = a0 - cv4[0], o1 = a1 - cv4[1], o2 = a2 - cv4[2], o3 = a3 - cv4[3];
         if (scores) {
-            double* dst = scores + row * (uint64_t)ld + col0;
+            double* dst = scores + row_c * (uint64_t)ld + col0;
             if (col0 + 0 < n_cols) dst[0] = (double)o0;
             if (col0 + 1 < n_cols) dst[1] = (double)o1;
             if (col0 + 2 < n_cols) dst[2] = (double)o2;
@@ -850,7 +864,7 @@ __global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
         } else {
             Vec4<PT> o;
             o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
-            o.store(Y + row * L + col0);
+            o.store(Y + row_c * L + col0);
         }
     }
 }
