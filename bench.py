@@ -42,8 +42,8 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
-KERNEL_SYMBOL = {"normalize_log1p": "k_row_apply<T> (in-place write-back from the row sums, side stream)",
-                 "row_sums": "k_row_sum<float>", "gene_moments": "k_gene_moments<float,u16,XF>",
+KERNEL_SYMBOL = {"normalize_log1p": "k_row_apply<T> (SRX_WB_SIDE=1 only: in-place write-back on the side stream; by default the moments pass stores the values)",
+                 "row_sums": "k_row_sum<float>", "gene_moments": "k_gene_moments<float,u16,XF,COUNT,WB> (f64 moments of the transform + the in-place store)",
                  "select": "k_gene_var + k_hvg_rank + k_hvg_take + k_sel_finish",
                  "hvg_compact": "k_rowcount + k_tfill (+ scan)", "spmm_fwd": "k_spmm_rows (row-major records x 64-col panel)",
                  "spmm_t": "k_spmm_t", "gram_sparse": "k_gram_stripes<float>",

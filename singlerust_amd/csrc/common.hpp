@@ -241,6 +241,7 @@ int32_t allreduce_f64(srx_ctx* ctx, double* d_buf, size_t count);
 struct RowXf {
     const double* row_sum = nullptr;
     double target = 0.0;
+    bool write_back = false;      // moments pass only: store the transformed value in place (at the storage precision)
 };
 int32_t upload_on(srx_ctx* ctx, const srx_csr* h, int32_t store, hipStream_t stream, srx_mat** out);   // ctx.hip
 int32_t ensure_tiles(srx_mat* m);

@@ -55,10 +55,13 @@ __device__ __forceinline__ void seg_bounds(const int64_t* __restrict__ indptr, c
 // the moments of the normalised + log1p'd matrix to f64 accuracy whatever the storage type, before (and without) the
 // in-place write-back.  COUNT = false: the per-gene counts are pattern-only and already cached on the matrix — one
 // LDS atomic per non-zero less.
-template <typename T, typename I, bool XF, bool COUNT>
+// WB (with XF): the transformed value is also stored back in place, at the storage precision — every stored value belongs to
+// exactly one (gene tile, row) segment, i.e. to one lane of one workgroup, so this pass IS the in-place normalise + log1p of
+// the pipeline and nothing reads the raw matrix after it.
+template <typename T, typename I, bool XF, bool COUNT, bool WB = false>
 __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     const int64_t* __restrict__ indptr, const int64_t* __restrict__ tp, const I* __restrict__ idx,
-    const T* __restrict__ vals, uint64_t n_rows, uint64_t n_cols, int n_tiles, int tile_genes,
+    std::conditional_t<WB, T, const T>* __restrict__ vals, uint64_t n_rows, uint64_t n_cols, int n_tiles, int tile_genes,
     uint64_t rows_per_block, const double* __restrict__ row_sum, double target, double fx_sum, double fx_sq,
     uint32_t* __restrict__ poison, uint32_t* __restrict__ part_cnt, double* __restrict__ part_sum, double* __restrict__ part_sq) {
     extern __shared__ double lds[];
@@ -143,6 +146,24 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
                         if (log1p_f64_moment_is_rare(x)) y4[j] = log1p_f64_rare(x, s_tab);
                     }
                 }
+            }
+        }
+        if constexpr (XF && WB) {
+            // the chunk's values go back as one 16-byte store (two for f64) when all four belong to the segment
+            T o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (T)y4[j];
+            if (rel >= 0 && (unsigned)(rel + 3) < len) {
+                if constexpr (sizeof(T) == 4) {
+                    *reinterpret_cast<float4*>(vals + e0) = float4{(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+                } else {
+                    *reinterpret_cast<double2*>(vals + e0) = double2{(double)o[0], (double)o[1]};
+                    *reinterpret_cast<double2*>(vals + e0 + 2) = double2{(double)o[2], (double)o[3]};
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((unsigned)(rel + j) < len) vals[e0 + j] = o[j];
             }
         }
 #pragma unroll
@@ -419,7 +440,8 @@ static int32_t local_moments(srx_mat* m, double** packed_out, RowXf xf = RowXf{}
     const size_t lds = (((size_t)m->tile_genes * 20 + 15) & ~(size_t)15) + (xf.row_sum ? (size_t)kLog1pTabBytes : 0);
     // s_i = 2 when the 16-bit index mirror exists (n_cols <= 65536), 4 otherwise
     const double bytes = (double)m->nnz * ((m->n_cols <= 65536 ? 2.0 : 4.0) + val_bytes(m)) + (double)(m->n_rows + 1) * 8.0 +
-                         (double)G * 24.0 + (xf.row_sum ? (double)m->n_rows * 8.0 : 0.0);
+                         (double)G * 24.0 + (xf.row_sum ? (double)m->n_rows * 8.0 : 0.0) +
+                         (xf.write_back ? (double)m->nnz * val_bytes(m) : 0.0);
     // fixed-point scales of the transformed sums: 62 bits hold n_rows values of magnitude < 2^6 (ln_1p(x) < 64, any
     // x < 6e27) resp. their squares
     double fx_sum = 0.0, fx_sq = 0.0;
@@ -437,7 +459,7 @@ static int32_t local_moments(srx_mat* m, double** packed_out, RowXf xf = RowXf{}
     {
         ProfScope ps(ctx, SRX_K_MOMENTS, bytes);
         dim3 grid((unsigned)(nb * m->n_tiles));
-        auto launch = [&](auto kern, const auto* idxp, const auto* valp) -> int32_t {
+        auto launch = [&](auto kern, const auto* idxp, auto* valp) -> int32_t {
             SRX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, grid, dim3(kMomThreads), lds, ctx->stream, m->d_indptr, m->d_tile_ptr, idxp, valp,
                                m->n_rows, G, m->n_tiles, m->tile_genes, rpb, xf.row_sum, xf.target, fx_sum, fx_sq, d_poison, p_cnt, p_sum, p_sq);
@@ -446,6 +468,10 @@ static int32_t local_moments(srx_mat* m, double** packed_out, RowXf xf = RowXf{}
         auto pick = [&](auto tval, auto tidx, const auto* idxp, const auto* valp) -> int32_t {
             using T = decltype(tval);
             using I = decltype(tidx);
+            if (xf.row_sum && xf.write_back) {
+                T* wp = const_cast<T*>(valp);
+                return have_cnt ? launch(k_gene_moments<T, I, true, false, true>, idxp, wp) : launch(k_gene_moments<T, I, true, true, true>, idxp, wp);
+            }
             if (xf.row_sum) return have_cnt ? launch(k_gene_moments<T, I, true, false>, idxp, valp) : launch(k_gene_moments<T, I, true, true>, idxp, valp);
             return have_cnt ? launch(k_gene_moments<T, I, false, false>, idxp, valp) : launch(k_gene_moments<T, I, false, true>, idxp, valp);
         };

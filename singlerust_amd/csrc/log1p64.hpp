@@ -276,11 +276,12 @@ __device__ __forceinline__ double xf_apply(T v, double scale, double row_table, 
     return y;
 }
 
-// What the in-place normalise + log1p pass leaves in X for a raw value v of a row with this scale — so that a pass which
-// reads the raw matrix (compaction) produces exactly the stored values: f32 storage rounds v * scale to f32 and takes the
-// f32 logarithm (k_row_pass<float, true, true>), f64 storage evaluates in f64.
-__device__ __forceinline__ float xf_stored(float v, double scale, const Log1pTabEntry*) {
-    return apply_log1p<float>((float)((double)v * scale));
+// What the pipeline leaves in X for a raw value v of a row with this scale — so that a pass which reads the raw matrix (the
+// compaction of a backed tile) produces exactly the stored values: the f64 logarithm the moments pass forms (degree-5 variant
+// for f32 storage, rounded once to f32: correctly rounded but for ~3 values in a million; the full-accuracy one for f64).
+// (The three separate calls on an f32 matrix round v * scale to f32 first and take the f32 logarithm: k_row_pass; <= 3e-7 apart.)
+__device__ __forceinline__ float xf_stored(float v, double scale, const Log1pTabEntry* __restrict__ tab) {
+    return (float)log1p_f64_moment((double)v * scale, tab);
 }
 __device__ __forceinline__ double xf_stored(double v, double scale, const Log1pTabEntry* __restrict__ tab) {
     return log1p_f64_fast(v * scale, tab);

@@ -3448,7 +3448,11 @@ int32_t srx_pipeline(srx_mat* m, double target_sum, uint64_t n_hvg, const srx_pc
     // side stream beside the Gram kernel.  CSC (cells are columns): the two calls, then the stored values.
     const uint64_t take = n_hvg < m->n_cols ? n_hvg : m->n_cols;
     const bool lazy = !m->csc && !getenv("SRX_NO_LAZY");
+    // SRX_WB_SIDE=1: the moments pass leaves X raw and the in-place pass runs on the side stream beside the iteration
+    // (the arrangement before the moments pass stored the values itself; kept for A/B runs)
+    static const bool side_wb = getenv("SRX_WB_SIDE") != nullptr;
     RowXf xf;
+    bool wrote_back = false;
     {
     Range r_("srx:normalize");
     if (m->csc) rc = srx_normalize_log1p_inplace(m, target_sum, nullptr);
@@ -3457,6 +3461,7 @@ int32_t srx_pipeline(srx_mat* m, double target_sum, uint64_t n_hvg, const srx_pc
         rc = launch_row_sums(m);
         xf.row_sum = m->d_row_sum;
         xf.target = target_sum;
+        xf.write_back = !side_wb;
         m->lazy_pending = true;
         m->lazy_target = target_sum;
     }
@@ -3467,6 +3472,16 @@ int32_t srx_pipeline(srx_mat* m, double target_sum, uint64_t n_hvg, const srx_pc
         Range r_("srx:gene_moments");
         if (lazy) {
             rc = ensure_moments_xf(m, xf);
+            if (rc == SRX_OK && xf.write_back) {
+                // X now holds the transformed values: the passes below read them as stored.  The bookkeeping of the two
+                // in-place calls (scale/mod.rs:74-83 -> F64, transform/mod.rs:43-55) belongs here, before the solve records
+                // the version of the matrix it ran on.
+                m->lazy_pending = false;
+                xf = RowXf{};
+                wrote_back = true;
+                m->dtype = SRX_F64;
+                touch(m);
+            }
             m->moments_version = m->version;          // what pca_device's ensure_moments looks at
         } else rc = ensure_moments(m);
     }
@@ -3497,6 +3512,9 @@ int32_t srx_pipeline(srx_mat* m, double target_sum, uint64_t n_hvg, const srx_pc
         if (rc == SRX_OK) rc = rc_wb;
     }
     (void)join_side(ctx);
+    // the moments cached on the matrix are those of the f64 transform, not of the values as stored: retired (a later
+    // compute_variance sees what X holds)
+    if (wrote_back) m->moments_version = m->version - 1;
     (void)hipEventRecord(ev[4], ctx->stream);
     (void)hipStreamSynchronize(ctx->stream);
     if (res) {

@@ -261,10 +261,10 @@ __global__ void k_row_number(const int64_t* __restrict__ indptr, uint64_t n_rows
     for (; i < n_rows; i += stride) out[i] = (uint32_t)(indptr[i + 1] - indptr[i]);
 }
 
-// The pipeline's in-place write-back: x <- ln_1p(x * target / row_sum) at the storage precision (f32: the product rounded
-// to f32, then the f32 logarithm; f64: the table-driven f64 logarithm) with the row sums the pipeline's first pass left in
-// `row_sum` — the moments and the compaction formed their values from the same sums through the same functions, so what
-// lands in X is exactly what they used.  No reduction, so nothing makes a wave wait for a whole row: 16-byte loads, four
+// In-place x <- ln_1p(x * target / row_sum) at the storage precision (the table-driven f64 logarithm, rounded once for f32
+// storage: `xf_stored`) with the row sums the pipeline's first pass left in `row_sum`.  The resident pipeline no longer needs
+// it — its moments pass stores the transformed values itself — it is the write-back of the SRX_WB_SIDE=1 order (the
+// round-2 arrangement: on a side stream beside the iteration).  No reduction, so nothing makes a wave wait for a whole row: 16-byte loads, four
 // in flight per lane, transformed and stored as they arrive.  (k_row_pass<T, true, true> re-sums every row first: 13 GB/s
 // per CU at f32, its time proportional to the CUs it was given — 3.0 ms beside the iteration on 224 CUs.)
 constexpr int kApplyUnroll = 4;
@@ -273,11 +273,9 @@ __global__ __launch_bounds__(256) void k_row_apply(const int64_t* __restrict__ i
                                                    double target, const double* __restrict__ row_sum) {
     using Vec = RowVec<T>;
     constexpr int V = 16 / sizeof(T);
-    __shared__ Log1pTabEntry s_tab[sizeof(T) == 8 ? 128 : 1];
-    if constexpr (sizeof(T) == 8) {
-        stage_log1p_table(s_tab);
-        __syncthreads();
-    }
+    __shared__ Log1pTabEntry s_tab[128];
+    stage_log1p_table(s_tab);
+    __syncthreads();
     const uint64_t wave = global_wave_id();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
