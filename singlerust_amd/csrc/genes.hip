@@ -194,37 +194,60 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
             }
         }
     };
-    for (uint64_t rbase = r0 + wave; rbase < r1; rbase += (uint64_t)kWaves * kMomRows) {
-        int64_t lo[kMomRows], hi[kMomRows];
-        double scale[kMomRows];
+    // Two groups of kMomRows / 2 row segments, worked on alternately: the pointers and the data of one are fetched while the
+    // other is evaluated (ping-pong between two register sets; the loads are unconditional — lanes past a segment's end read
+    // its first chunk again — because a branch around a load makes the compiler's wait for this group's data wait for the
+    // other group's loads too).
+    constexpr int kGrp = kMomRows / 2;
+    struct Group {
+        int64_t lo[kGrp], hi[kGrp];
+        double scale[kGrp];
+        Chunk c[kGrp];
+    };
+    auto fetch = [&](Group& g, uint64_t rbase) {
 #pragma unroll
-        for (int u = 0; u < kMomRows; ++u) {
+        for (int u = 0; u < kGrp; ++u) {
             const uint64_t r = rbase + (uint64_t)u * kWaves;
-            scale[u] = 1.0;
+            g.scale[u] = 1.0;
+            g.lo[u] = g.hi[u] = 0;
             if (r < r1) {
-                seg_bounds(indptr, tp, n_rows, n_tiles, tile, r, lo[u], hi[u]);
+                seg_bounds(indptr, tp, n_rows, n_tiles, tile, r, g.lo[u], g.hi[u]);
                 if constexpr (XF) {
                     const double sr = row_sum[r];
-                    scale[u] = sr == 0.0 ? 0.0 : target / sr;            // scale/mod.rs:9-15
+                    g.scale[u] = sr == 0.0 ? 0.0 : target / sr;            // scale/mod.rs:9-15
                 }
-            } else lo[u] = hi[u] = 0;
-        }
-        Chunk c[kMomRows];
-#pragma unroll
-        for (int u = 0; u < kMomRows; ++u) {
-            const int64_t e0 = (lo[u] & ~(int64_t)3) + 4 * lane;
-            if (e0 < hi[u]) load_chunk(e0, c[u]);
+            }
         }
 #pragma unroll
-        for (int u = 0; u < kMomRows; ++u) {
-            const int64_t e0 = (lo[u] & ~(int64_t)3) + 4 * lane;
-            if (e0 < hi[u]) add_chunk(e0, lo[u], hi[u], c[u], scale[u]);
+        for (int u = 0; u < kGrp; ++u) {
+            const int64_t b0 = g.lo[u] & ~(int64_t)3, e0 = b0 + 4 * lane;
+            load_chunk(e0 < g.hi[u] ? e0 : b0, g.c[u]);
+        }
+    };
+    auto compute = [&](const Group& g) {
+#pragma unroll
+        for (int u = 0; u < kGrp; ++u) {
+            const int64_t e0 = (g.lo[u] & ~(int64_t)3) + 4 * lane;
+            if (e0 < g.hi[u]) add_chunk(e0, g.lo[u], g.hi[u], g.c[u], g.scale[u]);
             // segments longer than 256 entries: the rest, one chunk at a time
-            for (int64_t e1 = e0 + 4 * kWave; e1 < hi[u]; e1 += 4 * kWave) {
+            for (int64_t e1 = e0 + 4 * kWave; e1 < g.hi[u]; e1 += 4 * kWave) {
                 Chunk cc;
                 load_chunk(e1, cc);
-                add_chunk(e1, lo[u], hi[u], cc, scale[u]);
+                add_chunk(e1, g.lo[u], g.hi[u], cc, g.scale[u]);
             }
+        }
+    };
+    {
+        const uint64_t stride = (uint64_t)kWaves * kGrp;
+        Group A, B;
+        uint64_t rbase = r0 + wave;
+        fetch(A, rbase);
+        while (rbase < r1) {
+            fetch(B, rbase + stride);
+            compute(A);
+            fetch(A, rbase + 2 * stride);
+            compute(B);
+            rbase += 2 * stride;
         }
     }
     __syncthreads();
