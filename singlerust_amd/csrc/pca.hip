@@ -1591,6 +1591,78 @@ __global__ __launch_bounds__(1024) void k_chol_factor(const double* __restrict__
     if (bad && tid == 0) atomicOr(status, kStatChol);
 }
 
+// The plain factorisation (no shift, no dropped columns) in panels of kCholPanel rows: wave 0 factors a panel on its own, in
+// registers — eight dependent steps of (v_readlane, rsqrt, multiply-subtract), no LDS round trip and no barrier — then all
+// threads subtract the panel's rank-8 update from the trailing rows: 16 barriers for l = 64 instead of 64 (the CholeskyQR
+// runs five times per solve).  Same outputs and status as k_chol_factor(shifted = 0).
+constexpr int kCholPanel = 8;
+__global__ __launch_bounds__(1024) void k_chol_factor_panels(const double* __restrict__ G, int n, double* __restrict__ Rout,
+                                                             double* __restrict__ dinv, int* __restrict__ status) {
+    __shared__ double A[L][L + 1];           // the rows of a finished panel hold R
+    __shared__ int s_bad;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < L * L; e += 1024) {
+        const int r = e >> 6, c = e & 63;
+        A[r][c] = (r < n && c < n) ? G[(size_t)r * L + c] : 0.0;
+    }
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += kCholPanel) {
+        const int j1 = j0 + kCholPanel < n ? j0 + kCholPanel : n;
+        if (tid < kWave) {
+            // lane c holds column c of the panel's rows in registers; pivots and multipliers travel by v_readlane (a pivot
+            // step through LDS — read the pivot, write the row, read the multipliers, update — was 0.6 us of latency,
+            // the same as the one-barrier-per-step kernel)
+            const int c = tid;
+            double a[kCholPanel];
+#pragma unroll
+            for (int jj = 0; jj < kCholPanel; ++jj) a[jj] = j0 + jj < j1 ? A[j0 + jj][c] : 0.0;
+#pragma unroll
+            for (int jj = 0; jj < kCholPanel; ++jj) {
+                const int j = j0 + jj;
+                if (j < j1) {                                   // (uniform)
+                    const double d = readlane_v(a[jj], j);
+                    if (!(d > 0.0) && c == 0) s_bad = 1;
+                    const double inv = rsqrt(d);
+                    const double rjc = (c >= j && c < n) ? a[jj] * inv : 0.0;
+                    a[jj] = rjc;                                // row j of R (zero left of the diagonal and right of n)
+                    if (c == j) dinv[j] = inv;
+#pragma unroll
+                    for (int rr = jj + 1; rr < kCholPanel; ++rr) {
+                        const int r = j0 + rr;
+                        if (r < j1) {
+                            const double rjr = readlane_v(rjc, r);
+                            if (c >= r && c < n) a[rr] -= rjr * rjc;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < kCholPanel; ++jj)
+                if (j0 + jj < j1) {
+                    A[j0 + jj][c] = a[jj];
+                    Rout[(size_t)(j0 + jj) * L + c] = a[jj];
+                }
+        }
+        __syncthreads();
+        // trailing rows r >= j1: a_rc -= sum over the panel of r_jr r_jc, c >= r
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 1024 * u, r = e >> 6, c = e & 63;
+            if (r >= j1 && c >= r && c < n) {
+                double acc = A[r][c];
+                for (int j = j0; j < j1; ++j) acc -= A[j][r] * A[j][c];
+                A[r][c] = acc;
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < L * L; e += 1024)
+        if ((e >> 6) >= n) Rout[e] = 0.0;
+    if (tid < L && tid >= n) dinv[tid] = 0.0;
+    if (tid == 0 && s_bad) atomicOr(status, kStatChol);
+}
+
 // W[row] R = Wp[row]: w_j = (wp_j - sum_{i<j} w_i R[i][j]) / R[j][j], one thread per row, the row in
 // registers (the j / i loops are fully unrolled: static register indices), R transposed in LDS so that
 // the i-loop of a column reads consecutive words (wave-uniform addresses: broadcast, no conflicts).
@@ -2407,8 +2479,10 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     // thread of the substitution owns one row); G lands in dHG + L*L
     auto orth = [&](const double* src) -> int32_t {
         SRX_TRY(gram2(ctx, w, src, src, k));
-        hipLaunchKernelGGL(k_chol_factor, dim3(1), dim3(1024), 0, ctx->stream, w.dHG + L * L, l_act, w.dM, w.dDinv, d_status,
-                           o.robust ? 1 : 0);
+        if (o.robust)
+            hipLaunchKernelGGL(k_chol_factor, dim3(1), dim3(1024), 0, ctx->stream, w.dHG + L * L, l_act, w.dM, w.dDinv, d_status, 1);
+        else
+            hipLaunchKernelGGL(k_chol_factor_panels, dim3(1), dim3(1024), 0, ctx->stream, w.dHG + L * L, l_act, w.dM, w.dDinv, d_status);
         hipLaunchKernelGGL(k_trsm_rows, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, src, w.dM, w.dDinv, k, w.W);
         SRX_HIP(ctx, hipGetLastError());
         if (o.robust) {                         // second pass: the first one may have run on a shifted Gram matrix
