@@ -28,6 +28,13 @@ def test_pipeline_orders_agree(tmp_path, store, vtol):
     base = run(str(tmp_path), "default", store)
     side = run(str(tmp_path), "side", store, SRX_WB_SIDE="1")
     eager = run(str(tmp_path), "eager", store, SRX_NO_LAZY="1")
+    # the device-side ranking of HighlyVariable(n): candidates above a sampled threshold (default), every gene
+    # (SRX_HVG_FULL_RANK), and the fallback taken on the device when the threshold leaves too few candidates
+    full = run(str(tmp_path), "full", store, SRX_HVG_FULL_RANK="1")
+    miss = run(str(tmp_path), "miss", store, SRX_HVG_FORCE_MISS="1")
+    np.testing.assert_array_equal(base["hv"], full["hv"])
+    np.testing.assert_array_equal(base["hv"], miss["hv"])
+    np.testing.assert_allclose(miss["evr"], base["evr"], rtol=1e-9)       # (the Gram sums differ in their last bits run to run)
     assert base["residual"] <= 1e-7 and side["residual"] <= 1e-7 and eager["residual"] <= 1e-7
     # the stored matrix: default and side stream store the same function of the same arguments
     np.testing.assert_array_equal(base["values"], side["values"])
