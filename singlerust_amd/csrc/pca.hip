@@ -1414,7 +1414,7 @@ __global__ void k_finish_t(const double* __restrict__ T, const double* __restric
 
 // H = A^T B, G = B^T B for two k x 64 blocks (f64).  Each workgroup reduces a slice of the k rows
 // (staged through LDS) into a partial 64 x 64 pair; k_gram2_reduce sums the slices in fixed order.
-constexpr int kGram2Blocks = 32;
+constexpr int kGram2Blocks = 64;
 __global__ __launch_bounds__(1024) void k_gram2_part(const double* __restrict__ A, const double* __restrict__ B, int k,
                                                      double* __restrict__ part /* [blocks][2][64*64] */) {
     constexpr int R = 32;
@@ -2395,7 +2395,7 @@ static int32_t alloc_work(srx_ctx* ctx, int k, Work& w) {
 }
 
 static int32_t gram2(srx_ctx* ctx, const Work& w, const double* A, const double* B, int k) {
-    int nb = (k + 63) / 64;
+    int nb = (k + 31) / 32;                    // one 32-row slab per workgroup where the block count allows
     if (nb > kGram2Blocks) nb = kGram2Blocks;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(k_gram2_part, dim3(nb), dim3(1024), 0, ctx->stream, A, B, k, w.gpart);
