@@ -146,6 +146,7 @@ int32_t srx_backed_create(srx_ctx* ctx, uint64_t n_cols, int32_t store, srx_back
     SRX_HIP(ctx, hipSetDevice(ctx->device));
     srx_backed* b = new srx_backed();
     b->ctx = ctx;
+    ctx->pool_on += 1;             // the tiles' device buffers are recycled from here on (common.hpp)
     b->n_cols = n_cols;
     b->store_req = store;
     auto bail = [&](int32_t rc) { srx_backed_destroy(b); return rc; };
@@ -181,6 +182,7 @@ void srx_backed_destroy(srx_backed* b) {
         delete b->acc;
     }
     if (b->up_stream) (void)hipStreamDestroy(b->up_stream);
+    if (b->ctx && b->ctx->pool_on > 0 && --b->ctx->pool_on == 0) pool_clear(b->ctx);
     delete b;
 }
 

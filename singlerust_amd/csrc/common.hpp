@@ -91,6 +91,11 @@ struct srx_ctx {
     // named scratch buffers that only ever grow (no hipMalloc inside the steady-state path)
     struct Scratch { void* p = nullptr; size_t bytes = 0; };
     std::map<std::string, Scratch> scratch;
+    // Device buffers of matrices that come and go (the row tiles of a backed session: a hipMalloc / hipFree pair of ~0.6 GB
+    // per array and tile) are recycled instead of returned: after some tens of such pairs a single hipMalloc took 2.5 s
+    // (profiles/r02_c5_backed.json: sweep 2 at 25 instead of 63 GB/s).  `pool_on` counts the open backed sessions.
+    int pool_on = 0;
+    std::vector<std::pair<void*, size_t>> pool;
     // pinned host staging for small D2H/H2D blocks
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
@@ -140,6 +145,7 @@ struct srx_mat {
     uint64_t n_rows = 0, n_cols = 0, nnz = 0;
     int32_t dtype = SRX_F32;   // logical dtype (DynCsrMatrix variant)
     int32_t store = SRX_STORE_F32;
+    bool pooled = false;           // buffers go back to ctx->pool when the matrix is freed
     bool store_auto = false;   // SRX_STORE_AUTO at creation: normalize_total / log1p promote f32 storage to f64 where the
                                // reference's DynCsrMatrix variant becomes F64 (scale/mod.rs:74-83, transform/mod.rs:48-55)
     int64_t* d_indptr = nullptr;
@@ -244,6 +250,8 @@ struct RowXf {
     bool write_back = false;      // moments pass only: store the transformed value in place (at the storage precision)
 };
 int32_t upload_on(srx_ctx* ctx, const srx_csr* h, int32_t store, hipStream_t stream, srx_mat** out);   // ctx.hip
+hipError_t dev_malloc(srx_ctx* ctx, void** p, size_t bytes);     // ctx.hip: hipMalloc, or a recycled buffer while ctx->pool_on
+void pool_clear(srx_ctx* ctx);
 int32_t ensure_tiles(srx_mat* m);
 int32_t promote_to_f64(srx_mat* m);                   // ctx.hip: f32 storage -> f64 storage, values unchanged
 int32_t ensure_pattern_counts(srx_mat* m);            // genes.hip

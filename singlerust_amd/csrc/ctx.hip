@@ -5,6 +5,7 @@
 // indices, f32 or f64 values — the narrowing of the reference's usize indices
 // (nalgebra_sparse::CsrMatrix) happens once, here.
 #include "common.hpp"
+#include <chrono>
 
 #include <dlfcn.h>
 
@@ -225,18 +226,45 @@ static int32_t convert_chunked(srx_ctx* ctx, hipStream_t stream, const char* tmp
     return SRX_OK;
 }
 
+// hipMalloc, or — while a backed session is open on the context — a recycled buffer of about the size (best fit among those
+// at most a quarter larger; fresh ones get 3 % of headroom so that the next tile's slightly different size still fits)
+hipError_t dev_malloc(srx_ctx* ctx, void** p, size_t bytes) {
+    if (!ctx->pool_on) return hipMalloc(p, bytes);
+    int best = -1;
+    for (size_t i = 0; i < ctx->pool.size(); ++i) {
+        const size_t cap = ctx->pool[i].second;
+        if (cap >= bytes && cap <= bytes + bytes / 4 + (1u << 20) && (best < 0 || cap < ctx->pool[(size_t)best].second)) best = (int)i;
+    }
+    if (best >= 0) {
+        *p = ctx->pool[(size_t)best].first;
+        ctx->pool.erase(ctx->pool.begin() + best);
+        return hipSuccess;
+    }
+    return hipMalloc(p, bytes + bytes / 32 + 65536);
+}
+static void dev_release(srx_mat* m, void* p) {
+    if (!p) return;
+    size_t cap = 0;
+    if (m->pooled && m->ctx && hipMemPtrGetInfo(p, &cap) == hipSuccess && cap > 0) m->ctx->pool.emplace_back(p, cap);
+    else (void)hipFree(p);
+}
+void pool_clear(srx_ctx* ctx) {
+    for (auto& b : ctx->pool) (void)hipFree(b.first);
+    ctx->pool.clear();
+}
+
 static void free_mat_buffers(srx_mat* m) {
     if (!m) return;
-    (void)hipFree(m->d_indptr);
-    (void)hipFree(m->d_indices);
-    (void)hipFree(m->d_values);
-    (void)hipFree(m->d_tile_ptr);
-    (void)hipFree(m->d_idx16);
-    (void)hipFree(m->d_cnt);
-    (void)hipFree(m->d_cnt_pat);
-    (void)hipFree(m->d_sum);
-    (void)hipFree(m->d_sq);
-    (void)hipFree(m->d_row_sum);
+    dev_release(m, m->d_indptr);
+    dev_release(m, m->d_indices);
+    dev_release(m, m->d_values);
+    dev_release(m, m->d_tile_ptr);
+    dev_release(m, m->d_idx16);
+    dev_release(m, m->d_cnt);
+    dev_release(m, m->d_cnt_pat);
+    dev_release(m, m->d_sum);
+    dev_release(m, m->d_sq);
+    dev_release(m, m->d_row_sum);
     (void)hipFree(m->pca.d_scores);
 }
 
@@ -393,9 +421,15 @@ int32_t upload_on(srx_ctx* ctx, const srx_csr* h, int32_t store, hipStream_t str
     if (h->indptr[h->n_rows] - base != h->nnz)
         return fail(ctx, SRX_E_FORMAT, "X is not a CSR matrix: row_offsets do not span nnz");
     srx_mat* m = nullptr;
+    static const bool trace = getenv("SRX_UPLOAD_TRACE") != nullptr;        // reports uploads that take > 100 ms, by phase
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tt[6] = {0, 0, 0, 0, 0, 0};
+    tt[0] = trace ? now() : 0.0;
     SRX_TRY(srx_matrix_alloc(ctx, h->n_rows, h->n_cols, h->nnz, h->dtype, store, &m));
+    tt[1] = trace ? now() : 0.0;
     auto bail = [&](int32_t rc) { srx_matrix_free(m); return rc; };
     hipError_t e = hipMemcpy(m->d_indptr, h->indptr, (h->n_rows + 1) * sizeof(int64_t), hipMemcpyHostToDevice);
+    tt[2] = trace ? now() : 0.0;
     if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "H2D indptr: %s", hipGetErrorString(e)));
     if (base)
         hipLaunchKernelGGL(k_rebase_indptr, dim3((unsigned)((h->n_rows + 256) / 256)), dim3(256), 0, stream, m->d_indptr,
@@ -416,10 +450,12 @@ int32_t upload_on(srx_ctx* ctx, const srx_csr* h, int32_t store, hipStream_t str
         if (rc) return bail(rc);
         if (bad_col) return bail(fail(ctx, SRX_E_BOUNDS, "column index out of bounds (>= n_cols = %llu)",
                                       (unsigned long long)h->n_cols));
+        tt[3] = trace ? now() : 0.0;
         if (plain_values) {
             rc = parallel_h2d(ctx, h->values, m->d_values, h->nnz, false, val_bytes(m), 0, nullptr);
             if (rc) return bail(rc);
         }
+        tt[4] = trace ? now() : 0.0;
     }
     (void)tmp_tag;
     if (!plain_values && h->nnz) {
@@ -446,6 +482,9 @@ int32_t upload_on(srx_ctx* ctx, const srx_csr* h, int32_t store, hipStream_t str
     if (flag & 1) return bail(fail(ctx, SRX_E_BOUNDS, "column index out of bounds (>= n_cols = %llu)",
                                    (unsigned long long)h->n_cols));
     if (flag & 2) return bail(fail(ctx, SRX_E_FORMAT, "X is not a canonical CSR matrix (unsorted/duplicate column indices)"));
+    if (trace && now() - tt[0] > 100.0)
+        fprintf(stderr, "[upload] SLOW: alloc %.1f indptr %.1f indices %.1f values %.1f validate %.1f ms\n", tt[1] - tt[0], tt[2] - tt[1],
+                tt[3] - tt[2], tt[4] - tt[3], now() - tt[4]);
     *out = m;
     return SRX_OK;
 }
@@ -501,6 +540,7 @@ void srx_ctx_destroy(srx_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     srx_comm_destroy(ctx);
     for (auto& kv : ctx->scratch) (void)hipFree(kv.second.p);
+    pool_clear(ctx);
     for (int c = 0; c < SRX_K_COUNT_; ++c)
         for (auto& pr : ctx->prof[c].pending) {
             (void)hipEventDestroy(pr.first);
@@ -573,11 +613,12 @@ int32_t srx_matrix_alloc(srx_ctx* ctx, uint64_t n_rows, uint64_t n_cols, uint64_
     m->store = resolve_store(dtype, store);
     m->store_auto = store == SRX_STORE_AUTO;
     m->n_rows_global = n_rows;
+    m->pooled = ctx->pool_on > 0;
     hipError_t e;
-    e = hipMalloc((void**)&m->d_indptr, (n_rows + 1) * sizeof(int64_t));
+    e = dev_malloc(ctx, (void**)&m->d_indptr, (n_rows + 1) * sizeof(int64_t));
     // +16 elements: the streaming kernels read 16-byte vectors that may run past a row's last entry
-    if (e == hipSuccess) e = hipMalloc((void**)&m->d_indices, (nnz + 16) * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc(&m->d_values, (nnz + 16) * val_bytes(m));
+    if (e == hipSuccess) e = dev_malloc(ctx, (void**)&m->d_indices, (nnz + 16) * sizeof(int32_t));
+    if (e == hipSuccess) e = dev_malloc(ctx, &m->d_values, (nnz + 16) * val_bytes(m));
     if (e == hipSuccess) e = hipMemsetAsync(m->d_indices + nnz, 0, 16 * sizeof(int32_t), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync((char*)m->d_values + nnz * val_bytes(m), 0, 16 * val_bytes(m), ctx->stream);
     if (e != hipSuccess) {

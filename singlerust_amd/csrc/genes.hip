@@ -415,11 +415,11 @@ int32_t ensure_tiles(srx_mat* m) {
     int nt, tg;
     tile_geometry(m, nt, tg);
     if (nt > 1) {
-        SRX_HIP(ctx, hipMalloc((void**)&m->d_tile_ptr, (size_t)(nt - 1) * (m->n_rows ? m->n_rows : 1) * sizeof(int64_t)));
+        SRX_HIP(ctx, dev_malloc(ctx, (void**)&m->d_tile_ptr, (size_t)(nt - 1) * (m->n_rows ? m->n_rows : 1) * sizeof(int64_t)));
         SRX_TRY(launch_tile_ptr(ctx, m->d_indptr, m->d_indices, m->n_rows, nt, tg, m->d_tile_ptr));
     }
     if (m->n_cols <= 65536 && !m->d_idx16) {
-        SRX_HIP(ctx, hipMalloc((void**)&m->d_idx16, (m->nnz + 16) * sizeof(uint16_t)));
+        SRX_HIP(ctx, dev_malloc(ctx, (void**)&m->d_idx16, (m->nnz + 16) * sizeof(uint16_t)));
         uint64_t g = (m->nnz + 16 + 1023) / 1024;
         if (g < 1) g = 1;
         if (g > 65535) g = 65535;
@@ -459,7 +459,7 @@ static int32_t local_moments(srx_mat* m, double** packed_out, RowXf xf = RowXf{}
     // the per-gene counts depend on the sparsity pattern only: computed by the first pass over a pattern, kept on the
     // matrix (clones inherit them), and the count atomic is left out of every later pass
     const bool have_cnt = m->cnt_pat_valid && m->d_cnt_pat;
-    if (!m->d_cnt_pat) SRX_HIP(ctx, hipMalloc((void**)&m->d_cnt_pat, (G ? G : 1) * sizeof(uint32_t)));
+    if (!m->d_cnt_pat) SRX_HIP(ctx, dev_malloc(ctx, (void**)&m->d_cnt_pat, (G ? G : 1) * sizeof(uint32_t)));
     const size_t lds = (((size_t)m->tile_genes * 20 + 15) & ~(size_t)15) + (xf.row_sum ? (size_t)kLog1pTabBytes : 0);
     // s_i = 2 when the 16-bit index mirror exists (n_cols <= 65536), 4 otherwise
     const double bytes = (double)m->nnz * ((m->n_cols <= 65536 ? 2.0 : 4.0) + val_bytes(m)) + (double)(m->n_rows + 1) * 8.0 +

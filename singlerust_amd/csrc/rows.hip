@@ -321,7 +321,7 @@ int32_t launch_normalize(srx_mat* m, double target, bool do_norm, bool do_log, h
     srx_ctx* ctx = m->ctx;
     SRX_HIP(ctx, hipSetDevice(ctx->device));
     if (!stream) stream = ctx->stream;
-    if (do_norm && !m->d_row_sum) SRX_HIP(ctx, hipMalloc((void**)&m->d_row_sum, (m->n_rows ? m->n_rows : 1) * sizeof(double)));
+    if (do_norm && !m->d_row_sum) SRX_HIP(ctx, dev_malloc(ctx, (void**)&m->d_row_sum, (m->n_rows ? m->n_rows : 1) * sizeof(double)));
     int g = row_grid(m);
     if (wgs_per_cu > 0 && g > ctx->n_cus * wgs_per_cu) g = ctx->n_cus * wgs_per_cu;
     const double bytes = (double)m->nnz * 2.0 * val_bytes(m) + (double)(m->n_rows + 1) * 8.0;
@@ -376,7 +376,7 @@ int32_t launch_row_apply(srx_mat* m, double target, hipStream_t stream) {
 int32_t launch_row_sums(srx_mat* m) {
     srx_ctx* ctx = m->ctx;
     SRX_HIP(ctx, hipSetDevice(ctx->device));
-    if (!m->d_row_sum) SRX_HIP(ctx, hipMalloc((void**)&m->d_row_sum, (m->n_rows ? m->n_rows : 1) * sizeof(double)));
+    if (!m->d_row_sum) SRX_HIP(ctx, dev_malloc(ctx, (void**)&m->d_row_sum, (m->n_rows ? m->n_rows : 1) * sizeof(double)));
     const int g = row_grid(m);
     ProfScope ps(ctx, SRX_K_ROWSUM, (double)m->nnz * val_bytes(m) + (double)(m->n_rows + 1) * 8.0 + (double)m->n_rows * 8.0);
     if (is_f32(m))
