@@ -52,9 +52,9 @@ KERNEL_SYMBOL = {"normalize_log1p": "k_row_apply<T> (SRX_WB_SIDE=1 only: in-plac
 ROOF_NOTE = {
     "gram_sparse": "algorithmic bytes = the row-major HVG-compacted matrix (8-byte entries) and the 12-byte owner records read "
                    "once + the packed upper triangle of G written once.  Not an HBM-bound kernel: N m(m+1)/2 = 3.4e9 scalar "
-                   "products per launch at c3, each one lane of an f64 LDS atomic (LDS pipe 66 % busy, 14 clk per 36-lane "
+                   "products per launch at c3, each one lane of an f64 LDS atomic (LDS pipe 72 % busy, 14 clk per ~34-lane "
                    "instruction) fed by one gathered 8-byte operand (every row suffix is re-read once per kept entry of its "
-                   "row: 19 GB through the fabric per launch) — profiles/r02_pmc_gram.md",
+                   "row: 19 GB of L2 requests, 11-19 GB through the fabric per launch) — profiles/r02_pmc_gram.md",
     "spmm_fwd": "algorithmic bytes: the row-major compacted matrix (nnz_w * 8) + row pointers and row order (N * 12) + the "
                 "k x 64 f32 panel once per workgroup column slice + the output, which for this launch (the transform) is the "
                 "N x n_pc f64 score matrix written by the SpMM itself.  Not HBM-bound either: 64 multiply-adds per kept "
