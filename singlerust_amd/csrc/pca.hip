@@ -2024,6 +2024,9 @@ static int32_t build_compact(srx_mat* m, const std::vector<int32_t>& remap, int 
     SRX_TRY(scratch(ctx, "pca_cvals", (c.nnz ? c.nnz : 1) * vb, &c.vals));
     const size_t pb = vb == 4 ? sizeof(GramPk<float>) : sizeof(GramPk<double>);
     SRX_TRY(scratch(ctx, "pca_rm_pk", (c.nnz + 64) * pb, &rm.pk));
+    // the 64 entries behind the last row are READ by the forward kernel (a row's last chunk runs past its end: value masked
+    // to 0, column used as is): they must name a real column, or 0 x panel[garbage] is NaN
+    SRX_HIP(ctx, hipMemsetAsync((char*)rm.pk + c.nnz * pb, 0, 64 * pb, ctx->stream));
     const unsigned pg = (unsigned)std::min<uint64_t>((c.nnz + 255) / 256 + 1, 65536);
     if (is_f32(m)) {
         hipLaunchKernelGGL((k_compact_fill<float>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream, m->d_indptr,
@@ -2144,6 +2147,9 @@ static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words,
     }
     const size_t pb = is_f32(m) ? sizeof(GramPk<float>) : sizeof(GramPk<double>);
     SRX_TRY(scratch(ctx, "pca_rm_pk", ((size_t)total + 64) * pb, &rm.pk));
+    // the 64 entries behind the last row are READ by the forward kernel (a row's last chunk runs past its end: value masked
+    // to 0, column used as is): they must name a real column, or 0 x panel[garbage] is NaN
+    SRX_HIP(ctx, hipMemsetAsync((char*)rm.pk + (size_t)total * pb, 0, 64 * pb, ctx->stream));
     rm.n_rows = N;
     rm.nnz = (uint64_t)total;
     rm.k = k;
