@@ -17,8 +17,11 @@ per GPU) is measured after it with fewer steps.
 One JSON line on rank 0.  Besides the contract's fields it carries (N = 1 only, each a short bounded run after the
 timed region): the f64-storage pipeline (`f64_storage`), the matrix-free solver's SpMM kernels (`roofline_spmm_iter`),
 a skewed-gene matrix (`skewed_genes`), a hard spectrum (`hard_spectrum`), the rate including the upload of a host CSR
-and the download of the scores (`incl_h2d`), and two CPU baselines timed on this box (`cpu_baseline`: the
-reference-faithful serial restatement; `cpu_baseline_threaded`: the OpenMP variant with the cheaper k x k PCA).
+and the download of the scores (`incl_h2d`), the pipeline on a fresh un-prepared handle (`cold_step`), configs[4] streamed
+from pinned host memory through the backed session (`c5_backed`), and three CPU baselines timed on this box (`cpu_baseline`:
+the OpenMP restatement on <= 64 threads; `cpu_baseline_reference_faithful`: serial loops + full SVD on a sample;
+`cpu_baseline_c1_serial`: BASELINE.md's C1 whole on one thread).  `python bench.py --gpus N` with N > 1 and no launcher
+environment starts its own N ranks (one per GPU).
 """
 from __future__ import annotations
 
@@ -50,8 +53,9 @@ KERNEL_SYMBOL = {"normalize_log1p": "k_row_apply<T> (SRX_WB_SIDE=1 only: in-plac
                  "gram_bucket": "k_rec_count + k_rec_scan + k_bucket (owner records of the Gram kernel)",
                  "iterate": "k x 64 subspace iteration (hipGraph replays)", "dense_apply": "k_dense_apply"}
 ROOF_NOTE = {
-    "gram_sparse": "algorithmic bytes = the row-major HVG-compacted matrix (8-byte entries) and the 12-byte owner records read "
-                   "once + the packed upper triangle of G written once.  Not an HBM-bound kernel: N m(m+1)/2 = 3.4e9 scalar "
+    "gram_sparse": "algorithmic bytes = what any Gram kernel must move: the row-major HVG-compacted matrix (8-byte entries) and "
+                   "its row pointers read once + the packed upper triangle of G written once; the 12-byte owner records and block "
+                   "offsets this kernel reads besides are `aux_bytes_per_launch`.  Not an HBM-bound kernel: N m(m+1)/2 = 3.4e9 scalar "
                    "products per launch at c3, each one lane of an f64 LDS atomic (LDS pipe 72 % busy, 14 clk per ~34-lane "
                    "instruction) fed by one gathered 8-byte operand (every row suffix is re-read once per kept entry of its "
                    "row: 19 GB of L2 requests, 11-19 GB through the fabric per launch) — profiles/r02_pmc_gram.md",
@@ -113,7 +117,7 @@ def usable_cores():
 
 def load_traffic(config):
     """HBM bytes per pipeline step from the committed PMC passes (profiles/make_traffic.py), per bench kernel class."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{config}.json")
         try:
             with open(path) as fh:
@@ -161,6 +165,7 @@ class Bench:
         self.dist = self.group if (self.world > 1 or launched) else None
         self.json_fd = None
         self.collective = None
+        self.comm_info = None
         if self.dist is not None:
             self._comm_init()
 
@@ -191,15 +196,29 @@ class Bench:
                 # RCCL could not be brought up on some rank (or SRX_BENCH_COLLECTIVE=host): the sums over ranks go
                 # through the host transport hook of the C-ABI (srx_comm_init_host) over the rendezvous sockets.
                 # Same arithmetic, slower exchange; the JSON line says which one ran.
+                if os.environ.get("SRX_BENCH_COLLECTIVE", "rccl") != "host":
+                    # a scaling curve over the host star would not be a measurement of RCCL over xGMI: refuse
+                    print(f"[bench rank {rank}] RCCL could not be brought up ({comm_err or 'see other ranks'}); "
+                          "SRX_BENCH_COLLECTIVE=host selects the host transport explicitly", file=sys.stderr)
+                    sys.exit(3)
                 F.check(self.lib.srx_comm_destroy(ctx.handle), ctx.handle)
                 ctx.comm_init_host(world, rank, group.allreduce_sum_f64)
                 collective = "host-star"
-                print(f"[bench rank {rank}] RCCL unavailable ({comm_err or 'see other ranks'}): host all-reduce", file=sys.stderr)
         finally:
             # fd 1 stays on stderr for the rest of a multi-rank run (RCCL may warn on stdout at any collective); the one
             # JSON line goes to the saved descriptor at the end
             self.json_fd = saved
         self.collective = collective
+        # what the sums really go through: kind, RCCL version, and a 1.0 summed over the communicator by the path's own
+        # all-reduce (a collective call: every rank makes it) — must equal the world size
+        kind, nr, ver, seen = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        F.check(self.lib.srx_comm_info(ctx.handle, C.byref(kind), C.byref(nr), C.byref(ver), C.byref(seen)), ctx.handle)
+        self.comm_info = {"collective": collective, "kind": {0: "none", 1: "rccl", 2: "host"}[kind.value],
+                          "rccl_version": ver.value, "n_ranks": nr.value, "n_ranks_seen": seen.value,
+                          "launcher": os.environ.get("SRX_BENCH_LAUNCHER", "torch.distributed.run / external")}
+        if seen.value != world or (collective == "rccl") != (kind.value == 1):
+            print(f"[bench rank {rank}] communicator check failed: {self.comm_info}", file=sys.stderr)
+            sys.exit(3)
 
     def sync_all(self):
         self.ctx.synchronize()               # every kernel of the path runs on this context's streams (the pipeline joins them)
@@ -305,7 +324,9 @@ class Bench:
         for cls_, name in classes.items():
             ms, n, b = ctx.prof_get(cls_)
             if n:
+                aux = ctx.prof_get_aux(cls_)
                 prof[name] = {"launches": n, "avg_ms": ms / n, "alg_bytes_per_launch": b / n,
+                              **({"aux_bytes_per_launch": aux / n} if aux else {}),
                               "GBps": (b / n) / (ms / n * 1e-3) / 1e9 if ms > 0 else None,
                               "frac_of_peak": (b / n) / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None}
         ctx.prof_enable(0)
@@ -337,7 +358,52 @@ def attributed(prof, steps):
 def roof(d, kernel, note):
     return {"bound": "hbm", "kernel": kernel, "achieved": d.get("GBps"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": d.get("frac_of_peak"), "traffic": d.get("hbm_traffic_per_launch"), "launches": d.get("launches"),
-            "avg_ms": d.get("avg_ms"), "alg_bytes_per_launch": d.get("alg_bytes_per_launch"), "note": note}
+            "avg_ms": d.get("avg_ms"), "alg_bytes_per_launch": d.get("alg_bytes_per_launch"),
+            **({"aux_bytes_per_launch": d["aux_bytes_per_launch"]} if d.get("aux_bytes_per_launch") else {}), "note": note}
+
+
+def cold_step(B, config, n_global, storage, reps=3):
+    """What a caller pays who runs the path ONCE per dataset: srx_pipeline on a FRESH handle — no srx_matrix_prepare, no
+    srx_matrix_reserve_results before the clock; the matrix itself resident in HBM.  The first call builds the pattern-only
+    structures (16-bit index mirror, gene-tile cuts, per-gene counts) and allocates the result block inside the step.  Run after
+    the timed region, so the context is warm (scratch buffers, captured graphs, code objects): the cost measured is the
+    matrix's own.  `prepare_ms` / `reserve_ms`: the two set-up calls timed on their own on another fresh handle."""
+    a, F, sr, lib, ctx = B.a, B.F, B.sr, B.lib, B.ctx
+    p = B.params(config, n_global)
+    f64 = storage == "f64"
+    opts = F.PcaOpts(a.npc, -1, -1, -1, 0, 0, 0, 0.0, 12345)
+    res = F.PipelineResult()
+
+    def fresh():
+        h = C.c_void_p()
+        F.check(lib.srx_synth_generate(ctx.handle, C.byref(p), 0, n_global, F.F64 if f64 else F.F32,
+                                       F.STORE_F64 if f64 else F.STORE_F32, C.byref(h)), ctx.handle)
+        m = sr.DeviceCsr(ctx, h)
+        ctx.synchronize()
+        return m
+    runs = []
+    for _ in range(reps):
+        m = fresh()
+        t0 = time.perf_counter()
+        F.check(lib.srx_pipeline(m.handle, a.target_sum, a.hvg, C.byref(opts), C.byref(res)), ctx.handle)
+        ctx.synchronize()
+        runs.append((time.perf_counter() - t0) * 1e3)
+        m.free()
+    m = fresh()
+    t0 = time.perf_counter()
+    m.prepare()
+    ctx.synchronize()
+    t1 = time.perf_counter()
+    m.reserve_results(a.hvg, a.npc)
+    ctx.synchronize()
+    t2 = time.perf_counter()
+    m.free()
+    best = min(runs)
+    return {"ms": best, "value": n_global / (best * 1e-3), "unit": "cells/s", "runs_ms": runs,
+            "prepare_ms": (t1 - t0) * 1e3, "reserve_results_ms": (t2 - t1) * 1e3,
+            "note": "srx_pipeline on a fresh, un-prepared, un-reserved handle (the matrix resident in HBM, the context warm): "
+                    "the device-resident cost of running the path once per dataset; the headline `value` is the steady state of "
+                    "repeated steps on prepared clones (pattern-only structures and result block amortised)"}
 
 
 def host_sample(B, config, n_cells):
@@ -388,7 +454,22 @@ def incl_h2d(B, ip, idx, val, genes):
                     "the backed session (--backed)"}
 
 
+def _blas_limit(n):
+    """Context manager limiting the BLAS / OpenMP pools numpy and scipy call into (threadpoolctl; a no-op without it)."""
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=n)
+    except Exception:       # noqa: BLE001
+        import contextlib
+        return contextlib.nullcontext()
+
+
 def cpu_baselines(B, ip, idx, val, genes):
+    """Three CPU legs on this box's host cores (oracle/ = the checker, here as the thing timed):
+    cpu_baseline                     — OpenMP restatement on <= 64 threads over the 100k-cell host sample (SURVEY.md 8(d) ii);
+    cpu_baseline_reference_faithful  — the reference's own algorithm (serial loops, densify, full SVD) on a 24k-cell sample,
+                                       BLAS pinned to <= 64 threads, extrapolated linearly in cells (said so);
+    cpu_baseline_c1_serial           — BASELINE.md section 3's C1 (2.7k x 32k, 7 %) whole, one thread."""
     import numpy as np
     import oracle
     from oracle import pca_oracle
@@ -396,60 +477,89 @@ def cpu_baselines(B, ip, idx, val, genes):
     oracle.lib()
     out = {}
     model, cores = cpu_model(), usable_cores()
-    # (i) reference-faithful: the serial loops + densify + full-SVD PCA (numpy / LAPACK, all cores) on a bounded sample
-    n1 = min(a.cpu_sample_cells, len(ip) - 1)
-    e1 = int(ip[n1])
-    m1 = oracle.Csr(n1, genes, ip[:n1 + 1], idx[:e1], val[:e1])
-    t0 = time.perf_counter()
-    lg = oracle.log1p_transform(oracle.normalize_total(m1, a.target_sum, oracle.ROW))
-    t1 = time.perf_counter()
-    sel = pca_oracle.select_features_hvg(lg, a.hvg)
-    t2 = time.perf_counter()
-    pca_oracle.pca_inplace(lg, a.npc, None, None, sel)
-    t3 = time.perf_counter()
-    out["cpu_baseline"] = {
-        "value": n1 / (t3 - t0), "unit": "cells/s", "cores": cores, "kind": "port", "cpu_model": model,
-        "sample": f"first {n1} cells of the same synthetic matrix ({e1} nnz): serial C restatement of normalize_total + log1p "
-                  f"({t1 - t0:.2f} s) and nz-variance HVG({a.hvg}) ({t2 - t1:.2f} s) on 1 thread — the reference's loops are "
-                  f"serial —, densify + full-SVD PCA via numpy / LAPACK on the box's {cores} usable cores ({t3 - t2:.2f} s); "
-                  "the exact SVD is linear in cells at fixed k, so cells/s carries to the full size",
-        "seconds": t3 - t0}
+    threads = max(1, min(cores, 64))
     # (ii) threaded: OpenMP over every loop + k x k covariance and a symmetric eigen-solve instead of the full SVD
     n2 = len(ip) - 1
-    threads = max(1, min(cores, 64))
     m2 = oracle.Csr(n2, genes, ip, idx, val)
     t0 = time.perf_counter()
     vals, hv, order, cov, mean, sd, secs = oracle.omp_pipeline(m2, a.target_sum, a.hvg, threads)
     t1 = time.perf_counter()
     import scipy.linalg as sla
-    k = cov.shape[0]
-    w, v = sla.eigh(cov, subset_by_index=[max(0, k - a.npc), k - 1])
-    t2 = time.perf_counter()
-    # scores = Z V for the sample: sparse x dense through scipy (threaded BLAS does not apply; counted as is)
     import scipy.sparse as sp
-    x = sp.csr_matrix((vals, idx.astype(np.int64), ip.astype(np.int64)), shape=(n2, genes))[:, order.astype(np.int64)]
-    pv = v / sd[:, None]
-    _ = x @ pv - (mean / sd) @ v
+    k = cov.shape[0]
+    with _blas_limit(threads):
+        w, v = sla.eigh(cov, subset_by_index=[max(0, k - a.npc), k - 1])
+        t2 = time.perf_counter()
+        # scores = Z V for the sample: sparse x dense through scipy (threaded BLAS does not apply; counted as is)
+        x = sp.csr_matrix((vals, idx.astype(np.int64), ip.astype(np.int64)), shape=(n2, genes))[:, order.astype(np.int64)]
+        pv = v / sd[:, None]
+        _ = x @ pv - (mean / sd) @ v
     t3 = time.perf_counter()
-    out["cpu_baseline_threaded"] = {
-        "value": n2 / (t3 - t0), "unit": "cells/s", "cores": threads, "kind": "port", "cpu_model": model,
-        "sample": f"first {n2} cells ({len(val)} nnz): oracle/omp_baseline.c on {threads} OpenMP threads — normalise + log1p "
-                  f"{secs[0]:.2f} s, moments + HVG {secs[1]:.2f} s, k x k Gram {secs[2]:.2f} s — then LAPACK eigh of the "
-                  f"{k} x {k} covariance (top {a.npc}) {t2 - t1:.2f} s and the scores {t3 - t2:.2f} s; SURVEY.md 8(d) variant "
-                  "(ii): algorithmically cheaper than the reference's full SVD, i.e. a baseline that favours the CPU",
+    out["cpu_baseline"] = {
+        "value": n2 / (t3 - t0), "unit": "cells/s", "cores": threads, "kind": "port", "cpu_model": model, "host_cores": cores,
+        "sample": f"first {n2} cells of the same synthetic matrix ({len(val)} nnz), timed whole: oracle/omp_baseline.c on {threads} "
+                  f"OpenMP threads — normalise + log1p {secs[0]:.2f} s, moments + HVG {secs[1]:.2f} s, k x k Gram {secs[2]:.2f} s — "
+                  f"then LAPACK eigh of the {k} x {k} covariance (top {a.npc}, <= {threads} BLAS threads) {t2 - t1:.2f} s and the "
+                  f"scores {t3 - t2:.2f} s; SURVEY.md 8(d) variant (ii): a restatement, algorithmically cheaper than the "
+                  "reference's full SVD, i.e. a baseline that favours the CPU",
+        "seconds": t3 - t0}
+    # (i) reference-faithful: the serial loops + densify + full-SVD PCA (numpy / LAPACK) on a bounded sample
+    n1 = min(a.cpu_sample_cells, len(ip) - 1)
+    e1 = int(ip[n1])
+    m1 = oracle.Csr(n1, genes, ip[:n1 + 1], idx[:e1], val[:e1])
+    with _blas_limit(threads):
+        t0 = time.perf_counter()
+        lg = oracle.log1p_transform(oracle.normalize_total(m1, a.target_sum, oracle.ROW))
+        t1 = time.perf_counter()
+        sel = pca_oracle.select_features_hvg(lg, a.hvg)
+        t2 = time.perf_counter()
+        pca_oracle.pca_inplace(lg, a.npc, None, None, sel)
+        t3 = time.perf_counter()
+    out["cpu_baseline_reference_faithful"] = {
+        "value": n1 / (t3 - t0), "unit": "cells/s", "cores": threads, "kind": "port", "cpu_model": model,
+        "sample": f"first {n1} cells ({e1} nnz): serial C restatement of normalize_total + log1p ({t1 - t0:.2f} s) and nz-variance "
+                  f"HVG({a.hvg}) ({t2 - t1:.2f} s) on 1 thread — the reference's loops are serial —, densify + full-SVD PCA via "
+                  f"numpy / LAPACK pinned to {threads} BLAS threads ({t3 - t2:.2f} s).  EXTRAPOLATED: the exact SVD is linear in "
+                  "cells at fixed k, so the rate carries to the full size; not the headline baseline",
+        "seconds": t3 - t0}
+    # 2.7k x 32k at 7 %, the reference's own CPU-runnable case, whole, on ONE thread
+    c1_cells, c1_genes, c1_density, c1_seed = 2700, 32000, 0.07, 1001
+    p1 = B.F.SynthParams()
+    B.lib.srx_synth_defaults(C.byref(p1), c1_seed, c1_cells, c1_genes, c1_density)
+    ip1 = np.zeros(c1_cells + 1, dtype=np.uint64)
+    B.lib.srx_synth_indptr(C.byref(p1), 0, c1_cells, B.F.ptr(ip1))
+    idx1 = np.zeros(int(ip1[-1]), np.uint64)
+    val1 = np.zeros(int(ip1[-1]), np.float32)
+    B.lib.srx_synth_fill_host(C.byref(p1), 0, c1_cells, B.F.ptr(ip1), B.F.ptr(idx1), B.F.ptr(val1))
+    mc = oracle.Csr(c1_cells, c1_genes, ip1, idx1, val1)
+    with _blas_limit(1):
+        t0 = time.perf_counter()
+        lg = oracle.log1p_transform(oracle.normalize_total(mc, a.target_sum, oracle.ROW))
+        t1 = time.perf_counter()
+        sel = pca_oracle.select_features_hvg(lg, a.hvg)
+        t2 = time.perf_counter()
+        pca_oracle.pca_inplace(lg, a.npc, None, None, sel)
+        t3 = time.perf_counter()
+    out["cpu_baseline_c1_serial"] = {
+        "value": c1_cells / (t3 - t0), "unit": "cells/s", "cores": 1, "kind": "port", "cpu_model": model,
+        "sample": f"BASELINE.json configs[0] / BASELINE.md section 3 C1 whole: {c1_cells} x {c1_genes}, {int(ip1[-1])} nnz, seed "
+                  f"{c1_seed}; reference-faithful serial restatement on 1 thread: normalise + log1p {t1 - t0:.3f} s, HVG({a.hvg}) "
+                  f"{t2 - t1:.3f} s, densify + full-SVD PCA (1 BLAS thread) {t3 - t2:.2f} s",
         "seconds": t3 - t0}
     return out
 
 
-def backed_run(B):
+def backed_run(B, config=None, cells_override=0, n_runs=None):
     """configs[4] as specified, on one GPU: the matrix lives in pinned host memory and goes through the backed session as
-    row tiles (two sweeps: statistics, then compaction + Gram), H2D overlapped with the kernels of the previous tile."""
+    row tiles (two sweeps: statistics, then compaction + Gram), H2D overlapped with the kernels of the previous tile.
+    Returns the JSON object of the run (`--backed` prints it; the default line carries it as the `c5_backed` block)."""
     import numpy as np
     a, F, lib, ctx = B.a, B.F, B.lib, B.ctx
-    cells, genes, density, seed = CONFIGS[a.config]
-    if a.cells:
-        cells = a.cells
-    p = B.params(a.config, cells)
+    config = config or a.config
+    cells, genes, density, seed = CONFIGS[config]
+    if cells_override:
+        cells = cells_override
+    p = B.params(config, cells)
     tile = a.tile_rows
     t_gen = time.perf_counter()
     ip = np.zeros(cells + 1, dtype=np.uint64)
@@ -487,7 +597,7 @@ def backed_run(B):
             yield F.Csr(r1 - r0, genes, int(ip[r1]) - e0, ip[r0:].ctypes.data, idx[e0:].ctypes.data, val[e0:].ctypes.data, F.F32)
 
     runs = []
-    for _ in range(max(1, a.steps)):
+    for _ in range(max(1, n_runs if n_runs is not None else a.steps)):
         h = C.c_void_p()
         F.check(lib.srx_backed_create(ctx.handle, genes, F.STORE_F32, C.byref(h)), ctx.handle)
         t0 = time.perf_counter()
@@ -514,7 +624,7 @@ def backed_run(B):
         "value": cells / best["total_s"], "unit": "cells/s", "n_gpus": 1, "steps": len(runs), "warmup": 0,
         "ms_per_step": best["total_s"] * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{a.config} OUT OF CORE: {cells} cells x {genes} genes, density {density}, seed {seed}; the CSR "
+        "config": {"workload": f"{config} OUT OF CORE: {cells} cells x {genes} genes, density {density}, seed {seed}; the CSR "
                                f"({host_bytes / 1e9:.1f} GB: u64 offsets / indices + f32 values) stays in "
                                f"{'pinned' if pinned else 'pageable'} host memory and is streamed as {tile}-cell tiles "
                                "through srx_backed_* (sweep 1: statistics; select; sweep 2: compaction + Gram; solve)",
@@ -525,25 +635,62 @@ def backed_run(B):
                         "kernels of a tile run under the upload of the next one"},
         "runs": runs, "setup": {"host_generate_s": t_gen},
     }
-    print(json.dumps(out), flush=True)
+    del idx, val
     if pinned:
         hip.hipHostFree.argtypes = [C.c_void_p]
         hip.hipHostFree(hidx); hip.hipHostFree(hval)
+    return out
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` typed as it stands (no launcher): this process becomes the launcher — N ranks of this very
+    command, one per GPU, with the environment torch.distributed.run would give them (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT); rank 0 inherits stdout (the one JSON line), the others' stdout goes to stderr.  Any rank
+    failing fails the launch (non-zero exit) and takes the others down (by PID)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               TORCHELASTIC_RUN_ID=f"self{os.getpid()}", SRX_BENCH_LAUNCHER="self")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__), *sys.argv[1:]]
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=None if r == 0 else sys.stderr.fileno()))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"[bench launcher] rank {r} exited with {code}: stopping the other ranks", file=sys.stderr)
+                for o in pending:
+                    procs[o].terminate()
+        if pending:
+            time.sleep(0.05)
+    sys.exit(rc)
 
 
 def main():
     a = parse()
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if world_env != a.gpus:
-        if world_env == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N with N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+        if world_env == 1 and a.gpus > 1 and "RANK" not in os.environ:
+            self_launch(a.gpus)
         a.gpus = world_env
     B = Bench(a)
     rank, world = B.rank, B.world
     if a.backed:
         if world != 1:
             sys.exit("--backed is a single-GPU measurement")
-        backed_run(B)
+        print(json.dumps(backed_run(B, cells_override=a.cells)), flush=True)
         B.close()
         return
     cells, genes, density, seed = CONFIGS[a.config]
@@ -584,6 +731,7 @@ def main():
                     "note": "the same pipeline with f64 value storage (12 B per non-zero, 16-byte compacted records): the "
                             "reference's f64 arithmetic to ~1e-15; HighlyVariable(n) is the reference's at either storage"}
         attempt("f64_storage" if other == "f64" else "f32_storage", f_other)
+        attempt("cold_step", lambda: cold_step(B, a.config, n_global, a.storage))
 
         def f_fast():
             os.environ["SRX_NO_LAZY"] = "1"
@@ -638,6 +786,12 @@ def main():
             except Exception as e:
                 extra["incl_h2d"] = {"failed": repr(e)}
 
+        if a.config == "c3" and not a.cells and not os.environ.get("SRX_BENCH_NO_C5"):
+            def f_c5():
+                r = backed_run(B, config="c5", n_runs=1)
+                return {k_: r[k_] for k_ in ("value", "unit", "ms_per_step", "config", "h2d", "runs", "setup")}
+            attempt("c5_backed", f_c5)
+
     if rank == 0:
         prof = main_["prof"]
         value = n_global * a.steps / main_["elapsed"]
@@ -646,6 +800,11 @@ def main():
             per_step = traffic.get(name)
             d["hbm_traffic_per_launch"] = per_step / (d["launches"] / a.steps) if per_step else None
         per, serial = attributed(prof, a.steps)
+        # the step as a whole against the HBM peak: algorithmic bytes of every serial class (dense_apply sits inside iterate)
+        serial_cls = [k_ for k_ in prof if k_ not in ("dense_apply", "normalize_log1p")]
+        step_alg = sum(prof[k_]["alg_bytes_per_launch"] * prof[k_]["launches"] / a.steps for k_ in serial_cls)
+        step_aux = sum(prof[k_].get("aux_bytes_per_launch", 0.0) * prof[k_]["launches"] / a.steps for k_ in serial_cls)
+        step_traffic = sum(traffic[k_] for k_ in serial_cls if traffic.get(k_)) if traffic else None
         cand = {k_: v for k_, v in per.items() if k_ not in ("iterate", "dense_apply", "select")}
         dom_name = max(cand, key=cand.get) if cand else None
         dom = prof.get(dom_name, {})
@@ -660,7 +819,7 @@ def main():
                             f"{a.npc}-PC PCA; values {a.storage} / indices i32 in HBM; rows {row0}..{row1} on rank 0",
                 "cells_global": n_global, "genes": genes, "nnz_rank0": main_["nnz"], "hvg": a.hvg, "n_pc": a.npc,
                 "panel_width": 64, "parallelism": f"row-shard x{world} (nnz-balanced)",
-                **({"collective": B.collective} if B.dist is not None else {}),
+                **(B.comm_info if B.dist is not None else {}),
                 "nnz_hvg_compacted_rank0": main_["nnz_selected"],
                 "subspace_iterations": main_["iters"], "pca_residual": main_["residual"], "pca_solver": main_["solver"],
                 "hvg_selection": "f64 moments of ln_1p(v * scale) from the raw matrix: identical to the reference's at f32 storage",
@@ -676,6 +835,13 @@ def main():
             "kernel_ms_per_step": per,
             # step time outside every bracketed class (launch gaps, host waits, scans, small copies)
             "unattributed_ms_per_step": main_["ms_per_step"] - serial,
+            "step_roofline": {"step_alg_bytes": step_alg, "step_aux_bytes": step_aux, "step_hbm_traffic": step_traffic,
+                              "achieved_GBps": step_alg / (main_["ms_per_step"] * 1e-3) / 1e9,
+                              "frac_of_peak": step_alg / (main_["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "traffic_GBps": step_traffic / (main_["ms_per_step"] * 1e-3) / 1e9 if step_traffic else None,
+                              "note": "algorithmic bytes of every kernel class of a step (minimum data each must move, SURVEY.md "
+                                      "8(d)) over the whole step time; step_hbm_traffic = PMC counter traffic of the same classes "
+                                      "from the committed profile"},
             "writeback_overlapped_ms_per_step": per.get("normalize_log1p"),
             "stage_ms_per_step": main_["stage_ms_per_step"],
             "traffic_source": f"profiles/{traffic_round}_traffic_{a.config}.json" if traffic_round else None,
@@ -686,8 +852,6 @@ def main():
         out.update(extra)
         if "cpu_baseline" in out and out["cpu_baseline"].get("value"):
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-        if "cpu_baseline_threaded" in out and out["cpu_baseline_threaded"].get("value"):
-            out["gpu_over_cpu_threaded"] = value / out["cpu_baseline_threaded"]["value"]
         if B.json_fd is not None:
             sys.stdout.flush()
             os.write(B.json_fd, (json.dumps(out) + "\n").encode())

@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define SRX_ABI_VERSION 3      /* 2: srx_matrix_reserve_results, kernel classes 7-9, srx_synth_params.skew; 3: kernel class 10 */
+#define SRX_ABI_VERSION 4      /* 2: srx_matrix_reserve_results, kernel classes 7-9, srx_synth_params.skew; 3: kernel class 10;
+                                  4: srx_comm_info, srx_prof_get_aux */
 
 typedef struct srx_ctx srx_ctx;   /* one GPU + stream + (optional) RCCL communicator      */
 typedef struct srx_mat srx_mat;   /* device-resident CSR (the `X` of an IMAnnData)        */
@@ -105,6 +106,12 @@ int32_t srx_comm_init(srx_ctx* ctx, int32_t n_ranks, int32_t rank, const void* i
 typedef int32_t (*srx_host_allreduce_fn)(void* user, double* buf, uint64_t count);
 int32_t srx_comm_init_host(srx_ctx* ctx, int32_t n_ranks, int32_t rank, srx_host_allreduce_fn fn, void* user);
 int32_t srx_comm_destroy(srx_ctx* ctx);
+/* What the context's cross-rank sums go through: *kind_out = 0 (no communicator), 1 (RCCL), 2 (host transport);
+ * *rccl_version_out = ncclGetVersion() (0 when RCCL is not loaded); *ranks_seen_out = a 1.0 summed over the
+ * communicator with the same all-reduce the path uses (a COLLECTIVE call when kind != 0: every rank makes it) —
+ * equal to n_ranks when every rank really takes part.  Any out pointer may be NULL. */
+int32_t srx_comm_info(srx_ctx* ctx, int32_t* kind_out, int32_t* n_ranks_out, int32_t* rccl_version_out,
+                      int32_t* ranks_seen_out);
 /* Contiguous nnz-balanced row ranges: cut[r]..cut[r+1] is rank r's rows (cut has
  * n_ranks+1 entries).  Pure host helper, no GPU needed. */
 int32_t srx_partition_rows(const uint64_t* indptr, uint64_t n_rows, int32_t n_ranks,
@@ -382,6 +389,9 @@ int32_t srx_prof_enable(srx_ctx* ctx, uint32_t class_mask);
 int32_t srx_prof_reset(srx_ctx* ctx);
 int32_t srx_prof_get(srx_ctx* ctx, int32_t kernel_class, double* total_ms, uint64_t* launches,
                      double* algorithmic_bytes);
+/* Bytes of AUXILIARY structures the launches of a class read or wrote besides their algorithmic bytes (the Gram
+ * kernel's owner records and block offsets): this implementation's own, never part of a roofline figure. */
+int32_t srx_prof_get_aux(srx_ctx* ctx, int32_t kernel_class, double* aux_bytes);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,7 @@
 #![allow(non_camel_case_types, dead_code)]
 use std::os::raw::{c_char, c_void};
 
-pub const SRX_ABI_VERSION: i32 = 3;
+pub const SRX_ABI_VERSION: i32 = 4;
 pub const SRX_UNIQUE_ID_BYTES: usize = 128;
 pub const SRX_OK: i32 = 0;
 pub const SRX_E_ARG: i32 = -1;
@@ -143,6 +143,8 @@ extern "C" {
     pub fn srx_comm_init(ctx: *mut SrxCtx, n_ranks: i32, rank: i32, id_128: *const c_void) -> i32;
     pub fn srx_comm_init_host(ctx: *mut SrxCtx, n_ranks: i32, rank: i32, fn_: SrxHostAllreduceFn, user: *mut c_void) -> i32;
     pub fn srx_comm_destroy(ctx: *mut SrxCtx) -> i32;
+    pub fn srx_comm_info(ctx: *mut SrxCtx, kind_out: *mut i32, n_ranks_out: *mut i32, rccl_version_out: *mut i32,
+                         ranks_seen_out: *mut i32) -> i32;
     pub fn srx_partition_rows(indptr: *const u64, n_rows: u64, n_ranks: i32, cut_out: *mut u64) -> i32;
     pub fn srx_matrix_upload(ctx: *mut SrxCtx, host: *const SrxCsr, store: i32, out: *mut *mut SrxMat) -> i32;
     pub fn srx_matrix_upload_csc(ctx: *mut SrxCtx, host: *const SrxCsr, store: i32, out: *mut *mut SrxMat) -> i32;
@@ -205,4 +207,5 @@ extern "C" {
     pub fn srx_prof_reset(ctx: *mut SrxCtx) -> i32;
     pub fn srx_prof_get(ctx: *mut SrxCtx, kernel_class: i32, total_ms: *mut f64, launches: *mut u64,
                         algorithmic_bytes: *mut f64) -> i32;
+    pub fn srx_prof_get_aux(ctx: *mut SrxCtx, kernel_class: i32, aux_bytes: *mut f64) -> i32;
 }

@@ -90,6 +90,7 @@ _SIGS = {
     "srx_comm_init": (C.c_int32, [P, C.c_int32, C.c_int32, P]),
     "srx_comm_init_host": (C.c_int32, [P, C.c_int32, C.c_int32, C.c_void_p, P]),
     "srx_comm_destroy": (C.c_int32, [P]),
+    "srx_comm_info": (C.c_int32, [P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "srx_partition_rows": (C.c_int32, [P, C.c_uint64, C.c_int32, P]),
     "srx_matrix_upload": (C.c_int32, [P, C.POINTER(Csr), C.c_int32, C.POINTER(P)]),
     "srx_matrix_upload_csc": (C.c_int32, [P, C.POINTER(Csr), C.c_int32, C.POINTER(P)]),
@@ -137,6 +138,7 @@ _SIGS = {
     "srx_prof_enable": (C.c_int32, [P, C.c_uint32]),
     "srx_prof_reset": (C.c_int32, [P]),
     "srx_prof_get": (C.c_int32, [P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    "srx_prof_get_aux": (C.c_int32, [P, C.c_int32, C.POINTER(C.c_double)]),
     # srx_synth.h
     "srx_synth_defaults": (None, [C.POINTER(SynthParams), C.c_uint64, C.c_uint64, C.c_uint64, C.c_double]),
     "srx_synth_indptr": (C.c_int32, [C.POINTER(SynthParams), C.c_uint64, C.c_uint64, P]),

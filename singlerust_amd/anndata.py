@@ -139,6 +139,11 @@ class Context:
         F.check(F.lib().srx_prof_get(self._h, cls_, C.byref(ms), C.byref(n), C.byref(b)), self._h)
         return ms.value, n.value, b.value
 
+    def prof_get_aux(self, cls_: int) -> float:
+        b = C.c_double()
+        F.check(F.lib().srx_prof_get_aux(self._h, cls_, C.byref(b)), self._h)
+        return b.value
+
     def close(self) -> None:
         if self._h:
             F.lib().srx_ctx_destroy(self._h)

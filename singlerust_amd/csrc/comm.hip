@@ -27,6 +27,7 @@ struct RcclApi {
     rcclResult (*CommDestroy)(ncclComm*) = nullptr;
     rcclResult (*AllReduce)(const void*, void*, size_t, int, int, ncclComm*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(rcclResult) = nullptr;
+    rcclResult (*GetVersion)(int*) = nullptr;
 };
 
 static RcclApi g_rccl;
@@ -47,6 +48,7 @@ static int32_t load_rccl(srx_ctx* ctx) {
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
     a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+    a.GetVersion = (decltype(a.GetVersion))dlsym(h, "ncclGetVersion");
     if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce)
         return fail(ctx, SRX_E_RCCL, "librccl lacks the expected nccl* symbols");
     g_rccl = a;
@@ -120,6 +122,28 @@ int32_t srx_comm_init_host(srx_ctx* ctx, int32_t n_ranks, int32_t rank, srx_host
     ctx->rank = rank;
     ctx->host_allreduce = fn;
     ctx->host_allreduce_user = user;
+    return SRX_OK;
+}
+
+int32_t srx_comm_info(srx_ctx* ctx, int32_t* kind_out, int32_t* n_ranks_out, int32_t* rccl_version_out,
+                      int32_t* ranks_seen_out) {
+    if (!ctx) return fail(nullptr, SRX_E_ARG, "null ctx");
+    const int kind = ctx->comm ? 1 : (ctx->host_allreduce ? 2 : 0);
+    if (kind_out) *kind_out = kind;
+    if (n_ranks_out) *n_ranks_out = ctx->n_ranks;
+    if (rccl_version_out) {
+        int v = 0;
+        if (g_rccl.h && g_rccl.GetVersion) (void)g_rccl.GetVersion(&v);
+        *rccl_version_out = v;
+    }
+    if (ranks_seen_out) {
+        double one = 1.0, *d = nullptr;
+        SRX_TRY(scratch(ctx, "comm_probe", 64, (void**)&d));
+        SRX_TRY(h2d(ctx, d, &one, sizeof one));
+        SRX_TRY(allreduce_f64(ctx, d, 1));
+        SRX_TRY(d2h(ctx, &one, d, sizeof one));
+        *ranks_seen_out = (int32_t)(one + 0.5);
+    }
     return SRX_OK;
 }
 

@@ -59,7 +59,7 @@ __device__ __forceinline__ T wave_max(T v) {
 struct ProfAcc {
     double ms = 0.0;
     uint64_t launches = 0;
-    double bytes = 0.0;
+    double bytes = 0.0, aux_bytes = 0.0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 
@@ -224,7 +224,9 @@ struct ProfScope {
     int cls;
     hipStream_t stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    ProfScope(srx_ctx* c, int cls_, double alg_bytes, hipStream_t stream_ = nullptr);
+    // alg_bytes: the minimum data the launches must move; aux_bytes: auxiliary structures of this
+    // implementation read or written besides (owner records, ...) — reported separately, never part of the roofline figure
+    ProfScope(srx_ctx* c, int cls_, double alg_bytes, hipStream_t stream_ = nullptr, double aux_bytes = 0.0);
     ~ProfScope();
 };
 

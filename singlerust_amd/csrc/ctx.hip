@@ -129,12 +129,13 @@ static hipEvent_t take_event(srx_ctx* ctx) {
     return e;
 }
 
-ProfScope::ProfScope(srx_ctx* c, int cls_, double alg_bytes, hipStream_t stream_) : ctx(c), cls(cls_), stream(stream_ ? stream_ : c->stream) {
+ProfScope::ProfScope(srx_ctx* c, int cls_, double alg_bytes, hipStream_t stream_, double aux_bytes) : ctx(c), cls(cls_), stream(stream_ ? stream_ : c->stream) {
     if (!(ctx->prof_mask & (1u << cls)) || ctx->capturing) return;      // no event nodes inside a captured graph
     e0 = take_event(ctx);
     e1 = take_event(ctx);
     if (!e0 || !e1) { e0 = e1 = nullptr; return; }
     ctx->prof[cls].bytes += alg_bytes;
+    ctx->prof[cls].aux_bytes += aux_bytes;
     ctx->prof[cls].launches += 1;
     (void)hipEventRecord(e0, stream);
 }
@@ -693,6 +694,12 @@ int32_t srx_matrix_download_values(srx_mat* m, void* out, int32_t dtype_out) {
     return d2h(ctx, out, d_tmp, m->nnz * ob);
 }
 
+int32_t srx_prof_get_aux(srx_ctx* ctx, int32_t cls, double* aux_bytes) {
+    if (!ctx || cls < 0 || cls >= SRX_K_COUNT_) return fail(ctx, SRX_E_ARG, "bad kernel class");
+    if (aux_bytes) *aux_bytes = ctx->prof[cls].aux_bytes;
+    return SRX_OK;
+}
+
 }  // extern "C"
 
 namespace srx {
@@ -810,6 +817,7 @@ int32_t srx_prof_reset(srx_ctx* ctx) {
         ctx->prof[c].ms = 0.0;
         ctx->prof[c].launches = 0;
         ctx->prof[c].bytes = 0.0;
+        ctx->prof[c].aux_bytes = 0.0;
     }
     return SRX_OK;
 }

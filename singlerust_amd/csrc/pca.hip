@@ -2122,7 +2122,9 @@ static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words,
     SRX_TRY(scratch(ctx, "pca_rm_ptr", (N + 1) * sizeof(int64_t), (void**)&rm.ptr));
     SRX_TRY(scratch(ctx, "pca_t256_ptr", (n256 + 1) * sizeof(int64_t), (void**)&t256.tptr));
     const double s_i = m->d_idx16 ? 2.0 : 4.0;          // bytes per column index streamed by the two passes
-    ProfScope ps(ctx, SRX_K_COMPACT, (double)m->nnz * s_i * 2.0 + (double)m->nnz * val_bytes(m) + (double)(N + 1) * 8.0 * 2.0);
+    // algorithmic bytes: the column indices of the whole matrix once per pass (count, fill) + row pointers in, row pointers
+    // out; the KEPT values read and the compacted entries written are added below, once their number is known
+    ProfScope ps(ctx, SRX_K_COMPACT, (double)m->nnz * s_i * 2.0 + (double)(N + 1) * 8.0 * 2.0);
     const size_t cnt_lds = sel_lds + 4 * (size_t)kCompactRows * kWave * sizeof(uint32_t);      // + 8 x 64 counters per wave
     if (!t256p) {
         const size_t bits_lds = (size_t)n_words * sizeof(uint32_t);
@@ -2174,7 +2176,7 @@ static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words,
     else fill_t(double{}, (GramPk<double>*)rm.pk, (GramPk<double>*)t256.tpk);
     SRX_HIP(ctx, hipGetLastError());
     if (ctx->prof_mask & (1u << SRX_K_COMPACT))
-        ctx->prof[SRX_K_COMPACT].bytes += (double)total * (4.0 + val_bytes(m)) * (t256p ? 3.0 : 2.0);   // read once, written once or twice
+        ctx->prof[SRX_K_COMPACT].bytes += (double)total * (val_bytes(m) + (double)pb * (t256p ? 2.0 : 1.0));   // kept values read, entries written once or twice
     return SRX_OK;
 }
 
@@ -2338,11 +2340,12 @@ static int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp) {
                            (const GramPk<VT>*)rm.pk, rm.n_rows, g.rblk, rm.k, g.sr_shift, g.n_wg, g.n_stripes, rec_base, boff, recs);
         SRX_HIP(ctx, hipGetLastError());
     }
-    // SRX_K_GRAM: the stripe kernel alone.  Algorithmic bytes: the compacted matrix and the records read once, the block
-    // offsets, G written once.  Every row suffix is read once per kept entry of its row (from L2 / Infinity Cache): that shows
-    // up in the PMC traffic, not here.
-    ProfScope ps(ctx, SRX_K_GRAM, (double)rm.nnz * sizeof(GramPk<VT>) + (double)n_recs * sizeof(GramRec<VT>) +
-                                      (double)g.n_rblk * (g.n_wg + 1) * 4.0 + (double)rm.k * (rm.k + 1) / 2 * 8.0);
+    // SRX_K_GRAM: the stripe kernel alone.  Algorithmic bytes = what ANY Gram kernel must move: the compacted matrix and its
+    // row pointers read once, the packed triangle written once.  The owner records and block offsets are this kernel's own
+    // auxiliary input (aux bytes).  Every row suffix is read once per kept entry of its row (from L2 / Infinity Cache): that
+    // shows up in the PMC traffic, not here.
+    ProfScope ps(ctx, SRX_K_GRAM, (double)rm.nnz * sizeof(GramPk<VT>) + (double)(rm.n_rows + 1) * 8.0 + (double)rm.k * (rm.k + 1) / 2 * 8.0,
+                 nullptr, (double)n_recs * sizeof(GramRec<VT>) + (double)g.n_rblk * (g.n_wg + 1) * 4.0);
     SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_stripes<VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
     hipLaunchKernelGGL((k_gram_stripes<VT>), dim3((unsigned)(g.n_wg * g.n_z)), dim3(kGramWaves * kWave), g.lds_bytes, ctx->stream,
                        rm.ptr, (const GramPk<VT>*)rm.pk, boff, rec_base, recs, g.n_rblk, g.rblk, rm.k, g.sr_shift, g.n_wg,

@@ -41,3 +41,38 @@ def test_two_rank_bench_line():
     assert abs(w["value"] - world * cells / (w["ms_per_step"] * 1e-3)) <= 1e-6 * w["value"]
     assert d["unattributed_ms_per_step"] is not None
     assert c["pca_residual"] < 1e-6 and d["roofline"]["frac"] > 0 and d["roofline"]["bound"] == "hbm"
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_self_launch_two_ranks():
+    """`python bench.py --gpus 2` typed as it stands (no launcher environment): bench.py starts its own two ranks and still
+    prints exactly one JSON line; the line says what the sums went through and how many ranks the communicator saw."""
+    cells = 60000
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cells", str(cells), "--steps", "2", "--warmup", "1",
+           "--lean"]
+    p = subprocess.run(cmd, env=_clean_env(SRX_BENCH_DEVICE="0", SRX_BENCH_COLLECTIVE="host"), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, cwd=ROOT, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and c["cells_global"] == cells
+    assert c["collective"] == "host-star" and c["kind"] == "host" and c["n_ranks_seen"] == 2 and c["launcher"] == "self"
+    assert c["pca_residual"] < 1e-6
+
+
+def test_host_fallback_is_refused_unless_asked_for():
+    """Two ranks on ONE device: RCCL cannot come up.  Without SRX_BENCH_COLLECTIVE=host the launch must fail (non-zero exit,
+    no JSON line) instead of quietly producing a scaling number over the host star."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cells", "20000", "--steps", "1", "--warmup", "0", "--lean"]
+    p = subprocess.run(cmd, env=_clean_env(SRX_BENCH_DEVICE="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT,
+                       timeout=600)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.decode().splitlines() if ln.strip().startswith("{")]
+    assert "SRX_BENCH_COLLECTIVE=host" in p.stderr.decode()

@@ -102,6 +102,28 @@ def test_full_size_pipeline_properties(ctx, big):
     # sign convention: the largest-|.| loading of every component is positive
     assert np.all(comps[np.argmax(np.abs(comps), axis=0), np.arange(50)] > 0)
 
+    # --- a ROW SAMPLE against the oracle: the first 20k cells regenerated on the host (the generator is keyed by (seed, row)),
+    # normalised / log-transformed by the serial C restatement, pushed through the oracle's dense transform with the GPU's own
+    # selection, mean / std and components (pca/mod.rs:156-185: scores = Z . components) ---
+    import oracle
+    ns = 20_000
+    p = F.SynthParams()
+    lib.srx_synth_defaults(C.byref(p), CONFIGS["c3" if N < 10_000_000 else "c5"][3], N, G, DENSITY)
+    ip = np.zeros(ns + 1, dtype=np.uint64)
+    lib.srx_synth_indptr(C.byref(p), 0, ns, F.ptr(ip))
+    idx, val = np.zeros(int(ip[-1]), np.uint64), np.zeros(int(ip[-1]), np.float32)
+    lib.srx_synth_fill_host(C.byref(p), 0, ns, F.ptr(ip), F.ptr(idx), F.ptr(val))
+    ms = oracle.Csr(ns, G, ip, idx, val)
+    assert np.array_equal(n_cell[:ns], oracle.compute_number(ms, oracle.ROW))                # bit-exact, the sample's rows
+    assert np.array_equal(s_cell[:ns], oracle.compute_sum(ms, oracle.ROW))
+    lg = oracle.log1p_transform(oracle.normalize_total(ms, 1e4, oracle.ROW))
+    dense = oracle.densify_selected(lg, hv)                                                  # N_s x 2000, columns in rank order
+    want = ((dense - mean) / std) @ comps                                                    # (fetched mean / std / rows of comps: same order)
+    for c in range(50):
+        e = np.linalg.norm(scores[:ns, c] - want[:, c]) / np.linalg.norm(want[:, c])
+        assert e < 1e-5, (c, e)
+    assert np.allclose(r_sum[:ns], oracle.compute_sum(lg, oracle.ROW), rtol=1e-6)           # row sums of the transformed sample
+
 
 def test_backed_session_at_full_c3_size_matches_the_resident_pipeline(ctx):
     """configs[4]'s machinery at configs[2]'s size: the 1.3M x 28k matrix stays in HOST memory (13 GB in the reference
@@ -163,6 +185,14 @@ def test_backed_session_at_full_c3_size_matches_the_resident_pipeline(ctx):
     hv = np.zeros(2000, np.uint64)
     F.check(lib.srx_backed_select(b, 2000, None, 0, C.byref(opts), F.ptr(hv), C.byref(n_out)), ctx.handle)
     assert n_out.value == 2000 and np.array_equal(hv, hv0)              # identical selection, identical order
+    # ... and it is the ORACLE's: the serial C restatement walks all 1.09e9 non-zeros of the host copy (normalise, log1p,
+    # nz-variance per gene, stable descending sort) — HighlyVariable(2000) at configs[2]'s full size, index for index
+    import oracle
+    mh = oracle.Csr(n, g, ip, idx, val)
+    lg = oracle.log1p_transform(oracle.normalize_total(mh, 1e4, oracle.ROW))
+    want_hv = oracle.select_hvg(oracle.compute_variance(lg, oracle.COLUMN), 2000)
+    del lg, mh
+    assert np.array_equal(hv0, want_hv)
     for r0, r1, t in tiles():
         F.check(lib.srx_backed_gram_tile(b, C.byref(t), 1e4, xf), ctx.handle)
     info = F.PcaInfo()

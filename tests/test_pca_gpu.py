@@ -38,17 +38,28 @@ def assert_components_within_conditioning(got, ref, eigvals, store, what, tol=TO
     ~ ||dC|| / gap under a perturbation dC of the matrix; the inputs of the f32-storage path are the f64 oracle's values
     rounded to f32 (2^-24 relative), those of the f64 path differ at 2^-53.  So component c must agree to
         max(tol, 8 * eps_store / relgap_c),    relgap_c = distance to the nearest other eigenvalue / eigenvalue
-    — 1e-5 for every component whose gap exceeds 5e-2 (f32) / 1e-10 (f64), and the perturbation bound for the crowded tail."""
+    — at f64 storage that IS the plain 1e-5 for every component with a relative gap above 1e-10 (asserted below for every gap
+    >= 1e-3), at f32 storage 1e-5 for gaps above 5e-2 and the perturbation bound for the crowded tail.  Prints, per call, the
+    worst observed error / bound ratio and how many components needed more than the plain 1e-5, so that the slack actually used
+    is on record (pytest -s / the captured output of a failure)."""
     ev = np.asarray(eigvals, dtype=np.float64)
     gap = np.minimum(np.abs(np.diff(ev, prepend=np.inf)), np.abs(np.diff(ev, append=0.0))) / ev
     if len(ev) > 1:                                  # the eigenvalue below the last one is not known: take the gap above it
         gap[-1] = abs(ev[-2] - ev[-1]) / ev[-1]
     eps = 2.0 ** -24 if store == 1 else 2.0 ** -53
+    worst_ratio, worst_err, n_slack = 0.0, 0.0, 0
     for c in range(ref.shape[1]):
         sgn = 1.0 if np.dot(got[:, c], ref[:, c]) >= 0 else -1.0
         e = np.linalg.norm(got[:, c] - sgn * ref[:, c]) / np.linalg.norm(ref[:, c])
         bound = max(tol, 8.0 * eps / gap[c])
+        if store == 2 and gap[c] >= 1e-3:
+            bound = tol                              # f64 storage: the plain bar, no conditioning argument
         assert np.isfinite(e) and e < bound, f"{what} component {c}: error {e:.3e} > {bound:.3e} (relative eigengap {gap[c]:.2e})"
+        worst_ratio, worst_err = max(worst_ratio, e / bound), max(worst_err, e)
+        n_slack += e >= tol
+    print(f"[parity] {what} (store {store}): {ref.shape[1]} components, worst error {worst_err:.2e}, worst error/bound "
+          f"{worst_ratio:.2e}, components above the plain {tol:g}: {n_slack}, smallest relative eigengap {gap.min():.1e}")
+    assert_components_within_conditioning.last = {"worst_ratio": worst_ratio, "worst_err": worst_err, "n_slack": n_slack}
     return gap
 
 
