@@ -74,8 +74,12 @@ typedef struct srx_csr {
 } srx_csr;
 
 /* Device value storage chosen at upload. AUTO: I8/I16/U8/U16/F32 -> f32 (exact), I32/U32/
- * F64 -> f64.  F32 halves the HBM traffic of every pass and still meets the 1e-5 bound;
- * F64 reproduces the reference's f64 arithmetic to ~1e-15. */
+ * F64 -> f64 — and the storage then FOLLOWS the reference's variant: where the reference turns X
+ * into DynCsrMatrix::F64 (normalize_total on anything, log1p on a non-F32 matrix:
+ * scale/mod.rs:74-83, transform/mod.rs:48-55) an AUTO handle held in f32 is widened to f64, under
+ * the separate calls and under srx_pipeline alike; srx_matrix_copy_values on an AUTO destination
+ * follows the source's storage.  An explicit F32 keeps f32 throughout: half the HBM traffic of
+ * every pass, still within the 1e-5 bound; F64 reproduces the reference's f64 arithmetic to ~1e-15. */
 typedef enum srx_store { SRX_STORE_AUTO = 0, SRX_STORE_F32 = 1, SRX_STORE_F64 = 2 } srx_store;
 
 /* ---- context ---------------------------------------------------------------------------- */

@@ -228,26 +228,51 @@ static int32_t convert_chunked(srx_ctx* ctx, hipStream_t stream, const char* tmp
 }
 
 // hipMalloc, or — while a backed session is open on the context — a recycled buffer of about the size (best fit among those
-// at most a quarter larger; fresh ones get 3 % of headroom so that the next tile's slightly different size still fits)
+// at most a quarter larger; fresh buffers of 1 MiB and more get 3 % of headroom so that the next tile's slightly different
+// size still fits).  The pool only holds what a session's tiles give back: it is capped (kPoolCapBytes, oldest buffers freed
+// first), and when the device runs out of memory it is emptied and the allocation tried again.
+constexpr size_t kPoolCapBytes = 24ull << 30;
+static size_t pool_bytes(const srx_ctx* ctx) {
+    size_t t = 0;
+    for (auto& b : ctx->pool) t += b.second;
+    return t;
+}
 hipError_t dev_malloc(srx_ctx* ctx, void** p, size_t bytes) {
-    if (!ctx->pool_on) return hipMalloc(p, bytes);
-    int best = -1;
-    for (size_t i = 0; i < ctx->pool.size(); ++i) {
-        const size_t cap = ctx->pool[i].second;
-        if (cap >= bytes && cap <= bytes + bytes / 4 + (1u << 20) && (best < 0 || cap < ctx->pool[(size_t)best].second)) best = (int)i;
+    if (ctx->pool_on) {
+        int best = -1;
+        for (size_t i = 0; i < ctx->pool.size(); ++i) {
+            const size_t cap = ctx->pool[i].second;
+            if (cap >= bytes && cap <= bytes + bytes / 4 + (1u << 20) && (best < 0 || cap < ctx->pool[(size_t)best].second)) best = (int)i;
+        }
+        if (best >= 0) {
+            *p = ctx->pool[(size_t)best].first;
+            ctx->pool.erase(ctx->pool.begin() + best);
+            return hipSuccess;
+        }
     }
-    if (best >= 0) {
-        *p = ctx->pool[(size_t)best].first;
-        ctx->pool.erase(ctx->pool.begin() + best);
-        return hipSuccess;
+    const size_t want = (ctx->pool_on && bytes >= (1u << 20)) ? bytes + bytes / 32 + 65536 : bytes;
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess && !ctx->pool.empty()) {         // out of memory with recycled buffers parked: give them back, try again
+        (void)hipGetLastError();
+        pool_clear(ctx);
+        e = hipMalloc(p, want);
     }
-    return hipMalloc(p, bytes + bytes / 32 + 65536);
+    return e;
 }
 static void dev_release(srx_mat* m, void* p) {
     if (!p) return;
+    srx_ctx* ctx = m->ctx;
     size_t cap = 0;
-    if (m->pooled && m->ctx && hipMemPtrGetInfo(p, &cap) == hipSuccess && cap > 0) m->ctx->pool.emplace_back(p, cap);
-    else (void)hipFree(p);
+    // recycled only while a session is open NOW (a matrix made during a session and freed after it frees its buffers)
+    if (m->pooled && ctx && ctx->pool_on > 0 && hipMemPtrGetInfo(p, &cap) == hipSuccess && cap > 0) {
+        ctx->pool.emplace_back(p, cap);
+        while (ctx->pool.size() > 1 && pool_bytes(ctx) > kPoolCapBytes) {       // oldest first
+            (void)hipFree(ctx->pool.front().first);
+            ctx->pool.erase(ctx->pool.begin());
+        }
+    } else {
+        (void)hipFree(p);
+    }
 }
 void pool_clear(srx_ctx* ctx) {
     for (auto& b : ctx->pool) (void)hipFree(b.first);
@@ -785,8 +810,20 @@ int32_t srx_matrix_prepare(srx_mat* m) {
 int32_t srx_matrix_copy_values(srx_mat* dst, const srx_mat* src) {
     if (!dst || !src) return fail(nullptr, SRX_E_ARG, "null argument");
     srx_ctx* ctx = dst->ctx;
-    if (dst->nnz != src->nnz || dst->n_rows != src->n_rows || dst->store != src->store)
-        return fail(ctx, SRX_E_ARG, "copy_values: pattern/storage mismatch");
+    if (dst->nnz != src->nnz || dst->n_rows != src->n_rows)
+        return fail(ctx, SRX_E_ARG, "copy_values: pattern mismatch");
+    if (dst->store != src->store) {
+        // a SRX_STORE_AUTO work copy that normalize_total / log1p / srx_pipeline promoted to f64 being restored from its
+        // pristine f32 source (or the other way round): the value buffer follows the source's storage again
+        if (!dst->store_auto) return fail(ctx, SRX_E_ARG, "copy_values: storage mismatch (explicit storage on the destination)");
+        void* d_new = nullptr;
+        SRX_HIP(ctx, hipMalloc(&d_new, (src->nnz + 16) * val_bytes(src)));
+        SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(dst->d_values);
+        dst->d_values = d_new;
+        dst->store = src->store;
+        SRX_HIP(ctx, hipMemsetAsync((char*)d_new + src->nnz * val_bytes(src), 0, 16 * val_bytes(src), ctx->stream));
+    }
     SRX_HIP(ctx, hipMemcpyAsync(dst->d_values, src->d_values, src->nnz * val_bytes(src),
                                 hipMemcpyDeviceToDevice, ctx->stream));
     dst->dtype = src->dtype;

@@ -175,6 +175,8 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
                     x0 = y4[j];
                     if (__builtin_expect(!(fabs(x0) < 64.0), 0)) {     // NaN, infinite, or outside the fixed-point range: the gene's moments are NaN
                         poison[(uint64_t)gbase + g0] = 1u;
+                        // the entry still COUNTS: the per-gene counts of this pass are cached as pattern-only counts
+                        if constexpr (COUNT) __hip_atomic_fetch_add(&s_cnt[g0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         continue;
                     }
                     // round-to-nearest integer of x * 2^shift through the 1.5 * 2^52 trick (|x * 2^shift| < 2^51)
@@ -601,6 +603,14 @@ int32_t ensure_moments_xf(srx_mat* m, RowXf xf) {
     SRX_TRY(alloc_moments(m));
     double* packed;
     SRX_TRY(local_moments(m, &packed, xf));
+    if (xf.write_back) {
+        // the pass above has stored the transformed values in place: whatever fails from here on (all-reduce, read-back), X
+        // must not be transformed a second time by the pipeline's epilogue — the bookkeeping of normalize_total + log1p
+        // (scale/mod.rs:74-83 -> F64, transform/mod.rs:43-55) belongs to the moment the kernel is in the stream
+        m->lazy_pending = false;
+        m->dtype = SRX_F64;
+        touch(m);
+    }
     SRX_TRY(allreduce_f64(ctx, packed, 3 * G + 1));
     hipLaunchKernelGGL(k_moments_unpack, dim3((unsigned)((G + 255) / 256 + 1)), dim3(256), 0, ctx->stream, packed, G,
                        m->d_cnt, m->d_sum, m->d_sq);

@@ -3524,6 +3524,14 @@ int32_t srx_pipeline(srx_mat* m, double target_sum, uint64_t n_hvg, const srx_pc
             return fail(ctx, SRX_E_HIP, "srx_pipeline: hipEventCreate failed");
         }
     int32_t rc = SRX_OK;
+    // SRX_STORE_AUTO: the storage follows the reference's variant (scale/mod.rs:74-83: X becomes DynCsrMatrix::F64 at
+    // normalize_total) exactly as under the three separate calls — the raw values widen to f64 first and the whole path runs at
+    // f64 storage.  The f32 fast path (X ends as f32(ln_1p(f64(v) * scale))) is for handles created with SRX_STORE_F32.
+    if (!m->csc) rc = promote_to_f64(m);
+    if (rc != SRX_OK) {
+        cleanup();
+        return rc;
+    }
     (void)hipEventRecord(ev[0], ctx->stream);
     // normalize_total_inplace(target, Row) + log1p_transform_inplace.  CSR: the passes that follow read the RAW matrix
     // and form y = ln_1p(v * scale_row) on the fly in f64 (RowXf) — so the per-gene moments behind HighlyVariable(n)
@@ -3555,17 +3563,13 @@ int32_t srx_pipeline(srx_mat* m, double target_sum, uint64_t n_hvg, const srx_pc
         Range r_("srx:gene_moments");
         if (lazy) {
             rc = ensure_moments_xf(m, xf);
-            if (rc == SRX_OK && xf.write_back) {
-                // X now holds the transformed values: the passes below read them as stored.  The bookkeeping of the two
-                // in-place calls (scale/mod.rs:74-83 -> F64, transform/mod.rs:43-55) belongs here, before the solve records
-                // the version of the matrix it ran on.
-                m->lazy_pending = false;
+            if (xf.write_back && !m->lazy_pending) {
+                // X now holds the transformed values (ensure_moments_xf did the bookkeeping of the two in-place calls as soon
+                // as its kernel was in the stream, also when a later step of it failed): the passes below read them as stored
                 xf = RowXf{};
                 wrote_back = true;
-                m->dtype = SRX_F64;
-                touch(m);
             }
-            m->moments_version = m->version;          // what pca_device's ensure_moments looks at
+            if (rc == SRX_OK) m->moments_version = m->version;          // what pca_device's ensure_moments looks at
         } else rc = ensure_moments(m);
     }
     (void)hipEventRecord(ev[2], ctx->stream);
