@@ -1824,6 +1824,8 @@ __global__ __launch_bounds__(1024) void k_jacobi_eig(const double* __restrict__ 
     }
 }
 
+#include "jacobi.inl"
+
 // ---- Chebyshev filter between two Rayleigh–Ritz steps ----------------------------------------------
 // After a Ritz step the block holds Ritz vectors V (A2) with values theta and C V (A1).  The eigenvalues
 // that are NOT wanted lie in [0, b] with b <= theta_l (the smallest Ritz value of the block bounds
@@ -2461,6 +2463,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     const size_t kl = (size_t)k * L;
     const bool use_graph = graphable && !getenv("SRX_NO_GRAPH");
     const bool use_cheb = l_act > o.n_pc && !o.robust && !o.direct && !getenv("SRX_NO_CHEB");      // both solvers: the filter only needs `apply`
+    const bool jacobi_old = getenv("SRX_JACOBI_OLD") != nullptr;       // A/B switch: the 1024-thread kernel with U in LDS
     constexpr int kSlots = srx_ctx::kAsyncSlots, kSlotDoubles = 8;
     if (!ctx->pin_async) {
         SRX_HIP(ctx, hipHostMalloc((void**)&ctx->pin_async, kSlots * kSlotDoubles * sizeof(double), hipHostMallocDefault));
@@ -2472,10 +2475,11 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     SRX_TRY(scratch(ctx, "pca_res", kSlots * kSlotDoubles * sizeof(double), (void**)&d_res));
     SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_jacobi_eig, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)kJacobiLds));
+    SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_jacobi_eig2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(J2Lds)));
     // what a captured segment depends on besides its own schedule: shapes, options, every buffer it touches
     char key0[256];
     snprintf(key0, sizeof key0, "k%d l%d p%d w%d r%d n%d s%llu|%p %p %p %p %p %p %p %p %p", k, l_act, o.power, o.warm,
-             (o.robust ? 1 : 0) + (o.direct ? 2 : 0), o.n_pc,
+             (o.robust ? 1 : 0) + (o.direct ? 2 : 0) + (jacobi_old ? 4 : 0), o.n_pc,
              (unsigned long long)o.seed, apply_id, (void*)w.W, (void*)w.Wp, (void*)w.A1, (void*)w.A2, (void*)w.small,
              (void*)w.gpart, (void*)d_status, (void*)d_status_sel);
     const std::string key_base(key0);
@@ -2524,8 +2528,12 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     auto ritz_kernels = [&](int slot, bool loose = false) -> int32_t {
         SRX_TRY(apply(w.W, w.Wp));
         SRX_TRY(gram2(ctx, w, w.W, w.Wp, k));
-        hipLaunchKernelGGL(k_jacobi_eig, dim3(1), dim3(1024), kJacobiLds, ctx->stream, w.dHG, l_act, w.dM2, w.dTheta,
-                           d_status, loose ? 1e-10 : 1e-30);
+        if (jacobi_old)
+            hipLaunchKernelGGL(k_jacobi_eig, dim3(1), dim3(1024), kJacobiLds, ctx->stream, w.dHG, l_act, w.dM2, w.dTheta,
+                               d_status, loose ? 1e-10 : 1e-30);
+        else
+            hipLaunchKernelGGL(k_jacobi_eig2, dim3(1), dim3(kJ2Threads), sizeof(J2Lds), ctx->stream, w.dHG, l_act, w.dM2, w.dTheta,
+                               d_status, loose ? 1e-10 : 1e-30);
         hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.Wp, w.dM2, k, w.A1);
         hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.W, w.dM2, k, w.A2);
         hipLaunchKernelGGL(k_col_resid, dim3(1), dim3(1024), 0, ctx->stream, w.A1, w.A2, w.dTheta, k, w.dRho, w.dColmax);
