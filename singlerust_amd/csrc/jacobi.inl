@@ -181,7 +181,7 @@ __device__ __forceinline__ void j2_u_rounds(double (&u)[L], const J2Lds& S, int&
     ((J2Round<Rs + 1>::apply(u, S.tu[par]), j2_barrier(), par ^= 1), ...);
 }
 
-__global__ __launch_bounds__(kJ2Threads) void k_jacobi_eig2(const double* __restrict__ H, int n, double* __restrict__ U,
+__global__ __launch_bounds__(kJ2Threads) void k_jacobi_eig2(const double* __restrict__ H, int n_part, int n, double* __restrict__ U,
                                                             double* __restrict__ theta, int* __restrict__ status, double off_tol2) {
     static_assert(L == 64, "the block mapping is written for l = 64");
     extern __shared__ double j2_lds_raw[];
@@ -189,9 +189,26 @@ __global__ __launch_bounds__(kJ2Threads) void k_jacobi_eig2(const double* __rest
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     const int lane = tid & (kWave - 1);
-    for (int e = tid; e < L * L; e += kJ2Threads) {
-        const int a = e >> 6, b = e & 63;
-        if (a < b) S.A[0][a][b] = (a < n && b < n) ? 0.5 * (H[(size_t)a * L + b] + H[(size_t)b * L + a]) : 0.0;
+    // H = the sum of n_part <= 16 partial matrices (k_gram1_part), in fixed order: summed into the second copy of the matrix
+    // (free until round 0 writes it), all partial loads of an entry in flight; then symmetrised, the diagonal parked in scale[0]
+    {
+        double* const T = &S.A[1][0][0];
+        for (int e = tid; e < L * L; e += kJ2Threads) {
+            double v[kGram1Blocks];
+#pragma unroll
+            for (int p = 0; p < kGram1Blocks; ++p) v[p] = p < n_part ? H[(size_t)p * L * L + e] : 0.0;
+            double h = 0.0;
+#pragma unroll
+            for (int p = 0; p < kGram1Blocks; ++p) h += v[p];
+            T[e] = h;
+        }
+        j2_barrier();
+        for (int e = tid; e < L * L; e += kJ2Threads) {
+            const int a = e >> 6, b = e & 63;
+            const bool in = a < n && b < n;
+            if (a < b) S.A[0][a][b] = in ? 0.5 * (T[a * L + b] + T[b * L + a]) : 0.0;
+            if (a == b) S.scale[0][a] = in ? T[e] : 0.0;
+        }
     }
     if (tid < L) S.scale[1][tid] = 1.0;
     if (tid == 0) S.flag = 0;
@@ -200,7 +217,7 @@ __global__ __launch_bounds__(kJ2Threads) void k_jacobi_eig2(const double* __rest
     if (tid < L / 2) {
         const int p = 2 * tid, q = p + 1;
         const double apq = S.A[0][p][q];
-        const double app = p < n ? H[(size_t)p * L + p] : 0.0, aqq = q < n ? H[(size_t)q * L + q] : 0.0;
+        const double app = S.scale[0][p], aqq = S.scale[0][q];
         double t, c, dp, dq;
         j2_rotation(app, aqq, apq, t, c, dp, dq);
         S.rec[0][tid][0] = t;

@@ -1313,19 +1313,31 @@ __global__ void k_gram_expand(const double* __restrict__ P, int k, const double*
 // accumulators.  Both operands are read straight from global memory in fragment order with no LDS
 // staging: lane l of the A fragment needs C[row0 + (l & 15)][kk + (l >> 4)], which by symmetry is
 // C[kk + (l >> 4)][row0 + (l & 15)] — 16 consecutive doubles per K index, fully coalesced; the B
-// fragment W[kk + (l >> 4)][16 t + (l & 15)] is coalesced as it stands.  The K slices (split-K 16:
-// ~1000 waves for k = 2000, one per SIMD) are combined with f64 atomics into the zeroed Wp.
+// fragment W[kk + (l >> 4)][16 t + (l & 15)] is coalesced as it stands.  The K slices (split-K 16 across
+// workgroups x 4 waves inside one: ~4000 waves for k = 2000) are combined in LDS, then with f64 atomics into the zeroed Wp.
 // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg (not the f32 map).
-constexpr int kDenseSplit = 16;
+#ifndef SRX_DENSE_SPLIT          // measured at k = 2000 (split x waves: us): 16x4 21.8, 8x8 21.9, 8x4 18.8, 4x4 17.8, 4x8 17.5, 8x2 28.3, 4x16 36.3 —
+#define SRX_DENSE_SPLIT 4       // the f64 atomics into Wp (k x 64 x split) weigh more than the number of waves in flight
+#define SRX_DENSE_WAVES 8
+#endif
+constexpr int kDenseSplit = SRX_DENSE_SPLIT;
+constexpr int kDenseWaves = SRX_DENSE_WAVES;             // waves of a workgroup: consecutive quarters of the workgroup's K slice
 typedef double dvec4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(64) void k_dense_apply(const double* __restrict__ C, const double* __restrict__ W, int k,
-                                                    double* __restrict__ Wp) {
-    const int lane = threadIdx.x;
+// Workgroup = 32 output rows x 64 columns x one K slice, its four waves on consecutive quarters of the slice (four waves per
+// SIMD keep ~4x the loads in flight: one wave per SIMD left the load latency of every group of 16 K indices exposed, 27 us
+// per application against ~7 us of MFMA time); the waves' partial tiles meet in LDS (ds_add_f64), then one f64 atomic per
+// output element and K slice into the zeroed Wp.
+__global__ __launch_bounds__(kDenseWaves * 64) void k_dense_apply(const double* __restrict__ C, const double* __restrict__ W, int k,
+                                                                  double* __restrict__ Wp) {
+    __shared__ double red[32][L];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int row0 = blockIdx.x * 32;
-    const int kchunk = (((k + kDenseSplit - 1) / kDenseSplit) + 3) / 4 * 4;
-    const int kbeg = blockIdx.y * kchunk;
-    const int kend = kbeg + kchunk < k ? kbeg + kchunk : k;
+    const int kchunk = (((k + kDenseSplit - 1) / kDenseSplit) + 4 * kDenseWaves - 1) / (4 * kDenseWaves) * (4 * kDenseWaves);      // per workgroup: waves x a multiple of 4
+    const int kq = kchunk / kDenseWaves;
+    const int kbeg = blockIdx.y * kchunk + wv * kq;
+    const int kend = kbeg + kq < k ? kbeg + kq : k;
+    for (int e = threadIdx.x; e < 32 * L; e += kDenseWaves * 64) (&red[0][0])[e] = 0.0;
     dvec4 acc[2][4];
 #pragma unroll
     for (int sI = 0; sI < 2; ++sI)
@@ -1333,7 +1345,7 @@ __global__ __launch_bounds__(64) void k_dense_apply(const double* __restrict__ C
         for (int t = 0; t < 4; ++t) acc[sI][t] = dvec4{0.0, 0.0, 0.0, 0.0};
     const bool r0ok = row0 + li < k, r1ok = row0 + 16 + li < k;
     // groups of 4 K-steps (16 K indices), two register buffers: the 24 loads of group g+1 are in flight
-    // while the 32 MFMAs of group g issue (one wave per SIMD: nothing else would hide the latency)
+    // while the 32 MFMAs of group g issue
     struct Frag { double a0[4], a1[4], bq[4][4]; };
     auto load = [&](Frag& f, int kk) {
 #pragma unroll
@@ -1365,16 +1377,19 @@ __global__ __launch_bounds__(64) void k_dense_apply(const double* __restrict__ C
         load(f0, kk + 32);
         fma(f1);
     }
+    __syncthreads();                             // (the tile is zeroed)
+    // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
     for (int sI = 0; sI < 2; ++sI)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int r = row0 + 16 * sI + lk + 4 * v;
-            if (r < k) {
+        for (int v = 0; v < 4; ++v)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) atomicAdd(&Wp[(size_t)r * L + 16 * t + li], acc[sI][t][v]);
-            }
-        }
+            for (int t = 0; t < 4; ++t) atomicAdd(&red[16 * sI + lk + 4 * v][16 * t + li], acc[sI][t][v]);
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * L; e += kDenseWaves * 64) {
+        const int r = row0 + e / L;
+        if (r < k) atomicAdd(&Wp[(size_t)r * L + (e % L)], (&red[0][0])[e]);
+    }
 }
 
 // ---- k x l helper kernels (f64, replicated per rank) --------------------------------------------
@@ -1455,6 +1470,97 @@ __global__ void k_gram2_reduce(const double* __restrict__ part, int n_blocks, do
     double s = 0.0;
     for (int b = 0; b < n_blocks; ++b) s += part[(size_t)b * 2 * L * L + e];
     HG[e] = s;
+}
+
+// ONE product of two k x 64 blocks, H = A^T B (A == B: the Gram matrix of a block), as kGram1Blocks partial 64 x 64 sums
+// over row slices.  The consumer — k_chol_factor_panels or k_jacobi_eig2, through (part, n_part) — adds the partials in fixed
+// order while it loads the matrix: no reduction kernel between the two, and half the arithmetic of k_gram2_part, which forms
+// both products whichever is wanted.
+constexpr int kGram1Blocks = 16;
+__global__ __launch_bounds__(1024) void k_gram1_part(const double* __restrict__ A, const double* __restrict__ B, int k,
+                                                     double* __restrict__ part /* [blocks][64*64] */) {
+    constexpr int R = 32;
+    __shared__ double sa[R][L], sb[R][L];
+    const bool same = A == B;
+    double h[4] = {0, 0, 0, 0};
+    const int b = threadIdx.x & (L - 1), a0 = threadIdx.x / L;    // entries (a0 + 16u, b), u < 4
+    const int rows_per = (k + gridDim.x - 1) / gridDim.x;
+    const int jb0 = blockIdx.x * rows_per;
+    const int jb1 = jb0 + rows_per < k ? jb0 + rows_per : k;
+    for (int j0 = jb0; j0 < jb1; j0 += R) {
+        for (int e = threadIdx.x; e < R * L; e += 1024) {
+            const int j = j0 + e / L;
+            const double bv = j < jb1 ? B[(size_t)j * L + (e % L)] : 0.0;
+            sb[e / L][e % L] = bv;
+            sa[e / L][e % L] = same ? bv : (j < jb1 ? A[(size_t)j * L + (e % L)] : 0.0);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int r = 0; r < R; ++r) {
+            const double bv = sb[r][b];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) h[u] += sa[r][a0 + 16 * u] * bv;
+        }
+        __syncthreads();
+    }
+    double* out = part + (size_t)blockIdx.x * L * L;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) out[(a0 + 16 * u) * L + b] = h[u];
+}
+
+// The tail of a Rayleigh–Ritz step in one pass over the rows: A1 = Wp U (= C W U), A2 = W U (the Ritz vectors), and per
+// block the partial sums of || A1[:, c] - theta_c A2[:, c] ||^2 and the entry of largest |.| of A2[:, c] (ties: the smallest
+// row).  k_resid_final adds the partials in fixed order.  (Was: k_right_mul twice, k_col_resid on ONE workgroup, k_resid_scalar.)
+constexpr int kRitzBlocks = 128;
+__global__ __launch_bounds__(256) void k_ritz_post(const double* __restrict__ W, const double* __restrict__ Wp,
+                                                   const double* __restrict__ M, const double* __restrict__ theta, int k,
+                                                   double* __restrict__ A1, double* __restrict__ A2,
+                                                   double* __restrict__ part /* [blocks][3][64]: r2, best value, its row */) {
+    __shared__ double sm[L][L + 1];
+    __shared__ double s_r[4][L], s_v[4][L], s_j[4][L];
+    for (int e = threadIdx.x; e < L * L; e += 256) sm[e / L][e % L] = M[e];
+    __syncthreads();
+    const int c = threadIdx.x & (L - 1), sub = threadIdx.x / L;    // 4 rows per pass
+    const double th = theta[c];
+    double acc = 0.0, best = 0.0, best_j = 0.0;
+    for (int j = blockIdx.x * 4 + sub; j < k; j += gridDim.x * 4) {
+        const double* rw = W + (size_t)j * L;
+        const double* rp = Wp + (size_t)j * L;
+        double a1 = 0.0, a2 = 0.0;
+#pragma unroll 8
+        for (int b = 0; b < L; ++b) {
+            const double m = sm[b][c];
+            a1 += rp[b] * m;
+            a2 += rw[b] * m;
+        }
+        A1[(size_t)j * L + c] = a1;
+        A2[(size_t)j * L + c] = a2;
+        const double r = a1 - th * a2;
+        acc += r * r;
+        if (fabs(a2) > fabs(best)) {          // rows come in increasing order: the first one of the largest magnitude stays
+            best = a2;
+            best_j = (double)j;
+        }
+    }
+    s_r[sub][c] = acc;
+    s_v[sub][c] = best;
+    s_j[sub][c] = best_j;
+    __syncthreads();
+    if (sub == 0) {
+        double t = 0.0, bv = 0.0, bj = 0.0;
+        for (int w = 0; w < 4; ++w) {
+            t += s_r[w][c];
+            const double v = s_v[w][c], jj = s_j[w][c];
+            if (fabs(v) > fabs(bv) || (fabs(v) == fabs(bv) && v != 0.0 && jj < bj)) {
+                bv = v;
+                bj = jj;
+            }
+        }
+        double* out = part + (size_t)blockIdx.x * 3 * L;
+        out[c] = t;
+        out[L + c] = bv;
+        out[2 * L + c] = bj;
+    }
 }
 
 // Out = In * M  (k x 64 times 64 x 64), M row-major.
@@ -1596,14 +1702,20 @@ __global__ __launch_bounds__(1024) void k_chol_factor(const double* __restrict__
 // threads subtract the panel's rank-8 update from the trailing rows: 16 barriers for l = 64 instead of 64 (the CholeskyQR
 // runs five times per solve).  Same outputs and status as k_chol_factor(shifted = 0).
 constexpr int kCholPanel = 8;
-__global__ __launch_bounds__(1024) void k_chol_factor_panels(const double* __restrict__ G, int n, double* __restrict__ Rout,
+__global__ __launch_bounds__(1024) void k_chol_factor_panels(const double* __restrict__ G, int n_part, int n, double* __restrict__ Rout,
                                                              double* __restrict__ dinv, int* __restrict__ status) {
     __shared__ double A[L][L + 1];           // the rows of a finished panel hold R
     __shared__ int s_bad;
     const int tid = threadIdx.x;
-    for (int e = tid; e < L * L; e += 1024) {
+    for (int e = tid; e < L * L; e += 1024) {      // G = the sum of n_part <= 16 partial matrices (k_gram1_part), in fixed order
         const int r = e >> 6, c = e & 63;
-        A[r][c] = (r < n && c < n) ? G[(size_t)r * L + c] : 0.0;
+        double v[kGram1Blocks];
+#pragma unroll
+        for (int p = 0; p < kGram1Blocks; ++p) v[p] = p < n_part ? G[(size_t)p * L * L + e] : 0.0;      // all in flight
+        double g = 0.0;
+#pragma unroll
+        for (int p = 0; p < kGram1Blocks; ++p) g += v[p];
+        A[r][c] = (r < n && c < n) ? g : 0.0;
     }
     if (tid == 0) s_bad = 0;
     __syncthreads();
@@ -1848,12 +1960,14 @@ __global__ void k_cheb_first(double* __restrict__ A1, const double* __restrict__
     A1[e] = a * A1[e] - A2[e];
 }
 // prev <- 2 (a Z - cur) - prev   (Y_{j+1} from Z = C Y_j, Y_j, Y_{j-1})
-__global__ void k_cheb_step(const double* __restrict__ Z, const double* __restrict__ cur, double* __restrict__ prev,
+// (Z is left ZEROED: it is the destination of the next application of C, which accumulates into a zeroed block)
+__global__ void k_cheb_step(double* __restrict__ Z, const double* __restrict__ cur, double* __restrict__ prev,
                             const double* __restrict__ theta, int l_act, size_t n) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     const double a = 2.0 / cheb_b(theta, l_act);
     prev[e] = 2.0 * (a * Z[e] - cur[e]) - prev[e];
+    Z[e] = 0.0;
 }
 // column i divided by T_d(t_i), t_i = (2 theta_i - b) / b: the filtered columns are (nearly) eigenvectors
 // scaled by T_d(t_i); taking the known factor out keeps the CholeskyQR that follows well conditioned
@@ -1896,6 +2010,57 @@ __global__ void k_resid_scalar(const double* __restrict__ rho, const double* __r
     out[4] = theta[l_act - 1] > 0 ? theta[0] / theta[l_act - 1] : 1.0;      // spread of the block: bounds the filter degree
 }
 
+// k_ritz_post's partials -> rho[c], colmax[c], then the scalars of k_resid_scalar (same slots of `out`).  1024 threads:
+// 16 slices of the blocks per column (a single wave walking 128 x 3 dependent loads took 45 us), combined in fixed order.
+__global__ __launch_bounds__(1024) void k_resid_final(const double* __restrict__ part, int n_blocks, const double* __restrict__ theta,
+                                                      int n_pc, int l_act, const int* __restrict__ status,
+                                                      const int* __restrict__ status_sel, double* __restrict__ rho,
+                                                      double* __restrict__ colmax, double* __restrict__ out) {
+    __shared__ double s_t[16][L], s_v[16][L], s_j[16][L], s_rho[L];
+    const int c = threadIdx.x & (L - 1), sl = threadIdx.x / L;
+    double t = 0.0, bv = 0.0, bj = 0.0;
+    for (int b = sl; b < n_blocks; b += 16) {
+        const double* p = part + (size_t)b * 3 * L;
+        t += p[c];
+        const double v = p[L + c], jj = p[2 * L + c];
+        if (fabs(v) > fabs(bv) || (fabs(v) == fabs(bv) && v != 0.0 && jj < bj)) {
+            bv = v;
+            bj = jj;
+        }
+    }
+    s_t[sl][c] = t;
+    s_v[sl][c] = bv;
+    s_j[sl][c] = bj;
+    __syncthreads();
+    if (sl == 0) {
+        t = 0.0; bv = 0.0; bj = 0.0;
+        for (int w = 0; w < 16; ++w) {
+            t += s_t[w][c];
+            const double v = s_v[w][c], jj = s_j[w][c];
+            if (fabs(v) > fabs(bv) || (fabs(v) == fabs(bv) && v != 0.0 && jj < bj)) {
+                bv = v;
+                bj = jj;
+            }
+        }
+        const double r = sqrt(t);
+        rho[c] = r;
+        colmax[c] = bv;
+        s_rho[c] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double resid = 0.0;
+    for (int i = 0; i < n_pc; ++i) {
+        const double den = theta[i] > 1e-5 * theta[0] ? theta[i] : 1e-5 * theta[0];      // (see k_resid_scalar)
+        const double q = den > 0 ? s_rho[i] / den : s_rho[i];
+        if (!(q <= resid)) resid = q;
+    }
+    out[0] = resid;
+    out[1] = (double)*status;
+    out[2] = theta[n_pc - 1] > 0 ? theta[l_act - 1] / theta[n_pc - 1] : 1.0;
+    out[3] = status_sel ? (double)*status_sel : 0.0;
+    out[4] = theta[l_act - 1] > 0 ? theta[0] / theta[l_act - 1] : 1.0;
+}
 
 // ---- compacted matrix: row-major records + the tile-major view of the forward SpMM ------------------
 struct CompactCsr {
@@ -2473,6 +2638,8 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     double* d_res;
     SRX_TRY(scratch(ctx, "pca_status", 256, (void**)&d_status));
     SRX_TRY(scratch(ctx, "pca_res", kSlots * kSlotDoubles * sizeof(double), (void**)&d_res));
+    double* d_ritz;
+    SRX_TRY(scratch(ctx, "pca_ritzpart", (size_t)kRitzBlocks * 3 * L * sizeof(double), (void**)&d_ritz));
     SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_jacobi_eig, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)kJacobiLds));
     SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_jacobi_eig2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(J2Lds)));
@@ -2481,7 +2648,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     snprintf(key0, sizeof key0, "k%d l%d p%d w%d r%d n%d s%llu|%p %p %p %p %p %p %p %p %p", k, l_act, o.power, o.warm,
              (o.robust ? 1 : 0) + (o.direct ? 2 : 0) + (jacobi_old ? 4 : 0), o.n_pc,
              (unsigned long long)o.seed, apply_id, (void*)w.W, (void*)w.Wp, (void*)w.A1, (void*)w.A2, (void*)w.small,
-             (void*)w.gpart, (void*)d_status, (void*)d_status_sel);
+             (void*)w.gpart, (void*)d_status, (void*)d_status_sel);       // (d_ritz, d_res: allocated with d_status, never regrown)
     const std::string key_base(key0);
 
     // Everything below only ENQUEUES work: the l x l factorisations run on the device, and the one
@@ -2490,12 +2657,22 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
 
     // orthonormalise src -> W  (CholeskyQR: G = src^T src = R^T R, W = src R^-1; src == W is fine: every
     // thread of the substitution owns one row); G lands in dHG + L*L
+    auto gram1 = [&](const double* A, const double* B) -> int32_t {       // partial sums of A^T B in w.gpart
+        int nb = (k + 31) / 32;
+        if (nb > kGram1Blocks) nb = kGram1Blocks;
+        hipLaunchKernelGGL(k_gram1_part, dim3(nb), dim3(1024), 0, ctx->stream, A, B, k, w.gpart);
+        SRX_HIP(ctx, hipGetLastError());
+        return nb;
+    };
     auto orth = [&](const double* src) -> int32_t {
-        SRX_TRY(gram2(ctx, w, src, src, k));
-        if (o.robust)
+        if (o.robust) {
+            SRX_TRY(gram2(ctx, w, src, src, k));
             hipLaunchKernelGGL(k_chol_factor, dim3(1), dim3(1024), 0, ctx->stream, w.dHG + L * L, l_act, w.dM, w.dDinv, d_status, 1);
-        else
-            hipLaunchKernelGGL(k_chol_factor_panels, dim3(1), dim3(1024), 0, ctx->stream, w.dHG + L * L, l_act, w.dM, w.dDinv, d_status);
+        } else {
+            const int32_t nb = gram1(src, src);
+            if (nb < 0) return nb;
+            hipLaunchKernelGGL(k_chol_factor_panels, dim3(1), dim3(1024), 0, ctx->stream, (const double*)w.gpart, nb, l_act, w.dM, w.dDinv, d_status);
+        }
         hipLaunchKernelGGL(k_trsm_rows, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, src, w.dM, w.dDinv, k, w.W);
         SRX_HIP(ctx, hipGetLastError());
         if (o.robust) {                         // second pass: the first one may have run on a shifted Gram matrix
@@ -2512,7 +2689,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         const double* cur = src;
         for (int t = 0; t < n; ++t) {
             double* dst = (cur == w.Wp) ? w.A1 : w.Wp;
-            SRX_TRY(apply(cur, dst));
+            SRX_TRY(apply(cur, dst, false));
             cur = dst;
         }
         *out = cur;
@@ -2525,20 +2702,30 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     // the cyclic Jacobi two slow sweeps: it may stop at an off-diagonal norm of 1e-5 of the diagonal (7 -> 5 sweeps).  The
     // residuals are measured on the vectors actually formed, so a loosely rotated basis is judged as what it is: at the
     // default tolerances (1e-7 / 1e-9) such a step is never accepted as converged — the next, exact one decides.
-    auto ritz_kernels = [&](int slot, bool loose = false) -> int32_t {
-        SRX_TRY(apply(w.W, w.Wp));
-        SRX_TRY(gram2(ctx, w, w.W, w.Wp, k));
-        if (jacobi_old)
+    auto ritz_kernels = [&](int slot, bool loose = false, bool wp_zero = false) -> int32_t {
+        SRX_TRY(apply(w.W, w.Wp, wp_zero));
+        if (jacobi_old) {
+            SRX_TRY(gram2(ctx, w, w.W, w.Wp, k));
             hipLaunchKernelGGL(k_jacobi_eig, dim3(1), dim3(1024), kJacobiLds, ctx->stream, w.dHG, l_act, w.dM2, w.dTheta,
                                d_status, loose ? 1e-10 : 1e-30);
-        else
-            hipLaunchKernelGGL(k_jacobi_eig2, dim3(1), dim3(kJ2Threads), sizeof(J2Lds), ctx->stream, w.dHG, l_act, w.dM2, w.dTheta,
-                               d_status, loose ? 1e-10 : 1e-30);
-        hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.Wp, w.dM2, k, w.A1);
-        hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.W, w.dM2, k, w.A2);
-        hipLaunchKernelGGL(k_col_resid, dim3(1), dim3(1024), 0, ctx->stream, w.A1, w.A2, w.dTheta, k, w.dRho, w.dColmax);
-        hipLaunchKernelGGL(k_resid_scalar, dim3(1), dim3(64), 0, ctx->stream, w.dRho, w.dTheta, o.n_pc, l_act, d_status,
-                           d_status_sel, d_res + kSlotDoubles * slot);
+            hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.Wp, w.dM2, k, w.A1);
+            hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.W, w.dM2, k, w.A2);
+            hipLaunchKernelGGL(k_col_resid, dim3(1), dim3(1024), 0, ctx->stream, w.A1, w.A2, w.dTheta, k, w.dRho, w.dColmax);
+            hipLaunchKernelGGL(k_resid_scalar, dim3(1), dim3(64), 0, ctx->stream, w.dRho, w.dTheta, o.n_pc, l_act, d_status,
+                               d_status_sel, d_res + kSlotDoubles * slot);
+        } else {
+            // H = W^T (C W) as partial sums -> eigen-solve (adds them on load) -> Ritz vectors, C x Ritz vectors, residual and
+            // largest-entry partials in one pass -> the step's scalars: 4 launches (9 on the old route)
+            const int32_t nb = gram1(w.W, w.Wp);
+            if (nb < 0) return nb;
+            hipLaunchKernelGGL(k_jacobi_eig2, dim3(1), dim3(kJ2Threads), sizeof(J2Lds), ctx->stream, (const double*)w.gpart, nb, l_act,
+                               w.dM2, w.dTheta, d_status, loose ? 1e-10 : 1e-30);
+            hipLaunchKernelGGL(k_ritz_post, dim3(kRitzBlocks), dim3(256), 0, ctx->stream, (const double*)w.W, (const double*)w.Wp,
+                               (const double*)w.dM2, (const double*)w.dTheta, k, w.A1, w.A2, d_ritz);
+            hipLaunchKernelGGL(k_resid_final, dim3(1), dim3(1024), 0, ctx->stream, (const double*)d_ritz, kRitzBlocks,
+                               (const double*)w.dTheta, o.n_pc, l_act, d_status, d_status_sel, w.dRho, w.dColmax,
+                               d_res + kSlotDoubles * slot);
+        }
         SRX_HIP(ctx, hipGetLastError());
         return SRX_OK;
     };
@@ -2609,14 +2796,14 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         hipLaunchKernelGGL(k_cheb_first, dim3(cheb_grid), dim3(256), 0, ctx->stream, w.A1, (const double*)w.A2,
                            (const double*)w.dTheta, l_act, kl);
         SRX_HIP(ctx, hipGetLastError());
-        return apply(w.A1, w.Wp);
+        return apply(w.A1, w.Wp, false);
     };
     // the rest of a degree-d filter (Z = C Y1 is in Wp, cur = A1, prev = A2), CholeskyQR, Ritz step
     auto cheb_rest = [&](int d, int slot) -> int32_t {
         double *cur = w.A1, *prev = w.A2;
         for (int j = 1; j < d; ++j) {
-            if (j > 1) SRX_TRY(apply(cur, w.Wp));
-            hipLaunchKernelGGL(k_cheb_step, dim3(cheb_grid), dim3(256), 0, ctx->stream, (const double*)w.Wp,
+            if (j > 1) SRX_TRY(apply(cur, w.Wp, true));          // (the step before left Wp zeroed)
+            hipLaunchKernelGGL(k_cheb_step, dim3(cheb_grid), dim3(256), 0, ctx->stream, w.Wp,
                                (const double*)cur, prev, (const double*)w.dTheta, l_act, kl);
             double* t = cur;
             cur = prev;
@@ -2625,7 +2812,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         hipLaunchKernelGGL(k_cheb_scale, dim3(cheb_grid), dim3(256), 0, ctx->stream, cur, (const double*)w.dTheta, l_act, d, kl);
         SRX_HIP(ctx, hipGetLastError());
         SRX_TRY(orth(cur));
-        return ritz_kernels(slot);
+        return ritz_kernels(slot, false, true);          // (Wp: zeroed by the last filter step, untouched by the CholeskyQR)
     };
     // segment "next": [advance] + (m - 1) plain sweeps + a Ritz step into `slot`
     auto seg_next = [&](bool with_advance, int m, int slot) -> int32_t {
@@ -2988,10 +3175,10 @@ static int32_t run_pca(srx_ctx* ctx, const RowMajor* parts, int n_parts, const T
             SRX_HIP(ctx, hipGetLastError());
             return SRX_OK;
         };
-        auto apply = [&](const double* Win, double* Wout) -> int32_t {
+        auto apply = [&](const double* Win, double* Wout, bool out_zeroed) -> int32_t {
             ProfScope ps(ctx, SRX_K_DENSE, (double)k * k * 8.0 + 2.0 * k * L * 8.0);
-            SRX_HIP(ctx, hipMemsetAsync(Wout, 0, kl * 8, ctx->stream));
-            hipLaunchKernelGGL(k_dense_apply, dim3((k + 31) / 32, kDenseSplit), dim3(64), 0, ctx->stream, C, Win, k, Wout);
+            if (!out_zeroed) SRX_HIP(ctx, hipMemsetAsync(Wout, 0, kl * 8, ctx->stream));
+            hipLaunchKernelGGL(k_dense_apply, dim3((k + 31) / 32, kDenseSplit), dim3(kDenseWaves * 64), 0, ctx->stream, C, Win, k, Wout);
             SRX_HIP(ctx, hipGetLastError());
             return SRX_OK;
         };
@@ -3022,7 +3209,7 @@ static int32_t run_pca(srx_ctx* ctx, const RowMajor* parts, int n_parts, const T
             SRX_HIP(ctx, hipMemsetAsync(v_lock, 0, (kl + L) * 8, ctx->stream));
             return SRX_OK;
         };
-        auto apply = [&](const double* Win, double* Wout) -> int32_t {
+        auto apply = [&](const double* Win, double* Wout, bool) -> int32_t {
             hipLaunchKernelGGL((k_make_panel<PT>), dim3(1), dim3(1024), 0, ctx->stream, Win, w.d, w.mu,
                                (const double*)nullptr, k, o.center, P, cvec);
             SRX_HIP(ctx, hipGetLastError());
