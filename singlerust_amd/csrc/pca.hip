@@ -1477,35 +1477,35 @@ __global__ void k_gram2_reduce(const double* __restrict__ part, int n_blocks, do
 // order while it loads the matrix: no reduction kernel between the two, and half the arithmetic of k_gram2_part, which forms
 // both products whichever is wanted.
 constexpr int kGram1Blocks = 16;
+// On the f64 matrix cores: wave w of a workgroup owns the 16 x 16 output tile (w / 4, w % 4); both operands come straight
+// from global memory in fragment order (lane l: row kk + (l >> 4), column 16 t + (l & 15) — 128 contiguous bytes per
+// 16 lanes), eight K-steps of loads in flight.  (The LDS-staged scalar version was LDS-read bound: 24 us a launch.)
 __global__ __launch_bounds__(1024) void k_gram1_part(const double* __restrict__ A, const double* __restrict__ B, int k,
                                                      double* __restrict__ part /* [blocks][64*64] */) {
-    constexpr int R = 32;
-    __shared__ double sa[R][L], sb[R][L];
-    const bool same = A == B;
-    double h[4] = {0, 0, 0, 0};
-    const int b = threadIdx.x & (L - 1), a0 = threadIdx.x / L;    // entries (a0 + 16u, b), u < 4
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int ti = wv >> 2, tj = wv & 3;
     const int rows_per = (k + gridDim.x - 1) / gridDim.x;
     const int jb0 = blockIdx.x * rows_per;
     const int jb1 = jb0 + rows_per < k ? jb0 + rows_per : k;
-    for (int j0 = jb0; j0 < jb1; j0 += R) {
-        for (int e = threadIdx.x; e < R * L; e += 1024) {
-            const int j = j0 + e / L;
-            const double bv = j < jb1 ? B[(size_t)j * L + (e % L)] : 0.0;
-            sb[e / L][e % L] = bv;
-            sa[e / L][e % L] = same ? bv : (j < jb1 ? A[(size_t)j * L + (e % L)] : 0.0);
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int r = 0; r < R; ++r) {
-            const double bv = sb[r][b];
+    dvec4 acc = dvec4{0.0, 0.0, 0.0, 0.0};
+    constexpr int kU = 8;
+    for (int j0 = jb0; j0 < jb1; j0 += 4 * kU) {
+        double av[kU], bv[kU];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) h[u] += sa[r][a0 + 16 * u] * bv;
+        for (int u = 0; u < kU; ++u) {
+            const int r = j0 + 4 * u + lk;
+            const bool ok = r < jb1;
+            av[u] = ok ? A[(size_t)r * L + 16 * ti + li] : 0.0;
+            bv[u] = ok ? B[(size_t)r * L + 16 * tj + li] : 0.0;
         }
-        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kU; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
     }
+    // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
     double* out = part + (size_t)blockIdx.x * L * L;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) out[(a0 + 16 * u) * L + b] = h[u];
+    for (int v = 0; v < 4; ++v) out[(16 * ti + lk + 4 * v) * L + 16 * tj + li] = acc[v];
 }
 
 // The tail of a Rayleigh–Ritz step in one pass over the rows: A1 = Wp U (= C W U), A2 = W U (the Ritz vectors), and per
@@ -1701,6 +1701,12 @@ __global__ __launch_bounds__(1024) void k_chol_factor(const double* __restrict__
 // registers — eight dependent steps of (v_readlane, rsqrt, multiply-subtract), no LDS round trip and no barrier — then all
 // threads subtract the panel's rank-8 update from the trailing rows: 16 barriers for l = 64 instead of 64 (the CholeskyQR
 // runs five times per solve).  Same outputs and status as k_chol_factor(shifted = 0).
+// 1 / sqrt(x), normal positive x: the hardware seed (2^-24, bench_micro/rsq_precision.hip) and one third-order correction
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-x * y, y, 1.0);
+    return __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
+}
 constexpr int kCholPanel = 8;
 __global__ __launch_bounds__(1024) void k_chol_factor_panels(const double* __restrict__ G, int n_part, int n, double* __restrict__ Rout,
                                                              double* __restrict__ dinv, int* __restrict__ status) {
@@ -1735,7 +1741,7 @@ __global__ __launch_bounds__(1024) void k_chol_factor_panels(const double* __res
                 if (j < j1) {                                   // (uniform)
                     const double d = readlane_v(a[jj], j);
                     if (!(d > 0.0) && c == 0) s_bad = 1;
-                    const double inv = rsqrt(d);
+                    const double inv = d > 1e-290 ? fast_rsqrt(d) : rsqrt(d);      // (the library's: ~10 dependent operations)
                     const double rjc = (c >= j && c < n) ? a[jj] * inv : 0.0;
                     a[jj] = rjc;                                // row j of R (zero left of the diagonal and right of n)
                     if (c == j) dinv[j] = inv;
@@ -1794,7 +1800,7 @@ __global__ __launch_bounds__(64) void k_trsm_rows(const double* __restrict__ Wp,
     for (int j = 0; j < L; ++j) w[j] = src[j];
 #pragma unroll
     for (int j = 0; j < L; ++j) {
-        double acc0 = w[j], acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+        double acc0 = w[j], acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;      // (eight chains instead of four: 32 -> 56 us, the row spills)
 #pragma unroll
         for (int i = 0; i + 3 < j; i += 4) {
             acc0 -= w[i] * Rt[j][i];
