@@ -774,7 +774,7 @@ __global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
     const int64_t* __restrict__ rm_ptr, const GramPk<VT>* __restrict__ rm, const uint32_t* __restrict__ perm /* nullable */,
     uint64_t n_rows, int k, const PT* __restrict__ P /* k x 64 */, const PT* __restrict__ cvec /* 64 */,
     int n_cols /* panel columns wanted */, double* __restrict__ scores /* n_rows x ld f64 (nullable) */,
-    PT* __restrict__ Y /* n_rows x 64 (nullable) */, int ld) {
+    PT* __restrict__ Y /* n_rows x 64 (nullable) */, int ld, int ldp /* elements between two genes of the slice in LDS */) {
     constexpr int C = 4 * Q;
     extern __shared__ double lds_raw[];
     PT* panel = reinterpret_cast<PT*>(lds_raw);                 // k x C
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
         const int j = e / Q, cq = e % Q;
         Vec4<PT> v;
         v.load(P + (size_t)j * L + slice * C + cq * 4);
-        v.store(panel + (size_t)j * C + cq * 4);
+        v.store(panel + (size_t)j * ldp + cq * 4);
     }
     __syncthreads();
     const int ql = threadIdx.x % Q;                             // lane within the row's lane group
@@ -846,7 +846,7 @@ __global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
                 PT v = (PT)quad_bcast_v<Q>(cur.r[s_ & 3].v, s_ >> 2);
                 if (st + s_ >= n) v = PT(0);                    // past the row's end (j is then a valid column of a later row)
                 Vec4<PT> pv;
-                pv.load(panel_q + (size_t)j * C);
+                pv.load(panel_q + (size_t)j * ldp);
                 a0 += v * pv[0];
                 a1 += v * pv[1];
                 a2 += v * pv[2];
@@ -2294,7 +2294,13 @@ static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words,
     SRX_TRY(scratch(ctx, "pca_cnt256", (n256 ? n256 : 1) * sizeof(int64_t), (void**)&cnt256));
     SRX_TRY(scratch(ctx, "pca_rm_ptr", (N + 1) * sizeof(int64_t), (void**)&rm.ptr));
     SRX_TRY(scratch(ctx, "pca_t256_ptr", (n256 + 1) * sizeof(int64_t), (void**)&t256.tptr));
-    const double s_i = m->d_idx16 ? 2.0 : 4.0;          // bytes per column index streamed by the two passes
+    // (A single-pass form — count, decoupled look-back over groups of 8 rows, fill from the indices still in L2; the output
+    //  size known beforehand from the cached per-gene counts — was built and measured in round 3: 3.0 ms against 1.73 for
+    //  count + scan + fill.  The groups have to stay small for the second walk to hit L2 (16 KB of L2 per resident
+    //  workgroup), and 162 500 groups make the prefix chain the bound: 64 groups per ~1.5 us hop.  It also needs every wave
+    //  of the grid resident, which the occupancy query over-promised at 8 workgroups per CU.  Not kept.)
+    const double s_i = m->d_idx16 ? 2.0 : 4.0;          // bytes per column index streamed by the passes
+    const size_t pb = is_f32(m) ? sizeof(GramPk<float>) : sizeof(GramPk<double>);
     // algorithmic bytes: the column indices of the whole matrix once per pass (count, fill) + row pointers in, row pointers
     // out; the KEPT values read and the compacted entries written are added below, once their number is known
     ProfScope ps(ctx, SRX_K_COMPACT, (double)m->nnz * s_i * 2.0 + (double)(N + 1) * 8.0 * 2.0);
@@ -2320,7 +2326,6 @@ static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words,
         SRX_TRY(scan_exclusive(ctx, cnt256, n256, t256.tptr, nullptr));
         SRX_TRY(alloc_tiled(m, N, (uint64_t)total, k, KT, t256));
     }
-    const size_t pb = is_f32(m) ? sizeof(GramPk<float>) : sizeof(GramPk<double>);
     SRX_TRY(scratch(ctx, "pca_rm_pk", ((size_t)total + 64) * pb, &rm.pk));
     // the 64 entries behind the last row are READ by the forward kernel (a row's last chunk runs past its end: value masked
     // to 0, column used as is): they must name a real column, or 0 x panel[garbage] is NaN
@@ -2417,7 +2422,12 @@ static int32_t launch_fwd_rows(srx_ctx* ctx, const RowMajor& r, const PT* P, con
         constexpr int Q = decltype(qtag)::value;
         constexpr int C = 4 * Q;
         const int n_slices = (n_cols + C - 1) / C;
-        const size_t lds = (size_t)r.k * C * sizeof(PT);
+        // (a gene's C = 16 f32 columns are 64 bytes, so every 16-byte read of a wave's 16 cells starts in bank 0 or 16: half of
+        //  the LDS pipe's time goes to bank conflicts, profiles/r03_pmc_spmm.md.  A padded stride of 80 bytes — eight different
+        //  bank offsets, k <= 2047 — was measured: 0.746 against 0.745 ms.  The pipe is 51 % busy either way; the kernel waits
+        //  on its dependent DPP -> address -> LDS -> FMA chains at four waves per SIMD, not on LDS bandwidth.)
+        const int ldp = C;
+        const size_t lds = (size_t)r.k * ldp * sizeof(PT);
         const uint64_t groups = kFwdRowsThreads / Q;
         uint64_t n_wg = (r.n_rows + groups - 1) / groups;
         const uint64_t cap = std::max<uint64_t>(1, (uint64_t)ctx->n_cus / n_slices);      // one workgroup per CU
@@ -2428,7 +2438,7 @@ static int32_t launch_fwd_rows(srx_ctx* ctx, const RowMajor& r, const PT* P, con
                                               (double)r.k * L * sizeof(PT) + (r.perm ? (double)r.n_rows * 4.0 : 0.0));
         SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_spmm_rows<VT, PT, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((k_spmm_rows<VT, PT, Q>), dim3((unsigned)(n_wg * n_slices)), dim3(kFwdRowsThreads), lds, ctx->stream, r.ptr,
-                           (const GramPk<VT>*)r.pk, (const uint32_t*)r.perm, r.n_rows, r.k, P, cvec, n_cols, scores, Y, ld);
+                           (const GramPk<VT>*)r.pk, (const uint32_t*)r.perm, r.n_rows, r.k, P, cvec, n_cols, scores, Y, ld, ldp);
         SRX_HIP(ctx, hipGetLastError());
         return SRX_OK;
     };
