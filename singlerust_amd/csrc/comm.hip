@@ -75,6 +75,16 @@ int32_t allreduce_f64(srx_ctx* ctx, double* d_buf, size_t count) {
     return SRX_OK;
 }
 
+bool comm_is_rccl(const srx_ctx* ctx) { return ctx->comm != nullptr && !ctx->host_allreduce; }
+
+int32_t allreduce_f64_on(srx_ctx* ctx, double* d_buf, size_t count, hipStream_t stream) {
+    if (count == 0) return SRX_OK;
+    if (!comm_is_rccl(ctx)) return fail(ctx, SRX_E_ARG, "allreduce_f64_on needs an RCCL communicator");
+    rcclResult r = g_rccl.AllReduce(d_buf, d_buf, count, rcclFloat64, rcclSum, ctx->comm, stream);
+    if (r != 0) return fail(ctx, SRX_E_RCCL, "ncclAllReduce(f64, %zu) failed: %s", count, rccl_err(r));
+    return SRX_OK;
+}
+
 }  // namespace srx
 
 using namespace srx;

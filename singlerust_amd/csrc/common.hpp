@@ -72,6 +72,8 @@ struct srx_ctx {
     hipStream_t stream = nullptr;
     // side stream of the pipeline: the in-place write-back of the normalised values runs beside the Gram kernel
     hipStream_t side_stream = nullptr;
+    hipStream_t comm_stream = nullptr;       // collectives issued beside the compute stream (launch_gram); events for fork / join
+    hipEvent_t comm_fork = nullptr, comm_join = nullptr;
     hipEvent_t side_fork = nullptr, side_join = nullptr;
     bool side_busy = false;
     struct srx_mat* wb_after_gram = nullptr;      // pipeline: matrix whose write-back run_pca queues behind the Gram kernel
@@ -242,6 +244,10 @@ struct Range {
 // ---- cross-rank sum (RCCL) --------------------------------------------------------------------
 // In-place f64 sum over all ranks on ctx->stream; no-op for a single rank.
 int32_t allreduce_f64(srx_ctx* ctx, double* d_buf, size_t count);
+// the same sum on another stream of the context (RCCL communicator only; comm.hip): the Gram triangle's first half is summed
+// over the ranks while the second half is still being computed
+int32_t allreduce_f64_on(srx_ctx* ctx, double* d_buf, size_t count, hipStream_t stream);
+bool comm_is_rccl(const srx_ctx* ctx);
 
 // ---- internal entry points shared between translation units -----------------------------------
 // The fused normalise + log1p transform applied ON THE FLY by a pass that reads raw values: y = ln_1p(f64(v) * scale_r),

@@ -148,6 +148,7 @@ ProfScope::~ProfScope() {
 static int32_t prof_drain(srx_ctx* ctx) {
     SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->side_stream) SRX_HIP(ctx, hipStreamSynchronize(ctx->side_stream));
+    if (ctx->comm_stream) SRX_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
     for (int c = 0; c < SRX_K_COUNT_; ++c) {
         for (auto& pr : ctx->prof[c].pending) {
             float ms = 0.f;
@@ -588,6 +589,9 @@ void srx_ctx_destroy(srx_ctx* ctx) {
     if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
     if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
+    if (ctx->comm_fork) (void)hipEventDestroy(ctx->comm_fork);
+    if (ctx->comm_join) (void)hipEventDestroy(ctx->comm_join);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

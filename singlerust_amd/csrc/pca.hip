@@ -1151,14 +1151,14 @@ template <typename VT>
 __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     const int64_t* __restrict__ rm_ptr, const GramPk<VT>* __restrict__ rm, const uint32_t* __restrict__ boff,
     const int64_t* __restrict__ rec_base, const GramRec<VT>* __restrict__ recs, uint64_t n_rblk, uint32_t rblk, int k,
-    int sr_shift, int n_wg, int n_stripes, uint32_t n_chunk,
+    int sr_shift, int n_wg, int n_stripes, uint32_t n_chunk, int w0 /* first owner of this launch */, int n_w /* owners in it */,
     double* __restrict__ Gp /* packed upper triangle, ACCUMULATED into (global f64 atomics) */) {
     using Entry = GramPk<VT>;
     using Rec = GramRec<VT>;
     // suffix loads in flight per batch: 16-byte f64 entries take twice the registers (8 of them spilled)
     constexpr int kUnroll = sizeof(VT) == 8 ? kGramUnroll / 2 : kGramUnroll;
     extern __shared__ double acc[];
-    const int w = blockIdx.x % n_wg, z = blockIdx.x / n_wg;
+    const int w = w0 + blockIdx.x % n_w, z = blockIdx.x / n_w;
     const int SR = 1 << sr_shift;
     const int a0 = w * SR, b0 = (n_stripes - 1 - w) * SR;
     const int WA = k - a0, WB = k - b0 > 0 ? k - b0 : 0;
@@ -2494,8 +2494,11 @@ static int32_t launch_t(srx_ctx* ctx, const Tiled& c, const YT* Y, double* T /* 
 
 // G += A^T A of the row-major compacted matrix, into the packed upper triangle `Gp` (k (k + 1) / 2 doubles; the
 // caller zeroes it for a fresh sum): owner buckets, then the stripe kernel.
+// `reduce` (nullable): sum the triangle over the ranks HERE, the first half of the owners' rows on the communication stream
+// while the second half is still being computed (*reduce is set when that was done; otherwise the caller's all-reduce follows).
 template <typename VT>
-static int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp) {
+static int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce = nullptr) {
+    if (reduce) *reduce = false;
     if (rm.n_rows == 0) return SRX_OK;
     GramPlan g;
     SRX_TRY(gram_plan(ctx, rm.k, rm.n_rows, g));
@@ -2530,9 +2533,46 @@ static int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp) {
     ProfScope ps(ctx, SRX_K_GRAM, (double)rm.nnz * sizeof(GramPk<VT>) + (double)(rm.n_rows + 1) * 8.0 + (double)rm.k * (rm.k + 1) / 2 * 8.0,
                  nullptr, (double)n_recs * sizeof(GramRec<VT>) + (double)g.n_rblk * (g.n_wg + 1) * 4.0);
     SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_stripes<VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
-    hipLaunchKernelGGL((k_gram_stripes<VT>), dim3((unsigned)(g.n_wg * g.n_z)), dim3(kGramWaves * kWave), g.lds_bytes, ctx->stream,
-                       rm.ptr, (const GramPk<VT>*)rm.pk, boff, rec_base, recs, g.n_rblk, g.rblk, rm.k, g.sr_shift, g.n_wg,
-                       g.n_stripes, g.n_chunk, Gp);
+    auto launch = [&](int w0, int n_w) {
+        hipLaunchKernelGGL((k_gram_stripes<VT>), dim3((unsigned)(n_w * g.n_z)), dim3(kGramWaves * kWave), g.lds_bytes, ctx->stream,
+                           rm.ptr, (const GramPk<VT>*)rm.pk, boff, rec_base, recs, g.n_rblk, g.rblk, rm.k, g.sr_shift, g.n_wg,
+                           g.n_stripes, g.n_chunk, w0, n_w, Gp);
+    };
+    // Sharded rows: owner w holds the stripes w and n_stripes - 1 - w, so the owners [0, h) hold the rows [0, h SR) and
+    // [k - h SR, k) of the triangle — two contiguous ranges of the packed array — and the others the rows between.  Two
+    // launches; the first one's ranges go round the ranks (RCCL, communication stream) under the second launch, the middle
+    // range after it: half of the 16 MB exchange is hidden.  (One launch on a single rank: the owners of a chunk share what
+    // they pull into L2, and halving them costs more than nothing.)
+    static const bool force_split = getenv("SRX_GRAM_OVERLAP") != nullptr;      // test switch: the split with a 1-rank communicator
+    const int h = g.n_wg / 2;
+    if (reduce && comm_is_rccl(ctx) && (ctx->n_ranks > 1 || force_split) && h >= 1 && g.n_wg - h >= 1) {
+        if (!ctx->comm_stream) {
+            SRX_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+            SRX_HIP(ctx, hipEventCreateWithFlags(&ctx->comm_fork, hipEventDisableTiming));
+            SRX_HIP(ctx, hipEventCreateWithFlags(&ctx->comm_join, hipEventDisableTiming));
+        }
+        const int SR = 1 << g.sr_shift, k = rm.k;
+        const int r_lo = std::min(k, h * SR), r_hi = std::min(k, std::max(r_lo, (g.n_stripes - h) * SR));      // rows [0, r_lo) + [r_hi, k): the first launch
+        auto off = [&](int row) { return (size_t)row * (size_t)k - (size_t)row * (size_t)(row - 1) / 2; };      // packed offset of (row, row)
+        launch(0, h);
+        SRX_HIP(ctx, hipGetLastError());
+        SRX_HIP(ctx, hipEventRecord(ctx->comm_fork, ctx->stream));
+        SRX_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->comm_fork, 0));
+        SRX_TRY(allreduce_f64_on(ctx, Gp, off(r_lo), ctx->comm_stream));
+        SRX_TRY(allreduce_f64_on(ctx, Gp + off(r_hi), off(k) - off(r_hi), ctx->comm_stream));
+        launch(h, g.n_wg - h);
+        SRX_HIP(ctx, hipGetLastError());
+        // the middle rows: on the communication stream too (one stream for all of the communicator's collectives in
+        // flight), after the second launch
+        SRX_HIP(ctx, hipEventRecord(ctx->comm_fork, ctx->stream));
+        SRX_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->comm_fork, 0));
+        SRX_TRY(allreduce_f64_on(ctx, Gp + off(r_lo), off(r_hi) - off(r_lo), ctx->comm_stream));
+        SRX_HIP(ctx, hipEventRecord(ctx->comm_join, ctx->comm_stream));
+        SRX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->comm_join, 0));
+        *reduce = true;
+        return SRX_OK;
+    }
+    launch(0, g.n_wg);
     SRX_HIP(ctx, hipGetLastError());
     return SRX_OK;
 }
@@ -3177,9 +3217,12 @@ static int32_t run_pca(srx_ctx* ctx, const RowMajor* parts, int n_parts, const T
             Range r_("srx:gram");
             SRX_TRY(scratch(ctx, "pca_gpacked", n_packed * sizeof(double), (void**)&Pk));
             SRX_HIP(ctx, hipMemsetAsync(Pk, 0, n_packed * sizeof(double), ctx->stream));
-            SRX_TRY(launch_gram<VT>(ctx, *rmp, Pk));
+            bool reduced = false;
+            SRX_TRY(launch_gram<VT>(ctx, *rmp, Pk, &reduced));        // (sharded rows: the exchange overlaps the second half)
+            if (!reduced) SRX_TRY(allreduce_f64(ctx, Pk, n_packed));
+        } else {
+            SRX_TRY(allreduce_f64(ctx, Pk, n_packed));            // the one exchange of this solver: the packed upper triangle
         }
-        SRX_TRY(allreduce_f64(ctx, Pk, n_packed));                // the one exchange of this solver: the packed upper triangle
         if (ctx->wb_after_gram) {
             srx_mat* wm = ctx->wb_after_gram;
             ctx->wb_after_gram = nullptr;

@@ -41,3 +41,16 @@ def test_single_rank_communicator_runs_the_collectives(solver):
     _ffi.check(lib.srx_comm_destroy(comm.handle), comm.handle)
     comm.close()
     plain.close()
+
+
+def test_gram_exchange_overlapped_with_the_second_half():
+    """The sharded-run arrangement of the Gram solver (two launches of the stripe kernel, the first half's rows of the packed
+    triangle all-reduced on the communication stream under the second launch) on a 1-rank RCCL communicator: SRX_GRAM_OVERLAP=1
+    forces the split a multi-rank context takes by itself."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, os.path.join(here, "comm_overlap_worker.py")], env=dict(os.environ, SRX_GRAM_OVERLAP="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0 and b"overlap ok" in p.stdout, p.stderr.decode()[-3000:]
