@@ -12,7 +12,9 @@
 //   memory::processing::log1p_transform_inplace       src/memory/processing/mod.rs:324-326 -> transform/mod.rs:36-57
 //   memory::processing::dim_red::select_features      src/memory/processing/dim_red/mod.rs:123-156 (HighlyVariable arm)
 //   memory::processing::dim_red::pca_inplace          src/memory/processing/dim_red/mod.rs:24-94
-//   memory::processing::filter_cells / filter_genes   src/memory/processing/mod.rs:86-146,245-299
+//   memory::processing::filter_cells[_inplace] / filter_genes[_inplace]   src/memory/processing/mod.rs:86-146,245-299
+//   memory::statistics::qc_vars_inplace               src/memory/statistics/mod.rs:74-103
+//   backed::statistics::{compute_number, compute_sum} src/backed/statistics/mod.rs:5-45
 mod ffi;                                   // rust/srx_sys.rs
 use ffi::*;
 
@@ -294,10 +296,11 @@ pub fn pipeline(ctx: &Ctx, adata: &mut IMAnnData, target_sum: f64, n_hvg: usize,
 // The reference's FREE FUNCTIONS with their exact signatures (no context argument): what `src/memory/statistics/mod.rs`,
 // `src/memory/processing/mod.rs` and `src/memory/processing/dim_red/mod.rs` export today, bodies replaced.  A caller of
 // SingleRust recompiles against the `hip` feature and changes nothing.  The context lives in a `thread_local!` (one per
-// thread, as include/srx.h requires); every call uploads X under the reference's own guard, works on the handle and — for
-// the in-place operations — writes the result back into the IMAnnData, INCLUDING the variant change to
-// `DynCsrMatrix::F64` that `scale_row_csr` performs (scale/mod.rs:74-83).  Callers that run the whole path should use
-// `pipeline()` above (one upload, nothing copied back but the scores).
+// thread, as include/srx.h requires); X is uploaded under the reference's own guard ONCE per matrix (resident-handle cache
+// below), every call works on the handle and — for the in-place operations — the result goes back into the IMAnnData,
+// INCLUDING the variant change to `DynCsrMatrix::F64` that `scale_row_csr` performs (scale/mod.rs:74-83): at once by
+// default, on `flush` under `set_lazy_writeback(true)`.  `pipeline()` above is the one-call form (nothing copied back but
+// the scores).
 // ================================================================================================================
 use std::cell::OnceCell;
 use std::ops::DerefMut;
@@ -322,23 +325,126 @@ fn with_ctx<R>(f: impl FnOnce(&Ctx) -> Result<R>) -> Result<R> {
     })
 }
 
+// ---- resident-handle cache ------------------------------------------------------------------------------------------
+// The free functions below keep ONE uploaded X per thread, keyed on the identity of the IMAnnData's X element: the canonical
+// sequence normalize_total_inplace -> log1p_transform_inplace -> pca_inplace uploads once.  An in-place
+// operation runs on the device and then either copies the values back at once (the default: the IMAnnData is current after
+// every call, exactly as with the reference) or, under `set_lazy_writeback(true)`, only marks the host copy stale — `flush`
+// (called by every function here that hands X to host code, and by the caller before touching `adata.x()` directly) brings
+// it back.  `invalidate()` drops the handle: for callers that modify X behind the shim's back.
+use std::cell::{Cell, RefCell};
+
+struct Resident {
+    key: (usize, usize, usize, usize),          // (identity of the X element, n_obs, n_vars, nnz)
+    dev: DeviceX<'static>,                      // (the context is the thread's own, alive as long as the thread)
+    host_stale: bool,                           // the device holds newer values than the IMAnnData
+    keep_f32: bool,                             // how the pending write-back treats an F32 matrix (log1p keeps it F32)
+}
+thread_local! {
+    static RESIDENT: RefCell<Option<Resident>> = const { RefCell::new(None) };
+    static LAZY_WRITEBACK: Cell<bool> = const { Cell::new(false) };
+}
+pub fn set_lazy_writeback(on: bool) { LAZY_WRITEBACK.with(|c| c.set(on)) }
+pub fn invalidate() { RESIDENT.with(|r| *r.borrow_mut() = None) }
+
+/// Identity of the X element: the address of the slot's shared allocation (`IMArrayElement(Slot<ArrayData>)`, an
+/// `Arc<RwLock<..>>` — a deep clone has its own) together with the shape and the number of stored entries.
+fn x_key(adata: &IMAnnData) -> (usize, usize, usize, usize) {
+    let x = adata.x();
+    let nnz = match x.0.read_inner().deref() {
+        ArrayData::CsrMatrix(m) => m.nnz(),
+        ArrayData::CscMatrix(m) => m.nnz(),
+        _ => 0,
+    };
+    (x.0.as_ptr() as usize, adata.n_obs(), adata.n_vars(), nnz)
+}
+
+/// Runs `f` on the resident handle of `adata`, uploading X first when the cache holds another matrix (or nothing).
+fn with_resident<R>(adata: &IMAnnData, f: impl FnOnce(&mut DeviceX<'static>) -> Result<R>) -> Result<R> {
+    with_ctx(|c| {
+        let key = x_key(adata);
+        RESIDENT.with(|r| {
+            let mut slot = r.borrow_mut();
+            if slot.as_ref().map_or(true, |s| s.key != key) {
+                // (a stale host copy of ANOTHER matrix cannot be written back from here: lazy mode asks for flush() first)
+                let ctx: &'static Ctx = unsafe { &*(c as *const Ctx) };
+                *slot = Some(Resident { key, dev: DeviceX::upload(ctx, adata)?, host_stale: false, keep_f32: false });
+            }
+            f(&mut slot.as_mut().expect("resident").dev)
+        })
+    })
+}
+/// After an in-place operation on the resident handle: copy back now, or remember that the host copy is stale.
+fn after_inplace(adata: &mut IMAnnData, keep_f32: bool) -> Result<()> {
+    if LAZY_WRITEBACK.with(|c| c.get()) {
+        RESIDENT.with(|r| if let Some(s) = r.borrow_mut().as_mut() { s.host_stale = true; s.keep_f32 = keep_f32; });
+        return Ok(());
+    }
+    RESIDENT.with(|r| write_back(adata, &r.borrow().as_ref().expect("resident").dev, keep_f32))
+}
+/// Brings the IMAnnData up to date with the device (lazy write-back only; a no-op otherwise).
+pub fn flush(adata: &mut IMAnnData) -> Result<()> {
+    let pending = RESIDENT.with(|r| r.borrow().as_ref().map_or(false, |s| s.host_stale && s.key == x_key(adata)));
+    if !pending { return Ok(()); }
+    RESIDENT.with(|r| {
+        let mut slot = r.borrow_mut();
+        let s = slot.as_mut().expect("resident");
+        write_back(adata, &s.dev, s.keep_f32)?;
+        s.host_stale = false;
+        s.key = x_key(adata);                    // (the variant change keeps the element, its nnz and its shape)
+        Ok(())
+    })
+}
+/// The device-side result of a filter becomes the resident handle of the IMAnnData that holds the same subset.
+fn adopt(adata: &IMAnnData, dev: DeviceX<'static>) {
+    RESIDENT.with(|r| *r.borrow_mut() = Some(Resident { key: x_key(adata), dev, host_stale: false, keep_f32: false }));
+}
+
 pub mod statistics_free {
-    //! src/memory/statistics/mod.rs:10-46, signatures unchanged.
+    //! src/memory/statistics/mod.rs:10-103, signatures unchanged.
     use super::*;
+    use polars::prelude::{NamedFrom, Series};
     pub fn compute_number(adata: &IMAnnData, direction: Direction) -> anyhow::Result<Vec<u32>> {
-        with_ctx(|c| DeviceX::upload(c, adata)?.compute_number(direction))
+        with_resident(adata, |x| x.compute_number(direction))
     }
     pub fn compute_sum(adata: &IMAnnData, direction: Direction) -> anyhow::Result<Vec<f64>> {
-        with_ctx(|c| DeviceX::upload(c, adata)?.compute_sum(direction))
+        with_resident(adata, |x| x.compute_sum(direction))
     }
     pub fn compute_variance(adata: &IMAnnData, direction: Direction) -> anyhow::Result<Vec<f64>> {
-        with_ctx(|c| DeviceX::upload(c, adata)?.compute_variance(direction))
+        with_resident(adata, |x| x.compute_variance(direction))
     }
     pub fn compute_min_max(adata: &IMAnnData, direction: Direction) -> anyhow::Result<(Vec<f64>, Vec<f64>)> {
-        with_ctx(|c| DeviceX::upload(c, adata)?.compute_min_max(direction))
+        with_resident(adata, |x| x.compute_min_max(direction))
     }
     pub fn compute_std_dev(adata: &IMAnnData, direction: Direction) -> anyhow::Result<Vec<f64>> {
-        with_ctx(|c| DeviceX::upload(c, adata)?.compute_std_dev(direction))
+        with_resident(adata, |x| x.compute_std_dev(direction))
+    }
+
+    /// src/memory/statistics/mod.rs:48-72: the reference's own container, filled from one row pass and one column pass.
+    pub fn compute_qc_variables(adata: &IMAnnData) -> anyhow::Result<crate::memory::statistics::StatisticsContainer> {
+        let (num_per_cell, num_per_gene, expr_per_gene, expr_per_cell, variance_per_gene, variance_per_cell, std_dev_per_cell,
+             std_dev_per_gene) = with_resident(adata, |x| x.compute_qc_variables())?;
+        Ok(crate::memory::statistics::StatisticsContainer {
+            num_per_cell, num_per_gene, expr_per_gene, expr_per_cell, variance_per_gene, variance_per_cell, std_dev_per_cell,
+            std_dev_per_gene,
+        })
+    }
+    /// src/memory/statistics/mod.rs:74-103, unchanged but for where the eight vectors come from.
+    pub fn qc_vars_inplace(adata: &IMAnnData) -> anyhow::Result<()> {
+        let data = compute_qc_variables(adata)?;
+        let mut obs_df = adata.obs().get_data();
+        let mut var_df = adata.var().get_data();
+        obs_df.with_column(Series::from_vec("num_genes_per_cell", data.num_per_cell))?;
+        obs_df.with_column(Series::from_vec("sum_expr_per_cell", data.expr_per_cell))?;
+        obs_df.with_column(Series::from_vec("var_expr_per_cell", data.variance_per_cell))?;
+        obs_df.with_column(Series::from_vec("std_dev_per_cell", data.std_dev_per_cell))?;
+        var_df.with_column(Series::from_vec("num_cells_per_gene", data.num_per_gene))?;
+        var_df.with_column(Series::from_vec("sum_expr_per_gene", data.expr_per_gene))?;
+        var_df.with_column(Series::from_vec("var_expr_per_gene", data.variance_per_gene))?;
+        var_df.with_column(Series::from_vec("std_dev_per_gene", data.std_dev_per_gene))?;
+        adata.obs().set_data(obs_df)?;
+        adata.var().set_data(var_df)?;
+        Ok(())
     }
 }
 
@@ -391,28 +497,69 @@ pub mod processing_free {
     //! src/memory/processing/mod.rs:303-332, signatures unchanged.
     use super::*;
     pub fn normalize_total_inplace(adata: &mut IMAnnData, target_sum: f64, direction: Direction) -> anyhow::Result<()> {
-        with_ctx(|c| {
-            let mut x = DeviceX::upload(c, adata)?;
-            x.normalize_total_inplace(target_sum, direction)?;
-            write_back(adata, &x, false)                    // X becomes DynCsrMatrix::F64 whatever it was
-        })
+        with_resident(adata, |x| x.normalize_total_inplace(target_sum, direction))?;
+        after_inplace(adata, false)                         // X becomes DynCsrMatrix::F64 whatever it was
     }
     pub fn normalize_total(adata: &IMAnnData, target_sum: f64, direction: Direction) -> anyhow::Result<IMAnnData> {
         let mut new_data = adata.deep_clone();              // :319, as in the reference
         normalize_total_inplace(&mut new_data, target_sum, direction)?;
+        flush(&mut new_data)?;                              // a returned copy is always current
         Ok(new_data)
     }
     pub fn log1p_transform_inplace(adata: &mut IMAnnData) -> anyhow::Result<()> {
-        with_ctx(|c| {
-            let mut x = DeviceX::upload(c, adata)?;
-            x.log1p_transform_inplace()?;
-            write_back(adata, &x, true)                     // F32 stays F32, every other dtype becomes F64
-        })
+        with_resident(adata, |x| x.log1p_transform_inplace())?;
+        after_inplace(adata, true)                          // F32 stays F32, every other dtype becomes F64
     }
     pub fn log1p_transform(adata: &IMAnnData) -> anyhow::Result<IMAnnData> {
         let mut new_data = adata.deep_clone();
         log1p_transform_inplace(&mut new_data)?;
+        flush(&mut new_data)?;
         Ok(new_data)
+    }
+
+    // ---- src/memory/processing/mod.rs:86-146,245-299, signatures unchanged -------------------------------------------
+    // The keep-mask (statistics, interpolated quantiles, limits) and the subset of X come from the device; obs / var and
+    // the host copy of X are subset by the reference's own `subset[_inplace]`, and the device-side subset becomes the
+    // resident handle of the result, so that the calls which follow (normalise, log1p, PCA) do not upload again.
+    use anndata::data::SelectInfoElem;
+    use ndarray::Array1;
+    pub fn filter_cells_inplace(adata: &mut IMAnnData, lower_lim: FlexValue, upper_lim: FlexValue) -> anyhow::Result<()> {
+        let (filtered, keep) = with_resident(adata, |x| x.filter_cells(&lower_lim, &upper_lim))?;
+        flush(adata)?;                                      // anndata-memory subsets the HOST copy: it must be current
+        let mask = Array1::from_vec(keep);
+        let selection = crate::shared::processing::get_select_info_obs(Some(mask.view()))?;
+        let selection_refs: Vec<&SelectInfoElem> = selection.iter().collect();
+        adata.subset_inplace(selection_refs.as_slice())?;
+        adopt(adata, filtered);
+        Ok(())
+    }
+    pub fn filter_cells(adata: &IMAnnData, lower_lim: FlexValue, upper_lim: FlexValue) -> anyhow::Result<IMAnnData> {
+        let (filtered, keep) = with_resident(adata, |x| x.filter_cells(&lower_lim, &upper_lim))?;
+        let mask = Array1::from_vec(keep);
+        let selection = crate::shared::processing::get_select_info_obs(Some(mask.view()))?;
+        let selection_refs: Vec<&SelectInfoElem> = selection.iter().collect();
+        let out = adata.subset(selection_refs.as_slice())?;
+        adopt(&out, filtered);
+        Ok(out)
+    }
+    pub fn filter_genes_inplace(adata: &mut IMAnnData, lower_lim: FlexValue, upper_lim: FlexValue) -> anyhow::Result<()> {
+        let (filtered, keep) = with_resident(adata, |x| x.filter_genes(&lower_lim, &upper_lim))?;
+        flush(adata)?;
+        let mask = Array1::from_vec(keep);
+        let selection = crate::shared::processing::get_select_info_vars(Some(mask.view()))?;
+        let selection_refs: Vec<&SelectInfoElem> = selection.iter().collect();
+        adata.subset_inplace(selection_refs.as_slice())?;
+        adopt(adata, filtered);
+        Ok(())
+    }
+    pub fn filter_genes(adata: &IMAnnData, lower_lim: FlexValue, upper_lim: FlexValue) -> anyhow::Result<IMAnnData> {
+        let (filtered, keep) = with_resident(adata, |x| x.filter_genes(&lower_lim, &upper_lim))?;
+        let mask = Array1::from_vec(keep);
+        let selection = crate::shared::processing::get_select_info_vars(Some(mask.view()))?;
+        let selection_refs: Vec<&SelectInfoElem> = selection.iter().collect();
+        let out = adata.subset(selection_refs.as_slice())?;
+        adopt(&out, filtered);
+        Ok(out)
     }
 
     pub mod dim_red {
@@ -425,8 +572,7 @@ pub mod processing_free {
                                                  feature_selection: &FeatureSelection, _svd_mode: S) -> anyhow::Result<()> {
             // HighlyVariableCol / Randomized / VarianceThreshold: the reference's own host code makes the index list
             // (dim_red/mod.rs:125-134,141-153); HighlyVariable(n) and None go to the device
-            let (scores, evr, selected, n_pc) = with_ctx(|c| {
-                let x = DeviceX::upload(c, anndata)?;
+            let (scores, evr, selected, n_pc) = with_resident(anndata, |x| {
                 match feature_selection {
                     FeatureSelection::HighlyVariable(_) | FeatureSelection::None => x.pca(n_components, center, scale, n_threads, feature_selection),
                     other => {
@@ -459,5 +605,72 @@ pub mod processing_free {
             }
             Ok(())
         }
+    }
+}
+
+pub mod backed_statistics_free {
+    //! src/backed/statistics/mod.rs:5-45, signatures unchanged.  `ComputationMode::Chunked(size)` walks anndata's row-chunk
+    //! iterator and hands every chunk to the session as a row tile (the device keeps the per-gene accumulators and writes
+    //! the per-cell results at the tile's GLOBAL row offset — the reference's chunk loop indexes them by the chunk-local
+    //! row, csr.rs:57-62,126-131); `Whole` reads X once, as the reference does.
+    use super::*;
+    use anndata::{AnnData, AnnDataOp, ArrayElemOp, Backend};
+    use crate::shared::ComputationMode;
+
+    struct Session<'c> { ctx: &'c Ctx, h: *mut SrxBacked }
+    impl Drop for Session<'_> { fn drop(&mut self) { unsafe { srx_backed_destroy(self.h) } } }
+
+    /// One sweep over the chunks: per-cell counts / sums land in `row_num` / `row_sum`, the per-gene ones stay in the session.
+    fn sweep<B: Backend>(c: &Ctx, adata: &AnnData<B>, size: usize, row_num: Option<&mut [u32]>, row_sum: Option<&mut [f64]>)
+                         -> Result<(Vec<u64>, Vec<f64>)> {
+        let n_vars = adata.n_vars();
+        let mut h = null_mut();
+        c.check(unsafe { srx_backed_create(c.0, n_vars as u64, SRX_STORE_AUTO, &mut h) })?;
+        let s = Session { ctx: c, h };
+        let (mut num_p, mut sum_p) = (row_num.map_or(null_mut(), |v| v.as_mut_ptr()), row_sum.map_or(null_mut(), |v| v.as_mut_ptr()));
+        for (chunk, start, end) in adata.x().iter::<ArrayData>(size) {
+            let d = match &chunk {
+                ArrayData::CsrMatrix(DynCsrMatrix::F64(m)) => csr_descriptor!(m, SRX_F64),
+                ArrayData::CsrMatrix(DynCsrMatrix::F32(m)) => csr_descriptor!(m, SRX_F32),
+                ArrayData::CsrMatrix(DynCsrMatrix::U32(m)) => csr_descriptor!(m, SRX_U32),
+                ArrayData::CsrMatrix(DynCsrMatrix::I32(m)) => csr_descriptor!(m, SRX_I32),
+                ArrayData::CsrMatrix(DynCsrMatrix::U16(m)) => csr_descriptor!(m, SRX_U16),
+                ArrayData::CsrMatrix(DynCsrMatrix::I16(m)) => csr_descriptor!(m, SRX_I16),
+                ArrayData::CsrMatrix(DynCsrMatrix::U8(m)) => csr_descriptor!(m, SRX_U8),
+                ArrayData::CsrMatrix(DynCsrMatrix::I8(m)) => csr_descriptor!(m, SRX_I8),
+                _ => bail!("X is not a CSR matrix"),
+            };
+            s.ctx.check(unsafe { srx_backed_stats_tile(s.h, &d, 0.0, 0, num_p, sum_p) })?;      // transform 0: the raw values
+            let rows = end - start;
+            if !num_p.is_null() { num_p = unsafe { num_p.add(rows) }; }
+            if !sum_p.is_null() { sum_p = unsafe { sum_p.add(rows) }; }
+        }
+        let (mut cnt, mut sum) = (vec![0u64; n_vars], vec![0f64; n_vars]);
+        let mut n_rows = 0u64;
+        s.ctx.check(unsafe { srx_backed_moments(s.h, cnt.as_mut_ptr(), sum.as_mut_ptr(), null_mut(), &mut n_rows) })?;
+        Ok((cnt, sum))
+    }
+
+    pub fn compute_number<B: Backend>(adata: AnnData<B>, direction: Direction, mode: ComputationMode) -> anyhow::Result<Vec<u32>> {
+        let size = match mode { ComputationMode::Chunked(size) => size, ComputationMode::Whole => adata.n_obs().max(1) };
+        with_ctx(|c| match direction {
+            Direction::Row => {
+                let mut v = vec![0u32; adata.n_obs()];
+                sweep(c, &adata, size, Some(&mut v), None)?;
+                Ok(v)
+            }
+            Direction::Column => Ok(sweep(c, &adata, size, None, None)?.0.into_iter().map(|n| n as u32).collect()),
+        })
+    }
+    pub fn compute_sum<B: Backend>(adata: AnnData<B>, direction: Direction, mode: ComputationMode) -> anyhow::Result<Vec<f64>> {
+        let size = match mode { ComputationMode::Chunked(size) => size, ComputationMode::Whole => adata.n_obs().max(1) };
+        with_ctx(|c| match direction {
+            Direction::Row => {
+                let mut v = vec![0f64; adata.n_obs()];
+                sweep(c, &adata, size, None, Some(&mut v))?;
+                Ok(v)
+            }
+            Direction::Column => Ok(sweep(c, &adata, size, None, None)?.1),
+        })
     }
 }

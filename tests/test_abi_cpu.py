@@ -162,7 +162,7 @@ def test_integration_excerpts_are_the_shim():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     shim = open(os.path.join(ROOT, "rust", "shim.rs")).read()
     blocks = re.findall(r"```rust\n// rust/shim\.rs[^\n]*\n(.*?)```", doc, flags=re.S)
-    assert len(blocks) >= 5
+    assert len(blocks) >= 7
     for b in blocks:
         assert b.rstrip("\n") in shim, b[:200]
     # and the free functions carry the reference's signatures (src/memory/processing/mod.rs:303-332, dim_red/mod.rs:24)
@@ -172,5 +172,15 @@ def test_integration_excerpts_are_the_shim():
                 "pub fn log1p_transform(adata: &IMAnnData) -> anyhow::Result<IMAnnData>",
                 "pub fn compute_number(adata: &IMAnnData, direction: Direction) -> anyhow::Result<Vec<u32>>",
                 "pub fn compute_variance(adata: &IMAnnData, direction: Direction) -> anyhow::Result<Vec<f64>>",
-                "pub fn pca_inplace<S: SVDImplementation>(anndata: &mut IMAnnData, n_components: Option<usize>, center: Option<bool>,"):
+                "pub fn pca_inplace<S: SVDImplementation>(anndata: &mut IMAnnData, n_components: Option<usize>, center: Option<bool>,",
+                # the (f) rows: src/memory/processing/mod.rs:86,120,245,273, src/memory/statistics/mod.rs:48,74,
+                # src/backed/statistics/mod.rs:5,26
+                "pub fn filter_cells_inplace(adata: &mut IMAnnData, lower_lim: FlexValue, upper_lim: FlexValue) -> anyhow::Result<()>",
+                "pub fn filter_cells(adata: &IMAnnData, lower_lim: FlexValue, upper_lim: FlexValue) -> anyhow::Result<IMAnnData>",
+                "pub fn filter_genes_inplace(adata: &mut IMAnnData, lower_lim: FlexValue, upper_lim: FlexValue) -> anyhow::Result<()>",
+                "pub fn filter_genes(adata: &IMAnnData, lower_lim: FlexValue, upper_lim: FlexValue) -> anyhow::Result<IMAnnData>",
+                "pub fn compute_qc_variables(adata: &IMAnnData) -> anyhow::Result<crate::memory::statistics::StatisticsContainer>",
+                "pub fn qc_vars_inplace(adata: &IMAnnData) -> anyhow::Result<()>",
+                "pub fn compute_number<B: Backend>(adata: AnnData<B>, direction: Direction, mode: ComputationMode) -> anyhow::Result<Vec<u32>>",
+                "pub fn compute_sum<B: Backend>(adata: AnnData<B>, direction: Direction, mode: ComputationMode) -> anyhow::Result<Vec<f64>>"):
         assert sig in shim, sig
