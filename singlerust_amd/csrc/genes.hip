@@ -58,6 +58,11 @@ __device__ __forceinline__ void seg_bounds(const int64_t* __restrict__ indptr, c
 // WB (with XF): the transformed value is also stored back in place, at the storage precision — every stored value belongs to
 // exactly one (gene tile, row) segment, i.e. to one lane of one workgroup, so this pass IS the in-place normalise + log1p of
 // the pipeline and nothing reads the raw matrix after it.
+// (Round 3, measured and not kept: for COUNT DATA a per-segment value table — each lane makes ONE logarithm per group of row
+//  segments, ln_1p(c * scale) for c = 1 .. 32, parked in the LDS the cached counts leave free; a value then costs an exactness
+//  test and one ds_read_b64 instead of the ~30-instruction logarithm.  Bit-identical results, 16x fewer logarithms, and
+//  3.64 ms against 3.18: the four dependent LDS reads of a chunk queue behind the other waves' atomics, and the arithmetic
+//  they replace was what hid that latency.)
 template <typename T, typename I, bool XF, bool COUNT, bool WB = false>
 __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     const int64_t* __restrict__ indptr, const int64_t* __restrict__ tp, const I* __restrict__ idx,
