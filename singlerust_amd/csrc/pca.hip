@@ -341,6 +341,96 @@ __global__ __launch_bounds__(256) void k_rowcount(const int64_t* __restrict__ in
     }
 }
 
+// Two-pass compaction, second form (round 3): the count pass also LEAVES A LIST of what it found — per kept entry one 32-bit
+// word (position in the row << 16 | compacted column) at kept[indptr[r] + rank], i.e. at the start of the row's own span of a
+// scratch array as long as the matrix — so that the fill pass never walks the column indices again: per row it reads its
+// ~72 words (one coalesced load), gathers the ~72 values and stores the entries.  Needs n_cols <= 65536 (16-bit positions and
+// columns) and the row-major layout alone (no 256-tiled view).
+template <typename I>
+__global__ __launch_bounds__(256) void k_rowcount_list(const int64_t* __restrict__ indptr, const I* __restrict__ idx,
+                                                       const uint32_t* __restrict__ g_bits, const uint32_t* __restrict__ g_prefix,
+                                                       int n_words, uint64_t n_rows, int k, int64_t* __restrict__ cntrow,
+                                                       uint32_t* __restrict__ kept) {
+    extern __shared__ double lds_raw[];
+    const SelLds sel = stage_selection(g_bits, g_prefix, n_words, reinterpret_cast<uint32_t*>(lds_raw));
+    const uint64_t wave = global_wave_id();
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
+    const int lane = lane_id();
+    constexpr int kCountUnroll = 16;          // 1024 entries in flight: a ~840-entry row is one round trip
+    for (uint64_t r0 = wave * kCompactRows; r0 < n_rows; r0 += n_waves * kCompactRows) {
+        const int nr = (int)(n_rows - r0 < (uint64_t)kCompactRows ? n_rows - r0 : kCompactRows);
+        uint32_t mine = 0;                    // lane i: row r0 + i
+        for (int i = 0; i < nr; ++i) {
+            const int64_t lo = indptr[r0 + i], hi = indptr[r0 + i + 1];
+            uint32_t rank0 = 0;               // kept entries of the row before this batch (wave-uniform)
+            for (int64_t base = lo; base < hi; base += kCountUnroll * kWave) {
+                int32_t g[kCountUnroll];
+#pragma unroll
+                for (int u = 0; u < kCountUnroll; ++u) {
+                    const int64_t p = base + u * kWave + lane;
+                    g[u] = p < hi ? (int32_t)idx[p] : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < kCountUnroll; ++u) {
+                    int c = g[u] >= 0 ? sel.column(g[u]) : -1;
+                    if (c >= k) c = -1;       // only a broken selection (NaN variances) has such columns: dropped
+                    const unsigned long long mask = __ballot(c >= 0);
+                    if (c >= 0) {
+                        const uint32_t rank = rank0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                        const uint32_t pos = (uint32_t)(base - lo) + (uint32_t)(u * kWave + lane);
+                        kept[lo + rank] = (pos << 16) | (uint32_t)c;
+                    }
+                    rank0 += (uint32_t)__popcll(mask);
+                }
+            }
+            if (lane == i) mine = rank0;
+        }
+        if (lane < nr) cntrow[r0 + lane] = (int64_t)mine;     // 8 counters = one 64-byte line
+    }
+}
+
+// XF: `vals` are the raw values and the kept entries are stored as ln_1p(f64(v) * scale_row), rounded once (RowXf).
+template <typename T, bool XF>
+__global__ __launch_bounds__(256) void k_tfill_list(const int64_t* __restrict__ indptr, const T* __restrict__ vals,
+                                                    const uint32_t* __restrict__ kept, uint64_t n_rows,
+                                                    const int64_t* __restrict__ rm_ptr, const double* __restrict__ row_sum,
+                                                    double target, GramPk<T>* __restrict__ rm) {
+    __shared__ Log1pTabEntry s_tab[XF ? 128 : 1];
+    if constexpr (XF) {
+        stage_log1p_table(s_tab);
+        __syncthreads();
+    }
+    const uint64_t wave = global_wave_id();
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
+    const int lane = lane_id();
+    // a wave takes two rows at a time, half a wave each (a row keeps ~72 of its entries: two steps of 32); the rows of a pair
+    // are neighbours, so their words, their values and their entries are neighbours too
+    for (uint64_t r0 = wave * 2; r0 < n_rows; r0 += n_waves * 2) {
+        const uint64_t r = r0 + (lane >> 5);
+        const bool live = r < n_rows;
+        const int64_t lo = live ? indptr[r] : 0;
+        const int64_t o0 = live ? rm_ptr[r] : 0;
+        const int n = live ? (int)(rm_ptr[r + 1] - o0) : 0;
+        double scale = 1.0;
+        if constexpr (XF) {
+            const double sr = live ? row_sum[r] : 0.0;
+            scale = sr == 0.0 ? 0.0 : target / sr;      // scale/mod.rs:9-15
+        }
+        const int n_max = __builtin_amdgcn_readfirstlane(max(__shfl(n, 0, kWave), __shfl(n, 32, kWave)));
+        for (int t = lane & 31; t < n_max; t += 32) {
+            if (t < n) {
+                const uint32_t w = kept[lo + t];
+                T v = vals[lo + (w >> 16)];
+                if constexpr (XF) v = xf_stored(v, scale, s_tab);         // the value the write-back stores in X
+                GramPk<T> e{};
+                e.j = (int32_t)(w & 0xffffu);
+                e.v = v;
+                rm[o0 + t] = e;
+            }
+        }
+    }
+}
+
 template <typename I>
 __global__ __launch_bounds__(256) void k_tcount(const int64_t* __restrict__ indptr, const I* __restrict__ idx,
                                                 const uint32_t* __restrict__ g_bits,
@@ -2303,9 +2393,21 @@ static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words,
     const size_t pb = is_f32(m) ? sizeof(GramPk<float>) : sizeof(GramPk<double>);
     // algorithmic bytes: the column indices of the whole matrix once per pass (count, fill) + row pointers in, row pointers
     // out; the KEPT values read and the compacted entries written are added below, once their number is known
-    ProfScope ps(ctx, SRX_K_COMPACT, (double)m->nnz * s_i * 2.0 + (double)(N + 1) * 8.0 * 2.0);
+    ProfScope ps(ctx, SRX_K_COMPACT, (double)m->nnz * s_i * ((!t256p && m->n_cols <= 65536 && !getenv("SRX_COMPACT_NOLIST")) ? 1.0 : 2.0) +
+                                         (double)(N + 1) * 8.0 * 2.0);
     const size_t cnt_lds = sel_lds + 4 * (size_t)kCompactRows * kWave * sizeof(uint32_t);      // + 8 x 64 counters per wave
-    if (!t256p) {
+    static const bool no_list = getenv("SRX_COMPACT_NOLIST") != nullptr;       // A/B switch
+    const bool list = !t256p && m->n_cols <= 65536 && !no_list;
+    uint32_t* kept = nullptr;
+    if (list) {
+        SRX_TRY(scratch(ctx, "pca_keptlist", (m->nnz + 64) * sizeof(uint32_t), (void**)&kept));
+        if (m->d_idx16)
+            hipLaunchKernelGGL((k_rowcount_list<uint16_t>), dim3(grid_rows(ctx, N, 4)), dim3(256), sel_lds, ctx->stream, m->d_indptr,
+                               (const uint16_t*)m->d_idx16, d_sel, d_sel + n_words, n_words, N, k, cntrow, kept);
+        else
+            hipLaunchKernelGGL((k_rowcount_list<int32_t>), dim3(grid_rows(ctx, N, 4)), dim3(256), sel_lds, ctx->stream, m->d_indptr,
+                               (const int32_t*)m->d_indices, d_sel, d_sel + n_words, n_words, N, k, cntrow, kept);
+    } else if (!t256p) {
         const size_t bits_lds = (size_t)n_words * sizeof(uint32_t);
         if (m->d_idx16)
             hipLaunchKernelGGL((k_rowcount<uint16_t>), dim3(grid_rows(ctx, N, 4)), dim3(256), bits_lds, ctx->stream, m->d_indptr,
@@ -2350,11 +2452,23 @@ static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words,
             else fill(k_tfill<T, int32_t, false>, ip, valp, rmp, pk256);
         }
     };
-    if (is_f32(m)) fill_t(float{}, (GramPk<float>*)rm.pk, (GramPk<float>*)t256.tpk);
+    if (list) {
+        const unsigned g2 = (unsigned)grid_rows(ctx, N, 8);
+        if (is_f32(m)) {
+            if (xf.row_sum) hipLaunchKernelGGL((k_tfill_list<float, true>), dim3(g2), dim3(256), 0, ctx->stream, m->d_indptr, (const float*)m->d_values, kept, N, rm.ptr, xf.row_sum, xf.target, (GramPk<float>*)rm.pk);
+            else hipLaunchKernelGGL((k_tfill_list<float, false>), dim3(g2), dim3(256), 0, ctx->stream, m->d_indptr, (const float*)m->d_values, kept, N, rm.ptr, xf.row_sum, xf.target, (GramPk<float>*)rm.pk);
+        } else {
+            if (xf.row_sum) hipLaunchKernelGGL((k_tfill_list<double, true>), dim3(g2), dim3(256), 0, ctx->stream, m->d_indptr, (const double*)m->d_values, kept, N, rm.ptr, xf.row_sum, xf.target, (GramPk<double>*)rm.pk);
+            else hipLaunchKernelGGL((k_tfill_list<double, false>), dim3(g2), dim3(256), 0, ctx->stream, m->d_indptr, (const double*)m->d_values, kept, N, rm.ptr, xf.row_sum, xf.target, (GramPk<double>*)rm.pk);
+        }
+    } else if (is_f32(m)) fill_t(float{}, (GramPk<float>*)rm.pk, (GramPk<float>*)t256.tpk);
     else fill_t(double{}, (GramPk<double>*)rm.pk, (GramPk<double>*)t256.tpk);
     SRX_HIP(ctx, hipGetLastError());
     if (ctx->prof_mask & (1u << SRX_K_COMPACT))
+    {
         ctx->prof[SRX_K_COMPACT].bytes += (double)total * (val_bytes(m) + (double)pb * (t256p ? 2.0 : 1.0));   // kept values read, entries written once or twice
+        if (list) ctx->prof[SRX_K_COMPACT].aux_bytes += (double)total * 4.0 * 2.0;      // the list of kept entries: written, read
+    }
     return SRX_OK;
 }
 
