@@ -254,6 +254,10 @@ constexpr int kGramUnroll = 8;            // suffix loads in flight per wave
 // entry itself — the diagonal product — and a suffix longer than a wave is cut into several records).
 // pos: first suffix entry of this record, relative to its block's first entry; lenrb = lanes | rbase << 8, where
 // rbase + jb is the index of G[ja][jb] among the owner's LDS accumulators (gram_row_base: may be negative, jb >= ja).
+// (8-byte records — the entry's value fetched in the kernel instead of carried in the record, the piece index in the spare bits
+//  of lenrb — were measured in round 3: the bucket pass gains 0.13 ms (0.93 -> 0.80) and the stripe kernel loses 0.45 with a
+//  scalar load of the value (it shares lgkmcnt with the LDS atomics: waiting for it drains them) and 1.35 with a wave-uniform
+//  vector load (one more L1 access per record).  The value stays in the record.)
 template <typename VT> struct GramRec { uint32_t pos, lenrb; VT va; };
 // records of a row with n kept entries: sum over suffix lengths L = 1 .. n of ceil(L / 64)
 __host__ __device__ __forceinline__ uint64_t gram_row_records(uint64_t n) {
