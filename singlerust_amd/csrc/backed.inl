@@ -105,8 +105,8 @@ template <typename VT>
 static int32_t backed_gram_tile(srx_backed* b, srx_mat* m, RowXf xf) {
     srx_ctx* ctx = b->ctx;
     RowMajor rm;
-    if (b->dev_sel) SRX_TRY(build_tiled_fused(m, b->hv.d_bits, b->hv.n_words, b->k, rm, nullptr, xf));
-    else SRX_TRY(build_tiled_fused(m, b->remap, b->k, rm, nullptr, xf));
+    if (b->dev_sel) SRX_TRY(build_tiled_fused(m, b->hv.d_bits, b->hv.n_words, b->k, rm, nullptr, xf, true));
+    else SRX_TRY(build_tiled_fused(m, b->remap, b->k, rm, nullptr, xf, true));
     SRX_TRY(launch_gram<VT>(ctx, rm, b->d_gram));            // accumulates into the session's packed matrix
     SRX_TRY(build_row_order(ctx, rm));
     // keep the row-major records of this tile for the transform: exact-size copies out of the scratch buffers

@@ -2193,6 +2193,8 @@ struct RowMajor {
     int64_t* ptr = nullptr;    // n_rows + 1
     void* pk = nullptr;
     uint32_t* perm = nullptr;  // rows ordered by their number of kept entries (forward SpMM), or null
+    int64_t n_recs = -1;       // >= 0: the Gram kernel's record counts were made with the compaction (scratch pca_brtot / pca_brbase
+                               // hold them): launch_gram starts at the bucket pass, one host wait less per step
 };
 static int32_t gram_plan(srx_ctx* ctx, int k, uint64_t n_rows, GramPlan& g) {
     g.k = k;
@@ -2374,7 +2376,8 @@ static int32_t alloc_tiled(srx_mat* m, uint64_t N, uint64_t nnz, int k, int kt, 
 
 // `d_sel`: n_words selection bits followed by n_words prefix counts, on the device (the compacted column of a
 // gene is its rank among the selected genes in ascending gene order)
-static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words, int k, RowMajor& rm, Tiled* t256p, RowXf xf = RowXf{}) {
+static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words, int k, RowMajor& rm, Tiled* t256p, RowXf xf = RowXf{},
+                                 bool want_recs = false) {
     Tiled t256_dummy;
     Tiled& t256 = t256p ? *t256p : t256_dummy;          // the 256-tiled view is only made for the matrix-free solver
     srx_ctx* ctx = m->ctx;
@@ -2426,8 +2429,24 @@ static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words,
         hipLaunchKernelGGL((k_tcount<int32_t>), dim3(grid_rows(ctx, N, 4)), dim3(256), cnt_lds, ctx->stream, m->d_indptr,
                            (const int32_t*)m->d_indices, d_sel, d_sel + n_words, n_words, N, nt128, nt256, k, cntrow, cnt256);
     SRX_TRY(scan_exclusive(ctx, cntrow, N, rm.ptr, &d_total));
+    // The Gram kernel's record counts only need the row lengths: made HERE, before the read-back of the compacted size, so
+    // that both numbers come back behind ONE drain of the stream (the second wait cost ~90 us of idle device per step)
+    int64_t* d_nrecs = nullptr;
+    rm.n_recs = -1;
+    if (want_recs && N > 0) {
+        GramPlan g;
+        SRX_TRY(gram_plan(ctx, k, N, g));
+        int64_t *blk_total, *rec_base;
+        SRX_TRY(scratch(ctx, "pca_brtot", g.n_rblk * sizeof(int64_t), (void**)&blk_total));
+        SRX_TRY(scratch(ctx, "pca_brbase", (g.n_rblk + 1) * sizeof(int64_t), (void**)&rec_base));
+        hipLaunchKernelGGL(k_rec_count, dim3((unsigned)g.n_rblk), dim3(256), 0, ctx->stream, (const int64_t*)rm.ptr, N, g.rblk, blk_total);
+        hipLaunchKernelGGL(k_rec_scan, dim3(1), dim3(1024), 0, ctx->stream, (const int64_t*)blk_total, g.n_rblk, rec_base);
+        SRX_HIP(ctx, hipGetLastError());
+        d_nrecs = rec_base + g.n_rblk;
+    }
     int64_t total = 0;
     SRX_TRY(d2h(ctx, &total, d_total, sizeof(int64_t)));
+    if (d_nrecs) SRX_TRY(d2h(ctx, &rm.n_recs, d_nrecs, sizeof(int64_t)));     // (the stream has drained: a copy, no wait)
     if (t256p) {
         SRX_TRY(scan_exclusive(ctx, cnt256, n256, t256.tptr, nullptr));
         SRX_TRY(alloc_tiled(m, N, (uint64_t)total, k, KT, t256));
@@ -2477,7 +2496,8 @@ static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words,
 }
 
 // host-side selection (srx_pca with an explicit feature list): bitmask + prefix counts from the remap table
-static int32_t build_tiled_fused(srx_mat* m, const std::vector<int32_t>& remap, int k, RowMajor& rm, Tiled* t256, RowXf xf = RowXf{}) {
+static int32_t build_tiled_fused(srx_mat* m, const std::vector<int32_t>& remap, int k, RowMajor& rm, Tiled* t256, RowXf xf = RowXf{},
+                                 bool want_recs = false) {
     srx_ctx* ctx = m->ctx;
     const int n_words = (int)((remap.size() + 31) / 32);
     std::vector<uint32_t> hsel(2 * (size_t)n_words, 0u);
@@ -2491,7 +2511,7 @@ static int32_t build_tiled_fused(srx_mat* m, const std::vector<int32_t>& remap, 
     uint32_t* d_sel;
     SRX_TRY(scratch(ctx, "pca_selbits", (hsel.size() ? hsel.size() : 1) * sizeof(uint32_t), (void**)&d_sel));
     SRX_TRY(h2d(ctx, d_sel, hsel.data(), hsel.size() * sizeof(uint32_t)));
-    return build_tiled_fused(m, d_sel, n_words, k, rm, t256, xf);
+    return build_tiled_fused(m, d_sel, n_words, k, rm, t256, xf, want_recs);
 }
 
 // ---- launches ---------------------------------------------------------------------------------
@@ -2632,10 +2652,14 @@ static int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* r
         // the records written once
         ProfScope ps(ctx, SRX_K_BUCKET, (double)rm.nnz * sizeof(GramPk<VT>) + (double)(rm.n_rows + 1) * 8.0 * 2.0);
         // how many records each block makes (a suffix longer than a wave is several), and where its records start
-        hipLaunchKernelGGL(k_rec_count, dim3((unsigned)g.n_rblk), dim3(256), 0, ctx->stream, rm.ptr, rm.n_rows, g.rblk, blk_total);
-        hipLaunchKernelGGL(k_rec_scan, dim3(1), dim3(1024), 0, ctx->stream, blk_total, g.n_rblk, rec_base);
-        SRX_HIP(ctx, hipGetLastError());
-        SRX_TRY(d2h(ctx, &n_recs, rec_base + g.n_rblk, sizeof(int64_t)));
+        if (rm.n_recs >= 0) {
+            n_recs = rm.n_recs;                  // counted with the compaction (build_tiled_fused): blk_total / rec_base are filled
+        } else {
+            hipLaunchKernelGGL(k_rec_count, dim3((unsigned)g.n_rblk), dim3(256), 0, ctx->stream, rm.ptr, rm.n_rows, g.rblk, blk_total);
+            hipLaunchKernelGGL(k_rec_scan, dim3(1), dim3(1024), 0, ctx->stream, blk_total, g.n_rblk, rec_base);
+            SRX_HIP(ctx, hipGetLastError());
+            SRX_TRY(d2h(ctx, &n_recs, rec_base + g.n_rblk, sizeof(int64_t)));
+        }
         SRX_TRY(scratch(ctx, "pca_brecs", ((size_t)n_recs + kGramUnroll) * sizeof(GramRec<VT>), (void**)&recs));
         if (ctx->prof_mask & (1u << SRX_K_BUCKET)) ctx->prof[SRX_K_BUCKET].bytes += (double)n_recs * sizeof(GramRec<VT>);
         SRX_HIP(ctx, hipMemsetAsync(recs + n_recs, 0, kGramUnroll * sizeof(GramRec<VT>), ctx->stream));
@@ -3651,9 +3675,9 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     const bool fits_rows = is_f32(m) ? fwd_rows_fits<float, float>(k) : fwd_rows_fits<double, double>(k);
     const bool need_t256 = o.solver == 2 || !fits_rows || getenv("SRX_FWD_TILED") != nullptr;
     if (dev_sel) {
-        SRX_TRY(build_tiled_fused(m, hv.d_bits, hv.n_words, k, rm, need_t256 ? &t256 : nullptr, xf));
+        SRX_TRY(build_tiled_fused(m, hv.d_bits, hv.n_words, k, rm, need_t256 ? &t256 : nullptr, xf, o.solver == 1));
     } else if ((k + KG - 1) / KG <= kWave) {
-        SRX_TRY(build_tiled_fused(m, remap, k, rm, need_t256 ? &t256 : nullptr, xf));
+        SRX_TRY(build_tiled_fused(m, remap, k, rm, need_t256 ? &t256 : nullptr, xf, o.solver == 1));
     } else {
         // the general route reads stored values: the matrix is transformed in place first
         if (xf.row_sum) {
