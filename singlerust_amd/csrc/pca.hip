@@ -3820,7 +3820,10 @@ int32_t srx_matrix_reserve_results(srx_mat* m, uint64_t n_selected, int32_t n_co
     size_t score_bytes, small_doubles;
     // dim = k bounds the number of rounds from above (fewer dimensions never take more rounds)
     result_layout(n_cells, k, n_pc, k, score_bytes, small_doubles);
-    return ensure_result_capacity(ctx, m->pca, score_bytes + small_doubles * 8);
+    SRX_TRY(ensure_result_capacity(ctx, m->pca, score_bytes + small_doubles * 8));
+    // the per-cell sums of the pipeline's first pass belong to the same promise: no device allocation inside a step
+    if (!m->csc && !m->d_row_sum) SRX_HIP(ctx, hipMalloc((void**)&m->d_row_sum, (m->n_rows ? m->n_rows : 1) * sizeof(double)));
+    return SRX_OK;
 }
 
 int32_t srx_pca(srx_mat* m, const uint64_t* sel, uint64_t k, const srx_pca_opts* opts, double* scores,
