@@ -934,17 +934,22 @@ __global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
         Chunk cur = load_chunk(0);
         for (int st = 0; st < n; st += 4 * Q) {
             const Chunk nxt = load_chunk(st + 4 * Q);
+            // all 4 Q panel reads of the chunk first (their addresses only need the broadcast columns), then the 4 Q x 4
+            // multiply-adds: with read and use interleaved step by step the wave sat out an LDS round trip per entry
+            Vec4<PT> pv[4 * Q];
 #pragma unroll
             for (int s_ = 0; s_ < 4 * Q; ++s_) {
                 const int j = quad_bcast<Q>(cur.r[s_ & 3].j, s_ >> 2);
+                pv[s_].load(panel_q + (size_t)j * ldp);
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < 4 * Q; ++s_) {
                 PT v = (PT)quad_bcast_v<Q>(cur.r[s_ & 3].v, s_ >> 2);
                 if (st + s_ >= n) v = PT(0);                    // past the row's end (j is then a valid column of a later row)
-                Vec4<PT> pv;
-                pv.load(panel_q + (size_t)j * ldp);
-                a0 += v * pv[0];
-                a1 += v * pv[1];
-                a2 += v * pv[2];
-                a3 += v * pv[3];
+                a0 += v * pv[s_][0];
+                a1 += v * pv[s_][1];
+                a2 += v * pv[s_][2];
+                a3 += v * pv[s_][3];
             }
             cur = nxt;
         }
