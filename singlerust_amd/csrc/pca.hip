@@ -1516,6 +1516,62 @@ __global__ __launch_bounds__(1024) void k_make_panel(const double* __restrict__ 
     }
 }
 
+// The same for the END of a round, on many workgroups and with the round's bookkeeping folded in (one workgroup walking the
+// k x 64 block took 48 us, and three device-to-device copies and k_signs followed it): sign of each Ritz vector from its
+// largest entry, P = PT(d .* V * sign), per-block partial sums of mu^T P (k_cvec_reduce adds them in fixed order), and the
+// copy of the Ritz vectors, values and signs into the matrix's result block.
+constexpr int kPanelBlocks = 32;
+template <typename PT>
+__global__ __launch_bounds__(1024) void k_make_panel_mb(const double* __restrict__ W, const double* __restrict__ d,
+                                                        const double* __restrict__ mu, const double* __restrict__ colmax,
+                                                        const double* __restrict__ theta, int k, PT* __restrict__ P,
+                                                        double* __restrict__ part /* [blocks][64] */, double* __restrict__ sgn_out,
+                                                        double* __restrict__ blk /* k*64 vectors | 64 values | 64 signs */) {
+    __shared__ double s_part[16][L];
+    const int c = threadIdx.x & (L - 1), sl = threadIdx.x / L;   // 16 row slices x 64 columns
+    const double sg = colmax[c] < 0 ? -1.0 : 1.0;
+    if (blockIdx.x == 0 && sl == 0) {
+        sgn_out[c] = sg;
+        blk[(size_t)k * L + c] = theta[c];
+        blk[(size_t)k * L + L + c] = sg;
+    }
+    double acc = 0.0;
+    for (int j = blockIdx.x * 16 + sl; j < k; j += gridDim.x * 16) {
+        const double wv = W[(size_t)j * L + c];
+        blk[(size_t)j * L + c] = wv;
+        const PT p = (PT)(d[j] * wv * sg);
+        P[(size_t)j * L + c] = p;
+        acc += mu[j] * (double)p;
+    }
+    s_part[sl][c] = acc;
+    __syncthreads();
+    if (sl == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += s_part[w][c];
+        part[(size_t)blockIdx.x * L + c] = t;
+    }
+}
+template <typename PT>
+__global__ void k_cvec_reduce(const double* __restrict__ part, int n_blocks, int cen, PT* __restrict__ cvec) {
+    const int c = threadIdx.x;
+    double t = 0.0;
+    for (int b = 0; b < n_blocks; ++b) t += part[(size_t)b * L + c];
+    cvec[c] = cen ? (PT)t : PT(0);
+}
+
+// up to four small device-to-device copies in one launch (32-bit words)
+struct CopySegs {
+    const uint32_t* src[4];
+    uint32_t* dst[4];
+    uint32_t words[4];
+};
+__global__ void k_copy_segs(CopySegs sg) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        for (uint32_t e = t; e < sg.words[i]; e += stride) sg.dst[i][e] = sg.src[i][e];
+}
+
 // W' = d .* (T - cen * mu s^T)
 __global__ void k_finish_t(const double* __restrict__ T, const double* __restrict__ d, const double* __restrict__ mu,
                            int k, int cen, double* __restrict__ Wp) {
@@ -3254,9 +3310,11 @@ static int32_t run_pca(srx_ctx* ctx, const RowMajor* parts, int n_parts, const T
     // written by the SpMM itself.  The Ritz vectors, values and signs move out of the (per-context) scratch into
     // the matrix's own block; their host copies are made by the first fetch (pca_materialize).
     auto finish_round = [&](int r, int col0, int n_r) -> int32_t {
-        hipLaunchKernelGGL(k_signs, dim3(1), dim3(L), 0, ctx->stream, w.dColmax, w.dSgn);
-        hipLaunchKernelGGL((k_make_panel<PT>), dim3(1), dim3(1024), 0, ctx->stream, w.A2, w.d, w.mu, (const double*)w.dSgn,
-                           k, o.center, P, cvec);
+        // signs, panel, centring partials and the copy of (Ritz vectors, values, signs) into the result block: one pass
+        double* blk = d_small + (size_t)r * (kl + 2 * L);
+        hipLaunchKernelGGL((k_make_panel_mb<PT>), dim3(kPanelBlocks), dim3(1024), 0, ctx->stream, (const double*)w.A2, (const double*)w.d,
+                           (const double*)w.mu, (const double*)w.dColmax, (const double*)w.dTheta, k, P, w.gpart, w.dSgn, blk);
+        hipLaunchKernelGGL((k_cvec_reduce<PT>), dim3(1), dim3(L), 0, ctx->stream, (const double*)w.gpart, kPanelBlocks, o.center, cvec);
         SRX_HIP(ctx, hipGetLastError());
         // scores = Z V: the transform from the row-major records, one launch per row tile (the tile-major kernel — 1.22 ms
         // at c3 against 0.84 — when its view was made: matrix-free solver, panel slice larger than the LDS, SRX_FWD_TILED)
@@ -3269,10 +3327,6 @@ static int32_t run_pca(srx_ctx* ctx, const RowMajor* parts, int n_parts, const T
                 row0 += parts[i].n_rows;
             }
         }
-        double* blk = d_small + (size_t)r * (kl + 2 * L);
-        SRX_HIP(ctx, hipMemcpyAsync(blk, w.A2, kl * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        SRX_HIP(ctx, hipMemcpyAsync(blk + kl, w.dTheta, L * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        SRX_HIP(ctx, hipMemcpyAsync(blk + kl + L, w.dSgn, L * 8, hipMemcpyDeviceToDevice, ctx->stream));
         return SRX_OK;
     };
     // Runs a plan of deflation rounds with the solver's `apply`; `reset` restores the undeflated operator, `deflate`
@@ -3509,11 +3563,13 @@ static int32_t stash_results(srx_ctx* ctx, srx_pca_state& st, int k, int n_pc, c
     double* sm = st.d_small + (size_t)st.rounds * (kl + 2 * L);      // behind the per-round blocks
     st.dev_sel = hv != nullptr;
     if (hv) {
-        SRX_HIP(ctx, hipMemcpyAsync(sm, hv->d_mu, (size_t)k * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        SRX_HIP(ctx, hipMemcpyAsync(sm + k, hv->d_sd, (size_t)k * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        SRX_HIP(ctx, hipMemcpyAsync(sm + 2 * (size_t)k, hv->d_trace, 8, hipMemcpyDeviceToDevice, ctx->stream));
-        SRX_HIP(ctx, hipMemcpyAsync(sm + 2 * (size_t)k + 2, hv->d_sel_rank, (size_t)k * sizeof(int32_t),
-                                    hipMemcpyDeviceToDevice, ctx->stream));
+        CopySegs cs;                                           // (four runtime copies were 20 us of dispatches)
+        cs.src[0] = (const uint32_t*)hv->d_mu;       cs.dst[0] = (uint32_t*)sm;                          cs.words[0] = (uint32_t)k * 2;
+        cs.src[1] = (const uint32_t*)hv->d_sd;       cs.dst[1] = (uint32_t*)(sm + k);                    cs.words[1] = (uint32_t)k * 2;
+        cs.src[2] = (const uint32_t*)hv->d_trace;    cs.dst[2] = (uint32_t*)(sm + 2 * (size_t)k);        cs.words[2] = 2;
+        cs.src[3] = (const uint32_t*)hv->d_sel_rank; cs.dst[3] = (uint32_t*)(sm + 2 * (size_t)k + 2);    cs.words[3] = (uint32_t)k;
+        hipLaunchKernelGGL(k_copy_segs, dim3(16), dim3(256), 0, ctx->stream, cs);
+        SRX_HIP(ctx, hipGetLastError());
         st.sel.clear();
     } else {
         st.pend_mu = mu;
