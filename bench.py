@@ -550,9 +550,12 @@ def cpu_baselines(B, ip, idx, val, genes):
 
 
 def backed_run(B, config=None, cells_override=0, n_runs=None):
-    """configs[4] as specified, on one GPU: the matrix lives in pinned host memory and goes through the backed session as
-    row tiles (two sweeps: statistics, then compaction + Gram), H2D overlapped with the kernels of the previous tile.
-    Returns the JSON object of the run (`--backed` prints it; the default line carries it as the `c5_backed` block)."""
+    """configs[4] as specified: the matrix lives in pinned host memory and goes through the backed session as row tiles (two
+    sweeps: statistics, then compaction + Gram), H2D overlapped with the kernels of the previous tile.  N ranks: every rank
+    holds and streams ITS row range of the same matrix (nnz-balanced cut; 72 GB / N of host CSR each) through its own session;
+    the per-gene moments and the packed Gram triangle are summed over the ranks inside srx_backed_select / srx_backed_solve.
+    Returns the JSON object of the run on rank 0, None elsewhere (`--backed` prints it; the default line carries it as the
+    `c5_backed` block)."""
     import numpy as np
     a, F, lib, ctx = B.a, B.F, B.lib, B.ctx
     config = config or a.config
@@ -560,16 +563,18 @@ def backed_run(B, config=None, cells_override=0, n_runs=None):
     if cells_override:
         cells = cells_override
     p = B.params(config, cells)
+    row0, row1 = B.shard(p, cells)
+    rows = row1 - row0
     tile = a.tile_rows
     t_gen = time.perf_counter()
-    ip = np.zeros(cells + 1, dtype=np.uint64)
-    lib.srx_synth_indptr(C.byref(p), 0, cells, F.ptr(ip))
+    ip = np.zeros(rows + 1, dtype=np.uint64)
+    lib.srx_synth_indptr(C.byref(p), row0, row1, F.ptr(ip))            # offsets of this rank's rows, from 0
     nnz = int(ip[-1])
     # pinned host memory for the two big arrays (the session's H2D workers copy straight out of it)
     hidx, hval = C.c_void_p(), C.c_void_p()
     hip = C.CDLL("libamdhip64.so")
     hip.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
-    pinned = hip.hipHostMalloc(C.byref(hidx), nnz * 8, 0) == 0 and hip.hipHostMalloc(C.byref(hval), nnz * 4, 0) == 0
+    pinned = hip.hipHostMalloc(C.byref(hidx), max(nnz, 1) * 8, 0) == 0 and hip.hipHostMalloc(C.byref(hval), max(nnz, 1) * 4, 0) == 0
     if pinned:
         idx = np.ctypeslib.as_array(C.cast(hidx, C.POINTER(C.c_uint64)), shape=(nnz,))
         val = np.ctypeslib.as_array(C.cast(hval, C.POINTER(C.c_float)), shape=(nnz,))
@@ -578,28 +583,32 @@ def backed_run(B, config=None, cells_override=0, n_runs=None):
     # fill tile by tile on a thread pool (the host generator is serial per call; ctypes releases the GIL)
     import concurrent.futures as cf
 
-    def fill(r0):
-        r1 = min(cells, r0 + tile)
+    def fill(r0):                                                  # r0: local row
+        r1 = min(rows, r0 + tile)
         e0, e1 = int(ip[r0]), int(ip[r1])
         sub = (ip[r0:r1 + 1] - ip[r0]).astype(np.uint64)
-        lib.srx_synth_fill_host(C.byref(p), r0, r1, F.ptr(sub), F.ptr(idx[e0:e1]), F.ptr(val[e0:e1]))
-    with cf.ThreadPoolExecutor(max_workers=max(1, min(usable_cores(), 64))) as ex:
-        list(ex.map(fill, range(0, cells, tile)))
+        lib.srx_synth_fill_host(C.byref(p), row0 + r0, row0 + r1, F.ptr(sub), F.ptr(idx[e0:e1]), F.ptr(val[e0:e1]))
+    with cf.ThreadPoolExecutor(max_workers=max(1, min(usable_cores() // max(B.world, 1), 64))) as ex:
+        list(ex.map(fill, range(0, rows, tile)))
     t_gen = time.perf_counter() - t_gen
     host_bytes = ip.nbytes + idx.nbytes + val.nbytes
     opts = F.PcaOpts(a.npc, -1, -1, -1, 0, 0, 1, 0.0, 12345)
     xf = F.BACKED_NORMALIZE | F.BACKED_LOG1P
 
     def tiles():
-        for r0 in range(0, cells, tile):
-            r1 = min(cells, r0 + tile)
+        for r0 in range(0, rows, tile):
+            r1 = min(rows, r0 + tile)
             e0 = int(ip[r0])
             yield F.Csr(r1 - r0, genes, int(ip[r1]) - e0, ip[r0:].ctypes.data, idx[e0:].ctypes.data, val[e0:].ctypes.data, F.F32)
+
+    def tmax(x):                                                   # the slowest rank's time
+        return B.dist.allreduce_max(x) if B.dist is not None else x
 
     runs = []
     for _ in range(max(1, n_runs if n_runs is not None else a.steps)):
         h = C.c_void_p()
         F.check(lib.srx_backed_create(ctx.handle, genes, F.STORE_F32, C.byref(h)), ctx.handle)
+        B.sync_all()
         t0 = time.perf_counter()
         for t in tiles():
             F.check(lib.srx_backed_stats_tile(h, C.byref(t), a.target_sum, xf, None, None), ctx.handle)
@@ -613,24 +622,28 @@ def backed_run(B, config=None, cells_override=0, n_runs=None):
         t3 = time.perf_counter()
         info = F.PcaInfo()
         F.check(lib.srx_backed_solve(h, C.byref(info)), ctx.handle)
-        ctx.synchronize()
+        B.sync_all()
         t4 = time.perf_counter()
         lib.srx_backed_destroy(h)
-        runs.append({"total_s": t4 - t0, "sweep1_s": t1 - t0, "select_s": t2 - t1, "sweep2_s": t3 - t2, "solve_s": t4 - t3,
-                     "residual": float(info.residual), "iterations": int(info.n_iter)})
+        runs.append({"total_s": tmax(t4 - t0), "sweep1_s": tmax(t1 - t0), "select_s": tmax(t2 - t1), "sweep2_s": tmax(t3 - t2),
+                     "solve_s": tmax(t4 - t3), "residual": float(info.residual), "iterations": int(info.n_iter),
+                     "cells_global_seen": int(info.n_cells_global)})
     best = min(runs, key=lambda r: r["total_s"])
     out = {
         "metric": "cells/sec end-to-end normalise->HVG->50-PC PCA; SpMM achieved HBM GB/s vs peak",
-        "value": cells / best["total_s"], "unit": "cells/s", "n_gpus": 1, "steps": len(runs), "warmup": 0,
-        "ms_per_step": best["total_s"] * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic",
+        "value": cells / best["total_s"], "unit": "cells/s", "n_gpus": B.world, "steps": len(runs), "warmup": 0,
+        "ms_per_step": best["total_s"] * 1e3, "higher_is_better": True, "scaling": "strong" if B.world > 1 else "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{config} OUT OF CORE: {cells} cells x {genes} genes, density {density}, seed {seed}; the CSR "
-                               f"({host_bytes / 1e9:.1f} GB: u64 offsets / indices + f32 values) stays in "
+                               f"(rank 0: {host_bytes / 1e9:.1f} GB: u64 offsets / indices + f32 values) stays in "
                                f"{'pinned' if pinned else 'pageable'} host memory and is streamed as {tile}-cell tiles "
-                               "through srx_backed_* (sweep 1: statistics; select; sweep 2: compaction + Gram; solve)",
-                   "cells_global": cells, "genes": genes, "nnz": nnz, "hvg": a.hvg, "n_pc": a.npc, "tile_rows": tile},
-        "h2d": {"host_bytes_per_sweep": host_bytes, "GBps_sweep1": host_bytes / best["sweep1_s"] / 1e9,
-                "GBps_sweep2": host_bytes / best["sweep2_s"] / 1e9,
+                               "through srx_backed_* (sweep 1: statistics; select; sweep 2: compaction + Gram; solve)"
+                               + (f"; rows {row0}..{row1} on rank 0 of {B.world}, moments and Gram triangle all-reduced" if B.world > 1 else ""),
+                   "cells_global": cells, "genes": genes, "nnz_rank0": nnz, "hvg": a.hvg, "n_pc": a.npc, "tile_rows": tile,
+                   "parallelism": f"row-shard x{B.world} (nnz-balanced), one backed session per rank",
+                   **(B.comm_info if B.dist is not None and B.comm_info else {})},
+        "h2d": {"host_bytes_per_sweep_rank0": host_bytes, "GBps_sweep1_rank0": host_bytes / best["sweep1_s"] / 1e9,
+                "GBps_sweep2_rank0": host_bytes / best["sweep2_s"] / 1e9,
                 "note": "both sweeps cross PCIe (u64 indices narrowed to i32 on the host side of the link); upload-bound: the "
                         "kernels of a tile run under the upload of the next one"},
         "runs": runs, "setup": {"host_generate_s": t_gen},
@@ -639,7 +652,7 @@ def backed_run(B, config=None, cells_override=0, n_runs=None):
     if pinned:
         hip.hipHostFree.argtypes = [C.c_void_p]
         hip.hipHostFree(hidx); hip.hipHostFree(hval)
-    return out
+    return out if B.rank == 0 else None
 
 
 def self_launch(n):
@@ -688,9 +701,13 @@ def main():
     B = Bench(a)
     rank, world = B.rank, B.world
     if a.backed:
-        if world != 1:
-            sys.exit("--backed is a single-GPU measurement")
-        print(json.dumps(backed_run(B, cells_override=a.cells)), flush=True)
+        out = backed_run(B, cells_override=a.cells)
+        if rank == 0:
+            if B.json_fd is not None:
+                sys.stdout.flush()
+                os.write(B.json_fd, (json.dumps(out) + "\n").encode())
+            else:
+                print(json.dumps(out), flush=True)
         B.close()
         return
     cells, genes, density, seed = CONFIGS[a.config]

@@ -76,3 +76,26 @@ def test_host_fallback_is_refused_unless_asked_for():
     assert p.returncode != 0
     assert not [ln for ln in p.stdout.decode().splitlines() if ln.strip().startswith("{")]
     assert "SRX_BENCH_COLLECTIVE=host" in p.stderr.decode()
+
+
+def test_backed_run_across_two_ranks():
+    """configs[4]'s form on more than one rank: `bench.py --gpus 2 --backed` — every rank streams its own row range of the
+    host matrix through its own backed session, the moments and the Gram triangle are summed over the ranks — against the
+    single-rank backed run of the same matrix (same selection, same residual)."""
+    cells = 60000
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c2", "--cells", str(cells), "--backed", "--tile-rows", "8000",
+            "--steps", "1"]
+    env = _clean_env(SRX_BENCH_DEVICE="0", SRX_BENCH_COLLECTIVE="host")
+    p1 = subprocess.run(base + ["--gpus", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, timeout=600)
+    assert p1.returncode == 0, p1.stderr.decode()[-3000:]
+    p2 = subprocess.run(base + ["--gpus", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, timeout=600)
+    assert p2.returncode == 0, p2.stderr.decode()[-3000:]
+    d1 = json.loads([ln for ln in p1.stdout.decode().splitlines() if ln.strip()][-1])
+    lines2 = [ln for ln in p2.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines2) == 1
+    d2 = json.loads(lines2[0])
+    assert d2["n_gpus"] == 2 and d2["config"]["cells_global"] == cells and d2["config"]["n_ranks_seen"] == 2
+    r1, r2 = d1["runs"][0], d2["runs"][0]
+    assert r2["cells_global_seen"] == cells == r1["cells_global_seen"]
+    assert r1["residual"] < 1e-6 and r2["residual"] < 1e-6
+    assert abs(d2["value"] - cells / (d2["ms_per_step"] * 1e-3)) <= 1e-6 * d2["value"]
