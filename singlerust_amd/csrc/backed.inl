@@ -270,10 +270,7 @@ static int32_t backed_select_impl(srx_backed* b, uint64_t n_hvg, const uint64_t*
     b->k = k;
     if ((k + KG - 1) / KG > kWave)
         return fail(ctx, SRX_E_ARG, "backed: %d selected features exceed the %d the fused compaction takes", k, kWave * KG);
-    // the scores are written by the row-major forward kernel, whose panel slice (4 columns of all k genes per lane) must fit the LDS
-    if (!(b->store == SRX_STORE_F64 ? fwd_rows_fits<double, double>(k) : fwd_rows_fits<float, float>(k)))
-        return fail(ctx, SRX_E_ARG, "backed: %d selected features exceed the forward kernel's LDS panel slice (%s storage)", k,
-                    b->store == SRX_STORE_F64 ? "f64: 5119" : "f32: 10239");
+    // (the scores are written by the row-major forward kernel: any k — beyond its widest LDS slice it walks gene ranges)
     SRX_TRY(resolve_opts(ctx, opts, k, acc->n_rows_global, b->store == SRX_STORE_F32, b->o, b->l_act));
     if (opts && opts->solver == 2) return fail(ctx, SRX_E_ARG, "backed: only the Gram solver works on row tiles");
     if (b->o.solver != 1) { b->o.solver = 1; b->o.power = 3; b->o.warm = 2; }

@@ -863,13 +863,21 @@ __global__ __launch_bounds__(256) void k_len_scatter(const int64_t* __restrict__
     }
 }
 
-template <typename VT, typename PT, int Q>
+// RANGE: the panel slice of ALL k genes does not fit the LDS (f64 panels beyond 5118 genes): the launch covers the genes
+// [k_lo, k_hi) only — entries outside contribute nothing — and, from the second range on (`accumulate`), adds to what the
+// earlier ranges left in the output.
+template <typename VT, typename PT, int Q, bool RANGE = false>
 __global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
     const int64_t* __restrict__ rm_ptr, const GramPk<VT>* __restrict__ rm, const uint32_t* __restrict__ perm /* nullable */,
     uint64_t n_rows, int k, const PT* __restrict__ P /* k x 64 */, const PT* __restrict__ cvec /* 64 */,
     int n_cols /* panel columns wanted */, double* __restrict__ scores /* n_rows x ld f64 (nullable) */,
-    PT* __restrict__ Y /* n_rows x 64 (nullable) */, int ld, int ldp /* elements between two genes of the slice in LDS */) {
+    PT* __restrict__ Y /* n_rows x 64 (nullable) */, int ld, int ldp /* elements between two genes of the slice in LDS */,
+    int k_lo = 0, int k_hi = 0, int accumulate = 0) {
     constexpr int C = 4 * Q;
+    if constexpr (!RANGE) {
+        k_lo = 0;
+        k_hi = k;
+    }
     extern __shared__ double lds_raw[];
     PT* panel = reinterpret_cast<PT*>(lds_raw);                 // k x C
     const int n_slices = (n_cols + C - 1) / C;
@@ -886,10 +894,10 @@ __global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
         slice = blockIdx.x % n_slices;
         wg = blockIdx.x / n_slices;
     }
-    for (int e = threadIdx.x; e < k * Q; e += kFwdRowsThreads) {
+    for (int e = threadIdx.x; e < (k_hi - k_lo) * Q; e += kFwdRowsThreads) {
         const int j = e / Q, cq = e % Q;
         Vec4<PT> v;
-        v.load(P + (size_t)j * L + slice * C + cq * 4);
+        v.load(P + (size_t)(k_lo + j) * L + slice * C + cq * 4);
         v.store(panel + (size_t)j * ldp + cq * 4);
     }
     __syncthreads();
@@ -937,15 +945,21 @@ __global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
             // all 4 Q panel reads of the chunk first (their addresses only need the broadcast columns), then the 4 Q x 4
             // multiply-adds: with read and use interleaved step by step the wave sat out an LDS round trip per entry
             Vec4<PT> pv[4 * Q];
+            bool in_range[4 * Q];
 #pragma unroll
             for (int s_ = 0; s_ < 4 * Q; ++s_) {
-                const int j = quad_bcast<Q>(cur.r[s_ & 3].j, s_ >> 2);
+                int j = quad_bcast<Q>(cur.r[s_ & 3].j, s_ >> 2);
+                in_range[s_] = true;
+                if constexpr (RANGE) {
+                    in_range[s_] = j >= k_lo && j < k_hi;
+                    j = in_range[s_] ? j - k_lo : 0;
+                }
                 pv[s_].load(panel_q + (size_t)j * ldp);
             }
 #pragma unroll
             for (int s_ = 0; s_ < 4 * Q; ++s_) {
                 PT v = (PT)quad_bcast_v<Q>(cur.r[s_ & 3].v, s_ >> 2);
-                if (st + s_ >= n) v = PT(0);                    // past the row's end (j is then a valid column of a later row)
+                if (st + s_ >= n || !in_range[s_]) v = PT(0);   // past the row's end (j is then a valid column of a later row)
                 a0 += v * pv[s_][0];
                 a1 += v * pv[s_][1];
                 a2 += v * pv[s_][2];
@@ -953,16 +967,29 @@ __global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
             }
             cur = nxt;
         }
-        const PT o0 = a0 - cv4[0], o1 = a1 - cv4[1], o2 = a2 - cv4[2], o3 = a3 - cv4[3];
+        PT o0 = a0 - cv4[0], o1 = a1 - cv4[1], o2 = a2 - cv4[2], o3 = a3 - cv4[3];
+        if (RANGE && accumulate) { o0 = a0; o1 = a1; o2 = a2; o3 = a3; }      // (the centring term went in with the first range)
         if (scores) {
             double* dst = scores + row_c * (uint64_t)ld + col0;
-            if (col0 + 0 < n_cols) dst[0] = (double)o0;
-            if (col0 + 1 < n_cols) dst[1] = (double)o1;
-            if (col0 + 2 < n_cols) dst[2] = (double)o2;
-            if (col0 + 3 < n_cols) dst[3] = (double)o3;
+            if (RANGE && accumulate) {
+                if (col0 + 0 < n_cols) dst[0] += (double)o0;
+                if (col0 + 1 < n_cols) dst[1] += (double)o1;
+                if (col0 + 2 < n_cols) dst[2] += (double)o2;
+                if (col0 + 3 < n_cols) dst[3] += (double)o3;
+            } else {
+                if (col0 + 0 < n_cols) dst[0] = (double)o0;
+                if (col0 + 1 < n_cols) dst[1] = (double)o1;
+                if (col0 + 2 < n_cols) dst[2] = (double)o2;
+                if (col0 + 3 < n_cols) dst[3] = (double)o3;
+            }
         } else {
             Vec4<PT> o;
-            o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
+            if (RANGE && accumulate) {
+                o.load(Y + row_c * L + col0);
+                o[0] += o0; o[1] += o1; o[2] += o2; o[3] += o3;
+            } else {
+                o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
+            }
             o.store(Y + row_c * L + col0);
         }
     }
@@ -2610,15 +2637,16 @@ static int fwd_rows_q(int k) {
         if ((size_t)k * 4 * q * sizeof(PT) <= budget) return q;
     return 0;
 }
+// (the row-major forward kernel takes any k: beyond the widest single slice it walks the genes in ranges)
 template <typename VT, typename PT>
-static bool fwd_rows_fits(int k) { return fwd_rows_q<PT>(k) > 0; }
+static bool fwd_rows_fits(int) { return true; }
 template <typename VT, typename PT>
 static int32_t launch_fwd_rows(srx_ctx* ctx, const RowMajor& r, const PT* P, const PT* cvec, int n_cols, double* scores, PT* Y,
                                int ld) {
     const int Qr = fwd_rows_q<PT>(r.k);
-    if (Qr == 0) return fail(ctx, SRX_E_ARG, "pca: %d selected features exceed the LDS panel slice of the row-major forward kernel", r.k);
-    auto go = [&](auto qtag) -> int32_t {
+    auto go = [&](auto qtag, auto rtag, int k_lo, int k_hi, int accumulate) -> int32_t {
         constexpr int Q = decltype(qtag)::value;
+        constexpr bool RANGE = decltype(rtag)::value;
         constexpr int C = 4 * Q;
         const int n_slices = (n_cols + C - 1) / C;
         // (a gene's C = 16 f32 columns are 64 bytes, so every 16-byte read of a wave's 16 cells starts in bank 0 or 16: half of
@@ -2626,7 +2654,7 @@ static int32_t launch_fwd_rows(srx_ctx* ctx, const RowMajor& r, const PT* P, con
         //  bank offsets, k <= 2047 — was measured: 0.746 against 0.745 ms.  The pipe is 51 % busy either way; the kernel waits
         //  on its dependent DPP -> address -> LDS -> FMA chains at four waves per SIMD, not on LDS bandwidth.)
         const int ldp = C;
-        const size_t lds = (size_t)r.k * ldp * sizeof(PT);
+        const size_t lds = (size_t)(k_hi - k_lo) * ldp * sizeof(PT);
         const uint64_t groups = kFwdRowsThreads / Q;
         uint64_t n_wg = (r.n_rows + groups - 1) / groups;
         const uint64_t cap = std::max<uint64_t>(1, (uint64_t)ctx->n_cus / n_slices);      // one workgroup per CU
@@ -2634,19 +2662,27 @@ static int32_t launch_fwd_rows(srx_ctx* ctx, const RowMajor& r, const PT* P, con
         if (n_wg < 1) n_wg = 1;
         const double out_bytes = scores ? (double)r.n_rows * n_cols * 8.0 : (double)r.n_rows * L * sizeof(PT);
         ProfScope ps(ctx, SRX_K_SPMM_FWD, (double)r.nnz * sizeof(GramPk<VT>) + (double)(r.n_rows + 1) * 8.0 + out_bytes +
-                                              (double)r.k * L * sizeof(PT) + (r.perm ? (double)r.n_rows * 4.0 : 0.0));
-        SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_spmm_rows<VT, PT, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_spmm_rows<VT, PT, Q>), dim3((unsigned)(n_wg * n_slices)), dim3(kFwdRowsThreads), lds, ctx->stream, r.ptr,
-                           (const GramPk<VT>*)r.pk, (const uint32_t*)r.perm, r.n_rows, r.k, P, cvec, n_cols, scores, Y, ld, ldp);
+                                              (double)(k_hi - k_lo) * L * sizeof(PT) + (r.perm ? (double)r.n_rows * 4.0 : 0.0));
+        SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_spmm_rows<VT, PT, Q, RANGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_spmm_rows<VT, PT, Q, RANGE>), dim3((unsigned)(n_wg * n_slices)), dim3(kFwdRowsThreads), lds, ctx->stream, r.ptr,
+                           (const GramPk<VT>*)r.pk, (const uint32_t*)r.perm, r.n_rows, r.k, P, cvec, n_cols, scores, Y, ld, ldp,
+                           k_lo, k_hi, accumulate);
         SRX_HIP(ctx, hipGetLastError());
         return SRX_OK;
     };
+    using No = std::false_type;
+    using Yes = std::true_type;
     if (Qr == 4) {
-        if constexpr (sizeof(PT) == 4) return go(std::integral_constant<int, 4>{});
+        if constexpr (sizeof(PT) == 4) return go(std::integral_constant<int, 4>{}, No{}, 0, r.k, 0);
         else return SRX_E_ARG;
     }
-    if (Qr == 2) return go(std::integral_constant<int, 2>{});
-    return go(std::integral_constant<int, 1>{});
+    if (Qr == 2) return go(std::integral_constant<int, 2>{}, No{}, 0, r.k, 0);
+    if (Qr == 1) return go(std::integral_constant<int, 1>{}, No{}, 0, r.k, 0);
+    // wider than one slice of four columns: gene ranges of the widest slice, one launch each, the later ones accumulating
+    const int per = (int)((163840 - 64) / (4 * sizeof(PT)));
+    for (int k_lo = 0, i = 0; k_lo < r.k; k_lo += per, ++i)
+        SRX_TRY(go(std::integral_constant<int, 1>{}, Yes{}, k_lo, std::min(r.k, k_lo + per), i > 0 ? 1 : 0));
+    return SRX_OK;
 }
 
 // rows ordered by their number of kept entries (k_spmm_rows); r.ptr must be complete

@@ -147,3 +147,23 @@ def test_backed_pipeline_explicit_selection_and_errors(ctx, tmp_path):
     with pytest.raises(_ffi.SrxError):
         s.stats_tile(chunk)
     s.close()
+
+
+def test_wide_selection_at_f64_storage_walks_gene_ranges(ctx, tmp_path):
+    """6000 selected features at f64 storage: the forward kernel's panel slice of four f64 columns holds 5118 genes, so the
+    scores come from two gene ranges, the second accumulating (round 2 refused this selection in backed mode).  Resident
+    pipeline and backed session against the oracle's exact SVD."""
+    from singlerust_amd import backed
+    m, _ = synth_host(31, 1500, 6400, 0.03)
+    n_hvg, n_pc = 6000, 6
+    scores, comps, evr, mean, std, hv = run_resident(m, ctx, n_hvg, n_pc, 2)
+    lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
+    want_sel = oracle.select_hvg(oracle.compute_variance(lg, COLUMN), n_hvg)
+    assert np.array_equal(hv, want_sel)
+    want, wc, wevr, *_ = pca_oracle.pca_inplace(lg, n_pc, None, None, hv)
+    assert col_err(scores, want) < 1e-7 and col_err(comps, wc) < 1e-7
+    assert np.allclose(evr, wevr, rtol=1e-8)
+    ad = backed.BackedAnnData.open(store_of(m, tmp_path), ctx)
+    r = backed.processing.pca_pipeline(ad, 400, 1e4, n_hvg, n_pc, store=2)
+    assert np.array_equal(r.selected, hv)
+    assert col_err(r.x_pca, want) < 1e-7 and col_err(r.components, wc) < 1e-7
