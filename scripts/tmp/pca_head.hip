@@ -787,14 +787,14 @@ __device__ __forceinline__ int quad_bcast(int x, int s) {
         return x;                                               // one lane per row: nothing to broadcast
     } else if constexpr (Q == 4) {
         switch (s) {                                            // v_mov_b32_dpp quad_perm:[s,s,s,s]
-            case 0: return __builtin_amdgcn_update_dpp(0, x, 0x00, 0xf, 0xf, true);   // (bound_ctrl: no "old" value to set up)
-            case 1: return __builtin_amdgcn_update_dpp(0, x, 0x55, 0xf, 0xf, true);
-            case 2: return __builtin_amdgcn_update_dpp(0, x, 0xaa, 0xf, 0xf, true);
-            default: return __builtin_amdgcn_update_dpp(0, x, 0xff, 0xf, 0xf, true);
+            case 0: return __builtin_amdgcn_update_dpp(0, x, 0x00, 0xf, 0xf, false);
+            case 1: return __builtin_amdgcn_update_dpp(0, x, 0x55, 0xf, 0xf, false);
+            case 2: return __builtin_amdgcn_update_dpp(0, x, 0xaa, 0xf, 0xf, false);
+            default: return __builtin_amdgcn_update_dpp(0, x, 0xff, 0xf, 0xf, false);
         }
     } else {                                                    // pairs: lanes (2i, 2i+1) of every quad
-        return s == 0 ? __builtin_amdgcn_update_dpp(0, x, 0xa0, 0xf, 0xf, true)       // [0,0,2,2]
-                      : __builtin_amdgcn_update_dpp(0, x, 0xf5, 0xf, 0xf, true);      // [1,1,3,3]
+        return s == 0 ? __builtin_amdgcn_update_dpp(0, x, 0xa0, 0xf, 0xf, false)      // [0,0,2,2]
+                      : __builtin_amdgcn_update_dpp(0, x, 0xf5, 0xf, 0xf, false);     // [1,1,3,3]
     }
 }
 template <int Q>
@@ -866,26 +866,21 @@ __global__ __launch_bounds__(256) void k_len_scatter(const int64_t* __restrict__
 // RANGE: the panel slice of ALL k genes does not fit the LDS (f64 panels beyond 5118 genes): the launch covers the genes
 // [k_lo, k_hi) only — entries outside contribute nothing — and, from the second range on (`accumulate`), adds to what the
 // earlier ranges left in the output.
-// CL: panel columns per lane — 4, or 5 (the lane's four + one of the slice's last Q columns): a slice of 5 Q columns of all k
-// genes is the widest the LDS takes at k = 2000 (160 000 B), and n_pc = 50 then needs 3 (f32; 5 with f64 panels) passes over
-// the matrix instead of 4 (7) — the kernel is bound by its reads (see the note in the body), not by what it does with them.
-template <typename VT, typename PT, int Q, bool RANGE = false, int CL = 4>
+template <typename VT, typename PT, int Q, bool RANGE = false>
 __global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
-    const int64_t* __restrict__ rm_ptr, const GramPk<VT>* rm /* NOT __restrict__: see the barrier behind the chunk loads */,
-    const uint32_t* __restrict__ perm /* nullable */,
+    const int64_t* __restrict__ rm_ptr, const GramPk<VT>* __restrict__ rm, const uint32_t* __restrict__ perm /* nullable */,
     uint64_t n_rows, int k, const PT* __restrict__ P /* k x 64 */, const PT* __restrict__ cvec /* 64 */,
     int n_cols /* panel columns wanted */, double* __restrict__ scores /* n_rows x ld f64 (nullable) */,
     PT* __restrict__ Y /* n_rows x 64 (nullable) */, int ld, int ldp /* elements between two genes of the slice in LDS */,
-    int k_lo = 0, int k_hi = 0, int accumulate = 0, int col_base = 0 /* first panel column of this launch */) {
-    static_assert(CL == 4 || CL == 5, "columns per lane");
-    constexpr int C = CL * Q;
+    int k_lo = 0, int k_hi = 0, int accumulate = 0) {
+    constexpr int C = 4 * Q;
     if constexpr (!RANGE) {
         k_lo = 0;
         k_hi = k;
     }
     extern __shared__ double lds_raw[];
     PT* panel = reinterpret_cast<PT*>(lds_raw);                 // k x C
-    const int n_slices = (n_cols - col_base + C - 1) / C;
+    const int n_slices = (n_cols + C - 1) / C;
     // the column slices of one row range sit on the SAME XCD (consecutive workgroup ids go round the 8 XCDs): they walk the
     // same rows at the same pace, so the entries come out of that XCD's L2 for all but the first of them
     const uint64_t n_wg = gridDim.x / n_slices;
@@ -899,105 +894,84 @@ __global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
         slice = blockIdx.x % n_slices;
         wg = blockIdx.x / n_slices;
     }
-    // a gene of the slice in LDS: its C columns in panel order
-    if constexpr (C % 4 == 0) {
-        for (int e = threadIdx.x; e < (k_hi - k_lo) * (C / 4); e += kFwdRowsThreads) {
-            const int j = e / (C / 4), cq = e % (C / 4);
-            Vec4<PT> v;
-            v.load(P + (size_t)(k_lo + j) * L + col_base + slice * C + cq * 4);
-            v.store(panel + (size_t)j * ldp + cq * 4);
-        }
-    } else {
-        for (int e = threadIdx.x; e < (k_hi - k_lo) * C; e += kFwdRowsThreads) {
-            const int j = e / C, cq = e % C;
-            panel[(size_t)j * ldp + cq] = P[(size_t)(k_lo + j) * L + col_base + slice * C + cq];
-        }
+    for (int e = threadIdx.x; e < (k_hi - k_lo) * Q; e += kFwdRowsThreads) {
+        const int j = e / Q, cq = e % Q;
+        Vec4<PT> v;
+        v.load(P + (size_t)(k_lo + j) * L + slice * C + cq * 4);
+        v.store(panel + (size_t)j * ldp + cq * 4);
     }
     __syncthreads();
     const int ql = threadIdx.x % Q;                             // lane within the row's lane group
     constexpr uint64_t kGroups = kFwdRowsThreads / Q;
-    const int col0 = col_base + slice * C + ql * 4;             // the lane's four columns ...
-    const int colx = col_base + slice * C + 4 * Q + ql;         // ... and, CL = 5, its one of the slice's last Q
+    const int col0 = slice * C + ql * 4;
     Vec4<PT> cv4;
     cv4.load(cvec + col0);
-    PT cvx = PT(0);
-    if constexpr (CL == 5) cvx = cvec[colx];
-    constexpr int kGeneBytes = C * (int)sizeof(PT);             // one gene of the slice in LDS
-    const char* panel_q = reinterpret_cast<const char*>(panel) + ql * 4 * (int)sizeof(PT);
-    const char* panel_x = reinterpret_cast<const char*>(panel) + (4 * Q + ql) * (int)sizeof(PT);
+    const PT* panel_q = panel + ql * 4;
     // sorted position i -> row perm[i]; a wave's groups take consecutive positions (equal lengths), the workgroups
-    // interleave so that the long rows at the end are spread over all of them.
-    // A chunk = 4 Q consecutive records of a row (lane ql holds records 4 ql .. 4 ql + 3: one 32- / 64-byte load per lane); a
-    // BATCH = kSub chunks.  The lane group's rows are one stream of batches worked through with two register sets: the batch
-    // after this one — the row's next, or the first of the next row, whose pointers came a row ahead — is in flight while this
-    // one is multiplied, and a row's output stores are issued behind the loads of the next row's first batch (vmcnt counts in
-    // order: a load waited for behind a store waits for the store's acknowledgement too).
-    // What round 2's loop did instead, timed inside the kernel (-DSPMM_TIMING, ns per 16-row step of a wave, 7.1-10.7 us in
-    // all): it had "load the next chunk, work on this one, cur = nxt", which the compiler turned into "load this chunk,
-    // wait, work on it" (the next load equals the following iteration's) — an exposed ~0.85 us round trip per chunk; its 16
-    // panel reads per chunk were re-interleaved with the multiply-adds two reads deep by the scheduler — 16 LDS round
-    // trips per chunk, 1.7 us per row; the copy of the next row's pointers at the top of the body waited for the loads
-    // just issued; four 8-byte stores per lane behind exec branches.
-#ifndef SPMM_KSUB
-#define SPMM_KSUB 2
-#endif
-    constexpr int kSub = sizeof(VT) == 4 && CL == 4 ? SPMM_KSUB : 1;
-    constexpr int kBatch = kSub * 4 * Q;                        // records of a batch
-    const uint64_t stride = n_wg * kGroups, i_first = wg * kGroups + threadIdx.x / Q, last_row = n_rows ? n_rows - 1 : 0;
-    if (i_first >= n_rows) return;
+    // interleave so that the long rows at the end are spread over all of them
+    // position -> row -> row pointers -> entries is three dependent loads: the row of the position after next and the pointers
+    // of the next row are fetched while this row is multiplied (positions past the end are clamped: loaded, never used)
+    const uint64_t stride = n_wg * kGroups, i_first = wg * kGroups + threadIdx.x / Q, last = n_rows ? n_rows - 1 : 0;
     auto row_at = [&](uint64_t i) -> uint64_t {
-        const uint64_t c = i < n_rows ? i : last_row;
+        const uint64_t c = i < n_rows ? i : last;
         return perm ? (uint64_t)perm[c] : c;
     };
-    struct Batch { GramPk<VT> r[kSub][4]; };
-    auto load_batch = [&](Batch& b, const GramPk<VT>* base /* the row's records */, int st, int n) {
+    uint64_t row = row_at(i_first), row_n = row_at(i_first + stride);
+    int64_t lo = n_rows ? rm_ptr[row] : 0, hi = n_rows ? rm_ptr[row + 1] : 0;
+    for (uint64_t i = i_first; i < n_rows; i += stride) {
+        const int64_t lo_n = rm_ptr[row_n], hi_n = rm_ptr[row_n + 1];
+        const uint64_t row_nn = row_at(i + 2 * stride);
+        const int n = (int)(hi - lo);
+        const GramPk<VT>* rr = rm + lo;
+        const uint64_t row_c = row;
+        row = row_n;
+        row_n = row_nn;
+        lo = lo_n;
+        hi = hi_n;
+        PT a0 = PT(0), a1 = PT(0), a2 = PT(0), a3 = PT(0);
+        // a chunk = 4 Q consecutive records of the row: lane ql holds records 4 ql .. 4 ql + 3 (one 32- / 64-byte load per
+        // lane), and the next chunk's load is in flight while this one's 4 Q records are broadcast and multiplied — with one
+        // Q-record step per load the loop ran at one memory round trip per step
+        struct Chunk { GramPk<VT> r[4]; };
+        auto load_chunk = [&](int at) {
+            Chunk c;
 #pragma unroll
-        for (int c = 0; c < kSub; ++c) {
-            // (a chunk past the row's end is not fetched: its lanes read the row's first chunk again)
-            const GramPk<VT>* at = st + c * 4 * Q < n ? base + st + c * 4 * Q : base;
+            for (int u = 0; u < 4; ++u) c.r[u] = rr[at + ql * 4 + u];        // (the array is padded by a wave of records)
+            return c;
+        };
+        Chunk cur = load_chunk(0);
+        for (int st = 0; st < n; st += 4 * Q) {
+            const Chunk nxt = load_chunk(st + 4 * Q);
+            // all 4 Q panel reads of the chunk first (their addresses only need the broadcast columns), then the 4 Q x 4
+            // multiply-adds: with read and use interleaved step by step the wave sat out an LDS round trip per entry
+            Vec4<PT> pv[4 * Q];
+            bool in_range[4 * Q];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) b.r[c][u] = at[ql * 4 + u];    // (the array is padded by a wave of records)
-        }
-    };
-    uint64_t i = i_first;
-    // position -> row -> row pointers -> records is three dependent loads: the pointers of the next row are resident, those of
-    // the row after it and the row of the position behind that one were asked for a row ago (a step selects between "this
-    // row's next batch" and "the next row's first" — it needs the next row's pointers at once)
-    uint64_t row_c = row_at(i), row_n = row_at(i + stride), row_nn = row_at(i + 2 * stride), row_n3 = row_at(i + 3 * stride);
-    int64_t lo = rm_ptr[row_c];
-    int n = (int)(rm_ptr[row_c + 1] - lo);
-    int64_t lo_n = rm_ptr[row_n], hi_n = rm_ptr[row_n + 1];
-    int64_t lo_nn = rm_ptr[row_nn], hi_nn = rm_ptr[row_nn + 1];
-    const GramPk<VT>* rr = rm + lo;
-    int st = 0;
-    PT a0 = PT(0), a1 = PT(0), a2 = PT(0), a3 = PT(0), ax = PT(0);
-    bool done = false;
-#ifdef SPMM_TIMING
-    long long tW = 0, tM = 0, tO = 0, tRows = 0, tBatches = 0;
-#define SPMM_STAMP(x) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(0) : "memory"); const long long x = wall_clock64();
-#endif
-    struct Out { uint64_t row; PT o[4]; PT x; };
-    auto store_row = [&](const Out& q) {
-        const PT o0 = q.o[0], o1 = q.o[1], o2 = q.o[2], o3 = q.o[3], ox = q.x;
-        const uint64_t row_o = q.row;
-#ifdef SPMM_NOSTORE
-        if (o0 == PT(123456.0))
-#endif
-        if (scores) {
-            if constexpr (CL == 5) {
-                if (colx < n_cols) {
-                    double* dx = scores + row_o * (uint64_t)ld + colx;
-                    *dx = RANGE && accumulate ? *dx + (double)ox : (double)ox;
+            for (int s_ = 0; s_ < 4 * Q; ++s_) {
+                int j = quad_bcast<Q>(cur.r[s_ & 3].j, s_ >> 2);
+                in_range[s_] = true;
+                if constexpr (RANGE) {
+                    in_range[s_] = j >= k_lo && j < k_hi;
+                    j = in_range[s_] ? j - k_lo : 0;
                 }
+                pv[s_].load(panel_q + (size_t)j * ldp);
             }
-            double* dst = scores + row_o * (uint64_t)ld + col0;
-            if (!(RANGE && accumulate) && col0 + 3 < n_cols && ld % 2 == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0) {
-                // four doubles as two 16-byte stores.  (Non-temporal stores: 0.79 against 0.68 ms — the pieces of a row written
-                // by the slices' workgroups meet in L2.  Lanes owning the column pairs {2q, 2q + 1} and {2Q + 2q, ..} so that a
-                // store instruction covers 64 contiguous bytes per row, and record loads laid out the same way: no change.)
-                *reinterpret_cast<double2*>(dst) = double2{(double)o0, (double)o1};
-                *reinterpret_cast<double2*>(dst + 2) = double2{(double)o2, (double)o3};
-            } else if (RANGE && accumulate) {
+#pragma unroll
+            for (int s_ = 0; s_ < 4 * Q; ++s_) {
+                PT v = (PT)quad_bcast_v<Q>(cur.r[s_ & 3].v, s_ >> 2);
+                if (st + s_ >= n || !in_range[s_]) v = PT(0);   // past the row's end (j is then a valid column of a later row)
+                a0 += v * pv[s_][0];
+                a1 += v * pv[s_][1];
+                a2 += v * pv[s_][2];
+                a3 += v * pv[s_][3];
+            }
+            cur = nxt;
+        }
+        PT o0 = a0 - cv4[0], o1 = a1 - cv4[1], o2 = a2 - cv4[2], o3 = a3 - cv4[3];
+        if (RANGE && accumulate) { o0 = a0; o1 = a1; o2 = a2; o3 = a3; }      // (the centring term went in with the first range)
+        if (scores) {
+            double* dst = scores + row_c * (uint64_t)ld + col0;
+            if (RANGE && accumulate) {
                 if (col0 + 0 < n_cols) dst[0] += (double)o0;
                 if (col0 + 1 < n_cols) dst[1] += (double)o1;
                 if (col0 + 2 < n_cols) dst[2] += (double)o2;
@@ -1011,137 +985,14 @@ __global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
         } else {
             Vec4<PT> o;
             if (RANGE && accumulate) {
-                o.load(Y + row_o * L + col0);
+                o.load(Y + row_c * L + col0);
                 o[0] += o0; o[1] += o1; o[2] += o2; o[3] += o3;
             } else {
                 o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
             }
-            o.store(Y + row_o * L + col0);
-            if constexpr (CL == 5) {
-                PT* yx = Y + row_o * L + colx;
-                *yx = RANGE && accumulate ? *yx + ox : ox;
-            }
+            o.store(Y + row_c * L + col0);
         }
-    };
-    // one batch: fetch the following one into `nxt`, multiply `cur`, finish the row if this was its last batch
-    auto step = [&](const Batch& cur, Batch& nxt) {
-        const bool last = st + kBatch >= n;
-        load_batch(nxt, last ? rm + lo_n : rr, last ? 0 : st + kBatch, last ? (int)(hi_n - lo_n) : n);
-        // the loads stay HERE (`rm` is not `__restrict__`: a load nothing can alias may be moved across this barrier, and the
-        // compiler then sinks it to its first use — behind the multiplication)
-        asm volatile("" ::: "memory");
-#ifdef SPMM_TIMING
-        const long long t1 = wall_clock64();
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kSub * (int)sizeof(GramPk<VT>) / 8) : "memory");   // cur is here
-        const long long t2 = wall_clock64();
-        tW += t2 - t1;
-        ++tBatches;
-#endif
-#pragma unroll
-        for (int c = 0; c < kSub; ++c) {
-            const int s0 = st + c * 4 * Q;
-            if (s0 >= n && c > 0) break;
-#ifdef SPMM_NOMUL
-            a0 += (PT)cur.r[c][0].v + (PT)cur.r[c][1].j + (PT)cur.r[c][2].v + (PT)cur.r[c][3].v;
-            continue;
-#endif
-            // the lane's own four records: byte offset of the gene in the slice, value zeroed past the row's end (the
-            // column is then a valid one of a later row, or of the zeroed tail) or outside the launch's gene range
-            int off[4];
-            PT val[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int j = cur.r[c][u].j;
-                bool ok = s0 + ql * 4 + u < n;
-                if constexpr (RANGE) {
-                    const bool in = j >= k_lo && j < k_hi;
-                    ok = ok && in;
-                    j = in ? j - k_lo : 0;
-                }
-                off[u] = j * kGeneBytes;
-                val[u] = ok ? (PT)cur.r[c][u].v : PT(0);
-            }
-            // kDeep panel reads first (their addresses only need the broadcast offsets), then their multiply-adds; the barrier
-            // keeps the scheduler from re-interleaving them two deep to save registers
-            constexpr int kDeep = sizeof(PT) == 4 ? (CL == 4 ? 4 * Q : 2 * Q) : (Q >= 2 ? 2 * Q : 4 * Q);
-#pragma unroll
-            for (int h = 0; h < 4 * Q; h += kDeep) {
-                Vec4<PT> pv[kDeep];
-                PT px[kDeep];
-#pragma unroll
-                for (int s_ = 0; s_ < kDeep; ++s_) {
-                    const int o = quad_bcast<Q>(off[(h + s_) & 3], (h + s_) >> 2);
-                    pv[s_].load(reinterpret_cast<const PT*>(panel_q + o));
-                    if constexpr (CL == 5) px[s_] = *reinterpret_cast<const PT*>(panel_x + o);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int s_ = 0; s_ < kDeep; ++s_) {
-                    const PT v = quad_bcast_v<Q>(val[(h + s_) & 3], (h + s_) >> 2);
-                    a0 += v * pv[s_][0];
-                    a1 += v * pv[s_][1];
-                    a2 += v * pv[s_][2];
-                    a3 += v * pv[s_][3];
-                    if constexpr (CL == 5) ax += v * px[s_];
-                }
-            }
-        }
-#ifdef SPMM_TIMING
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const long long t3 = wall_clock64();
-        tM += t3 - t2;
-#endif
-        if (!last) {
-            st += kBatch;
-            return;
-        }
-        // (a register queue that sent the results of 2 / 4 rows out together changed nothing: it is not the stores' latency)
-        i += stride;
-        done = i >= n_rows;
-        {
-            Out q;
-            q.row = row_c;
-            q.o[0] = a0 - cv4[0]; q.o[1] = a1 - cv4[1]; q.o[2] = a2 - cv4[2]; q.o[3] = a3 - cv4[3];
-            q.x = ax - cvx;
-            if (RANGE && accumulate) { q.o[0] = a0; q.o[1] = a1; q.o[2] = a2; q.o[3] = a3; q.x = ax; }   // (the centring term went in with the first range)
-            store_row(q);
-        }
-        // next row
-        row_c = row_n;
-        lo = lo_n;
-        n = (int)(hi_n - lo_n);
-        rr = rm + lo;
-        st = 0;
-        a0 = a1 = a2 = a3 = ax = PT(0);
-        row_n = row_nn;
-        lo_n = lo_nn;
-        hi_n = hi_nn;
-        row_nn = row_n3;
-        lo_nn = rm_ptr[row_nn];
-        hi_nn = rm_ptr[row_nn + 1];
-        row_n3 = row_at(i + 3 * stride);
-#ifdef SPMM_TIMING
-        tO += wall_clock64() - t3;
-        ++tRows;
-#endif
-    };
-    Batch A, B;
-    load_batch(A, rr, 0, n);
-#ifdef SPMM_TIMING
-    const long long tk0 = wall_clock64();
-#endif
-    for (;;) {
-        step(A, B);
-        if (done) break;
-        step(B, A);
-        if (done) break;
     }
-#ifdef SPMM_TIMING
-    if (threadIdx.x % 64 == 0 && (threadIdx.x / 64) % 5 == 0 && blockIdx.x % 67 == 0 && tRows)
-        printf("[spmm timing blk %d wave %d] rows %lld, %.2f batches per row, %.0f ns per row: waiting for the batch %.0f, multiply %.0f, output + next pointers (issue) %.0f\n",
-               (int)blockIdx.x, (int)(threadIdx.x / 64), tRows, (double)tBatches / tRows, (wall_clock64() - tk0) * 10.0 / tRows,
-               tW * 10.0 / tRows, tM * 10.0 / tRows, tO * 10.0 / tRows);
-#endif
 }
 
 // ---- transposed SpMM: T = A^T Y (k x l), s = 1^T Y ---------------------------------------------
@@ -2793,54 +2644,44 @@ template <typename VT, typename PT>
 static int32_t launch_fwd_rows(srx_ctx* ctx, const RowMajor& r, const PT* P, const PT* cvec, int n_cols, double* scores, PT* Y,
                                int ld) {
     const int Qr = fwd_rows_q<PT>(r.k);
-    auto go = [&](auto qtag, auto rtag, auto cltag, int k_lo, int k_hi, int accumulate) -> int32_t {
+    auto go = [&](auto qtag, auto rtag, int k_lo, int k_hi, int accumulate) -> int32_t {
         constexpr int Q = decltype(qtag)::value;
         constexpr bool RANGE = decltype(rtag)::value;
-        constexpr int CL = decltype(cltag)::value;
-        constexpr int C = CL * Q;
+        constexpr int C = 4 * Q;
         const int n_slices = (n_cols + C - 1) / C;
-        // (a gene's 16 f32 columns are 64 bytes, so every 16-byte read of a wave's 16 cells starts in bank 0 or 16: half of
-        //  the LDS pipe's time goes to bank conflicts, profiles/r03_pmc_spmm.md.  A padded stride of 80 bytes was measured:
-        //  0.746 against 0.745 ms — the multiplication is hidden behind the kernel's reads and stores either way)
+        // (a gene's C = 16 f32 columns are 64 bytes, so every 16-byte read of a wave's 16 cells starts in bank 0 or 16: half of
+        //  the LDS pipe's time goes to bank conflicts, profiles/r03_pmc_spmm.md.  A padded stride of 80 bytes — eight different
+        //  bank offsets, k <= 2047 — was measured: 0.746 against 0.745 ms.  The pipe is 51 % busy either way; the kernel waits
+        //  on its dependent DPP -> address -> LDS -> FMA chains at four waves per SIMD, not on LDS bandwidth.)
         const int ldp = C;
         const size_t lds = (size_t)(k_hi - k_lo) * ldp * sizeof(PT);
         const uint64_t groups = kFwdRowsThreads / Q;
         uint64_t n_wg = (r.n_rows + groups - 1) / groups;
-        uint64_t cap = std::max<uint64_t>(1, (uint64_t)ctx->n_cus / n_slices);      // one workgroup per CU
-        if (cap > 8) cap &= ~(uint64_t)7;           // (whole rounds of the 8 XCDs: the slices of a row range share an L2)
+        const uint64_t cap = std::max<uint64_t>(1, (uint64_t)ctx->n_cus / n_slices);      // one workgroup per CU
         if (n_wg > cap) n_wg = cap;
         if (n_wg < 1) n_wg = 1;
         const double out_bytes = scores ? (double)r.n_rows * n_cols * 8.0 : (double)r.n_rows * L * sizeof(PT);
         ProfScope ps(ctx, SRX_K_SPMM_FWD, (double)r.nnz * sizeof(GramPk<VT>) + (double)(r.n_rows + 1) * 8.0 + out_bytes +
                                               (double)(k_hi - k_lo) * L * sizeof(PT) + (r.perm ? (double)r.n_rows * 4.0 : 0.0));
-        SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_spmm_rows<VT, PT, Q, RANGE, CL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_spmm_rows<VT, PT, Q, RANGE, CL>), dim3((unsigned)(n_wg * n_slices)), dim3(kFwdRowsThreads), lds, ctx->stream,
-                           r.ptr, (const GramPk<VT>*)r.pk, (const uint32_t*)r.perm, r.n_rows, r.k, P, cvec, n_cols, scores, Y, ld, ldp,
-                           k_lo, k_hi, accumulate, 0);
+        SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_spmm_rows<VT, PT, Q, RANGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_spmm_rows<VT, PT, Q, RANGE>), dim3((unsigned)(n_wg * n_slices)), dim3(kFwdRowsThreads), lds, ctx->stream, r.ptr,
+                           (const GramPk<VT>*)r.pk, (const uint32_t*)r.perm, r.n_rows, r.k, P, cvec, n_cols, scores, Y, ld, ldp,
+                           k_lo, k_hi, accumulate);
         SRX_HIP(ctx, hipGetLastError());
         return SRX_OK;
     };
     using No = std::false_type;
     using Yes = std::true_type;
-    using C4 = std::integral_constant<int, 4>;
-    using C5 = std::integral_constant<int, 5>;
-    // five columns per lane where the wider slice fits the LDS, saves a pass over the matrix (n_pc = 50: 3 slices of 20 instead
-    // of 4 of 16; 5 of 10 instead of 7 of 8 with f64 panels) and stays inside the panel's 64 columns
-    constexpr int Qmax = sizeof(PT) == 4 ? 4 : 2;
-    const int wide_slices = (n_cols + 5 * Qmax - 1) / (5 * Qmax), narrow_slices = (n_cols + 4 * Qmax - 1) / (4 * Qmax);
-    const bool wide = Qr == Qmax && (size_t)r.k * 5 * Qmax * sizeof(PT) <= (size_t)163840 && wide_slices < narrow_slices &&
-                      wide_slices * 5 * Qmax <= L && !getenv("SRX_FWD_NARROW");
-    if (wide) return go(std::integral_constant<int, Qmax>{}, No{}, C5{}, 0, r.k, 0);
     if (Qr == 4) {
-        if constexpr (sizeof(PT) == 4) return go(std::integral_constant<int, 4>{}, No{}, C4{}, 0, r.k, 0);
+        if constexpr (sizeof(PT) == 4) return go(std::integral_constant<int, 4>{}, No{}, 0, r.k, 0);
         else return SRX_E_ARG;
     }
-    if (Qr == 2) return go(std::integral_constant<int, 2>{}, No{}, C4{}, 0, r.k, 0);
-    if (Qr == 1) return go(std::integral_constant<int, 1>{}, No{}, C4{}, 0, r.k, 0);
+    if (Qr == 2) return go(std::integral_constant<int, 2>{}, No{}, 0, r.k, 0);
+    if (Qr == 1) return go(std::integral_constant<int, 1>{}, No{}, 0, r.k, 0);
     // wider than one slice of four columns: gene ranges of the widest slice, one launch each, the later ones accumulating
     const int per = (int)((163840 - 64) / (4 * sizeof(PT)));
     for (int k_lo = 0, i = 0; k_lo < r.k; k_lo += per, ++i)
-        SRX_TRY(go(std::integral_constant<int, 1>{}, Yes{}, C4{}, k_lo, std::min(r.k, k_lo + per), i > 0 ? 1 : 0));
+        SRX_TRY(go(std::integral_constant<int, 1>{}, Yes{}, k_lo, std::min(r.k, k_lo + per), i > 0 ? 1 : 0));
     return SRX_OK;
 }
 
