@@ -58,7 +58,10 @@ ROOF_NOTE = {
                    "offsets this kernel reads besides are `aux_bytes_per_launch`.  Not an HBM-bound kernel: N m(m+1)/2 = 3.4e9 scalar "
                    "products per launch at c3, each one lane of an f64 LDS atomic (LDS pipe 72 % busy, 14 clk per ~34-lane "
                    "instruction) fed by one gathered 8-byte operand (every row suffix is re-read once per kept entry of its "
-                   "row: 19 GB of L2 requests, 11-19 GB through the fabric per launch) — profiles/r02_pmc_gram.md",
+                   "row: 19 GB of L2 requests, 11-19 GB through the fabric per launch) — profiles/r02_pmc_gram.md.  Round 3 knock-outs "
+                   "(DESIGN.md section 3c): without the atomics 3.73 of 3.91 ms, without atomics and suffix loads 3.11 (13-14 scalar "
+                   "instructions per record on the CU's one scalar unit); an inline-asm core with 5 of them: 3.92 ms, and 1.99 without "
+                   "its suffix loads — the launch is its 2.98e8 L1->L2 requests, 0.125 per clock and CU",
     "spmm_fwd": "algorithmic bytes: the row-major compacted matrix (nnz_w * 8) + row pointers and row order (N * 12) + the "
                 "k x 64 f32 panel once per workgroup column slice + the output, which for this launch (the transform) is the "
                 "N x n_pc f64 score matrix written by the SpMM itself.  What bounds it, by knock-out builds of the kernel "
