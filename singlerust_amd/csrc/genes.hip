@@ -80,8 +80,23 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     for (int g = threadIdx.x; g < tile_genes; g += kMomThreads) { s_sum[g] = 0.0; s_sq[g] = 0.0; s_cnt[g] = 0u; }
     __syncthreads();
 
-    const int tile = blockIdx.x % n_tiles;
-    const uint64_t rb = blockIdx.x / n_tiles;
+    // The gene tiles of one row block run on the SAME XCD (consecutive workgroup ids go round the 8 XCDs): a row's tile segments
+    // share their boundary cache lines — read by two tiles, and each tile's in-place stores cover only part of them — and
+    // with the tiles on four different L2s every such line was fetched (and, written, merged) once per tile: 15.7 GB of HBM
+    // traffic for 10.9 GB of data (profiles/r03_traffic_c3.json).
+    int tile;
+    uint64_t rb;
+    {
+        const uint64_t n_rb = gridDim.x / (unsigned)n_tiles;
+        if (n_rb % 8 == 0) {
+            const uint64_t slot = blockIdx.x / 8;
+            tile = (int)(slot % (unsigned)n_tiles);
+            rb = (slot / (unsigned)n_tiles) * 8 + blockIdx.x % 8;
+        } else {
+            tile = blockIdx.x % n_tiles;
+            rb = blockIdx.x / n_tiles;
+        }
+    }
     const int32_t gbase = tile * tile_genes;
     const uint64_t r0 = rb * rows_per_block;
     const uint64_t r1 = r0 + rows_per_block < n_rows ? r0 + rows_per_block : n_rows;
@@ -96,7 +111,10 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     // of accumulators allow 16 waves per CU, so a wave keeps kMomRows row segments in flight (pointer loads
     // of all of them, then data loads of all of them, then the atomics): with one segment per wave only
     // ~20 KB per CU were outstanding against the ~60 KB that HBM latency x bandwidth asks for.
-    constexpr int kMomRows = 4;
+#ifndef MOM_ROWS
+#define MOM_ROWS 4
+#endif
+    constexpr int kMomRows = MOM_ROWS;
     struct Chunk {
         int gg[4];
         T v[4];
@@ -137,9 +155,14 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const double x = (double)c.v[j] * scale;
+#ifdef MOM_NOLOG
+                y4[j] = x * 0.125;
+                continue;
+#endif
                 if constexpr (sizeof(T) == 4) y4[j] = log1p_f64_moment_common(x, s_tab);
                 else y4[j] = log1p_f64_fast(x, s_tab);
             }
+#ifndef MOM_NOLOG
             if constexpr (sizeof(T) == 4) {
                 bool any_rare = false;
 #pragma unroll
@@ -152,7 +175,11 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
                     }
                 }
             }
+#endif
         }
+#ifdef MOM_NOWB
+        if (y4[0] == 123.456)
+#endif
         if constexpr (XF && WB) {
             // the chunk's values go back as one 16-byte store (two for f64) when all four belong to the segment
             T o[4];
@@ -191,6 +218,10 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
                     // (a poisoned value adds nothing while the reduction still takes its magic bits off: the gene's sums are
                     //  replaced by NaN anyway)
                     if constexpr (COUNT) __hip_atomic_fetch_add(&s_cnt[g0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef MOM_NOATOM
+                    if (is + iq == 12345ull) s_sum[g0] = 1.0;
+                    continue;
+#endif
                     __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&s_sum[g0]), is, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&s_sq[g0]), iq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     continue;
@@ -434,11 +465,75 @@ __global__ void k_narrow16(const int32_t* __restrict__ idx, uint64_t nnz, uint64
     for (; e < n_out; e += stride) out[e] = e < nnz ? (uint16_t)idx[e] : (uint16_t)0;
 }
 
+// Both pattern-only structures of a fresh CSR matrix in ONE walk over its 32-bit column indices: the 16-bit mirror and the
+// NB = n_tiles - 1 interior gene-tile cuts of every row.  A wave per row, 256 entries per step; a row is sorted by column, so
+// the cut at `bound` is the row's start + the number of entries below it = the popcounts of the waves' `idx < bound` ballots
+// (scalar instructions; no search, no second pass).  k_tile_ptr's binary searches + k_narrow16 read the indices twice and
+// moved 10.9 GB at c3 (2.3 ms of a cold step's 14.7); this moves 6.6.
+template <int NB>
+__global__ __launch_bounds__(256) void k_narrow16_tiles(const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx,
+                                                        uint64_t n_rows, int tile_genes, uint16_t* __restrict__ out,
+                                                        int64_t* __restrict__ tp) {
+    const int lane = lane_id();
+    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x / kWave);
+    constexpr int kU = 4;
+    for (uint64_t r = global_wave_id(); r < n_rows; r += n_waves) {
+        const int64_t lo = indptr[r], hi = indptr[r + 1];
+        int cnt[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) cnt[b] = 0;
+        for (int64_t e0 = lo; e0 < hi; e0 += kU * kWave) {
+            int32_t v[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int64_t e = e0 + u * kWave + lane;
+                v[u] = e < hi ? idx[e] : 0x7fffffff;
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int64_t e = e0 + u * kWave + lane;
+                if (e < hi) out[e] = (uint16_t)v[u];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) cnt[b] += __popcll(__ballot(v[u] < (b + 1) * tile_genes));
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) tp[(uint64_t)b * n_rows + r] = lo + cnt[b];
+        }
+    }
+    // (the 16 padding entries behind the last non-zero)
+    if (blockIdx.x == 0 && threadIdx.x < 16) out[indptr[n_rows] + threadIdx.x] = (uint16_t)0;
+}
+
 int32_t ensure_tiles(srx_mat* m) {
     srx_ctx* ctx = m->ctx;
     if (m->n_tiles) return SRX_OK;
     int nt, tg;
     tile_geometry(m, nt, tg);
+    if (nt > 1 && nt <= 9 && m->n_cols <= 65536 && !m->d_idx16 && !m->d_tile_ptr && m->n_rows > 0 && !getenv("SRX_TILES_TWO_PASS")) {
+        SRX_HIP(ctx, dev_malloc(ctx, (void**)&m->d_tile_ptr, (size_t)(nt - 1) * m->n_rows * sizeof(int64_t)));
+        SRX_HIP(ctx, dev_malloc(ctx, (void**)&m->d_idx16, (m->nnz + 16) * sizeof(uint16_t)));
+        const unsigned g = (unsigned)std::min<uint64_t>((m->n_rows + 3) / 4, (uint64_t)ctx->n_cus * 32);
+        auto go = [&](auto nb) {
+            hipLaunchKernelGGL(k_narrow16_tiles<decltype(nb)::value>, dim3(g ? g : 1), dim3(256), 0, ctx->stream, m->d_indptr, m->d_indices,
+                               m->n_rows, tg, m->d_idx16, m->d_tile_ptr);
+        };
+        switch (nt - 1) {
+            case 1: go(std::integral_constant<int, 1>{}); break;
+            case 2: go(std::integral_constant<int, 2>{}); break;
+            case 3: go(std::integral_constant<int, 3>{}); break;
+            case 4: go(std::integral_constant<int, 4>{}); break;
+            case 5: go(std::integral_constant<int, 5>{}); break;
+            case 6: go(std::integral_constant<int, 6>{}); break;
+            case 7: go(std::integral_constant<int, 7>{}); break;
+            default: go(std::integral_constant<int, 8>{}); break;
+        }
+        SRX_HIP(ctx, hipGetLastError());
+        m->n_tiles = nt;
+        m->tile_genes = tg;
+        return SRX_OK;
+    }
     if (nt > 1) {
         SRX_HIP(ctx, dev_malloc(ctx, (void**)&m->d_tile_ptr, (size_t)(nt - 1) * (m->n_rows ? m->n_rows : 1) * sizeof(int64_t)));
         SRX_TRY(launch_tile_ptr(ctx, m->d_indptr, m->d_indices, m->n_rows, nt, tg, m->d_tile_ptr));

@@ -234,6 +234,7 @@ __global__ __launch_bounds__(kJ2Threads) void k_jacobi_eig2(const double* __rest
 
     bool converged = false;
     int par = 0;                          // parity of the running round counter g = 63 * sweep + r
+    // (s_setprio 3 for wave 0, the round's critical path: 184.1 against 183.9 us — the waves sit on different SIMDs)
     if (wave < kJ2BWaves) {
         // ---- B: wave 0 takes blocks 0 .. 63 of the table (one per lane), waves 1 .. 4 the other 432 (two per thread);
         // everything below is fixed for the life of the kernel ----
