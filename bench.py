@@ -67,8 +67,8 @@ ROOF_NOTE = {
                 "N x n_pc f64 score matrix written by the SpMM itself.  What bounds it, by knock-out builds of the kernel "
                 "(round 3, DESIGN.md section 3c): without the multiplication (LDS reads + FMAs) the launch takes the SAME time, "
                 "without the score stores 0.45 instead of 0.65 ms — the arithmetic is hidden; the kernel is its ~0.45 ms of record "
-                "and pointer reads (one pass over the matrix per 20-column panel slice: 3 passes, 85 % L2 hits, per-CU L1-miss "
-                "throughput) plus ~0.2 ms of scattered 160-byte score-row pieces",
+                "and pointer reads (one pass over the matrix per 16-column panel slice: 4 passes, 85 % L2 hits, per-CU L1-miss "
+                "throughput) plus ~0.2 ms of scattered 128-byte score-row pieces",
 }
 
 

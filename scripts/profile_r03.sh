@@ -10,6 +10,7 @@ python profiles/make_traffic.py gpurun_out/r3p/pf/c3_results.db gpurun_out/r3p/p
 python profiles/timeline_rocpd.py gpurun_out/r3p/kt/c3_results.db k_row_sum > gpurun_out/r3p/timeline_c3.md
 bash scripts/pmc_gram.sh k_gram_stripes > gpurun_out/r3p/pmc_gram.txt 2>&1
 bash scripts/pmc_gram.sh k_gene_moments > gpurun_out/r3p/pmc_moments.txt 2>&1
+bash scripts/pmc_kernel.sh k_spmm_rows > gpurun_out/r3p/pmc_spmm_rows.txt 2>&1
 tail -3 gpurun_out/r3p/kt_bench.json | cut -c1-400
 head -30 gpurun_out/r3p/rocprof_c3_table.md
 rm -rf gpurun_out/r3p/kt gpurun_out/r3p/pf gpurun_out/r3p/pw gpurun_out/pmcg*
