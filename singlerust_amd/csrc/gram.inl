@@ -1,0 +1,430 @@
+// gram.inl — included by pca.hip inside namespace srx (one translation unit: the kernels share its helpers and constants).
+// G = A^T A from the row-major compacted matrix: record counts, owner buckets, the stripe kernel, expansion to C.
+
+// ---- explicit sparse Gram: G = A^T A from the ROW-MAJOR compacted matrix ----------------------------
+// Round 2 design.  The work is N m(m+1)/2 scalar products (m = kept entries of a cell), each ending in an
+// f64 LDS atomic; what the round-1 kernel paid on top of that was two staged LDS reads and ~17 VALU
+// instructions of index arithmetic per product slice, with 22-30 of 64 lanes busy per atomic
+// (profiles/r01_pmc_gram_v6.md).  Here ONE wave instruction is one (cell, entry): the entry (ja, va) and the
+// SUFFIX of its row — the entries with column >= ja, contiguous in the row-major layout — so that lane q
+// holds (jb_q, vb_q) straight from a coalesced global load and adds va * vb_q to G[ja][jb_q].  No staging,
+// no per-product index arithmetic, every cell's upper-triangle products exactly once.
+//
+// Ownership: G's upper triangle is cut into STRIPES of SR rows; workgroup w owns stripes w and
+// n_stripes - 1 - w (long rows at the top, short ones at the bottom: SR (k + SR) doubles of LDS per
+// workgroup whatever w — 64 KiB at k = 2000, SR = 4, two workgroups per CU).  The entries a workgroup needs
+// are those whose column lies in its two stripes: k_bucket sorts the entries of every block of kBucketRows
+// cells by owner, so that a wave fetches its share of a block as one contiguous run of 8-byte records
+// (position of the entry relative to the block, suffix length).  All workgroups walk the row blocks in the
+// same order at about the same pace, so the row-major matrix streams through L2 / Infinity Cache once per
+// XCD while every cell is visited by the ~m workgroups that own one of its entries.
+template <typename VT> struct GramPk;
+__device__ __forceinline__ double gram_product(float a, float b) { return (double)(a * b); }
+__device__ __forceinline__ double gram_product(double a, double b) { return a * b; }
+
+// Records of a block of `rblk` cells, grouped by owning workgroup (counting sort in LDS; the order inside a group is
+// whatever the LDS atomics make it — the Gram sums are order-dependent in their last bits anyway).
+// boff[rb][w] .. boff[rb][w + 1]: records of owner w, relative to the block's first record (rec_base[rb]).
+constexpr int kBucketThreads = 1024;
+constexpr int kBucketGroup = 8;           // consecutive rows a wave walks as one flat run
+constexpr int kBucketUnroll = 8;          // 64-entry chunks of the run in flight
+
+// per-block record totals (k_bucket's layout needs their prefix sums before it runs)
+__global__ __launch_bounds__(256) void k_rec_count(const int64_t* __restrict__ rm_ptr, uint64_t n_rows, uint32_t rblk,
+                                                   int64_t* __restrict__ blk_total) {
+    const uint64_t r0 = (uint64_t)blockIdx.x * rblk;
+    const uint64_t r1 = r0 + rblk < n_rows ? r0 + rblk : n_rows;
+    uint64_t acc = 0;
+    for (uint64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) acc += gram_row_records((uint64_t)(rm_ptr[r + 1] - rm_ptr[r]));
+    acc = wave_sum(acc);
+    __shared__ uint64_t part[4];
+    if (lane_id() == 0) part[threadIdx.x / kWave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) blk_total[blockIdx.x] = (int64_t)(part[0] + part[1] + part[2] + part[3]);
+}
+// exclusive scan of the block totals by one workgroup: base[0 .. n], base[n] = all records
+__global__ __launch_bounds__(1024) void k_rec_scan(const int64_t* __restrict__ blk_total, uint64_t n, int64_t* __restrict__ base) {
+    __shared__ int64_t wsum[16];
+    __shared__ int64_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = lane_id(), wave = threadIdx.x / kWave;
+    for (uint64_t i0 = 0; i0 < n; i0 += 1024) {
+        const uint64_t i = i0 + threadIdx.x;
+        const int64_t v = i < n ? blk_total[i] : 0;
+        int64_t inc = v;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const int64_t o = __shfl_up(inc, off, kWave);
+            if (lane >= off) inc += o;
+        }
+        if (lane == kWave - 1) wsum[wave] = inc;
+        __syncthreads();
+        int64_t before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (i < n) base[i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) base[n] = carry_s;
+}
+
+template <typename VT>
+__global__ __launch_bounds__(kBucketThreads) void k_bucket(const int64_t* __restrict__ rm_ptr, const GramPk<VT>* __restrict__ rm,
+                                                           uint64_t n_rows, uint32_t rblk, int k, int sr_shift, int n_wg, int n_stripes,
+                                                           const int64_t* __restrict__ rec_base, uint32_t* __restrict__ boff,
+                                                           GramRec<VT>* __restrict__ recs) {
+    extern __shared__ double lds_raw[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(lds_raw);        // n_wg + 1 counters, then rblk + 1 row ends
+    uint32_t* rptr = hist + n_wg + 1;                             // row starts of the block, relative to its first entry
+    const uint64_t rb = blockIdx.x;
+    const uint64_t r0 = rb * rblk;
+    const uint64_t r1 = r0 + rblk < n_rows ? r0 + rblk : n_rows;
+    const int nr = (int)(r1 - r0);
+    const int lane = lane_id(), wave = threadIdx.x / kWave;
+    const int64_t base = rm_ptr[r0];
+    for (int e = threadIdx.x; e <= n_wg; e += kBucketThreads) hist[e] = 0u;
+    for (int e = threadIdx.x; e <= nr + kBucketGroup; e += kBucketThreads)
+        rptr[e] = (uint32_t)(rm_ptr[r0 + (e < nr ? e : nr)] - base);          // padded by a group of empty rows
+    __syncthreads();
+    const GramPk<VT>* rmb = rm + base;
+    // A wave takes kBucketGroup consecutive rows at a time: their entries are one contiguous run, walked flat 64 at a time
+    // (coalesced), and the row of an entry is found by comparing with the group's three inner row starts — the suffix
+    // length of an entry (its record count) needs the row's end.  `visit(p, j, v, row_end)` for every entry of the block.
+    auto walk = [&](auto visit) {
+        for (int g0 = wave * kBucketGroup; g0 < nr; g0 += (kBucketThreads / kWave) * kBucketGroup) {
+            uint32_t b[kBucketGroup + 1];
+#pragma unroll
+            for (int i = 0; i <= kBucketGroup; ++i) b[i] = rptr[g0 + i];
+            for (uint32_t p0 = b[0]; p0 < b[kBucketGroup]; p0 += kBucketUnroll * kWave) {
+                GramPk<VT> x[kBucketUnroll];
+#pragma unroll
+                for (int u = 0; u < kBucketUnroll; ++u) {
+                    const uint32_t p = p0 + u * kWave + lane;
+                    x[u].j = -1;
+                    if (p < b[kBucketGroup]) x[u] = rmb[p];
+                }
+#pragma unroll
+                for (int u = 0; u < kBucketUnroll; ++u) {
+                    const uint32_t p = p0 + u * kWave + lane;
+                    if (x[u].j < 0) continue;
+                    uint32_t end = b[1];
+#pragma unroll
+                    for (int i = 1; i < kBucketGroup; ++i) end = p >= b[i] ? b[i + 1] : end;
+                    visit(p, x[u].j, x[u].v, end);
+                }
+            }
+        }
+    };
+    walk([&](uint32_t p, int j, VT, uint32_t end) {
+        __hip_atomic_fetch_add(&hist[gram_owner(j, sr_shift, n_wg, n_stripes)], (end - p + 63u) >> 6, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+    });
+    __syncthreads();
+    // exclusive scan of the n_wg counters by wave 0, 64 at a time
+    if (wave == 0) {
+        uint32_t carry = 0;
+        for (int c0 = 0; c0 < n_wg; c0 += kWave) {
+            const int i = c0 + lane;
+            const uint32_t v = i < n_wg ? hist[i] : 0u;
+            uint32_t inc = v;
+#pragma unroll
+            for (int off = 1; off < kWave; off <<= 1) {
+                const uint32_t o = __shfl_up(inc, off, kWave);
+                if (lane >= off) inc += o;
+            }
+            if (i < n_wg) {
+                hist[i] = carry + inc - v;
+                boff[rb * (uint64_t)(n_wg + 1) + i] = carry + inc - v;
+            }
+            carry += __shfl(inc, kWave - 1, kWave);
+        }
+        if (lane == 0) boff[rb * (uint64_t)(n_wg + 1) + n_wg] = carry;
+    }
+    __syncthreads();
+    GramRec<VT>* rcb = recs + rec_base[rb];
+    walk([&](uint32_t p, int j, VT v, uint32_t end) {
+        const uint32_t len = end - p, nch = (len + 63u) >> 6;
+        uint32_t slot = __hip_atomic_fetch_add(&hist[gram_owner(j, sr_shift, n_wg, n_stripes)], nch, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t rb8 = (uint32_t)gram_row_base(j, k, sr_shift, n_wg, n_stripes) << 8;
+        for (uint32_t o = 0; o < len; o += kWave, ++slot)
+            rcb[slot] = GramRec<VT>{p + o, (len - o < (uint32_t)kWave ? len - o : (uint32_t)kWave) | rb8, v};
+    });
+}
+
+__device__ __forceinline__ float readfirst_v(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+__device__ __forceinline__ double readfirst_v(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// entries [0, len) of `base`, lane l taking entry l; lanes >= len return zeros without touching memory
+__device__ __forceinline__ GramPk<float> suffix_load(const GramPk<float>* base, uint32_t len, int lane) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<GramPk<float>*>(base), (short)0, (int)(len * 8u), 0x00020000);
+    const auto x = __builtin_amdgcn_raw_buffer_load_b64(rs, lane * 8, 0, 0);
+    return GramPk<float>{(int)x[0], __builtin_bit_cast(float, (unsigned)x[1])};
+}
+__device__ __forceinline__ GramPk<double> suffix_load(const GramPk<double>* base, uint32_t len, int lane) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<GramPk<double>*>(base), (short)0, (int)(len * 16u), 0x00020000);
+    const auto x = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, 0, 0);
+    GramPk<double> e;
+    e.j = (int)x[0];
+    e.pad_ = 0;
+    e.v = __builtin_bit_cast(double, ((unsigned long long)(unsigned)x[3] << 32) | (unsigned)x[2]);
+    return e;
+}
+
+// index of (i, j), i <= j, in the packed upper triangle (row-major, row i holds columns i .. k - 1)
+__host__ __device__ __forceinline__ size_t tri_index(int i, int j, int k) {
+    return (size_t)i * (size_t)k - (size_t)i * (size_t)(i - 1) / 2 + (size_t)(j - i);
+}
+
+template <typename VT>
+__global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
+    const int64_t* __restrict__ rm_ptr, const GramPk<VT>* __restrict__ rm, const uint32_t* __restrict__ boff,
+    const int64_t* __restrict__ rec_base, const GramRec<VT>* __restrict__ recs, uint64_t n_rblk, uint32_t rblk, int k,
+    int sr_shift, int n_wg, int n_stripes, uint32_t n_chunk, int w0 /* first owner of this launch */, int n_w /* owners in it */,
+    double* __restrict__ Gp /* packed upper triangle, ACCUMULATED into (global f64 atomics) */) {
+    using Entry = GramPk<VT>;
+    using Rec = GramRec<VT>;
+    // suffix loads in flight per batch: 16-byte f64 entries take twice the registers (8 of them spilled)
+    constexpr int kUnroll = sizeof(VT) == 8 ? kGramUnroll / 2 : kGramUnroll;
+    extern __shared__ double acc[];
+    const int w = w0 + blockIdx.x % n_w, z = blockIdx.x / n_w;
+    const int SR = 1 << sr_shift;
+    const int a0 = w * SR, b0 = (n_stripes - 1 - w) * SR;
+    const int WA = k - a0, WB = k - b0 > 0 ? k - b0 : 0;
+    const int n_acc = SR * (WA + WB);
+    for (int e = threadIdx.x; e < n_acc; e += blockDim.x) acc[e] = 0.0;
+    __syncthreads();
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    // Workgroup = (owner w, chunk z of n_chunk consecutive row blocks); blockIdx = z * n_wg + w, so the dispatcher starts
+    // all owners of a chunk together and they walk its rows in the same order: what one workgroup pulls into its
+    // XCD's L2 the ~60 others on that XCD hit (free-running persistent workgroups drift tens of MB apart: L2 hit rate
+    // 12 %, 50 GB of fabric reads per launch at c3).  Wave v takes blocks v, v + 16, ... of the chunk.
+    //
+    // A wave reads its records 64 at a time (one 12-byte vector load per lane, the slab after this one in flight while this
+    // one is worked through) and hands them out kUnroll at a time: v_readlane makes (pos, len, rbase, va) of a record
+    // wave-uniform, the suffix load takes (scalar base, 32-bit lane offset), and what is left per record is lane < len, the
+    // product, its conversion and the LDS address.  Two batches are in flight: one being fetched, one being added.
+    // (Records fetched by scalar loads, one batch ahead: the stream alone cost 3.1 ms — every batch a dependent round trip
+    // through the scalar cache; slabs fetched only when the previous one was used up: 4 of 5 slab loads exposed.)
+    struct Blk {
+        uint32_t n;
+        const Entry* rmb;
+        const Rec* rc;
+    };
+    const uint64_t rb0 = (uint64_t)z * n_chunk, rb1 = rb0 + n_chunk < n_rblk ? rb0 + n_chunk : n_rblk;
+    auto scalars = [&](uint64_t rb) -> Blk {
+        Blk k_{0u, rm, recs};
+        if (rb < rb1) {
+            const uint32_t* bo = boff + rb * (uint64_t)(n_wg + 1) + w;
+            const uint32_t o0 = bo[0], o1 = bo[1];
+            k_.n = o1 - o0;
+            k_.rmb = rm + rm_ptr[rb * rblk];
+            k_.rc = recs + rec_base[rb] + o0;
+        }
+        return k_;
+    };
+    uint64_t rb = rb0 + wave;
+    uint32_t i0 = 0;
+    Blk cur = scalars(rb), nxt = scalars(rb + kGramWaves);
+    struct Slab {                         // up to 64 records of one block, lane l holding record l
+        Rec r;
+        uint32_t n;
+        const Entry* rmb;
+    };
+    auto next_slab = [&]() -> Slab {
+        while (i0 >= cur.n && rb < rb1) {
+            rb += kGramWaves;
+            cur = nxt;
+            nxt = scalars(rb + kGramWaves);
+            i0 = 0;
+        }
+        Slab sl;
+        sl.rmb = cur.rmb;
+        sl.n = i0 < cur.n ? (cur.n - i0 < (uint32_t)kWave ? cur.n - i0 : (uint32_t)kWave) : 0u;
+        sl.r = Rec{0u, 0u, (VT)0};
+        if ((uint32_t)lane < sl.n) sl.r = cur.rc[i0 + lane];
+        i0 += kWave;
+        return sl;
+    };
+    struct Loaded {                       // a batch of records with their suffix entries on the way
+        Entry e[kUnroll];
+        uint32_t lenrb[kUnroll];
+        VT va[kUnroll];
+    };
+    auto batch = [&](const Slab& sl, int u0) -> Loaded {
+        Loaded l;
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {       // lanes past sl.n hold empty records: len 0, pos 0
+            const uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.pos, u0 + u);
+            l.lenrb[u] = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.lenrb, u0 + u);
+            l.va[u] = readlane_v(sl.r.va, u0 + u);
+            // a buffer load whose range is the suffix itself: lanes past `len` are out of range and fetch nothing (the L1
+            // works through a wave's load 64 bytes at a time — reading all 64 lanes of every ~36-entry suffix was 2 of the
+            // kernel's 4.2 ms), the address is (scalar base, constant lane offset), and there is no branch or exec mask
+            // around the load for the compiler's wait counting to trip over
+            l.e[u] = suffix_load(sl.rmb + pos, l.lenrb[u] & 0xffu, lane);
+        }
+        return l;
+    };
+    auto process = [&](const Loaded& l) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int rbase = (int)l.lenrb[u] >> 8;
+            const uint32_t len = l.lenrb[u] & 0xffu;
+            if ((uint32_t)lane < len)
+                __hip_atomic_fetch_add(&acc[rbase + l.e[u].j], gram_product(l.va[u], l.e[u].v), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    // All batches of slab `sl`, two in flight (ping-pong between two register sets: a `now = next` copy makes the compiler
+    // wait for next's loads).  The OTHER slab (used up before this one) is refilled right after this slab's first batch has
+    // gone out: when its records are first read, a slab later, every load issued after it has long been waited for — the
+    // compiler waits for ALL outstanding loads at that point (vmcnt is in order and it cannot count across the loop), so a
+    // refill issued last would be a full round trip exposed per slab.
+    auto consume = [&](const Slab& sl, Slab& other) {
+        const int n = (int)sl.n;
+        Loaded A = batch(sl, 0), B;
+        other = next_slab();
+#pragma unroll
+        for (int u0 = 0; u0 < kWave; u0 += 2 * kUnroll) {
+            // no branch around a batch's loads (slots past n are empty records, their loads hit the block's first line):
+            // after a conditional load the compiler's wait for A's entries also waits for B's
+            B = batch(sl, u0 + kUnroll);
+            process(A);
+            if (u0 + 2 * kUnroll < kWave) A = batch(sl, u0 + 2 * kUnroll);
+            process(B);
+            if (u0 + 2 * kUnroll >= n) break;
+        }
+    };
+    {
+        Slab S = next_slab(), T;
+        T.n = 0;
+        while (S.n > 0) {
+            consume(S, T);
+            if (T.n == 0) break;
+            consume(T, S);
+        }
+    }
+    __syncthreads();
+    // flush: the upper-triangle part of both stripes, added to the packed matrix (row splits and, in backed
+    // mode, earlier row tiles have been there before)
+    for (int e = threadIdx.x; e < SR * WA; e += blockDim.x) {
+        const int r = e / WA, c = a0 + e % WA, row = a0 + r;
+        const double v = acc[e];
+        if (row < k && c >= row && v != 0.0) atomicAdd(&Gp[tri_index(row, c, k)], v);
+    }
+    for (int e = threadIdx.x; e < SR * WB; e += blockDim.x) {
+        const int r = e / WB, c = b0 + e % WB, row = b0 + r;
+        const double v = acc[SR * WA + e];
+        if (row < k && c >= row && v != 0.0) atomicAdd(&Gp[tri_index(row, c, k)], v);
+    }
+}
+
+// C (k x k, both triangles) from the packed upper triangle: (i, j) and (j, i) read the same entry, so C is
+// EXACTLY symmetric (k_dense_apply reads it transposed).  With d != nullptr: C = D (G - cen N mu mu^T) D.
+__global__ void k_gram_expand(const double* __restrict__ P, int k, const double* __restrict__ d,
+                              const double* __restrict__ mu, int cen, double n_cells, double* __restrict__ C) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (uint64_t)k * k) return;
+    const int i = (int)(e / k), j = (int)(e % k);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    double g = P[tri_index(lo, hi, k)];
+    if (d) {
+        if (cen) g -= n_cells * (mu[i] * mu[j]);            // (mu_i mu_j) first: symmetric to the last bit
+        g = d[i] * d[j] * g;
+    }
+    C[e] = g;
+}
+
+// Wp += C[:, krange] W[krange, :] for the dense SYMMETRIC k x k matrix C and a k x 64 block (f64), on the
+// f64 matrix cores.  One wave = 32 output rows x 64 columns x one K slice: eight v_mfma_f64_16x16x4
+// accumulators.  Both operands are read straight from global memory in fragment order with no LDS
+// staging: lane l of the A fragment needs C[row0 + (l & 15)][kk + (l >> 4)], which by symmetry is
+// C[kk + (l >> 4)][row0 + (l & 15)] — 16 consecutive doubles per K index, fully coalesced; the B
+// fragment W[kk + (l >> 4)][16 t + (l & 15)] is coalesced as it stands.  The K slices (split-K 16 across
+// workgroups x 4 waves inside one: ~4000 waves for k = 2000) are combined in LDS, then with f64 atomics into the zeroed Wp.
+// C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg (not the f32 map).
+#ifndef SRX_DENSE_SPLIT          // measured at k = 2000 (split x waves: us): 16x4 21.8, 8x8 21.9, 8x4 18.8, 4x4 17.8, 4x8 17.5, 8x2 28.3, 4x16 36.3 —
+#define SRX_DENSE_SPLIT 4       // the f64 atomics into Wp (k x 64 x split) weigh more than the number of waves in flight
+#define SRX_DENSE_WAVES 8
+#endif
+constexpr int kDenseSplit = SRX_DENSE_SPLIT;
+constexpr int kDenseWaves = SRX_DENSE_WAVES;             // waves of a workgroup: consecutive quarters of the workgroup's K slice
+typedef double dvec4 __attribute__((ext_vector_type(4)));
+// Workgroup = 32 output rows x 64 columns x one K slice, its four waves on consecutive quarters of the slice (four waves per
+// SIMD keep ~4x the loads in flight: one wave per SIMD left the load latency of every group of 16 K indices exposed, 27 us
+// per application against ~7 us of MFMA time); the waves' partial tiles meet in LDS (ds_add_f64), then one f64 atomic per
+// output element and K slice into the zeroed Wp.
+__global__ __launch_bounds__(kDenseWaves * 64) void k_dense_apply(const double* __restrict__ C, const double* __restrict__ W, int k,
+                                                                  double* __restrict__ Wp) {
+    __shared__ double red[32][L];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int row0 = blockIdx.x * 32;
+    const int kchunk = (((k + kDenseSplit - 1) / kDenseSplit) + 4 * kDenseWaves - 1) / (4 * kDenseWaves) * (4 * kDenseWaves);      // per workgroup: waves x a multiple of 4
+    const int kq = kchunk / kDenseWaves;
+    const int kbeg = blockIdx.y * kchunk + wv * kq;
+    const int kend = kbeg + kq < k ? kbeg + kq : k;
+    for (int e = threadIdx.x; e < 32 * L; e += kDenseWaves * 64) (&red[0][0])[e] = 0.0;
+    dvec4 acc[2][4];
+#pragma unroll
+    for (int sI = 0; sI < 2; ++sI)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[sI][t] = dvec4{0.0, 0.0, 0.0, 0.0};
+    const bool r0ok = row0 + li < k, r1ok = row0 + 16 + li < k;
+    // groups of 4 K-steps (16 K indices), two register buffers: the 24 loads of group g+1 are in flight
+    // while the 32 MFMAs of group g issue
+    struct Frag { double a0[4], a1[4], bq[4][4]; };
+    auto load = [&](Frag& f, int kk) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kr = kk + 4 * u + lk;
+            const bool kok = kr < kend;
+            const double* crow = C + (size_t)(kok ? kr : 0) * k + row0 + li;
+            const double* wrow = W + (size_t)(kok ? kr : 0) * L + li;
+            f.a0[u] = (kok && r0ok) ? crow[0] : 0.0;
+            f.a1[u] = (kok && r1ok) ? crow[16] : 0.0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) f.bq[u][t] = kok ? wrow[16 * t] : 0.0;
+        }
+    };
+    auto fma = [&](const Frag& f) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a0[u], f.bq[u][t], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a1[u], f.bq[u][t], acc[1][t], 0, 0, 0);
+            }
+    };
+    Frag f0, f1;
+    load(f0, kbeg);
+    for (int kk = kbeg; kk < kend; kk += 32) {
+        load(f1, kk + 16);
+        fma(f0);
+        load(f0, kk + 32);
+        fma(f1);
+    }
+    __syncthreads();                             // (the tile is zeroed)
+    // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int sI = 0; sI < 2; ++sI)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) atomicAdd(&red[16 * sI + lk + 4 * v][16 * t + li], acc[sI][t][v]);
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * L; e += kDenseWaves * 64) {
+        const int r = row0 + e / L;
+        if (r < k) atomicAdd(&Wp[(size_t)r * L + (e % L)], (&red[0][0])[e]);
+    }
+}

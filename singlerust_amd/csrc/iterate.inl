@@ -1,0 +1,734 @@
+// iterate.inl — included by pca.hip inside namespace srx (one translation unit: the kernels share its helpers and constants).
+// Kernels of the k x 64 subspace iteration: dense application of C, CholeskyQR, Rayleigh-Ritz (jacobi.inl), Chebyshev filter, result assembly.
+
+// ---- k x l helper kernels (f64, replicated per rank) --------------------------------------------
+// P = PT(d .* W * sign), cvec = cen * mu^T P (exact f64 sum of the ROUNDED panel, so Y's column
+// sums vanish to rounding).
+template <typename PT>
+__global__ __launch_bounds__(1024) void k_make_panel(const double* __restrict__ W, const double* __restrict__ d,
+                                                     const double* __restrict__ mu, const double* __restrict__ sgn,
+                                                     int k, int cen, PT* __restrict__ P, PT* __restrict__ cvec) {
+    __shared__ double s_part[16][L];
+    const int c = threadIdx.x & (L - 1), part = threadIdx.x / L;   // 16 row slices x 64 columns
+    double acc = 0.0;
+    const double sg = sgn ? sgn[c] : 1.0;
+    for (int j = part; j < k; j += 16) {
+        PT p = (PT)(d[j] * W[(size_t)j * L + c] * sg);
+        P[(size_t)j * L + c] = p;
+        acc += mu[j] * (double)p;
+    }
+    s_part[part][c] = acc;
+    __syncthreads();
+    if (part == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += s_part[w][c];
+        cvec[c] = cen ? (PT)t : PT(0);
+    }
+}
+
+// The same for the END of a round, on many workgroups and with the round's bookkeeping folded in (one workgroup walking the
+// k x 64 block took 48 us, and three device-to-device copies and k_signs followed it): sign of each Ritz vector from its
+// largest entry, P = PT(d .* V * sign), per-block partial sums of mu^T P (k_cvec_reduce adds them in fixed order), and the
+// copy of the Ritz vectors, values and signs into the matrix's result block.
+constexpr int kPanelBlocks = 32;
+template <typename PT>
+__global__ __launch_bounds__(1024) void k_make_panel_mb(const double* __restrict__ W, const double* __restrict__ d,
+                                                        const double* __restrict__ mu, const double* __restrict__ colmax,
+                                                        const double* __restrict__ theta, int k, PT* __restrict__ P,
+                                                        double* __restrict__ part /* [blocks][64] */, double* __restrict__ sgn_out,
+                                                        double* __restrict__ blk /* k*64 vectors | 64 values | 64 signs */) {
+    __shared__ double s_part[16][L];
+    const int c = threadIdx.x & (L - 1), sl = threadIdx.x / L;   // 16 row slices x 64 columns
+    const double sg = colmax[c] < 0 ? -1.0 : 1.0;
+    if (blockIdx.x == 0 && sl == 0) {
+        sgn_out[c] = sg;
+        blk[(size_t)k * L + c] = theta[c];
+        blk[(size_t)k * L + L + c] = sg;
+    }
+    double acc = 0.0;
+    for (int j = blockIdx.x * 16 + sl; j < k; j += gridDim.x * 16) {
+        const double wv = W[(size_t)j * L + c];
+        blk[(size_t)j * L + c] = wv;
+        const PT p = (PT)(d[j] * wv * sg);
+        P[(size_t)j * L + c] = p;
+        acc += mu[j] * (double)p;
+    }
+    s_part[sl][c] = acc;
+    __syncthreads();
+    if (sl == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += s_part[w][c];
+        part[(size_t)blockIdx.x * L + c] = t;
+    }
+}
+template <typename PT>
+__global__ void k_cvec_reduce(const double* __restrict__ part, int n_blocks, int cen, PT* __restrict__ cvec) {
+    const int c = threadIdx.x;
+    double t = 0.0;
+    for (int b = 0; b < n_blocks; ++b) t += part[(size_t)b * L + c];
+    cvec[c] = cen ? (PT)t : PT(0);
+}
+
+// up to four small device-to-device copies in one launch (32-bit words)
+struct CopySegs {
+    const uint32_t* src[4];
+    uint32_t* dst[4];
+    uint32_t words[4];
+};
+__global__ void k_copy_segs(CopySegs sg) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        for (uint32_t e = t; e < sg.words[i]; e += stride) sg.dst[i][e] = sg.src[i][e];
+}
+
+// W' = d .* (T - cen * mu s^T)
+__global__ void k_finish_t(const double* __restrict__ T, const double* __restrict__ d, const double* __restrict__ mu,
+                           int k, int cen, double* __restrict__ Wp) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (uint64_t)k * L) return;
+    int j = (int)(e / L), c = (int)(e % L);
+    double s = T[(size_t)k * L + c];
+    Wp[e] = d[j] * (T[e] - (cen ? mu[j] * s : 0.0));
+}
+
+// H = A^T B, G = B^T B for two k x 64 blocks (f64).  Each workgroup reduces a slice of the k rows
+// (staged through LDS) into a partial 64 x 64 pair; k_gram2_reduce sums the slices in fixed order.
+constexpr int kGram2Blocks = 64;
+__global__ __launch_bounds__(1024) void k_gram2_part(const double* __restrict__ A, const double* __restrict__ B, int k,
+                                                     double* __restrict__ part /* [blocks][2][64*64] */) {
+    constexpr int R = 32;
+    __shared__ double sa[R][L], sb[R][L];
+    double h[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0};
+    const int b = threadIdx.x & (L - 1), a0 = threadIdx.x / L;    // entries (a0 + 16u, b), u < 4
+    const int rows_per = (k + gridDim.x - 1) / gridDim.x;
+    const int jb0 = blockIdx.x * rows_per;
+    const int jb1 = jb0 + rows_per < k ? jb0 + rows_per : k;
+    for (int j0 = jb0; j0 < jb1; j0 += R) {
+        for (int e = threadIdx.x; e < R * L; e += 1024) {
+            int j = j0 + e / L;
+            sa[e / L][e % L] = j < jb1 ? A[(size_t)j * L + (e % L)] : 0.0;
+            sb[e / L][e % L] = j < jb1 ? B[(size_t)j * L + (e % L)] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int r = 0; r < R; ++r) {
+            double bv = sb[r][b];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                h[u] += sa[r][a0 + 16 * u] * bv;
+                g[u] += sb[r][a0 + 16 * u] * bv;
+            }
+        }
+        __syncthreads();
+    }
+    double* out = part + (size_t)blockIdx.x * 2 * L * L;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        out[(a0 + 16 * u) * L + b] = h[u];
+        out[L * L + (a0 + 16 * u) * L + b] = g[u];
+    }
+}
+__global__ void k_gram2_reduce(const double* __restrict__ part, int n_blocks, double* __restrict__ HG /* 2*64*64 */) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * L * L) return;
+    double s = 0.0;
+    for (int b = 0; b < n_blocks; ++b) s += part[(size_t)b * 2 * L * L + e];
+    HG[e] = s;
+}
+
+// ONE product of two k x 64 blocks, H = A^T B (A == B: the Gram matrix of a block), as kGram1Blocks partial 64 x 64 sums
+// over row slices.  The consumer — k_chol_factor_panels or k_jacobi_eig2, through (part, n_part) — adds the partials in fixed
+// order while it loads the matrix: no reduction kernel between the two, and half the arithmetic of k_gram2_part, which forms
+// both products whichever is wanted.
+constexpr int kGram1Blocks = 16;
+// On the f64 matrix cores: wave w of a workgroup owns the 16 x 16 output tile (w / 4, w % 4); both operands come straight
+// from global memory in fragment order (lane l: row kk + (l >> 4), column 16 t + (l & 15) — 128 contiguous bytes per
+// 16 lanes), eight K-steps of loads in flight.  (The LDS-staged scalar version was LDS-read bound: 24 us a launch.)
+__global__ __launch_bounds__(1024) void k_gram1_part(const double* __restrict__ A, const double* __restrict__ B, int k,
+                                                     double* __restrict__ part /* [blocks][64*64] */) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int ti = wv >> 2, tj = wv & 3;
+    const int rows_per = (k + gridDim.x - 1) / gridDim.x;
+    const int jb0 = blockIdx.x * rows_per;
+    const int jb1 = jb0 + rows_per < k ? jb0 + rows_per : k;
+    dvec4 acc = dvec4{0.0, 0.0, 0.0, 0.0};
+    constexpr int kU = 8;
+    for (int j0 = jb0; j0 < jb1; j0 += 4 * kU) {
+        double av[kU], bv[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int r = j0 + 4 * u + lk;
+            const bool ok = r < jb1;
+            av[u] = ok ? A[(size_t)r * L + 16 * ti + li] : 0.0;
+            bv[u] = ok ? B[(size_t)r * L + 16 * tj + li] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    }
+    // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+    double* out = part + (size_t)blockIdx.x * L * L;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) out[(16 * ti + lk + 4 * v) * L + 16 * tj + li] = acc[v];
+}
+
+// The tail of a Rayleigh–Ritz step in one pass over the rows: A1 = Wp U (= C W U), A2 = W U (the Ritz vectors), and per
+// block the partial sums of || A1[:, c] - theta_c A2[:, c] ||^2 and the entry of largest |.| of A2[:, c] (ties: the smallest
+// row).  k_resid_final adds the partials in fixed order.  (Was: k_right_mul twice, k_col_resid on ONE workgroup, k_resid_scalar.)
+constexpr int kRitzBlocks = 128;
+__global__ __launch_bounds__(256) void k_ritz_post(const double* __restrict__ W, const double* __restrict__ Wp,
+                                                   const double* __restrict__ M, const double* __restrict__ theta, int k,
+                                                   double* __restrict__ A1, double* __restrict__ A2,
+                                                   double* __restrict__ part /* [blocks][3][64]: r2, best value, its row */) {
+    __shared__ double sm[L][L + 1];
+    __shared__ double s_r[4][L], s_v[4][L], s_j[4][L];
+    for (int e = threadIdx.x; e < L * L; e += 256) sm[e / L][e % L] = M[e];
+    __syncthreads();
+    const int c = threadIdx.x & (L - 1), sub = threadIdx.x / L;    // 4 rows per pass
+    const double th = theta[c];
+    double acc = 0.0, best = 0.0, best_j = 0.0;
+    for (int j = blockIdx.x * 4 + sub; j < k; j += gridDim.x * 4) {
+        const double* rw = W + (size_t)j * L;
+        const double* rp = Wp + (size_t)j * L;
+        double a1 = 0.0, a2 = 0.0;
+#pragma unroll 8
+        for (int b = 0; b < L; ++b) {
+            const double m = sm[b][c];
+            a1 += rp[b] * m;
+            a2 += rw[b] * m;
+        }
+        A1[(size_t)j * L + c] = a1;
+        A2[(size_t)j * L + c] = a2;
+        const double r = a1 - th * a2;
+        acc += r * r;
+        if (fabs(a2) > fabs(best)) {          // rows come in increasing order: the first one of the largest magnitude stays
+            best = a2;
+            best_j = (double)j;
+        }
+    }
+    s_r[sub][c] = acc;
+    s_v[sub][c] = best;
+    s_j[sub][c] = best_j;
+    __syncthreads();
+    if (sub == 0) {
+        double t = 0.0, bv = 0.0, bj = 0.0;
+        for (int w = 0; w < 4; ++w) {
+            t += s_r[w][c];
+            const double v = s_v[w][c], jj = s_j[w][c];
+            if (fabs(v) > fabs(bv) || (fabs(v) == fabs(bv) && v != 0.0 && jj < bj)) {
+                bv = v;
+                bj = jj;
+            }
+        }
+        double* out = part + (size_t)blockIdx.x * 3 * L;
+        out[c] = t;
+        out[L + c] = bv;
+        out[2 * L + c] = bj;
+    }
+}
+
+// Out = In * M  (k x 64 times 64 x 64), M row-major.
+__global__ __launch_bounds__(256) void k_right_mul(const double* __restrict__ In, const double* __restrict__ M, int k,
+                                                   double* __restrict__ Out) {
+    __shared__ double sm[L][L + 1];
+    for (int e = threadIdx.x; e < L * L; e += 256) sm[e / L][e % L] = M[e];
+    __syncthreads();
+    const int c = threadIdx.x & (L - 1), sub = threadIdx.x / L;    // 4 rows per pass
+    for (int j = blockIdx.x * 4 + sub; j < k; j += gridDim.x * 4) {
+        const double* row = In + (size_t)j * L;
+        double acc = 0.0;
+#pragma unroll 8
+        for (int b = 0; b < L; ++b) acc += row[b] * sm[b][c];
+        Out[(size_t)j * L + c] = acc;
+    }
+}
+
+// rho[c] = || A1[:,c] - theta[c] * A2[:,c] ||_2 ; also colmax: entry of largest |.| of A2[:,c].
+__global__ __launch_bounds__(1024) void k_col_resid(const double* __restrict__ A1, const double* __restrict__ A2,
+                                                    const double* __restrict__ theta, int k,
+                                                    double* __restrict__ rho, double* __restrict__ colmax) {
+    __shared__ double s_r[16][L], s_m[16][L];
+    const int c = threadIdx.x & (L - 1), part = threadIdx.x / L;
+    double acc = 0.0, best = 0.0;
+    const double th = theta[c];
+    for (int j = part; j < k; j += 16) {
+        double v2 = A2[(size_t)j * L + c];
+        double r = A1[(size_t)j * L + c] - th * v2;
+        acc += r * r;
+        if (fabs(v2) > fabs(best)) best = v2;
+    }
+    s_r[part][c] = acc;
+    s_m[part][c] = best;
+    __syncthreads();
+    if (part == 0) {
+        double t = 0.0, bm = 0.0;
+        for (int w = 0; w < 16; ++w) {
+            t += s_r[w][c];
+            if (fabs(s_m[w][c]) > fabs(bm)) bm = s_m[w][c];    // ties keep the lowest row slice
+        }
+        rho[c] = sqrt(t);
+        colmax[c] = bm;
+    }
+}
+
+// ---- l x l algebra of the subspace iteration, on the device ---------------------------------------
+// One workgroup each; they exist so that a whole PCA is ONE uninterrupted stream of launches: with
+// the l x l Cholesky / eigen-solves on the host every sweep cost two or three stream drains plus
+// whatever the host cores happened to be doing (measured: 3.5 ms per pipeline step on an idle box,
+// 17 ms on a busy one).  Status bits are OR-ed into *status and read back with the residual.
+constexpr int kStatChol = 1, kStatEig = 2;
+constexpr size_t kJacobiLds = (2 * L * (L + 1) + L + 32) * sizeof(double) + 2 * L * sizeof(int);
+
+// Start block: counter-based N(0,1) entries, deterministic in (seed, gene slot, column).
+__device__ __forceinline__ uint64_t dmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ void k_identity_block(int k, double* __restrict__ W) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < k * L) W[e] = (e / L == e % L) ? 1.0 : 0.0;
+}
+__global__ void k_init_block(uint64_t seed, int k, int l_act, double* __restrict__ Wp) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= k * L) return;
+    const int j = e / L, cc = e % L;
+    double v = 0.0;
+    if (cc < l_act) {
+        const uint64_t base = dmix64(seed ^ dmix64((uint64_t)j));
+        const uint64_t h1 = dmix64(base + 2 * (uint64_t)cc), h2 = dmix64(base + 2 * (uint64_t)cc + 1);
+        const double u1 = ((double)(h1 >> 11) + 0.5) / 9007199254740992.0;
+        const double u2 = ((double)(h2 >> 11) + 0.5) / 9007199254740992.0;
+        v = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+    }
+    Wp[e] = v;
+}
+
+// CholeskyQR, device side: G = R^T R (upper Cholesky of the leading n x n block of G, ld = L), then
+// W = Wp R^-1 by one forward substitution per ROW of Wp (k independent rows) — no explicit inverse.
+//
+// k_chol_factor: one workgroup, right-looking: at step j every thread subtracts a_jr a_jc / a_jj from the
+// trailing elements it owns (one barrier per step).  Rout (L x L, row-major) receives R, zero outside
+// the upper triangle of the leading block; dinv[j] = 1 / R[j][j] (0 for j >= n).
+// `shifted` (the robust mode of the driver): a pivot that has fallen below 1e-13 of the largest diagonal entry of G is
+// held at that floor instead of being reported — the factor then belongs to a slightly shifted G, W = Wp R^-1 stays
+// bounded and of full rank, and a second plain pass (CholeskyQR2) makes it orthonormal (shifted CholeskyQR3 idea).
+__global__ __launch_bounds__(1024) void k_chol_factor(const double* __restrict__ G, int n, double* __restrict__ Rout,
+                                                      double* __restrict__ dinv, int* __restrict__ status, int shifted) {
+    __shared__ double A[L][L + 1];
+    __shared__ double s_floor, s_diag[L];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < L * L; e += 1024) {
+        const int r = e >> 6, c = e & 63;
+        A[r][c] = (r < n && c < n) ? G[(size_t)r * L + c] : 0.0;
+    }
+    __syncthreads();
+    if (tid < L) s_diag[tid] = A[tid][tid];
+    if (tid == 0) {
+        double mx = 0.0;
+        for (int j = 0; j < n; ++j) mx = A[j][j] > mx ? A[j][j] : mx;
+        s_floor = shifted ? 1e-13 * mx : 0.0;
+    }
+    __syncthreads();
+    bool bad = false;
+    for (int j = 0; j < n; ++j) {
+        double d = A[j][j];
+        // shifted (last-resort) mode: a pivot below 1e-13 of the largest diagonal entry means the column depends on the
+        // ones before it — the block is wider than the numerical rank of the data (a handful of cells, most selected
+        // columns empty).  The column is DROPPED (zero in Q: dinv = 0, empty row of R) instead of being scaled up from
+        // rounding noise; it stays zero under C, and its Ritz pair comes out as (0, 0).  "Dependent" = the pivot is
+        // below 1e-13 of the column's OWN squared norm (s_diag, taken before the elimination).  (A zero or NaN matrix
+        // keeps its non-positive pivot: reported below.)
+        const bool drop = shifted && s_floor > 0.0 && d == d && !(d > 1e-13 * s_diag[j]);
+        if (!drop && shifted && !(d > s_floor)) d = s_floor;   // independent but tiny next to the others: lifted as before
+        if (!drop && !(d > 0.0)) bad = true;
+        const double inv = drop ? 0.0 : rsqrt(d), inv2 = inv * inv;
+        if (tid < L) {
+            Rout[(size_t)j * L + tid] = (tid >= j && tid < n) ? (drop ? (tid == j ? 1.0 : 0.0) : A[j][tid] * inv) : 0.0;
+            if (tid == j) dinv[j] = inv;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 1024 * u, r = e >> 6, c = e & 63;
+            if (r > j && c >= r && c < n) A[r][c] -= A[j][r] * A[j][c] * inv2;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < L * L; e += 1024)
+        if ((e >> 6) >= n) Rout[e] = 0.0;
+    if (tid < L && tid >= n) dinv[tid] = 0.0;
+    if (bad && tid == 0) atomicOr(status, kStatChol);
+}
+
+// The plain factorisation (no shift, no dropped columns) in panels of kCholPanel rows: wave 0 factors a panel on its own, in
+// registers — eight dependent steps of (v_readlane, rsqrt, multiply-subtract), no LDS round trip and no barrier — then all
+// threads subtract the panel's rank-8 update from the trailing rows: 16 barriers for l = 64 instead of 64 (the CholeskyQR
+// runs five times per solve).  Same outputs and status as k_chol_factor(shifted = 0).
+// 1 / sqrt(x), normal positive x: the hardware seed (2^-24, bench_micro/rsq_precision.hip) and one third-order correction
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-x * y, y, 1.0);
+    return __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
+}
+constexpr int kCholPanel = 8;
+__global__ __launch_bounds__(1024) void k_chol_factor_panels(const double* __restrict__ G, int n_part, int n, double* __restrict__ Rout,
+                                                             double* __restrict__ dinv, int* __restrict__ status) {
+    __shared__ double A[L][L + 1];           // the rows of a finished panel hold R
+    __shared__ int s_bad;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < L * L; e += 1024) {      // G = the sum of n_part <= 16 partial matrices (k_gram1_part), in fixed order
+        const int r = e >> 6, c = e & 63;
+        double v[kGram1Blocks];
+#pragma unroll
+        for (int p = 0; p < kGram1Blocks; ++p) v[p] = p < n_part ? G[(size_t)p * L * L + e] : 0.0;      // all in flight
+        double g = 0.0;
+#pragma unroll
+        for (int p = 0; p < kGram1Blocks; ++p) g += v[p];
+        A[r][c] = (r < n && c < n) ? g : 0.0;
+    }
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += kCholPanel) {
+        const int j1 = j0 + kCholPanel < n ? j0 + kCholPanel : n;
+        if (tid < kWave) {
+            // lane c holds column c of the panel's rows in registers; pivots and multipliers travel by v_readlane (a pivot
+            // step through LDS — read the pivot, write the row, read the multipliers, update — was 0.6 us of latency,
+            // the same as the one-barrier-per-step kernel)
+            const int c = tid;
+            double a[kCholPanel];
+#pragma unroll
+            for (int jj = 0; jj < kCholPanel; ++jj) a[jj] = j0 + jj < j1 ? A[j0 + jj][c] : 0.0;
+#pragma unroll
+            for (int jj = 0; jj < kCholPanel; ++jj) {
+                const int j = j0 + jj;
+                if (j < j1) {                                   // (uniform)
+                    const double d = readlane_v(a[jj], j);
+                    if (!(d > 0.0) && c == 0) s_bad = 1;
+                    const double inv = d > 1e-290 ? fast_rsqrt(d) : rsqrt(d);      // (the library's: ~10 dependent operations)
+                    const double rjc = (c >= j && c < n) ? a[jj] * inv : 0.0;
+                    a[jj] = rjc;                                // row j of R (zero left of the diagonal and right of n)
+                    if (c == j) dinv[j] = inv;
+#pragma unroll
+                    for (int rr = jj + 1; rr < kCholPanel; ++rr) {
+                        const int r = j0 + rr;
+                        if (r < j1) {
+                            const double rjr = readlane_v(rjc, r);
+                            if (c >= r && c < n) a[rr] -= rjr * rjc;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < kCholPanel; ++jj)
+                if (j0 + jj < j1) {
+                    A[j0 + jj][c] = a[jj];
+                    Rout[(size_t)(j0 + jj) * L + c] = a[jj];
+                }
+        }
+        __syncthreads();
+        // trailing rows r >= j1: a_rc -= sum over the panel of r_jr r_jc, c >= r
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 1024 * u, r = e >> 6, c = e & 63;
+            if (r >= j1 && c >= r && c < n) {
+                double acc = A[r][c];
+                for (int j = j0; j < j1; ++j) acc -= A[j][r] * A[j][c];
+                A[r][c] = acc;
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < L * L; e += 1024)
+        if ((e >> 6) >= n) Rout[e] = 0.0;
+    if (tid < L && tid >= n) dinv[tid] = 0.0;
+    if (tid == 0 && s_bad) atomicOr(status, kStatChol);
+}
+
+// W[row] R = Wp[row]: w_j = (wp_j - sum_{i<j} w_i R[i][j]) / R[j][j], one thread per row, the row in
+// registers (the j / i loops are fully unrolled: static register indices), R transposed in LDS so that
+// the i-loop of a column reads consecutive words (wave-uniform addresses: broadcast, no conflicts).
+// One wave per workgroup: k / 64 workgroups spread over as many compute units.
+__global__ __launch_bounds__(64) void k_trsm_rows(const double* __restrict__ Wp, const double* __restrict__ R,
+                                                  const double* __restrict__ dinv, int k, double* __restrict__ W) {
+    __shared__ double Rt[L][L];          // Rt[j][i] = R[i][j]
+    __shared__ double di[L];
+    for (int e = threadIdx.x; e < L * L; e += 64) Rt[e & 63][e >> 6] = R[e];
+    di[threadIdx.x] = dinv[threadIdx.x];
+    __syncthreads();
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= k) return;
+    double w[L];
+    const double* src = Wp + (size_t)row * L;
+#pragma unroll
+    for (int j = 0; j < L; ++j) w[j] = src[j];
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        double acc0 = w[j], acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;      // (eight chains instead of four: 32 -> 56 us, the row spills)
+#pragma unroll
+        for (int i = 0; i + 3 < j; i += 4) {
+            acc0 -= w[i] * Rt[j][i];
+            acc1 -= w[i + 1] * Rt[j][i + 1];
+            acc2 -= w[i + 2] * Rt[j][i + 2];
+            acc3 -= w[i + 3] * Rt[j][i + 3];
+        }
+#pragma unroll
+        for (int i = j & ~3; i < j; ++i) acc0 -= w[i] * Rt[j][i];
+        w[j] = ((acc0 + acc1) + (acc2 + acc3)) * di[j];
+    }
+    double* dst = W + (size_t)row * L;
+#pragma unroll
+    for (int j = 0; j < L; ++j) dst[j] = w[j];
+}
+
+// Eigen-decomposition of the symmetric leading n x n block of H (ld = L) by two-sided cyclic Jacobi,
+// 32 disjoint rotations per round in the round-robin ordering (63 rounds = one sweep).  Thread (I, J)
+// owns the 2 x 2 block (pair I) x (pair J) and applies J_I^T . B . J_J in place: the rotated matrix
+// stays exactly symmetric and a round needs two barriers.  The projected matrices of successive
+// Rayleigh–Ritz steps are close to diagonal, so late solves take two or three sweeps.
+// U (L x L, row-major) receives eigenvector c in COLUMN c, eigenvalues descending; rows / columns
+// >= n are 0, theta[c >= n] = 0.
+__device__ __forceinline__ void jacobi_pair(int m, int r, int& p, int& q) {
+    if (m == 0) {
+        p = L - 1;
+        q = r;
+    } else {
+        p = (r + m) % (L - 1);
+        q = (r + (L - 1) - m) % (L - 1);
+    }
+}
+__global__ __launch_bounds__(1024) void k_jacobi_eig(const double* __restrict__ H, int n, double* __restrict__ U,
+                                                     double* __restrict__ theta, int* __restrict__ status, double off_tol2) {
+    static_assert(L == 64, "the block mapping below is written for l = 64");
+    extern __shared__ double lds_raw[];
+    double (*A)[L + 1] = reinterpret_cast<double (*)[L + 1]>(lds_raw);
+    double (*V)[L + 1] = reinterpret_cast<double (*)[L + 1]>(lds_raw + L * (L + 1));
+    double (*cs)[2] = reinterpret_cast<double (*)[2]>(lds_raw + 2 * L * (L + 1));
+    double (*red)[16] = reinterpret_cast<double (*)[16]>(lds_raw + 2 * L * (L + 1) + L);
+    int* rank = reinterpret_cast<int*>(lds_raw + 2 * L * (L + 1) + L + 32);
+    int (*pq)[2] = reinterpret_cast<int (*)[2]>(rank + L);
+    const int tid = threadIdx.x, I = tid >> 5, J = tid & 31;
+    for (int e = tid; e < L * L; e += 1024) {
+        const int a = e >> 6, b = e & 63;
+        A[a][b] = (a < n && b < n) ? 0.5 * (H[(size_t)a * L + b] + H[(size_t)b * L + a]) : 0.0;
+        V[a][b] = a == b ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    bool done = false;
+    for (int sweep = 0; sweep < 30 && !done; ++sweep) {
+        double off = 0.0, dg = 0.0;
+        for (int e = tid; e < L * L; e += 1024) {
+            const int a = e >> 6, b = e & 63;
+            const double x = A[a][b];
+            if (a < b) off += x * x;
+            if (a == b) dg += x * x;
+        }
+        off = wave_sum(off);
+        dg = wave_sum(dg);
+        if ((tid & 63) == 0) {
+            red[0][tid >> 6] = off;
+            red[1][tid >> 6] = dg;
+        }
+        __syncthreads();
+        off = dg = 0.0;
+        for (int w = 0; w < 16; ++w) {
+            off += red[0][w];
+            dg += red[1][w];
+        }
+        __syncthreads();
+        if (!(off > off_tol2 * dg)) {         // also leaves on NaN (reported through the residual)
+            done = true;
+            break;
+        }
+        for (int r = 0; r < L - 1; ++r) {
+            if (tid < L / 2) {
+                int p, q;
+                jacobi_pair(tid, r, p, q);
+                pq[tid][0] = p;
+                pq[tid][1] = q;
+                // rotation annihilating a_pq, division-free: with d = a_qq - a_pp, b = 2 a_pq,
+                // h = hypot(b, d), u = |d| + h:  c = u / hypot(u, b),  s = sgn(d b) |b| / hypot(u, b)
+                const double b = 2.0 * A[p][q], d = A[q][q] - A[p][p];
+                double c = 1.0, sn = 0.0;
+                if (b != 0.0) {
+                    const double u = fabs(d) + sqrt(b * b + d * d);
+                    const double wv = rsqrt(u * u + b * b);
+                    c = u * wv;
+                    sn = ((d >= 0.0) == (b >= 0.0) ? fabs(b) : -fabs(b)) * wv;
+                }
+                cs[tid][0] = c;
+                cs[tid][1] = sn;
+            }
+            __syncthreads();
+            const int p = pq[I][0], q = pq[I][1], rr = pq[J][0], ss = pq[J][1];
+            const double cP = cs[I][0], sP = cs[I][1], cR = cs[J][0], sR = cs[J][1];
+            const double b00 = A[p][rr], b01 = A[p][ss], b10 = A[q][rr], b11 = A[q][ss];
+            const double t00 = cP * b00 - sP * b10, t01 = cP * b01 - sP * b11;
+            const double t10 = sP * b00 + cP * b10, t11 = sP * b01 + cP * b11;
+            double n00 = cR * t00 - sR * t01, n01 = sR * t00 + cR * t01;
+            double n10 = cR * t10 - sR * t11, n11 = sR * t10 + cR * t11;
+            if (I == J) n01 = n10 = 0.0;      // the pivot, annihilated exactly
+            A[p][rr] = n00;
+            A[p][ss] = n01;
+            A[q][rr] = n10;
+            A[q][ss] = n11;
+            // eigenvectors: V <- V J_J on rows 2I, 2I+1
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = 2 * I + h;
+                const double v0 = V[row][rr], v1 = V[row][ss];
+                V[row][rr] = cR * v0 - sR * v1;
+                V[row][ss] = sR * v0 + cR * v1;
+            }
+            __syncthreads();
+        }
+    }
+    if (!done && tid == 0) atomicOr(status, kStatEig);
+    // descending order; padded indices (>= n) go last
+    if (tid < L) {
+        const double mine = A[tid][tid];
+        int rk = 0;
+        for (int j = 0; j < L; ++j) {
+            if (j == tid) continue;
+            const double other = A[j][j];
+            bool before;
+            if (tid >= n) before = (j < n) || j < tid;
+            else before = (j < n) && (other > mine || (other == mine && j < tid));
+            rk += before ? 1 : 0;
+        }
+        rank[tid] = rk;
+        theta[rk] = tid < n ? mine : 0.0;
+    }
+    __syncthreads();
+    for (int e = tid; e < L * L; e += 1024) {
+        const int a = e >> 6, b = e & 63;
+        U[(size_t)a * L + rank[b]] = (a < n && b < n) ? V[a][b] : 0.0;
+    }
+}
+
+#include "jacobi.inl"
+
+// ---- Chebyshev filter between two Rayleigh–Ritz steps ----------------------------------------------
+// After a Ritz step the block holds Ritz vectors V (A2) with values theta and C V (A1).  The eigenvalues
+// that are NOT wanted lie in [0, b] with b <= theta_l (the smallest Ritz value of the block bounds
+// lambda_{l+1} from above), so instead of plain powers C^m V the block is filtered with the Chebyshev
+// polynomial T_d((2C - bI)/b): |T_d| <= 1 on [0, b] and grows like cosh(d acosh t) outside — for the bench
+// spectrum (theta_l/theta_npc = 0.24) a factor 14.9 per application of C against 4.2 for a plain power.
+//   Y0 = V,  Y1 = a C V - V,  Y_{j+1} = 2 (a C Y_j - Y_j) - Y_{j-1},   a = 2 / b
+// b is read from the device (theta[l_act - 1], floored at 1e-10 theta_0 so that a rank-deficient C cannot
+// divide by zero: any b at or above the unwanted spectrum is a valid filter).
+__device__ __forceinline__ double cheb_b(const double* __restrict__ theta, int l_act) {
+    const double b = theta[l_act - 1], floor_ = 1e-10 * theta[0];
+    return b > floor_ ? b : (floor_ > 0 ? floor_ : 1.0);
+}
+// A1 <- a A1 - A2   (Y1 from C V and V)
+__global__ void k_cheb_first(double* __restrict__ A1, const double* __restrict__ A2, const double* __restrict__ theta,
+                             int l_act, size_t n) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const double a = 2.0 / cheb_b(theta, l_act);
+    A1[e] = a * A1[e] - A2[e];
+}
+// prev <- 2 (a Z - cur) - prev   (Y_{j+1} from Z = C Y_j, Y_j, Y_{j-1})
+// (Z is left ZEROED: it is the destination of the next application of C, which accumulates into a zeroed block)
+__global__ void k_cheb_step(double* __restrict__ Z, const double* __restrict__ cur, double* __restrict__ prev,
+                            const double* __restrict__ theta, int l_act, size_t n) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const double a = 2.0 / cheb_b(theta, l_act);
+    prev[e] = 2.0 * (a * Z[e] - cur[e]) - prev[e];
+    Z[e] = 0.0;
+}
+// column i divided by T_d(t_i), t_i = (2 theta_i - b) / b: the filtered columns are (nearly) eigenvectors
+// scaled by T_d(t_i); taking the known factor out keeps the CholeskyQR that follows well conditioned
+__global__ void k_cheb_scale(double* __restrict__ Y, const double* __restrict__ theta, int l_act, int d, size_t n) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int c = (int)(e % L);
+    if (c >= l_act) return;
+    const double b = cheb_b(theta, l_act);
+    const double t = (2.0 * theta[c] - b) / b;
+    const double Td = t > 1.0 ? cosh((double)d * acosh(t)) : 1.0;
+    Y[e] /= Td;
+}
+
+// sign convention of the components: the largest-|.| entry of each Ritz vector is positive
+__global__ void k_signs(const double* __restrict__ colmax, double* __restrict__ sgn) {
+    sgn[threadIdx.x] = colmax[threadIdx.x] < 0 ? -1.0 : 1.0;
+}
+
+// out[0] = max_{i < n_pc} rho_i / theta_i (NaN-propagating), out[1] = status bits,
+// out[2] = theta[l_act - 1] / theta[n_pc - 1]: the smallest Ritz value of the block over the last wanted
+// one — an upper estimate of the per-application convergence factor of the wanted pairs
+__global__ void k_resid_scalar(const double* __restrict__ rho, const double* __restrict__ theta, int n_pc, int l_act,
+                               const int* __restrict__ status, const int* __restrict__ status_sel,
+                               double* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    double resid = 0.0;
+    for (int i = 0; i < n_pc; ++i) {
+        // relative to the pair's own eigenvalue, but not to less than 1e-5 of the largest one: pairs of a numerically
+        // zero eigenvalue (more components asked than the data have rank) are judged on the scale of the problem
+        // (their absolute residual is ~1e-16 theta_1: 1e-11 on this scale)
+        const double den = theta[i] > 1e-5 * theta[0] ? theta[i] : 1e-5 * theta[0];
+        const double r = den > 0 ? rho[i] / den : rho[i];
+        if (!(r <= resid)) resid = r;
+    }
+    out[0] = resid;
+    out[1] = (double)*status;
+    out[2] = theta[n_pc - 1] > 0 ? theta[l_act - 1] / theta[n_pc - 1] : 1.0;
+    out[3] = status_sel ? (double)*status_sel : 0.0;      // device-side feature selection: bit 0 = NaN variance
+    out[4] = theta[l_act - 1] > 0 ? theta[0] / theta[l_act - 1] : 1.0;      // spread of the block: bounds the filter degree
+}
+
+// k_ritz_post's partials -> rho[c], colmax[c], then the scalars of k_resid_scalar (same slots of `out`).  1024 threads:
+// 16 slices of the blocks per column (a single wave walking 128 x 3 dependent loads took 45 us), combined in fixed order.
+__global__ __launch_bounds__(1024) void k_resid_final(const double* __restrict__ part, int n_blocks, const double* __restrict__ theta,
+                                                      int n_pc, int l_act, const int* __restrict__ status,
+                                                      const int* __restrict__ status_sel, double* __restrict__ rho,
+                                                      double* __restrict__ colmax, double* __restrict__ out) {
+    __shared__ double s_t[16][L], s_v[16][L], s_j[16][L], s_rho[L];
+    const int c = threadIdx.x & (L - 1), sl = threadIdx.x / L;
+    double t = 0.0, bv = 0.0, bj = 0.0;
+    for (int b = sl; b < n_blocks; b += 16) {
+        const double* p = part + (size_t)b * 3 * L;
+        t += p[c];
+        const double v = p[L + c], jj = p[2 * L + c];
+        if (fabs(v) > fabs(bv) || (fabs(v) == fabs(bv) && v != 0.0 && jj < bj)) {
+            bv = v;
+            bj = jj;
+        }
+    }
+    s_t[sl][c] = t;
+    s_v[sl][c] = bv;
+    s_j[sl][c] = bj;
+    __syncthreads();
+    if (sl == 0) {
+        t = 0.0; bv = 0.0; bj = 0.0;
+        for (int w = 0; w < 16; ++w) {
+            t += s_t[w][c];
+            const double v = s_v[w][c], jj = s_j[w][c];
+            if (fabs(v) > fabs(bv) || (fabs(v) == fabs(bv) && v != 0.0 && jj < bj)) {
+                bv = v;
+                bj = jj;
+            }
+        }
+        const double r = sqrt(t);
+        rho[c] = r;
+        colmax[c] = bv;
+        s_rho[c] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double resid = 0.0;
+    for (int i = 0; i < n_pc; ++i) {
+        const double den = theta[i] > 1e-5 * theta[0] ? theta[i] : 1e-5 * theta[0];      // (see k_resid_scalar)
+        const double q = den > 0 ? s_rho[i] / den : s_rho[i];
+        if (!(q <= resid)) resid = q;
+    }
+    out[0] = resid;
+    out[1] = (double)*status;
+    out[2] = theta[n_pc - 1] > 0 ? theta[l_act - 1] / theta[n_pc - 1] : 1.0;
+    out[3] = status_sel ? (double)*status_sel : 0.0;
+    out[4] = theta[l_act - 1] > 0 ? theta[0] / theta[l_act - 1] : 1.0;
+}

@@ -6,23 +6,23 @@
 // when scale) is never formed.  The top eigenpairs of C = Z^T Z are found by block subspace
 // iteration with a Rayleigh–Ritz step on a k x 64 block W; two ways of applying C:
 //
-//  GRAM solver (default for k <= 4096)
-//     G = A^T A is accumulated ONCE, exactly, in f64: gene-tile pairs (128 x 128 f64 tiles in
-//     LDS), every cell contributing the outer product of its two tile segments through LDS
-//     atomics — N m^2/2 lane-atomics in total (m = non-zeros per cell among the k genes).
-//     C = D (G - c N mu mu^T) D is then a dense k x k matrix and every iteration is a dense
-//     (k x k)(k x 64) product on the f64 matrix cores.  Across row shards: ONE all-reduce of G's
-//     upper tiles.  The whole iteration (CholeskyQR, Jacobi eigen-solve of the projected matrix,
-//     residuals) runs on the device, replayed from hipGraphs; the host reads one residual per
-//     Rayleigh–Ritz step.
+//  GRAM solver (default up to k = 16384)
+//     G = A^T A is accumulated ONCE, exactly, in f64 (gram.inl): every kept entry times the suffix of its row, one f64 LDS
+//     atomic per product, G's rows owned in stripes by the workgroups (12-byte owner records made by a bucket pass).
+//     C = D (G - c N mu mu^T) D is then a dense k x k matrix and every iteration is a dense (k x k)(k x 64) product on the
+//     f64 matrix cores (iterate.inl).  Across row shards: ONE all-reduce of G's packed upper triangle, half of it under the
+//     kernel.  The whole iteration (CholeskyQR, Jacobi eigen-solve of the projected matrix — jacobi.inl —, Chebyshev filter,
+//     residuals) runs on the device, replayed from hipGraphs; the host reads one residual per Rayleigh–Ritz step.
 //  SPMM solver (matrix-free, any k)
-//     forward     Y  = Z W   = A (D W) - 1 (mu^T D W)        CSR x dense panel, panel in LDS
+//     forward     Y  = Z W   = A (D W) - 1 (mu^T D W)        sparse x dense panel, panel in LDS        (spmm.inl)
 //     transposed  W' = Z^T Y = D (A^T Y - c mu (1^T Y))      scatter form, LDS f64 atomics
 //     N m 64 lane-atomics PER ITERATION; across shards one all-reduce of the k x 64 block each.
 //
 // Either way the scores are one forward SpMM  Z V  (transform, pca/mod.rs:156-185).
-// A is the HVG-COMPACTED matrix in TILE-MAJOR layout (see below); everything of size k x 64 is
-// replicated per rank and kept in f64.
+// A is the HVG-COMPACTED matrix (compact.inl): row-major (column, value) records — what the Gram kernel and the forward
+// product read — and, for the matrix-free solver, a tile-major view; everything of size k x 64 is replicated per rank and
+// kept in f64.  This file: the compacted-matrix plumbing, the launches and the driver (run_pca, srx_pca, srx_pipeline,
+// srx_spmm), with backed.inl (out-of-core sessions) at the end.
 //
 // Measured on MI355X (profiles/r01_*): LDS f32 float atomics (ds_add_f32) run ~10x slower than
 // ds_add_f64, so every LDS accumulation here is f64; pure-f32 accumulation also stalls at ~2e-5
@@ -49,530 +49,7 @@ int32_t select_hvg_host(srx_ctx* ctx, const std::vector<double>& var, uint64_t n
 int32_t launch_tile_ptr(srx_ctx* ctx, const int64_t* indptr, const int32_t* idx, uint64_t n_rows, int n_tiles,
                         int tile_genes, int64_t* tp);
 
-// ---- HVG compaction --------------------------------------------------------------------------
-// remap[g] = position of gene g among the selected genes in ascending gene order, or -1.
-__global__ __launch_bounds__(256) void k_compact_count(const int64_t* __restrict__ indptr,
-                                                       const int32_t* __restrict__ idx,
-                                                       const int32_t* __restrict__ remap, uint64_t n_rows,
-                                                       int64_t* __restrict__ counts) {
-    const uint64_t wave = global_wave_id();
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
-    const int lane = lane_id();
-    for (uint64_t r = wave; r < n_rows; r += n_waves) {
-        const int64_t lo = indptr[r], hi = indptr[r + 1];
-        int c = 0;
-        for (int64_t p = lo + lane; p < hi; p += kWave) c += remap[idx[p]] >= 0;
-        c = wave_sum(c);
-        if (lane == 0) counts[r] = c;
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_compact_fill(const int64_t* __restrict__ indptr,
-                                                      const int32_t* __restrict__ idx, const T* __restrict__ vals,
-                                                      const int32_t* __restrict__ remap, uint64_t n_rows,
-                                                      const int64_t* __restrict__ out_ptr,
-                                                      int32_t* __restrict__ out_idx, T* __restrict__ out_vals) {
-    const uint64_t wave = global_wave_id();
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
-    const int lane = lane_id();
-    for (uint64_t r = wave; r < n_rows; r += n_waves) {
-        const int64_t lo = indptr[r], hi = indptr[r + 1];
-        int64_t o = out_ptr[r];
-        for (int64_t base = lo; base < hi; base += kWave) {
-            int64_t p = base + lane;
-            int32_t c = p < hi ? remap[idx[p]] : -1;
-            unsigned long long mask = __ballot(c >= 0);
-            if (c >= 0) {
-                int pos = __popcll(mask & ((1ull << lane) - 1ull));
-                out_idx[o + pos] = c;
-                out_vals[o + pos] = vals[p];
-            }
-            o += __popcll(mask);
-        }
-    }
-}
-
-// ---- exclusive scan of int64 counts (3 phases, 4096 elements per block) ------------------------
-constexpr int kScanItems = 4;
-constexpr int kScanBlock = 1024;
-__global__ __launch_bounds__(kScanBlock) void k_scan_block_sums(const int64_t* __restrict__ in, uint64_t n,
-                                                                int64_t* __restrict__ block_sums) {
-    __shared__ int64_t s_w[kScanBlock / kWave];
-    uint64_t base = (uint64_t)blockIdx.x * kScanBlock * kScanItems;
-    int64_t s = 0;
-    for (int t = 0; t < kScanItems; ++t) {
-        uint64_t i = base + (uint64_t)threadIdx.x * kScanItems + t;
-        if (i < n) s += in[i];
-    }
-    s = wave_sum(s);
-    if (lane_id() == 0) s_w[threadIdx.x / kWave] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int64_t tot = 0;
-        for (int w = 0; w < kScanBlock / kWave; ++w) tot += s_w[w];
-        block_sums[blockIdx.x] = tot;
-    }
-}
-// Exclusive scan of the block sums in place by ONE workgroup (nb is n/4096: a few thousand).
-__global__ __launch_bounds__(kScanBlock) void k_scan_serial(int64_t* __restrict__ block_sums, uint64_t nb,
-                                                            int64_t* __restrict__ total) {
-    __shared__ int64_t s_w[kScanBlock / kWave];
-    const uint64_t per = (nb + kScanBlock - 1) / kScanBlock;
-    const uint64_t b0 = (uint64_t)threadIdx.x * per;
-    const uint64_t b1 = b0 + per < nb ? b0 + per : nb;
-    int64_t s = 0;
-    for (uint64_t b = b0; b < b1; ++b) s += block_sums[b];
-    int64_t inc = s;
-    const int lane = lane_id();
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        int64_t o = __shfl_up(inc, off, kWave);
-        if (lane >= off) inc += o;
-    }
-    if (lane == kWave - 1) s_w[threadIdx.x / kWave] = inc;
-    __syncthreads();
-    int64_t wave_off = 0, all = 0;
-    for (int w = 0; w < kScanBlock / kWave; ++w) {
-        if (w < (int)(threadIdx.x / kWave)) wave_off += s_w[w];
-        all += s_w[w];
-    }
-    int64_t acc = wave_off + inc - s;
-    for (uint64_t b = b0; b < b1; ++b) {
-        int64_t v = block_sums[b];
-        block_sums[b] = acc;
-        acc += v;
-    }
-    if (threadIdx.x == 0) *total = all;
-}
-__global__ __launch_bounds__(kScanBlock) void k_scan_apply(const int64_t* __restrict__ in, uint64_t n,
-                                                           const int64_t* __restrict__ block_offs,
-                                                           const int64_t* __restrict__ total,
-                                                           int64_t* __restrict__ out /* n + 1 */) {
-    __shared__ int64_t s_w[kScanBlock / kWave];
-    uint64_t base = (uint64_t)blockIdx.x * kScanBlock * kScanItems;
-    int64_t v[kScanItems];
-    int64_t s = 0;
-    for (int t = 0; t < kScanItems; ++t) {
-        uint64_t i = base + (uint64_t)threadIdx.x * kScanItems + t;
-        v[t] = i < n ? in[i] : 0;
-        s += v[t];
-    }
-    // inclusive scan of the per-thread sums across the wave, then across waves
-    int64_t inc = s;
-    const int lane = lane_id();
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        int64_t o = __shfl_up(inc, off, kWave);
-        if (lane >= off) inc += o;
-    }
-    if (lane == kWave - 1) s_w[threadIdx.x / kWave] = inc;
-    __syncthreads();
-    int64_t wave_off = 0;
-    for (int w = 0; w < (int)(threadIdx.x / kWave); ++w) wave_off += s_w[w];
-    int64_t excl = block_offs[blockIdx.x] + wave_off + inc - s;
-    for (int t = 0; t < kScanItems; ++t) {
-        uint64_t i = base + (uint64_t)threadIdx.x * kScanItems + t;
-        if (i < n) out[i] = excl;
-        excl += v[t];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
-}
-
-// ---- tile-major layout of the compacted matrix --------------------------------------------------
-// The compacted N x k matrix is stored as n_t = ceil(k / kt) sub-matrices, one per GENE TILE of
-// kt compacted columns, back to back: sub-matrix t holds, row by row, the entries of every
-// cell that fall in columns [kt t, kt t + kt), with LOCAL column indices and row pointers
-// tptr[t*N + i].  A workgroup that owns (tile, row range) therefore streams ONE contiguous
-// index/value range, fully coalesced, instead of ~9-entry pieces of 1.3M rows.
-//   kt = 256 (KT)  SpMM kernels: 256 x 64 panel entries are what LDS holds — 64 KiB as f32
-//                  (forward panel tile, two workgroups per CU), 128 KiB as f64 (transposed
-//                  accumulators, one workgroup per CU);
-//   kt = 128 (KG)  Gram kernel: a 128 x 128 f64 tile of A^T A is 128 KiB.
-constexpr int KT = 256;
-constexpr int KG = 128;
-
-__global__ void k_seglen(const int64_t* __restrict__ indptr, const int64_t* __restrict__ tp, uint64_t n_rows, int nt,
-                         int64_t* __restrict__ seglen) {
-    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    uint64_t total = (uint64_t)nt * n_rows;
-    for (; e < total; e += stride) {
-        uint64_t t = e / n_rows, i = e % n_rows;
-        int64_t lo = t == 0 ? indptr[i] : tp[(t - 1) * n_rows + i];
-        int64_t hi = t == (uint64_t)nt - 1 ? indptr[i + 1] : tp[t * n_rows + i];
-        seglen[e] = hi - lo;
-    }
-}
-
-// One entry of a tile-major layout: local column and value side by side, so that every consumer (Gram kernel,
-// forward / transposed SpMM) fetches an entry with ONE 8-byte (f32 storage) or 16-byte (f64) load and the
-// compaction writes it with one store.
-template <typename VT> struct GramPk;
-template <> struct __attribute__((aligned(8))) GramPk<float> { int32_t j; float v; };
-template <> struct __attribute__((aligned(16))) GramPk<double> { int32_t j; int32_t pad_; double v; };
-
-template <typename T>
-__global__ __launch_bounds__(256) void k_retile(const int64_t* __restrict__ indptr, const int64_t* __restrict__ tp,
-                                                const int32_t* __restrict__ idx, const T* __restrict__ vals,
-                                                uint64_t n_rows, int nt, int kt, const int64_t* __restrict__ tptr,
-                                                GramPk<T>* __restrict__ tpk) {
-    const uint64_t wave = global_wave_id();
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
-    const int lane = lane_id();
-    for (uint64_t r = wave; r < n_rows; r += n_waves) {
-        const int64_t lo = indptr[r], hi = indptr[r + 1];
-        for (int64_t p = lo + lane; p < hi; p += kWave) {
-            int32_t c = idx[p];
-            int t = c / kt;
-            int64_t seg_lo = t == 0 ? lo : tp[(uint64_t)(t - 1) * n_rows + r];
-            int64_t dst = tptr[(uint64_t)t * n_rows + r] + (p - seg_lo);
-            GramPk<T> e{};
-            e.j = c - t * kt;
-            e.v = vals[p];
-            tpk[dst] = e;
-        }
-    }
-}
-
-// ---- fused HVG compaction straight into the tile-major layouts (<= 64 tiles of 128) ----------------
-// Pass 1 (k_tcount): per cell, the number of kept entries in each 128-column tile (and, summed in
-// pairs, in each 256-column tile).  Kept entries of a row are sorted by compacted column, so the
-// tiles present in a 64-entry chunk are found with a short ballot-match loop; lane t of the wave
-// is the counter of tile t.  Pass 2 (k_tfill) re-reads the row and scatters every kept entry to
-//   tptr[tile*N + i] + (rank of the entry among the row's kept entries - kept entries in earlier tiles)
-// in BOTH layouts.  The scans of the counts in between give tptr.
-// Membership + compacted column of a gene WITHOUT a G-entry remap table in L2 (a 4-byte gather per
-// non-zero drags a 64-byte line each: 70 GB of L2 traffic at c3): the selection is a bitmask
-// (G/32 words) plus the number of selected genes before each word, both staged in LDS (7 KB at
-// G = 28k); column = prefix[w] + popcount(bits[w] below the gene's bit).
-// ---- owner buckets of the Gram kernel (k_gram_stripes, below) -----------------------------------------
-constexpr int kGramWaves = 16;            // waves per Gram workgroup
-constexpr int kGramUnroll = 8;            // suffix loads in flight per wave
-
-// One unit of Gram work: entry (ja, va) times up to 64 consecutive entries of its row's suffix (the suffix starts at the
-// entry itself — the diagonal product — and a suffix longer than a wave is cut into several records).
-// pos: first suffix entry of this record, relative to its block's first entry; lenrb = lanes | rbase << 8, where
-// rbase + jb is the index of G[ja][jb] among the owner's LDS accumulators (gram_row_base: may be negative, jb >= ja).
-// (8-byte records — the entry's value fetched in the kernel instead of carried in the record, the piece index in the spare bits
-//  of lenrb — were measured in round 3: the bucket pass gains 0.13 ms (0.93 -> 0.80) and the stripe kernel loses 0.45 with a
-//  scalar load of the value (it shares lgkmcnt with the LDS atomics: waiting for it drains them) and 1.35 with a wave-uniform
-//  vector load (one more L1 access per record).  The value stays in the record.)
-template <typename VT> struct GramRec { uint32_t pos, lenrb; VT va; };
-// records of a row with n kept entries: sum over suffix lengths L = 1 .. n of ceil(L / 64)
-__host__ __device__ __forceinline__ uint64_t gram_row_records(uint64_t n) {
-    const uint64_t q = n >> 6, r = n & 63;
-    return 32 * q * (q + 1) + r * (q + 1);
-}
-
-__device__ __forceinline__ int gram_owner(int c, int sr_shift, int n_wg, int n_stripes) {
-    const int s = c >> sr_shift;
-    return s < n_wg ? s : n_stripes - 1 - s;
-}
-
-// accumulator layout of an owner: stripe A (rows a0 .. a0 + SR - 1, WA = k - a0 columns from a0), then stripe B (rows from
-// b0 = the mirrored stripe, WB = k - b0 columns): the offset to which a column index jb >= ja is added
-__device__ __forceinline__ int gram_row_base(int ja, int k, int sr_shift, int n_wg, int n_stripes) {
-    const int s = ja >> sr_shift, SR = 1 << sr_shift;
-    const int s0 = s << sr_shift;                       // first row of ja's stripe
-    if (s < n_wg) return (ja - s0) * (k - s0) - s0;
-    const int a0 = (n_stripes - 1 - s) << sr_shift;     // the owner's stripe A
-    return SR * (k - a0) + (ja - s0) * (k - s0) - s0;
-}
-
-struct SelLds {
-    const uint32_t* bits;
-    const uint32_t* prefix;
-    __device__ __forceinline__ int column(int32_t gene) const {
-        const uint32_t w = bits[gene >> 5];
-        const uint32_t bit = 1u << (gene & 31);
-        return (w & bit) ? (int)(prefix[gene >> 5] + __popc(w & (bit - 1u))) : -1;
-    }
-};
-__device__ __forceinline__ SelLds stage_selection(const uint32_t* __restrict__ g_bits,
-                                                  const uint32_t* __restrict__ g_prefix, int n_words, uint32_t* lds) {
-    for (int e = threadIdx.x; e < n_words; e += blockDim.x) {
-        lds[e] = g_bits[e];
-        lds[n_words + e] = g_prefix[e];
-    }
-    __syncthreads();
-    return SelLds{lds, lds + n_words};
-}
-
-constexpr int kFillUnroll = 4;       // 64-entry chunks of a row in flight per wave in k_tfill
-constexpr int kCompactRows = 8;      // consecutive rows per wave visit (one 64-byte line of 8-byte per-row counters)
-// rows r0*8 .. r0*8+7 of a wave's block, then the block n_waves further on
-__device__ __forceinline__ uint64_t next_compact_row(uint64_t r, uint64_t n_waves) {
-    return ((r + 1) % kCompactRows) ? r + 1 : r + 1 + (n_waves - 1) * kCompactRows;
-}
-
-// Kept entries per row, nothing else (the row-major layout's row lengths; the tile counters of k_tcount are only wanted by
-// the matrix-free solver's 256-tiled view): the bit of the gene in the selection mask is the whole test — one LDS read per
-// entry, no prefix lookup, no LDS atomic.  The mask holds at most k bits (k_sel_finish / the host route make sure).
-template <typename I>
-__global__ __launch_bounds__(256) void k_rowcount(const int64_t* __restrict__ indptr, const I* __restrict__ idx,
-                                                  const uint32_t* __restrict__ g_bits, int n_words, uint64_t n_rows,
-                                                  int64_t* __restrict__ cntrow) {
-    extern __shared__ double lds_raw[];
-    uint32_t* bits = reinterpret_cast<uint32_t*>(lds_raw);
-    for (int e = threadIdx.x; e < n_words; e += blockDim.x) bits[e] = g_bits[e];
-    __syncthreads();
-    const uint64_t wave = global_wave_id();
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
-    const int lane = lane_id();
-    constexpr int kCountUnroll = 16;          // 1024 entries in flight: a ~840-entry row is one round trip
-    for (uint64_t r0 = wave * kCompactRows; r0 < n_rows; r0 += n_waves * kCompactRows) {
-        const int nr = (int)(n_rows - r0 < (uint64_t)kCompactRows ? n_rows - r0 : kCompactRows);
-        uint32_t mine = 0;                    // lane i: row r0 + i
-        for (int i = 0; i < nr; ++i) {
-            const int64_t lo = indptr[r0 + i], hi = indptr[r0 + i + 1];
-            uint32_t c = 0;
-            for (int64_t base = lo; base < hi; base += kCountUnroll * kWave) {
-                int32_t g[kCountUnroll];
-#pragma unroll
-                for (int u = 0; u < kCountUnroll; ++u) {
-                    const int64_t p = base + u * kWave + lane;
-                    g[u] = p < hi ? (int32_t)idx[p] : -1;
-                }
-#pragma unroll
-                for (int u = 0; u < kCountUnroll; ++u)
-                    if (g[u] >= 0) c += (bits[g[u] >> 5] >> (g[u] & 31)) & 1u;
-            }
-            c = wave_sum(c);
-            if (lane == i) mine = c;
-        }
-        if (lane < nr) cntrow[r0 + lane] = (int64_t)mine;     // 8 counters = one 64-byte line
-    }
-}
-
-// Two-pass compaction, second form (round 3): the count pass also LEAVES A LIST of what it found — per kept entry one 32-bit
-// word (position in the row << 16 | compacted column) at kept[indptr[r] + rank], i.e. at the start of the row's own span of a
-// scratch array as long as the matrix — so that the fill pass never walks the column indices again: per row it reads its
-// ~72 words (one coalesced load), gathers the ~72 values and stores the entries.  Needs n_cols <= 65536 (16-bit positions and
-// columns) and the row-major layout alone (no 256-tiled view).
-template <typename I>
-__global__ __launch_bounds__(256) void k_rowcount_list(const int64_t* __restrict__ indptr, const I* __restrict__ idx,
-                                                       const uint32_t* __restrict__ g_bits, const uint32_t* __restrict__ g_prefix,
-                                                       int n_words, uint64_t n_rows, int k, int64_t* __restrict__ cntrow,
-                                                       uint32_t* __restrict__ kept) {
-    extern __shared__ double lds_raw[];
-    const SelLds sel = stage_selection(g_bits, g_prefix, n_words, reinterpret_cast<uint32_t*>(lds_raw));
-    const uint64_t wave = global_wave_id();
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
-    const int lane = lane_id();
-    constexpr int kCountUnroll = 16;          // 1024 entries in flight: a ~840-entry row is one round trip
-    for (uint64_t r0 = wave * kCompactRows; r0 < n_rows; r0 += n_waves * kCompactRows) {
-        const int nr = (int)(n_rows - r0 < (uint64_t)kCompactRows ? n_rows - r0 : kCompactRows);
-        uint32_t mine = 0;                    // lane i: row r0 + i
-        for (int i = 0; i < nr; ++i) {
-            const int64_t lo = indptr[r0 + i], hi = indptr[r0 + i + 1];
-            uint32_t rank0 = 0;               // kept entries of the row before this batch (wave-uniform)
-            for (int64_t base = lo; base < hi; base += kCountUnroll * kWave) {
-                int32_t g[kCountUnroll];
-#pragma unroll
-                for (int u = 0; u < kCountUnroll; ++u) {
-                    const int64_t p = base + u * kWave + lane;
-                    g[u] = p < hi ? (int32_t)idx[p] : -1;
-                }
-#pragma unroll
-                for (int u = 0; u < kCountUnroll; ++u) {
-                    int c = g[u] >= 0 ? sel.column(g[u]) : -1;
-                    if (c >= k) c = -1;       // only a broken selection (NaN variances) has such columns: dropped
-                    const unsigned long long mask = __ballot(c >= 0);
-                    if (c >= 0) {
-                        const uint32_t rank = rank0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                        const uint32_t pos = (uint32_t)(base - lo) + (uint32_t)(u * kWave + lane);
-                        kept[lo + rank] = (pos << 16) | (uint32_t)c;
-                    }
-                    rank0 += (uint32_t)__popcll(mask);
-                }
-            }
-            if (lane == i) mine = rank0;
-        }
-        if (lane < nr) cntrow[r0 + lane] = (int64_t)mine;     // 8 counters = one 64-byte line
-    }
-}
-
-// XF: `vals` are the raw values and the kept entries are stored as ln_1p(f64(v) * scale_row), rounded once (RowXf).
-template <typename T, bool XF>
-__global__ __launch_bounds__(256) void k_tfill_list(const int64_t* __restrict__ indptr, const T* __restrict__ vals,
-                                                    const uint32_t* __restrict__ kept, uint64_t n_rows,
-                                                    const int64_t* __restrict__ rm_ptr, const double* __restrict__ row_sum,
-                                                    double target, GramPk<T>* __restrict__ rm) {
-    __shared__ Log1pTabEntry s_tab[XF ? 128 : 1];
-    if constexpr (XF) {
-        stage_log1p_table(s_tab);
-        __syncthreads();
-    }
-    const uint64_t wave = global_wave_id();
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
-    const int lane = lane_id();
-    // a wave takes two rows at a time, half a wave each (a row keeps ~72 of its entries: two steps of 32); the rows of a pair
-    // are neighbours, so their words, their values and their entries are neighbours too
-    for (uint64_t r0 = wave * 2; r0 < n_rows; r0 += n_waves * 2) {
-        const uint64_t r = r0 + (lane >> 5);
-        const bool live = r < n_rows;
-        const int64_t lo = live ? indptr[r] : 0;
-        const int64_t o0 = live ? rm_ptr[r] : 0;
-        const int n = live ? (int)(rm_ptr[r + 1] - o0) : 0;
-        double scale = 1.0;
-        if constexpr (XF) {
-            const double sr = live ? row_sum[r] : 0.0;
-            scale = sr == 0.0 ? 0.0 : target / sr;      // scale/mod.rs:9-15
-        }
-        const int n_max = __builtin_amdgcn_readfirstlane(max(__shfl(n, 0, kWave), __shfl(n, 32, kWave)));
-        for (int t = lane & 31; t < n_max; t += 32) {
-            if (t < n) {
-                const uint32_t w = kept[lo + t];
-                T v = vals[lo + (w >> 16)];
-                if constexpr (XF) v = xf_stored(v, scale, s_tab);         // the value the write-back stores in X
-                GramPk<T> e{};
-                e.j = (int32_t)(w & 0xffffu);
-                e.v = v;
-                rm[o0 + t] = e;
-            }
-        }
-    }
-}
-
-template <typename I>
-__global__ __launch_bounds__(256) void k_tcount(const int64_t* __restrict__ indptr, const I* __restrict__ idx,
-                                                const uint32_t* __restrict__ g_bits,
-                                                const uint32_t* __restrict__ g_prefix, int n_words, uint64_t n_rows,
-                                                int nt128, int nt256, int k, int64_t* __restrict__ cntrow,
-                                                int64_t* __restrict__ cnt256) {
-    extern __shared__ double lds_raw[];
-    const SelLds sel = stage_selection(g_bits, g_prefix, n_words, reinterpret_cast<uint32_t*>(lds_raw));
-    const uint64_t wave = global_wave_id();
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
-    const int lane = lane_id();
-    // per-wave tile counters in LDS (after the selection table): a kept entry is one ds_add_u32 on its
-    // tile's counter — ~5 active lanes per 64-entry chunk — instead of a ballot-match loop over the tiles
-    // present in the chunk (the loop made this pass VALU-bound);
-    // one 64-counter row per row of the wave's current block of kCompactRows rows
-    uint32_t* tcnt = reinterpret_cast<uint32_t*>(lds_raw) + 2 * n_words + (threadIdx.x / kWave) * (kCompactRows * kWave);
-#pragma unroll
-    for (int i = 0; i < kCompactRows; ++i) tcnt[i * kWave + lane] = 0u;
-    // A wave takes kCompactRows CONSECUTIVE rows at a time and writes their counters out together: lane (tile, row)
-    // stores 8 bytes next to its 7 neighbours, i.e. one full 64-byte line per tile — stored row by row, the 24
-    // strided 8-byte counters of a row cost ~44 bytes of HBM write each (1.39 GB written for 0.25 GB of counters).
-    // Lane l of a chunk takes entry l (2-byte loads): consecutive entries of a row are ~1 bitmask word apart, so
-    // the 64 lookups of a chunk fall into 64 different LDS banks — 8 consecutive entries per lane (16-byte loads)
-    // were tried and cost an 8-way bank conflict per lookup.  kCountUnroll chunks (1024 entries) are issued
-    // together: with 4 a ~840-entry row was 4 dependent round trips to HBM.
-    constexpr int kCountUnroll = 16;
-    for (uint64_t r0 = wave * kCompactRows; r0 < n_rows; r0 += n_waves * kCompactRows) {
-        const int nr = (int)(n_rows - r0 < (uint64_t)kCompactRows ? n_rows - r0 : kCompactRows);
-        for (int i = 0; i < nr; ++i) {
-            const int64_t lo = indptr[r0 + i], hi = indptr[r0 + i + 1];
-            uint32_t* row_cnt = tcnt + i * kWave;
-            for (int64_t base = lo; base < hi; base += kCountUnroll * kWave) {
-                int32_t g[kCountUnroll];
-#pragma unroll
-                for (int u = 0; u < kCountUnroll; ++u) {
-                    const int64_t p = base + u * kWave + lane;
-                    g[u] = p < hi ? (int32_t)idx[p] : -1;
-                }
-#pragma unroll
-                for (int u = 0; u < kCountUnroll; ++u) {
-                    int col = g[u] >= 0 ? sel.column(g[u]) : -1;             // -1 for dropped entries
-                    if (col >= k) col = -1;          // only a broken selection (NaN variances) has such columns: dropped
-                    if (col >= 0) __hip_atomic_fetch_add(&row_cnt[col >> 7], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // lane q -> (tile q / 8, row q % 8)
-        if (lane < nr) {                                   // kept entries of row r0 + lane (the row-major layout's row length)
-            uint32_t tot = 0;
-            for (int t = 0; t < nt128; ++t) tot += tcnt[lane * kWave + t];
-            cntrow[r0 + lane] = (int64_t)tot;
-        }
-        for (int q = lane; q < nt256 * kCompactRows; q += kWave) {
-            const int t = q / kCompactRows, i = q % kCompactRows;
-            if (i < nr) cnt256[(uint64_t)t * n_rows + r0 + i] = (int64_t)(tcnt[i * kWave + 2 * t] + tcnt[i * kWave + 2 * t + 1]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-        for (int i = 0; i < kCompactRows; ++i) tcnt[i * kWave + lane] = 0u;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    }
-}
-
-// XF: `vals` are the raw values and the kept entries are stored as ln_1p(f64(v) * scale_row), rounded once (RowXf).
-template <typename T, typename I, bool XF>
-__global__ __launch_bounds__(256) void k_tfill(const int64_t* __restrict__ indptr, const I* __restrict__ idx,
-                                               const T* __restrict__ vals, const uint32_t* __restrict__ g_bits,
-                                               const uint32_t* __restrict__ g_prefix, int n_words, uint64_t n_rows,
-                                               int nt256, int k, const int64_t* __restrict__ cnt256,
-                                               const int64_t* __restrict__ rm_ptr,
-                                               const int64_t* __restrict__ tptr256, const double* __restrict__ row_sum,
-                                               double target, GramPk<T>* __restrict__ rm, GramPk<T>* __restrict__ pk256) {
-    extern __shared__ double lds_raw[];
-    __shared__ Log1pTabEntry s_tab[XF ? 128 : 1];
-    if constexpr (XF) stage_log1p_table(s_tab);
-    const SelLds sel = stage_selection(g_bits, g_prefix, n_words, reinterpret_cast<uint32_t*>(lds_raw));
-    const uint64_t wave = global_wave_id();
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
-    const int lane = lane_id();
-    for (uint64_t r = (wave * kCompactRows); r < n_rows; r = next_compact_row(r, n_waves)) {
-        const int64_t lo = indptr[r], hi = indptr[r + 1];
-        // lane t: kept entries before 256-tile t in this row (exclusive prefix over the tile counters)
-        const int c_t = lane < nt256 ? (int)cnt256[(uint64_t)lane * n_rows + r] : 0;
-        int inc = c_t;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const int o = __shfl_up(inc, off, kWave);
-            if (lane >= off) inc += o;
-        }
-        const int before256 = inc - c_t;
-        // destination bias of each tile: tptr - (kept entries before the tile)
-        const int64_t off256 = (lane < nt256 ? tptr256[(uint64_t)lane * n_rows + r] : 0) - before256;
-        const int64_t row_base = rm_ptr[r];
-        double scale = 1.0, row_table = 0.0;
-        if constexpr (XF) {
-            const double sr = row_sum[r];
-            scale = sr == 0.0 ? 0.0 : target / sr;      // scale/mod.rs:9-15
-        }
-        (void)row_table;
-        int rank0 = 0;                                  // kept entries of the row before this chunk
-        // (tried and slower at c3: 16 chunks in flight, 2.42 ms — the ballots / shuffles of the masked-out tail
-        //  chunks cost more than the loads gain; parking the kept entries in LDS and writing them out per row,
-        //  2.59 ms — the value gather then waits for the whole row and the stage halves the occupancy; bucketing the
-        //  entries by Gram owner here, one workgroup per row block: 2.65 ms against 1.3 + a separate 0.4 ms pass)
-        for (int64_t base = lo; base < hi; base += kFillUnroll * kWave) {
-            int32_t g[kFillUnroll];
-#pragma unroll
-            for (int u = 0; u < kFillUnroll; ++u) {
-                const int64_t p = base + u * kWave + lane;
-                g[u] = p < hi ? (int32_t)idx[p] : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < kFillUnroll; ++u) {
-                const int64_t p = base + u * kWave + lane;
-                int32_t c = g[u] >= 0 ? sel.column(g[u]) : -1;
-                if (c >= k) c = -1;
-                const unsigned long long mask = __ballot(c >= 0);
-                const int cc = c >= 0 ? c : 0;
-                const int64_t o256 = __shfl(off256, cc >> 8, kWave);   // shuffles run with all lanes active
-                if (c >= 0) {
-                    const int rank = rank0 + __popcll(mask & ((1ull << lane) - 1ull));
-                    T v = vals[p];
-                    if constexpr (XF) v = xf_stored(v, scale, s_tab);         // the value the write-back stores in X
-                    GramPk<T> e{};
-                    e.j = c;
-                    e.v = v;
-                    rm[row_base + rank] = e;
-                    if (nt256 > 0) {
-                        e.j = c & 255;
-                        pk256[o256 + rank] = e;
-                    }
-                }
-                rank0 += __popcll(mask);
-            }
-        }
-    }
-}
+#include "compact.inl"
 
 // ---- small vector helpers ------------------------------------------------------------------------
 template <typename PT> struct Vec4;
@@ -623,1781 +100,11 @@ __device__ __forceinline__ double readlane_v(double x, int l) {
     return __builtin_bit_cast(double, readlane64(__builtin_bit_cast(long long, x), l));
 }
 
-// ---- forward SpMM: Y = A P - 1 cvec^T ----------------------------------------------------------
-// Workgroup = 512 threads = 32 groups of 16 lanes; a group owns 16 consecutive cells and lane
-// q of it owns panel columns 4q..4q+3 of all 16 output rows (64 accumulator registers).  The
-// workgroup walks the gene tiles; per tile it stages the 256 x 64 panel tile in LDS (64 KiB
-// as f32), then every group reads the <= 16 (index, value) pairs of each of its rows' tile
-// segment with one coalesced load and every lane visits them in DPP-rotated order (lane q
-// takes pair (q+s)%16 at step s): one conflict-free ds_read_b128 of the panel row + 4 FMAs
-// per pair, no broadcast and no atomics.  Empty slots carry value 0 and index 0.
-constexpr int kFwdThreads = 512;
-template <typename PT> struct FwdCfg;
-template <> struct FwdCfg<float> { static constexpr int kRows = 8, kWavesPerSimd = 4, kStage = 8; };   // 2 workgroups / CU
-template <> struct FwdCfg<double> { static constexpr int kRows = 8, kWavesPerSimd = 2, kStage = 4; };   // 1 workgroup / CU
+#include "spmm.inl"
 
-template <typename PT, int S>
-struct FwdRot {
-    // Step S uses the pair currently in (ci, cv), then rotates both by ONE lane for the next step.
-    // (Rotating the original pair by S at every step gives the scheduler 30 independent DPP moves
-    // per row to hoist — it did, and spilled; the chain keeps one live copy.)
-    static __device__ __forceinline__ void run(int ci, PT cv, const PT* __restrict__ panel_q, PT (&a)[4]) {
-        Vec4<PT> p;
-        p.load(panel_q + ci);
-        a[0] += cv * p[0];
-        a[1] += cv * p[1];
-        a[2] += cv * p[2];
-        a[3] += cv * p[3];
-        // at most 4 panel reads (16 VGPRs) in flight: without the fence the scheduler hoists the
-        // ds_read_b128 of all 16 steps (64 VGPRs per row) and spills under the 128-VGPR budget
-        if constexpr ((S & 3) == 3) asm volatile("" ::: "memory");
-        if constexpr (S + 1 < 16) FwdRot<PT, S + 1>::run(ror16<1>(ci), ror16<1>(cv), panel_q, a);
-    }
-};
+#include "gram.inl"
 
-// One batch of kStage rows of a group: issue their (index, value) chunk loads together, then
-// run the 16 rotation steps of each.  H is a compile-time row offset so that the accumulator
-// array is only ever indexed statically (it must stay in registers).  Rows of a group are
-// consecutive, so row r's segment ends where row r+1's starts: `la` (lane q: start of row q,
-// relative to the group's first entry) and `le` (end of the last row) describe all of them.
-// Index loads are unconditional (the arrays are padded by 64 entries; a stray index is a valid
-// local column) and only the VALUE is masked to 0 — no divergent branches around the loads.
-template <typename VT, typename PT, int kRows, int kStage, int H>
-__device__ __forceinline__ void fwd_stage(const GramPk<VT>* __restrict__ gpk, int la, int le, int c, int q,
-                                          const PT* __restrict__ panel_q, PT (&acc)[kRows][4]) {
-    if constexpr (H < kRows) {
-        int ci[kStage];
-        PT cvv[kStage];
-#pragma unroll
-        for (int r = 0; r < kStage; ++r) {
-            const int lo = __shfl(la, H + r, 16) + c;
-            const int hi = (H + r + 1 < 16) ? __shfl(la, (H + r + 1) & 15, 16) : le;
-            const int p = lo + q;
-            const GramPk<VT> e = gpk[p];
-            ci[r] = e.j * L;
-            cvv[r] = p < hi ? (PT)e.v : PT(0);
-        }
-#pragma unroll
-        for (int r = 0; r < kStage; ++r) FwdRot<PT, 0>::run(ci[r], cvv[r], panel_q, acc[H + r]);
-        fwd_stage<VT, PT, kRows, kStage, H + kStage>(gpk, la, le, c, q, panel_q, acc);
-    }
-}
-
-// Entries 16.. of row H (and, recursively, of the rows after it) for the groups that have them.
-template <typename VT, typename PT, int kRows, int H>
-__device__ __forceinline__ void fwd_overflow(const GramPk<VT>* __restrict__ gpk, int la, int le, int q,
-                                             const PT* __restrict__ panel_q, PT (&acc)[kRows][4]) {
-    if constexpr (H < kRows) {
-        const int lo = __shfl(la, H, 16);
-        const int hi = (H + 1 < 16) ? __shfl(la, (H + 1) & 15, 16) : le;
-        for (int c = 16; __any(hi - lo > c); c += 16) {
-            const int p = lo + c + q;
-            const GramPk<VT> e = gpk[p];
-            FwdRot<PT, 0>::run(e.j * L, p < hi ? (PT)e.v : PT(0), panel_q, acc[H]);
-        }
-        fwd_overflow<VT, PT, kRows, H + 1>(gpk, la, le, q, panel_q, acc);
-    }
-}
-
-template <typename VT, typename PT>
-__global__ __launch_bounds__(kFwdThreads, FwdCfg<PT>::kWavesPerSimd) void k_spmm_fwd(
-    const int64_t* __restrict__ tptr, const GramPk<VT>* __restrict__ tpk, uint64_t n_rows,
-    int nt, int k, const PT* __restrict__ P, const PT* __restrict__ cvec, PT* __restrict__ Y,
-    double* __restrict__ scores /* nullable: n_rows x ld row-major f64 (first n_pc panel columns), written INSTEAD of Y */,
-    int n_pc, int ld) {
-    constexpr int kRows = FwdCfg<PT>::kRows;            // rows per 16-lane group
-    constexpr int kRowsPerWg = (kFwdThreads / 16) * kRows;
-    constexpr int kStage = FwdCfg<PT>::kStage;          // rows whose (index, value) chunks are in flight together
-    extern __shared__ double lds_raw[];
-    PT* panel = reinterpret_cast<PT*>(lds_raw);
-    const int q = threadIdx.x & 15;
-    const int group = threadIdx.x >> 4;
-    const PT* panel_q = panel + 4 * q;
-    Vec4<PT> cv4;
-    cv4.load(cvec + 4 * q);
-    const uint64_t n_blocks = (n_rows + kRowsPerWg - 1) / kRowsPerWg;
-    for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-        const uint64_t i0 = blk * kRowsPerWg + (uint64_t)group * kRows;
-        PT acc[kRows][4];
-#pragma unroll
-        for (int r = 0; r < kRows; ++r) acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = PT(0);
-        for (int t = 0; t < nt; ++t) {
-            __syncthreads();                         // everyone is done with the previous tile
-            for (int e = threadIdx.x * 4; e < KT * L; e += kFwdThreads * 4) {
-                Vec4<PT> v;
-                if (t * KT + e / L < k) v.load(P + (size_t)t * KT * L + e);
-                else v[0] = v[1] = v[2] = v[3] = PT(0);
-                v.store(panel + e);
-            }
-            __syncthreads();
-            // lane q: start of row i0+q in this tile (rows past the end collapse to empty segments)
-            const int64_t* tp = tptr + (uint64_t)t * n_rows;
-            const uint64_t rq = i0 + q < n_rows ? i0 + q : n_rows;
-            const uint64_t rend = i0 + kRows < n_rows ? i0 + kRows : n_rows;
-            const int64_t pa = tp[rq];
-            const int64_t p0 = __shfl(pa, 0, 16);
-            const int la = (int)(pa - p0);
-            const int le = (int)(tp[rend] - p0);
-            // NB: the shuffle must run with every lane active (a lane-dependent ?: would mask lane 15
-            // out of the ds_bpermute and lane 14 would read 0 from it)
-            const int la_next = __shfl(la, (q + 1) & 15, 16);
-            const int nxt = (q + 1 < 16) ? la_next : le;
-            const int len = q < kRows ? (q + 1 < kRows ? nxt : le) - la : 0;
-            const GramPk<VT>* gpk = tpk + p0;
-            fwd_stage<VT, PT, kRows, kStage, 0>(gpk, la, le, 0, q, panel_q, acc);
-            // segments longer than 16 entries are rare (~1 % of rows at m/k*256 = 9): finish them row by
-            // row instead of sending the whole wave through another 16-row pass
-            if (__any(len > 16)) fwd_overflow<VT, PT, kRows, 0>(gpk, la, le, q, panel_q, acc);
-        }
-#pragma unroll
-        for (int r = 0; r < kRows; ++r) {
-            const uint64_t row = i0 + r;
-            if (row < n_rows) {
-                Vec4<PT> o;
-                o[0] = acc[r][0] - cv4[0];
-                o[1] = acc[r][1] - cv4[1];
-                o[2] = acc[r][2] - cv4[2];
-                o[3] = acc[r][3] - cv4[3];
-                if (scores) {            // the transform pass: obsm["X_pca"] layout directly (dim_red/mod.rs:105-106)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (4 * q + j < n_pc) scores[row * (uint64_t)ld + 4 * q + j] = (double)o[j];
-                } else {
-                    o.store(Y + row * L + 4 * q);
-                }
-            }
-        }
-    }
-}
-
-// ---- forward SpMM from the ROW-MAJOR records: Y[:, slice] = A P[:, slice] - 1 c^T (round 2) -------------------------
-// The tile-major kernel above cuts the gene axis into 256-column tiles because a 64-column panel does not fit the LDS
-// (2000 x 64 x 4 B = 512 KB); a row then falls into ~8 segments of ~9 entries, visited in 16-slot chunks: 56 % of the
-// rotation steps carry a zero.  Here the PANEL COLUMNS are cut instead: a workgroup holds C = 4 Q columns of ALL k genes
-// (k x C x sizeof(PT): 128 KB at k = 2000 with C = 16 floats / 8 doubles) and walks whole rows; the n_pc / C column
-// slices of the same rows run on neighbouring workgroups (blockIdx = row group x n_slices + slice), so the matrix comes
-// out of L2 for all but the first of them.  A row is taken by Q adjacent lanes (lane q owns columns 4q .. 4q+3 of the
-// slice): they load Q consecutive records per step and broadcast them to each other in order (DPP quad_perm), one
-// ds_read_b128 of the panel row + 4 FMAs per record and lane — chunks of Q instead of 16: no padding worth mentioning.
-constexpr int kFwdRowsThreads = 1024;
-
-template <int Q>
-__device__ __forceinline__ int quad_bcast(int x, int s) {
-    if constexpr (Q == 1) {
-        return x;                                               // one lane per row: nothing to broadcast
-    } else if constexpr (Q == 4) {
-        switch (s) {                                            // v_mov_b32_dpp quad_perm:[s,s,s,s]
-            case 0: return __builtin_amdgcn_update_dpp(0, x, 0x00, 0xf, 0xf, true);   // (bound_ctrl: no "old" value to set up)
-            case 1: return __builtin_amdgcn_update_dpp(0, x, 0x55, 0xf, 0xf, true);
-            case 2: return __builtin_amdgcn_update_dpp(0, x, 0xaa, 0xf, 0xf, true);
-            default: return __builtin_amdgcn_update_dpp(0, x, 0xff, 0xf, 0xf, true);
-        }
-    } else {                                                    // pairs: lanes (2i, 2i+1) of every quad
-        return s == 0 ? __builtin_amdgcn_update_dpp(0, x, 0xa0, 0xf, 0xf, true)       // [0,0,2,2]
-                      : __builtin_amdgcn_update_dpp(0, x, 0xf5, 0xf, 0xf, true);      // [1,1,3,3]
-    }
-}
-template <int Q>
-__device__ __forceinline__ float quad_bcast_v(float x, int s) {
-    return __builtin_bit_cast(float, quad_bcast<Q>(__builtin_bit_cast(int, x), s));
-}
-template <int Q>
-__device__ __forceinline__ double quad_bcast_v(double x, int s) {
-    const long long b = __builtin_bit_cast(long long, x);
-    const int lo = quad_bcast<Q>((int)(b & 0xffffffffll), s), hi = quad_bcast<Q>((int)(b >> 32), s);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
-
-// Rows ordered by their number of kept entries (counting sort on the length, `perm`): the Q-lane groups of a wave then
-// hold rows of (nearly) equal length and the record loop is wave-uniform — with rows in natural order a wave runs as long as
-// the longest of its 16 rows (+30 %), and walking several rows per group as one stream instead puts a row-boundary test
-// into every step of 16 independent streams (that version: 1.44 ms against the tile-major kernel's 1.22).
-constexpr int kLenBins = 512;
-constexpr int kLenRowsPerWg = 4096;
-__global__ __launch_bounds__(256) void k_len_hist(const int64_t* __restrict__ rm_ptr, uint64_t n_rows,
-                                                  uint32_t* __restrict__ hist /* kLenBins, zeroed */) {
-    __shared__ uint32_t s[kLenBins];
-    for (int e = threadIdx.x; e < kLenBins; e += blockDim.x) s[e] = 0u;
-    __syncthreads();
-    const uint64_t r0 = (uint64_t)blockIdx.x * kLenRowsPerWg, r1 = r0 + kLenRowsPerWg < n_rows ? r0 + kLenRowsPerWg : n_rows;
-    for (uint64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
-        const int64_t n = rm_ptr[r + 1] - rm_ptr[r];
-        atomicAdd(&s[n < kLenBins - 1 ? (int)n : kLenBins - 1], 1u);
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < kLenBins; e += blockDim.x)
-        if (s[e]) atomicAdd(&hist[e], s[e]);
-}
-__global__ void k_len_scan(uint32_t* __restrict__ hist /* kLenBins counts -> exclusive offsets */) {
-    __shared__ uint32_t s[kLenBins];
-    const int t = threadIdx.x;
-    s[t] = hist[t];
-    __syncthreads();
-    if (t == 0) {
-        uint32_t run = 0;
-        for (int i = 0; i < kLenBins; ++i) { const uint32_t c = s[i]; s[i] = run; run += c; }
-    }
-    __syncthreads();
-    hist[t] = s[t];
-}
-// a workgroup reserves, per length, a run for its rows with ONE global atomic and fills it through LDS cursors
-__global__ __launch_bounds__(256) void k_len_scatter(const int64_t* __restrict__ rm_ptr, uint64_t n_rows,
-                                                     uint32_t* __restrict__ cursor, uint32_t* __restrict__ perm) {
-    __shared__ uint32_t s[kLenBins];
-    for (int e = threadIdx.x; e < kLenBins; e += blockDim.x) s[e] = 0u;
-    __syncthreads();
-    const uint64_t r0 = (uint64_t)blockIdx.x * kLenRowsPerWg, r1 = r0 + kLenRowsPerWg < n_rows ? r0 + kLenRowsPerWg : n_rows;
-    for (uint64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
-        const int64_t n = rm_ptr[r + 1] - rm_ptr[r];
-        atomicAdd(&s[n < kLenBins - 1 ? (int)n : kLenBins - 1], 1u);
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < kLenBins; e += blockDim.x) {
-        const uint32_t c = s[e];
-        s[e] = c ? atomicAdd(&cursor[e], c) : 0u;
-    }
-    __syncthreads();
-    for (uint64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
-        const int64_t n = rm_ptr[r + 1] - rm_ptr[r];
-        perm[atomicAdd(&s[n < kLenBins - 1 ? (int)n : kLenBins - 1], 1u)] = (uint32_t)r;
-    }
-}
-
-// RANGE: the panel slice of ALL k genes does not fit the LDS (f64 panels beyond 5118 genes): the launch covers the genes
-// [k_lo, k_hi) only — entries outside contribute nothing — and, from the second range on (`accumulate`), adds to what the
-// earlier ranges left in the output.
-// CL: panel columns per lane — 4, or 5 (the lane's four + one of the slice's last Q columns): a slice of 5 Q columns of all k
-// genes is the widest the LDS takes at k = 2000 (160 000 B), and n_pc = 50 then needs 3 (f32; 5 with f64 panels) passes over
-// the matrix instead of 4 (7) — the kernel is bound by its reads (see the note in the body), not by what it does with them.
-template <typename VT, typename PT, int Q, bool RANGE = false, int CL = 4>
-__global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
-    const int64_t* __restrict__ rm_ptr, const GramPk<VT>* rm /* NOT __restrict__: see the barrier behind the chunk loads */,
-    const uint32_t* __restrict__ perm /* nullable */,
-    uint64_t n_rows, int k, const PT* __restrict__ P /* k x 64 */, const PT* __restrict__ cvec /* 64 */,
-    int n_cols /* panel columns wanted */, double* __restrict__ scores /* n_rows x ld f64 (nullable) */,
-    PT* __restrict__ Y /* n_rows x 64 (nullable) */, int ld, int ldp /* elements between two genes of the slice in LDS */,
-    int k_lo = 0, int k_hi = 0, int accumulate = 0, int col_base = 0 /* first panel column of this launch */) {
-    static_assert(CL == 4 || CL == 5, "columns per lane");
-    constexpr int C = CL * Q;
-    if constexpr (!RANGE) {
-        k_lo = 0;
-        k_hi = k;
-    }
-    extern __shared__ double lds_raw[];
-    PT* panel = reinterpret_cast<PT*>(lds_raw);                 // k x C
-    const int n_slices = (n_cols - col_base + C - 1) / C;
-    // the column slices of one row range sit on the SAME XCD (consecutive workgroup ids go round the 8 XCDs): they walk the
-    // same rows at the same pace, so the entries come out of that XCD's L2 for all but the first of them
-    const uint64_t n_wg = gridDim.x / n_slices;
-    int slice;
-    uint64_t wg;
-    if (n_wg % 8 == 0) {
-        const uint64_t t = blockIdx.x / 8;
-        slice = (int)(t % n_slices);
-        wg = (t / n_slices) * 8 + blockIdx.x % 8;
-    } else {
-        slice = blockIdx.x % n_slices;
-        wg = blockIdx.x / n_slices;
-    }
-    // a gene of the slice in LDS: its C columns in panel order
-    if constexpr (C % 4 == 0) {
-        for (int e = threadIdx.x; e < (k_hi - k_lo) * (C / 4); e += kFwdRowsThreads) {
-            const int j = e / (C / 4), cq = e % (C / 4);
-            Vec4<PT> v;
-            v.load(P + (size_t)(k_lo + j) * L + col_base + slice * C + cq * 4);
-            v.store(panel + (size_t)j * ldp + cq * 4);
-        }
-    } else {
-        for (int e = threadIdx.x; e < (k_hi - k_lo) * C; e += kFwdRowsThreads) {
-            const int j = e / C, cq = e % C;
-            panel[(size_t)j * ldp + cq] = P[(size_t)(k_lo + j) * L + col_base + slice * C + cq];
-        }
-    }
-    __syncthreads();
-    const int ql = threadIdx.x % Q;                             // lane within the row's lane group
-    constexpr uint64_t kGroups = kFwdRowsThreads / Q;
-    const int col0 = col_base + slice * C + ql * 4;             // the lane's four columns ...
-    const int colx = col_base + slice * C + 4 * Q + ql;         // ... and, CL = 5, its one of the slice's last Q
-    Vec4<PT> cv4;
-    cv4.load(cvec + col0);
-    PT cvx = PT(0);
-    if constexpr (CL == 5) cvx = cvec[colx];
-    constexpr int kGeneBytes = C * (int)sizeof(PT);             // one gene of the slice in LDS
-    const char* panel_q = reinterpret_cast<const char*>(panel) + ql * 4 * (int)sizeof(PT);
-    const char* panel_x = reinterpret_cast<const char*>(panel) + (4 * Q + ql) * (int)sizeof(PT);
-    // sorted position i -> row perm[i]; a wave's groups take consecutive positions (equal lengths), the workgroups
-    // interleave so that the long rows at the end are spread over all of them.
-    // A chunk = 4 Q consecutive records of a row (lane ql holds records 4 ql .. 4 ql + 3: one 32- / 64-byte load per lane); a
-    // BATCH = kSub chunks.  The lane group's rows are one stream of batches worked through with two register sets: the batch
-    // after this one — the row's next, or the first of the next row, whose pointers came a row ahead — is in flight while this
-    // one is multiplied, and a row's output stores are issued behind the loads of the next row's first batch (vmcnt counts in
-    // order: a load waited for behind a store waits for the store's acknowledgement too).
-    // What round 2's loop did instead, timed inside the kernel (-DSPMM_TIMING, ns per 16-row step of a wave, 7.1-10.7 us in
-    // all): it had "load the next chunk, work on this one, cur = nxt", which the compiler turned into "load this chunk,
-    // wait, work on it" (the next load equals the following iteration's) — an exposed ~0.85 us round trip per chunk; its 16
-    // panel reads per chunk were re-interleaved with the multiply-adds two reads deep by the scheduler — 16 LDS round
-    // trips per chunk, 1.7 us per row; the copy of the next row's pointers at the top of the body waited for the loads
-    // just issued; four 8-byte stores per lane behind exec branches.
-#ifndef SPMM_KSUB
-#define SPMM_KSUB 2
-#endif
-    constexpr int kSub = sizeof(VT) == 4 && CL == 4 ? SPMM_KSUB : 1;
-    constexpr int kBatch = kSub * 4 * Q;                        // records of a batch
-    const uint64_t stride = n_wg * kGroups, i_first = wg * kGroups + threadIdx.x / Q, last_row = n_rows ? n_rows - 1 : 0;
-    if (i_first >= n_rows) return;
-    auto row_at = [&](uint64_t i) -> uint64_t {
-        const uint64_t c = i < n_rows ? i : last_row;
-        return perm ? (uint64_t)perm[c] : c;
-    };
-    struct Batch { GramPk<VT> r[kSub][4]; };
-    auto load_batch = [&](Batch& b, const GramPk<VT>* base /* the row's records */, int st, int n) {
-#pragma unroll
-        for (int c = 0; c < kSub; ++c) {
-            // (a chunk past the row's end is not fetched: its lanes read the row's first chunk again)
-            const GramPk<VT>* at = st + c * 4 * Q < n ? base + st + c * 4 * Q : base;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) b.r[c][u] = at[ql * 4 + u];    // (the array is padded by a wave of records)
-        }
-    };
-    uint64_t i = i_first;
-    // position -> row -> row pointers -> records is three dependent loads: the pointers of the next row are resident, those of
-    // the row after it and the row of the position behind that one were asked for a row ago (a step selects between "this
-    // row's next batch" and "the next row's first" — it needs the next row's pointers at once)
-    uint64_t row_c = row_at(i), row_n = row_at(i + stride), row_nn = row_at(i + 2 * stride), row_n3 = row_at(i + 3 * stride);
-    int64_t lo = rm_ptr[row_c];
-    int n = (int)(rm_ptr[row_c + 1] - lo);
-    int64_t lo_n = rm_ptr[row_n], hi_n = rm_ptr[row_n + 1];
-    int64_t lo_nn = rm_ptr[row_nn], hi_nn = rm_ptr[row_nn + 1];
-    const GramPk<VT>* rr = rm + lo;
-    int st = 0;
-    PT a0 = PT(0), a1 = PT(0), a2 = PT(0), a3 = PT(0), ax = PT(0);
-    bool done = false;
-#ifdef SPMM_TIMING
-    long long tW = 0, tM = 0, tO = 0, tRows = 0, tBatches = 0;
-#define SPMM_STAMP(x) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(0) : "memory"); const long long x = wall_clock64();
-#endif
-    struct Out { uint64_t row; PT o[4]; PT x; };
-    auto store_row = [&](const Out& q) {
-        const PT o0 = q.o[0], o1 = q.o[1], o2 = q.o[2], o3 = q.o[3], ox = q.x;
-        const uint64_t row_o = q.row;
-#ifdef SPMM_NOSTORE
-        if (o0 == PT(123456.0))
-#endif
-        if (scores) {
-            if constexpr (CL == 5) {
-                if (colx < n_cols) {
-                    double* dx = scores + row_o * (uint64_t)ld + colx;
-                    *dx = RANGE && accumulate ? *dx + (double)ox : (double)ox;
-                }
-            }
-            double* dst = scores + row_o * (uint64_t)ld + col0;
-            if (!(RANGE && accumulate) && col0 + 3 < n_cols && ld % 2 == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0) {
-                // four doubles as two 16-byte stores.  (Non-temporal stores: 0.79 against 0.68 ms — the pieces of a row written
-                // by the slices' workgroups meet in L2.  Lanes owning the column pairs {2q, 2q + 1} and {2Q + 2q, ..} so that a
-                // store instruction covers 64 contiguous bytes per row, and record loads laid out the same way: no change.)
-                *reinterpret_cast<double2*>(dst) = double2{(double)o0, (double)o1};
-                *reinterpret_cast<double2*>(dst + 2) = double2{(double)o2, (double)o3};
-            } else if (RANGE && accumulate) {
-                if (col0 + 0 < n_cols) dst[0] += (double)o0;
-                if (col0 + 1 < n_cols) dst[1] += (double)o1;
-                if (col0 + 2 < n_cols) dst[2] += (double)o2;
-                if (col0 + 3 < n_cols) dst[3] += (double)o3;
-            } else {
-                if (col0 + 0 < n_cols) dst[0] = (double)o0;
-                if (col0 + 1 < n_cols) dst[1] = (double)o1;
-                if (col0 + 2 < n_cols) dst[2] = (double)o2;
-                if (col0 + 3 < n_cols) dst[3] = (double)o3;
-            }
-        } else {
-            Vec4<PT> o;
-            if (RANGE && accumulate) {
-                o.load(Y + row_o * L + col0);
-                o[0] += o0; o[1] += o1; o[2] += o2; o[3] += o3;
-            } else {
-                o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
-            }
-            o.store(Y + row_o * L + col0);
-            if constexpr (CL == 5) {
-                PT* yx = Y + row_o * L + colx;
-                *yx = RANGE && accumulate ? *yx + ox : ox;
-            }
-        }
-    };
-    // one batch: fetch the following one into `nxt`, multiply `cur`, finish the row if this was its last batch
-    auto step = [&](const Batch& cur, Batch& nxt) {
-        const bool last = st + kBatch >= n;
-        load_batch(nxt, last ? rm + lo_n : rr, last ? 0 : st + kBatch, last ? (int)(hi_n - lo_n) : n);
-        // the loads stay HERE (`rm` is not `__restrict__`: a load nothing can alias may be moved across this barrier, and the
-        // compiler then sinks it to its first use — behind the multiplication)
-        asm volatile("" ::: "memory");
-#ifdef SPMM_TIMING
-        const long long t1 = wall_clock64();
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kSub * (int)sizeof(GramPk<VT>) / 8) : "memory");   // cur is here
-        const long long t2 = wall_clock64();
-        tW += t2 - t1;
-        ++tBatches;
-#endif
-#pragma unroll
-        for (int c = 0; c < kSub; ++c) {
-            const int s0 = st + c * 4 * Q;
-            if (s0 >= n && c > 0) break;
-#ifdef SPMM_NOMUL
-            a0 += (PT)cur.r[c][0].v + (PT)cur.r[c][1].j + (PT)cur.r[c][2].v + (PT)cur.r[c][3].v;
-            continue;
-#endif
-            // the lane's own four records: byte offset of the gene in the slice, value zeroed past the row's end (the
-            // column is then a valid one of a later row, or of the zeroed tail) or outside the launch's gene range
-            int off[4];
-            PT val[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int j = cur.r[c][u].j;
-                bool ok = s0 + ql * 4 + u < n;
-                if constexpr (RANGE) {
-                    const bool in = j >= k_lo && j < k_hi;
-                    ok = ok && in;
-                    j = in ? j - k_lo : 0;
-                }
-                off[u] = j * kGeneBytes;
-                val[u] = ok ? (PT)cur.r[c][u].v : PT(0);
-            }
-            // kDeep panel reads first (their addresses only need the broadcast offsets), then their multiply-adds; the barrier
-            // keeps the scheduler from re-interleaving them two deep to save registers
-            constexpr int kDeep = sizeof(PT) == 4 ? (CL == 4 ? 4 * Q : 2 * Q) : (Q >= 2 ? 2 * Q : 4 * Q);
-#pragma unroll
-            for (int h = 0; h < 4 * Q; h += kDeep) {
-                Vec4<PT> pv[kDeep];
-                PT px[kDeep];
-#pragma unroll
-                for (int s_ = 0; s_ < kDeep; ++s_) {
-                    const int o = quad_bcast<Q>(off[(h + s_) & 3], (h + s_) >> 2);
-                    pv[s_].load(reinterpret_cast<const PT*>(panel_q + o));
-                    if constexpr (CL == 5) px[s_] = *reinterpret_cast<const PT*>(panel_x + o);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int s_ = 0; s_ < kDeep; ++s_) {
-                    const PT v = quad_bcast_v<Q>(val[(h + s_) & 3], (h + s_) >> 2);
-                    a0 += v * pv[s_][0];
-                    a1 += v * pv[s_][1];
-                    a2 += v * pv[s_][2];
-                    a3 += v * pv[s_][3];
-                    if constexpr (CL == 5) ax += v * px[s_];
-                }
-            }
-        }
-#ifdef SPMM_TIMING
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const long long t3 = wall_clock64();
-        tM += t3 - t2;
-#endif
-        if (!last) {
-            st += kBatch;
-            return;
-        }
-        // (a register queue that sent the results of 2 / 4 rows out together changed nothing: it is not the stores' latency)
-        i += stride;
-        done = i >= n_rows;
-        {
-            Out q;
-            q.row = row_c;
-            q.o[0] = a0 - cv4[0]; q.o[1] = a1 - cv4[1]; q.o[2] = a2 - cv4[2]; q.o[3] = a3 - cv4[3];
-            q.x = ax - cvx;
-            if (RANGE && accumulate) { q.o[0] = a0; q.o[1] = a1; q.o[2] = a2; q.o[3] = a3; q.x = ax; }   // (the centring term went in with the first range)
-            store_row(q);
-        }
-        // next row
-        row_c = row_n;
-        lo = lo_n;
-        n = (int)(hi_n - lo_n);
-        rr = rm + lo;
-        st = 0;
-        a0 = a1 = a2 = a3 = ax = PT(0);
-        row_n = row_nn;
-        lo_n = lo_nn;
-        hi_n = hi_nn;
-        row_nn = row_n3;
-        lo_nn = rm_ptr[row_nn];
-        hi_nn = rm_ptr[row_nn + 1];
-        row_n3 = row_at(i + 3 * stride);
-#ifdef SPMM_TIMING
-        tO += wall_clock64() - t3;
-        ++tRows;
-#endif
-    };
-    Batch A, B;
-    load_batch(A, rr, 0, n);
-#ifdef SPMM_TIMING
-    const long long tk0 = wall_clock64();
-#endif
-    for (;;) {
-        step(A, B);
-        if (done) break;
-        step(B, A);
-        if (done) break;
-    }
-#ifdef SPMM_TIMING
-    if (threadIdx.x % 64 == 0 && (threadIdx.x / 64) % 5 == 0 && blockIdx.x % 67 == 0 && tRows)
-        printf("[spmm timing blk %d wave %d] rows %lld, %.2f batches per row, %.0f ns per row: waiting for the batch %.0f, multiply %.0f, output + next pointers (issue) %.0f\n",
-               (int)blockIdx.x, (int)(threadIdx.x / 64), tRows, (double)tBatches / tRows, (wall_clock64() - tk0) * 10.0 / tRows,
-               tW * 10.0 / tRows, tM * 10.0 / tRows, tO * 10.0 / tRows);
-#endif
-}
-
-// ---- transposed SpMM: T = A^T Y (k x l), s = 1^T Y ---------------------------------------------
-// Workgroup = (gene tile, row block), 1024 threads; the tile's 256 x 64 accumulators live in
-// LDS (128 KiB as f64).  A wave takes 16 consecutive cells at a time: their tile segments
-// are ONE contiguous range of the tile-major arrays (coalesced 64-wide loads), lane c holds
-// y[r][c] of the 16 rows in registers, and each non-zero is broadcast with v_readlane and
-// scattered with one 64-lane LDS atomic add on 64 consecutive words (conflict-free).  The
-// per-row-block partials are summed in fixed order by k_t_reduce.
-constexpr int kTBatch = 16;
-
-template <typename VT, typename YT, typename AT>
-__global__ __launch_bounds__(kTThreads) void k_spmm_t(const int64_t* __restrict__ tptr,
-                                                      const GramPk<VT>* __restrict__ tpk, uint64_t n_rows, int k, int nt,
-                                                      uint64_t rows_per_block, const YT* __restrict__ Y,
-                                                      AT* __restrict__ part /* [rb][k][L] */,
-                                                      double* __restrict__ part_s /* [rb][L] */) {
-    extern __shared__ double lds_raw[];
-    AT* acc = reinterpret_cast<AT*>(lds_raw);
-    for (int e = threadIdx.x; e < KT * L; e += kTThreads) acc[e] = AT(0);
-    __syncthreads();
-    const int tile = blockIdx.x % nt;
-    const uint64_t rb = blockIdx.x / nt;
-    const uint64_t r0 = rb * rows_per_block;
-    const uint64_t r1 = r0 + rows_per_block < n_rows ? r0 + rows_per_block : n_rows;
-    const int lane = lane_id();
-    const int wave = threadIdx.x / kWave;
-    constexpr int kWaves = kTThreads / kWave;
-    const int64_t* tp = tptr + (uint64_t)tile * n_rows;
-    double ysum = 0.0;
-    for (uint64_t rr = r0 + (uint64_t)wave * kTBatch; rr < r1; rr += (uint64_t)kWaves * kTBatch) {
-        const int nb = (int)(r1 - rr < (uint64_t)kTBatch ? r1 - rr : (uint64_t)kTBatch);
-        const int64_t myp = lane <= nb ? tp[rr + lane] : 0;
-        AT y[kTBatch];
-#pragma unroll
-        for (int r = 0; r < kTBatch; ++r) y[r] = r < nb ? (AT)Y[(rr + r) * L + lane] : AT(0);
-        if (tile == 0) {
-#pragma unroll
-            for (int r = 0; r < kTBatch; ++r) ysum += (double)y[r];
-        }
-        int64_t p[kTBatch + 1];
-#pragma unroll
-        for (int r = 0; r <= kTBatch; ++r) p[r] = readlane64(myp, r < nb ? r : nb);
-        const int64_t pend = p[kTBatch];
-        for (int64_t cb = p[0]; cb < pend; cb += kWave) {
-            const int64_t pq = cb + lane;
-            const GramPk<VT> e = tpk[pq < pend ? pq : p[0]];
-            const int32_t ci = pq < pend ? e.j * L : 0;
-            const VT cvv = pq < pend ? e.v : VT(0);
-#pragma unroll
-            for (int r = 0; r < kTBatch; ++r) {
-                const int64_t a = p[r] > cb ? p[r] : cb;
-                const int64_t b = p[r + 1] < cb + kWave ? p[r + 1] : cb + kWave;
-                const int lo = (int)(a - cb), hi = (int)(b - cb);
-                for (int s = lo; s < hi; ++s) {
-                    const int j = __builtin_amdgcn_readlane(ci, s);
-                    const AT v = (AT)readlane_v(cvv, s);
-                    __hip_atomic_fetch_add(&acc[j + lane], v * y[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < KT * L; e += kTThreads) {
-        int j = tile * KT + e / L;
-        if (j < k) part[(rb * (uint64_t)k + j) * L + (e % L)] = acc[e];
-    }
-    if (tile == 0) {
-        __shared__ double s_y[kWaves][L];
-        s_y[wave][lane] = ysum;
-        __syncthreads();
-        if (threadIdx.x < L) {
-            double t = 0.0;
-            for (int w = 0; w < kWaves; ++w) t += s_y[w][threadIdx.x];
-            part_s[rb * L + threadIdx.x] = t;
-        }
-    }
-}
-
-
-// T[k*L .. k*L+L) receives s.  Fixed summation order over the row blocks.
-template <typename AT>
-__global__ void k_t_reduce(const AT* __restrict__ part, const double* __restrict__ part_s, int k, uint64_t n_rb,
-                           double* __restrict__ T) {
-    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t kl = (uint64_t)k * L;
-    if (e < kl) {
-        double s = 0.0;
-        for (uint64_t b = 0; b < n_rb; ++b) s += (double)part[b * kl + e];
-        T[e] = s;
-    } else if (e < kl + L) {
-        double s = 0.0;
-        for (uint64_t b = 0; b < n_rb; ++b) s += part_s[b * L + (e - kl)];
-        T[e] = s;
-    }
-}
-
-// ---- explicit sparse Gram: G = A^T A from the ROW-MAJOR compacted matrix ----------------------------
-// Round 2 design.  The work is N m(m+1)/2 scalar products (m = kept entries of a cell), each ending in an
-// f64 LDS atomic; what the round-1 kernel paid on top of that was two staged LDS reads and ~17 VALU
-// instructions of index arithmetic per product slice, with 22-30 of 64 lanes busy per atomic
-// (profiles/r01_pmc_gram_v6.md).  Here ONE wave instruction is one (cell, entry): the entry (ja, va) and the
-// SUFFIX of its row — the entries with column >= ja, contiguous in the row-major layout — so that lane q
-// holds (jb_q, vb_q) straight from a coalesced global load and adds va * vb_q to G[ja][jb_q].  No staging,
-// no per-product index arithmetic, every cell's upper-triangle products exactly once.
-//
-// Ownership: G's upper triangle is cut into STRIPES of SR rows; workgroup w owns stripes w and
-// n_stripes - 1 - w (long rows at the top, short ones at the bottom: SR (k + SR) doubles of LDS per
-// workgroup whatever w — 64 KiB at k = 2000, SR = 4, two workgroups per CU).  The entries a workgroup needs
-// are those whose column lies in its two stripes: k_bucket sorts the entries of every block of kBucketRows
-// cells by owner, so that a wave fetches its share of a block as one contiguous run of 8-byte records
-// (position of the entry relative to the block, suffix length).  All workgroups walk the row blocks in the
-// same order at about the same pace, so the row-major matrix streams through L2 / Infinity Cache once per
-// XCD while every cell is visited by the ~m workgroups that own one of its entries.
-template <typename VT> struct GramPk;
-__device__ __forceinline__ double gram_product(float a, float b) { return (double)(a * b); }
-__device__ __forceinline__ double gram_product(double a, double b) { return a * b; }
-
-// Records of a block of `rblk` cells, grouped by owning workgroup (counting sort in LDS; the order inside a group is
-// whatever the LDS atomics make it — the Gram sums are order-dependent in their last bits anyway).
-// boff[rb][w] .. boff[rb][w + 1]: records of owner w, relative to the block's first record (rec_base[rb]).
-constexpr int kBucketThreads = 1024;
-constexpr int kBucketGroup = 8;           // consecutive rows a wave walks as one flat run
-constexpr int kBucketUnroll = 8;          // 64-entry chunks of the run in flight
-
-// per-block record totals (k_bucket's layout needs their prefix sums before it runs)
-__global__ __launch_bounds__(256) void k_rec_count(const int64_t* __restrict__ rm_ptr, uint64_t n_rows, uint32_t rblk,
-                                                   int64_t* __restrict__ blk_total) {
-    const uint64_t r0 = (uint64_t)blockIdx.x * rblk;
-    const uint64_t r1 = r0 + rblk < n_rows ? r0 + rblk : n_rows;
-    uint64_t acc = 0;
-    for (uint64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) acc += gram_row_records((uint64_t)(rm_ptr[r + 1] - rm_ptr[r]));
-    acc = wave_sum(acc);
-    __shared__ uint64_t part[4];
-    if (lane_id() == 0) part[threadIdx.x / kWave] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) blk_total[blockIdx.x] = (int64_t)(part[0] + part[1] + part[2] + part[3]);
-}
-// exclusive scan of the block totals by one workgroup: base[0 .. n], base[n] = all records
-__global__ __launch_bounds__(1024) void k_rec_scan(const int64_t* __restrict__ blk_total, uint64_t n, int64_t* __restrict__ base) {
-    __shared__ int64_t wsum[16];
-    __shared__ int64_t carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    const int lane = lane_id(), wave = threadIdx.x / kWave;
-    for (uint64_t i0 = 0; i0 < n; i0 += 1024) {
-        const uint64_t i = i0 + threadIdx.x;
-        const int64_t v = i < n ? blk_total[i] : 0;
-        int64_t inc = v;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const int64_t o = __shfl_up(inc, off, kWave);
-            if (lane >= off) inc += o;
-        }
-        if (lane == kWave - 1) wsum[wave] = inc;
-        __syncthreads();
-        int64_t before = carry_s;
-        for (int w = 0; w < wave; ++w) before += wsum[w];
-        if (i < n) base[i] = before + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = before + inc;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) base[n] = carry_s;
-}
-
-template <typename VT>
-__global__ __launch_bounds__(kBucketThreads) void k_bucket(const int64_t* __restrict__ rm_ptr, const GramPk<VT>* __restrict__ rm,
-                                                           uint64_t n_rows, uint32_t rblk, int k, int sr_shift, int n_wg, int n_stripes,
-                                                           const int64_t* __restrict__ rec_base, uint32_t* __restrict__ boff,
-                                                           GramRec<VT>* __restrict__ recs) {
-    extern __shared__ double lds_raw[];
-    uint32_t* hist = reinterpret_cast<uint32_t*>(lds_raw);        // n_wg + 1 counters, then rblk + 1 row ends
-    uint32_t* rptr = hist + n_wg + 1;                             // row starts of the block, relative to its first entry
-    const uint64_t rb = blockIdx.x;
-    const uint64_t r0 = rb * rblk;
-    const uint64_t r1 = r0 + rblk < n_rows ? r0 + rblk : n_rows;
-    const int nr = (int)(r1 - r0);
-    const int lane = lane_id(), wave = threadIdx.x / kWave;
-    const int64_t base = rm_ptr[r0];
-    for (int e = threadIdx.x; e <= n_wg; e += kBucketThreads) hist[e] = 0u;
-    for (int e = threadIdx.x; e <= nr + kBucketGroup; e += kBucketThreads)
-        rptr[e] = (uint32_t)(rm_ptr[r0 + (e < nr ? e : nr)] - base);          // padded by a group of empty rows
-    __syncthreads();
-    const GramPk<VT>* rmb = rm + base;
-    // A wave takes kBucketGroup consecutive rows at a time: their entries are one contiguous run, walked flat 64 at a time
-    // (coalesced), and the row of an entry is found by comparing with the group's three inner row starts — the suffix
-    // length of an entry (its record count) needs the row's end.  `visit(p, j, v, row_end)` for every entry of the block.
-    auto walk = [&](auto visit) {
-        for (int g0 = wave * kBucketGroup; g0 < nr; g0 += (kBucketThreads / kWave) * kBucketGroup) {
-            uint32_t b[kBucketGroup + 1];
-#pragma unroll
-            for (int i = 0; i <= kBucketGroup; ++i) b[i] = rptr[g0 + i];
-            for (uint32_t p0 = b[0]; p0 < b[kBucketGroup]; p0 += kBucketUnroll * kWave) {
-                GramPk<VT> x[kBucketUnroll];
-#pragma unroll
-                for (int u = 0; u < kBucketUnroll; ++u) {
-                    const uint32_t p = p0 + u * kWave + lane;
-                    x[u].j = -1;
-                    if (p < b[kBucketGroup]) x[u] = rmb[p];
-                }
-#pragma unroll
-                for (int u = 0; u < kBucketUnroll; ++u) {
-                    const uint32_t p = p0 + u * kWave + lane;
-                    if (x[u].j < 0) continue;
-                    uint32_t end = b[1];
-#pragma unroll
-                    for (int i = 1; i < kBucketGroup; ++i) end = p >= b[i] ? b[i + 1] : end;
-                    visit(p, x[u].j, x[u].v, end);
-                }
-            }
-        }
-    };
-    walk([&](uint32_t p, int j, VT, uint32_t end) {
-        __hip_atomic_fetch_add(&hist[gram_owner(j, sr_shift, n_wg, n_stripes)], (end - p + 63u) >> 6, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
-    });
-    __syncthreads();
-    // exclusive scan of the n_wg counters by wave 0, 64 at a time
-    if (wave == 0) {
-        uint32_t carry = 0;
-        for (int c0 = 0; c0 < n_wg; c0 += kWave) {
-            const int i = c0 + lane;
-            const uint32_t v = i < n_wg ? hist[i] : 0u;
-            uint32_t inc = v;
-#pragma unroll
-            for (int off = 1; off < kWave; off <<= 1) {
-                const uint32_t o = __shfl_up(inc, off, kWave);
-                if (lane >= off) inc += o;
-            }
-            if (i < n_wg) {
-                hist[i] = carry + inc - v;
-                boff[rb * (uint64_t)(n_wg + 1) + i] = carry + inc - v;
-            }
-            carry += __shfl(inc, kWave - 1, kWave);
-        }
-        if (lane == 0) boff[rb * (uint64_t)(n_wg + 1) + n_wg] = carry;
-    }
-    __syncthreads();
-    GramRec<VT>* rcb = recs + rec_base[rb];
-    walk([&](uint32_t p, int j, VT v, uint32_t end) {
-        const uint32_t len = end - p, nch = (len + 63u) >> 6;
-        uint32_t slot = __hip_atomic_fetch_add(&hist[gram_owner(j, sr_shift, n_wg, n_stripes)], nch, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t rb8 = (uint32_t)gram_row_base(j, k, sr_shift, n_wg, n_stripes) << 8;
-        for (uint32_t o = 0; o < len; o += kWave, ++slot)
-            rcb[slot] = GramRec<VT>{p + o, (len - o < (uint32_t)kWave ? len - o : (uint32_t)kWave) | rb8, v};
-    });
-}
-
-__device__ __forceinline__ float readfirst_v(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
-}
-__device__ __forceinline__ double readfirst_v(double x) {
-    const long long b = __builtin_bit_cast(long long, x);
-    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
-
-// entries [0, len) of `base`, lane l taking entry l; lanes >= len return zeros without touching memory
-__device__ __forceinline__ GramPk<float> suffix_load(const GramPk<float>* base, uint32_t len, int lane) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<GramPk<float>*>(base), (short)0, (int)(len * 8u), 0x00020000);
-    const auto x = __builtin_amdgcn_raw_buffer_load_b64(rs, lane * 8, 0, 0);
-    return GramPk<float>{(int)x[0], __builtin_bit_cast(float, (unsigned)x[1])};
-}
-__device__ __forceinline__ GramPk<double> suffix_load(const GramPk<double>* base, uint32_t len, int lane) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<GramPk<double>*>(base), (short)0, (int)(len * 16u), 0x00020000);
-    const auto x = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, 0, 0);
-    GramPk<double> e;
-    e.j = (int)x[0];
-    e.pad_ = 0;
-    e.v = __builtin_bit_cast(double, ((unsigned long long)(unsigned)x[3] << 32) | (unsigned)x[2]);
-    return e;
-}
-
-// index of (i, j), i <= j, in the packed upper triangle (row-major, row i holds columns i .. k - 1)
-__host__ __device__ __forceinline__ size_t tri_index(int i, int j, int k) {
-    return (size_t)i * (size_t)k - (size_t)i * (size_t)(i - 1) / 2 + (size_t)(j - i);
-}
-
-template <typename VT>
-__global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
-    const int64_t* __restrict__ rm_ptr, const GramPk<VT>* __restrict__ rm, const uint32_t* __restrict__ boff,
-    const int64_t* __restrict__ rec_base, const GramRec<VT>* __restrict__ recs, uint64_t n_rblk, uint32_t rblk, int k,
-    int sr_shift, int n_wg, int n_stripes, uint32_t n_chunk, int w0 /* first owner of this launch */, int n_w /* owners in it */,
-    double* __restrict__ Gp /* packed upper triangle, ACCUMULATED into (global f64 atomics) */) {
-    using Entry = GramPk<VT>;
-    using Rec = GramRec<VT>;
-    // suffix loads in flight per batch: 16-byte f64 entries take twice the registers (8 of them spilled)
-    constexpr int kUnroll = sizeof(VT) == 8 ? kGramUnroll / 2 : kGramUnroll;
-    extern __shared__ double acc[];
-    const int w = w0 + blockIdx.x % n_w, z = blockIdx.x / n_w;
-    const int SR = 1 << sr_shift;
-    const int a0 = w * SR, b0 = (n_stripes - 1 - w) * SR;
-    const int WA = k - a0, WB = k - b0 > 0 ? k - b0 : 0;
-    const int n_acc = SR * (WA + WB);
-    for (int e = threadIdx.x; e < n_acc; e += blockDim.x) acc[e] = 0.0;
-    __syncthreads();
-    const int lane = lane_id();
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    // Workgroup = (owner w, chunk z of n_chunk consecutive row blocks); blockIdx = z * n_wg + w, so the dispatcher starts
-    // all owners of a chunk together and they walk its rows in the same order: what one workgroup pulls into its
-    // XCD's L2 the ~60 others on that XCD hit (free-running persistent workgroups drift tens of MB apart: L2 hit rate
-    // 12 %, 50 GB of fabric reads per launch at c3).  Wave v takes blocks v, v + 16, ... of the chunk.
-    //
-    // A wave reads its records 64 at a time (one 12-byte vector load per lane, the slab after this one in flight while this
-    // one is worked through) and hands them out kUnroll at a time: v_readlane makes (pos, len, rbase, va) of a record
-    // wave-uniform, the suffix load takes (scalar base, 32-bit lane offset), and what is left per record is lane < len, the
-    // product, its conversion and the LDS address.  Two batches are in flight: one being fetched, one being added.
-    // (Records fetched by scalar loads, one batch ahead: the stream alone cost 3.1 ms — every batch a dependent round trip
-    // through the scalar cache; slabs fetched only when the previous one was used up: 4 of 5 slab loads exposed.)
-    struct Blk {
-        uint32_t n;
-        const Entry* rmb;
-        const Rec* rc;
-    };
-    const uint64_t rb0 = (uint64_t)z * n_chunk, rb1 = rb0 + n_chunk < n_rblk ? rb0 + n_chunk : n_rblk;
-    auto scalars = [&](uint64_t rb) -> Blk {
-        Blk k_{0u, rm, recs};
-        if (rb < rb1) {
-            const uint32_t* bo = boff + rb * (uint64_t)(n_wg + 1) + w;
-            const uint32_t o0 = bo[0], o1 = bo[1];
-            k_.n = o1 - o0;
-            k_.rmb = rm + rm_ptr[rb * rblk];
-            k_.rc = recs + rec_base[rb] + o0;
-        }
-        return k_;
-    };
-    uint64_t rb = rb0 + wave;
-    uint32_t i0 = 0;
-    Blk cur = scalars(rb), nxt = scalars(rb + kGramWaves);
-    struct Slab {                         // up to 64 records of one block, lane l holding record l
-        Rec r;
-        uint32_t n;
-        const Entry* rmb;
-    };
-    auto next_slab = [&]() -> Slab {
-        while (i0 >= cur.n && rb < rb1) {
-            rb += kGramWaves;
-            cur = nxt;
-            nxt = scalars(rb + kGramWaves);
-            i0 = 0;
-        }
-        Slab sl;
-        sl.rmb = cur.rmb;
-        sl.n = i0 < cur.n ? (cur.n - i0 < (uint32_t)kWave ? cur.n - i0 : (uint32_t)kWave) : 0u;
-        sl.r = Rec{0u, 0u, (VT)0};
-        if ((uint32_t)lane < sl.n) sl.r = cur.rc[i0 + lane];
-        i0 += kWave;
-        return sl;
-    };
-    struct Loaded {                       // a batch of records with their suffix entries on the way
-        Entry e[kUnroll];
-        uint32_t lenrb[kUnroll];
-        VT va[kUnroll];
-    };
-    auto batch = [&](const Slab& sl, int u0) -> Loaded {
-        Loaded l;
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {       // lanes past sl.n hold empty records: len 0, pos 0
-            const uint32_t pos = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.pos, u0 + u);
-            l.lenrb[u] = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.lenrb, u0 + u);
-            l.va[u] = readlane_v(sl.r.va, u0 + u);
-            // a buffer load whose range is the suffix itself: lanes past `len` are out of range and fetch nothing (the L1
-            // works through a wave's load 64 bytes at a time — reading all 64 lanes of every ~36-entry suffix was 2 of the
-            // kernel's 4.2 ms), the address is (scalar base, constant lane offset), and there is no branch or exec mask
-            // around the load for the compiler's wait counting to trip over
-            l.e[u] = suffix_load(sl.rmb + pos, l.lenrb[u] & 0xffu, lane);
-        }
-        return l;
-    };
-    auto process = [&](const Loaded& l) {
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            const int rbase = (int)l.lenrb[u] >> 8;
-            const uint32_t len = l.lenrb[u] & 0xffu;
-            if ((uint32_t)lane < len)
-                __hip_atomic_fetch_add(&acc[rbase + l.e[u].j], gram_product(l.va[u], l.e[u].v), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    };
-    // All batches of slab `sl`, two in flight (ping-pong between two register sets: a `now = next` copy makes the compiler
-    // wait for next's loads).  The OTHER slab (used up before this one) is refilled right after this slab's first batch has
-    // gone out: when its records are first read, a slab later, every load issued after it has long been waited for — the
-    // compiler waits for ALL outstanding loads at that point (vmcnt is in order and it cannot count across the loop), so a
-    // refill issued last would be a full round trip exposed per slab.
-    auto consume = [&](const Slab& sl, Slab& other) {
-        const int n = (int)sl.n;
-        Loaded A = batch(sl, 0), B;
-        other = next_slab();
-#pragma unroll
-        for (int u0 = 0; u0 < kWave; u0 += 2 * kUnroll) {
-            // no branch around a batch's loads (slots past n are empty records, their loads hit the block's first line):
-            // after a conditional load the compiler's wait for A's entries also waits for B's
-            B = batch(sl, u0 + kUnroll);
-            process(A);
-            if (u0 + 2 * kUnroll < kWave) A = batch(sl, u0 + 2 * kUnroll);
-            process(B);
-            if (u0 + 2 * kUnroll >= n) break;
-        }
-    };
-    {
-        Slab S = next_slab(), T;
-        T.n = 0;
-        while (S.n > 0) {
-            consume(S, T);
-            if (T.n == 0) break;
-            consume(T, S);
-        }
-    }
-    __syncthreads();
-    // flush: the upper-triangle part of both stripes, added to the packed matrix (row splits and, in backed
-    // mode, earlier row tiles have been there before)
-    for (int e = threadIdx.x; e < SR * WA; e += blockDim.x) {
-        const int r = e / WA, c = a0 + e % WA, row = a0 + r;
-        const double v = acc[e];
-        if (row < k && c >= row && v != 0.0) atomicAdd(&Gp[tri_index(row, c, k)], v);
-    }
-    for (int e = threadIdx.x; e < SR * WB; e += blockDim.x) {
-        const int r = e / WB, c = b0 + e % WB, row = b0 + r;
-        const double v = acc[SR * WA + e];
-        if (row < k && c >= row && v != 0.0) atomicAdd(&Gp[tri_index(row, c, k)], v);
-    }
-}
-
-// C (k x k, both triangles) from the packed upper triangle: (i, j) and (j, i) read the same entry, so C is
-// EXACTLY symmetric (k_dense_apply reads it transposed).  With d != nullptr: C = D (G - cen N mu mu^T) D.
-__global__ void k_gram_expand(const double* __restrict__ P, int k, const double* __restrict__ d,
-                              const double* __restrict__ mu, int cen, double n_cells, double* __restrict__ C) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (uint64_t)k * k) return;
-    const int i = (int)(e / k), j = (int)(e % k);
-    const int lo = i < j ? i : j, hi = i < j ? j : i;
-    double g = P[tri_index(lo, hi, k)];
-    if (d) {
-        if (cen) g -= n_cells * (mu[i] * mu[j]);            // (mu_i mu_j) first: symmetric to the last bit
-        g = d[i] * d[j] * g;
-    }
-    C[e] = g;
-}
-
-// Wp += C[:, krange] W[krange, :] for the dense SYMMETRIC k x k matrix C and a k x 64 block (f64), on the
-// f64 matrix cores.  One wave = 32 output rows x 64 columns x one K slice: eight v_mfma_f64_16x16x4
-// accumulators.  Both operands are read straight from global memory in fragment order with no LDS
-// staging: lane l of the A fragment needs C[row0 + (l & 15)][kk + (l >> 4)], which by symmetry is
-// C[kk + (l >> 4)][row0 + (l & 15)] — 16 consecutive doubles per K index, fully coalesced; the B
-// fragment W[kk + (l >> 4)][16 t + (l & 15)] is coalesced as it stands.  The K slices (split-K 16 across
-// workgroups x 4 waves inside one: ~4000 waves for k = 2000) are combined in LDS, then with f64 atomics into the zeroed Wp.
-// C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg (not the f32 map).
-#ifndef SRX_DENSE_SPLIT          // measured at k = 2000 (split x waves: us): 16x4 21.8, 8x8 21.9, 8x4 18.8, 4x4 17.8, 4x8 17.5, 8x2 28.3, 4x16 36.3 —
-#define SRX_DENSE_SPLIT 4       // the f64 atomics into Wp (k x 64 x split) weigh more than the number of waves in flight
-#define SRX_DENSE_WAVES 8
-#endif
-constexpr int kDenseSplit = SRX_DENSE_SPLIT;
-constexpr int kDenseWaves = SRX_DENSE_WAVES;             // waves of a workgroup: consecutive quarters of the workgroup's K slice
-typedef double dvec4 __attribute__((ext_vector_type(4)));
-// Workgroup = 32 output rows x 64 columns x one K slice, its four waves on consecutive quarters of the slice (four waves per
-// SIMD keep ~4x the loads in flight: one wave per SIMD left the load latency of every group of 16 K indices exposed, 27 us
-// per application against ~7 us of MFMA time); the waves' partial tiles meet in LDS (ds_add_f64), then one f64 atomic per
-// output element and K slice into the zeroed Wp.
-__global__ __launch_bounds__(kDenseWaves * 64) void k_dense_apply(const double* __restrict__ C, const double* __restrict__ W, int k,
-                                                                  double* __restrict__ Wp) {
-    __shared__ double red[32][L];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    const int row0 = blockIdx.x * 32;
-    const int kchunk = (((k + kDenseSplit - 1) / kDenseSplit) + 4 * kDenseWaves - 1) / (4 * kDenseWaves) * (4 * kDenseWaves);      // per workgroup: waves x a multiple of 4
-    const int kq = kchunk / kDenseWaves;
-    const int kbeg = blockIdx.y * kchunk + wv * kq;
-    const int kend = kbeg + kq < k ? kbeg + kq : k;
-    for (int e = threadIdx.x; e < 32 * L; e += kDenseWaves * 64) (&red[0][0])[e] = 0.0;
-    dvec4 acc[2][4];
-#pragma unroll
-    for (int sI = 0; sI < 2; ++sI)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[sI][t] = dvec4{0.0, 0.0, 0.0, 0.0};
-    const bool r0ok = row0 + li < k, r1ok = row0 + 16 + li < k;
-    // groups of 4 K-steps (16 K indices), two register buffers: the 24 loads of group g+1 are in flight
-    // while the 32 MFMAs of group g issue
-    struct Frag { double a0[4], a1[4], bq[4][4]; };
-    auto load = [&](Frag& f, int kk) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int kr = kk + 4 * u + lk;
-            const bool kok = kr < kend;
-            const double* crow = C + (size_t)(kok ? kr : 0) * k + row0 + li;
-            const double* wrow = W + (size_t)(kok ? kr : 0) * L + li;
-            f.a0[u] = (kok && r0ok) ? crow[0] : 0.0;
-            f.a1[u] = (kok && r1ok) ? crow[16] : 0.0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) f.bq[u][t] = kok ? wrow[16 * t] : 0.0;
-        }
-    };
-    auto fma = [&](const Frag& f) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a0[u], f.bq[u][t], acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a1[u], f.bq[u][t], acc[1][t], 0, 0, 0);
-            }
-    };
-    Frag f0, f1;
-    load(f0, kbeg);
-    for (int kk = kbeg; kk < kend; kk += 32) {
-        load(f1, kk + 16);
-        fma(f0);
-        load(f0, kk + 32);
-        fma(f1);
-    }
-    __syncthreads();                             // (the tile is zeroed)
-    // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
-#pragma unroll
-    for (int sI = 0; sI < 2; ++sI)
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) atomicAdd(&red[16 * sI + lk + 4 * v][16 * t + li], acc[sI][t][v]);
-    __syncthreads();
-    for (int e = threadIdx.x; e < 32 * L; e += kDenseWaves * 64) {
-        const int r = row0 + e / L;
-        if (r < k) atomicAdd(&Wp[(size_t)r * L + (e % L)], (&red[0][0])[e]);
-    }
-}
-
-// ---- k x l helper kernels (f64, replicated per rank) --------------------------------------------
-// P = PT(d .* W * sign), cvec = cen * mu^T P (exact f64 sum of the ROUNDED panel, so Y's column
-// sums vanish to rounding).
-template <typename PT>
-__global__ __launch_bounds__(1024) void k_make_panel(const double* __restrict__ W, const double* __restrict__ d,
-                                                     const double* __restrict__ mu, const double* __restrict__ sgn,
-                                                     int k, int cen, PT* __restrict__ P, PT* __restrict__ cvec) {
-    __shared__ double s_part[16][L];
-    const int c = threadIdx.x & (L - 1), part = threadIdx.x / L;   // 16 row slices x 64 columns
-    double acc = 0.0;
-    const double sg = sgn ? sgn[c] : 1.0;
-    for (int j = part; j < k; j += 16) {
-        PT p = (PT)(d[j] * W[(size_t)j * L + c] * sg);
-        P[(size_t)j * L + c] = p;
-        acc += mu[j] * (double)p;
-    }
-    s_part[part][c] = acc;
-    __syncthreads();
-    if (part == 0) {
-        double t = 0.0;
-        for (int w = 0; w < 16; ++w) t += s_part[w][c];
-        cvec[c] = cen ? (PT)t : PT(0);
-    }
-}
-
-// The same for the END of a round, on many workgroups and with the round's bookkeeping folded in (one workgroup walking the
-// k x 64 block took 48 us, and three device-to-device copies and k_signs followed it): sign of each Ritz vector from its
-// largest entry, P = PT(d .* V * sign), per-block partial sums of mu^T P (k_cvec_reduce adds them in fixed order), and the
-// copy of the Ritz vectors, values and signs into the matrix's result block.
-constexpr int kPanelBlocks = 32;
-template <typename PT>
-__global__ __launch_bounds__(1024) void k_make_panel_mb(const double* __restrict__ W, const double* __restrict__ d,
-                                                        const double* __restrict__ mu, const double* __restrict__ colmax,
-                                                        const double* __restrict__ theta, int k, PT* __restrict__ P,
-                                                        double* __restrict__ part /* [blocks][64] */, double* __restrict__ sgn_out,
-                                                        double* __restrict__ blk /* k*64 vectors | 64 values | 64 signs */) {
-    __shared__ double s_part[16][L];
-    const int c = threadIdx.x & (L - 1), sl = threadIdx.x / L;   // 16 row slices x 64 columns
-    const double sg = colmax[c] < 0 ? -1.0 : 1.0;
-    if (blockIdx.x == 0 && sl == 0) {
-        sgn_out[c] = sg;
-        blk[(size_t)k * L + c] = theta[c];
-        blk[(size_t)k * L + L + c] = sg;
-    }
-    double acc = 0.0;
-    for (int j = blockIdx.x * 16 + sl; j < k; j += gridDim.x * 16) {
-        const double wv = W[(size_t)j * L + c];
-        blk[(size_t)j * L + c] = wv;
-        const PT p = (PT)(d[j] * wv * sg);
-        P[(size_t)j * L + c] = p;
-        acc += mu[j] * (double)p;
-    }
-    s_part[sl][c] = acc;
-    __syncthreads();
-    if (sl == 0) {
-        double t = 0.0;
-        for (int w = 0; w < 16; ++w) t += s_part[w][c];
-        part[(size_t)blockIdx.x * L + c] = t;
-    }
-}
-template <typename PT>
-__global__ void k_cvec_reduce(const double* __restrict__ part, int n_blocks, int cen, PT* __restrict__ cvec) {
-    const int c = threadIdx.x;
-    double t = 0.0;
-    for (int b = 0; b < n_blocks; ++b) t += part[(size_t)b * L + c];
-    cvec[c] = cen ? (PT)t : PT(0);
-}
-
-// up to four small device-to-device copies in one launch (32-bit words)
-struct CopySegs {
-    const uint32_t* src[4];
-    uint32_t* dst[4];
-    uint32_t words[4];
-};
-__global__ void k_copy_segs(CopySegs sg) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        for (uint32_t e = t; e < sg.words[i]; e += stride) sg.dst[i][e] = sg.src[i][e];
-}
-
-// W' = d .* (T - cen * mu s^T)
-__global__ void k_finish_t(const double* __restrict__ T, const double* __restrict__ d, const double* __restrict__ mu,
-                           int k, int cen, double* __restrict__ Wp) {
-    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (uint64_t)k * L) return;
-    int j = (int)(e / L), c = (int)(e % L);
-    double s = T[(size_t)k * L + c];
-    Wp[e] = d[j] * (T[e] - (cen ? mu[j] * s : 0.0));
-}
-
-// H = A^T B, G = B^T B for two k x 64 blocks (f64).  Each workgroup reduces a slice of the k rows
-// (staged through LDS) into a partial 64 x 64 pair; k_gram2_reduce sums the slices in fixed order.
-constexpr int kGram2Blocks = 64;
-__global__ __launch_bounds__(1024) void k_gram2_part(const double* __restrict__ A, const double* __restrict__ B, int k,
-                                                     double* __restrict__ part /* [blocks][2][64*64] */) {
-    constexpr int R = 32;
-    __shared__ double sa[R][L], sb[R][L];
-    double h[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0};
-    const int b = threadIdx.x & (L - 1), a0 = threadIdx.x / L;    // entries (a0 + 16u, b), u < 4
-    const int rows_per = (k + gridDim.x - 1) / gridDim.x;
-    const int jb0 = blockIdx.x * rows_per;
-    const int jb1 = jb0 + rows_per < k ? jb0 + rows_per : k;
-    for (int j0 = jb0; j0 < jb1; j0 += R) {
-        for (int e = threadIdx.x; e < R * L; e += 1024) {
-            int j = j0 + e / L;
-            sa[e / L][e % L] = j < jb1 ? A[(size_t)j * L + (e % L)] : 0.0;
-            sb[e / L][e % L] = j < jb1 ? B[(size_t)j * L + (e % L)] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int r = 0; r < R; ++r) {
-            double bv = sb[r][b];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                h[u] += sa[r][a0 + 16 * u] * bv;
-                g[u] += sb[r][a0 + 16 * u] * bv;
-            }
-        }
-        __syncthreads();
-    }
-    double* out = part + (size_t)blockIdx.x * 2 * L * L;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        out[(a0 + 16 * u) * L + b] = h[u];
-        out[L * L + (a0 + 16 * u) * L + b] = g[u];
-    }
-}
-__global__ void k_gram2_reduce(const double* __restrict__ part, int n_blocks, double* __restrict__ HG /* 2*64*64 */) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= 2 * L * L) return;
-    double s = 0.0;
-    for (int b = 0; b < n_blocks; ++b) s += part[(size_t)b * 2 * L * L + e];
-    HG[e] = s;
-}
-
-// ONE product of two k x 64 blocks, H = A^T B (A == B: the Gram matrix of a block), as kGram1Blocks partial 64 x 64 sums
-// over row slices.  The consumer — k_chol_factor_panels or k_jacobi_eig2, through (part, n_part) — adds the partials in fixed
-// order while it loads the matrix: no reduction kernel between the two, and half the arithmetic of k_gram2_part, which forms
-// both products whichever is wanted.
-constexpr int kGram1Blocks = 16;
-// On the f64 matrix cores: wave w of a workgroup owns the 16 x 16 output tile (w / 4, w % 4); both operands come straight
-// from global memory in fragment order (lane l: row kk + (l >> 4), column 16 t + (l & 15) — 128 contiguous bytes per
-// 16 lanes), eight K-steps of loads in flight.  (The LDS-staged scalar version was LDS-read bound: 24 us a launch.)
-__global__ __launch_bounds__(1024) void k_gram1_part(const double* __restrict__ A, const double* __restrict__ B, int k,
-                                                     double* __restrict__ part /* [blocks][64*64] */) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    const int ti = wv >> 2, tj = wv & 3;
-    const int rows_per = (k + gridDim.x - 1) / gridDim.x;
-    const int jb0 = blockIdx.x * rows_per;
-    const int jb1 = jb0 + rows_per < k ? jb0 + rows_per : k;
-    dvec4 acc = dvec4{0.0, 0.0, 0.0, 0.0};
-    constexpr int kU = 8;
-    for (int j0 = jb0; j0 < jb1; j0 += 4 * kU) {
-        double av[kU], bv[kU];
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const int r = j0 + 4 * u + lk;
-            const bool ok = r < jb1;
-            av[u] = ok ? A[(size_t)r * L + 16 * ti + li] : 0.0;
-            bv[u] = ok ? B[(size_t)r * L + 16 * tj + li] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < kU; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
-    }
-    // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
-    double* out = part + (size_t)blockIdx.x * L * L;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) out[(16 * ti + lk + 4 * v) * L + 16 * tj + li] = acc[v];
-}
-
-// The tail of a Rayleigh–Ritz step in one pass over the rows: A1 = Wp U (= C W U), A2 = W U (the Ritz vectors), and per
-// block the partial sums of || A1[:, c] - theta_c A2[:, c] ||^2 and the entry of largest |.| of A2[:, c] (ties: the smallest
-// row).  k_resid_final adds the partials in fixed order.  (Was: k_right_mul twice, k_col_resid on ONE workgroup, k_resid_scalar.)
-constexpr int kRitzBlocks = 128;
-__global__ __launch_bounds__(256) void k_ritz_post(const double* __restrict__ W, const double* __restrict__ Wp,
-                                                   const double* __restrict__ M, const double* __restrict__ theta, int k,
-                                                   double* __restrict__ A1, double* __restrict__ A2,
-                                                   double* __restrict__ part /* [blocks][3][64]: r2, best value, its row */) {
-    __shared__ double sm[L][L + 1];
-    __shared__ double s_r[4][L], s_v[4][L], s_j[4][L];
-    for (int e = threadIdx.x; e < L * L; e += 256) sm[e / L][e % L] = M[e];
-    __syncthreads();
-    const int c = threadIdx.x & (L - 1), sub = threadIdx.x / L;    // 4 rows per pass
-    const double th = theta[c];
-    double acc = 0.0, best = 0.0, best_j = 0.0;
-    for (int j = blockIdx.x * 4 + sub; j < k; j += gridDim.x * 4) {
-        const double* rw = W + (size_t)j * L;
-        const double* rp = Wp + (size_t)j * L;
-        double a1 = 0.0, a2 = 0.0;
-#pragma unroll 8
-        for (int b = 0; b < L; ++b) {
-            const double m = sm[b][c];
-            a1 += rp[b] * m;
-            a2 += rw[b] * m;
-        }
-        A1[(size_t)j * L + c] = a1;
-        A2[(size_t)j * L + c] = a2;
-        const double r = a1 - th * a2;
-        acc += r * r;
-        if (fabs(a2) > fabs(best)) {          // rows come in increasing order: the first one of the largest magnitude stays
-            best = a2;
-            best_j = (double)j;
-        }
-    }
-    s_r[sub][c] = acc;
-    s_v[sub][c] = best;
-    s_j[sub][c] = best_j;
-    __syncthreads();
-    if (sub == 0) {
-        double t = 0.0, bv = 0.0, bj = 0.0;
-        for (int w = 0; w < 4; ++w) {
-            t += s_r[w][c];
-            const double v = s_v[w][c], jj = s_j[w][c];
-            if (fabs(v) > fabs(bv) || (fabs(v) == fabs(bv) && v != 0.0 && jj < bj)) {
-                bv = v;
-                bj = jj;
-            }
-        }
-        double* out = part + (size_t)blockIdx.x * 3 * L;
-        out[c] = t;
-        out[L + c] = bv;
-        out[2 * L + c] = bj;
-    }
-}
-
-// Out = In * M  (k x 64 times 64 x 64), M row-major.
-__global__ __launch_bounds__(256) void k_right_mul(const double* __restrict__ In, const double* __restrict__ M, int k,
-                                                   double* __restrict__ Out) {
-    __shared__ double sm[L][L + 1];
-    for (int e = threadIdx.x; e < L * L; e += 256) sm[e / L][e % L] = M[e];
-    __syncthreads();
-    const int c = threadIdx.x & (L - 1), sub = threadIdx.x / L;    // 4 rows per pass
-    for (int j = blockIdx.x * 4 + sub; j < k; j += gridDim.x * 4) {
-        const double* row = In + (size_t)j * L;
-        double acc = 0.0;
-#pragma unroll 8
-        for (int b = 0; b < L; ++b) acc += row[b] * sm[b][c];
-        Out[(size_t)j * L + c] = acc;
-    }
-}
-
-// rho[c] = || A1[:,c] - theta[c] * A2[:,c] ||_2 ; also colmax: entry of largest |.| of A2[:,c].
-__global__ __launch_bounds__(1024) void k_col_resid(const double* __restrict__ A1, const double* __restrict__ A2,
-                                                    const double* __restrict__ theta, int k,
-                                                    double* __restrict__ rho, double* __restrict__ colmax) {
-    __shared__ double s_r[16][L], s_m[16][L];
-    const int c = threadIdx.x & (L - 1), part = threadIdx.x / L;
-    double acc = 0.0, best = 0.0;
-    const double th = theta[c];
-    for (int j = part; j < k; j += 16) {
-        double v2 = A2[(size_t)j * L + c];
-        double r = A1[(size_t)j * L + c] - th * v2;
-        acc += r * r;
-        if (fabs(v2) > fabs(best)) best = v2;
-    }
-    s_r[part][c] = acc;
-    s_m[part][c] = best;
-    __syncthreads();
-    if (part == 0) {
-        double t = 0.0, bm = 0.0;
-        for (int w = 0; w < 16; ++w) {
-            t += s_r[w][c];
-            if (fabs(s_m[w][c]) > fabs(bm)) bm = s_m[w][c];    // ties keep the lowest row slice
-        }
-        rho[c] = sqrt(t);
-        colmax[c] = bm;
-    }
-}
-
-// ---- l x l algebra of the subspace iteration, on the device ---------------------------------------
-// One workgroup each; they exist so that a whole PCA is ONE uninterrupted stream of launches: with
-// the l x l Cholesky / eigen-solves on the host every sweep cost two or three stream drains plus
-// whatever the host cores happened to be doing (measured: 3.5 ms per pipeline step on an idle box,
-// 17 ms on a busy one).  Status bits are OR-ed into *status and read back with the residual.
-constexpr int kStatChol = 1, kStatEig = 2;
-constexpr size_t kJacobiLds = (2 * L * (L + 1) + L + 32) * sizeof(double) + 2 * L * sizeof(int);
-
-// Start block: counter-based N(0,1) entries, deterministic in (seed, gene slot, column).
-__device__ __forceinline__ uint64_t dmix64(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
-__global__ void k_identity_block(int k, double* __restrict__ W) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < k * L) W[e] = (e / L == e % L) ? 1.0 : 0.0;
-}
-__global__ void k_init_block(uint64_t seed, int k, int l_act, double* __restrict__ Wp) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= k * L) return;
-    const int j = e / L, cc = e % L;
-    double v = 0.0;
-    if (cc < l_act) {
-        const uint64_t base = dmix64(seed ^ dmix64((uint64_t)j));
-        const uint64_t h1 = dmix64(base + 2 * (uint64_t)cc), h2 = dmix64(base + 2 * (uint64_t)cc + 1);
-        const double u1 = ((double)(h1 >> 11) + 0.5) / 9007199254740992.0;
-        const double u2 = ((double)(h2 >> 11) + 0.5) / 9007199254740992.0;
-        v = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
-    }
-    Wp[e] = v;
-}
-
-// CholeskyQR, device side: G = R^T R (upper Cholesky of the leading n x n block of G, ld = L), then
-// W = Wp R^-1 by one forward substitution per ROW of Wp (k independent rows) — no explicit inverse.
-//
-// k_chol_factor: one workgroup, right-looking: at step j every thread subtracts a_jr a_jc / a_jj from the
-// trailing elements it owns (one barrier per step).  Rout (L x L, row-major) receives R, zero outside
-// the upper triangle of the leading block; dinv[j] = 1 / R[j][j] (0 for j >= n).
-// `shifted` (the robust mode of the driver): a pivot that has fallen below 1e-13 of the largest diagonal entry of G is
-// held at that floor instead of being reported — the factor then belongs to a slightly shifted G, W = Wp R^-1 stays
-// bounded and of full rank, and a second plain pass (CholeskyQR2) makes it orthonormal (shifted CholeskyQR3 idea).
-__global__ __launch_bounds__(1024) void k_chol_factor(const double* __restrict__ G, int n, double* __restrict__ Rout,
-                                                      double* __restrict__ dinv, int* __restrict__ status, int shifted) {
-    __shared__ double A[L][L + 1];
-    __shared__ double s_floor, s_diag[L];
-    const int tid = threadIdx.x;
-    for (int e = tid; e < L * L; e += 1024) {
-        const int r = e >> 6, c = e & 63;
-        A[r][c] = (r < n && c < n) ? G[(size_t)r * L + c] : 0.0;
-    }
-    __syncthreads();
-    if (tid < L) s_diag[tid] = A[tid][tid];
-    if (tid == 0) {
-        double mx = 0.0;
-        for (int j = 0; j < n; ++j) mx = A[j][j] > mx ? A[j][j] : mx;
-        s_floor = shifted ? 1e-13 * mx : 0.0;
-    }
-    __syncthreads();
-    bool bad = false;
-    for (int j = 0; j < n; ++j) {
-        double d = A[j][j];
-        // shifted (last-resort) mode: a pivot below 1e-13 of the largest diagonal entry means the column depends on the
-        // ones before it — the block is wider than the numerical rank of the data (a handful of cells, most selected
-        // columns empty).  The column is DROPPED (zero in Q: dinv = 0, empty row of R) instead of being scaled up from
-        // rounding noise; it stays zero under C, and its Ritz pair comes out as (0, 0).  "Dependent" = the pivot is
-        // below 1e-13 of the column's OWN squared norm (s_diag, taken before the elimination).  (A zero or NaN matrix
-        // keeps its non-positive pivot: reported below.)
-        const bool drop = shifted && s_floor > 0.0 && d == d && !(d > 1e-13 * s_diag[j]);
-        if (!drop && shifted && !(d > s_floor)) d = s_floor;   // independent but tiny next to the others: lifted as before
-        if (!drop && !(d > 0.0)) bad = true;
-        const double inv = drop ? 0.0 : rsqrt(d), inv2 = inv * inv;
-        if (tid < L) {
-            Rout[(size_t)j * L + tid] = (tid >= j && tid < n) ? (drop ? (tid == j ? 1.0 : 0.0) : A[j][tid] * inv) : 0.0;
-            if (tid == j) dinv[j] = inv;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = tid + 1024 * u, r = e >> 6, c = e & 63;
-            if (r > j && c >= r && c < n) A[r][c] -= A[j][r] * A[j][c] * inv2;
-        }
-        __syncthreads();
-    }
-    for (int e = tid; e < L * L; e += 1024)
-        if ((e >> 6) >= n) Rout[e] = 0.0;
-    if (tid < L && tid >= n) dinv[tid] = 0.0;
-    if (bad && tid == 0) atomicOr(status, kStatChol);
-}
-
-// The plain factorisation (no shift, no dropped columns) in panels of kCholPanel rows: wave 0 factors a panel on its own, in
-// registers — eight dependent steps of (v_readlane, rsqrt, multiply-subtract), no LDS round trip and no barrier — then all
-// threads subtract the panel's rank-8 update from the trailing rows: 16 barriers for l = 64 instead of 64 (the CholeskyQR
-// runs five times per solve).  Same outputs and status as k_chol_factor(shifted = 0).
-// 1 / sqrt(x), normal positive x: the hardware seed (2^-24, bench_micro/rsq_precision.hip) and one third-order correction
-__device__ __forceinline__ double fast_rsqrt(double x) {
-    const double y = __builtin_amdgcn_rsq(x);
-    const double e = __builtin_fma(-x * y, y, 1.0);
-    return __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
-}
-constexpr int kCholPanel = 8;
-__global__ __launch_bounds__(1024) void k_chol_factor_panels(const double* __restrict__ G, int n_part, int n, double* __restrict__ Rout,
-                                                             double* __restrict__ dinv, int* __restrict__ status) {
-    __shared__ double A[L][L + 1];           // the rows of a finished panel hold R
-    __shared__ int s_bad;
-    const int tid = threadIdx.x;
-    for (int e = tid; e < L * L; e += 1024) {      // G = the sum of n_part <= 16 partial matrices (k_gram1_part), in fixed order
-        const int r = e >> 6, c = e & 63;
-        double v[kGram1Blocks];
-#pragma unroll
-        for (int p = 0; p < kGram1Blocks; ++p) v[p] = p < n_part ? G[(size_t)p * L * L + e] : 0.0;      // all in flight
-        double g = 0.0;
-#pragma unroll
-        for (int p = 0; p < kGram1Blocks; ++p) g += v[p];
-        A[r][c] = (r < n && c < n) ? g : 0.0;
-    }
-    if (tid == 0) s_bad = 0;
-    __syncthreads();
-    for (int j0 = 0; j0 < n; j0 += kCholPanel) {
-        const int j1 = j0 + kCholPanel < n ? j0 + kCholPanel : n;
-        if (tid < kWave) {
-            // lane c holds column c of the panel's rows in registers; pivots and multipliers travel by v_readlane (a pivot
-            // step through LDS — read the pivot, write the row, read the multipliers, update — was 0.6 us of latency,
-            // the same as the one-barrier-per-step kernel)
-            const int c = tid;
-            double a[kCholPanel];
-#pragma unroll
-            for (int jj = 0; jj < kCholPanel; ++jj) a[jj] = j0 + jj < j1 ? A[j0 + jj][c] : 0.0;
-#pragma unroll
-            for (int jj = 0; jj < kCholPanel; ++jj) {
-                const int j = j0 + jj;
-                if (j < j1) {                                   // (uniform)
-                    const double d = readlane_v(a[jj], j);
-                    if (!(d > 0.0) && c == 0) s_bad = 1;
-                    const double inv = d > 1e-290 ? fast_rsqrt(d) : rsqrt(d);      // (the library's: ~10 dependent operations)
-                    const double rjc = (c >= j && c < n) ? a[jj] * inv : 0.0;
-                    a[jj] = rjc;                                // row j of R (zero left of the diagonal and right of n)
-                    if (c == j) dinv[j] = inv;
-#pragma unroll
-                    for (int rr = jj + 1; rr < kCholPanel; ++rr) {
-                        const int r = j0 + rr;
-                        if (r < j1) {
-                            const double rjr = readlane_v(rjc, r);
-                            if (c >= r && c < n) a[rr] -= rjr * rjc;
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int jj = 0; jj < kCholPanel; ++jj)
-                if (j0 + jj < j1) {
-                    A[j0 + jj][c] = a[jj];
-                    Rout[(size_t)(j0 + jj) * L + c] = a[jj];
-                }
-        }
-        __syncthreads();
-        // trailing rows r >= j1: a_rc -= sum over the panel of r_jr r_jc, c >= r
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = tid + 1024 * u, r = e >> 6, c = e & 63;
-            if (r >= j1 && c >= r && c < n) {
-                double acc = A[r][c];
-                for (int j = j0; j < j1; ++j) acc -= A[j][r] * A[j][c];
-                A[r][c] = acc;
-            }
-        }
-        __syncthreads();
-    }
-    for (int e = tid; e < L * L; e += 1024)
-        if ((e >> 6) >= n) Rout[e] = 0.0;
-    if (tid < L && tid >= n) dinv[tid] = 0.0;
-    if (tid == 0 && s_bad) atomicOr(status, kStatChol);
-}
-
-// W[row] R = Wp[row]: w_j = (wp_j - sum_{i<j} w_i R[i][j]) / R[j][j], one thread per row, the row in
-// registers (the j / i loops are fully unrolled: static register indices), R transposed in LDS so that
-// the i-loop of a column reads consecutive words (wave-uniform addresses: broadcast, no conflicts).
-// One wave per workgroup: k / 64 workgroups spread over as many compute units.
-__global__ __launch_bounds__(64) void k_trsm_rows(const double* __restrict__ Wp, const double* __restrict__ R,
-                                                  const double* __restrict__ dinv, int k, double* __restrict__ W) {
-    __shared__ double Rt[L][L];          // Rt[j][i] = R[i][j]
-    __shared__ double di[L];
-    for (int e = threadIdx.x; e < L * L; e += 64) Rt[e & 63][e >> 6] = R[e];
-    di[threadIdx.x] = dinv[threadIdx.x];
-    __syncthreads();
-    const int row = blockIdx.x * 64 + threadIdx.x;
-    if (row >= k) return;
-    double w[L];
-    const double* src = Wp + (size_t)row * L;
-#pragma unroll
-    for (int j = 0; j < L; ++j) w[j] = src[j];
-#pragma unroll
-    for (int j = 0; j < L; ++j) {
-        double acc0 = w[j], acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;      // (eight chains instead of four: 32 -> 56 us, the row spills)
-#pragma unroll
-        for (int i = 0; i + 3 < j; i += 4) {
-            acc0 -= w[i] * Rt[j][i];
-            acc1 -= w[i + 1] * Rt[j][i + 1];
-            acc2 -= w[i + 2] * Rt[j][i + 2];
-            acc3 -= w[i + 3] * Rt[j][i + 3];
-        }
-#pragma unroll
-        for (int i = j & ~3; i < j; ++i) acc0 -= w[i] * Rt[j][i];
-        w[j] = ((acc0 + acc1) + (acc2 + acc3)) * di[j];
-    }
-    double* dst = W + (size_t)row * L;
-#pragma unroll
-    for (int j = 0; j < L; ++j) dst[j] = w[j];
-}
-
-// Eigen-decomposition of the symmetric leading n x n block of H (ld = L) by two-sided cyclic Jacobi,
-// 32 disjoint rotations per round in the round-robin ordering (63 rounds = one sweep).  Thread (I, J)
-// owns the 2 x 2 block (pair I) x (pair J) and applies J_I^T . B . J_J in place: the rotated matrix
-// stays exactly symmetric and a round needs two barriers.  The projected matrices of successive
-// Rayleigh–Ritz steps are close to diagonal, so late solves take two or three sweeps.
-// U (L x L, row-major) receives eigenvector c in COLUMN c, eigenvalues descending; rows / columns
-// >= n are 0, theta[c >= n] = 0.
-__device__ __forceinline__ void jacobi_pair(int m, int r, int& p, int& q) {
-    if (m == 0) {
-        p = L - 1;
-        q = r;
-    } else {
-        p = (r + m) % (L - 1);
-        q = (r + (L - 1) - m) % (L - 1);
-    }
-}
-__global__ __launch_bounds__(1024) void k_jacobi_eig(const double* __restrict__ H, int n, double* __restrict__ U,
-                                                     double* __restrict__ theta, int* __restrict__ status, double off_tol2) {
-    static_assert(L == 64, "the block mapping below is written for l = 64");
-    extern __shared__ double lds_raw[];
-    double (*A)[L + 1] = reinterpret_cast<double (*)[L + 1]>(lds_raw);
-    double (*V)[L + 1] = reinterpret_cast<double (*)[L + 1]>(lds_raw + L * (L + 1));
-    double (*cs)[2] = reinterpret_cast<double (*)[2]>(lds_raw + 2 * L * (L + 1));
-    double (*red)[16] = reinterpret_cast<double (*)[16]>(lds_raw + 2 * L * (L + 1) + L);
-    int* rank = reinterpret_cast<int*>(lds_raw + 2 * L * (L + 1) + L + 32);
-    int (*pq)[2] = reinterpret_cast<int (*)[2]>(rank + L);
-    const int tid = threadIdx.x, I = tid >> 5, J = tid & 31;
-    for (int e = tid; e < L * L; e += 1024) {
-        const int a = e >> 6, b = e & 63;
-        A[a][b] = (a < n && b < n) ? 0.5 * (H[(size_t)a * L + b] + H[(size_t)b * L + a]) : 0.0;
-        V[a][b] = a == b ? 1.0 : 0.0;
-    }
-    __syncthreads();
-    bool done = false;
-    for (int sweep = 0; sweep < 30 && !done; ++sweep) {
-        double off = 0.0, dg = 0.0;
-        for (int e = tid; e < L * L; e += 1024) {
-            const int a = e >> 6, b = e & 63;
-            const double x = A[a][b];
-            if (a < b) off += x * x;
-            if (a == b) dg += x * x;
-        }
-        off = wave_sum(off);
-        dg = wave_sum(dg);
-        if ((tid & 63) == 0) {
-            red[0][tid >> 6] = off;
-            red[1][tid >> 6] = dg;
-        }
-        __syncthreads();
-        off = dg = 0.0;
-        for (int w = 0; w < 16; ++w) {
-            off += red[0][w];
-            dg += red[1][w];
-        }
-        __syncthreads();
-        if (!(off > off_tol2 * dg)) {         // also leaves on NaN (reported through the residual)
-            done = true;
-            break;
-        }
-        for (int r = 0; r < L - 1; ++r) {
-            if (tid < L / 2) {
-                int p, q;
-                jacobi_pair(tid, r, p, q);
-                pq[tid][0] = p;
-                pq[tid][1] = q;
-                // rotation annihilating a_pq, division-free: with d = a_qq - a_pp, b = 2 a_pq,
-                // h = hypot(b, d), u = |d| + h:  c = u / hypot(u, b),  s = sgn(d b) |b| / hypot(u, b)
-                const double b = 2.0 * A[p][q], d = A[q][q] - A[p][p];
-                double c = 1.0, sn = 0.0;
-                if (b != 0.0) {
-                    const double u = fabs(d) + sqrt(b * b + d * d);
-                    const double wv = rsqrt(u * u + b * b);
-                    c = u * wv;
-                    sn = ((d >= 0.0) == (b >= 0.0) ? fabs(b) : -fabs(b)) * wv;
-                }
-                cs[tid][0] = c;
-                cs[tid][1] = sn;
-            }
-            __syncthreads();
-            const int p = pq[I][0], q = pq[I][1], rr = pq[J][0], ss = pq[J][1];
-            const double cP = cs[I][0], sP = cs[I][1], cR = cs[J][0], sR = cs[J][1];
-            const double b00 = A[p][rr], b01 = A[p][ss], b10 = A[q][rr], b11 = A[q][ss];
-            const double t00 = cP * b00 - sP * b10, t01 = cP * b01 - sP * b11;
-            const double t10 = sP * b00 + cP * b10, t11 = sP * b01 + cP * b11;
-            double n00 = cR * t00 - sR * t01, n01 = sR * t00 + cR * t01;
-            double n10 = cR * t10 - sR * t11, n11 = sR * t10 + cR * t11;
-            if (I == J) n01 = n10 = 0.0;      // the pivot, annihilated exactly
-            A[p][rr] = n00;
-            A[p][ss] = n01;
-            A[q][rr] = n10;
-            A[q][ss] = n11;
-            // eigenvectors: V <- V J_J on rows 2I, 2I+1
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int row = 2 * I + h;
-                const double v0 = V[row][rr], v1 = V[row][ss];
-                V[row][rr] = cR * v0 - sR * v1;
-                V[row][ss] = sR * v0 + cR * v1;
-            }
-            __syncthreads();
-        }
-    }
-    if (!done && tid == 0) atomicOr(status, kStatEig);
-    // descending order; padded indices (>= n) go last
-    if (tid < L) {
-        const double mine = A[tid][tid];
-        int rk = 0;
-        for (int j = 0; j < L; ++j) {
-            if (j == tid) continue;
-            const double other = A[j][j];
-            bool before;
-            if (tid >= n) before = (j < n) || j < tid;
-            else before = (j < n) && (other > mine || (other == mine && j < tid));
-            rk += before ? 1 : 0;
-        }
-        rank[tid] = rk;
-        theta[rk] = tid < n ? mine : 0.0;
-    }
-    __syncthreads();
-    for (int e = tid; e < L * L; e += 1024) {
-        const int a = e >> 6, b = e & 63;
-        U[(size_t)a * L + rank[b]] = (a < n && b < n) ? V[a][b] : 0.0;
-    }
-}
-
-#include "jacobi.inl"
-
-// ---- Chebyshev filter between two Rayleigh–Ritz steps ----------------------------------------------
-// After a Ritz step the block holds Ritz vectors V (A2) with values theta and C V (A1).  The eigenvalues
-// that are NOT wanted lie in [0, b] with b <= theta_l (the smallest Ritz value of the block bounds
-// lambda_{l+1} from above), so instead of plain powers C^m V the block is filtered with the Chebyshev
-// polynomial T_d((2C - bI)/b): |T_d| <= 1 on [0, b] and grows like cosh(d acosh t) outside — for the bench
-// spectrum (theta_l/theta_npc = 0.24) a factor 14.9 per application of C against 4.2 for a plain power.
-//   Y0 = V,  Y1 = a C V - V,  Y_{j+1} = 2 (a C Y_j - Y_j) - Y_{j-1},   a = 2 / b
-// b is read from the device (theta[l_act - 1], floored at 1e-10 theta_0 so that a rank-deficient C cannot
-// divide by zero: any b at or above the unwanted spectrum is a valid filter).
-__device__ __forceinline__ double cheb_b(const double* __restrict__ theta, int l_act) {
-    const double b = theta[l_act - 1], floor_ = 1e-10 * theta[0];
-    return b > floor_ ? b : (floor_ > 0 ? floor_ : 1.0);
-}
-// A1 <- a A1 - A2   (Y1 from C V and V)
-__global__ void k_cheb_first(double* __restrict__ A1, const double* __restrict__ A2, const double* __restrict__ theta,
-                             int l_act, size_t n) {
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const double a = 2.0 / cheb_b(theta, l_act);
-    A1[e] = a * A1[e] - A2[e];
-}
-// prev <- 2 (a Z - cur) - prev   (Y_{j+1} from Z = C Y_j, Y_j, Y_{j-1})
-// (Z is left ZEROED: it is the destination of the next application of C, which accumulates into a zeroed block)
-__global__ void k_cheb_step(double* __restrict__ Z, const double* __restrict__ cur, double* __restrict__ prev,
-                            const double* __restrict__ theta, int l_act, size_t n) {
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const double a = 2.0 / cheb_b(theta, l_act);
-    prev[e] = 2.0 * (a * Z[e] - cur[e]) - prev[e];
-    Z[e] = 0.0;
-}
-// column i divided by T_d(t_i), t_i = (2 theta_i - b) / b: the filtered columns are (nearly) eigenvectors
-// scaled by T_d(t_i); taking the known factor out keeps the CholeskyQR that follows well conditioned
-__global__ void k_cheb_scale(double* __restrict__ Y, const double* __restrict__ theta, int l_act, int d, size_t n) {
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const int c = (int)(e % L);
-    if (c >= l_act) return;
-    const double b = cheb_b(theta, l_act);
-    const double t = (2.0 * theta[c] - b) / b;
-    const double Td = t > 1.0 ? cosh((double)d * acosh(t)) : 1.0;
-    Y[e] /= Td;
-}
-
-// sign convention of the components: the largest-|.| entry of each Ritz vector is positive
-__global__ void k_signs(const double* __restrict__ colmax, double* __restrict__ sgn) {
-    sgn[threadIdx.x] = colmax[threadIdx.x] < 0 ? -1.0 : 1.0;
-}
-
-// out[0] = max_{i < n_pc} rho_i / theta_i (NaN-propagating), out[1] = status bits,
-// out[2] = theta[l_act - 1] / theta[n_pc - 1]: the smallest Ritz value of the block over the last wanted
-// one — an upper estimate of the per-application convergence factor of the wanted pairs
-__global__ void k_resid_scalar(const double* __restrict__ rho, const double* __restrict__ theta, int n_pc, int l_act,
-                               const int* __restrict__ status, const int* __restrict__ status_sel,
-                               double* __restrict__ out) {
-    if (threadIdx.x != 0) return;
-    double resid = 0.0;
-    for (int i = 0; i < n_pc; ++i) {
-        // relative to the pair's own eigenvalue, but not to less than 1e-5 of the largest one: pairs of a numerically
-        // zero eigenvalue (more components asked than the data have rank) are judged on the scale of the problem
-        // (their absolute residual is ~1e-16 theta_1: 1e-11 on this scale)
-        const double den = theta[i] > 1e-5 * theta[0] ? theta[i] : 1e-5 * theta[0];
-        const double r = den > 0 ? rho[i] / den : rho[i];
-        if (!(r <= resid)) resid = r;
-    }
-    out[0] = resid;
-    out[1] = (double)*status;
-    out[2] = theta[n_pc - 1] > 0 ? theta[l_act - 1] / theta[n_pc - 1] : 1.0;
-    out[3] = status_sel ? (double)*status_sel : 0.0;      // device-side feature selection: bit 0 = NaN variance
-    out[4] = theta[l_act - 1] > 0 ? theta[0] / theta[l_act - 1] : 1.0;      // spread of the block: bounds the filter degree
-}
-
-// k_ritz_post's partials -> rho[c], colmax[c], then the scalars of k_resid_scalar (same slots of `out`).  1024 threads:
-// 16 slices of the blocks per column (a single wave walking 128 x 3 dependent loads took 45 us), combined in fixed order.
-__global__ __launch_bounds__(1024) void k_resid_final(const double* __restrict__ part, int n_blocks, const double* __restrict__ theta,
-                                                      int n_pc, int l_act, const int* __restrict__ status,
-                                                      const int* __restrict__ status_sel, double* __restrict__ rho,
-                                                      double* __restrict__ colmax, double* __restrict__ out) {
-    __shared__ double s_t[16][L], s_v[16][L], s_j[16][L], s_rho[L];
-    const int c = threadIdx.x & (L - 1), sl = threadIdx.x / L;
-    double t = 0.0, bv = 0.0, bj = 0.0;
-    for (int b = sl; b < n_blocks; b += 16) {
-        const double* p = part + (size_t)b * 3 * L;
-        t += p[c];
-        const double v = p[L + c], jj = p[2 * L + c];
-        if (fabs(v) > fabs(bv) || (fabs(v) == fabs(bv) && v != 0.0 && jj < bj)) {
-            bv = v;
-            bj = jj;
-        }
-    }
-    s_t[sl][c] = t;
-    s_v[sl][c] = bv;
-    s_j[sl][c] = bj;
-    __syncthreads();
-    if (sl == 0) {
-        t = 0.0; bv = 0.0; bj = 0.0;
-        for (int w = 0; w < 16; ++w) {
-            t += s_t[w][c];
-            const double v = s_v[w][c], jj = s_j[w][c];
-            if (fabs(v) > fabs(bv) || (fabs(v) == fabs(bv) && v != 0.0 && jj < bj)) {
-                bv = v;
-                bj = jj;
-            }
-        }
-        const double r = sqrt(t);
-        rho[c] = r;
-        colmax[c] = bv;
-        s_rho[c] = r;
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    double resid = 0.0;
-    for (int i = 0; i < n_pc; ++i) {
-        const double den = theta[i] > 1e-5 * theta[0] ? theta[i] : 1e-5 * theta[0];      // (see k_resid_scalar)
-        const double q = den > 0 ? s_rho[i] / den : s_rho[i];
-        if (!(q <= resid)) resid = q;
-    }
-    out[0] = resid;
-    out[1] = (double)*status;
-    out[2] = theta[n_pc - 1] > 0 ? theta[l_act - 1] / theta[n_pc - 1] : 1.0;
-    out[3] = status_sel ? (double)*status_sel : 0.0;
-    out[4] = theta[l_act - 1] > 0 ? theta[0] / theta[l_act - 1] : 1.0;
-}
+#include "iterate.inl"
 
 // ---- compacted matrix: row-major records + the tile-major view of the forward SpMM ------------------
 struct CompactCsr {
