@@ -553,7 +553,9 @@ int32_t ensure_tiles(srx_mat* m) {
 }
 
 static void block_geometry(const srx_mat* m, uint64_t& n_blocks, uint64_t& rows_per_block) {
-    uint64_t want = (uint64_t)(2 * m->ctx->n_cus) / (uint64_t)m->n_tiles;
+    // four workgroups per CU, one resident at a time (the accumulators fill the LDS): c3, XF + write-back pass, 1 / 2 / 4 / 8 / 16
+    // per CU: 3.23 / 3.12 / 3.06 / 3.10 / 3.19 ms (shorter workgroups even out the CUs; more of them means more partial sums)
+    uint64_t want = (uint64_t)(4 * m->ctx->n_cus) / (uint64_t)m->n_tiles;
     if (want < 1) want = 1;
     uint64_t by_rows = (m->n_rows + 63) / 64;   // at least ~64 rows per block
     if (by_rows < 1) by_rows = 1;
