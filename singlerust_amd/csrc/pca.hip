@@ -513,7 +513,9 @@ static int32_t launch_fwd_rows(srx_ctx* ctx, const RowMajor& r, const PT* P, con
         const size_t lds = (size_t)(k_hi - k_lo) * ldp * sizeof(PT);
         const uint64_t groups = kFwdRowsThreads / Q;
         uint64_t n_wg = (r.n_rows + groups - 1) / groups;
-        uint64_t cap = std::max<uint64_t>(1, (uint64_t)ctx->n_cus / n_slices);      // one workgroup per CU
+        // one workgroup per CU at a time (the panel slice fills the LDS), eight in a row: shorter workgroups even out the CUs
+        // (c3, f32: 1 / 2 / 4 / 8 / 16 / 32 per CU: 0.73 / 0.71 / 0.70 / 0.69 / 0.68 / 0.77 ms; f64 panels 1.37 -> 1.30 at 8)
+        uint64_t cap = std::max<uint64_t>(1, (uint64_t)ctx->n_cus * 8 / n_slices);
         if (cap > 8) cap &= ~(uint64_t)7;           // (whole rounds of the 8 XCDs: the slices of a row range share an L2)
         if (n_wg > cap) n_wg = cap;
         if (n_wg < 1) n_wg = 1;
