@@ -772,7 +772,7 @@ def main():
             fw, tr = r["prof"].get("spmm_fwd", {}), r["prof"].get("spmm_t", {})
             return {"steps": 2, "ms_per_step": r["ms_per_step"], "subspace_iterations": r["iters"], "pca_residual": r["residual"],
                     "spmm_fwd": roof(fw, KERNEL_SYMBOL["spmm_fwd"], "f64 panels (the matrix-free iteration runs its products in f64)"),
-                    "spmm_t": roof(tr, KERNEL_SYMBOL["spmm_t"], "N m 64 f64 LDS lane-atomics per launch: LDS-atomic bound"),
+                    "spmm_t": roof(tr, KERNEL_SYMBOL["spmm_t"], "N m 64 f64 LDS lane-atomics per launch; without them the launch takes the same time (DESIGN.md section 3c): ~8 instructions per non-zero for 64 multiply-adds"),
                     "note": "--solver 2: the matrix-free subspace iteration, one forward and one transposed SpMM per application of "
                             "C — the kernels BASELINE.json's second metric means; the default Gram solver runs the forward "
                             "SpMM once per solve (roofline_spmm)"}
