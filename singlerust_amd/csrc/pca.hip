@@ -1384,9 +1384,11 @@ static int32_t run_pca(srx_ctx* ctx, const RowMajor* parts, int n_parts, const T
             hipLaunchKernelGGL((k_make_panel<PT>), dim3(1), dim3(1024), 0, ctx->stream, Win, w.d, w.mu,
                                (const double*)nullptr, k, o.center, P, cvec);
             SRX_HIP(ctx, hipGetLastError());
-            // forward product: the row-major batch-stream kernel (8 slices of 8 f64 columns) where the records are there —
-            // 2.0 against 2.45 ms per application at c3 for the tile-major kernel
-            if (parts[0].pk && !getenv("SRX_FWD_TILED")) SRX_TRY((launch_fwd_rows<VT, PT>(ctx, parts[0], P, cvec, L, (double*)nullptr, Y, L)));
+            // forward product: the row-major batch-stream kernel where its widest slice (8 f64 columns of all k genes: k <= 2559)
+            // fits the LDS — 8 passes over the records, 1.48 against 2.45 ms per application at c3 for the tile-major kernel,
+            // which reads the matrix once whatever k is and stays the route beyond (narrower slices mean 16+ passes)
+            if (parts[0].pk && fwd_rows_q<PT>(k) >= 2 && !getenv("SRX_FWD_TILED"))
+                SRX_TRY((launch_fwd_rows<VT, PT>(ctx, parts[0], P, cvec, L, (double*)nullptr, Y, L)));
             else SRX_TRY((launch_fwd<VT, PT>(ctx, t256, P, cvec, Y)));
             SRX_TRY((launch_t<VT, PT>(ctx, t256, Y, w.T)));
             SRX_TRY(allreduce_f64(ctx, w.T, kl + L));             // the one exchange per iteration
