@@ -68,6 +68,31 @@ def omp_pipeline(m, target_sum: float, n_hvg: int, n_threads: int):
     return out, hv, order, cov, mean, sd, secs
 
 
+def omp_cov_selected(m, sel, n_threads: int):
+    """Standardised covariance Z^T Z (k x k, f64) of the selection `sel` (slot i = feature sel[i]) of the f64 matrix `m`, mean and
+    sd (ddof 0) per slot — omp_baseline.c::orc_omp_cov_selected: the independent eigen-reference of a PCA at sizes where the
+    exact SVD of the densified N x k matrix (pca_oracle) does not fit a test."""
+    build()
+    lo = ctypes.CDLL(_OMP_PATH)
+    sel = np.ascontiguousarray(sel, dtype=np.uint64)
+    k = len(sel)
+    vals = np.ascontiguousarray(m.values, dtype=np.float64)
+    ip = np.ascontiguousarray(m.indptr, dtype=np.uint64)
+    ix = np.ascontiguousarray(m.indices, dtype=np.uint64)
+    cov, mean, sd = np.zeros((k, k)), np.zeros(k), np.zeros(k)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lo.orc_omp_cov_selected.restype = ctypes.c_int
+    lo.orc_omp_cov_selected.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p]
+    rc = lo.orc_omp_cov_selected(m.n_rows, m.n_cols, vp(ip), vp(ix), vp(vals), vp(sel), k, n_threads, vp(cov), vp(mean), vp(sd))
+    if rc == -1:
+        raise MemoryError("orc_omp_cov_selected: out of memory")
+    if rc != 0:
+        raise ValueError("orc_omp_cov_selected: a feature is selected twice or out of range")
+    return cov, mean, sd
+
+
 class _Csr(ctypes.Structure):
     _fields_ = [
         ("n_rows", ctypes.c_uint64), ("n_cols", ctypes.c_uint64), ("nnz", ctypes.c_uint64),

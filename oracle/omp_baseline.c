@@ -139,3 +139,64 @@ int orc_omp_pipeline(uint64_t n_rows, uint64_t n_cols, const uint64_t* indptr, c
     seconds[3] = 0.0;
     return 0;
 }
+
+/* Standardised covariance Z^T Z of a GIVEN feature selection (sel[k], any order: slot i = feature sel[i]) of the f64 matrix
+ * `values` — the independent k x k check of a PCA at sizes where the oracle's exact SVD of the densified N x k matrix does not
+ * fit a test (tests/test_fullsize_gpu.py at configs[2]: 1.3M x 28k).  mean / sd over ALL rows, ddof 0 (pca/mod.rs:87-94);
+ * cov[i][j] = (sum_r x_ri x_rj - N mean_i mean_j) / (sd_i sd_j), both triangles.  Returns 0, -1 out of memory, -2 when a
+ * feature is selected twice or out of range. */
+int orc_omp_cov_selected(uint64_t n_rows, uint64_t n_cols, const uint64_t* indptr, const uint64_t* indices,
+                         const double* values, const uint64_t* sel, uint64_t k, int n_threads, double* cov, double* mean,
+                         double* sd) {
+    if (n_threads < 1) n_threads = 1;
+    omp_set_num_threads(n_threads);
+    int32_t* remap = malloc(n_cols * sizeof *remap);
+    double* gpart = calloc((size_t)n_threads * k * k, sizeof(double));
+    double* spart = calloc((size_t)n_threads * k, sizeof(double));
+    if (!remap || !gpart || !spart) { free(remap); free(gpart); free(spart); return -1; }
+    for (uint64_t j = 0; j < n_cols; ++j) remap[j] = -1;
+    for (uint64_t i = 0; i < k; ++i) {
+        if (sel[i] >= n_cols || remap[sel[i]] >= 0) { free(remap); free(gpart); free(spart); return -2; }
+        remap[sel[i]] = (int32_t)i;
+    }
+#pragma omp parallel
+    {
+        double* g = gpart + (size_t)omp_get_thread_num() * k * k;
+        double* s = spart + (size_t)omp_get_thread_num() * k;
+        int32_t* cj = malloc(k * sizeof *cj);
+        double* cv = malloc(k * sizeof *cv);
+#pragma omp for schedule(dynamic, 64)
+        for (uint64_t r = 0; r < n_rows; ++r) {
+            uint64_t m = 0;
+            for (uint64_t p = indptr[r]; p < indptr[r + 1]; ++p) {
+                const int32_t c = remap[indices[p]];
+                if (c >= 0) { cj[m] = c; cv[m] = values[p]; ++m; }
+            }
+            for (uint64_t a = 0; a < m; ++a) {
+                double* row = g + (size_t)cj[a] * k;
+                const double va = cv[a];
+                s[cj[a]] += va;
+                for (uint64_t b = 0; b < m; ++b) row[cj[b]] += va * cv[b];
+            }
+        }
+        free(cj); free(cv);
+    }
+    const double nd = (double)n_rows;
+#pragma omp parallel for schedule(static)
+    for (uint64_t i = 0; i < k; ++i) {
+        double s = 0, q = 0;
+        for (int t = 0; t < n_threads; ++t) { s += spart[(size_t)t * k + i]; q += gpart[(size_t)t * k * k + i * k + i]; }
+        mean[i] = s / nd;
+        double var = q / nd - mean[i] * mean[i];
+        sd[i] = var > 0 ? sqrt(var) : 1.0;
+    }
+#pragma omp parallel for schedule(static)
+    for (uint64_t e = 0; e < k * k; ++e) {
+        double s = 0;
+        for (int t = 0; t < n_threads; ++t) s += gpart[(size_t)t * k * k + e];
+        const uint64_t i = e / k, j = e % k;
+        cov[e] = (s - nd * (mean[i] * mean[j])) / (sd[i] * sd[j]);      /* (mean_i mean_j) first: symmetric to the last bit */
+    }
+    free(remap); free(gpart); free(spart);
+    return 0;
+}

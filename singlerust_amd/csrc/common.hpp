@@ -74,6 +74,10 @@ struct srx_ctx {
     hipStream_t side_stream = nullptr;
     hipStream_t comm_stream = nullptr;       // collectives issued beside the compute stream (launch_gram); events for fork / join
     hipEvent_t comm_fork = nullptr, comm_join = nullptr;
+    // sharded rows: the second half of the Gram kernel runs here, off the CUs left to the collective (launch_gram)
+    hipStream_t gram_stream = nullptr;
+    bool gram_stream_masked = false;
+    hipEvent_t gram_fork = nullptr, gram_join = nullptr;
     hipEvent_t side_fork = nullptr, side_join = nullptr;
     bool side_busy = false;
     struct srx_mat* wb_after_gram = nullptr;      // pipeline: matrix whose write-back run_pca queues behind the Gram kernel

@@ -598,24 +598,62 @@ static int32_t launch_t(srx_ctx* ctx, const Tiled& c, const YT* Y, double* T /* 
     return SRX_OK;
 }
 
+// The Gram kernel's second half runs on a stream whose CU mask leaves `kCommFreeCus` CUs alone when the rows are sharded: the
+// collective's workgroups (RCCL: one per channel, persistent) then find a CU with room whatever the dispatcher does with the
+// stripe kernel's 10 000 queued workgroups — measured in round 3: a second stream's first kernel sat 2.8 ms in its queue
+// beside that grid, stream priority or not.  6 % of the CUs cost the half launch ~0.1 ms.
+constexpr int kCommFreeCus = 16;
+static int32_t ensure_comm_streams(srx_ctx* ctx) {
+    if (!ctx->comm_stream) {
+        SRX_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+        SRX_HIP(ctx, hipEventCreateWithFlags(&ctx->comm_fork, hipEventDisableTiming));
+        SRX_HIP(ctx, hipEventCreateWithFlags(&ctx->comm_join, hipEventDisableTiming));
+    }
+    if (!ctx->gram_stream) {
+        uint32_t mask[8];
+        const int n_cus = ctx->n_cus > 256 ? 256 : ctx->n_cus;
+        for (int w = 0; w < 8; ++w) mask[w] = 0u;
+        for (int c = 0; c < n_cus; ++c)
+            if (c >= kCommFreeCus) mask[c >> 5] |= 1u << (c & 31);
+        if (n_cus <= 2 * kCommFreeCus ||
+            hipExtStreamCreateWithCUMask(&ctx->gram_stream, (uint32_t)((n_cus + 31) / 32), mask) != hipSuccess) {
+            (void)hipGetLastError();
+            SRX_HIP(ctx, hipStreamCreateWithFlags(&ctx->gram_stream, hipStreamNonBlocking));
+            ctx->gram_stream_masked = false;
+        } else {
+            ctx->gram_stream_masked = true;
+        }
+        SRX_HIP(ctx, hipEventCreateWithFlags(&ctx->gram_fork, hipEventDisableTiming));
+        SRX_HIP(ctx, hipEventCreateWithFlags(&ctx->gram_join, hipEventDisableTiming));
+    }
+    return SRX_OK;
+}
+
 // G += A^T A of the row-major compacted matrix, into the packed upper triangle `Gp` (k (k + 1) / 2 doubles; the
 // caller zeroes it for a fresh sum): owner buckets, then the stripe kernel.
 // `reduce` (nullable): sum the triangle over the ranks HERE, the first half of the owners' rows on the communication stream
 // while the second half is still being computed (*reduce is set when that was done; otherwise the caller's all-reduce follows).
+// Whether the exchange is split is decided from rank-invariant data only (k, the communicator): a rank WITHOUT rows — more
+// ranks than non-empty rows, a skewed cut, a filter that emptied a shard — skips the kernels and issues the same three
+// collectives with the same counts as everybody else.
 template <typename VT>
 static int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce = nullptr) {
     if (reduce) *reduce = false;
-    if (rm.n_rows == 0) return SRX_OK;
     GramPlan g;
     SRX_TRY(gram_plan(ctx, rm.k, rm.n_rows, g));
-    uint32_t* boff;
-    int64_t *blk_total, *rec_base;
-    GramRec<VT>* recs;
-    SRX_TRY(scratch(ctx, "pca_boff", g.n_rblk * (size_t)(g.n_wg + 1) * sizeof(uint32_t), (void**)&boff));
-    SRX_TRY(scratch(ctx, "pca_brtot", g.n_rblk * sizeof(int64_t), (void**)&blk_total));
-    SRX_TRY(scratch(ctx, "pca_brbase", (g.n_rblk + 1) * sizeof(int64_t), (void**)&rec_base));
+    static const bool force_split = getenv("SRX_GRAM_OVERLAP") != nullptr;      // test switch: the split with a 1-rank communicator
+    const int h = g.n_wg / 2;
+    const bool split = reduce && comm_is_rccl(ctx) && (ctx->n_ranks > 1 || force_split) && h >= 1 && g.n_wg - h >= 1;
+    const bool empty = rm.n_rows == 0;
+    if (empty && !split) return SRX_OK;
+    uint32_t* boff = nullptr;
+    int64_t *blk_total = nullptr, *rec_base = nullptr;
+    GramRec<VT>* recs = nullptr;
     int64_t n_recs = 0;
-    {
+    if (!empty) {
+        SRX_TRY(scratch(ctx, "pca_boff", g.n_rblk * (size_t)(g.n_wg + 1) * sizeof(uint32_t), (void**)&boff));
+        SRX_TRY(scratch(ctx, "pca_brtot", g.n_rblk * sizeof(int64_t), (void**)&blk_total));
+        SRX_TRY(scratch(ctx, "pca_brbase", (g.n_rblk + 1) * sizeof(int64_t), (void**)&rec_base));
         // SRX_K_BUCKET: record counts, their read-back, the bucket pass — the compacted matrix read once (twice through L2),
         // the records written once
         ProfScope ps(ctx, SRX_K_BUCKET, (double)rm.nnz * sizeof(GramPk<VT>) + (double)(rm.n_rows + 1) * 8.0 * 2.0);
@@ -642,47 +680,47 @@ static int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* r
     // shows up in the PMC traffic, not here.
     ProfScope ps(ctx, SRX_K_GRAM, (double)rm.nnz * sizeof(GramPk<VT>) + (double)(rm.n_rows + 1) * 8.0 + (double)rm.k * (rm.k + 1) / 2 * 8.0,
                  nullptr, (double)n_recs * sizeof(GramRec<VT>) + (double)g.n_rblk * (g.n_wg + 1) * 4.0);
-    SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_stripes<VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
-    auto launch = [&](int w0, int n_w) {
-        hipLaunchKernelGGL((k_gram_stripes<VT>), dim3((unsigned)(n_w * g.n_z)), dim3(kGramWaves * kWave), g.lds_bytes, ctx->stream,
+    if (!empty) SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_stripes<VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
+    auto launch = [&](int w0, int n_w, hipStream_t st) {
+        if (empty) return;
+        hipLaunchKernelGGL((k_gram_stripes<VT>), dim3((unsigned)(n_w * g.n_z)), dim3(kGramWaves * kWave), g.lds_bytes, st,
                            rm.ptr, (const GramPk<VT>*)rm.pk, boff, rec_base, recs, g.n_rblk, g.rblk, rm.k, g.sr_shift, g.n_wg,
                            g.n_stripes, g.n_chunk, w0, n_w, Gp);
     };
     // Sharded rows: owner w holds the stripes w and n_stripes - 1 - w, so the owners [0, h) hold the rows [0, h SR) and
     // [k - h SR, k) of the triangle — two contiguous ranges of the packed array — and the others the rows between.  Two
-    // launches; the first one's ranges go round the ranks (RCCL, communication stream) under the second launch, the middle
-    // range after it: half of the 16 MB exchange is hidden.  (One launch on a single rank: the owners of a chunk share what
-    // they pull into L2, and halving them costs more than nothing.)
-    static const bool force_split = getenv("SRX_GRAM_OVERLAP") != nullptr;      // test switch: the split with a 1-rank communicator
-    const int h = g.n_wg / 2;
-    if (reduce && comm_is_rccl(ctx) && (ctx->n_ranks > 1 || force_split) && h >= 1 && g.n_wg - h >= 1) {
-        if (!ctx->comm_stream) {
-            SRX_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
-            SRX_HIP(ctx, hipEventCreateWithFlags(&ctx->comm_fork, hipEventDisableTiming));
-            SRX_HIP(ctx, hipEventCreateWithFlags(&ctx->comm_join, hipEventDisableTiming));
-        }
+    // launches; the first one's ranges go round the ranks (RCCL, communication stream) under the second launch — which runs
+    // on the CU-masked stream, so that the collective's workgroups have CUs of their own —, the middle range after it: half
+    // of the 16 MB exchange is hidden.  (One launch on a single rank: the owners of a chunk share what they pull into L2,
+    // and halving them costs more than nothing.)
+    if (split) {
+        SRX_TRY(ensure_comm_streams(ctx));
         const int SR = 1 << g.sr_shift, k = rm.k;
         const int r_lo = std::min(k, h * SR), r_hi = std::min(k, std::max(r_lo, (g.n_stripes - h) * SR));      // rows [0, r_lo) + [r_hi, k): the first launch
         auto off = [&](int row) { return (size_t)row * (size_t)k - (size_t)row * (size_t)(row - 1) / 2; };      // packed offset of (row, row)
-        launch(0, h);
+        launch(0, h, ctx->stream);
         SRX_HIP(ctx, hipGetLastError());
         SRX_HIP(ctx, hipEventRecord(ctx->comm_fork, ctx->stream));
         SRX_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->comm_fork, 0));
         SRX_TRY(allreduce_f64_on(ctx, Gp, off(r_lo), ctx->comm_stream));
         SRX_TRY(allreduce_f64_on(ctx, Gp + off(r_hi), off(k) - off(r_hi), ctx->comm_stream));
-        launch(h, g.n_wg - h);
+        // second half of the owners on the masked stream, joined back into the context's stream
+        SRX_HIP(ctx, hipEventRecord(ctx->gram_fork, ctx->stream));
+        SRX_HIP(ctx, hipStreamWaitEvent(ctx->gram_stream, ctx->gram_fork, 0));
+        launch(h, g.n_wg - h, ctx->gram_stream);
         SRX_HIP(ctx, hipGetLastError());
+        SRX_HIP(ctx, hipEventRecord(ctx->gram_join, ctx->gram_stream));
+        SRX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->gram_join, 0));
         // the middle rows: on the communication stream too (one stream for all of the communicator's collectives in
         // flight), after the second launch
-        SRX_HIP(ctx, hipEventRecord(ctx->comm_fork, ctx->stream));
-        SRX_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->comm_fork, 0));
+        SRX_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->gram_join, 0));
         SRX_TRY(allreduce_f64_on(ctx, Gp + off(r_lo), off(r_hi) - off(r_lo), ctx->comm_stream));
         SRX_HIP(ctx, hipEventRecord(ctx->comm_join, ctx->comm_stream));
         SRX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->comm_join, 0));
         *reduce = true;
         return SRX_OK;
     }
-    launch(0, g.n_wg);
+    launch(0, g.n_wg, ctx->stream);
     SRX_HIP(ctx, hipGetLastError());
     return SRX_OK;
 }

@@ -55,9 +55,11 @@ def test_config0_shape_every_stage_against_the_oracle(ctx, store, vtol):
     assert np.allclose(evr, wevr, rtol=1e-5) and np.allclose(mean, wmean, rtol=1e-5, atol=1e-7) and np.allclose(std, wstd, rtol=1e-5)
     # 1e-5 per component wherever the eigengap supports it (N = 2700: the tail eigenvalues crowd), the perturbation bound
     # of the storage precision elsewhere — no blanket factor
-    gaps = assert_components_within_conditioning(scores, want, wevr, store, "c1-shape score")
+    # asserted slack budget 0 at BOTH storages: every one of the 50 components meets the plain 1e-5 (measured: worst 8.6e-7 at
+    # f32 storage, 2.8e-10 at f64), the conditioning argument is not drawn on
+    gaps = assert_components_within_conditioning(scores, want, wevr, store, "c1-shape score", max_slack=0)
     used = assert_components_within_conditioning.last
-    assert_components_within_conditioning(comps, wc, wevr, store, "c1-shape loading")
+    assert_components_within_conditioning(comps, wc, wevr, store, "c1-shape loading", max_slack=0)
     assert (gaps[:10] > 1e-3).all()
     # the leading ten components (gaps > 1e-3) meet the plain 1e-5 at EITHER storage: the conditioning slack is for the tail
     assert col_err(scores[:, :10], want[:, :10]) < TOL and col_err(comps[:, :10], wc[:, :10]) < TOL
@@ -66,20 +68,21 @@ def test_config0_shape_every_stage_against_the_oracle(ctx, store, vtol):
     assert np.abs(wc @ (wc.T @ comps) - comps).max() < 1e-4
 
 
-def test_config1_shape_against_the_oracle(ctx):
+@pytest.mark.parametrize("store,vtol", [(1, 1e-6), (2, 4e-16)])
+def test_config1_shape_against_the_oracle(ctx, store, vtol):
     import scipy.sparse as sp
     import singlerust_amd as sr
     from singlerust_amd.memory import statistics as st
     n, g = 100_000, 20_000
     m, _ = synth_host(2002, n, g, 0.05)
     assert 0.9e8 < len(m.values) < 1.1e8
-    a, scores, comps, evr, mean, std, hv = pipeline(ctx, m, 1, 2000, 50)
+    a, scores, comps, evr, mean, std, hv = pipeline(ctx, m, store, 2000, 50)
     lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))            # serial C loops over 1e8 non-zeros
-    assert rel_err(a.x_values(np.float64), lg.values.astype(np.float64)) <= 1e-6
+    assert rel_err(a.x_values(np.float64), lg.values.astype(np.float64)) <= vtol
     want_var = oracle.compute_variance(lg, COLUMN)
-    assert np.allclose(st.compute_variance(a, sr.Direction.Column), want_var, rtol=1e-4, atol=1e-12)
+    assert np.allclose(st.compute_variance(a, sr.Direction.Column), want_var, rtol=1e-4 if store == 1 else 1e-11, atol=1e-12)
     want_sel = oracle.select_hvg(want_var, 2000)
-    # f32 storage, f64 moments: HighlyVariable(2000) is the reference's, index for index
+    # either storage, f64 moments: HighlyVariable(2000) is the reference's, index for index
     assert np.array_equal(hv, want_sel)
     # PCA of the GPU's own selection: covariance eigendecomposition in f64
     x = sp.csr_matrix((lg.values.astype(np.float64), lg.indices.astype(np.int64), lg.indptr.astype(np.int64)), shape=(n, g))
@@ -94,9 +97,10 @@ def test_config1_shape_against_the_oracle(ctx):
     wv, vv = w[order], v[:, order]
     assert np.allclose(mean, mu, rtol=1e-5, atol=1e-7) and np.allclose(std, sd, rtol=1e-5)
     assert np.allclose(evr, wv / np.trace(cov), rtol=1e-5)
-    assert_components_within_conditioning(comps, vv, wv, 1, "c2-shape loading")
+    # slack budget 0: all 50 components at the plain 1e-5 at either storage (measured at f32: loadings 1.0e-7, scores 2.8e-7)
+    assert_components_within_conditioning(comps, vv, wv, store, "c2-shape loading", max_slack=0)
     want_scores = (xs @ (vv / sd[:, None])) - (mu / sd) @ vv
-    assert_components_within_conditioning(scores, np.asarray(want_scores), wv, 1, "c2-shape score")
+    assert_components_within_conditioning(scores, np.asarray(want_scores), wv, store, "c2-shape score", max_slack=0)
 
 
 def test_wide_matrix_without_the_16bit_index_mirror(ctx, tmp_path):

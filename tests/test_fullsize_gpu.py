@@ -4,6 +4,7 @@ size: the reference's own row-sum property (src/memory/processing/mod.rs:451-462
 a checksum of checksums, sortedness of the HVG ranking, orthonormality / centring / ordering of the PCA output,
 and idempotence of the statistics."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -149,7 +150,9 @@ def test_backed_session_at_full_c3_size_matches_the_resident_pipeline(ctx):
     res = F.PipelineResult()
     F.check(lib.srx_pipeline(dev.handle, 1e4, 2000, C.byref(opts), C.byref(res)), ctx.handle)
     scores0, evr0, hv0 = np.zeros((n, 50)), np.zeros(50), np.zeros(2000, np.uint64)
-    F.check(lib.srx_result_fetch(dev.handle, F.ptr(scores0), None, F.ptr(evr0), None, None, F.ptr(hv0)), ctx.handle)
+    comps0, mean0, std0 = np.zeros((2000, 50)), np.zeros(2000), np.zeros(2000)
+    F.check(lib.srx_result_fetch(dev.handle, F.ptr(scores0), F.ptr(comps0), F.ptr(evr0), F.ptr(mean0), F.ptr(std0), F.ptr(hv0)),
+            ctx.handle)
     dev.free()
     # the same matrix on the host, reference layout
     tile = 200_000
@@ -191,8 +194,27 @@ def test_backed_session_at_full_c3_size_matches_the_resident_pipeline(ctx):
     mh = oracle.Csr(n, g, ip, idx, val)
     lg = oracle.log1p_transform(oracle.normalize_total(mh, 1e4, oracle.ROW))
     want_hv = oracle.select_hvg(oracle.compute_variance(lg, oracle.COLUMN), 2000)
-    del lg, mh
     assert np.array_equal(hv0, want_hv)
+    # ... and ALL 50 components against an INDEPENDENT eigendecomposition at full size: the 2000 x 2000 standardised covariance
+    # Z^T Z of the selection formed on the host from the oracle's f64 values (OpenMP, oracle/omp_baseline.c), numpy eigh — the
+    # k x k form of the oracle's SVD (eigenvalues s^2, eigenvectors V: pca/mod.rs:124-144).  An invariant-subspace bug that
+    # returned 50 exact eigenvectors which are not the TOP 50 fails here.
+    from test_pca_gpu import assert_components_within_conditioning
+    cov, mu, sd = oracle.omp_cov_selected(lg, hv0, min(64, os.cpu_count() or 1))
+    w, v = np.linalg.eigh(cov)
+    order = np.argsort(w)[::-1][:50]
+    wv, vv = w[order], v[:, order]
+    assert np.allclose(mean0, mu, rtol=1e-5, atol=1e-7) and np.allclose(std0, sd, rtol=1e-5)
+    assert np.allclose(evr0, wv / np.trace(cov), rtol=1e-5)                  # ratio over ALL eigenvalues (pca/mod.rs:131-133)
+    # slack budget 0 at f32 storage: every component of the planted c3 spectrum at the plain 1e-5
+    assert_components_within_conditioning(comps0, vv, wv, 1, "c3 full-size loading", max_slack=0)
+    # scores of a row sample from the INDEPENDENT eigenvectors: (Z . V)[rows] (pca/mod.rs:156-185), the first 20k cells
+    ns = 20_000
+    sub = oracle.Csr(ns, g, (ip[:ns + 1]).copy(), idx[:int(ip[ns])], lg.values[:int(ip[ns])])
+    dense = oracle.densify_selected(sub, hv0)
+    want_scores = ((dense - mu) / sd) @ vv
+    assert_components_within_conditioning(scores0[:ns], want_scores, wv, 1, "c3 full-size score (20k-cell sample)", max_slack=0)
+    del lg, mh, sub, dense, cov
     for r0, r1, t in tiles():
         F.check(lib.srx_backed_gram_tile(b, C.byref(t), 1e4, xf), ctx.handle)
     info = F.PcaInfo()

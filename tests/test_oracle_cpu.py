@@ -1,6 +1,6 @@
 """CPU tests (-m "not gpu"): pin the oracle before trusting it.
 
-* against the hand-derived 4x5 KAT (tests/golden/kat_4x5.json);
+* against the hand-derived 4x5 KAT (tests/golden/kat_4x5.json) and the hand-derived PCA KAT (kat_pca_6x4.json);
 * against the committed golden vectors computed with independent numpy/scipy/sklearn maths
   (tests/golden/make_golden.py);
 * against the reference's own property test, restated: after normalize_total every
@@ -138,6 +138,56 @@ def test_pca_oracle_vs_sklearn():
     # defaults: n_components None -> 2 (dim_red/mod.rs:52)
     s2, c2, *_ = pca_oracle.pca_inplace(lg, None, None, None, sel)
     assert s2.shape == (600, 2) and c2.shape == (120, 2)
+
+
+def _kat_pca():
+    k = json.load(open(os.path.join(GOLD, "kat_pca_6x4.json")))
+    return k, {n: np.array(k[n], dtype=np.float64) for n in ("mean", "std", "explained_variance_ratio", "components", "scores",
+                                                               "loadings", "eigenvalues")}
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32, np.float64])
+def test_pca_oracle_against_the_hand_derived_kat(dtype):
+    """tests/golden/kat_pca_6x4.json: a rank-2 6 x 4 matrix whose standardised SVD follows by hand from
+    pca/mod.rs:87-144 — the first PCA vector that does not come out of numpy.  Pins the oracle's mean / std (ddof 0),
+    eigenvalue normalisation s^2/(n-1), ratio over ALL eigenvalues, component / score / loading layout."""
+    k, w = _kat_pca()
+    m = Csr(k["n_rows"], k["n_cols"], k["indptr"], k["indices"], np.array(k["data"], dtype=dtype))
+    assert np.array_equal(oracle.densify_selected(m, np.arange(4, dtype=np.uint64)), np.array(k["dense"], dtype=np.float64))
+    pca = pca_oracle.Pca(n_components=k["n_components"], center=True, scale=True)
+    pca.fit(np.array(k["dense"], dtype=np.float64))
+    np.testing.assert_allclose(pca.mean, w["mean"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(pca.std_dev, w["std"], rtol=1e-15)
+    np.testing.assert_allclose(pca.eigenvalues, w["eigenvalues"], atol=1e-14)
+    assert abs(pca.total_variance - k["total_variance"]) < 1e-14
+    scores, comps, evr, mean, std = pca_oracle.pca_inplace(m, None, None, None, None)     # defaults: 2 components, centre, scale
+    np.testing.assert_allclose(evr, w["explained_variance_ratio"], rtol=1e-14)
+    for c in range(2):
+        s = np.sign(np.dot(comps[:, c], w["components"][:, c]))
+        np.testing.assert_allclose(s * comps[:, c], w["components"][:, c], atol=1e-14)
+        np.testing.assert_allclose(s * scores[:, c], w["scores"][:, c], atol=1e-14)
+        np.testing.assert_allclose(s * pca.compute_loadings()[c], w["loadings"][c], atol=1e-14)
+
+
+def test_omp_cov_selected_is_the_k_by_k_form_of_the_pca_oracle():
+    """oracle/omp_baseline.c::orc_omp_cov_selected (the full-size c3 eigen-reference of tests/test_fullsize_gpu.py) against the
+    exact-SVD oracle: eigh of Z^T Z gives the SVD's V and s^2, mean / sd per slot in selection order."""
+    m, z = load("planted_600x240")
+    lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
+    sel = pca_oracle.select_features_hvg(lg, 120)
+    cov, mean, sd = oracle.omp_cov_selected(lg, sel, 3)
+    scores, comps, evr, wmean, wstd = pca_oracle.pca_inplace(lg, 5, None, None, sel)
+    np.testing.assert_allclose(mean, wmean, rtol=1e-13)
+    np.testing.assert_allclose(sd, wstd, rtol=1e-13)
+    assert np.array_equal(cov, cov.T)
+    w, v = np.linalg.eigh(cov)
+    order = np.argsort(w)[::-1][:5]
+    np.testing.assert_allclose(w[order] / np.trace(cov), evr, rtol=1e-10)
+    for c in range(5):
+        s = np.sign(np.dot(v[:, order[c]], comps[:, c]))
+        np.testing.assert_allclose(s * v[:, order[c]], comps[:, c], atol=1e-9)
+    with pytest.raises(ValueError):
+        oracle.omp_cov_selected(lg, np.array([3, 3], np.uint64), 2)
 
 
 def test_filter_oracle_kat_4x5():
