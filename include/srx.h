@@ -31,8 +31,8 @@
 extern "C" {
 #endif
 
-#define SRX_ABI_VERSION 4      /* 2: srx_matrix_reserve_results, kernel classes 7-9, srx_synth_params.skew; 3: kernel class 10;
-                                  4: srx_comm_info, srx_prof_get_aux */
+#define SRX_ABI_VERSION 5      /* 2: srx_matrix_reserve_results, kernel classes 7-9, srx_synth_params.skew; 3: kernel class 10;
+                                  4: srx_comm_info, srx_prof_get_aux; 5: srx_comm_overlap_info */
 
 typedef struct srx_ctx srx_ctx;   /* one GPU + stream + (optional) RCCL communicator      */
 typedef struct srx_mat srx_mat;   /* device-resident CSR (the `X` of an IMAnnData)        */
@@ -116,6 +116,12 @@ int32_t srx_comm_destroy(srx_ctx* ctx);
  * equal to n_ranks when every rank really takes part.  Any out pointer may be NULL. */
 int32_t srx_comm_info(srx_ctx* ctx, int32_t* kind_out, int32_t* n_ranks_out, int32_t* rccl_version_out,
                       int32_t* ranks_seen_out);
+/* How the Gram solver's one exchange has been run on this context so far: *split_exchanges_out = the number of Gram
+ * matrices whose packed triangle went round the ranks in three pieces, two of them UNDER the second half of the stripe
+ * kernel (the arrangement of a multi-rank RCCL context); *cu_masked_out = 1 when that second half ran on a stream whose
+ * CU mask keeps it off the CUs left to the collective (0: the mask could not be set, or no split exchange yet).
+ * Introspection for tests and the bench line; either pointer may be NULL. */
+int32_t srx_comm_overlap_info(srx_ctx* ctx, int32_t* split_exchanges_out, int32_t* cu_masked_out);
 /* Contiguous nnz-balanced row ranges: cut[r]..cut[r+1] is rank r's rows (cut has
  * n_ranks+1 entries).  Pure host helper, no GPU needed. */
 int32_t srx_partition_rows(const uint64_t* indptr, uint64_t n_rows, int32_t n_ranks,

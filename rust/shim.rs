@@ -311,17 +311,26 @@ use nalgebra_sparse::{CscMatrix, CsrMatrix};
 use ndarray::Array2;
 use single_algebra::svd::SVDImplementation;            // the marker trait of pca_inplace's last argument (dim_red/mod.rs:12)
 
+// One thread-local holds BOTH the context and the resident handle: struct fields drop in declaration order, so the resident
+// matrix (srx_matrix_free) always goes before its context (srx_ctx_destroy) at thread exit, whichever of flush() /
+// invalidate() / a compute call touched the thread-local first.  (Two separate `thread_local!`s are destroyed in reverse
+// order of their FIRST USE: a first call to flush() registered RESIDENT before CTX — use after free at thread exit.)
+struct Tls {
+    resident: RefCell<Option<Resident>>,          // dropped first
+    lazy_writeback: Cell<bool>,
+    ctx: OnceCell<Ctx>,                           // dropped last
+}
 thread_local! {
-    static CTX: OnceCell<Ctx> = const { OnceCell::new() };
+    static TLS: Tls = const { Tls { resident: RefCell::new(None), lazy_writeback: Cell::new(false), ctx: OnceCell::new() } };
 }
 /// The thread's context: device `SRX_DEVICE` (default 0), created on first use.
 fn with_ctx<R>(f: impl FnOnce(&Ctx) -> Result<R>) -> Result<R> {
-    CTX.with(|cell| {
-        if cell.get().is_none() {
+    TLS.with(|t| {
+        if t.ctx.get().is_none() {
             let dev = std::env::var("SRX_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
-            let _ = cell.set(Ctx::new(dev)?);
+            let _ = t.ctx.set(Ctx::new(dev)?);
         }
-        f(cell.get().expect("context"))
+        f(t.ctx.get().expect("context"))
     })
 }
 
@@ -335,40 +344,59 @@ fn with_ctx<R>(f: impl FnOnce(&Ctx) -> Result<R>) -> Result<R> {
 use std::cell::{Cell, RefCell};
 
 struct Resident {
-    key: (usize, usize, usize, usize),          // (identity of the X element, n_obs, n_vars, nnz)
+    key: XKey,
+    x_elem: IMArrayElement,                     // a clone of the X slot's Arc: while the cache holds it the allocation cannot be
+                                                // freed, so its ADDRESS (part of the key) cannot be recycled by another matrix
     dev: DeviceX<'static>,                      // (the context is the thread's own, alive as long as the thread)
     host_stale: bool,                           // the device holds newer values than the IMAnnData
     keep_f32: bool,                             // how the pending write-back treats an F32 matrix (log1p keeps it F32)
 }
-thread_local! {
-    static RESIDENT: RefCell<Option<Resident>> = const { RefCell::new(None) };
-    static LAZY_WRITEBACK: Cell<bool> = const { Cell::new(false) };
-}
-pub fn set_lazy_writeback(on: bool) { LAZY_WRITEBACK.with(|c| c.set(on)) }
-pub fn invalidate() { RESIDENT.with(|r| *r.borrow_mut() = None) }
+pub fn set_lazy_writeback(on: bool) { TLS.with(|t| t.lazy_writeback.set(on)) }
+/// Drops the resident handle: for callers that modify X behind the shim's back (a host-side edit that keeps the shape, the
+/// number of stored entries and the variant is invisible to the key).
+pub fn invalidate() { TLS.with(|t| *t.resident.borrow_mut() = None) }
 
 /// Identity of the X element: the address of the slot's shared allocation (`IMArrayElement(Slot<ArrayData>)`, an
-/// `Arc<RwLock<..>>` — a deep clone has its own) together with the shape and the number of stored entries.
-fn x_key(adata: &IMAnnData) -> (usize, usize, usize, usize) {
+/// `Arc<RwLock<..>>` — a deep clone has its own; the cache keeps a clone of the Arc, so the address stays taken) together
+/// with the shape, the number of stored entries and the VARIANT (storage format + dtype: normalize_total on a host copy
+/// changes it, scale/mod.rs:82).
+type XKey = (usize, usize, usize, usize, u32);
+fn x_key(adata: &IMAnnData) -> XKey {
     let x = adata.x();
-    let nnz = match x.0.read_inner().deref() {
-        ArrayData::CsrMatrix(m) => m.nnz(),
-        ArrayData::CscMatrix(m) => m.nnz(),
-        _ => 0,
+    let (nnz, variant) = match x.0.read_inner().deref() {
+        ArrayData::CsrMatrix(m) => (m.nnz(), 0x100 | dyn_csr_dtype(m)),
+        ArrayData::CscMatrix(m) => (m.nnz(), 0x200 | dyn_csc_dtype(m)),
+        _ => (0, 0),
     };
-    (x.0.as_ptr() as usize, adata.n_obs(), adata.n_vars(), nnz)
+    (x.0.as_ptr() as usize, adata.n_obs(), adata.n_vars(), nnz, variant)
+}
+fn dyn_csr_dtype(m: &DynCsrMatrix) -> u32 {
+    match m {
+        DynCsrMatrix::I8(_) => SRX_I8 as u32, DynCsrMatrix::I16(_) => SRX_I16 as u32, DynCsrMatrix::I32(_) => SRX_I32 as u32,
+        DynCsrMatrix::U8(_) => SRX_U8 as u32, DynCsrMatrix::U16(_) => SRX_U16 as u32, DynCsrMatrix::U32(_) => SRX_U32 as u32,
+        DynCsrMatrix::F32(_) => SRX_F32 as u32, DynCsrMatrix::F64(_) => SRX_F64 as u32, _ => 0xff,
+    }
+}
+fn dyn_csc_dtype(m: &DynCscMatrix) -> u32 {
+    match m {
+        DynCscMatrix::I8(_) => SRX_I8 as u32, DynCscMatrix::I16(_) => SRX_I16 as u32, DynCscMatrix::I32(_) => SRX_I32 as u32,
+        DynCscMatrix::U8(_) => SRX_U8 as u32, DynCscMatrix::U16(_) => SRX_U16 as u32, DynCscMatrix::U32(_) => SRX_U32 as u32,
+        DynCscMatrix::F32(_) => SRX_F32 as u32, DynCscMatrix::F64(_) => SRX_F64 as u32, _ => 0xff,
+    }
 }
 
 /// Runs `f` on the resident handle of `adata`, uploading X first when the cache holds another matrix (or nothing).
+/// `f` must not call back into the shim's free functions: the cache is mutably borrowed while it runs.
 fn with_resident<R>(adata: &IMAnnData, f: impl FnOnce(&mut DeviceX<'static>) -> Result<R>) -> Result<R> {
     with_ctx(|c| {
         let key = x_key(adata);
-        RESIDENT.with(|r| {
-            let mut slot = r.borrow_mut();
+        TLS.with(|t| {
+            let mut slot = t.resident.borrow_mut();
             if slot.as_ref().map_or(true, |s| s.key != key) {
                 // (a stale host copy of ANOTHER matrix cannot be written back from here: lazy mode asks for flush() first)
                 let ctx: &'static Ctx = unsafe { &*(c as *const Ctx) };
-                *slot = Some(Resident { key, dev: DeviceX::upload(ctx, adata)?, host_stale: false, keep_f32: false });
+                *slot = None;                    // the old handle's HBM is free before the new upload asks for its own
+                *slot = Some(Resident { key, x_elem: adata.x(), dev: DeviceX::upload(ctx, adata)?, host_stale: false, keep_f32: false });
             }
             f(&mut slot.as_mut().expect("resident").dev)
         })
@@ -376,28 +404,45 @@ fn with_resident<R>(adata: &IMAnnData, f: impl FnOnce(&mut DeviceX<'static>) -> 
 }
 /// After an in-place operation on the resident handle: copy back now, or remember that the host copy is stale.
 fn after_inplace(adata: &mut IMAnnData, keep_f32: bool) -> Result<()> {
-    if LAZY_WRITEBACK.with(|c| c.get()) {
-        RESIDENT.with(|r| if let Some(s) = r.borrow_mut().as_mut() { s.host_stale = true; s.keep_f32 = keep_f32; });
+    if TLS.with(|t| t.lazy_writeback.get()) {
+        // keep_f32 may only go from true to false while a write-back is pending: normalize_total (-> F64, scale/mod.rs:74-83)
+        // followed by log1p on an F32 matrix must come back as F64 with f64 values, as in the reference
+        TLS.with(|t| if let Some(s) = t.resident.borrow_mut().as_mut() {
+            s.keep_f32 = if s.host_stale { s.keep_f32 && keep_f32 } else { keep_f32 };
+            s.host_stale = true;
+        });
         return Ok(());
     }
-    RESIDENT.with(|r| write_back(adata, &r.borrow().as_ref().expect("resident").dev, keep_f32))
+    TLS.with(|t| write_back(adata, &t.resident.borrow().as_ref().expect("resident").dev, keep_f32))?;
+    rekey(adata);
+    Ok(())
+}
+/// The write-back may have replaced the variant (-> F64): the cached key follows the element it belongs to.
+fn rekey(adata: &IMAnnData) {
+    TLS.with(|t| if let Some(s) = t.resident.borrow_mut().as_mut() { s.key = x_key(adata); });
+}
+/// Is a lazy write-back of THIS matrix pending?
+fn host_is_stale(adata: &IMAnnData) -> bool {
+    TLS.with(|t| t.resident.borrow().as_ref().map_or(false, |s| {
+        s.host_stale && s.key.0 == adata.x().0.as_ptr() as usize
+    }))
 }
 /// Brings the IMAnnData up to date with the device (lazy write-back only; a no-op otherwise).
 pub fn flush(adata: &mut IMAnnData) -> Result<()> {
-    let pending = RESIDENT.with(|r| r.borrow().as_ref().map_or(false, |s| s.host_stale && s.key == x_key(adata)));
-    if !pending { return Ok(()); }
-    RESIDENT.with(|r| {
-        let mut slot = r.borrow_mut();
+    if !host_is_stale(adata) { return Ok(()); }
+    TLS.with(|t| {
+        let mut slot = t.resident.borrow_mut();
         let s = slot.as_mut().expect("resident");
         write_back(adata, &s.dev, s.keep_f32)?;
         s.host_stale = false;
+        s.keep_f32 = false;
         s.key = x_key(adata);                    // (the variant change keeps the element, its nnz and its shape)
         Ok(())
     })
 }
 /// The device-side result of a filter becomes the resident handle of the IMAnnData that holds the same subset.
 fn adopt(adata: &IMAnnData, dev: DeviceX<'static>) {
-    RESIDENT.with(|r| *r.borrow_mut() = Some(Resident { key: x_key(adata), dev, host_stale: false, keep_f32: false }));
+    TLS.with(|t| *t.resident.borrow_mut() = Some(Resident { key: x_key(adata), x_elem: adata.x(), dev, host_stale: false, keep_f32: false }));
 }
 
 pub mod statistics_free {
@@ -504,6 +549,8 @@ pub mod processing_free {
         let mut new_data = adata.deep_clone();              // :319, as in the reference
         normalize_total_inplace(&mut new_data, target_sum, direction)?;
         flush(&mut new_data)?;                              // a returned copy is always current
+        // (the resident handle now belongs to `new_data` and holds its Arc: if the caller drops the result, the next
+        //  deep_clone cannot reuse the address, and a later call on `adata` uploads `adata` again)
         Ok(new_data)
     }
     pub fn log1p_transform_inplace(adata: &mut IMAnnData) -> anyhow::Result<()> {
@@ -534,6 +581,11 @@ pub mod processing_free {
         Ok(())
     }
     pub fn filter_cells(adata: &IMAnnData, lower_lim: FlexValue, upper_lim: FlexValue) -> anyhow::Result<IMAnnData> {
+        // `subset` copies the HOST X: with a lazy write-back pending it would copy pre-transform values that no later flush
+        // repairs (the copy gets a current device handle) — and a `&IMAnnData` cannot be flushed from here
+        if host_is_stale(adata) {
+            bail!("filter_cells: a lazy write-back of X is pending — call flush(adata) first (or use filter_cells_inplace)");
+        }
         let (filtered, keep) = with_resident(adata, |x| x.filter_cells(&lower_lim, &upper_lim))?;
         let mask = Array1::from_vec(keep);
         let selection = crate::shared::processing::get_select_info_obs(Some(mask.view()))?;
@@ -553,6 +605,11 @@ pub mod processing_free {
         Ok(())
     }
     pub fn filter_genes(adata: &IMAnnData, lower_lim: FlexValue, upper_lim: FlexValue) -> anyhow::Result<IMAnnData> {
+        // `subset` copies the HOST X: with a lazy write-back pending it would copy pre-transform values that no later flush
+        // repairs (the copy gets a current device handle) — and a `&IMAnnData` cannot be flushed from here
+        if host_is_stale(adata) {
+            bail!("filter_genes: a lazy write-back of X is pending — call flush(adata) first (or use filter_genes_inplace)");
+        }
         let (filtered, keep) = with_resident(adata, |x| x.filter_genes(&lower_lim, &upper_lim))?;
         let mask = Array1::from_vec(keep);
         let selection = crate::shared::processing::get_select_info_vars(Some(mask.view()))?;
@@ -572,15 +629,20 @@ pub mod processing_free {
                                                  feature_selection: &FeatureSelection, _svd_mode: S) -> anyhow::Result<()> {
             // HighlyVariableCol / Randomized / VarianceThreshold: the reference's own host code makes the index list
             // (dim_red/mod.rs:125-134,141-153); HighlyVariable(n) and None go to the device
-            let (scores, evr, selected, n_pc) = with_resident(anndata, |x| {
-                match feature_selection {
-                    FeatureSelection::HighlyVariable(_) | FeatureSelection::None => x.pca(n_components, center, scale, n_threads, feature_selection),
-                    other => {
-                        let sel: Vec<u64> = crate::memory::processing::dim_red::select_features(anndata, other)?
-                            .into_iter().map(|i| i as u64).collect();
-                        x.pca_with_selection(n_components, center, scale, Some(sel))
-                    }
+            // (the host-side selection runs BEFORE the resident handle is borrowed: for VarianceThreshold the reference's
+            //  select_features calls statistics::compute_variance, whose body is statistics_free::compute_variance here —
+            //  it takes the resident handle itself — and the host code must see current values: flush first)
+            let host_selection: Option<Vec<u64>> = match feature_selection {
+                FeatureSelection::HighlyVariable(_) | FeatureSelection::None => None,
+                other => {
+                    flush(anndata)?;
+                    Some(crate::memory::processing::dim_red::select_features(anndata, other)?
+                        .into_iter().map(|i| i as u64).collect())
                 }
+            };
+            let (scores, evr, selected, n_pc) = with_resident(anndata, |x| match host_selection {
+                None => x.pca(n_components, center, scale, n_threads, feature_selection),
+                Some(sel) => x.pca_with_selection(n_components, center, scale, Some(sel)),
             })?;
             let transformed = Array2::from_shape_vec((anndata.n_obs(), n_pc), scores)?;      // N x n_pc row-major, as pca.transform returns
             attach_pca_results(anndata, transformed, None, Some(evr), selected, n_pc)

@@ -91,6 +91,7 @@ _SIGS = {
     "srx_comm_init_host": (C.c_int32, [P, C.c_int32, C.c_int32, C.c_void_p, P]),
     "srx_comm_destroy": (C.c_int32, [P]),
     "srx_comm_info": (C.c_int32, [P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "srx_comm_overlap_info": (C.c_int32, [P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "srx_partition_rows": (C.c_int32, [P, C.c_uint64, C.c_int32, P]),
     "srx_matrix_upload": (C.c_int32, [P, C.POINTER(Csr), C.c_int32, C.POINTER(P)]),
     "srx_matrix_upload_csc": (C.c_int32, [P, C.POINTER(Csr), C.c_int32, C.POINTER(P)]),

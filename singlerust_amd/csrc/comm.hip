@@ -157,6 +157,13 @@ int32_t srx_comm_info(srx_ctx* ctx, int32_t* kind_out, int32_t* n_ranks_out, int
     return SRX_OK;
 }
 
+int32_t srx_comm_overlap_info(srx_ctx* ctx, int32_t* split_exchanges_out, int32_t* cu_masked_out) {
+    if (!ctx) return fail(nullptr, SRX_E_ARG, "null ctx");
+    if (split_exchanges_out) *split_exchanges_out = (int32_t)ctx->gram_splits;
+    if (cu_masked_out) *cu_masked_out = (ctx->gram_splits > 0 && ctx->gram_stream_masked) ? 1 : 0;
+    return SRX_OK;
+}
+
 int32_t srx_comm_destroy(srx_ctx* ctx) {
     if (!ctx) return fail(nullptr, SRX_E_ARG, "null ctx");
     ctx->host_allreduce = nullptr;

@@ -149,6 +149,7 @@ static int32_t prof_drain(srx_ctx* ctx) {
     SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->side_stream) SRX_HIP(ctx, hipStreamSynchronize(ctx->side_stream));
     if (ctx->comm_stream) SRX_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
+    if (ctx->gram_stream) SRX_HIP(ctx, hipStreamSynchronize(ctx->gram_stream));
     for (int c = 0; c < SRX_K_COUNT_; ++c) {
         for (auto& pr : ctx->prof[c].pending) {
             float ms = 0.f;
@@ -592,6 +593,9 @@ void srx_ctx_destroy(srx_ctx* ctx) {
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     if (ctx->comm_fork) (void)hipEventDestroy(ctx->comm_fork);
     if (ctx->comm_join) (void)hipEventDestroy(ctx->comm_join);
+    if (ctx->gram_stream) (void)hipStreamDestroy(ctx->gram_stream);
+    if (ctx->gram_fork) (void)hipEventDestroy(ctx->gram_fork);
+    if (ctx->gram_join) (void)hipEventDestroy(ctx->gram_join);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -823,9 +827,15 @@ int32_t srx_matrix_copy_values(srx_mat* dst, const srx_mat* src) {
         // a SRX_STORE_AUTO work copy that normalize_total / log1p / srx_pipeline promoted to f64 being restored from its
         // pristine f32 source (or the other way round): the value buffer follows the source's storage again
         if (!dst->store_auto) return fail(ctx, SRX_E_ARG, "copy_values: storage mismatch (explicit storage on the destination)");
+        // (an allocation, a stream drain and a free per call: steady-state loops that restore a work copy every step should
+        //  create it with an explicit SRX_STORE_F32 / SRX_STORE_F64 — then this branch is never taken)
         void* d_new = nullptr;
         SRX_HIP(ctx, hipMalloc(&d_new, (src->nnz + 16) * val_bytes(src)));
-        SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const hipError_t es = hipStreamSynchronize(ctx->stream);
+        if (es != hipSuccess) {
+            (void)hipFree(d_new);
+            return fail(ctx, SRX_E_HIP, "copy_values: %s", hipGetErrorString(es));
+        }
         (void)hipFree(dst->d_values);
         dst->d_values = d_new;
         dst->store = src->store;

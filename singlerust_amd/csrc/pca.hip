@@ -718,6 +718,7 @@ static int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* r
         SRX_HIP(ctx, hipEventRecord(ctx->comm_join, ctx->comm_stream));
         SRX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->comm_join, 0));
         *reduce = true;
+        ctx->gram_splits++;
         return SRX_OK;
     }
     launch(0, g.n_wg, ctx->stream);

@@ -32,6 +32,13 @@ def main():
         comm.comm_init(1, 0, sr.Context.comm_unique_id())
         s1, c1, e1 = run(comm)
         assert col_err(s1, s0) < 1e-6 and col_err(c1, c0) < 1e-6, (col_err(s1, s0), col_err(c1, c0))
+        # the exchange really went the split way, its second half on the CU-masked stream (srx_comm_overlap_info); the plain
+        # context never splits
+        splits, masked = C.c_int32(-1), C.c_int32(-1)
+        _ffi.check(lib.srx_comm_overlap_info(comm.handle, C.byref(splits), C.byref(masked)), comm.handle)
+        assert splits.value >= 1 and masked.value == 1, (splits.value, masked.value)
+        _ffi.check(lib.srx_comm_overlap_info(plain.handle, C.byref(splits), C.byref(masked)), plain.handle)
+        assert splits.value == 0 and masked.value == 0
         assert np.allclose(e1, e0, rtol=1e-9)
         _ffi.check(lib.srx_comm_destroy(comm.handle), comm.handle)
         comm.close()
