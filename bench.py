@@ -19,7 +19,7 @@ timed region): the f64-storage pipeline (`f64_storage`), the matrix-free solver'
 a skewed-gene matrix (`skewed_genes`), a hard spectrum (`hard_spectrum`), the rate including the upload of a host CSR
 and the download of the scores (`incl_h2d`), the pipeline on a fresh un-prepared handle (`cold_step`), configs[4] streamed
 from pinned host memory through the backed session (`c5_backed`), and three CPU baselines timed on this box (`cpu_baseline`:
-the OpenMP restatement on <= 64 threads; `cpu_baseline_reference_faithful`: serial loops + full SVD on a sample;
+the OpenMP restatement over the WHOLE matrix on every physical core; `cpu_baseline_reference_faithful`: serial loops + full SVD on a sample;
 `cpu_baseline_c1_serial`: BASELINE.md's C1 whole on one thread).  `python bench.py --gpus N` with N > 1 and no launcher
 environment starts its own N ranks (one per GPU).
 """
@@ -97,8 +97,8 @@ def parse():
     ap.add_argument("--lean", action="store_true", help="only the headline measurement (no extra blocks, no CPU baselines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=24000, help="reference-faithful CPU baseline: cells of the sample")
-    ap.add_argument("--host-sample-cells", type=int, default=100_000,
-                    help="cells of the host-side sample (incl_h2d block, threaded CPU baseline)")
+    ap.add_argument("--host-sample-cells", type=int, default=0,
+                    help="cells of the host-side legs (incl_h2d blocks, threaded CPU baseline); 0 = the whole configuration")
     ap.add_argument("--max-copies-gb", type=float, default=180.0)
     return ap.parse_args()
 
@@ -412,33 +412,79 @@ def cold_step(B, config, n_global, storage, reps=3):
                     "repeated steps on prepared clones (pattern-only structures and result block amortised)"}
 
 
-def host_sample(B, config, n_cells):
-    """First n_cells rows of the synthetic matrix in the REFERENCE layout on the host (u64 offsets / indices, f32 values)."""
-    import numpy as np
-    F, lib = B.F, B.lib
-    cells, genes, _, _ = CONFIGS[config]
-    p = B.params(config, B.a.cells or cells)
-    ip = np.zeros(n_cells + 1, dtype=np.uint64)
-    lib.srx_synth_indptr(C.byref(p), 0, n_cells, F.ptr(ip))
-    idx = np.zeros(int(ip[-1]), np.uint64)
-    val = np.zeros(int(ip[-1]), np.float32)
-    lib.srx_synth_fill_host(C.byref(p), 0, n_cells, F.ptr(ip), F.ptr(idx), F.ptr(val))
-    return ip, idx, val, genes
+class HostMatrix:
+    """The first `n_cells` rows of the synthetic matrix in the REFERENCE layout on the host (u64 offsets / indices, f32 values),
+    filled by a thread pool; the two big arrays in PINNED memory (hipHostMalloc) when `pinned` — what a caller gets who allocates
+    X for the device — or in plain numpy arrays (pageable: what a Rust Vec is)."""
+
+    def __init__(self, B, config, n_cells, pinned=True):
+        import concurrent.futures as cf
+        import numpy as np
+        F, lib = B.F, B.lib
+        cells, self.genes, _, _ = CONFIGS[config]
+        p = B.params(config, B.a.cells or cells)
+        self.n = n_cells
+        t0 = time.perf_counter()
+        self.ip = np.zeros(n_cells + 1, dtype=np.uint64)
+        lib.srx_synth_indptr(C.byref(p), 0, n_cells, F.ptr(self.ip))
+        nnz = int(self.ip[-1])
+        self._hip, self._raw = None, []
+        self.pinned = False
+        if pinned:
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+            hip.hipHostFree.argtypes = [C.c_void_p]
+            hidx, hval = C.c_void_p(), C.c_void_p()
+            if hip.hipHostMalloc(C.byref(hidx), max(nnz, 1) * 8, 0) == 0:
+                if hip.hipHostMalloc(C.byref(hval), max(nnz, 1) * 4, 0) == 0:
+                    self._hip, self._raw, self.pinned = hip, [hidx, hval], True
+                    self.idx = np.ctypeslib.as_array(C.cast(hidx, C.POINTER(C.c_uint64)), shape=(nnz,))
+                    self.val = np.ctypeslib.as_array(C.cast(hval, C.POINTER(C.c_float)), shape=(nnz,))
+                else:
+                    hip.hipHostFree(hidx)
+        if not self.pinned:
+            self.idx, self.val = np.zeros(nnz, np.uint64), np.zeros(nnz, np.float32)
+        tile = 20_000
+        ip, idx, val = self.ip, self.idx, self.val
+
+        def fill(r0):
+            r1 = min(n_cells, r0 + tile)
+            e0, e1 = int(ip[r0]), int(ip[r1])
+            sub = (ip[r0:r1 + 1] - ip[r0]).astype(np.uint64)
+            lib.srx_synth_fill_host(C.byref(p), r0, r1, F.ptr(sub), F.ptr(idx[e0:e1]), F.ptr(val[e0:e1]))
+        with cf.ThreadPoolExecutor(max_workers=max(1, min(usable_cores(), 64))) as ex:
+            list(ex.map(fill, range(0, n_cells, tile)))
+        self.generate_s = time.perf_counter() - t0
+        self.host_bytes = self.ip.nbytes + self.idx.nbytes + self.val.nbytes
+
+    def head(self, n):
+        """(ip, idx, val) of the first n cells: views, no copy."""
+        n = min(n, self.n)
+        e = int(self.ip[n])
+        return self.ip[:n + 1], self.idx[:e], self.val[:e]
+
+    def free(self):
+        self.idx = self.val = None
+        if self._hip is not None:
+            for h in self._raw:
+                self._hip.hipHostFree(h)
+            self._hip, self._raw = None, []
 
 
-def incl_h2d(B, ip, idx, val, genes):
-    """The rate a caller sees who hands over HOST buffers for every pipeline: upload of the reference-layout CSR (u64
-    indices narrowed on the way), the pipeline, download of the f64 scores."""
+def incl_h2d(B, H, what):
+    """SURVEY.md 8(d)'s second form of the metric: cells/s INCLUDING the H2D of the CSR and the D2H of the results — the rate
+    a caller sees who hands over HOST buffers for every pipeline: upload of the reference-layout CSR (u64 indices narrowed on
+    the host side of the link by the H2D workers), the pipeline on the fresh handle, download of the f64 scores."""
     import numpy as np
     a, F, sr, lib, ctx = B.a, B.F, B.sr, B.lib, B.ctx
-    n = len(ip) - 1
+    n, ip, idx, val = H.n, H.ip, H.idx, H.val
     opts = F.PcaOpts(a.npc, -1, -1, -1, 0, 0, 0, 0.0, 12345)
     res = F.PipelineResult()
     scores = np.zeros((n, a.npc))
     best = None
-    for _ in range(3):
+    for _ in range(2 if n > 500_000 else 3):
         t0 = time.perf_counter()
-        m = sr.DeviceCsr.upload(ctx, n, genes, ip, idx, val, F.STORE_F32)
+        m = sr.DeviceCsr.upload(ctx, n, H.genes, ip, idx, val, F.STORE_F32)
         ctx.synchronize()
         t1 = time.perf_counter()
         F.check(lib.srx_pipeline(m.handle, a.target_sum, a.hvg, C.byref(opts), C.byref(res)), ctx.handle)
@@ -450,14 +496,15 @@ def incl_h2d(B, ip, idx, val, genes):
         cur = (t3 - t0, t1 - t0, t2 - t1, t3 - t2)
         if best is None or cur[0] < best[0]:
             best = cur
-    host_bytes = ip.nbytes + idx.nbytes + val.nbytes
-    return {"cells": n, "host_bytes": host_bytes, "upload_s": best[1], "pipeline_s": best[2], "d2h_scores_s": best[3],
-            "value": n / best[0], "unit": "cells/s", "upload_GBps_of_host_bytes": host_bytes / best[1] / 1e9,
-            "note": "best of 3: srx_matrix_upload of the reference-layout host CSR (u64 offsets / indices, f32 values; pageable "
-                    "memory, 8 H2D workers) + srx_pipeline (first call on the handle: it also builds the pattern-only "
-                    "structures and allocates the result block) + srx_result_fetch of the f64 scores; the upload dominates — "
-                    "the drop-in uploads once and runs the whole path on the handle, a matrix larger than HBM goes through "
-                    "the backed session (--backed)"}
+    return {"cells": n, "host_bytes": H.host_bytes, "host_memory": "pinned (hipHostMalloc)" if H.pinned else "pageable",
+            "upload_s": best[1], "pipeline_s": best[2], "d2h_scores_s": best[3], "total_s": best[0],
+            "value": n / best[0], "unit": "cells/s", "upload_GBps_of_host_bytes": H.host_bytes / best[1] / 1e9,
+            "d2h_GBps": scores.nbytes / best[3] / 1e9,
+            "note": f"{what}: srx_matrix_upload of the reference-layout host CSR (u64 offsets / indices, f32 values: "
+                    f"{H.host_bytes / 1e9:.1f} GB; the H2D workers narrow the indices on the host side of the link) + srx_pipeline "
+                    "(first call on the handle: it also builds the pattern-only structures and allocates the result block) + "
+                    "srx_result_fetch of the f64 scores; best of the runs.  The upload dominates — the drop-in uploads once and "
+                    "runs the whole path on the handle; a matrix larger than HBM goes through the backed session (--backed)"}
 
 
 def _blas_limit(n):
@@ -470,9 +517,32 @@ def _blas_limit(n):
         return contextlib.nullcontext()
 
 
-def cpu_baselines(B, ip, idx, val, genes):
+def physical_cores():
+    """Physical cores this process may run on (unique (socket, core) pairs of /proc/cpuinfo among the affinity set)."""
+    try:
+        allowed = os.sched_getaffinity(0)
+        seen, cpu, phys, core = set(), None, None, None
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("processor"):
+                    cpu = int(line.split(":")[1])
+                elif line.startswith("physical id"):
+                    phys = int(line.split(":")[1])
+                elif line.startswith("core id"):
+                    core = int(line.split(":")[1])
+                elif not line.strip():
+                    if cpu in allowed and phys is not None and core is not None:
+                        seen.add((phys, core))
+                    cpu = phys = core = None
+        return len(seen) or usable_cores()
+    except Exception:       # noqa: BLE001
+        return usable_cores()
+
+
+def cpu_baselines(B, H):
     """Three CPU legs on this box's host cores (oracle/ = the checker, here as the thing timed):
-    cpu_baseline                     — OpenMP restatement on <= 64 threads over the 100k-cell host sample (SURVEY.md 8(d) ii);
+    cpu_baseline                     — the OpenMP restatement over the WHOLE host matrix `H` (the metric's configuration at full
+                                       size by default) on every physical core (SURVEY.md 8(d) ii, BASELINE.md section 3 row C3);
     cpu_baseline_reference_faithful  — the reference's own algorithm (serial loops, densify, full SVD) on a 24k-cell sample,
                                        BLAS pinned to <= 64 threads, extrapolated linearly in cells (said so);
     cpu_baseline_c1_serial           — BASELINE.md section 3's C1 (2.7k x 32k, 7 %) whole, one thread."""
@@ -482,37 +552,41 @@ def cpu_baselines(B, ip, idx, val, genes):
     a = B.a
     oracle.lib()
     out = {}
-    model, cores = cpu_model(), usable_cores()
-    threads = max(1, min(cores, 64))
+    model, cores, phys = cpu_model(), usable_cores(), physical_cores()
+    env_threads = int(os.environ.get("SRX_BENCH_CPU_THREADS", "0"))
+    threads = max(1, env_threads or min(cores, phys))
+    ip, idx, val, genes = H.ip, H.idx, H.val, H.genes
     # (ii) threaded: OpenMP over every loop + k x k covariance and a symmetric eigen-solve instead of the full SVD
-    n2 = len(ip) - 1
+    n2 = H.n
     m2 = oracle.Csr(n2, genes, ip, idx, val)
     t0 = time.perf_counter()
     vals, hv, order, cov, mean, sd, secs = oracle.omp_pipeline(m2, a.target_sum, a.hvg, threads)
     t1 = time.perf_counter()
     import scipy.linalg as sla
-    import scipy.sparse as sp
     k = cov.shape[0]
-    with _blas_limit(threads):
+    with _blas_limit(min(threads, 64)):
         w, v = sla.eigh(cov, subset_by_index=[max(0, k - a.npc), k - 1])
-        t2 = time.perf_counter()
-        # scores = Z V for the sample: sparse x dense through scipy (threaded BLAS does not apply; counted as is)
-        x = sp.csr_matrix((vals, idx.astype(np.int64), ip.astype(np.int64)), shape=(n2, genes))[:, order.astype(np.int64)]
-        pv = v / sd[:, None]
-        _ = x @ pv - (mean / sd) @ v
+    t2 = time.perf_counter()
+    # scores = Z V over every cell (OpenMP, omp_baseline.c::orc_omp_scores)
+    oracle.omp_scores(m2, vals, order, v / sd[:, None], (mean / sd) @ v, threads)
     t3 = time.perf_counter()
+    del vals
     out["cpu_baseline"] = {
         "value": n2 / (t3 - t0), "unit": "cells/s", "cores": threads, "kind": "port", "cpu_model": model, "host_cores": cores,
-        "sample": f"first {n2} cells of the same synthetic matrix ({len(val)} nnz), timed whole: oracle/omp_baseline.c on {threads} "
-                  f"OpenMP threads — normalise + log1p {secs[0]:.2f} s, moments + HVG {secs[1]:.2f} s, k x k Gram {secs[2]:.2f} s — "
-                  f"then LAPACK eigh of the {k} x {k} covariance (top {a.npc}, <= {threads} BLAS threads) {t2 - t1:.2f} s and the "
-                  f"scores {t3 - t2:.2f} s; SURVEY.md 8(d) variant (ii): a restatement, algorithmically cheaper than the "
-                  "reference's full SVD, i.e. a baseline that favours the CPU",
+        "host_physical_cores": phys,
+        "sample": f"{'the WHOLE matrix' if n2 >= (B.a.cells or CONFIGS[B.a.config][0]) else 'the first ' + str(n2) + ' cells'} "
+                  f"({n2} cells, {len(val)} nnz), timed whole: oracle/omp_baseline.c on {threads} OpenMP threads — normalise + log1p "
+                  f"{secs[0]:.2f} s, moments + HVG {secs[1]:.2f} s, k x k Gram {secs[2]:.2f} s — then LAPACK eigh of the {k} x {k} "
+                  f"covariance (top {a.npc}, <= {min(threads, 64)} BLAS threads) {t2 - t1:.2f} s and the scores of every cell (OpenMP) "
+                  f"{t3 - t2:.2f} s; SURVEY.md 8(d) variant (ii): a restatement, algorithmically cheaper than the reference's full "
+                  "SVD, i.e. a baseline that favours the CPU",
         "seconds": t3 - t0}
+    ip, idx, val = H.head(a.cpu_sample_cells)
     # (i) reference-faithful: the serial loops + densify + full-SVD PCA (numpy / LAPACK) on a bounded sample
     n1 = min(a.cpu_sample_cells, len(ip) - 1)
     e1 = int(ip[n1])
     m1 = oracle.Csr(n1, genes, ip[:n1 + 1], idx[:e1], val[:e1])
+    threads = min(threads, 64)
     with _blas_limit(threads):
         t0 = time.perf_counter()
         lg = oracle.log1p_transform(oracle.normalize_total(m1, a.target_sum, oracle.ROW))
@@ -797,17 +871,35 @@ def main():
         attempt("hard_spectrum", f_hard)
 
         if not a.no_cpu_baseline:
+            # the host-side legs at the metric's configuration in FULL (--host-sample-cells 0, the default): the whole matrix
+            # in the reference layout on the host — H2D-inclusive rate from pinned and from pageable caller buffers, the
+            # threaded CPU baseline over every cell
+            H = None
             try:
-                ns = min(a.host_sample_cells, n_global)
-                hs = host_sample(B, a.config, ns)
-                attempt("incl_h2d", lambda: incl_h2d(B, *hs))
+                ns = min(a.host_sample_cells or n_global, n_global)
+                H = HostMatrix(B, a.config, ns, pinned=True)
+                full = "the whole matrix" if ns == n_global else f"the first {ns} cells"
+                attempt("incl_h2d", lambda: incl_h2d(B, H, f"{full}, caller buffers in pinned host memory"))
+                if H.pinned and not os.environ.get("SRX_BENCH_NO_PAGEABLE"):
+                    def f_pageable():
+                        import numpy as np
+                        Hp = HostMatrix.__new__(HostMatrix)
+                        Hp.n, Hp.genes, Hp.ip, Hp.pinned, Hp.host_bytes = H.n, H.genes, H.ip, False, H.host_bytes
+                        Hp.idx, Hp.val = np.array(H.idx), np.array(H.val)          # plain (pageable) copies: a Rust Vec
+                        r = incl_h2d(B, Hp, f"{full}, caller buffers in PAGEABLE host memory")
+                        del Hp
+                        return r
+                    attempt("incl_h2d_pageable", f_pageable)
                 try:
-                    extra.update(cpu_baselines(B, *hs))
+                    extra.update(cpu_baselines(B, H))
                 except Exception as e:      # the baseline is a reported number, never a reason to lose the GPU line
                     extra["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": usable_cores(), "kind": "port",
                                              "sample": f"failed: {e!r}"}
             except Exception as e:
                 extra["incl_h2d"] = {"failed": repr(e)}
+            finally:
+                if H is not None:
+                    H.free()
 
         if a.config == "c3" and not a.cells and not os.environ.get("SRX_BENCH_NO_C5"):
             def f_c5():
@@ -849,6 +941,15 @@ def main():
                 # the ~80 small launches of the subspace iteration are replayed from captured hipGraphs (three
                 # segments per solve); they are bracketed as ONE class (`iterate`)
                 "pca_iteration_hip_graphs": main_["solver"] == "gram" and not os.environ.get("SRX_NO_GRAPH"),
+                # the side measurements of this run that belong beside `value` (full blocks further down the line)
+                "cold_step_ms": (extra.get("cold_step") or {}).get("ms"),
+                "prepare_ms": (extra.get("cold_step") or {}).get("prepare_ms"),
+                "f64_storage_ms_per_step": (extra.get("f64_storage") or {}).get("ms_per_step"),
+                "incl_h2d_cells_per_s": (extra.get("incl_h2d") or {}).get("value"),
+                "incl_h2d_cells": (extra.get("incl_h2d") or {}).get("cells"),
+                "incl_h2d_pageable_cells_per_s": (extra.get("incl_h2d_pageable") or {}).get("value"),
+                "cpu_baseline_cells_per_s": (extra.get("cpu_baseline") or {}).get("value"),
+                "cpu_baseline_threads": (extra.get("cpu_baseline") or {}).get("cores"),
             },
             # the kernel class with the largest share of the step (live HIP-event timing on the stream it runs on)
             "roofline": roof(dom, KERNEL_SYMBOL.get(dom_name, dom_name), ROOF_NOTE.get(dom_name, "")),

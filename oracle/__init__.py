@@ -93,6 +93,30 @@ def omp_cov_selected(m, sel, n_threads: int):
     return cov, mean, sd
 
 
+def omp_scores(m, values_f64, order, pv, cvec, n_threads: int):
+    """scores = Z V over all rows on `n_threads` OpenMP threads (omp_baseline.c::orc_omp_scores): `order` = the selected
+    features (slot i = feature order[i]), pv = V / sd[:, None] (k x n_pc), cvec = (mean / sd) @ V."""
+    build()
+    lo = ctypes.CDLL(_OMP_PATH)
+    order = np.ascontiguousarray(order, dtype=np.uint64)
+    pv = np.ascontiguousarray(pv, dtype=np.float64)
+    cvec = np.ascontiguousarray(cvec, dtype=np.float64)
+    k, n_pc = pv.shape
+    ip = np.ascontiguousarray(m.indptr, dtype=np.uint64)
+    ix = np.ascontiguousarray(m.indices, dtype=np.uint64)
+    vals = np.ascontiguousarray(values_f64, dtype=np.float64)
+    scores = np.empty((m.n_rows, n_pc))
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lo.orc_omp_scores.restype = ctypes.c_int
+    lo.orc_omp_scores.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                  ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
+                                  ctypes.c_int, ctypes.c_void_p]
+    if lo.orc_omp_scores(m.n_rows, m.n_cols, vp(ip), vp(ix), vp(vals), vp(order), k, vp(pv), vp(cvec), n_pc, n_threads,
+                         vp(scores)) != 0:
+        raise MemoryError("orc_omp_scores: out of memory")
+    return scores
+
+
 class _Csr(ctypes.Structure):
     _fields_ = [
         ("n_rows", ctypes.c_uint64), ("n_cols", ctypes.c_uint64), ("nnz", ctypes.c_uint64),

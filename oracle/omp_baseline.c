@@ -200,3 +200,31 @@ int orc_omp_cov_selected(uint64_t n_rows, uint64_t n_cols, const uint64_t* indpt
     free(remap); free(gpart); free(spart);
     return 0;
 }
+
+/* scores = Z V for every row (pca/mod.rs:156-185) from the transformed f64 values: slot(c) = remap of the selected features
+ * (`order[k]`: slot i = feature order[i]), pv[k * n_pc] = V scaled by 1 / sd (row i = slot i), cvec[n_pc] = (mean / sd) V.
+ * OpenMP over rows; the last leg of the threaded baseline at full size (scipy's sparse product is single-threaded). */
+int orc_omp_scores(uint64_t n_rows, uint64_t n_cols, const uint64_t* indptr, const uint64_t* indices, const double* values,
+                   const uint64_t* order, uint64_t k, const double* pv, const double* cvec, uint64_t n_pc, int n_threads,
+                   double* scores) {
+    if (n_threads < 1) n_threads = 1;
+    omp_set_num_threads(n_threads);
+    int32_t* remap = malloc(n_cols * sizeof *remap);
+    if (!remap) return -1;
+    for (uint64_t j = 0; j < n_cols; ++j) remap[j] = -1;
+    for (uint64_t i = 0; i < k; ++i) remap[order[i]] = (int32_t)i;
+#pragma omp parallel for schedule(dynamic, 256)
+    for (uint64_t r = 0; r < n_rows; ++r) {
+        double* out = scores + r * n_pc;
+        for (uint64_t c = 0; c < n_pc; ++c) out[c] = -cvec[c];
+        for (uint64_t p = indptr[r]; p < indptr[r + 1]; ++p) {
+            const int32_t s = remap[indices[p]];
+            if (s < 0) continue;
+            const double v = values[p];
+            const double* row = pv + (size_t)s * n_pc;
+            for (uint64_t c = 0; c < n_pc; ++c) out[c] += v * row[c];
+        }
+    }
+    free(remap);
+    return 0;
+}
