@@ -224,6 +224,7 @@ int32_t scratch(srx_ctx* ctx, const char* name, size_t bytes, void** out);
 int32_t pinned(srx_ctx* ctx, size_t bytes, void** out);
 int32_t d2h(srx_ctx* ctx, void* host, const void* dev, size_t bytes);   // via pinned, synchronises
 int32_t h2d(srx_ctx* ctx, void* dev, const void* host, size_t bytes);
+int32_t d2h_rows(srx_ctx* ctx, void* host, const void* dev, uint64_t rows, size_t width, size_t dev_pitch);   // strided rows -> dense
 
 // ---- profiling -------------------------------------------------------------------------------
 struct ProfScope {

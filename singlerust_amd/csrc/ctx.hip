@@ -65,6 +65,24 @@ int32_t d2h(srx_ctx* ctx, void* host, const void* dev, size_t bytes) {
     return SRX_OK;
 }
 
+// `rows` rows of `width` bytes, `dev_pitch` bytes apart on the device, to a dense host matrix
+int32_t d2h_rows(srx_ctx* ctx, void* host, const void* dev, uint64_t rows, size_t width, size_t dev_pitch) {
+    if (dev_pitch == width) return d2h(ctx, host, dev, rows * width);
+    if (rows == 0 || width == 0) return SRX_OK;
+    // strided DMA into the pinned staging buffer (64 MiB pieces), dense memcpy out of it
+    const uint64_t per = std::max<uint64_t>(1, (64u << 20) / width);
+    void* p;
+    SRX_TRY(pinned(ctx, (size_t)std::min<uint64_t>(per, rows) * width, &p));
+    for (uint64_t r0 = 0; r0 < rows; r0 += per) {
+        const uint64_t nr = std::min<uint64_t>(per, rows - r0);
+        SRX_HIP(ctx, hipMemcpy2DAsync(p, width, static_cast<const char*>(dev) + r0 * dev_pitch, dev_pitch, width, nr,
+                                      hipMemcpyDeviceToHost, ctx->stream));
+        SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(static_cast<char*>(host) + r0 * width, p, nr * width);
+    }
+    return SRX_OK;
+}
+
 int32_t h2d(srx_ctx* ctx, void* dev, const void* host, size_t bytes) {
     if (bytes == 0) return SRX_OK;
     if (bytes <= (64u << 20)) {

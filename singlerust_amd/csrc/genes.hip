@@ -21,7 +21,10 @@
 
 namespace srx {
 
-constexpr int kMaxTileGenes = 8000;       // 8000 * 20 B = 160000 B <= 163840 B of LDS
+constexpr int kMaxTileGenes = 10000;      // 10000 * 16 B (two 64-bit sums per gene) + the 2 KiB logarithm table <= 163840 B of LDS.
+                                          // c3 (28k genes): 3 tiles of 9334 — a row's tile segment is ~280 entries instead of ~210 with
+                                          // 4 tiles of 7000 (8000 * 20 B while the pass also counted): moments + store 3.09 -> see DESIGN;
+                                          // the other way round, 5 / 6 tiles: 3.28 / 3.66 ms (round 4 A/B, SRX_EXP_TILE_GENES)
 constexpr int kMomThreads = 1024;
 
 // lower_bound of `bound` inside each row's sorted column list, for the interior tile cuts.
@@ -49,12 +52,11 @@ __device__ __forceinline__ void seg_bounds(const int64_t* __restrict__ indptr, c
     hi = tile == n_tiles - 1 ? indptr[r + 1] : tp[(uint64_t)tile * n_rows + r];
 }
 
-// The three column passes of the reference — histogram (csr.rs:29-36), scatter-add of x
-// (csr.rs:94-100) and of x^2 (csr.rs:175-178) — in ONE walk.
+// The two value passes of the reference over the columns — scatter-add of x (csr.rs:94-100) and of x^2 (csr.rs:175-178) — in
+// ONE walk; the third, the histogram of the indices (csr.rs:29-36), depends on the pattern only and is k_gene_count's.
 // XF: the values are the RAW matrix and x = ln_1p(f64(v) * scale_row) is formed on the fly in f64 (RowXf, common.hpp):
 // the moments of the normalised + log1p'd matrix to f64 accuracy whatever the storage type, before (and without) the
-// in-place write-back.  COUNT = false: the per-gene counts are pattern-only and already cached on the matrix — one
-// LDS atomic per non-zero less.
+// in-place write-back.
 // WB (with XF): the transformed value is also stored back in place, at the storage precision — every stored value belongs to
 // exactly one (gene tile, row) segment, i.e. to one lane of one workgroup, so this pass IS the in-place normalise + log1p of
 // the pipeline and nothing reads the raw matrix after it.
@@ -63,21 +65,20 @@ __device__ __forceinline__ void seg_bounds(const int64_t* __restrict__ indptr, c
 //  test and one ds_read_b64 instead of the ~30-instruction logarithm.  Bit-identical results, 16x fewer logarithms, and
 //  3.64 ms against 3.18: the four dependent LDS reads of a chunk queue behind the other waves' atomics, and the arithmetic
 //  they replace was what hid that latency.)
-template <typename T, typename I, bool XF, bool COUNT, bool WB = false>
+template <typename T, typename I, bool XF, bool WB = false>
 __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     const int64_t* __restrict__ indptr, const int64_t* __restrict__ tp, const I* __restrict__ idx,
     std::conditional_t<WB, T, const T>* __restrict__ vals, uint64_t n_rows, uint64_t n_cols, int n_tiles, int tile_genes,
     uint64_t rows_per_block, const double* __restrict__ row_sum, double target, double fx_sum, double fx_sq,
-    uint32_t* __restrict__ poison, uint32_t* __restrict__ part_cnt, double* __restrict__ part_sum, double* __restrict__ part_sq) {
+    uint32_t* __restrict__ poison, double* __restrict__ part_sum, double* __restrict__ part_sq) {
     extern __shared__ double lds[];
     double* s_sum = lds;
     double* s_sq = lds + tile_genes;
-    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(lds + 2 * tile_genes);
-    // behind the accumulators (tile_genes * 20 B, rounded up to 16): the log1p table
+    // behind the accumulators (tile_genes * 16 B): the log1p table
     // (the table from global memory instead — 2 KB, L1-resident, one vector load per value — was tried: 5.7 ms against 3.5)
-    const Log1pTabEntry* s_tab = reinterpret_cast<const Log1pTabEntry*>(reinterpret_cast<char*>(lds) + (((size_t)tile_genes * 20 + 15) & ~(size_t)15));
+    const Log1pTabEntry* s_tab = reinterpret_cast<const Log1pTabEntry*>(reinterpret_cast<char*>(lds) + (size_t)tile_genes * 16);
     if constexpr (XF) stage_log1p_table(const_cast<Log1pTabEntry*>(s_tab));
-    for (int g = threadIdx.x; g < tile_genes; g += kMomThreads) { s_sum[g] = 0.0; s_sq[g] = 0.0; s_cnt[g] = 0u; }
+    for (int g = threadIdx.x; g < tile_genes; g += kMomThreads) { s_sum[g] = 0.0; s_sq[g] = 0.0; }
     __syncthreads();
 
     // The gene tiles of one row block run on the SAME XCD (consecutive workgroup ids go round the 8 XCDs): a row's tile segments
@@ -207,8 +208,6 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
                     x0 = y4[j];
                     if (__builtin_expect(!(fabs(x0) < 64.0), 0)) {     // NaN, infinite, or outside the fixed-point range: the gene's moments are NaN
                         poison[(uint64_t)gbase + g0] = 1u;
-                        // the entry still COUNTS: the per-gene counts of this pass are cached as pattern-only counts
-                        if constexpr (COUNT) __hip_atomic_fetch_add(&s_cnt[g0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         continue;
                     }
                     // round-to-nearest integer of x * 2^shift through the 1.5 * 2^52 trick (|x * 2^shift| < 2^51)
@@ -217,7 +216,6 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
                     const unsigned long long iq = (unsigned long long)__double_as_longlong(__builtin_fma(x0 * x0, fx_sq, kMagic));
                     // (a poisoned value adds nothing while the reduction still takes its magic bits off: the gene's sums are
                     //  replaced by NaN anyway)
-                    if constexpr (COUNT) __hip_atomic_fetch_add(&s_cnt[g0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifdef MOM_NOATOM
                     if (is + iq == 12345ull) s_sum[g0] = 1.0;
                     continue;
@@ -226,7 +224,6 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
                     __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&s_sq[g0]), iq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     continue;
                 }
-                if constexpr (COUNT) __hip_atomic_fetch_add(&s_cnt[g0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&s_sum[g0], x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&s_sq[g0], x0 * x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -292,25 +289,64 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     for (int g = threadIdx.x; g < tile_genes; g += kMomThreads) {
         uint64_t gene = (uint64_t)gbase + g;
         if (gene < n_cols) {
-            if constexpr (COUNT) part_cnt[rb * n_cols + gene] = s_cnt[g];
             part_sum[rb * n_cols + gene] = s_sum[g];
             part_sq[rb * n_cols + gene] = s_sq[g];
         }
     }
 }
 
+// Per-gene non-zero counts of the stored pattern (csr.rs:24-36: the column histogram of the indices) — a property of the
+// sparsity pattern alone: made once per pattern (srx_matrix_prepare, or the first pass that needs them), kept on the matrix,
+// inherited by clones; the moments passes then carry no count atomic and no counters in LDS (16 B per gene: 3 gene tiles at
+// 28k genes instead of 4).  Workgroup = (row block, gene tile) like the moments pass, 32-bit LDS counters, flushed with global
+// atomics into the zeroed `cnt`.
+template <typename I>
+__global__ __launch_bounds__(kMomThreads) void k_gene_count(const int64_t* __restrict__ indptr, const int64_t* __restrict__ tp,
+                                                            const I* __restrict__ idx, uint64_t n_rows, uint64_t n_cols, int n_tiles,
+                                                            int tile_genes, uint64_t rows_per_block, uint32_t* __restrict__ cnt) {
+    extern __shared__ double lds[];
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(lds);
+    for (int g = threadIdx.x; g < tile_genes; g += kMomThreads) s_cnt[g] = 0u;
+    __syncthreads();
+    const int tile = blockIdx.x % n_tiles;
+    const uint64_t rb = blockIdx.x / n_tiles;
+    const int32_t gbase = tile * tile_genes;
+    const uint64_t r0 = rb * rows_per_block;
+    const uint64_t r1 = r0 + rows_per_block < n_rows ? r0 + rows_per_block : n_rows;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    constexpr int kWaves = kMomThreads / kWave;
+    constexpr int kU = 4;
+    for (uint64_t r = r0 + wave; r < r1; r += kWaves) {
+        int64_t lo, hi;
+        seg_bounds(indptr, tp, n_rows, n_tiles, tile, r, lo, hi);
+        for (int64_t p0 = lo; p0 < hi; p0 += kU * kWave) {
+            int32_t g[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int64_t p = p0 + u * kWave + lane;
+                g[u] = p < hi ? (int32_t)idx[p] - gbase : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+                if (g[u] >= 0) __hip_atomic_fetch_add(&s_cnt[g[u]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < tile_genes; g += kMomThreads) {
+        const uint64_t gene = (uint64_t)gbase + g;
+        if (gene < n_cols && s_cnt[g]) atomicAdd(&cnt[gene], s_cnt[g]);
+    }
+}
+
 // Fixed-order sum of the per-row-block partials -> packed f64 [cnt | sum | sq | n_rows].
-// `cnt_cached` (nullable): this shard's per-gene counts, known from an earlier pass over the same sparsity pattern;
-// `cnt_store` (nullable): where to keep the counts summed here for the next time.
-__global__ void k_moments_reduce(const uint32_t* __restrict__ part_cnt, const double* __restrict__ part_sum,
-                                 const double* __restrict__ part_sq, uint64_t n_cols, uint64_t n_blocks,
-                                 uint64_t n_rows, const uint32_t* __restrict__ cnt_cached, uint32_t* __restrict__ cnt_store,
-                                 double inv_fx_sum, double inv_fx_sq, const uint32_t* __restrict__ poison,
-                                 double* __restrict__ packed) {
+// `cnt`: this shard's per-gene non-zero counts (pattern-only, k_gene_count).
+__global__ void k_moments_reduce(const double* __restrict__ part_sum, const double* __restrict__ part_sq, uint64_t n_cols,
+                                 uint64_t n_blocks, uint64_t n_rows, const uint32_t* __restrict__ cnt, double inv_fx_sum,
+                                 double inv_fx_sq, const uint32_t* __restrict__ poison, double* __restrict__ packed) {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j == 0) packed[3 * n_cols] = (double)n_rows;
     if (j >= n_cols) return;
-    uint64_t c = 0;
     double s = 0.0, q = 0.0;
     if (inv_fx_sum != 0.0) {                 // fixed-point partials (transformed values): exact integer sums
         long long is = 0, iq = 0;
@@ -318,27 +354,23 @@ __global__ void k_moments_reduce(const uint32_t* __restrict__ part_cnt, const do
         uint64_t b = 0;
         for (; b + 8 <= n_blocks; b += 8) {
             unsigned long long xs[8], xq[8];
-            uint32_t xc[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 xs[u] = (unsigned long long)__double_as_longlong(part_sum[(b + u) * n_cols + j]);
                 xq[u] = (unsigned long long)__double_as_longlong(part_sq[(b + u) * n_cols + j]);
-                xc[u] = cnt_cached ? 0u : part_cnt[(b + u) * n_cols + j];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 is = (long long)((unsigned long long)is + xs[u]);
                 iq = (long long)((unsigned long long)iq + xq[u]);
-                c += xc[u];
             }
         }
         for (; b < n_blocks; ++b) {
-            if (!cnt_cached) c += part_cnt[b * n_cols + j];
             is = (long long)((unsigned long long)is + (unsigned long long)__double_as_longlong(part_sum[b * n_cols + j]));
             iq = (long long)((unsigned long long)iq + (unsigned long long)__double_as_longlong(part_sq[b * n_cols + j]));
         }
         // every contribution carried the bit pattern of the 1.5 * 2^52 rounding constant along (k_gene_moments): off again
-        const unsigned long long cn = cnt_cached ? (unsigned long long)cnt_cached[j] : (unsigned long long)c;
+        const unsigned long long cn = (unsigned long long)cnt[j];
         const unsigned long long magic_bits = (unsigned long long)__double_as_longlong(6755399441055744.0);
         is = (long long)((unsigned long long)is - cn * magic_bits);
         iq = (long long)((unsigned long long)iq - cn * magic_bits);
@@ -347,13 +379,10 @@ __global__ void k_moments_reduce(const uint32_t* __restrict__ part_cnt, const do
         if (poison[j]) s = q = __builtin_nan("");
     } else
     for (uint64_t b = 0; b < n_blocks; ++b) {
-        if (!cnt_cached) c += part_cnt[b * n_cols + j];
         s += part_sum[b * n_cols + j];
         q += part_sq[b * n_cols + j];
     }
-    if (cnt_cached) c = cnt_cached[j];
-    else if (cnt_store) cnt_store[j] = (uint32_t)c;
-    packed[j] = (double)c;
+    packed[j] = (double)cnt[j];
     packed[n_cols + j] = s;
     packed[2 * n_cols + j] = q;
 }
@@ -442,7 +471,9 @@ __global__ void k_col_scale(const int32_t* __restrict__ idx, T* __restrict__ val
 
 static void tile_geometry(const srx_mat* m, int& n_tiles, int& tile_genes) {
     uint64_t G = m->n_cols ? m->n_cols : 1;
-    n_tiles = (int)((G + kMaxTileGenes - 1) / kMaxTileGenes);
+    static const int exp_tile = getenv("SRX_EXP_TILE_GENES") ? atoi(getenv("SRX_EXP_TILE_GENES")) : 0;      // A/B (round 4)
+    const uint64_t cap = exp_tile > 0 && exp_tile < kMaxTileGenes ? (uint64_t)exp_tile : (uint64_t)kMaxTileGenes;
+    n_tiles = (int)((G + cap - 1) / cap);
     tile_genes = (int)((G + n_tiles - 1) / n_tiles);
 }
 
@@ -572,17 +603,14 @@ static int32_t local_moments(srx_mat* m, double** packed_out, RowXf xf = RowXf{}
     const uint64_t G = m->n_cols;
     uint64_t nb, rpb;
     block_geometry(m, nb, rpb);
-    uint32_t* p_cnt;
     double *p_sum, *p_sq, *packed;
-    SRX_TRY(scratch(ctx, "mom_part_cnt", nb * (G ? G : 1) * sizeof(uint32_t), (void**)&p_cnt));
     SRX_TRY(scratch(ctx, "mom_part_sum", nb * (G ? G : 1) * sizeof(double), (void**)&p_sum));
     SRX_TRY(scratch(ctx, "mom_part_sq", nb * (G ? G : 1) * sizeof(double), (void**)&p_sq));
     SRX_TRY(scratch(ctx, "mom_packed", (3 * G + 1) * sizeof(double), (void**)&packed));
-    // the per-gene counts depend on the sparsity pattern only: computed by the first pass over a pattern, kept on the
-    // matrix (clones inherit them), and the count atomic is left out of every later pass
-    const bool have_cnt = m->cnt_pat_valid && m->d_cnt_pat;
-    if (!m->d_cnt_pat) SRX_HIP(ctx, dev_malloc(ctx, (void**)&m->d_cnt_pat, (G ? G : 1) * sizeof(uint32_t)));
-    const size_t lds = (((size_t)m->tile_genes * 20 + 15) & ~(size_t)15) + (xf.row_sum ? (size_t)kLog1pTabBytes : 0);
+    // the per-gene counts depend on the sparsity pattern only: counted once per pattern (here, or by srx_matrix_prepare), kept
+    // on the matrix (clones inherit them)
+    SRX_TRY(ensure_pattern_counts(m));
+    const size_t lds = (size_t)m->tile_genes * 16 + (xf.row_sum ? (size_t)kLog1pTabBytes : 0);
     // s_i = 2 when the 16-bit index mirror exists (n_cols <= 65536), 4 otherwise
     const double bytes = (double)m->nnz * ((m->n_cols <= 65536 ? 2.0 : 4.0) + val_bytes(m)) + (double)(m->n_rows + 1) * 8.0 +
                          (double)G * 24.0 + (xf.row_sum ? (double)m->n_rows * 8.0 : 0.0) +
@@ -607,18 +635,15 @@ static int32_t local_moments(srx_mat* m, double** packed_out, RowXf xf = RowXf{}
         auto launch = [&](auto kern, const auto* idxp, auto* valp) -> int32_t {
             SRX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, grid, dim3(kMomThreads), lds, ctx->stream, m->d_indptr, m->d_tile_ptr, idxp, valp,
-                               m->n_rows, G, m->n_tiles, m->tile_genes, rpb, xf.row_sum, xf.target, fx_sum, fx_sq, d_poison, p_cnt, p_sum, p_sq);
+                               m->n_rows, G, m->n_tiles, m->tile_genes, rpb, xf.row_sum, xf.target, fx_sum, fx_sq, d_poison, p_sum, p_sq);
             return SRX_OK;
         };
         auto pick = [&](auto tval, auto tidx, const auto* idxp, const auto* valp) -> int32_t {
             using T = decltype(tval);
             using I = decltype(tidx);
-            if (xf.row_sum && xf.write_back) {
-                T* wp = const_cast<T*>(valp);
-                return have_cnt ? launch(k_gene_moments<T, I, true, false, true>, idxp, wp) : launch(k_gene_moments<T, I, true, true, true>, idxp, wp);
-            }
-            if (xf.row_sum) return have_cnt ? launch(k_gene_moments<T, I, true, false>, idxp, valp) : launch(k_gene_moments<T, I, true, true>, idxp, valp);
-            return have_cnt ? launch(k_gene_moments<T, I, false, false>, idxp, valp) : launch(k_gene_moments<T, I, false, true>, idxp, valp);
+            if (xf.row_sum && xf.write_back) return launch(k_gene_moments<T, I, true, true>, idxp, const_cast<T*>(valp));
+            if (xf.row_sum) return launch(k_gene_moments<T, I, true>, idxp, valp);
+            return launch(k_gene_moments<T, I, false>, idxp, valp);
         };
         if (is_f32(m)) {
             if (m->d_idx16) SRX_TRY(pick(float{}, uint16_t{}, (const uint16_t*)m->d_idx16, (const float*)m->d_values));
@@ -627,22 +652,40 @@ static int32_t local_moments(srx_mat* m, double** packed_out, RowXf xf = RowXf{}
             if (m->d_idx16) SRX_TRY(pick(double{}, uint16_t{}, (const uint16_t*)m->d_idx16, (const double*)m->d_values));
             else SRX_TRY(pick(double{}, int32_t{}, (const int32_t*)m->d_indices, (const double*)m->d_values));
         }
-        hipLaunchKernelGGL(k_moments_reduce, dim3((unsigned)((G + 255) / 256 + 1)), dim3(256), 0, ctx->stream, p_cnt,
-                           p_sum, p_sq, G, nb, m->n_rows, have_cnt ? (const uint32_t*)m->d_cnt_pat : (const uint32_t*)nullptr,
-                           have_cnt ? (uint32_t*)nullptr : m->d_cnt_pat, fx_sum != 0.0 ? 1.0 / fx_sum : 0.0,
+        hipLaunchKernelGGL(k_moments_reduce, dim3((unsigned)((G + 255) / 256 + 1)), dim3(256), 0, ctx->stream, p_sum, p_sq, G, nb,
+                           m->n_rows, (const uint32_t*)m->d_cnt_pat, fx_sum != 0.0 ? 1.0 / fx_sum : 0.0,
                            fx_sq != 0.0 ? 1.0 / fx_sq : 0.0, (const uint32_t*)d_poison, packed);
     }
     SRX_HIP(ctx, hipGetLastError());
-    m->cnt_pat_valid = true;
     *packed_out = packed;
     return SRX_OK;
 }
 
-// srx_matrix_prepare: the pattern-only per-gene counts now (one pass), so that clones inherit them
+// The pattern-only per-gene counts (k_gene_count): one pass over the column indices, once per pattern — srx_matrix_prepare
+// makes them ahead of time, so that clones inherit them.
 int32_t ensure_pattern_counts(srx_mat* m) {
-    if (m->cnt_pat_valid) return SRX_OK;
-    double* packed;
-    return local_moments(m, &packed);
+    if (m->cnt_pat_valid && m->d_cnt_pat) return SRX_OK;
+    srx_ctx* ctx = m->ctx;
+    SRX_TRY(ensure_tiles(m));
+    const uint64_t G = m->n_cols;
+    if (!m->d_cnt_pat) SRX_HIP(ctx, dev_malloc(ctx, (void**)&m->d_cnt_pat, (G ? G : 1) * sizeof(uint32_t)));
+    SRX_HIP(ctx, hipMemsetAsync(m->d_cnt_pat, 0, (G ? G : 1) * sizeof(uint32_t), ctx->stream));
+    if (m->n_rows && m->nnz) {
+        uint64_t nb, rpb;
+        block_geometry(m, nb, rpb);
+        const dim3 grid((unsigned)(nb * m->n_tiles));
+        const size_t lds = (size_t)m->tile_genes * 4;
+        ProfScope ps(ctx, SRX_K_MOMENTS, (double)m->nnz * (m->d_idx16 ? 2.0 : 4.0) + (double)(m->n_rows + 1) * 8.0 + (double)G * 4.0);
+        if (m->d_idx16)
+            hipLaunchKernelGGL(k_gene_count<uint16_t>, grid, dim3(kMomThreads), lds, ctx->stream, m->d_indptr, m->d_tile_ptr,
+                               (const uint16_t*)m->d_idx16, m->n_rows, G, m->n_tiles, m->tile_genes, rpb, m->d_cnt_pat);
+        else
+            hipLaunchKernelGGL(k_gene_count<int32_t>, grid, dim3(kMomThreads), lds, ctx->stream, m->d_indptr, m->d_tile_ptr,
+                               (const int32_t*)m->d_indices, m->n_rows, G, m->n_tiles, m->tile_genes, rpb, m->d_cnt_pat);
+        SRX_HIP(ctx, hipGetLastError());
+    }
+    m->cnt_pat_valid = true;
+    return SRX_OK;
 }
 
 __global__ void k_add_f64(double* __restrict__ acc, const double* __restrict__ x, uint64_t n) {

@@ -1176,6 +1176,15 @@ __global__ void k_deflate(double* __restrict__ C, int k, const double* __restric
 
 // Size of a matrix's result allocation: the N x n_pc f64 scores followed by the block of small results
 // (layout: srx_pca_state::d_small) for the most rounds either plan can take.
+// Row stride (in doubles) of the score matrix IN HBM: n_pc rounded up to a whole number of 128-byte pieces (16 doubles), so
+// that the 16-column piece a panel-slice workgroup of the forward SpMM writes for a cell is its own two aligned 64-byte lines
+// — with the reference's N x n_pc layout (400-byte rows at n_pc = 50) every piece straddled lines shared with another
+// slice's workgroup.  srx_result_fetch hands out the dense N x n_pc matrix (obsm["X_pca"], dim_red/mod.rs:105-106) whatever
+// the stride in HBM is.
+static int scores_ld(int n_pc) {
+    static const bool dense = getenv("SRX_EXP_DENSE_SCORES") != nullptr;       // A/B (round 4): the unpadded layout
+    return dense ? n_pc : (n_pc + 15) / 16 * 16;
+}
 static void result_layout(uint64_t n_rows, int k, int n_pc, int dim, size_t& score_bytes, size_t& small_doubles,
                           std::vector<int>* plan_a_out = nullptr, std::vector<int>* plan_b_out = nullptr) {
     const size_t kl = (size_t)k * L;
@@ -1183,7 +1192,7 @@ static void result_layout(uint64_t n_rows, int k, int n_pc, int dim, size_t& sco
     const int n_b = (n_pc + kPcaPerRoundSafe - 1) / kPcaPerRoundSafe;
     const std::vector<int> pb = plan_rounds(dim, n_pc, (n_pc + n_b - 1) / n_b);
     const int rounds_cap = (int)std::max(pa.size(), pb.size());
-    score_bytes = (n_rows ? n_rows : 1) * (size_t)n_pc * 8;
+    score_bytes = (n_rows ? n_rows : 1) * (size_t)scores_ld(n_pc) * 8;
     small_doubles = (size_t)rounds_cap * (kl + 2 * L) + 2 * (size_t)k + 2 + ((size_t)k + 1) / 2;
     if (plan_a_out) *plan_a_out = pa;
     if (plan_b_out) *plan_b_out = pb;
@@ -1269,11 +1278,12 @@ static int32_t run_pca(srx_ctx* ctx, const RowMajor* parts, int n_parts, const T
         // scores = Z V: the transform from the row-major records, one launch per row tile (the tile-major kernel — 1.22 ms
         // at c3 against 0.84 — when its view was made: matrix-free solver, panel slice larger than the LDS, SRX_FWD_TILED)
         uint64_t row0 = 0;
+        const int ld_s = scores_ld(n_pc);
         if (t256p) {
-            SRX_TRY((launch_fwd<VT, PT>(ctx, *t256p, P, cvec, Y, st.d_scores + col0, n_r, n_pc)));
+            SRX_TRY((launch_fwd<VT, PT>(ctx, *t256p, P, cvec, Y, st.d_scores + col0, n_r, ld_s)));
         } else {
             for (int i = 0; i < n_parts; ++i) {
-                SRX_TRY((launch_fwd_rows<VT, PT>(ctx, parts[i], P, cvec, n_r, st.d_scores + row0 * (size_t)n_pc + col0, (PT*)nullptr, n_pc)));
+                SRX_TRY((launch_fwd_rows<VT, PT>(ctx, parts[i], P, cvec, n_r, st.d_scores + row0 * (size_t)ld_s + col0, (PT*)nullptr, ld_s)));
                 row0 += parts[i].n_rows;
             }
         }
@@ -1816,7 +1826,7 @@ int32_t srx_result_fetch(srx_mat* m, double* scores, double* components, double*
     SRX_HIP(ctx, hipSetDevice(ctx->device));
     if (components || evr || mean || std_ || hvg_idx) SRX_TRY(pca_materialize(m));
     const srx_pca_state& st = m->pca;
-    if (scores) SRX_TRY(d2h(ctx, scores, st.d_scores, (m->csc ? m->n_cols : m->n_rows) * (size_t)st.n_pc * 8));
+    if (scores) SRX_TRY(d2h_rows(ctx, scores, st.d_scores, m->csc ? m->n_cols : m->n_rows, (size_t)st.n_pc * 8, (size_t)scores_ld((int)st.n_pc) * 8));
     if (components) memcpy(components, st.components.data(), st.components.size() * 8);
     if (evr) memcpy(evr, st.evr.data(), st.evr.size() * 8);
     if (mean) memcpy(mean, st.mean.data(), st.mean.size() * 8);
