@@ -45,8 +45,8 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
-KERNEL_SYMBOL = {"normalize_log1p": "k_row_apply<T> (SRX_WB_SIDE=1 only: in-place write-back on the side stream; by default the moments pass stores the values)",
-                 "row_sums": "k_row_sum<float>", "gene_moments": "k_gene_moments<float,u16,XF,COUNT,WB> (f64 moments of the transform + the in-place store)",
+KERNEL_SYMBOL = {"normalize_log1p": "k_row_apply<T> / k_normalize<T> (the separate in-place calls; the pipeline's moments pass stores the values itself)",
+                 "row_sums": "k_row_sum<float>", "gene_moments": "k_gene_moments<float,u16,XF,WB> (f64 moments of the transform + the in-place store)",
                  "select": "k_gene_var + k_hvg_rank + k_hvg_take + k_sel_finish",
                  "hvg_compact": "k_rowcount + k_tfill (+ scan)", "spmm_fwd": "k_spmm_rows (row-major records x 64-col panel)",
                  "spmm_t": "k_spmm_t", "gram_sparse": "k_gram_stripes<float>",
@@ -830,17 +830,6 @@ def main():
         attempt("f64_storage" if other == "f64" else "f32_storage", f_other)
         attempt("cold_step", lambda: cold_step(B, a.config, n_global, a.storage))
 
-        def f_fast():
-            os.environ["SRX_NO_LAZY"] = "1"
-            try:
-                r = B.run(a.config, n_global, 0, n_global, a.storage, k5, 1, solver=a.solver)
-            finally:
-                del os.environ["SRX_NO_LAZY"]
-            return {"steps": k5, "ms_per_step": r["ms_per_step"], "value": n_global * k5 / r["elapsed"], "unit": "cells/s",
-                    "note": "SRX_NO_LAZY=1: in-place normalise + log1p first, moments of the f32-rounded stored values (round-1 "
-                            "order; near-ties of HighlyVariable(n) may swap against the reference) — what the exact selection costs"}
-        attempt("approximate_selection", f_fast)
-
         def f_iter():
             r = B.run(a.config, n_global, 0, n_global, a.storage, 2, 1, solver=2)
             fw, tr = r["prof"].get("spmm_fwd", {}), r["prof"].get("spmm_t", {})
@@ -966,7 +955,6 @@ def main():
                               "note": "algorithmic bytes of every kernel class of a step (minimum data each must move, SURVEY.md "
                                       "8(d)) over the whole step time; step_hbm_traffic = PMC counter traffic of the same classes "
                                       "from the committed profile"},
-            "writeback_overlapped_ms_per_step": per.get("normalize_log1p"),
             "stage_ms_per_step": main_["stage_ms_per_step"],
             "traffic_source": f"profiles/{traffic_round}_traffic_{a.config}.json" if traffic_round else None,
             "setup": {"generate_s": main_["generate_s"], "copies": main_["copies"]},

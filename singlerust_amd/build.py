@@ -17,7 +17,7 @@ OBJ = os.path.join(CSRC, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsrx_hip.so")
 
-SOURCES = ["ctx.hip", "rows.hip", "genes.hip", "comm.hip", "pca.hip", "synth.hip", "filter.hip", "csc.hip"]
+SOURCES = ["ctx.hip", "rows.hip", "genes.hip", "comm.hip", "pca_form.hip", "pca_solve.hip", "pca.hip", "synth.hip", "filter.hip", "csc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
          "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 

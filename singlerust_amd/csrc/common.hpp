@@ -70,8 +70,6 @@ struct srx_ctx {
     int device = 0;
     int n_cus = 256;
     hipStream_t stream = nullptr;
-    // side stream of the pipeline: the in-place write-back of the normalised values runs beside the Gram kernel
-    hipStream_t side_stream = nullptr;
     hipStream_t comm_stream = nullptr;       // collectives issued beside the compute stream (launch_gram); events for fork / join
     hipEvent_t comm_fork = nullptr, comm_join = nullptr;
     // sharded rows: the second half of the Gram kernel runs here, off the CUs left to the collective (launch_gram)
@@ -79,9 +77,6 @@ struct srx_ctx {
     bool gram_stream_masked = false;
     uint32_t gram_splits = 0;                // Gram exchanges run in the split arrangement (srx_comm_overlap_info)
     hipEvent_t gram_fork = nullptr, gram_join = nullptr;
-    hipEvent_t side_fork = nullptr, side_join = nullptr;
-    bool side_busy = false;
-    struct srx_mat* wb_after_gram = nullptr;      // pipeline: matrix whose write-back run_pca queues behind the Gram kernel
     std::string err;
     // RCCL (one process per GPU)
     ncclComm* comm = nullptr;

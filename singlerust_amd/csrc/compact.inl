@@ -1,4 +1,4 @@
-// compact.inl — included by pca.hip inside namespace srx (one translation unit: the kernels share its helpers and constants).
+// compact.inl — included by pca_form.hip inside namespace srx (the kernels share pca_internal.hpp's helpers and constants).
 // HVG compaction of the CSR matrix to the selected features: counts, scans, fill passes (row-major records, tile-major views), the selection table in LDS, the owner-record format of the Gram kernel.
 
 // ---- HVG compaction --------------------------------------------------------------------------
@@ -141,9 +141,6 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(const int64_t* __rest
 //                  (forward panel tile, two workgroups per CU), 128 KiB as f64 (transposed
 //                  accumulators, one workgroup per CU);
 //   kt = 128 (KG)  Gram kernel: a 128 x 128 f64 tile of A^T A is 128 KiB.
-constexpr int KT = 256;
-constexpr int KG = 128;
-
 __global__ void k_seglen(const int64_t* __restrict__ indptr, const int64_t* __restrict__ tp, uint64_t n_rows, int nt,
                          int64_t* __restrict__ seglen) {
     uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -160,10 +157,6 @@ __global__ void k_seglen(const int64_t* __restrict__ indptr, const int64_t* __re
 // One entry of a tile-major layout: local column and value side by side, so that every consumer (Gram kernel,
 // forward / transposed SpMM) fetches an entry with ONE 8-byte (f32 storage) or 16-byte (f64) load and the
 // compaction writes it with one store.
-template <typename VT> struct GramPk;
-template <> struct __attribute__((aligned(8))) GramPk<float> { int32_t j; float v; };
-template <> struct __attribute__((aligned(16))) GramPk<double> { int32_t j; int32_t pad_; double v; };
-
 template <typename T>
 __global__ __launch_bounds__(256) void k_retile(const int64_t* __restrict__ indptr, const int64_t* __restrict__ tp,
                                                 const int32_t* __restrict__ idx, const T* __restrict__ vals,
@@ -199,39 +192,6 @@ __global__ __launch_bounds__(256) void k_retile(const int64_t* __restrict__ indp
 // (G/32 words) plus the number of selected genes before each word, both staged in LDS (7 KB at
 // G = 28k); column = prefix[w] + popcount(bits[w] below the gene's bit).
 // ---- owner buckets of the Gram kernel (k_gram_stripes, below) -----------------------------------------
-constexpr int kGramWaves = 16;            // waves per Gram workgroup
-constexpr int kGramUnroll = 8;            // suffix loads in flight per wave
-
-// One unit of Gram work: entry (ja, va) times up to 64 consecutive entries of its row's suffix (the suffix starts at the
-// entry itself — the diagonal product — and a suffix longer than a wave is cut into several records).
-// pos: first suffix entry of this record, relative to its block's first entry; lenrb = lanes | rbase << 8, where
-// rbase + jb is the index of G[ja][jb] among the owner's LDS accumulators (gram_row_base: may be negative, jb >= ja).
-// (8-byte records — the entry's value fetched in the kernel instead of carried in the record, the piece index in the spare bits
-//  of lenrb — were measured in round 3: the bucket pass gains 0.13 ms (0.93 -> 0.80) and the stripe kernel loses 0.45 with a
-//  scalar load of the value (it shares lgkmcnt with the LDS atomics: waiting for it drains them) and 1.35 with a wave-uniform
-//  vector load (one more L1 access per record).  The value stays in the record.)
-template <typename VT> struct GramRec { uint32_t pos, lenrb; VT va; };
-// records of a row with n kept entries: sum over suffix lengths L = 1 .. n of ceil(L / 64)
-__host__ __device__ __forceinline__ uint64_t gram_row_records(uint64_t n) {
-    const uint64_t q = n >> 6, r = n & 63;
-    return 32 * q * (q + 1) + r * (q + 1);
-}
-
-__device__ __forceinline__ int gram_owner(int c, int sr_shift, int n_wg, int n_stripes) {
-    const int s = c >> sr_shift;
-    return s < n_wg ? s : n_stripes - 1 - s;
-}
-
-// accumulator layout of an owner: stripe A (rows a0 .. a0 + SR - 1, WA = k - a0 columns from a0), then stripe B (rows from
-// b0 = the mirrored stripe, WB = k - b0 columns): the offset to which a column index jb >= ja is added
-__device__ __forceinline__ int gram_row_base(int ja, int k, int sr_shift, int n_wg, int n_stripes) {
-    const int s = ja >> sr_shift, SR = 1 << sr_shift;
-    const int s0 = s << sr_shift;                       // first row of ja's stripe
-    if (s < n_wg) return (ja - s0) * (k - s0) - s0;
-    const int a0 = (n_stripes - 1 - s) << sr_shift;     // the owner's stripe A
-    return SR * (k - a0) + (ja - s0) * (k - s0) - s0;
-}
-
 struct SelLds {
     const uint32_t* bits;
     const uint32_t* prefix;

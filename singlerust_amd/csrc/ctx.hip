@@ -165,7 +165,6 @@ ProfScope::~ProfScope() {
 
 static int32_t prof_drain(srx_ctx* ctx) {
     SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->side_stream) SRX_HIP(ctx, hipStreamSynchronize(ctx->side_stream));
     if (ctx->comm_stream) SRX_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
     if (ctx->gram_stream) SRX_HIP(ctx, hipStreamSynchronize(ctx->gram_stream));
     for (int c = 0; c < SRX_K_COUNT_; ++c) {
@@ -467,7 +466,7 @@ int32_t upload_on(srx_ctx* ctx, const srx_csr* h, int32_t store, hipStream_t str
     if (h->indptr[h->n_rows] - base != h->nnz)
         return fail(ctx, SRX_E_FORMAT, "X is not a CSR matrix: row_offsets do not span nnz");
     srx_mat* m = nullptr;
-    static const bool trace = getenv("SRX_UPLOAD_TRACE") != nullptr;        // reports uploads that take > 100 ms, by phase
+    constexpr bool trace = false;                 // (development: reports uploads that take > 100 ms, by phase)
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tt[6] = {0, 0, 0, 0, 0, 0};
     tt[0] = trace ? now() : 0.0;
@@ -605,9 +604,6 @@ void srx_ctx_destroy(srx_ctx* ctx) {
     }
     for (auto e : ctx->async_ev)
         if (e) (void)hipEventDestroy(e);
-    if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
-    if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
-    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     if (ctx->comm_fork) (void)hipEventDestroy(ctx->comm_fork);
     if (ctx->comm_join) (void)hipEventDestroy(ctx->comm_join);

@@ -471,9 +471,7 @@ __global__ void k_col_scale(const int32_t* __restrict__ idx, T* __restrict__ val
 
 static void tile_geometry(const srx_mat* m, int& n_tiles, int& tile_genes) {
     uint64_t G = m->n_cols ? m->n_cols : 1;
-    static const int exp_tile = getenv("SRX_EXP_TILE_GENES") ? atoi(getenv("SRX_EXP_TILE_GENES")) : 0;      // A/B (round 4)
-    const uint64_t cap = exp_tile > 0 && exp_tile < kMaxTileGenes ? (uint64_t)exp_tile : (uint64_t)kMaxTileGenes;
-    n_tiles = (int)((G + cap - 1) / cap);
+    n_tiles = (int)((G + kMaxTileGenes - 1) / kMaxTileGenes);
     tile_genes = (int)((G + n_tiles - 1) / n_tiles);
 }
 
@@ -542,7 +540,7 @@ int32_t ensure_tiles(srx_mat* m) {
     if (m->n_tiles) return SRX_OK;
     int nt, tg;
     tile_geometry(m, nt, tg);
-    if (nt > 1 && nt <= 9 && m->n_cols <= 65536 && !m->d_idx16 && !m->d_tile_ptr && m->n_rows > 0 && !getenv("SRX_TILES_TWO_PASS")) {
+    if (nt > 1 && nt <= 9 && m->n_cols <= 65536 && !m->d_idx16 && !m->d_tile_ptr && m->n_rows > 0) {
         SRX_HIP(ctx, dev_malloc(ctx, (void**)&m->d_tile_ptr, (size_t)(nt - 1) * m->n_rows * sizeof(int64_t)));
         SRX_HIP(ctx, dev_malloc(ctx, (void**)&m->d_idx16, (m->nnz + 16) * sizeof(uint16_t)));
         const unsigned g = (unsigned)std::min<uint64_t>((m->n_rows + 3) / 4, (uint64_t)ctx->n_cus * 32);

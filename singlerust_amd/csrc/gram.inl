@@ -1,4 +1,4 @@
-// gram.inl — included by pca.hip inside namespace srx (one translation unit: the kernels share its helpers and constants).
+// gram.inl — included by pca_form.hip inside namespace srx (the kernels share pca_internal.hpp's helpers and constants).
 // G = A^T A from the row-major compacted matrix: record counts, owner buckets, the stripe kernel, expansion to C.
 
 // ---- explicit sparse Gram: G = A^T A from the ROW-MAJOR compacted matrix ----------------------------
@@ -18,7 +18,6 @@
 // (position of the entry relative to the block, suffix length).  All workgroups walk the row blocks in the
 // same order at about the same pace, so the row-major matrix streams through L2 / Infinity Cache once per
 // XCD while every cell is visited by the ~m workgroups that own one of its entries.
-template <typename VT> struct GramPk;
 __device__ __forceinline__ double gram_product(float a, float b) { return (double)(a * b); }
 __device__ __forceinline__ double gram_product(double a, double b) { return a * b; }
 
@@ -179,11 +178,6 @@ __device__ __forceinline__ GramPk<double> suffix_load(const GramPk<double>* base
     return e;
 }
 
-// index of (i, j), i <= j, in the packed upper triangle (row-major, row i holds columns i .. k - 1)
-__host__ __device__ __forceinline__ size_t tri_index(int i, int j, int k) {
-    return (size_t)i * (size_t)k - (size_t)i * (size_t)(i - 1) / 2 + (size_t)(j - i);
-}
-
 template <typename VT>
 __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     const int64_t* __restrict__ rm_ptr, const GramPk<VT>* __restrict__ rm, const uint32_t* __restrict__ boff,
@@ -329,102 +323,3 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     }
 }
 
-// C (k x k, both triangles) from the packed upper triangle: (i, j) and (j, i) read the same entry, so C is
-// EXACTLY symmetric (k_dense_apply reads it transposed).  With d != nullptr: C = D (G - cen N mu mu^T) D.
-__global__ void k_gram_expand(const double* __restrict__ P, int k, const double* __restrict__ d,
-                              const double* __restrict__ mu, int cen, double n_cells, double* __restrict__ C) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (uint64_t)k * k) return;
-    const int i = (int)(e / k), j = (int)(e % k);
-    const int lo = i < j ? i : j, hi = i < j ? j : i;
-    double g = P[tri_index(lo, hi, k)];
-    if (d) {
-        if (cen) g -= n_cells * (mu[i] * mu[j]);            // (mu_i mu_j) first: symmetric to the last bit
-        g = d[i] * d[j] * g;
-    }
-    C[e] = g;
-}
-
-// Wp += C[:, krange] W[krange, :] for the dense SYMMETRIC k x k matrix C and a k x 64 block (f64), on the
-// f64 matrix cores.  One wave = 32 output rows x 64 columns x one K slice: eight v_mfma_f64_16x16x4
-// accumulators.  Both operands are read straight from global memory in fragment order with no LDS
-// staging: lane l of the A fragment needs C[row0 + (l & 15)][kk + (l >> 4)], which by symmetry is
-// C[kk + (l >> 4)][row0 + (l & 15)] — 16 consecutive doubles per K index, fully coalesced; the B
-// fragment W[kk + (l >> 4)][16 t + (l & 15)] is coalesced as it stands.  The K slices (split-K 16 across
-// workgroups x 4 waves inside one: ~4000 waves for k = 2000) are combined in LDS, then with f64 atomics into the zeroed Wp.
-// C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg (not the f32 map).
-#ifndef SRX_DENSE_SPLIT          // measured at k = 2000 (split x waves: us): 16x4 21.8, 8x8 21.9, 8x4 18.8, 4x4 17.8, 4x8 17.5, 8x2 28.3, 4x16 36.3 —
-#define SRX_DENSE_SPLIT 4       // the f64 atomics into Wp (k x 64 x split) weigh more than the number of waves in flight
-#define SRX_DENSE_WAVES 8
-#endif
-constexpr int kDenseSplit = SRX_DENSE_SPLIT;
-constexpr int kDenseWaves = SRX_DENSE_WAVES;             // waves of a workgroup: consecutive quarters of the workgroup's K slice
-typedef double dvec4 __attribute__((ext_vector_type(4)));
-// Workgroup = 32 output rows x 64 columns x one K slice, its four waves on consecutive quarters of the slice (four waves per
-// SIMD keep ~4x the loads in flight: one wave per SIMD left the load latency of every group of 16 K indices exposed, 27 us
-// per application against ~7 us of MFMA time); the waves' partial tiles meet in LDS (ds_add_f64), then one f64 atomic per
-// output element and K slice into the zeroed Wp.
-__global__ __launch_bounds__(kDenseWaves * 64) void k_dense_apply(const double* __restrict__ C, const double* __restrict__ W, int k,
-                                                                  double* __restrict__ Wp) {
-    __shared__ double red[32][L];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    const int row0 = blockIdx.x * 32;
-    const int kchunk = (((k + kDenseSplit - 1) / kDenseSplit) + 4 * kDenseWaves - 1) / (4 * kDenseWaves) * (4 * kDenseWaves);      // per workgroup: waves x a multiple of 4
-    const int kq = kchunk / kDenseWaves;
-    const int kbeg = blockIdx.y * kchunk + wv * kq;
-    const int kend = kbeg + kq < k ? kbeg + kq : k;
-    for (int e = threadIdx.x; e < 32 * L; e += kDenseWaves * 64) (&red[0][0])[e] = 0.0;
-    dvec4 acc[2][4];
-#pragma unroll
-    for (int sI = 0; sI < 2; ++sI)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[sI][t] = dvec4{0.0, 0.0, 0.0, 0.0};
-    const bool r0ok = row0 + li < k, r1ok = row0 + 16 + li < k;
-    // groups of 4 K-steps (16 K indices), two register buffers: the 24 loads of group g+1 are in flight
-    // while the 32 MFMAs of group g issue
-    struct Frag { double a0[4], a1[4], bq[4][4]; };
-    auto load = [&](Frag& f, int kk) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int kr = kk + 4 * u + lk;
-            const bool kok = kr < kend;
-            const double* crow = C + (size_t)(kok ? kr : 0) * k + row0 + li;
-            const double* wrow = W + (size_t)(kok ? kr : 0) * L + li;
-            f.a0[u] = (kok && r0ok) ? crow[0] : 0.0;
-            f.a1[u] = (kok && r1ok) ? crow[16] : 0.0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) f.bq[u][t] = kok ? wrow[16 * t] : 0.0;
-        }
-    };
-    auto fma = [&](const Frag& f) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a0[u], f.bq[u][t], acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a1[u], f.bq[u][t], acc[1][t], 0, 0, 0);
-            }
-    };
-    Frag f0, f1;
-    load(f0, kbeg);
-    for (int kk = kbeg; kk < kend; kk += 32) {
-        load(f1, kk + 16);
-        fma(f0);
-        load(f0, kk + 32);
-        fma(f1);
-    }
-    __syncthreads();                             // (the tile is zeroed)
-    // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
-#pragma unroll
-    for (int sI = 0; sI < 2; ++sI)
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) atomicAdd(&red[16 * sI + lk + 4 * v][16 * t + li], acc[sI][t][v]);
-    __syncthreads();
-    for (int e = threadIdx.x; e < 32 * L; e += kDenseWaves * 64) {
-        const int r = row0 + e / L;
-        if (r < k) atomicAdd(&Wp[(size_t)r * L + (e % L)], (&red[0][0])[e]);
-    }
-}

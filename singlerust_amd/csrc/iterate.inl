@@ -1,5 +1,106 @@
-// iterate.inl — included by pca.hip inside namespace srx (one translation unit: the kernels share its helpers and constants).
+// iterate.inl — included by pca_solve.hip inside namespace srx (one translation unit: the kernels share its helpers and constants).
 // Kernels of the k x 64 subspace iteration: dense application of C, CholeskyQR, Rayleigh-Ritz (jacobi.inl), Chebyshev filter, result assembly.
+
+// C (k x k, both triangles) from the packed upper triangle: (i, j) and (j, i) read the same entry, so C is
+// EXACTLY symmetric (k_dense_apply reads it transposed).  With d != nullptr: C = D (G - cen N mu mu^T) D.
+__global__ void k_gram_expand(const double* __restrict__ P, int k, const double* __restrict__ d,
+                              const double* __restrict__ mu, int cen, double n_cells, double* __restrict__ C) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (uint64_t)k * k) return;
+    const int i = (int)(e / k), j = (int)(e % k);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    double g = P[tri_index(lo, hi, k)];
+    if (d) {
+        if (cen) g -= n_cells * (mu[i] * mu[j]);            // (mu_i mu_j) first: symmetric to the last bit
+        g = d[i] * d[j] * g;
+    }
+    C[e] = g;
+}
+
+// Wp += C[:, krange] W[krange, :] for the dense SYMMETRIC k x k matrix C and a k x 64 block (f64), on the
+// f64 matrix cores.  One wave = 32 output rows x 64 columns x one K slice: eight v_mfma_f64_16x16x4
+// accumulators.  Both operands are read straight from global memory in fragment order with no LDS
+// staging: lane l of the A fragment needs C[row0 + (l & 15)][kk + (l >> 4)], which by symmetry is
+// C[kk + (l >> 4)][row0 + (l & 15)] — 16 consecutive doubles per K index, fully coalesced; the B
+// fragment W[kk + (l >> 4)][16 t + (l & 15)] is coalesced as it stands.  The K slices (split-K 16 across
+// workgroups x 4 waves inside one: ~4000 waves for k = 2000) are combined in LDS, then with f64 atomics into the zeroed Wp.
+// C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg (not the f32 map).
+#ifndef SRX_DENSE_SPLIT          // measured at k = 2000 (split x waves: us): 16x4 21.8, 8x8 21.9, 8x4 18.8, 4x4 17.8, 4x8 17.5, 8x2 28.3, 4x16 36.3 —
+#define SRX_DENSE_SPLIT 4       // the f64 atomics into Wp (k x 64 x split) weigh more than the number of waves in flight
+#define SRX_DENSE_WAVES 8
+#endif
+constexpr int kDenseSplit = SRX_DENSE_SPLIT;
+constexpr int kDenseWaves = SRX_DENSE_WAVES;             // waves of a workgroup: consecutive quarters of the workgroup's K slice
+typedef double dvec4 __attribute__((ext_vector_type(4)));
+// Workgroup = 32 output rows x 64 columns x one K slice, its four waves on consecutive quarters of the slice (four waves per
+// SIMD keep ~4x the loads in flight: one wave per SIMD left the load latency of every group of 16 K indices exposed, 27 us
+// per application against ~7 us of MFMA time); the waves' partial tiles meet in LDS (ds_add_f64), then one f64 atomic per
+// output element and K slice into the zeroed Wp.
+__global__ __launch_bounds__(kDenseWaves * 64) void k_dense_apply(const double* __restrict__ C, const double* __restrict__ W, int k,
+                                                                  double* __restrict__ Wp) {
+    __shared__ double red[32][L];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int row0 = blockIdx.x * 32;
+    const int kchunk = (((k + kDenseSplit - 1) / kDenseSplit) + 4 * kDenseWaves - 1) / (4 * kDenseWaves) * (4 * kDenseWaves);      // per workgroup: waves x a multiple of 4
+    const int kq = kchunk / kDenseWaves;
+    const int kbeg = blockIdx.y * kchunk + wv * kq;
+    const int kend = kbeg + kq < k ? kbeg + kq : k;
+    for (int e = threadIdx.x; e < 32 * L; e += kDenseWaves * 64) (&red[0][0])[e] = 0.0;
+    dvec4 acc[2][4];
+#pragma unroll
+    for (int sI = 0; sI < 2; ++sI)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[sI][t] = dvec4{0.0, 0.0, 0.0, 0.0};
+    const bool r0ok = row0 + li < k, r1ok = row0 + 16 + li < k;
+    // groups of 4 K-steps (16 K indices), two register buffers: the 24 loads of group g+1 are in flight
+    // while the 32 MFMAs of group g issue
+    struct Frag { double a0[4], a1[4], bq[4][4]; };
+    auto load = [&](Frag& f, int kk) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kr = kk + 4 * u + lk;
+            const bool kok = kr < kend;
+            const double* crow = C + (size_t)(kok ? kr : 0) * k + row0 + li;
+            const double* wrow = W + (size_t)(kok ? kr : 0) * L + li;
+            f.a0[u] = (kok && r0ok) ? crow[0] : 0.0;
+            f.a1[u] = (kok && r1ok) ? crow[16] : 0.0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) f.bq[u][t] = kok ? wrow[16 * t] : 0.0;
+        }
+    };
+    auto fma = [&](const Frag& f) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a0[u], f.bq[u][t], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a1[u], f.bq[u][t], acc[1][t], 0, 0, 0);
+            }
+    };
+    Frag f0, f1;
+    load(f0, kbeg);
+    for (int kk = kbeg; kk < kend; kk += 32) {
+        load(f1, kk + 16);
+        fma(f0);
+        load(f0, kk + 32);
+        fma(f1);
+    }
+    __syncthreads();                             // (the tile is zeroed)
+    // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int sI = 0; sI < 2; ++sI)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) atomicAdd(&red[16 * sI + lk + 4 * v][16 * t + li], acc[sI][t][v]);
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * L; e += kDenseWaves * 64) {
+        const int r = row0 + e / L;
+        if (r < k) atomicAdd(&Wp[(size_t)r * L + (e % L)], (&red[0][0])[e]);
+    }
+}
+
 
 // ---- k x l helper kernels (f64, replicated per rank) --------------------------------------------
 // P = PT(d .* W * sign), cvec = cen * mu^T P (exact f64 sum of the ROUNDED panel, so Y's column
@@ -175,7 +276,7 @@ __global__ __launch_bounds__(1024) void k_gram1_part(const double* __restrict__ 
 
 // The tail of a Rayleigh–Ritz step in one pass over the rows: A1 = Wp U (= C W U), A2 = W U (the Ritz vectors), and per
 // block the partial sums of || A1[:, c] - theta_c A2[:, c] ||^2 and the entry of largest |.| of A2[:, c] (ties: the smallest
-// row).  k_resid_final adds the partials in fixed order.  (Was: k_right_mul twice, k_col_resid on ONE workgroup, k_resid_scalar.)
+// row).  k_resid_final adds the partials in fixed order.  (Round 2: two k_right_mul launches, the residuals on ONE workgroup, a scalar kernel.)
 constexpr int kRitzBlocks = 128;
 __global__ __launch_bounds__(256) void k_ritz_post(const double* __restrict__ W, const double* __restrict__ Wp,
                                                    const double* __restrict__ M, const double* __restrict__ theta, int k,
@@ -244,41 +345,7 @@ __global__ __launch_bounds__(256) void k_right_mul(const double* __restrict__ In
     }
 }
 
-// rho[c] = || A1[:,c] - theta[c] * A2[:,c] ||_2 ; also colmax: entry of largest |.| of A2[:,c].
-__global__ __launch_bounds__(1024) void k_col_resid(const double* __restrict__ A1, const double* __restrict__ A2,
-                                                    const double* __restrict__ theta, int k,
-                                                    double* __restrict__ rho, double* __restrict__ colmax) {
-    __shared__ double s_r[16][L], s_m[16][L];
-    const int c = threadIdx.x & (L - 1), part = threadIdx.x / L;
-    double acc = 0.0, best = 0.0;
-    const double th = theta[c];
-    for (int j = part; j < k; j += 16) {
-        double v2 = A2[(size_t)j * L + c];
-        double r = A1[(size_t)j * L + c] - th * v2;
-        acc += r * r;
-        if (fabs(v2) > fabs(best)) best = v2;
-    }
-    s_r[part][c] = acc;
-    s_m[part][c] = best;
-    __syncthreads();
-    if (part == 0) {
-        double t = 0.0, bm = 0.0;
-        for (int w = 0; w < 16; ++w) {
-            t += s_r[w][c];
-            if (fabs(s_m[w][c]) > fabs(bm)) bm = s_m[w][c];    // ties keep the lowest row slice
-        }
-        rho[c] = sqrt(t);
-        colmax[c] = bm;
-    }
-}
-
-// ---- l x l algebra of the subspace iteration, on the device ---------------------------------------
-// One workgroup each; they exist so that a whole PCA is ONE uninterrupted stream of launches: with
-// the l x l Cholesky / eigen-solves on the host every sweep cost two or three stream drains plus
-// whatever the host cores happened to be doing (measured: 3.5 ms per pipeline step on an idle box,
-// 17 ms on a busy one).  Status bits are OR-ed into *status and read back with the residual.
 constexpr int kStatChol = 1, kStatEig = 2;
-constexpr size_t kJacobiLds = (2 * L * (L + 1) + L + 32) * sizeof(double) + 2 * L * sizeof(int);
 
 // Start block: counter-based N(0,1) entries, deterministic in (seed, gene slot, column).
 __device__ __forceinline__ uint64_t dmix64(uint64_t x) {
@@ -482,133 +549,6 @@ __global__ __launch_bounds__(64) void k_trsm_rows(const double* __restrict__ Wp,
     for (int j = 0; j < L; ++j) dst[j] = w[j];
 }
 
-// Eigen-decomposition of the symmetric leading n x n block of H (ld = L) by two-sided cyclic Jacobi,
-// 32 disjoint rotations per round in the round-robin ordering (63 rounds = one sweep).  Thread (I, J)
-// owns the 2 x 2 block (pair I) x (pair J) and applies J_I^T . B . J_J in place: the rotated matrix
-// stays exactly symmetric and a round needs two barriers.  The projected matrices of successive
-// Rayleigh–Ritz steps are close to diagonal, so late solves take two or three sweeps.
-// U (L x L, row-major) receives eigenvector c in COLUMN c, eigenvalues descending; rows / columns
-// >= n are 0, theta[c >= n] = 0.
-__device__ __forceinline__ void jacobi_pair(int m, int r, int& p, int& q) {
-    if (m == 0) {
-        p = L - 1;
-        q = r;
-    } else {
-        p = (r + m) % (L - 1);
-        q = (r + (L - 1) - m) % (L - 1);
-    }
-}
-__global__ __launch_bounds__(1024) void k_jacobi_eig(const double* __restrict__ H, int n, double* __restrict__ U,
-                                                     double* __restrict__ theta, int* __restrict__ status, double off_tol2) {
-    static_assert(L == 64, "the block mapping below is written for l = 64");
-    extern __shared__ double lds_raw[];
-    double (*A)[L + 1] = reinterpret_cast<double (*)[L + 1]>(lds_raw);
-    double (*V)[L + 1] = reinterpret_cast<double (*)[L + 1]>(lds_raw + L * (L + 1));
-    double (*cs)[2] = reinterpret_cast<double (*)[2]>(lds_raw + 2 * L * (L + 1));
-    double (*red)[16] = reinterpret_cast<double (*)[16]>(lds_raw + 2 * L * (L + 1) + L);
-    int* rank = reinterpret_cast<int*>(lds_raw + 2 * L * (L + 1) + L + 32);
-    int (*pq)[2] = reinterpret_cast<int (*)[2]>(rank + L);
-    const int tid = threadIdx.x, I = tid >> 5, J = tid & 31;
-    for (int e = tid; e < L * L; e += 1024) {
-        const int a = e >> 6, b = e & 63;
-        A[a][b] = (a < n && b < n) ? 0.5 * (H[(size_t)a * L + b] + H[(size_t)b * L + a]) : 0.0;
-        V[a][b] = a == b ? 1.0 : 0.0;
-    }
-    __syncthreads();
-    bool done = false;
-    for (int sweep = 0; sweep < 30 && !done; ++sweep) {
-        double off = 0.0, dg = 0.0;
-        for (int e = tid; e < L * L; e += 1024) {
-            const int a = e >> 6, b = e & 63;
-            const double x = A[a][b];
-            if (a < b) off += x * x;
-            if (a == b) dg += x * x;
-        }
-        off = wave_sum(off);
-        dg = wave_sum(dg);
-        if ((tid & 63) == 0) {
-            red[0][tid >> 6] = off;
-            red[1][tid >> 6] = dg;
-        }
-        __syncthreads();
-        off = dg = 0.0;
-        for (int w = 0; w < 16; ++w) {
-            off += red[0][w];
-            dg += red[1][w];
-        }
-        __syncthreads();
-        if (!(off > off_tol2 * dg)) {         // also leaves on NaN (reported through the residual)
-            done = true;
-            break;
-        }
-        for (int r = 0; r < L - 1; ++r) {
-            if (tid < L / 2) {
-                int p, q;
-                jacobi_pair(tid, r, p, q);
-                pq[tid][0] = p;
-                pq[tid][1] = q;
-                // rotation annihilating a_pq, division-free: with d = a_qq - a_pp, b = 2 a_pq,
-                // h = hypot(b, d), u = |d| + h:  c = u / hypot(u, b),  s = sgn(d b) |b| / hypot(u, b)
-                const double b = 2.0 * A[p][q], d = A[q][q] - A[p][p];
-                double c = 1.0, sn = 0.0;
-                if (b != 0.0) {
-                    const double u = fabs(d) + sqrt(b * b + d * d);
-                    const double wv = rsqrt(u * u + b * b);
-                    c = u * wv;
-                    sn = ((d >= 0.0) == (b >= 0.0) ? fabs(b) : -fabs(b)) * wv;
-                }
-                cs[tid][0] = c;
-                cs[tid][1] = sn;
-            }
-            __syncthreads();
-            const int p = pq[I][0], q = pq[I][1], rr = pq[J][0], ss = pq[J][1];
-            const double cP = cs[I][0], sP = cs[I][1], cR = cs[J][0], sR = cs[J][1];
-            const double b00 = A[p][rr], b01 = A[p][ss], b10 = A[q][rr], b11 = A[q][ss];
-            const double t00 = cP * b00 - sP * b10, t01 = cP * b01 - sP * b11;
-            const double t10 = sP * b00 + cP * b10, t11 = sP * b01 + cP * b11;
-            double n00 = cR * t00 - sR * t01, n01 = sR * t00 + cR * t01;
-            double n10 = cR * t10 - sR * t11, n11 = sR * t10 + cR * t11;
-            if (I == J) n01 = n10 = 0.0;      // the pivot, annihilated exactly
-            A[p][rr] = n00;
-            A[p][ss] = n01;
-            A[q][rr] = n10;
-            A[q][ss] = n11;
-            // eigenvectors: V <- V J_J on rows 2I, 2I+1
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int row = 2 * I + h;
-                const double v0 = V[row][rr], v1 = V[row][ss];
-                V[row][rr] = cR * v0 - sR * v1;
-                V[row][ss] = sR * v0 + cR * v1;
-            }
-            __syncthreads();
-        }
-    }
-    if (!done && tid == 0) atomicOr(status, kStatEig);
-    // descending order; padded indices (>= n) go last
-    if (tid < L) {
-        const double mine = A[tid][tid];
-        int rk = 0;
-        for (int j = 0; j < L; ++j) {
-            if (j == tid) continue;
-            const double other = A[j][j];
-            bool before;
-            if (tid >= n) before = (j < n) || j < tid;
-            else before = (j < n) && (other > mine || (other == mine && j < tid));
-            rk += before ? 1 : 0;
-        }
-        rank[tid] = rk;
-        theta[rk] = tid < n ? mine : 0.0;
-    }
-    __syncthreads();
-    for (int e = tid; e < L * L; e += 1024) {
-        const int a = e >> 6, b = e & 63;
-        U[(size_t)a * L + rank[b]] = (a < n && b < n) ? V[a][b] : 0.0;
-    }
-}
-
-#include "jacobi.inl"
-
 // ---- Chebyshev filter between two Rayleigh–Ritz steps ----------------------------------------------
 // After a Ritz step the block holds Ritz vectors V (A2) with values theta and C V (A1).  The eigenvalues
 // that are NOT wanted lie in [0, b] with b <= theta_l (the smallest Ritz value of the block bounds
@@ -658,30 +598,15 @@ __global__ void k_signs(const double* __restrict__ colmax, double* __restrict__ 
     sgn[threadIdx.x] = colmax[threadIdx.x] < 0 ? -1.0 : 1.0;
 }
 
-// out[0] = max_{i < n_pc} rho_i / theta_i (NaN-propagating), out[1] = status bits,
-// out[2] = theta[l_act - 1] / theta[n_pc - 1]: the smallest Ritz value of the block over the last wanted
-// one — an upper estimate of the per-application convergence factor of the wanted pairs
-__global__ void k_resid_scalar(const double* __restrict__ rho, const double* __restrict__ theta, int n_pc, int l_act,
-                               const int* __restrict__ status, const int* __restrict__ status_sel,
-                               double* __restrict__ out) {
-    if (threadIdx.x != 0) return;
-    double resid = 0.0;
-    for (int i = 0; i < n_pc; ++i) {
-        // relative to the pair's own eigenvalue, but not to less than 1e-5 of the largest one: pairs of a numerically
-        // zero eigenvalue (more components asked than the data have rank) are judged on the scale of the problem
-        // (their absolute residual is ~1e-16 theta_1: 1e-11 on this scale)
-        const double den = theta[i] > 1e-5 * theta[0] ? theta[i] : 1e-5 * theta[0];
-        const double r = den > 0 ? rho[i] / den : rho[i];
-        if (!(r <= resid)) resid = r;
-    }
-    out[0] = resid;
-    out[1] = (double)*status;
-    out[2] = theta[n_pc - 1] > 0 ? theta[l_act - 1] / theta[n_pc - 1] : 1.0;
-    out[3] = status_sel ? (double)*status_sel : 0.0;      // device-side feature selection: bit 0 = NaN variance
-    out[4] = theta[l_act - 1] > 0 ? theta[0] / theta[l_act - 1] : 1.0;      // spread of the block: bounds the filter degree
-}
+#include "jacobi.inl"
 
-// k_ritz_post's partials -> rho[c], colmax[c], then the scalars of k_resid_scalar (same slots of `out`).  1024 threads:
+// k_ritz_post's partials -> rho[c], colmax[c], then the scalars the host reads back per Ritz step:
+//   out[0] = max_{i < n_pc} rho_i / max(theta_i, 1e-5 theta_1) (NaN-propagating; pairs of a numerically zero eigenvalue — more
+//            components asked than the data have rank — are judged on the scale of the problem), out[1] = status bits,
+//   out[2] = theta[l_act - 1] / theta[n_pc - 1]: the smallest Ritz value of the block over the last wanted one — an upper
+//            estimate of the per-application convergence factor of the wanted pairs,
+//   out[3] = status of the device-side feature selection (bit 0 = NaN variance), out[4] = theta_1 / theta_l (spread of the
+//            block: bounds the filter degree).  1024 threads:
 // 16 slices of the blocks per column (a single wave walking 128 x 3 dependent loads took 45 us), combined in fixed order.
 __global__ __launch_bounds__(1024) void k_resid_final(const double* __restrict__ part, int n_blocks, const double* __restrict__ theta,
                                                       int n_pc, int l_act, const int* __restrict__ status,
@@ -722,7 +647,7 @@ __global__ __launch_bounds__(1024) void k_resid_final(const double* __restrict__
     if (threadIdx.x != 0) return;
     double resid = 0.0;
     for (int i = 0; i < n_pc; ++i) {
-        const double den = theta[i] > 1e-5 * theta[0] ? theta[i] : 1e-5 * theta[0];      // (see k_resid_scalar)
+        const double den = theta[i] > 1e-5 * theta[0] ? theta[i] : 1e-5 * theta[0];
         const double q = den > 0 ? s_rho[i] / den : s_rho[i];
         if (!(q <= resid)) resid = q;
     }

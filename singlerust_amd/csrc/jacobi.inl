@@ -1,8 +1,8 @@
-// jacobi.inl — the l x l symmetric eigen-solve of the Rayleigh–Ritz steps (included by pca.hip, inside namespace srx).
+// jacobi.inl — the l x l symmetric eigen-solve of the Rayleigh–Ritz steps (included by pca_solve.hip through iterate.inl, inside namespace srx).
 //
 // k_jacobi_eig2: two-sided cyclic Jacobi on the 64 x 64 projected matrix, round-robin ordering (32 disjoint rotations per
 // round, 63 rounds per sweep), arranged so that a round costs ONE barrier, no index arithmetic and ~half the LDS traffic of
-// k_jacobi_eig (2300 clocks per round there: two barriers, a serial "make the 32 rotations" phase, B and U through LDS):
+// round 2's 1024-thread solver (2300 clocks per round there: two barriers, a serial "make the 32 rotations" phase, B and U through LDS):
 //
 //  * SLOT SPACE.  The matrix lives in LDS in tournament positions: pair m is always slots (2m, 2m + 1), and every round ends
 //    by moving the data one step round the circle (slot 0 fixed, c_0 = slot 1, c_i = slot 2i, c_{63-i} = slot 2i + 1;
@@ -20,7 +20,7 @@
 //    rotation).  Which players sit in pair m at round r is a compile-time constant in the fully unrolled 63-round body:
 //    every register index is static; the wave's only LDS traffic are 32 broadcast 16-byte reads per round.
 //
-// Same interface and outputs as k_jacobi_eig: U (L x L row-major) receives eigenvector c in COLUMN c, eigenvalues
+// Outputs: U (L x L row-major) receives eigenvector c in COLUMN c, eigenvalues
 // descending in theta; rows / columns >= n are 0, theta[c >= n] = 0; kStatEig on non-convergence after 30 sweeps.
 // `off_tol2`: the sweep loop stops when sum_{i<j} a_ij^2 <= off_tol2 * sum_i a_ii^2, measured before a sweep's first round;
 // the solve leaves after that round (the state is one round better than measured; players are back in their own slots).

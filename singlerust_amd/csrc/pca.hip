@@ -21,8 +21,10 @@
 // Either way the scores are one forward SpMM  Z V  (transform, pca/mod.rs:156-185).
 // A is the HVG-COMPACTED matrix (compact.inl): row-major (column, value) records — what the Gram kernel and the forward
 // product read — and, for the matrix-free solver, a tile-major view; everything of size k x 64 is replicated per rank and
-// kept in f64.  This file: the compacted-matrix plumbing, the launches and the driver (run_pca, srx_pca, srx_pipeline,
-// srx_spmm), with backed.inl (out-of-core sessions) at the end.
+// kept in f64.  Three translation units share pca_internal.hpp: pca_form.hip (compaction, owner records, G = A^T A and its
+// exchange across row shards), pca_solve.hip (the sparse products, the k x 64 iteration, the solver driver run_pca,
+// srx_spmm) and this file: feature selection plumbing, the per-matrix driver pca_device, the host copies of the results, the
+// out-of-core sessions (backed.inl) and the C entry points srx_pca / srx_pipeline / srx_result_fetch.
 //
 // Measured on MI355X (profiles/r01_*): LDS f32 float atomics (ds_add_f32) run ~10x slower than
 // ds_add_f64, so every LDS accumulation here is f64; pure-f32 accumulation also stalls at ~2e-5
@@ -31,1523 +33,9 @@
 // Algorithmic bytes per launch, s_v = bytes per stored value:
 //   forward     nnz_w*(4+s_v) + (n_t N+1)*8 + N*64*4 (write Y) + k*64*4 (panel)
 //   transposed  nnz_w*(4+s_v) + (n_t N+1)*8 + N*64*4 (read Y)  + k*64*8 (result)
-#include <algorithm>
-#include <cmath>
-#include <numeric>
-#include <type_traits>
-
-#include "common.hpp"
-#include "log1p64.hpp"
+#include "pca_internal.hpp"
 
 namespace srx {
-
-constexpr int L = 64;               // panel width l
-constexpr int kTThreads = 1024;     // transposed / Gram kernels: one workgroup per CU
-
-int32_t gene_variances(srx_mat* m, std::vector<double>& var);
-int32_t select_hvg_host(srx_ctx* ctx, const std::vector<double>& var, uint64_t n, std::vector<uint64_t>& out);
-int32_t launch_tile_ptr(srx_ctx* ctx, const int64_t* indptr, const int32_t* idx, uint64_t n_rows, int n_tiles,
-                        int tile_genes, int64_t* tp);
-
-#include "compact.inl"
-
-// ---- small vector helpers ------------------------------------------------------------------------
-template <typename PT> struct Vec4;
-template <> struct Vec4<float> {
-    float4 v;
-    __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
-    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
-    __device__ __forceinline__ float& operator[](int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
-};
-template <> struct Vec4<double> {
-    double2 a, b;
-    __device__ __forceinline__ void load(const double* p) {
-        a = *reinterpret_cast<const double2*>(p);
-        b = *reinterpret_cast<const double2*>(p + 2);
-    }
-    __device__ __forceinline__ void store(double* p) const {
-        *reinterpret_cast<double2*>(p) = a;
-        *reinterpret_cast<double2*>(p + 2) = b;
-    }
-    __device__ __forceinline__ double& operator[](int i) { return i == 0 ? a.x : i == 1 ? a.y : i == 2 ? b.x : b.y; }
-};
-
-// DPP row rotate inside each 16-lane row (v_mov_b32_dpp row_ror:S) — no LDS traffic.
-template <int S>
-__device__ __forceinline__ int ror16(int x) {
-    if constexpr (S == 0) return x;
-    else return __builtin_amdgcn_update_dpp(0, x, 0x120 + S, 0xf, 0xf, false);
-}
-template <int S>
-__device__ __forceinline__ float ror16(float x) {
-    return __builtin_bit_cast(float, ror16<S>(__builtin_bit_cast(int, x)));
-}
-template <int S>
-__device__ __forceinline__ double ror16(double x) {
-    long long b = __builtin_bit_cast(long long, x);
-    int lo = ror16<S>((int)(b & 0xffffffffll)), hi = ror16<S>((int)(b >> 32));
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
-__device__ __forceinline__ int64_t readlane64(int64_t x, int l) {
-    int lo = __builtin_amdgcn_readlane((int)(x & 0xffffffffll), l);
-    int hi = __builtin_amdgcn_readlane((int)(x >> 32), l);
-    return ((int64_t)hi << 32) | (uint32_t)lo;
-}
-__device__ __forceinline__ float readlane_v(float x, int l) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
-}
-__device__ __forceinline__ double readlane_v(double x, int l) {
-    return __builtin_bit_cast(double, readlane64(__builtin_bit_cast(long long, x), l));
-}
-
-#include "spmm.inl"
-
-#include "gram.inl"
-
-#include "iterate.inl"
-
-// ---- compacted matrix: row-major records + the tile-major view of the forward SpMM ------------------
-struct CompactCsr {
-    uint64_t n_rows = 0, nnz = 0;
-    int k = 0;
-    int64_t* indptr = nullptr;
-    int32_t* idx = nullptr;
-    void* vals = nullptr;
-};
-struct Tiled {
-    uint64_t n_rows = 0, nnz = 0;
-    int k = 0, kt = 0, nt = 0;
-    int64_t* tptr = nullptr;   // nt * n_rows + 1
-    void* tpk = nullptr;       // GramPk<VT> records: (local column within the tile, value)
-};
-// How G's upper triangle is cut into stripes of SR rows and paired into workgroups (k_gram_stripes)
-struct GramPlan {
-    int k = 0, sr_shift = 0, n_stripes = 0, n_wg = 0;
-    int n_z = 1;               // chunks: the grid is n_wg x n_z workgroups
-    uint32_t rblk = 512;       // cells per bucket block
-    uint32_t n_chunk = 0;      // consecutive row blocks per workgroup
-    uint64_t n_rblk = 0;
-    size_t lds_bytes = 0;
-};
-// X[:, sel] row by row: GramPk<VT> records (compacted column in [0, k), value), columns ascending within a row —
-// what the Gram kernel walks (a suffix of a row is one contiguous run)
-struct RowMajor {
-    uint64_t n_rows = 0, nnz = 0;
-    int k = 0;
-    int64_t* ptr = nullptr;    // n_rows + 1
-    void* pk = nullptr;
-    uint32_t* perm = nullptr;  // rows ordered by their number of kept entries (forward SpMM), or null
-    int64_t n_recs = -1;       // >= 0: the Gram kernel's record counts were made with the compaction (scratch pca_brtot / pca_brbase
-                               // hold them): launch_gram starts at the bucket pass, one host wait less per step
-};
-static int32_t gram_plan(srx_ctx* ctx, int k, uint64_t n_rows, GramPlan& g) {
-    g.k = k;
-    // the largest stripe height whose two stripes fit 64 KiB (two workgroups per CU); one row per stripe up to 160 KiB
-    static const int force_sr = getenv("SRX_GRAM_SR") ? atoi(getenv("SRX_GRAM_SR")) : 0;
-    int sr = 8;
-    while (sr > 1 && (size_t)sr * (size_t)(k + sr) * 8 > 65536) sr >>= 1;
-    if (force_sr == 1 || force_sr == 2 || force_sr == 4 || force_sr == 8) sr = force_sr;
-    g.sr_shift = sr == 8 ? 3 : sr == 4 ? 2 : sr == 2 ? 1 : 0;
-    g.n_stripes = (k + sr - 1) / sr;
-    g.n_stripes += g.n_stripes & 1;
-    g.n_wg = g.n_stripes / 2;
-    size_t widest = 0;
-    for (int w = 0; w < g.n_wg; ++w) {
-        const int a0 = w * sr, b0 = (g.n_stripes - 1 - w) * sr;
-        const size_t wd = (size_t)(k - a0) + (size_t)(k - b0 > 0 ? k - b0 : 0);
-        widest = std::max(widest, wd);
-    }
-    g.lds_bytes = (size_t)sr * widest * 8;
-    if (g.lds_bytes > 163840) return fail(ctx, SRX_E_ARG, "pca: %d selected features exceed the Gram kernel's LDS stripes", k);
-    static const int force_rblk = getenv("SRX_GRAM_RBLK") ? atoi(getenv("SRX_GRAM_RBLK")) : 0;
-    g.rblk = force_rblk > 0 ? (uint32_t)force_rblk : 512u;      // c3: bucket pass + stripe kernel 4.89 ms with 1024-cell blocks, 4.78 with 512, 5.07 with 256
-    g.n_rblk = (n_rows + g.rblk - 1) / g.rblk;
-    const int per_cu = g.lds_bytes <= 65536 ? 2 : 1;
-    // chunks of consecutive row blocks: ~16k cells each, at least one block per wave, and enough chunks to fill the device
-    static const int force_chunk = getenv("SRX_GRAM_CHUNK") ? atoi(getenv("SRX_GRAM_CHUNK")) : 0;
-    uint64_t chunk = force_chunk > 0 ? (uint64_t)force_chunk : std::max<uint64_t>(16384 / g.rblk, kGramWaves);      // c3: 4.5 ms with 16k-cell chunks, 5.2 with 32k, 5.0 with 8k
-    const uint64_t want_wgs = (uint64_t)ctx->n_cus * per_cu;
-    while (chunk > kGramWaves && ((g.n_rblk + chunk - 1) / chunk) * (uint64_t)g.n_wg < want_wgs) chunk /= 2;
-    g.n_chunk = (uint32_t)chunk;
-    int z = (int)((g.n_rblk + chunk - 1) / chunk);
-    if (z < 1) z = 1;
-    g.n_z = z;
-    return SRX_OK;
-}
-static int grid_rows(const srx_ctx* ctx, uint64_t n_rows, int rows_per_block) {
-    uint64_t want = (n_rows + rows_per_block - 1) / rows_per_block;
-    uint64_t cap = (uint64_t)ctx->n_cus * 8;
-    if (want < 1) want = 1;
-    return (int)(want < cap ? want : cap);
-}
-
-// out[0..n] = exclusive scan of in[0..n), out[n] = total (also left in *total_dev).
-int32_t scan_exclusive(srx_ctx* ctx, const int64_t* d_in, uint64_t n, int64_t* d_out, int64_t** total_dev) {
-    const uint64_t per_block = (uint64_t)kScanBlock * kScanItems;
-    const uint64_t nb = (n + per_block - 1) / per_block > 0 ? (n + per_block - 1) / per_block : 1;
-    int64_t* d_bsum;
-    SRX_TRY(scratch(ctx, "scan_bsum", (nb + 1) * sizeof(int64_t), (void**)&d_bsum));
-    int64_t* d_total = d_bsum + nb;
-    hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, d_in, n, d_bsum);
-    hipLaunchKernelGGL(k_scan_serial, dim3(1), dim3(kScanBlock), 0, ctx->stream, d_bsum, nb, d_total);
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, d_in, n, d_bsum, d_total,
-                       d_out);
-    SRX_HIP(ctx, hipGetLastError());
-    if (total_dev) *total_dev = d_total;
-    return SRX_OK;
-}
-
-// (idx, vals) of a compacted CSR -> packed row-major records
-template <typename T>
-__global__ void k_pack_records(const int32_t* __restrict__ idx, const T* __restrict__ vals, uint64_t n,
-                               GramPk<T>* __restrict__ out) {
-    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (; e < n; e += stride) {
-        GramPk<T> r{};
-        r.j = idx[e];
-        r.v = vals[e];
-        out[e] = r;
-    }
-}
-
-// X[:, sel] -> row-major compacted CSR (count, scan, fill); columns renumbered by `remap`.  General route
-// (more than 8192 selected features); `rm` receives the packed-record view of it.
-static int32_t build_compact(srx_mat* m, const std::vector<int32_t>& remap, int k, CompactCsr& c, RowMajor& rm) {
-    srx_ctx* ctx = m->ctx;
-    const uint64_t N = m->n_rows;
-    int32_t* d_remap;
-    int64_t *d_counts, *d_total;
-    SRX_TRY(scratch(ctx, "pca_remap", (remap.size() ? remap.size() : 1) * sizeof(int32_t), (void**)&d_remap));
-    SRX_TRY(h2d(ctx, d_remap, remap.data(), remap.size() * sizeof(int32_t)));
-    SRX_TRY(scratch(ctx, "pca_counts", (N ? N : 1) * sizeof(int64_t), (void**)&d_counts));
-    SRX_TRY(scratch(ctx, "pca_rm_ptr", (N + 1) * sizeof(int64_t), (void**)&c.indptr));
-    const double in_bytes = (double)m->nnz * 4.0 * 2.0 + (double)(N + 1) * 8.0 * 2.0;   // idx read by count + fill
-    ProfScope ps(ctx, SRX_K_COMPACT, in_bytes);
-    hipLaunchKernelGGL(k_compact_count, dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream, m->d_indptr,
-                       m->d_indices, d_remap, N, d_counts);
-    SRX_TRY(scan_exclusive(ctx, d_counts, N, c.indptr, &d_total));
-    int64_t total = 0;
-    SRX_TRY(d2h(ctx, &total, d_total, sizeof(int64_t)));
-    c.nnz = (uint64_t)total;
-    c.n_rows = N;
-    c.k = k;
-    const size_t vb = val_bytes(m);
-    SRX_TRY(scratch(ctx, "pca_cidx", (c.nnz ? c.nnz : 1) * sizeof(int32_t), (void**)&c.idx));
-    SRX_TRY(scratch(ctx, "pca_cvals", (c.nnz ? c.nnz : 1) * vb, &c.vals));
-    const size_t pb = vb == 4 ? sizeof(GramPk<float>) : sizeof(GramPk<double>);
-    SRX_TRY(scratch(ctx, "pca_rm_pk", (c.nnz + 64) * pb, &rm.pk));
-    // the 64 entries behind the last row are READ by the forward kernel (a row's last chunk runs past its end: value masked
-    // to 0, column used as is): they must name a real column, or 0 x panel[garbage] is NaN
-    SRX_HIP(ctx, hipMemsetAsync((char*)rm.pk + c.nnz * pb, 0, 64 * pb, ctx->stream));
-    const unsigned pg = (unsigned)std::min<uint64_t>((c.nnz + 255) / 256 + 1, 65536);
-    if (is_f32(m)) {
-        hipLaunchKernelGGL((k_compact_fill<float>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream, m->d_indptr,
-                           m->d_indices, (const float*)m->d_values, d_remap, N, c.indptr, c.idx, (float*)c.vals);
-        hipLaunchKernelGGL((k_pack_records<float>), dim3(pg), dim3(256), 0, ctx->stream, c.idx, (const float*)c.vals, c.nnz,
-                           (GramPk<float>*)rm.pk);
-    } else {
-        hipLaunchKernelGGL((k_compact_fill<double>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream,
-                           m->d_indptr, m->d_indices, (const double*)m->d_values, d_remap, N, c.indptr, c.idx,
-                           (double*)c.vals);
-        hipLaunchKernelGGL((k_pack_records<double>), dim3(pg), dim3(256), 0, ctx->stream, c.idx, (const double*)c.vals, c.nnz,
-                           (GramPk<double>*)rm.pk);
-    }
-    SRX_HIP(ctx, hipGetLastError());
-    rm.n_rows = N;
-    rm.nnz = c.nnz;
-    rm.k = k;
-    rm.ptr = c.indptr;
-    if (ctx->prof_mask & (1u << SRX_K_COMPACT)) ctx->prof[SRX_K_COMPACT].bytes += (double)c.nnz * (4.0 + vb) * 3.0;
-    return SRX_OK;
-}
-
-// Tile-major copy of a compacted CSR for gene tiles of kt columns (cut, scan, copy).
-static int32_t retile(srx_mat* m, const CompactCsr& c, int kt, Tiled& t) {
-    srx_ctx* ctx = m->ctx;
-    const uint64_t N = c.n_rows;
-    const size_t vb = val_bytes(m);
-    const std::string tag = "pca_t" + std::to_string(kt) + "_";
-    t.n_rows = N;
-    t.nnz = c.nnz;
-    t.k = c.k;
-    t.kt = kt;
-    t.nt = (c.k + kt - 1) / kt;
-    int64_t* d_tp = nullptr;
-    if (t.nt > 1) {
-        SRX_TRY(scratch(ctx, "pca_tp", (size_t)(t.nt - 1) * (N ? N : 1) * sizeof(int64_t), (void**)&d_tp));
-        SRX_TRY(launch_tile_ptr(ctx, c.indptr, c.idx, N, t.nt, kt, d_tp));
-    }
-    const uint64_t nseg = (uint64_t)t.nt * N;
-    int64_t* d_seglen;
-    SRX_TRY(scratch(ctx, "pca_seglen", (nseg ? nseg : 1) * sizeof(int64_t), (void**)&d_seglen));
-    SRX_TRY(scratch(ctx, (tag + "ptr").c_str(), (nseg + 1) * sizeof(int64_t), (void**)&t.tptr));
-    uint64_t g = (nseg + 255) / 256;
-    if (g < 1) g = 1;
-    if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(k_seglen, dim3((unsigned)g), dim3(256), 0, ctx->stream, c.indptr, d_tp, N, t.nt, d_seglen);
-    SRX_TRY(scan_exclusive(ctx, d_seglen, nseg, t.tptr, nullptr));
-    // +64 records of padding: the forward kernel reads 16-wide chunks unconditionally
-    const size_t pb = vb == 4 ? sizeof(GramPk<float>) : sizeof(GramPk<double>);
-    SRX_TRY(scratch(ctx, (tag + "pk").c_str(), (c.nnz + 64) * pb, &t.tpk));
-    SRX_HIP(ctx, hipMemsetAsync((char*)t.tpk + c.nnz * pb, 0, 64 * pb, ctx->stream));
-    if (is_f32(m))
-        hipLaunchKernelGGL((k_retile<float>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream, c.indptr, d_tp, c.idx,
-                           (const float*)c.vals, N, t.nt, kt, t.tptr, (GramPk<float>*)t.tpk);
-    else
-        hipLaunchKernelGGL((k_retile<double>), dim3(grid_rows(ctx, N, 4)), dim3(256), 0, ctx->stream, c.indptr, d_tp,
-                           c.idx, (const double*)c.vals, N, t.nt, kt, t.tptr, (GramPk<double>*)t.tpk);
-    SRX_HIP(ctx, hipGetLastError());
-    return SRX_OK;
-}
-
-// Fast path: the 256-tiled layout and the row-major records straight from X (count, two scans, fill); needs
-// <= 64 tiles of 128 columns (k <= 8192) because lane t of a wave is the counter of tile t.
-static int32_t alloc_tiled(srx_mat* m, uint64_t N, uint64_t nnz, int k, int kt, Tiled& t) {
-    srx_ctx* ctx = m->ctx;
-    const size_t vb = val_bytes(m);
-    const std::string tag = "pca_t" + std::to_string(kt) + "_";
-    t.n_rows = N;
-    t.nnz = nnz;
-    t.k = k;
-    t.kt = kt;
-    t.nt = (k + kt - 1) / kt;
-    const size_t pb = vb == 4 ? sizeof(GramPk<float>) : sizeof(GramPk<double>);
-    SRX_TRY(scratch(ctx, (tag + "pk").c_str(), (nnz + 64) * pb, &t.tpk));
-    SRX_HIP(ctx, hipMemsetAsync((char*)t.tpk + nnz * pb, 0, 64 * pb, ctx->stream));
-    return SRX_OK;
-}
-
-// `d_sel`: n_words selection bits followed by n_words prefix counts, on the device (the compacted column of a
-// gene is its rank among the selected genes in ascending gene order)
-static int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words, int k, RowMajor& rm, Tiled* t256p, RowXf xf = RowXf{},
-                                 bool want_recs = false) {
-    Tiled t256_dummy;
-    Tiled& t256 = t256p ? *t256p : t256_dummy;          // the 256-tiled view is only made for the matrix-free solver
-    srx_ctx* ctx = m->ctx;
-    const uint64_t N = m->n_rows;
-    const int nt128 = (k + KG - 1) / KG, nt256 = t256p ? (k + KT - 1) / KT : 0;
-    int64_t *cntrow, *cnt256, *d_total;
-    const size_t sel_lds = 2 * (size_t)n_words * sizeof(uint32_t);
-    if (sel_lds > 60000) return fail(ctx, SRX_E_ARG, "pca: %llu genes exceed the LDS selection table", (unsigned long long)m->n_cols);
-    const uint64_t n256 = (uint64_t)nt256 * N;
-    SRX_TRY(scratch(ctx, "pca_cntrow", (N ? N : 1) * sizeof(int64_t), (void**)&cntrow));
-    SRX_TRY(scratch(ctx, "pca_cnt256", (n256 ? n256 : 1) * sizeof(int64_t), (void**)&cnt256));
-    SRX_TRY(scratch(ctx, "pca_rm_ptr", (N + 1) * sizeof(int64_t), (void**)&rm.ptr));
-    SRX_TRY(scratch(ctx, "pca_t256_ptr", (n256 + 1) * sizeof(int64_t), (void**)&t256.tptr));
-    // (A single-pass form — count, decoupled look-back over groups of 8 rows, fill from the indices still in L2; the output
-    //  size known beforehand from the cached per-gene counts — was built and measured in round 3: 3.0 ms against 1.73 for
-    //  count + scan + fill.  The groups have to stay small for the second walk to hit L2 (16 KB of L2 per resident
-    //  workgroup), and 162 500 groups make the prefix chain the bound: 64 groups per ~1.5 us hop.  It also needs every wave
-    //  of the grid resident, which the occupancy query over-promised at 8 workgroups per CU.  Not kept.)
-    const double s_i = m->d_idx16 ? 2.0 : 4.0;          // bytes per column index streamed by the passes
-    const size_t pb = is_f32(m) ? sizeof(GramPk<float>) : sizeof(GramPk<double>);
-    // algorithmic bytes: the column indices of the whole matrix once per pass (count, fill) + row pointers in, row pointers
-    // out; the KEPT values read and the compacted entries written are added below, once their number is known
-    ProfScope ps(ctx, SRX_K_COMPACT, (double)m->nnz * s_i * ((!t256p && m->n_cols <= 65536 && !getenv("SRX_COMPACT_NOLIST")) ? 1.0 : 2.0) +
-                                         (double)(N + 1) * 8.0 * 2.0);
-    const size_t cnt_lds = sel_lds + 4 * (size_t)kCompactRows * kWave * sizeof(uint32_t);      // + 8 x 64 counters per wave
-    static const bool no_list = getenv("SRX_COMPACT_NOLIST") != nullptr;       // A/B switch
-    const bool list = !t256p && m->n_cols <= 65536 && !no_list;
-    uint32_t* kept = nullptr;
-    if (list) {
-        SRX_TRY(scratch(ctx, "pca_keptlist", (m->nnz + 64) * sizeof(uint32_t), (void**)&kept));
-        if (m->d_idx16)
-            hipLaunchKernelGGL((k_rowcount_list<uint16_t>), dim3(grid_rows(ctx, N, 4)), dim3(256), sel_lds, ctx->stream, m->d_indptr,
-                               (const uint16_t*)m->d_idx16, d_sel, d_sel + n_words, n_words, N, k, cntrow, kept);
-        else
-            hipLaunchKernelGGL((k_rowcount_list<int32_t>), dim3(grid_rows(ctx, N, 4)), dim3(256), sel_lds, ctx->stream, m->d_indptr,
-                               (const int32_t*)m->d_indices, d_sel, d_sel + n_words, n_words, N, k, cntrow, kept);
-    } else if (!t256p) {
-        const size_t bits_lds = (size_t)n_words * sizeof(uint32_t);
-        if (m->d_idx16)
-            hipLaunchKernelGGL((k_rowcount<uint16_t>), dim3(grid_rows(ctx, N, 4)), dim3(256), bits_lds, ctx->stream, m->d_indptr,
-                               (const uint16_t*)m->d_idx16, d_sel, n_words, N, cntrow);
-        else
-            hipLaunchKernelGGL((k_rowcount<int32_t>), dim3(grid_rows(ctx, N, 4)), dim3(256), bits_lds, ctx->stream, m->d_indptr,
-                               (const int32_t*)m->d_indices, d_sel, n_words, N, cntrow);
-    } else if (m->d_idx16)
-        hipLaunchKernelGGL((k_tcount<uint16_t>), dim3(grid_rows(ctx, N, 4)), dim3(256), cnt_lds, ctx->stream, m->d_indptr,
-                           (const uint16_t*)m->d_idx16, d_sel, d_sel + n_words, n_words, N, nt128, nt256, k, cntrow, cnt256);
-    else
-        hipLaunchKernelGGL((k_tcount<int32_t>), dim3(grid_rows(ctx, N, 4)), dim3(256), cnt_lds, ctx->stream, m->d_indptr,
-                           (const int32_t*)m->d_indices, d_sel, d_sel + n_words, n_words, N, nt128, nt256, k, cntrow, cnt256);
-    SRX_TRY(scan_exclusive(ctx, cntrow, N, rm.ptr, &d_total));
-    // The Gram kernel's record counts only need the row lengths: made HERE, before the read-back of the compacted size, so
-    // that both numbers come back behind ONE drain of the stream (the second wait cost ~90 us of idle device per step)
-    int64_t* d_nrecs = nullptr;
-    rm.n_recs = -1;
-    if (want_recs && N > 0) {
-        GramPlan g;
-        SRX_TRY(gram_plan(ctx, k, N, g));
-        int64_t *blk_total, *rec_base;
-        SRX_TRY(scratch(ctx, "pca_brtot", g.n_rblk * sizeof(int64_t), (void**)&blk_total));
-        SRX_TRY(scratch(ctx, "pca_brbase", (g.n_rblk + 1) * sizeof(int64_t), (void**)&rec_base));
-        hipLaunchKernelGGL(k_rec_count, dim3((unsigned)g.n_rblk), dim3(256), 0, ctx->stream, (const int64_t*)rm.ptr, N, g.rblk, blk_total);
-        hipLaunchKernelGGL(k_rec_scan, dim3(1), dim3(1024), 0, ctx->stream, (const int64_t*)blk_total, g.n_rblk, rec_base);
-        SRX_HIP(ctx, hipGetLastError());
-        d_nrecs = rec_base + g.n_rblk;
-    }
-    int64_t total = 0;
-    SRX_TRY(d2h(ctx, &total, d_total, sizeof(int64_t)));
-    if (d_nrecs) SRX_TRY(d2h(ctx, &rm.n_recs, d_nrecs, sizeof(int64_t)));     // (the stream has drained: a copy, no wait)
-    if (t256p) {
-        SRX_TRY(scan_exclusive(ctx, cnt256, n256, t256.tptr, nullptr));
-        SRX_TRY(alloc_tiled(m, N, (uint64_t)total, k, KT, t256));
-    }
-    SRX_TRY(scratch(ctx, "pca_rm_pk", ((size_t)total + 64) * pb, &rm.pk));
-    // the 64 entries behind the last row are READ by the forward kernel (a row's last chunk runs past its end: value masked
-    // to 0, column used as is): they must name a real column, or 0 x panel[garbage] is NaN
-    SRX_HIP(ctx, hipMemsetAsync((char*)rm.pk + (size_t)total * pb, 0, 64 * pb, ctx->stream));
-    rm.n_rows = N;
-    rm.nnz = (uint64_t)total;
-    rm.k = k;
-    auto fill = [&](auto kern, const auto* idxp, const auto* valp, auto* rmp, auto* pk256) {
-        hipLaunchKernelGGL(kern, dim3(grid_rows(ctx, N, 4)), dim3(256), sel_lds, ctx->stream, m->d_indptr, idxp, valp, d_sel,
-                           d_sel + n_words, n_words, N, nt256, k, cnt256, rm.ptr, t256.tptr, xf.row_sum, xf.target, rmp, pk256);
-    };
-    auto fill_t = [&](auto tval, auto* rmp, auto* pk256) {
-        using T = decltype(tval);
-        const T* valp = (const T*)m->d_values;
-        if (m->d_idx16) {
-            const uint16_t* ip = (const uint16_t*)m->d_idx16;
-            if (xf.row_sum) fill(k_tfill<T, uint16_t, true>, ip, valp, rmp, pk256);
-            else fill(k_tfill<T, uint16_t, false>, ip, valp, rmp, pk256);
-        } else {
-            const int32_t* ip = (const int32_t*)m->d_indices;
-            if (xf.row_sum) fill(k_tfill<T, int32_t, true>, ip, valp, rmp, pk256);
-            else fill(k_tfill<T, int32_t, false>, ip, valp, rmp, pk256);
-        }
-    };
-    if (list) {
-        const unsigned g2 = (unsigned)grid_rows(ctx, N, 8);
-        if (is_f32(m)) {
-            if (xf.row_sum) hipLaunchKernelGGL((k_tfill_list<float, true>), dim3(g2), dim3(256), 0, ctx->stream, m->d_indptr, (const float*)m->d_values, kept, N, rm.ptr, xf.row_sum, xf.target, (GramPk<float>*)rm.pk);
-            else hipLaunchKernelGGL((k_tfill_list<float, false>), dim3(g2), dim3(256), 0, ctx->stream, m->d_indptr, (const float*)m->d_values, kept, N, rm.ptr, xf.row_sum, xf.target, (GramPk<float>*)rm.pk);
-        } else {
-            if (xf.row_sum) hipLaunchKernelGGL((k_tfill_list<double, true>), dim3(g2), dim3(256), 0, ctx->stream, m->d_indptr, (const double*)m->d_values, kept, N, rm.ptr, xf.row_sum, xf.target, (GramPk<double>*)rm.pk);
-            else hipLaunchKernelGGL((k_tfill_list<double, false>), dim3(g2), dim3(256), 0, ctx->stream, m->d_indptr, (const double*)m->d_values, kept, N, rm.ptr, xf.row_sum, xf.target, (GramPk<double>*)rm.pk);
-        }
-    } else if (is_f32(m)) fill_t(float{}, (GramPk<float>*)rm.pk, (GramPk<float>*)t256.tpk);
-    else fill_t(double{}, (GramPk<double>*)rm.pk, (GramPk<double>*)t256.tpk);
-    SRX_HIP(ctx, hipGetLastError());
-    if (ctx->prof_mask & (1u << SRX_K_COMPACT))
-    {
-        ctx->prof[SRX_K_COMPACT].bytes += (double)total * (val_bytes(m) + (double)pb * (t256p ? 2.0 : 1.0));   // kept values read, entries written once or twice
-        if (list) ctx->prof[SRX_K_COMPACT].aux_bytes += (double)total * 4.0 * 2.0;      // the list of kept entries: written, read
-    }
-    return SRX_OK;
-}
-
-// host-side selection (srx_pca with an explicit feature list): bitmask + prefix counts from the remap table
-static int32_t build_tiled_fused(srx_mat* m, const std::vector<int32_t>& remap, int k, RowMajor& rm, Tiled* t256, RowXf xf = RowXf{},
-                                 bool want_recs = false) {
-    srx_ctx* ctx = m->ctx;
-    const int n_words = (int)((remap.size() + 31) / 32);
-    std::vector<uint32_t> hsel(2 * (size_t)n_words, 0u);
-    for (size_t g = 0; g < remap.size(); ++g)
-        if (remap[g] >= 0) hsel[g >> 5] |= 1u << (g & 31);
-    uint32_t run = 0;
-    for (int w = 0; w < n_words; ++w) {
-        hsel[n_words + w] = run;
-        run += (uint32_t)__builtin_popcount(hsel[w]);
-    }
-    uint32_t* d_sel;
-    SRX_TRY(scratch(ctx, "pca_selbits", (hsel.size() ? hsel.size() : 1) * sizeof(uint32_t), (void**)&d_sel));
-    SRX_TRY(h2d(ctx, d_sel, hsel.data(), hsel.size() * sizeof(uint32_t)));
-    return build_tiled_fused(m, d_sel, n_words, k, rm, t256, xf, want_recs);
-}
-
-// ---- launches ---------------------------------------------------------------------------------
-template <typename VT, typename PT>
-static int32_t launch_fwd(srx_ctx* ctx, const Tiled& c, const PT* P, const PT* cvec, PT* Y, double* scores = nullptr,
-                          int n_pc = 0, int ld = 0) {
-    // the output is either the N x 64 panel product (SpMM solver) or, for the transform, the N x n_pc f64 scores
-    const double out_bytes = scores ? (double)c.n_rows * n_pc * 8.0 : (double)c.n_rows * L * sizeof(PT);
-    const double bytes = (double)c.nnz * (4.0 + sizeof(VT)) + (double)((uint64_t)c.nt * c.n_rows + 1) * 8.0 + out_bytes +
-                         (double)c.k * L * sizeof(PT);
-    const size_t lds = (size_t)KT * L * sizeof(PT);
-    constexpr int kRowsPerWg = (kFwdThreads / 16) * FwdCfg<PT>::kRows;
-    const uint64_t n_blocks = (c.n_rows + kRowsPerWg - 1) / kRowsPerWg;
-    const int per_cu = sizeof(PT) == 4 ? 2 : 1;                 // 64 KiB vs 128 KiB of LDS per workgroup
-    uint64_t grid = (uint64_t)ctx->n_cus * per_cu;
-    if (grid > n_blocks) grid = n_blocks;
-    if (grid < 1) grid = 1;
-    ProfScope ps(ctx, SRX_K_SPMM_FWD, bytes);
-    SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_spmm_fwd<VT, PT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds));
-    hipLaunchKernelGGL((k_spmm_fwd<VT, PT>), dim3((unsigned)grid), dim3(kFwdThreads), lds, ctx->stream, c.tptr,
-                       (const GramPk<VT>*)c.tpk, c.n_rows, c.nt, c.k, P, cvec, Y, scores, n_pc, ld ? ld : n_pc);
-    SRX_HIP(ctx, hipGetLastError());
-    return SRX_OK;
-}
-
-// Forward product from the row-major records (k_spmm_rows); false when the panel slice does not fit the LDS (the caller
-// falls back on the tile-major kernel).
-// Lanes per row of the row-major forward kernel: the widest panel slice (4 Q columns of all k genes) that fits the LDS;
-// 0 when even one lane's four columns do not (the caller falls back on the tile-major kernel).
-template <typename PT>
-static int fwd_rows_q(int k) {
-    const size_t budget = 163840 - 64;
-    for (int q = sizeof(PT) == 4 ? 4 : 2; q >= 1; q >>= 1)
-        if ((size_t)k * 4 * q * sizeof(PT) <= budget) return q;
-    return 0;
-}
-// (the row-major forward kernel takes any k: beyond the widest single slice it walks the genes in ranges)
-template <typename VT, typename PT>
-static bool fwd_rows_fits(int) { return true; }
-template <typename VT, typename PT>
-static int32_t launch_fwd_rows(srx_ctx* ctx, const RowMajor& r, const PT* P, const PT* cvec, int n_cols, double* scores, PT* Y,
-                               int ld) {
-    const int Qr = fwd_rows_q<PT>(r.k);
-    auto go = [&](auto qtag, auto rtag, auto cltag, int k_lo, int k_hi, int accumulate) -> int32_t {
-        constexpr int Q = decltype(qtag)::value;
-        constexpr bool RANGE = decltype(rtag)::value;
-        constexpr int CL = decltype(cltag)::value;
-        constexpr int C = CL * Q;
-        const int n_slices = (n_cols + C - 1) / C;
-        // (a gene's 16 f32 columns are 64 bytes, so every 16-byte read of a wave's 16 cells starts in bank 0 or 16: half of
-        //  the LDS pipe's time goes to bank conflicts, profiles/r03_pmc_spmm.md.  A padded stride of 80 bytes was measured:
-        //  0.746 against 0.745 ms — the multiplication is hidden behind the kernel's reads and stores either way)
-        const int ldp = C;
-        const size_t lds = (size_t)(k_hi - k_lo) * ldp * sizeof(PT);
-        const uint64_t groups = kFwdRowsThreads / Q;
-        uint64_t n_wg = (r.n_rows + groups - 1) / groups;
-        // one workgroup per CU at a time (the panel slice fills the LDS), eight in a row: shorter workgroups even out the CUs
-        // (c3, f32: 1 / 2 / 4 / 8 / 16 / 32 per CU: 0.73 / 0.71 / 0.70 / 0.69 / 0.68 / 0.77 ms; f64 panels 1.37 -> 1.30 at 8)
-        uint64_t cap = std::max<uint64_t>(1, (uint64_t)ctx->n_cus * 8 / n_slices);
-        if (cap > 8) cap &= ~(uint64_t)7;           // (whole rounds of the 8 XCDs: the slices of a row range share an L2)
-        if (n_wg > cap) n_wg = cap;
-        if (n_wg < 1) n_wg = 1;
-        const double out_bytes = scores ? (double)r.n_rows * n_cols * 8.0 : (double)r.n_rows * L * sizeof(PT);
-        ProfScope ps(ctx, SRX_K_SPMM_FWD, (double)r.nnz * sizeof(GramPk<VT>) + (double)(r.n_rows + 1) * 8.0 + out_bytes +
-                                              (double)(k_hi - k_lo) * L * sizeof(PT) + (r.perm ? (double)r.n_rows * 4.0 : 0.0));
-        SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_spmm_rows<VT, PT, Q, RANGE, CL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_spmm_rows<VT, PT, Q, RANGE, CL>), dim3((unsigned)(n_wg * n_slices)), dim3(kFwdRowsThreads), lds, ctx->stream,
-                           r.ptr, (const GramPk<VT>*)r.pk, (const uint32_t*)r.perm, r.n_rows, r.k, P, cvec, n_cols, scores, Y, ld, ldp,
-                           k_lo, k_hi, accumulate, 0);
-        SRX_HIP(ctx, hipGetLastError());
-        return SRX_OK;
-    };
-    using No = std::false_type;
-    using Yes = std::true_type;
-    using C4 = std::integral_constant<int, 4>;
-    using C5 = std::integral_constant<int, 5>;
-    // five columns per lane where the wider slice fits the LDS, saves a pass over the matrix (n_pc = 50: 3 slices of 20 instead
-    // of 4 of 16; 5 of 10 instead of 7 of 8 with f64 panels) and stays inside the panel's 64 columns
-    constexpr int Qmax = sizeof(PT) == 4 ? 4 : 2;
-    const int wide_slices = (n_cols + 5 * Qmax - 1) / (5 * Qmax), narrow_slices = (n_cols + 4 * Qmax - 1) / (4 * Qmax);
-    // (f32 panels: 3 slices of 20 columns measured the same 0.64-0.70 ms as 4 of 16 — the launch is not bound by its passes, §3c —
-    //  with the LDS pipe 66 % busy instead of 51 (the 80-byte gene stride conflicts more) and 1.8 GB fetched instead of 1.2:
-    //  the wide form is for f64 panels, 1.85 -> 1.35 ms; SRX_FWD_WIDE=1 forces it)
-    const bool wide = Qr == Qmax && (size_t)r.k * 5 * Qmax * sizeof(PT) <= (size_t)163840 && wide_slices < narrow_slices &&
-                      wide_slices * 5 * Qmax <= L && (sizeof(PT) == 8 || getenv("SRX_FWD_WIDE")) && !getenv("SRX_FWD_NARROW");
-    if (wide) return go(std::integral_constant<int, Qmax>{}, No{}, C5{}, 0, r.k, 0);
-    if (Qr == 4) {
-        if constexpr (sizeof(PT) == 4) return go(std::integral_constant<int, 4>{}, No{}, C4{}, 0, r.k, 0);
-        else return SRX_E_ARG;
-    }
-    if (Qr == 2) return go(std::integral_constant<int, 2>{}, No{}, C4{}, 0, r.k, 0);
-    if (Qr == 1) return go(std::integral_constant<int, 1>{}, No{}, C4{}, 0, r.k, 0);
-    // wider than one slice of four columns: gene ranges of the widest slice, one launch each, the later ones accumulating
-    const int per = (int)((163840 - 64) / (4 * sizeof(PT)));
-    for (int k_lo = 0, i = 0; k_lo < r.k; k_lo += per, ++i)
-        SRX_TRY(go(std::integral_constant<int, 1>{}, Yes{}, C4{}, k_lo, std::min(r.k, k_lo + per), i > 0 ? 1 : 0));
-    return SRX_OK;
-}
-
-// rows ordered by their number of kept entries (k_spmm_rows); r.ptr must be complete
-static int32_t build_row_order(srx_ctx* ctx, RowMajor& r) {
-    uint32_t* hist;
-    SRX_TRY(scratch(ctx, "pca_rm_lenhist", kLenBins * sizeof(uint32_t), (void**)&hist));
-    SRX_TRY(scratch(ctx, "pca_rm_perm", (r.n_rows ? r.n_rows : 1) * sizeof(uint32_t), (void**)&r.perm));
-    SRX_HIP(ctx, hipMemsetAsync(hist, 0, kLenBins * sizeof(uint32_t), ctx->stream));
-    const unsigned g = (unsigned)((r.n_rows + kLenRowsPerWg - 1) / kLenRowsPerWg + (r.n_rows ? 0 : 1));
-    hipLaunchKernelGGL(k_len_hist, dim3(g), dim3(256), 0, ctx->stream, r.ptr, r.n_rows, hist);
-    hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(kLenBins), 0, ctx->stream, hist);
-    hipLaunchKernelGGL(k_len_scatter, dim3(g), dim3(256), 0, ctx->stream, r.ptr, r.n_rows, hist, r.perm);
-    SRX_HIP(ctx, hipGetLastError());
-    return SRX_OK;
-}
-
-template <typename VT, typename YT>
-static int32_t launch_t(srx_ctx* ctx, const Tiled& c, const YT* Y, double* T /* k*L + L */) {
-    uint64_t want = (uint64_t)(2 * ctx->n_cus) / (uint64_t)c.nt;
-    if (want < 1) want = 1;
-    uint64_t by_rows = (c.n_rows + 255) / 256;
-    if (by_rows < 1) by_rows = 1;
-    const uint64_t n_rb = want < by_rows ? want : by_rows;
-    const uint64_t rpb = (c.n_rows + n_rb - 1) / n_rb > 0 ? (c.n_rows + n_rb - 1) / n_rb : 1;
-    double *part, *part_s;
-    SRX_TRY(scratch(ctx, "pca_tpart", n_rb * (size_t)c.k * L * sizeof(double), (void**)&part));
-    SRX_TRY(scratch(ctx, "pca_tpart_s", n_rb * L * sizeof(double), (void**)&part_s));
-    const size_t lds = (size_t)KT * L * sizeof(double);
-    const double bytes = (double)c.nnz * (4.0 + sizeof(VT)) + (double)((uint64_t)c.nt * c.n_rows + 1) * 8.0 +
-                         (double)c.n_rows * L * sizeof(YT) + (double)c.k * L * 8.0;
-    {
-        ProfScope ps(ctx, SRX_K_SPMM_T, bytes);
-        SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_spmm_t<VT, YT, double>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_spmm_t<VT, YT, double>), dim3((unsigned)(n_rb * c.nt)), dim3(kTThreads), lds, ctx->stream,
-                           c.tptr, (const GramPk<VT>*)c.tpk, c.n_rows, c.k, c.nt, rpb, Y, part, part_s);
-        uint64_t tot = (uint64_t)c.k * L + L;
-        hipLaunchKernelGGL((k_t_reduce<double>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, part,
-                           part_s, c.k, n_rb, T);
-    }
-    SRX_HIP(ctx, hipGetLastError());
-    return SRX_OK;
-}
-
-// The Gram kernel's second half runs on a stream whose CU mask leaves `kCommFreeCus` CUs alone when the rows are sharded: the
-// collective's workgroups (RCCL: one per channel, persistent) then find a CU with room whatever the dispatcher does with the
-// stripe kernel's 10 000 queued workgroups — measured in round 3: a second stream's first kernel sat 2.8 ms in its queue
-// beside that grid, stream priority or not.  6 % of the CUs cost the half launch ~0.1 ms.
-constexpr int kCommFreeCus = 16;
-static int32_t ensure_comm_streams(srx_ctx* ctx) {
-    if (!ctx->comm_stream) {
-        SRX_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
-        SRX_HIP(ctx, hipEventCreateWithFlags(&ctx->comm_fork, hipEventDisableTiming));
-        SRX_HIP(ctx, hipEventCreateWithFlags(&ctx->comm_join, hipEventDisableTiming));
-    }
-    if (!ctx->gram_stream) {
-        uint32_t mask[8];
-        const int n_cus = ctx->n_cus > 256 ? 256 : ctx->n_cus;
-        for (int w = 0; w < 8; ++w) mask[w] = 0u;
-        for (int c = 0; c < n_cus; ++c)
-            if (c >= kCommFreeCus) mask[c >> 5] |= 1u << (c & 31);
-        if (n_cus <= 2 * kCommFreeCus ||
-            hipExtStreamCreateWithCUMask(&ctx->gram_stream, (uint32_t)((n_cus + 31) / 32), mask) != hipSuccess) {
-            (void)hipGetLastError();
-            SRX_HIP(ctx, hipStreamCreateWithFlags(&ctx->gram_stream, hipStreamNonBlocking));
-            ctx->gram_stream_masked = false;
-        } else {
-            ctx->gram_stream_masked = true;
-        }
-        SRX_HIP(ctx, hipEventCreateWithFlags(&ctx->gram_fork, hipEventDisableTiming));
-        SRX_HIP(ctx, hipEventCreateWithFlags(&ctx->gram_join, hipEventDisableTiming));
-    }
-    return SRX_OK;
-}
-
-// G += A^T A of the row-major compacted matrix, into the packed upper triangle `Gp` (k (k + 1) / 2 doubles; the
-// caller zeroes it for a fresh sum): owner buckets, then the stripe kernel.
-// `reduce` (nullable): sum the triangle over the ranks HERE, the first half of the owners' rows on the communication stream
-// while the second half is still being computed (*reduce is set when that was done; otherwise the caller's all-reduce follows).
-// Whether the exchange is split is decided from rank-invariant data only (k, the communicator): a rank WITHOUT rows — more
-// ranks than non-empty rows, a skewed cut, a filter that emptied a shard — skips the kernels and issues the same three
-// collectives with the same counts as everybody else.
-template <typename VT>
-static int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce = nullptr) {
-    if (reduce) *reduce = false;
-    GramPlan g;
-    SRX_TRY(gram_plan(ctx, rm.k, rm.n_rows, g));
-    static const bool force_split = getenv("SRX_GRAM_OVERLAP") != nullptr;      // test switch: the split with a 1-rank communicator
-    const int h = g.n_wg / 2;
-    const bool split = reduce && comm_is_rccl(ctx) && (ctx->n_ranks > 1 || force_split) && h >= 1 && g.n_wg - h >= 1;
-    const bool empty = rm.n_rows == 0;
-    if (empty && !split) return SRX_OK;
-    uint32_t* boff = nullptr;
-    int64_t *blk_total = nullptr, *rec_base = nullptr;
-    GramRec<VT>* recs = nullptr;
-    int64_t n_recs = 0;
-    if (!empty) {
-        SRX_TRY(scratch(ctx, "pca_boff", g.n_rblk * (size_t)(g.n_wg + 1) * sizeof(uint32_t), (void**)&boff));
-        SRX_TRY(scratch(ctx, "pca_brtot", g.n_rblk * sizeof(int64_t), (void**)&blk_total));
-        SRX_TRY(scratch(ctx, "pca_brbase", (g.n_rblk + 1) * sizeof(int64_t), (void**)&rec_base));
-        // SRX_K_BUCKET: record counts, their read-back, the bucket pass — the compacted matrix read once (twice through L2),
-        // the records written once
-        ProfScope ps(ctx, SRX_K_BUCKET, (double)rm.nnz * sizeof(GramPk<VT>) + (double)(rm.n_rows + 1) * 8.0 * 2.0);
-        // how many records each block makes (a suffix longer than a wave is several), and where its records start
-        if (rm.n_recs >= 0) {
-            n_recs = rm.n_recs;                  // counted with the compaction (build_tiled_fused): blk_total / rec_base are filled
-        } else {
-            hipLaunchKernelGGL(k_rec_count, dim3((unsigned)g.n_rblk), dim3(256), 0, ctx->stream, rm.ptr, rm.n_rows, g.rblk, blk_total);
-            hipLaunchKernelGGL(k_rec_scan, dim3(1), dim3(1024), 0, ctx->stream, blk_total, g.n_rblk, rec_base);
-            SRX_HIP(ctx, hipGetLastError());
-            SRX_TRY(d2h(ctx, &n_recs, rec_base + g.n_rblk, sizeof(int64_t)));
-        }
-        SRX_TRY(scratch(ctx, "pca_brecs", ((size_t)n_recs + kGramUnroll) * sizeof(GramRec<VT>), (void**)&recs));
-        if (ctx->prof_mask & (1u << SRX_K_BUCKET)) ctx->prof[SRX_K_BUCKET].bytes += (double)n_recs * sizeof(GramRec<VT>);
-        SRX_HIP(ctx, hipMemsetAsync(recs + n_recs, 0, kGramUnroll * sizeof(GramRec<VT>), ctx->stream));
-        hipLaunchKernelGGL((k_bucket<VT>), dim3((unsigned)g.n_rblk), dim3(kBucketThreads),
-                           (size_t)(g.n_wg + 1 + g.rblk + 1 + kBucketGroup) * sizeof(uint32_t), ctx->stream, rm.ptr,
-                           (const GramPk<VT>*)rm.pk, rm.n_rows, g.rblk, rm.k, g.sr_shift, g.n_wg, g.n_stripes, rec_base, boff, recs);
-        SRX_HIP(ctx, hipGetLastError());
-    }
-    // SRX_K_GRAM: the stripe kernel alone.  Algorithmic bytes = what ANY Gram kernel must move: the compacted matrix and its
-    // row pointers read once, the packed triangle written once.  The owner records and block offsets are this kernel's own
-    // auxiliary input (aux bytes).  Every row suffix is read once per kept entry of its row (from L2 / Infinity Cache): that
-    // shows up in the PMC traffic, not here.
-    ProfScope ps(ctx, SRX_K_GRAM, (double)rm.nnz * sizeof(GramPk<VT>) + (double)(rm.n_rows + 1) * 8.0 + (double)rm.k * (rm.k + 1) / 2 * 8.0,
-                 nullptr, (double)n_recs * sizeof(GramRec<VT>) + (double)g.n_rblk * (g.n_wg + 1) * 4.0);
-    if (!empty) SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_gram_stripes<VT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
-    auto launch = [&](int w0, int n_w, hipStream_t st) {
-        if (empty) return;
-        hipLaunchKernelGGL((k_gram_stripes<VT>), dim3((unsigned)(n_w * g.n_z)), dim3(kGramWaves * kWave), g.lds_bytes, st,
-                           rm.ptr, (const GramPk<VT>*)rm.pk, boff, rec_base, recs, g.n_rblk, g.rblk, rm.k, g.sr_shift, g.n_wg,
-                           g.n_stripes, g.n_chunk, w0, n_w, Gp);
-    };
-    // Sharded rows: owner w holds the stripes w and n_stripes - 1 - w, so the owners [0, h) hold the rows [0, h SR) and
-    // [k - h SR, k) of the triangle — two contiguous ranges of the packed array — and the others the rows between.  Two
-    // launches; the first one's ranges go round the ranks (RCCL, communication stream) under the second launch — which runs
-    // on the CU-masked stream, so that the collective's workgroups have CUs of their own —, the middle range after it: half
-    // of the 16 MB exchange is hidden.  (One launch on a single rank: the owners of a chunk share what they pull into L2,
-    // and halving them costs more than nothing.)
-    if (split) {
-        SRX_TRY(ensure_comm_streams(ctx));
-        const int SR = 1 << g.sr_shift, k = rm.k;
-        const int r_lo = std::min(k, h * SR), r_hi = std::min(k, std::max(r_lo, (g.n_stripes - h) * SR));      // rows [0, r_lo) + [r_hi, k): the first launch
-        auto off = [&](int row) { return (size_t)row * (size_t)k - (size_t)row * (size_t)(row - 1) / 2; };      // packed offset of (row, row)
-        launch(0, h, ctx->stream);
-        SRX_HIP(ctx, hipGetLastError());
-        SRX_HIP(ctx, hipEventRecord(ctx->comm_fork, ctx->stream));
-        SRX_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->comm_fork, 0));
-        SRX_TRY(allreduce_f64_on(ctx, Gp, off(r_lo), ctx->comm_stream));
-        SRX_TRY(allreduce_f64_on(ctx, Gp + off(r_hi), off(k) - off(r_hi), ctx->comm_stream));
-        // second half of the owners on the masked stream, joined back into the context's stream
-        SRX_HIP(ctx, hipEventRecord(ctx->gram_fork, ctx->stream));
-        SRX_HIP(ctx, hipStreamWaitEvent(ctx->gram_stream, ctx->gram_fork, 0));
-        launch(h, g.n_wg - h, ctx->gram_stream);
-        SRX_HIP(ctx, hipGetLastError());
-        SRX_HIP(ctx, hipEventRecord(ctx->gram_join, ctx->gram_stream));
-        SRX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->gram_join, 0));
-        // the middle rows: on the communication stream too (one stream for all of the communicator's collectives in
-        // flight), after the second launch
-        SRX_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->gram_join, 0));
-        SRX_TRY(allreduce_f64_on(ctx, Gp + off(r_lo), off(r_hi) - off(r_lo), ctx->comm_stream));
-        SRX_HIP(ctx, hipEventRecord(ctx->comm_join, ctx->comm_stream));
-        SRX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->comm_join, 0));
-        *reduce = true;
-        ctx->gram_splits++;
-        return SRX_OK;
-    }
-    launch(0, g.n_wg, ctx->stream);
-    SRX_HIP(ctx, hipGetLastError());
-    return SRX_OK;
-}
-static size_t gram_packed_count(int k) { return (size_t)k * (size_t)(k + 1) / 2; }
-
-// ---- the driver ---------------------------------------------------------------------------------
-struct Resolved {
-    int n_pc, center, scale, max_iter, solver;
-    double bail_ratio = 0.0; // > 0: give the round up after its first Ritz step when theta_l / theta_npc exceeds this (the
-                             // caller has a plan with more guard columns per round)
-    bool direct = false;     // k <= 64 with the explicit matrix: the block is the identity, one exact eigen-solve of C
-    bool robust = false;     // last resort after a breakdown: CholeskyQR after every application of C, shifted
-                             // CholeskyQR3, plain sweeps instead of Chebyshev filters
-    int power = 1;           // applications of C per Rayleigh–Ritz step
-    int warm = 0;            // leading sweeps of `power` applications + CholeskyQR WITHOUT a Rayleigh–Ritz step
-    double tol;
-    uint64_t seed;
-};
-
-static uint64_t mix64(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
-
-struct Work {                   // k x 64 f64 state, replicated per rank
-    double *W, *Wp, *T, *A1, *A2, *small, *mu, *d, *gpart;
-    double *dHG, *dM, *dM2, *dTheta, *dRho, *dColmax, *dSgn, *dDinv;
-};
-
-static int32_t alloc_work(srx_ctx* ctx, int k, Work& w) {
-    const size_t kl = (size_t)k * L;
-    SRX_TRY(scratch(ctx, "pca_W", kl * 8, (void**)&w.W));
-    SRX_TRY(scratch(ctx, "pca_Wp", kl * 8, (void**)&w.Wp));
-    SRX_TRY(scratch(ctx, "pca_T", (kl + L) * 8, (void**)&w.T));
-    SRX_TRY(scratch(ctx, "pca_A1", kl * 8, (void**)&w.A1));
-    SRX_TRY(scratch(ctx, "pca_A2", kl * 8, (void**)&w.A2));
-    SRX_TRY(scratch(ctx, "pca_small", (6 * L * L + 8 * L) * 8, (void**)&w.small));
-    SRX_TRY(scratch(ctx, "pca_mu", (size_t)k * 8, (void**)&w.mu));
-    SRX_TRY(scratch(ctx, "pca_d", (size_t)k * 8, (void**)&w.d));
-    SRX_TRY(scratch(ctx, "pca_g2part", (size_t)kGram2Blocks * 2 * L * L * 8, (void**)&w.gpart));
-    w.dHG = w.small;                    // H then G, contiguous 2 x L x L
-    w.dM = w.small + 2 * L * L;
-    w.dM2 = w.small + 3 * L * L;
-    w.dTheta = w.small + 4 * L * L;
-    w.dRho = w.dTheta + L;
-    w.dColmax = w.dRho + L;
-    w.dSgn = w.dColmax + L;
-    w.dDinv = w.dSgn + L;
-    return SRX_OK;
-}
-
-static int32_t gram2(srx_ctx* ctx, const Work& w, const double* A, const double* B, int k) {
-    int nb = (k + 31) / 32;                    // one 32-row slab per workgroup where the block count allows
-    if (nb > kGram2Blocks) nb = kGram2Blocks;
-    if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(k_gram2_part, dim3(nb), dim3(1024), 0, ctx->stream, A, B, k, w.gpart);
-    hipLaunchKernelGGL(k_gram2_reduce, dim3((2 * L * L + 255) / 256), dim3(256), 0, ctx->stream, w.gpart, nb, w.dHG);
-    SRX_HIP(ctx, hipGetLastError());
-    return SRX_OK;
-}
-
-// Run `enqueue` (kernel launches / async memsets and copies on ctx->stream, no host synchronisation, no
-// allocation) through a cached hipGraph: captured the first time a key is seen, one hipGraphLaunch afterwards.
-// The key must name everything the launches depend on (shapes, schedule, device pointers).  Any failure of the
-// graph machinery switches the context back to plain launches for good.
-template <typename Fn>
-static int32_t graphed(srx_ctx* ctx, bool enable, const std::string& key, Fn&& enqueue) {
-    if (!enable || ctx->graphs_off) return enqueue();
-    auto it = ctx->graphs.find(key);
-    if (it == ctx->graphs.end()) {
-        if (ctx->graphs.size() >= 32) {                     // stale keys (scratch regrown): start over
-            for (auto& kv : ctx->graphs) (void)hipGraphExecDestroy(kv.second);
-            ctx->graphs.clear();
-        }
-        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
-            (void)hipGetLastError();
-            ctx->graphs_off = true;
-            return enqueue();
-        }
-        ctx->capturing = true;
-        const int32_t rc = enqueue();
-        ctx->capturing = false;
-        hipGraph_t g = nullptr;
-        const hipError_t e = hipStreamEndCapture(ctx->stream, &g);
-        hipGraphExec_t ex = nullptr;
-        if (rc == SRX_OK && e == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess) {
-            (void)hipGraphDestroy(g);
-            it = ctx->graphs.emplace(key, ex).first;
-        } else {
-            if (g) (void)hipGraphDestroy(g);
-            (void)hipGetLastError();
-            ctx->graphs_off = true;
-            return rc != SRX_OK ? rc : enqueue();
-        }
-    }
-    SRX_HIP(ctx, hipGraphLaunch(it->second, ctx->stream));
-    return SRX_OK;
-}
-
-// Block subspace iteration with Rayleigh–Ritz on span(W); `apply(W, Wp)` computes Wp = C W.
-// On return w.A2 = W U holds the Ritz vectors (k x 64, leading n_pc columns meaningful),
-// theta their Ritz values, w.dColmax the largest-|.| entry of each Ritz vector.
-template <typename Apply>
-static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, const Resolved& o, Apply&& apply,
-                                const void* apply_id, bool graphable, const int* d_status_sel, double& resid, int& iters,
-                                bool& converged) {
-    const size_t kl = (size_t)k * L;
-    const bool use_graph = graphable && !getenv("SRX_NO_GRAPH");
-    const bool use_cheb = l_act > o.n_pc && !o.robust && !o.direct && !getenv("SRX_NO_CHEB");      // both solvers: the filter only needs `apply`
-    const bool jacobi_old = getenv("SRX_JACOBI_OLD") != nullptr;       // A/B switch: the 1024-thread kernel with U in LDS
-    constexpr int kSlots = srx_ctx::kAsyncSlots, kSlotDoubles = 8;
-    if (!ctx->pin_async) {
-        SRX_HIP(ctx, hipHostMalloc((void**)&ctx->pin_async, kSlots * kSlotDoubles * sizeof(double), hipHostMallocDefault));
-        for (auto& e : ctx->async_ev) SRX_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-    int* d_status;
-    double* d_res;
-    SRX_TRY(scratch(ctx, "pca_status", 256, (void**)&d_status));
-    SRX_TRY(scratch(ctx, "pca_res", kSlots * kSlotDoubles * sizeof(double), (void**)&d_res));
-    double* d_ritz;
-    SRX_TRY(scratch(ctx, "pca_ritzpart", (size_t)kRitzBlocks * 3 * L * sizeof(double), (void**)&d_ritz));
-    SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_jacobi_eig, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)kJacobiLds));
-    SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_jacobi_eig2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(J2Lds)));
-    // what a captured segment depends on besides its own schedule: shapes, options, every buffer it touches
-    char key0[256];
-    snprintf(key0, sizeof key0, "k%d l%d p%d w%d r%d n%d s%llu|%p %p %p %p %p %p %p %p %p", k, l_act, o.power, o.warm,
-             (o.robust ? 1 : 0) + (o.direct ? 2 : 0) + (jacobi_old ? 4 : 0), o.n_pc,
-             (unsigned long long)o.seed, apply_id, (void*)w.W, (void*)w.Wp, (void*)w.A1, (void*)w.A2, (void*)w.small,
-             (void*)w.gpart, (void*)d_status, (void*)d_status_sel);       // (d_ritz, d_res: allocated with d_status, never regrown)
-    const std::string key_base(key0);
-
-    // Everything below only ENQUEUES work: the l x l factorisations run on the device, and the one
-    // number the host needs per Rayleigh–Ritz step (the residual) comes back through a pinned slot
-    // and an event, read one step late so that the stream never drains.
-
-    // orthonormalise src -> W  (CholeskyQR: G = src^T src = R^T R, W = src R^-1; src == W is fine: every
-    // thread of the substitution owns one row); G lands in dHG + L*L
-    auto gram1 = [&](const double* A, const double* B) -> int32_t {       // partial sums of A^T B in w.gpart
-        int nb = (k + 31) / 32;
-        if (nb > kGram1Blocks) nb = kGram1Blocks;
-        hipLaunchKernelGGL(k_gram1_part, dim3(nb), dim3(1024), 0, ctx->stream, A, B, k, w.gpart);
-        SRX_HIP(ctx, hipGetLastError());
-        return nb;
-    };
-    auto orth = [&](const double* src) -> int32_t {
-        if (o.robust) {
-            SRX_TRY(gram2(ctx, w, src, src, k));
-            hipLaunchKernelGGL(k_chol_factor, dim3(1), dim3(1024), 0, ctx->stream, w.dHG + L * L, l_act, w.dM, w.dDinv, d_status, 1);
-        } else {
-            const int32_t nb = gram1(src, src);
-            if (nb < 0) return nb;
-            hipLaunchKernelGGL(k_chol_factor_panels, dim3(1), dim3(1024), 0, ctx->stream, (const double*)w.gpart, nb, l_act, w.dM, w.dDinv, d_status);
-        }
-        hipLaunchKernelGGL(k_trsm_rows, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, src, w.dM, w.dDinv, k, w.W);
-        SRX_HIP(ctx, hipGetLastError());
-        if (o.robust) {                         // second pass: the first one may have run on a shifted Gram matrix
-            SRX_TRY(gram2(ctx, w, w.W, w.W, k));
-            hipLaunchKernelGGL(k_chol_factor, dim3(1), dim3(1024), 0, ctx->stream, w.dHG + L * L, l_act, w.dM, w.dDinv, d_status, 1);
-            hipLaunchKernelGGL(k_trsm_rows, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, (const double*)w.W, w.dM, w.dDinv, k, w.W);
-            SRX_HIP(ctx, hipGetLastError());
-        }
-        return SRX_OK;
-    };
-    // `n` applications of C starting from `src`, ping-ponging between Wp and A1 (no copies); returns where
-    // the result is
-    auto apply_n = [&](const double* src, int n, const double** out) -> int32_t {
-        const double* cur = src;
-        for (int t = 0; t < n; ++t) {
-            double* dst = (cur == w.Wp) ? w.A1 : w.Wp;
-            SRX_TRY(apply(cur, dst, false));
-            cur = dst;
-        }
-        *out = cur;
-        return SRX_OK;
-    };
-    // one Rayleigh–Ritz step on span(W): Wp = C W, H = W^T Wp = U diag(theta) U^T, Ritz vectors
-    // A2 = W U, residuals || C v_i - theta_i v_i || in f64; slot <- (residual, status)
-    // `loose`: the step after the warm-up.  Its residuals are O(1e-2) whatever the eigen-solver does (it only feeds the
-    // filter's bounds and the rotated start), and the tail of the 64-column block holds clustered Ritz values that cost
-    // the cyclic Jacobi two slow sweeps: it may stop at an off-diagonal norm of 1e-5 of the diagonal (7 -> 5 sweeps).  The
-    // residuals are measured on the vectors actually formed, so a loosely rotated basis is judged as what it is: at the
-    // default tolerances (1e-7 / 1e-9) such a step is never accepted as converged — the next, exact one decides.
-    auto ritz_kernels = [&](int slot, bool loose = false, bool wp_zero = false) -> int32_t {
-        SRX_TRY(apply(w.W, w.Wp, wp_zero));
-        if (jacobi_old) {
-            SRX_TRY(gram2(ctx, w, w.W, w.Wp, k));
-            hipLaunchKernelGGL(k_jacobi_eig, dim3(1), dim3(1024), kJacobiLds, ctx->stream, w.dHG, l_act, w.dM2, w.dTheta,
-                               d_status, loose ? 1e-10 : 1e-30);
-            hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.Wp, w.dM2, k, w.A1);
-            hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, w.W, w.dM2, k, w.A2);
-            hipLaunchKernelGGL(k_col_resid, dim3(1), dim3(1024), 0, ctx->stream, w.A1, w.A2, w.dTheta, k, w.dRho, w.dColmax);
-            hipLaunchKernelGGL(k_resid_scalar, dim3(1), dim3(64), 0, ctx->stream, w.dRho, w.dTheta, o.n_pc, l_act, d_status,
-                               d_status_sel, d_res + kSlotDoubles * slot);
-        } else {
-            // H = W^T (C W) as partial sums -> eigen-solve (adds them on load) -> Ritz vectors, C x Ritz vectors, residual and
-            // largest-entry partials in one pass -> the step's scalars: 4 launches (9 on the old route)
-            const int32_t nb = gram1(w.W, w.Wp);
-            if (nb < 0) return nb;
-            // the step after the warm-up only feeds the filter's bounds and the rotated start (any invertible U spans the same
-            // block): off-diagonal norm 1e-3 of the diagonal is enough — the Ritz residual it reports, 1.63e-3 at c3, is the same
-            // to three digits as with 1e-5 (1.62e-3), one Jacobi sweep less; at 1e-2 it reads 1.7e-2 and the filter takes a degree more
-            static const double loose_tol2 = getenv("SRX_JACOBI_LOOSE") ? atof(getenv("SRX_JACOBI_LOOSE")) : 1e-6;
-            hipLaunchKernelGGL(k_jacobi_eig2, dim3(1), dim3(kJ2Threads), sizeof(J2Lds), ctx->stream, (const double*)w.gpart, nb, l_act,
-                               w.dM2, w.dTheta, d_status, loose ? loose_tol2 : 1e-30);
-            hipLaunchKernelGGL(k_ritz_post, dim3(kRitzBlocks), dim3(256), 0, ctx->stream, (const double*)w.W, (const double*)w.Wp,
-                               (const double*)w.dM2, (const double*)w.dTheta, k, w.A1, w.A2, d_ritz);
-            hipLaunchKernelGGL(k_resid_final, dim3(1), dim3(1024), 0, ctx->stream, (const double*)d_ritz, kRitzBlocks,
-                               (const double*)w.dTheta, o.n_pc, l_act, d_status, d_status_sel, w.dRho, w.dColmax,
-                               d_res + kSlotDoubles * slot);
-        }
-        SRX_HIP(ctx, hipGetLastError());
-        return SRX_OK;
-    };
-    // the read-back of a Ritz step (pinned slot + event): always a plain stream operation, never captured
-    auto ritz_readback = [&](int slot) -> int32_t {
-        SRX_HIP(ctx, hipMemcpyAsync(ctx->pin_async + kSlotDoubles * slot, d_res + kSlotDoubles * slot,
-                                    kSlotDoubles * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        SRX_HIP(ctx, hipEventRecord(ctx->async_ev[slot], ctx->stream));
-        return SRX_OK;
-    };
-    // the extra applications of C between two Rayleigh–Ritz steps (cheap dense products only; the
-    // block stays well conditioned: kappa ~ (theta_1/theta_l)^power) and the next CholeskyQR
-    auto advance = [&]() -> int32_t {
-        // continue from the ROTATED block A1 = (C W) U (same span): its columns are close to eigenvectors,
-        // so the next projected matrix is close to diagonal and its Jacobi solve takes 2-3 sweeps, not 8
-        const double* res;
-        SRX_TRY(apply_n(w.A1, o.power - 1, &res));
-        return orth(res);
-    };
-    double spread = 1.0;               // theta_1 / theta_l of the last collected Ritz step
-    auto collect = [&](int slot, double& r, double& ratio) -> int32_t {
-        SRX_HIP(ctx, hipEventSynchronize(ctx->async_ev[slot]));
-        r = ctx->pin_async[kSlotDoubles * slot];
-        const int st = (int)ctx->pin_async[kSlotDoubles * slot + 1];
-        ratio = ctx->pin_async[kSlotDoubles * slot + 2];
-        spread = ctx->pin_async[kSlotDoubles * slot + 4];
-        if ((int)ctx->pin_async[kSlotDoubles * slot + 3] & 1)
-            return fail(ctx, SRX_E_NAN, "NaN gene variance: called `Option::unwrap()` on a `None` value (partial_cmp)");
-        if (st & kStatChol) return fail(ctx, SRX_E_NOCONV, "pca: block lost rank (Cholesky pivot <= 0)");
-        if (st & kStatEig) return fail(ctx, SRX_E_NOCONV, "pca: l x l eigen-solver did not converge");
-        if (r != r) return fail(ctx, SRX_E_NOCONV, "pca: NaN in the Ritz residual");
-        return SRX_OK;
-    };
-    // one sweep WITHOUT a Rayleigh–Ritz step: `power` applications of C, then CholeskyQR
-    auto plain_sweep = [&]() -> int32_t {
-        const double* res;
-        SRX_TRY(apply_n(w.W, o.power, &res));
-        return orth(res);
-    };
-
-    // segment "start": random block, CholeskyQR2, warm-up sweeps (the first Ritz residuals are O(1) whatever
-    // happens — no Rayleigh–Ritz step to learn that), first Ritz step
-    auto seg_start = [&]() -> int32_t {
-        SRX_HIP(ctx, hipMemsetAsync(d_status, 0, 256, ctx->stream));
-        if (o.direct) {                    // W = I (k x k, k = l_act): H = C itself, Ritz pairs = eigenpairs whatever the rank
-            hipLaunchKernelGGL(k_identity_block, dim3((unsigned)((kl + 255) / 256)), dim3(256), 0, ctx->stream, k, w.W);
-            SRX_HIP(ctx, hipGetLastError());
-            return ritz_kernels(0, false);
-        }
-        // With a warm-up sweep the random block goes straight into C^power: the CholeskyQR that ends the sweep is the first
-        // orthonormalisation the block needs (the conditioning of C^power W is that of the operator's spectrum whether or not
-        // the Gaussian W — kappa ~ 1.4 at k = 2000, l = 64 — was orthonormalised first).  Without one (matrix-free solver,
-        // robust mode) the Rayleigh-Ritz step needs an orthonormal block: CholeskyQR2 on the random start.
-        const bool start_orth = o.robust || o.warm < 1;
-        hipLaunchKernelGGL(k_init_block, dim3((unsigned)((kl + 255) / 256)), dim3(256), 0, ctx->stream, o.seed, k, l_act,
-                           start_orth ? w.Wp : w.W);
-        if (start_orth) {
-            SRX_TRY(orth(w.Wp));
-            SRX_TRY(orth(w.W));
-        }
-        for (int sweep = 0; sweep < o.warm; ++sweep) SRX_TRY(plain_sweep());
-        return ritz_kernels(0, true);
-    };
-    // Chebyshev filter after the first Ritz step (Gram solver: w.T is free and `apply` has no collective).
-    // Speculative part: Y1 and Z = C Y1 (needed whatever the degree turns out to be, d >= 2).
-    const unsigned cheb_grid = (unsigned)((kl + 255) / 256);
-    auto cheb_spec = [&]() -> int32_t {
-        hipLaunchKernelGGL(k_cheb_first, dim3(cheb_grid), dim3(256), 0, ctx->stream, w.A1, (const double*)w.A2,
-                           (const double*)w.dTheta, l_act, kl);
-        SRX_HIP(ctx, hipGetLastError());
-        return apply(w.A1, w.Wp, false);
-    };
-    // the rest of a degree-d filter (Z = C Y1 is in Wp, cur = A1, prev = A2), CholeskyQR, Ritz step
-    auto cheb_rest = [&](int d, int slot) -> int32_t {
-        double *cur = w.A1, *prev = w.A2;
-        for (int j = 1; j < d; ++j) {
-            if (j > 1) SRX_TRY(apply(cur, w.Wp, true));          // (the step before left Wp zeroed)
-            hipLaunchKernelGGL(k_cheb_step, dim3(cheb_grid), dim3(256), 0, ctx->stream, w.Wp,
-                               (const double*)cur, prev, (const double*)w.dTheta, l_act, kl);
-            double* t = cur;
-            cur = prev;
-            prev = t;
-        }
-        hipLaunchKernelGGL(k_cheb_scale, dim3(cheb_grid), dim3(256), 0, ctx->stream, cur, (const double*)w.dTheta, l_act, d, kl);
-        SRX_HIP(ctx, hipGetLastError());
-        SRX_TRY(orth(cur));
-        return ritz_kernels(slot, false, true);          // (Wp: zeroed by the last filter step, untouched by the CholeskyQR)
-    };
-    // segment "next": [advance] + (m - 1) plain sweeps + a Ritz step into `slot`
-    auto seg_next = [&](bool with_advance, int m, int slot) -> int32_t {
-        if (with_advance) SRX_TRY(advance());
-        for (int sI = 1; sI < m; ++sI) SRX_TRY(plain_sweep());
-        return ritz_kernels(slot);
-    };
-
-    resid = INFINITY;
-    converged = false;
-    iters = 0;                         // sweeps after the warm-up
-    int n_ritz = 0, slot = 0;
-    int q_applied = o.warm * o.power + 1;          // applications of C the block has seen (warm-up + first Ritz step)
-    double r_last = INFINITY, rate_meas = 0.0;
-    int sweeps_since = 0;
-    SRX_TRY(graphed(ctx, use_graph, key_base + "|start", seg_start));
-    SRX_TRY(ritz_readback(slot));
-    for (;;) {
-        ++iters;
-        ++n_ritz;
-        const bool first = n_ritz == 1;
-        const bool cheb = use_cheb;
-        if (cheb && first) SRX_TRY(graphed(ctx, use_graph, key_base + "|cheb0", cheb_spec));   // speculative: Y1, C Y1
-        else if (first && !o.direct) SRX_TRY(graphed(ctx, use_graph, key_base + "|adv", advance));   // speculative: completes this sweep
-        double r, ratio;
-        SRX_TRY(collect(slot, r, ratio));
-        resid = r;
-        if (getenv("SRX_PCA_TRACE"))
-            fprintf(stderr, "[srx pca] sweep %d (ritz step %d): residual %.3e, theta_l/theta_npc %.3e\n", iters + o.warm,
-                    n_ritz, r, ratio);
-        if (r <= o.tol) {
-            converged = true;
-            break;
-        }
-        if (iters >= o.max_iter) break;
-        if (first && o.bail_ratio > 0.0 && ratio > o.bail_ratio) {
-            if (getenv("SRX_PCA_TRACE")) fprintf(stderr, "[srx pca] flat tail (theta_l / theta_npc = %.3f): leaving the round to the safe plan\n", ratio);
-            break;                                 // converged stays false
-        }
-        if (cheb) {
-            // degree: T_d(t_a) >= 4 r / tol with t_a = (2 theta_npc - b) / b = 2 / ratio - 1
-            const double ta = ratio > 0 && ratio < 1 ? 2.0 / ratio - 1.0 : 1.0;
-            int d = 3;
-            if (ta > 1.0) d = (int)std::ceil(std::acosh(std::max(4.0 * r / o.tol, 1.0)) / std::acosh(ta) - 1e-9);
-            // The block captures eigenvector j up to an error ~ (b / lambda_j)^q after q applications of C, and a
-            // degree-d filter multiplies that error (relative to the column's own component) by ~ (lambda_j / b)^d:
-            // with d <= q the leading eigenvectors cannot swamp the other columns.  A degree-12 filter on a block
-            // that had seen ONE application (SpMM solver, no warm-up) collapsed it ("block lost rank").
-            if (d > q_applied) d = q_applied;
-            if (d > 12) d = 12;                // T_12 of the largest t stays far inside f64; harder spectra take more rounds
-            // The filter multiplies the component of every column along the leading eigenvector by T_d(t_1), t_1 =
-            // 2 theta_1 / theta_l - 1, and the guard columns' own components by ~1: whatever rounding-level trace of v_1
-            // a guard column carries (1e-16) must stay small against the column itself, or the block collapses onto the
-            // leading directions and the next CholeskyQR finds a pivot <= 0.  T_d(t_1) <= 1e14 <=> d <= 32.9 / acosh(t_1):
-            // no limit in practice when the block's spectrum spans less than 5x, 6 at 30x, 5 at 100x.
-            {
-                const double t1 = 2.0 * (spread > 1.0 ? spread : 1.0) - 1.0;
-                const int d_safe = t1 > 1.0 + 1e-9 ? (int)std::floor(32.9 / std::acosh(t1)) : 12;
-                if (d > d_safe) d = d_safe;
-            }
-            if (d < 2) d = 2;
-            q_applied += d;                    // d - 1 applications in the filter + the one of the Ritz step
-            iters += (d + o.power - 1) / o.power;      // counted in sweep equivalents (max_iter bounds applications of C)
-            slot = (slot + 1) % kSlots;
-            char kn[64];
-            snprintf(kn, sizeof kn, "|cheb f%d d%d s%d", first ? 1 : 0, d, slot);
-            SRX_TRY(graphed(ctx, use_graph, key_base + kn, [&]() -> int32_t {
-                if (!first) SRX_TRY(cheb_spec());      // later rounds: nothing was queued speculatively
-                return cheb_rest(d, slot);
-            }));
-            SRX_TRY(ritz_readback(slot));
-            if (getenv("SRX_PCA_TRACE")) fprintf(stderr, "[srx pca] Chebyshev filter of degree %d (t_a = %.3f)\n", d, ta);
-            r_last = INFINITY;                 // the filter's gain says nothing about the rate of plain sweeps
-            sweeps_since = 0;
-            continue;
-        }
-        if (r_last < INFINITY && sweeps_since > 0 && r < r_last) rate_meas = std::pow(r / r_last, 1.0 / sweeps_since);
-        double rate = rate_meas > 0.0 ? rate_meas : std::pow(ratio < 1.0 ? ratio : 1.0, (double)o.power);
-        if (!(rate > 1e-8)) rate = 1e-8;
-        if (rate > 0.9) rate = 0.9;
-        int m = (int)std::ceil(std::log(o.tol / r) / std::log(rate) - 1e-9);
-        if (m < 1) m = 1;
-        if (m > 6) m = 6;
-        if (iters + m > o.max_iter) m = o.max_iter - iters;
-        iters += m - 1;
-        slot = (slot + 1) % kSlots;
-        {
-            const bool with_adv = !first;      // the first step's half-sweep was queued speculatively
-            char kn[64];
-            snprintf(kn, sizeof kn, "|next a%d m%d s%d", with_adv ? 1 : 0, m, slot);
-            SRX_TRY(graphed(ctx, use_graph, key_base + kn, [&]() { return seg_next(with_adv, m, slot); }));
-        }
-        SRX_TRY(ritz_readback(slot));
-        r_last = r;
-        sweeps_since = m;
-    }
-    return SRX_OK;
-}
-
-// Components per deflation round when more than L - 8 are asked of a k > L problem (the block keeps 16 guard
-// columns), and the number of rounds; the last round takes everything that is left once <= L dimensions remain.
-constexpr int kPcaPerRound = 48;
-constexpr int kPcaPerRoundSafe = 32;       // the fallback plan: >= 32 guard columns per round (c2, 1000 HVGs, 50 components:
-                                           // 12 -> 19.6 ms, 16 -> 16.3, 24 -> 15.5, 32 -> 10.7)
-// Components per round when at most `per` are asked of one round.
-static std::vector<int> plan_rounds(int k /* dimension of the operator's range */, int n_pc, int per) {
-    std::vector<int> counts;
-    if (k <= L) {                            // the block spans the whole range: one exact round
-        counts.push_back(n_pc);
-        return counts;
-    }
-    int done = 0;
-    while (done < n_pc) {
-        const int take = (k - done <= L) ? n_pc - done : std::min(per, n_pc - done);
-        counts.push_back(take);
-        done += take;
-    }
-    return counts;
-}
-
-// M (64 x 64, row-major) <- diag(s) M: row r scaled by s[r]
-__global__ void k_scale_rows(double* __restrict__ M, const double* __restrict__ s) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < L * L) M[e] *= s[e / L];
-}
-__global__ void k_sub_inplace(double* __restrict__ a, const double* __restrict__ b, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) a[i] -= b[i];
-}
-// columns [at, at + n) of the locked block <- the leading n Ritz vectors / values of a finished round
-__global__ void k_lock_columns(double* __restrict__ Vl, double* __restrict__ thl, const double* __restrict__ V,
-                               const double* __restrict__ theta, int k, int at, int n) {
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (size_t)k * n) return;
-    const int i = (int)(e / n), c = (int)(e % n);
-    Vl[(size_t)i * L + at + c] = V[(size_t)i * L + c];
-    if (i == 0) thl[at + c] = theta[c];
-}
-
-// C -= V diag(theta) V^T over the first n columns of V (k x 64): the resolved eigenpairs leave the operator.
-// theta_c * (v_ic * v_jc) is symmetric in (i, j) to the last bit, so C stays exactly symmetric.
-__global__ void k_deflate(double* __restrict__ C, int k, const double* __restrict__ V, const double* __restrict__ theta, int n) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (uint64_t)k * k) return;
-    const int i = (int)(e / k), j = (int)(e % k);
-    const double* vi = V + (size_t)i * L;
-    const double* vj = V + (size_t)j * L;
-    double s = 0.0;
-    for (int c = 0; c < n; ++c) s += theta[c] * (vi[c] * vj[c]);
-    C[e] -= s;
-}
-
-// Size of a matrix's result allocation: the N x n_pc f64 scores followed by the block of small results
-// (layout: srx_pca_state::d_small) for the most rounds either plan can take.
-// Row stride (in doubles) of the score matrix IN HBM: n_pc rounded up to a whole number of 128-byte pieces (16 doubles), so
-// that the 16-column piece a panel-slice workgroup of the forward SpMM writes for a cell is its own two aligned 64-byte lines
-// — with the reference's N x n_pc layout (400-byte rows at n_pc = 50) every piece straddled lines shared with another
-// slice's workgroup.  srx_result_fetch hands out the dense N x n_pc matrix (obsm["X_pca"], dim_red/mod.rs:105-106) whatever
-// the stride in HBM is.
-static int scores_ld(int n_pc) {
-    static const bool dense = getenv("SRX_EXP_DENSE_SCORES") != nullptr;       // A/B (round 4): the unpadded layout
-    return dense ? n_pc : (n_pc + 15) / 16 * 16;
-}
-static void result_layout(uint64_t n_rows, int k, int n_pc, int dim, size_t& score_bytes, size_t& small_doubles,
-                          std::vector<int>* plan_a_out = nullptr, std::vector<int>* plan_b_out = nullptr) {
-    const size_t kl = (size_t)k * L;
-    const std::vector<int> pa = plan_rounds(dim, n_pc, n_pc <= L - 8 ? n_pc : kPcaPerRound);
-    const int n_b = (n_pc + kPcaPerRoundSafe - 1) / kPcaPerRoundSafe;
-    const std::vector<int> pb = plan_rounds(dim, n_pc, (n_pc + n_b - 1) / n_b);
-    const int rounds_cap = (int)std::max(pa.size(), pb.size());
-    score_bytes = (n_rows ? n_rows : 1) * (size_t)scores_ld(n_pc) * 8;
-    small_doubles = (size_t)rounds_cap * (kl + 2 * L) + 2 * (size_t)k + 2 + ((size_t)k + 1) / 2;
-    if (plan_a_out) *plan_a_out = pa;
-    if (plan_b_out) *plan_b_out = pb;
-}
-static int32_t ensure_result_capacity(srx_ctx* ctx, srx_pca_state& st, size_t need) {
-    if (st.scores_cap < need) {
-        if (st.d_scores) SRX_HIP(ctx, hipFree(st.d_scores));
-        st.d_scores = nullptr;
-        st.scores_cap = 0;
-        SRX_HIP(ctx, hipMalloc((void**)&st.d_scores, need));
-        st.scores_cap = need;
-    }
-    return SRX_OK;
-}
-
-static int32_t launch_writeback(srx_mat* m);
-
-template <typename VT, typename PT>
-static int32_t run_pca(srx_ctx* ctx, const RowMajor* parts, int n_parts, const Tiled* t256p, double* gram_packed,
-                       const Resolved& o, const std::vector<double>& mu, const std::vector<double>& dinv,
-                       const HvgDev* hv, int l_act, double n_cells, srx_pca_state& st) {
-    // `parts`: the row-major compacted rows of this rank — one for a resident matrix, one per row tile in backed mode (then
-    // `gram_packed` holds the packed Gram matrix already summed over the row tiles); `t256p`: the 256-tiled view, made for
-    // the matrix-free solver and for selections too wide for the row kernel's LDS panel slice
-    const RowMajor* rmp = n_parts == 1 ? &parts[0] : nullptr;
-    const int k = parts[0].k;
-    struct { uint64_t n_rows, max_rows; } cc{0, 0};
-    for (int i = 0; i < n_parts; ++i) {
-        cc.n_rows += parts[i].n_rows;
-        cc.max_rows = std::max(cc.max_rows, parts[i].n_rows);
-    }
-    const size_t kl = (size_t)k * L;
-    Work w;
-    st.d_small = nullptr;
-    SRX_TRY(alloc_work(ctx, k, w));
-    if (hv) {                          // selection made on the device: centring / scaling vectors are already there
-        if (o.center) SRX_HIP(ctx, hipMemcpyAsync(w.mu, hv->d_mu, (size_t)k * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        else SRX_HIP(ctx, hipMemsetAsync(w.mu, 0, (size_t)k * 8, ctx->stream));
-        SRX_HIP(ctx, hipMemcpyAsync(w.d, hv->d_dinv, (size_t)k * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    } else {
-        SRX_TRY(h2d(ctx, w.mu, mu.data(), (size_t)k * 8));
-        SRX_TRY(h2d(ctx, w.d, dinv.data(), (size_t)k * 8));
-    }
-    PT *P, *cvec, *Y;
-    SRX_TRY(scratch(ctx, "pca_P", (kl + L) * sizeof(PT), (void**)&P));
-    cvec = P + kl;
-    SRX_TRY(scratch(ctx, "pca_Y", (cc.max_rows ? cc.max_rows : 1) * (size_t)L * sizeof(PT), (void**)&Y));
-
-    double resid = INFINITY;
-    int iters = 0;
-    bool converged = false;
-    // DEFLATION ROUNDS on the explicit C (Gram solver).  A round resolves the next eigenpairs with the 64-column block,
-    // writes their scores, and removes them from C (C -= V diag(theta) V^T), so that the next round's dominant
-    // subspace is the one after them.
-    //   plan A: everything in one round up to 56 components (48 per round beyond) — two Ritz steps when the spectrum
-    //           decays across the block, the normal case;
-    //   plan B: rounds of <= 32 components with 32+ guard columns each.  Taken when plan A breaks down or stalls: a flat
-    //           tail (theta_64 / theta_50 -> 1) needs Chebyshev filters of high total degree, and with the dominant
-    //           eigenvalues still in the operator (theta_1 / theta_64 ~ 20-100) a degree-12 filter amplifies the leading
-    //           directions by T_12(t_1) ~ 1e20 over the guard columns — the block collapses onto them ("Cholesky pivot
-    //           <= 0").  Once a round has deflated the leading eigenpairs the remaining spectrum is narrow and the same
-    //           filters are harmless.
-    const int n_pc = o.n_pc;
-    // dimension of the operator's range: min(k, N - 1) (N when not centred); a block as wide as that is exact
-    const int dim = o.direct ? k : (int)std::min<double>((double)k, n_cells - (o.center ? 1.0 : 0.0));
-    std::vector<int> plan_a, plan_b;
-    size_t score_bytes, small_doubles;
-    result_layout(cc.n_rows, k, n_pc, dim, score_bytes, small_doubles, &plan_a, &plan_b);
-    // one allocation: the scores, then the block of small results (srx_matrix_reserve_results makes it ahead of time)
-    SRX_TRY(ensure_result_capacity(ctx, st, score_bytes + small_doubles * 8));
-    double* const d_small = st.d_scores + score_bytes / 8;
-    // A2 = W U are the Ritz vectors (ascending-gene row order); sign: largest-|.| entry positive.
-    // scores = Z V (transform, pca/mod.rs:156-185): one forward SpMM per row tile with the panel D V, the f64 scores
-    // written by the SpMM itself.  The Ritz vectors, values and signs move out of the (per-context) scratch into
-    // the matrix's own block; their host copies are made by the first fetch (pca_materialize).
-    auto finish_round = [&](int r, int col0, int n_r) -> int32_t {
-        // signs, panel, centring partials and the copy of (Ritz vectors, values, signs) into the result block: one pass
-        double* blk = d_small + (size_t)r * (kl + 2 * L);
-        hipLaunchKernelGGL((k_make_panel_mb<PT>), dim3(kPanelBlocks), dim3(1024), 0, ctx->stream, (const double*)w.A2, (const double*)w.d,
-                           (const double*)w.mu, (const double*)w.dColmax, (const double*)w.dTheta, k, P, w.gpart, w.dSgn, blk);
-        hipLaunchKernelGGL((k_cvec_reduce<PT>), dim3(1), dim3(L), 0, ctx->stream, (const double*)w.gpart, kPanelBlocks, o.center, cvec);
-        SRX_HIP(ctx, hipGetLastError());
-        // scores = Z V: the transform from the row-major records, one launch per row tile (the tile-major kernel — 1.22 ms
-        // at c3 against 0.84 — when its view was made: matrix-free solver, panel slice larger than the LDS, SRX_FWD_TILED)
-        uint64_t row0 = 0;
-        const int ld_s = scores_ld(n_pc);
-        if (t256p) {
-            SRX_TRY((launch_fwd<VT, PT>(ctx, *t256p, P, cvec, Y, st.d_scores + col0, n_r, ld_s)));
-        } else {
-            for (int i = 0; i < n_parts; ++i) {
-                SRX_TRY((launch_fwd_rows<VT, PT>(ctx, parts[i], P, cvec, n_r, st.d_scores + row0 * (size_t)ld_s + col0, (PT*)nullptr, ld_s)));
-                row0 += parts[i].n_rows;
-            }
-        }
-        return SRX_OK;
-    };
-    // Runs a plan of deflation rounds with the solver's `apply`; `reset` restores the undeflated operator, `deflate`
-    // removes the eigenpairs a round has resolved (w.A2 / w.dTheta, leading n columns).  SRX_E_NOCONV (breakdown) or
-    // converged == false (budget spent) leave the decision to the caller.
-    auto run_plan = [&](const std::vector<int>& plan, int budget, bool robust, auto& apply, const void* apply_id, bool graphable,
-                        auto& reset, auto& deflate, double bail = 0.0) -> int32_t {
-        SRX_TRY(reset());
-        resid = 0.0;
-        converged = true;
-        iters = 0;
-        int done = 0;
-        const int rounds = (int)plan.size();
-        for (int r = 0; r < rounds; ++r) {
-            Resolved o_r = o;
-            o_r.n_pc = plan[r];
-            o_r.max_iter = budget;
-            o_r.seed = o.seed + (uint64_t)r;
-            o_r.bail_ratio = bail;
-            if (robust) {                       // CholeskyQR after every application, the same number of applications up front
-                o_r.robust = true;
-                o_r.warm = o.warm * o.power;
-                o_r.power = 1;
-                o_r.max_iter = budget * o.power;
-            }
-            const int l_r = rounds == 1 ? l_act : std::min(L, dim - done);        // dim - done: what is still in the operator
-            double resid_r = INFINITY;
-            int iters_r = 0;
-            bool conv_r = false;
-            {
-                ProfScope ps_it(ctx, SRX_K_ITERATE, (double)k * k * 8.0);
-                SRX_TRY(subspace_iterate(ctx, w, k, l_r, o_r, apply, apply_id, graphable, hv ? hv->d_status : nullptr, resid_r,
-                                         iters_r, conv_r));
-            }
-            resid = std::max(resid, resid_r);
-            iters += iters_r + o.warm;
-            if (!conv_r) {
-                converged = false;
-                return SRX_OK;
-            }
-            SRX_TRY(finish_round(r, done, o_r.n_pc));
-            if (r + 1 < rounds) SRX_TRY(deflate(done, o_r.n_pc));
-            done += o_r.n_pc;
-        }
-        st.rounds = (uint32_t)rounds;
-        st.round_counts = plan;
-        return SRX_OK;
-    };
-    // plan A, then plan B if it stalled or broke down.  One round for everything gets a short budget before the safe
-    // plan takes over; a plan A that already deflates (n_pc > 56) keeps the full one.
-    auto solve = [&](auto& apply, const void* apply_id, bool graphable, auto& reset, auto& deflate) -> int32_t {
-        const bool have_b = plan_b.size() > plan_a.size();
-        if (getenv("SRX_PCA_ROBUST")) {                               // test switch: the last-resort mode from the start
-            SRX_TRY(run_plan(have_b ? plan_b : plan_a, o.max_iter, true, apply, apply_id, graphable, reset, deflate));
-            iters -= o.warm;
-            return SRX_OK;
-        }
-        // (a one-round plan A is also given up at once when its first Ritz step shows a flat tail, theta_64 / theta_npc >
-        //  0.93: such a round needs a total filter degree of 45+ and plan B gets there sooner)
-        int32_t rc = run_plan(plan_a, have_b && plan_a.size() == 1 ? std::min(o.max_iter, 40) : o.max_iter, false, apply, apply_id,
-                              graphable, reset, deflate, have_b && plan_a.size() == 1 ? 0.93 : 0.0);
-        if (have_b && (rc == SRX_E_NOCONV || (rc == SRX_OK && !converged))) {
-            if (getenv("SRX_PCA_TRACE"))
-                fprintf(stderr, "[srx pca] plan A (%zu round(s)) %s at residual %.3e: rounds of <= %d components instead\n",
-                        plan_a.size(), rc == SRX_OK ? "stalled" : "broke down", resid, plan_b[0]);
-            const int spent = iters;
-            rc = run_plan(plan_b, o.max_iter, false, apply, apply_id, graphable, reset, deflate);
-            iters += spent;
-        }
-        if (rc == SRX_E_NOCONV) {
-            // last resort: a block whose spectrum spans more than ~1e8 between two CholeskyQRs (small exact-rank
-            // problems: k = 10 features of 6 cells have theta_1 / theta_5 ~ 1e3 and a sweep is three applications)
-            if (getenv("SRX_PCA_TRACE")) fprintf(stderr, "[srx pca] breakdown again: robust mode (CholeskyQR3 after every application)\n");
-            const int spent = iters;
-            rc = run_plan(have_b ? plan_b : plan_a, o.max_iter, true, apply, apply_id, graphable, reset, deflate);
-            iters += spent;
-        }
-        SRX_TRY(rc);
-        iters -= o.warm;                                              // st.info adds it back once below
-        return SRX_OK;
-    };
-    if (o.solver == 1) {
-        // explicit Gram: G = A^T A once (all-reduced), C = D (G - c N mu mu^T) D dense
-        double* C;
-        SRX_TRY(scratch(ctx, "pca_C", (size_t)k * k * 8, (void**)&C));
-        double* Pk = gram_packed;
-        const size_t n_packed = gram_packed_count(k);
-        if (!Pk) {
-            Range r_("srx:gram");
-            SRX_TRY(scratch(ctx, "pca_gpacked", n_packed * sizeof(double), (void**)&Pk));
-            SRX_HIP(ctx, hipMemsetAsync(Pk, 0, n_packed * sizeof(double), ctx->stream));
-            bool reduced = false;
-            SRX_TRY(launch_gram<VT>(ctx, *rmp, Pk, &reduced));        // (sharded rows: the exchange overlaps the second half)
-            if (!reduced) SRX_TRY(allreduce_f64(ctx, Pk, n_packed));
-        } else {
-            SRX_TRY(allreduce_f64(ctx, Pk, n_packed));            // the one exchange of this solver: the packed upper triangle
-        }
-        if (ctx->wb_after_gram) {
-            srx_mat* wm = ctx->wb_after_gram;
-            ctx->wb_after_gram = nullptr;
-            SRX_TRY(launch_writeback(wm));
-        }
-        auto reset = [&]() -> int32_t {
-            hipLaunchKernelGGL(k_gram_expand, dim3((unsigned)(((size_t)k * k + 255) / 256)), dim3(256), 0, ctx->stream, Pk,
-                               k, (const double*)w.d, (const double*)w.mu, o.center, n_cells, C);
-            SRX_HIP(ctx, hipGetLastError());
-            return SRX_OK;
-        };
-        auto apply = [&](const double* Win, double* Wout, bool out_zeroed) -> int32_t {
-            ProfScope ps(ctx, SRX_K_DENSE, (double)k * k * 8.0 + 2.0 * k * L * 8.0);
-            if (!out_zeroed) SRX_HIP(ctx, hipMemsetAsync(Wout, 0, kl * 8, ctx->stream));
-            hipLaunchKernelGGL(k_dense_apply, dim3((k + 31) / 32, kDenseSplit), dim3(kDenseWaves * 64), 0, ctx->stream, C, Win, k, Wout);
-            SRX_HIP(ctx, hipGetLastError());
-            return SRX_OK;
-        };
-        auto deflate = [&](int, int n_r) -> int32_t {                  // C -= V diag(theta) V^T
-            hipLaunchKernelGGL(k_deflate, dim3((unsigned)(((size_t)k * k + 255) / 256)), dim3(256), 0, ctx->stream, C, k,
-                               (const double*)w.A2, (const double*)w.dTheta, n_r);
-            SRX_HIP(ctx, hipGetLastError());
-            return SRX_OK;
-        };
-        Range r_("srx:iterate");
-        SRX_TRY(solve(apply, C, true, reset, deflate));
-    } else {
-        if (n_parts != 1 || !t256p) return fail(ctx, SRX_E_ARG, "pca: the SpMM solver needs the matrix resident in one piece");
-        const Tiled& t256 = *t256p;
-        if (ctx->wb_after_gram) {
-            srx_mat* wm = ctx->wb_after_gram;
-            ctx->wb_after_gram = nullptr;
-            SRX_TRY(launch_writeback(wm));
-        }
-        // matrix-free: Z^T (Z W) by a forward and a transposed SpMM; resolved eigenpairs are deflated IMPLICITLY,
-        // W' -= V_lock (theta_lock * (V_lock^T W)) with the locked vectors in a k x 64 block (plan B locks <= 48)
-        double* v_lock;
-        SRX_TRY(scratch(ctx, "pca_lock", (kl + L) * 8, (void**)&v_lock));
-        double* th_lock = v_lock + kl;
-        int n_lock = 0;
-        auto reset = [&]() -> int32_t {
-            n_lock = 0;
-            SRX_HIP(ctx, hipMemsetAsync(v_lock, 0, (kl + L) * 8, ctx->stream));
-            return SRX_OK;
-        };
-        auto apply = [&](const double* Win, double* Wout, bool) -> int32_t {
-            hipLaunchKernelGGL((k_make_panel<PT>), dim3(1), dim3(1024), 0, ctx->stream, Win, w.d, w.mu,
-                               (const double*)nullptr, k, o.center, P, cvec);
-            SRX_HIP(ctx, hipGetLastError());
-            // forward product: the row-major batch-stream kernel where its widest slice (8 f64 columns of all k genes: k <= 2559)
-            // fits the LDS — 8 passes over the records, 1.48 against 2.45 ms per application at c3 for the tile-major kernel,
-            // which reads the matrix once whatever k is and stays the route beyond (narrower slices mean 16+ passes)
-            if (parts[0].pk && fwd_rows_q<PT>(k) >= 2 && !getenv("SRX_FWD_TILED"))
-                SRX_TRY((launch_fwd_rows<VT, PT>(ctx, parts[0], P, cvec, L, (double*)nullptr, Y, L)));
-            else SRX_TRY((launch_fwd<VT, PT>(ctx, t256, P, cvec, Y)));
-            SRX_TRY((launch_t<VT, PT>(ctx, t256, Y, w.T)));
-            SRX_TRY(allreduce_f64(ctx, w.T, kl + L));             // the one exchange per iteration
-            hipLaunchKernelGGL(k_finish_t, dim3((unsigned)((kl + 255) / 256)), dim3(256), 0, ctx->stream, w.T, w.d, w.mu,
-                               k, o.center, Wout);
-            SRX_HIP(ctx, hipGetLastError());
-            if (n_lock > 0) {
-                SRX_TRY(gram2(ctx, w, v_lock, Win, k));                               // dHG <- V_lock^T W (64 x 64)
-                hipLaunchKernelGGL(k_scale_rows, dim3((L * L + 255) / 256), dim3(256), 0, ctx->stream, w.dHG, (const double*)th_lock);
-                hipLaunchKernelGGL(k_right_mul, dim3(128), dim3(256), 0, ctx->stream, (const double*)v_lock, (const double*)w.dHG, k, w.T);
-                hipLaunchKernelGGL(k_sub_inplace, dim3((unsigned)((kl + 255) / 256)), dim3(256), 0, ctx->stream, Wout, (const double*)w.T, kl);
-                SRX_HIP(ctx, hipGetLastError());
-            }
-            return SRX_OK;
-        };
-        auto deflate = [&](int, int n_r) -> int32_t {                  // the round's vectors join the locked block
-            if (n_lock + n_r > L) return fail(ctx, SRX_E_ARG, "pca: more than %d locked vectors in the matrix-free solver", L);
-            hipLaunchKernelGGL(k_lock_columns, dim3((unsigned)(((size_t)k * n_r + 255) / 256)), dim3(256), 0, ctx->stream, v_lock,
-                               th_lock, (const double*)w.A2, (const double*)w.dTheta, k, n_lock, n_r);
-            SRX_HIP(ctx, hipGetLastError());
-            n_lock += n_r;
-            return SRX_OK;
-        };
-        SRX_TRY(solve(apply, nullptr, false, reset, deflate));
-    }
-    st.d_small = d_small;
-    st.info.n_iter = (uint32_t)(iters + o.warm);
-    st.info.residual = resid;
-    if (!converged)
-        return fail(ctx, SRX_E_NOCONV, "pca: subspace iteration stopped at max_iter=%d with residual %.3e > tol %.3e",
-                    o.max_iter, resid, o.tol);
-    return SRX_OK;
-}
-
-// Defaults and limits of pca_inplace (dim_red/mod.rs:38-57) and of this solver.
-static int32_t resolve_opts(srx_ctx* ctx, const srx_pca_opts* opts, int k, uint64_t Ng, bool f32, Resolved& o, int& l_act) {
-    // dim_red/mod.rs:38-41: column(0)/column(1) and slice(..5) panic when k < 2 or N < 5
-    if (k < 2 || Ng < 5) return fail(ctx, SRX_E_SHAPE, "pca_inplace needs >= 2 selected features and >= 5 cells (k=%d, N=%llu)",
-                                     k, (unsigned long long)Ng);
-    int want = (!opts || opts->n_components < 0) ? 2 : opts->n_components;      // :52
-    o.n_pc = std::min(want, k);
-    o.center = (!opts || opts->center < 0) ? 1 : (opts->center != 0);           // :55
-    o.scale = (!opts || opts->scale < 0) ? 1 : (opts->scale != 0);              // :56
-    o.max_iter = (opts && opts->max_iter > 0) ? opts->max_iter : 0;          // default set below, once the solver is known
-    o.tol = (opts && opts->tol > 0) ? opts->tol : 0.0;
-    o.seed = opts ? opts->seed : 0;
-    o.solver = opts ? opts->solver : 0;
-    if (o.solver < 0 || o.solver > 2) return fail(ctx, SRX_E_ARG, "pca: solver must be 0 (auto), 1 (gram) or 2 (spmm)");
-    // auto: the explicit Gram matrix as long as it fits (k <= 16384: 2 GB of f64).  At c2's size k = 6000 / 8000 cost
-    // 13.6 / 20.5 ms per pipeline against 23.7 / 30 of the matrix-free iteration, and on a flat-tailed spectrum at
-    // k = 9000 (general compaction route) 105 ms against 297
-    if (o.solver == 0) o.solver = k <= 16384 ? 1 : 2;
-    // a sweep is `power` applications of C: the same default budget of 600 applications for both solvers
-    if (o.max_iter == 0) o.max_iter = o.solver == 1 ? 200 : 600;
-    o.power = o.solver == 1 ? 3 : 1;
-    o.warm = o.solver == 1 ? 2 : 0;
-    if (o.solver == 1 && k > 16384) return fail(ctx, SRX_E_ARG, "pca: the Gram solver holds a k x k f64 matrix; k=%d is too large", k);
-    // default tolerance on the relative Ritz residual: what the arithmetic of the solver supports
-    if (o.tol == 0.0) o.tol = f32 ? 1e-7 : 1e-9;
-    if (o.n_pc < 1) return fail(ctx, SRX_E_ARG, "pca: n_components must be >= 1");
-    if (opts && opts->block != 0 && opts->block != L) return fail(ctx, SRX_E_ARG, "pca: only block = %d is built", L);
-    // Z has rank <= min(k, N - 1) (N when not centred): a block wider than that cannot stay independent under C
-    const uint64_t rank_bound = std::min<uint64_t>((uint64_t)k, Ng - (o.center ? 1 : 0));
-    if ((uint64_t)o.n_pc > rank_bound && !(k <= L && o.solver == 1))
-        return fail(ctx, SRX_E_ARG, "pca: n_components %d exceeds the rank of the data (min(k, N%s) = %llu)", o.n_pc,
-                    o.center ? " - 1" : "", (unsigned long long)rank_bound);
-    l_act = (int)std::min<uint64_t>((uint64_t)L, rank_bound);
-    // k <= 64 with the explicit matrix: the k x k matrix goes straight to the eigen-solver (exact for any rank)
-    if (k <= L && o.solver == 1) {
-        o.direct = true;
-        l_act = k;
-    }
-    if (o.n_pc > l_act && o.solver != 1)
-        return fail(ctx, SRX_E_ARG, "pca: n_components %d exceeds what the %d-column block resolves (max %d)", o.n_pc, L, l_act);
-    // beyond L - 8 components the Gram solver runs deflation rounds on the explicit k x k matrix; the matrix-free
-    // solver has nothing to deflate
-    if (rank_bound > (uint64_t)L && o.n_pc > L - 8 && o.solver != 1)
-        return fail(ctx, SRX_E_ARG, "pca: n_components %d > %d needs the Gram solver (k <= 16384, opts.solver = 1)", o.n_pc, L - 8);
-    return SRX_OK;
-}
-
-// Everything the host side of the result needs stays on the device until the first fetch (pca_materialize).
-static int32_t stash_results(srx_ctx* ctx, srx_pca_state& st, int k, int n_pc, const HvgDev* hv,
-                             const std::vector<double>& mu, const std::vector<double>& sd, double trace,
-                             const std::vector<uint64_t>& selv) {
-    // Everything the host side of the result needs stays on the device until the first fetch.
-    const size_t kl = (size_t)k * L;
-    double* sm = st.d_small + (size_t)st.rounds * (kl + 2 * L);      // behind the per-round blocks
-    st.dev_sel = hv != nullptr;
-    if (hv) {
-        CopySegs cs;                                           // (four runtime copies were 20 us of dispatches)
-        cs.src[0] = (const uint32_t*)hv->d_mu;       cs.dst[0] = (uint32_t*)sm;                          cs.words[0] = (uint32_t)k * 2;
-        cs.src[1] = (const uint32_t*)hv->d_sd;       cs.dst[1] = (uint32_t*)(sm + k);                    cs.words[1] = (uint32_t)k * 2;
-        cs.src[2] = (const uint32_t*)hv->d_trace;    cs.dst[2] = (uint32_t*)(sm + 2 * (size_t)k);        cs.words[2] = 2;
-        cs.src[3] = (const uint32_t*)hv->d_sel_rank; cs.dst[3] = (uint32_t*)(sm + 2 * (size_t)k + 2);    cs.words[3] = (uint32_t)k;
-        hipLaunchKernelGGL(k_copy_segs, dim3(16), dim3(256), 0, ctx->stream, cs);
-        SRX_HIP(ctx, hipGetLastError());
-        st.sel.clear();
-    } else {
-        st.pend_mu = mu;
-        st.pend_sd = sd;
-        st.pend_trace = trace;
-        st.sel = selv;
-    }
-    st.k = (uint32_t)k;
-    st.n_pc = (uint32_t)n_pc;
-    st.host_pending = true;
-    st.valid = true;
-    return SRX_OK;
-}
 
 // Host-side view of an explicit selection: ascending-gene order, remap table, and the all-cells mean / std
 // (ddof 0) of the selected genes from the (global) moments of `m`.
@@ -1593,58 +81,20 @@ static int32_t prepare_host_selection(srx_mat* m, const std::vector<uint64_t>& s
     return SRX_OK;
 }
 
+// The in-place normalise + log1p of a matrix whose pipeline has been reading it raw (RowXf) and did not get as far as the
+// moments pass that stores the transformed values itself (an error on the way, or a selection too wide for the fused
+// compaction): from the row sums in m->d_row_sum, on the context's stream.
+static int32_t launch_writeback(srx_mat* m) {
+    if (!m->lazy_pending) return SRX_OK;
+    m->lazy_pending = false;
+    // (the moments cached on the matrix are those of the f64 transform, not of the values as stored: the version bump of
+    //  launch_row_apply retires them — a later compute_variance sees what X holds)
+    return launch_row_apply(m, m->lazy_target, m->ctx->stream);
+}
+
 // Everything up to and including the scores, left in m->pca (device scores + small host vectors).
 // `hvg_n` > 0: FeatureSelection::HighlyVariable(hvg_n) made on the device (the pipeline's route: no host round
 // trip between the moments pass and the compaction); otherwise `sel` (nullptr = all features).
-// The in-place normalise + log1p of a matrix whose pipeline has been reading it raw (RowXf), on the context's side
-// stream: it runs beside the bucket / Gram kernels, which do not touch X.  The caller joins before it returns.
-static int32_t launch_writeback(srx_mat* m) {
-    srx_ctx* ctx = m->ctx;
-    if (!m->lazy_pending) return SRX_OK;
-    if (!ctx->side_stream) {
-        // The side stream is kept off some of the CUs (CU mask): with the write-back's waves on every CU a 1024-thread
-        // workgroup of the iteration (k_gram2_part, the Cholesky / Jacobi kernels) found no CU with room until the
-        // write-back had finished — the two streams ran one after the other (profiles/r02 timeline).  The f32 write-back
-        // (k_row_apply<T>) is bandwidth-bound from ~160 CUs up: 2.2 ms on 224, 2.3 on 160, 2.6 on 128, 4.3 on 64; the
-        // iteration beside it takes 3.2 / 2.85 / 2.9 ms (2.2 alone: what is left is contention for the fabric).
-        static const int free_cus = getenv("SRX_WB_FREE_CUS") ? atoi(getenv("SRX_WB_FREE_CUS")) : 96;
-        uint32_t mask[8];
-        const int n_cus = ctx->n_cus > 256 ? 256 : ctx->n_cus;
-        for (int w = 0; w < 8; ++w) mask[w] = 0u;
-        for (int c = (free_cus < n_cus ? free_cus : 0); c < n_cus; ++c) mask[c >> 5] |= 1u << (c & 31);
-        if (free_cus <= 0 || free_cus >= n_cus ||
-            hipExtStreamCreateWithCUMask(&ctx->side_stream, (uint32_t)((n_cus + 31) / 32), mask) != hipSuccess) {
-            (void)hipGetLastError();
-            SRX_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-        }
-        SRX_HIP(ctx, hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
-        SRX_HIP(ctx, hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
-    }
-    static const bool serial = getenv("SRX_NO_OVERLAP") != nullptr;           // A/B switch: write back on the main stream
-    hipStream_t st = serial ? ctx->stream : ctx->side_stream;
-    if (!serial) {
-        SRX_HIP(ctx, hipEventRecord(ctx->side_fork, ctx->stream));
-        SRX_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
-    }
-    m->lazy_pending = false;
-    static const bool old_wb = getenv("SRX_WB_RESUM") != nullptr;
-    if (!old_wb) SRX_TRY(launch_row_apply(m, m->lazy_target, st));       // bumps the version
-    else SRX_TRY(launch_normalize(m, m->lazy_target, true, true, st, !is_f32(m), 0));
-    // (the moments cached on the matrix are those of the f64 transform, not of the values as stored: the version bump
-    //  above retires them — a later compute_variance sees what X holds)
-    if (!serial) {
-        SRX_HIP(ctx, hipEventRecord(ctx->side_join, ctx->side_stream));
-        ctx->side_busy = true;
-    }
-    return SRX_OK;
-}
-static int32_t join_side(srx_ctx* ctx) {
-    if (!ctx->side_busy) return SRX_OK;
-    ctx->side_busy = false;
-    SRX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_join, 0));
-    return SRX_OK;
-}
-
 static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const srx_pca_opts* opts, uint64_t hvg_n = 0,
                           RowXf xf = RowXf{}) {
     srx_ctx* ctx = m->ctx;
@@ -1699,26 +149,19 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
     Range r_compact("srx:compact");
     // the 256-tiled view only where something reads it
     const bool fits_rows = is_f32(m) ? fwd_rows_fits<float, float>(k) : fwd_rows_fits<double, double>(k);
-    const bool need_t256 = o.solver == 2 || !fits_rows || getenv("SRX_FWD_TILED") != nullptr;
+    const bool need_t256 = o.solver == 2 || !fits_rows;
     if (dev_sel) {
         SRX_TRY(build_tiled_fused(m, hv.d_bits, hv.n_words, k, rm, need_t256 ? &t256 : nullptr, xf, o.solver == 1));
     } else if ((k + KG - 1) / KG <= kWave) {
         SRX_TRY(build_tiled_fused(m, remap, k, rm, need_t256 ? &t256 : nullptr, xf, o.solver == 1));
     } else {
         // the general route reads stored values: the matrix is transformed in place first
-        if (xf.row_sum) {
-            SRX_TRY(launch_writeback(m));
-            SRX_TRY(join_side(ctx));
-        }
+        if (xf.row_sum) SRX_TRY(launch_writeback(m));
         CompactCsr cc;
         SRX_TRY(build_compact(m, remap, k, cc, rm));
         if (need_t256) SRX_TRY(retile(m, cc, KT, t256));
     }
     if (!need_t256) SRX_TRY(build_row_order(ctx, rm));      // the transform walks rows by length
-    // nothing below reads X.  The in-place write-back of the transformed values is queued on the side stream once the
-    // Gram kernel is (run_pca): it then runs beside the k x 64 iteration — ~100 small launches that leave HBM idle —
-    // instead of beside the Gram kernel, whose suffix gathers the streaming pass slowed by 3 ms when the two overlapped.
-    ctx->wb_after_gram = xf.row_sum ? m : nullptr;
     st.info = srx_pca_info{};
     st.info.n_cells_global = Ng;
     st.info.k = (uint32_t)k;
@@ -1862,74 +305,6 @@ int32_t srx_pca(srx_mat* m, const uint64_t* sel, uint64_t k, const srx_pca_opts*
     return rc2 != SRX_OK ? rc2 : rc;
 }
 
-// Kernel-level entry point: Y = X[:, sel] * P, T = X[:, sel]^T * Y and G = X[:, sel]^T X[:, sel]
-// for a caller-supplied 64-column panel (no centring / scaling).  Exists so the SpMM and Gram
-// kernels can be checked against a CPU reference in isolation, and as the raw operators.
-int32_t srx_spmm(srx_mat* m, const uint64_t* sel, uint64_t k64, const double* panel, double* y_out, double* t_out,
-                 double* gram_out) {
-    if (!m || !sel) return fail(m ? m->ctx : nullptr, SRX_E_ARG, "null argument");
-    if ((y_out || t_out) && !panel) return fail(m->ctx, SRX_E_ARG, "srx_spmm: panel is required for y/t");
-    if (m->csc) return fail(m->ctx, SRX_E_FORMAT, "srx_spmm walks cells: convert the CSC matrix with srx_matrix_to_csr");
-    srx_ctx* ctx = m->ctx;
-    SRX_HIP(ctx, hipSetDevice(ctx->device));
-    const int k = (int)k64;
-    const uint64_t G = m->n_cols;
-    std::vector<int32_t> remap(G, -1);
-    for (int s = 0; s < k; ++s) {
-        if (sel[s] >= G) return fail(ctx, SRX_E_BOUNDS, "selected feature index out of bounds");
-        if (s > 0 && sel[s] <= sel[s - 1]) return fail(ctx, SRX_E_ARG, "srx_spmm: sel must be strictly ascending");
-        remap[sel[s]] = s;
-    }
-    Tiled c256;
-    RowMajor crm;
-    if ((k + KG - 1) / KG <= kWave) {
-        SRX_TRY(build_tiled_fused(m, remap, k, crm, &c256));
-    } else {
-        CompactCsr cc;
-        SRX_TRY(build_compact(m, remap, k, cc, crm));
-        SRX_TRY(retile(m, cc, KT, c256));
-    }
-    const size_t kl = (size_t)k * L;
-    double* T;
-    SRX_TRY(scratch(ctx, "pca_T", (kl + L) * 8, (void**)&T));
-    auto run = [&](auto vt, auto pt) -> int32_t {
-        using VT = decltype(vt);
-        using PT = decltype(pt);
-        if (y_out || t_out) {
-            const Tiled& c = c256;
-            PT *P, *Y;
-            SRX_TRY(scratch(ctx, "pca_P", (kl + L) * sizeof(PT), (void**)&P));
-            SRX_TRY(scratch(ctx, "pca_Y", (c.n_rows ? c.n_rows : 1) * (size_t)L * sizeof(PT), (void**)&Y));
-            std::vector<PT> hp(kl + L, PT(0));
-            for (size_t e = 0; e < kl; ++e) hp[e] = (PT)panel[e];
-            SRX_TRY(h2d(ctx, P, hp.data(), (kl + L) * sizeof(PT)));
-            SRX_TRY((launch_fwd<VT, PT>(ctx, c, P, P + kl, Y)));
-            if (y_out) {
-                std::vector<PT> hy(c.n_rows * (size_t)L);
-                SRX_TRY(d2h(ctx, hy.data(), Y, hy.size() * sizeof(PT)));
-                for (size_t e = 0; e < hy.size(); ++e) y_out[e] = (double)hy[e];
-            }
-            if (t_out) {
-                SRX_TRY((launch_t<VT, PT>(ctx, c, Y, T)));
-                SRX_TRY(d2h(ctx, t_out, T, kl * 8));
-            }
-        }
-        if (gram_out) {
-            double *C, *Pk;
-            SRX_TRY(scratch(ctx, "pca_C", (size_t)k * k * 8, (void**)&C));
-            SRX_TRY(scratch(ctx, "pca_gpacked", gram_packed_count(k) * sizeof(double), (void**)&Pk));
-            SRX_HIP(ctx, hipMemsetAsync(Pk, 0, gram_packed_count(k) * sizeof(double), ctx->stream));
-            SRX_TRY(launch_gram<VT>(ctx, crm, Pk));
-            hipLaunchKernelGGL(k_gram_expand, dim3((unsigned)(((size_t)k * k + 255) / 256)), dim3(256), 0, ctx->stream, Pk,
-                               k, (const double*)nullptr, (const double*)nullptr, 0, 0.0, C);
-            SRX_HIP(ctx, hipGetLastError());
-            SRX_TRY(d2h(ctx, gram_out, C, (size_t)k * k * 8));
-        }
-        return SRX_OK;
-    };
-    return is_f32(m) ? run(float{}, float{}) : run(double{}, double{});
-}
-
 int32_t srx_pca_loadings(const double* components, const double* std_, const uint64_t* sel, uint64_t k,
                          uint64_t n_pc, uint64_t n_vars, double* out) {
     if (!components || !std_ || !sel || !out) return fail(nullptr, SRX_E_ARG, "null argument");
@@ -1970,21 +345,17 @@ int32_t srx_pipeline(srx_mat* m, double target_sum, uint64_t n_hvg, const srx_pc
     // are those of the reference's f64 values whatever the storage type — and the in-place write-back of y runs on the
     // side stream beside the Gram kernel.  CSC (cells are columns): the two calls, then the stored values.
     const uint64_t take = n_hvg < m->n_cols ? n_hvg : m->n_cols;
-    const bool lazy = !m->csc && !getenv("SRX_NO_LAZY");
-    // SRX_WB_SIDE=1: the moments pass leaves X raw and the in-place pass runs on the side stream beside the iteration
-    // (the arrangement before the moments pass stored the values itself; kept for A/B runs)
-    static const bool side_wb = getenv("SRX_WB_SIDE") != nullptr;
+    const bool lazy = !m->csc;
     RowXf xf;
     bool wrote_back = false;
     {
     Range r_("srx:normalize");
     if (m->csc) rc = srx_normalize_log1p_inplace(m, target_sum, nullptr);
-    else if (!lazy) rc = launch_normalize(m, target_sum, true, true);
     else {
         rc = launch_row_sums(m);
         xf.row_sum = m->d_row_sum;
         xf.target = target_sum;
-        xf.write_back = !side_wb;
+        xf.write_back = true;
         m->lazy_pending = true;
         m->lazy_target = target_sum;
     }
@@ -2025,12 +396,10 @@ int32_t srx_pipeline(srx_mat* m, double target_sum, uint64_t n_hvg, const srx_pc
         rc = dev_sel ? pca_device(m, nullptr, 0, opts, n_hvg, xf) : pca_device(m, sel.data(), sel.size(), opts, 0, xf);
     }
     // whatever happened above, X ends up normalised and log1p'd (the two in-place calls come first in the reference)
-    ctx->wb_after_gram = nullptr;
     if (m->lazy_pending) {
         const int32_t rc_wb = launch_writeback(m);
         if (rc == SRX_OK) rc = rc_wb;
     }
-    (void)join_side(ctx);
     // the moments cached on the matrix are those of the f64 transform, not of the values as stored: retired (a later
     // compute_variance sees what X holds)
     if (wrote_back) m->moments_version = m->version - 1;

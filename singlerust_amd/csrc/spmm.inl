@@ -1,4 +1,4 @@
-// spmm.inl — included by pca.hip inside namespace srx (one translation unit: the kernels share its helpers and constants).
+// spmm.inl — included by pca_solve.hip inside namespace srx (one translation unit: the kernels share its helpers and constants).
 // The sparse products with a k x 64 panel: forward (tile-major and row-major record forms) and transposed.
 
 // ---- forward SpMM: Y = A P - 1 cvec^T ----------------------------------------------------------

@@ -187,11 +187,11 @@ def test_gene_tiling_many_genes(ctx):
     assert np.array_equal(gmn, wmn) and np.array_equal(gmx, wmx)
 
 
-@pytest.mark.parametrize("n_genes", [9000, 32000, 65536])
-def test_tile_cuts_in_one_pass_equal_the_searched_ones(ctx, monkeypatch, n_genes):
-    """The index mirror and the gene-tile cuts come out of ONE walk over the indices (k_narrow16_tiles); the two-pass form
-    (binary searches + narrowing, SRX_TILES_TWO_PASS) must give the same per-gene statistics — empty rows, rows confined to one
-    tile and a gene count that fills the 16-bit range included — and both equal the oracle's."""
+@pytest.mark.parametrize("n_genes", [9000, 32000, 65536, 70000])
+def test_tile_cuts_against_the_oracle(ctx, n_genes):
+    """The index mirror and the gene-tile cuts come out of ONE walk over the indices (k_narrow16_tiles: up to 65 536 genes); beyond,
+    the cuts are binary-searched and there is no mirror (k_tile_ptr).  Either way the per-gene statistics are the oracle's —
+    empty rows, rows confined to the last tile and a gene count that fills the 16-bit range included."""
     import singlerust_amd as sr
     from singlerust_amd.memory import statistics
     m = create_large_test_data(2500, n_genes, 30.0, seed=n_genes, dtype=np.uint16)
@@ -205,18 +205,11 @@ def test_tile_cuts_in_one_pass_equal_the_searched_ones(ctx, monkeypatch, n_genes
     lens = np.diff(ip)
     lens[[3, 1200]] = 0
     m2 = oracle.Csr(2500, n_genes, np.concatenate([[0], np.cumsum(lens)]), ix[keep], vals[keep])
-    out = []
-    for two_pass in (False, True):
-        if two_pass:
-            monkeypatch.setenv("SRX_TILES_TWO_PASS", "1")
-        a = adata_of(m2, ctx)
-        out.append((statistics.compute_number(a, sr.Direction.Column), statistics.compute_sum(a, sr.Direction.Column),
-                    statistics.compute_variance(a, sr.Direction.Column)))
-    for x, y in zip(out[0], out[1]):
-        assert np.array_equal(x, y)
-    assert np.array_equal(out[0][0], oracle.compute_number(m2, COLUMN))
-    assert np.array_equal(out[0][1], oracle.compute_sum(m2, COLUMN))
-    np.testing.assert_allclose(out[0][2], oracle.compute_variance(m2, COLUMN), rtol=1e-9, atol=1e-9)
+    a = adata_of(m2, ctx)
+    assert np.array_equal(statistics.compute_number(a, sr.Direction.Column), oracle.compute_number(m2, COLUMN))
+    assert np.array_equal(statistics.compute_sum(a, sr.Direction.Column), oracle.compute_sum(m2, COLUMN))
+    np.testing.assert_allclose(statistics.compute_variance(a, sr.Direction.Column), oracle.compute_variance(m2, COLUMN), rtol=1e-9,
+                               atol=1e-9)
 
 
 def test_error_behaviour(ctx):
