@@ -272,6 +272,9 @@ __global__ __launch_bounds__(256) void k_rowcount_list(const int64_t* __restrict
     const uint64_t wave = global_wave_id();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
+    // (Round 4: four entries per lane and load — 8-byte loads of the index mirror, ranks from four ballots per 256-entry chunk:
+    //  bit-identical lists, 1.16-1.36 ms against 0.78.  Unlike k_gene_count, where the same change took 1.34 -> 0.54 ms, this pass is
+    //  bound by its ~24 VALU instructions and two LDS reads per entry slot, not by its 2-byte loads.)
     constexpr int kCountUnroll = 16;          // 1024 entries in flight: a ~840-entry row is one round trip
     for (uint64_t r0 = wave * kCompactRows; r0 < n_rows; r0 += n_waves * kCompactRows) {
         const int nr = (int)(n_rows - r0 < (uint64_t)kCompactRows ? n_rows - r0 : kCompactRows);

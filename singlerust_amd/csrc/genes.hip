@@ -299,7 +299,7 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
 // sparsity pattern alone: made once per pattern (srx_matrix_prepare, or the first pass that needs them), kept on the matrix,
 // inherited by clones; the moments passes then carry no count atomic and no counters in LDS (16 B per gene: 3 gene tiles at
 // 28k genes instead of 4).  Workgroup = (row block, gene tile) like the moments pass, 32-bit LDS counters, flushed with global
-// atomics into the zeroed `cnt`.
+// partials `cnt[row block][gene]`.
 template <typename I>
 __global__ __launch_bounds__(kMomThreads) void k_gene_count(const int64_t* __restrict__ indptr, const int64_t* __restrict__ tp,
                                                             const I* __restrict__ idx, uint64_t n_rows, uint64_t n_cols, int n_tiles,
@@ -316,27 +316,73 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_count(const int64_t* __res
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     constexpr int kWaves = kMomThreads / kWave;
-    constexpr int kU = 4;
-    for (uint64_t r = r0 + wave; r < r1; r += kWaves) {
-        int64_t lo, hi;
-        seg_bounds(indptr, tp, n_rows, n_tiles, tile, r, lo, hi);
-        for (int64_t p0 = lo; p0 < hi; p0 += kU * kWave) {
-            int32_t g[kU];
+    // four row segments per step; a lane takes 4 consecutive entries from the 4-entry boundary at or before the segment start
+    // (one 8-byte load of 16-bit indices, 16 bytes of 32-bit ones: 256 entries per wave instruction — one entry per lane and
+    // load left this pass at 1.3-1.7 TB/s), two such chunks of every segment in flight, entries outside [lo, hi) masked
+    // (the arrays are padded by 16 entries)
+    constexpr int kU = 2, kR = 4;
+    auto load4 = [&](int64_t e0, int32_t (&g)[4]) {
+        if constexpr (sizeof(I) == 4) {
+            const int4 g4 = *reinterpret_cast<const int4*>(idx + e0);
+            g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
+        } else {
+            const uint2 g2 = *reinterpret_cast<const uint2*>(idx + e0);
+            g[0] = (int)(g2.x & 0xffffu); g[1] = (int)(g2.x >> 16);
+            g[2] = (int)(g2.y & 0xffffu); g[3] = (int)(g2.y >> 16);
+        }
+    };
+    auto add4 = [&](int64_t e0, int64_t lo, int64_t hi, const int32_t (&g)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (e0 + j >= lo && e0 + j < hi)
+                __hip_atomic_fetch_add(&s_cnt[g[j] - gbase], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    for (uint64_t rb4 = r0 + wave; rb4 < r1; rb4 += (uint64_t)kWaves * kR) {
+        int64_t lo[kR], hi[kR];
+#pragma unroll
+        for (int q = 0; q < kR; ++q) {
+            const uint64_t r = rb4 + (uint64_t)q * kWaves;
+            lo[q] = hi[q] = 0;
+            if (r < r1) seg_bounds(indptr, tp, n_rows, n_tiles, tile, r, lo[q], hi[q]);
+        }
+        int32_t g[kR][kU][4];
+#pragma unroll
+        for (int q = 0; q < kR; ++q)
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
-                const int64_t p = p0 + u * kWave + lane;
-                g[u] = p < hi ? (int32_t)idx[p] - gbase : -1;
+                const int64_t b0 = lo[q] & ~(int64_t)3, e0 = b0 + 4 * (u * kWave + lane);
+                load4(e0 < hi[q] ? e0 : b0, g[q][u]);
             }
 #pragma unroll
-            for (int u = 0; u < kU; ++u)
-                if (g[u] >= 0) __hip_atomic_fetch_add(&s_cnt[g[u]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int q = 0; q < kR; ++q) {
+            const int64_t b0 = lo[q] & ~(int64_t)3;
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int64_t e0 = b0 + 4 * (u * kWave + lane);
+                if (e0 < hi[q]) add4(e0, lo[q], hi[q], g[q][u]);
+            }
+            // segments longer than kU x 256 entries: the rest, a chunk at a time
+            for (int64_t e0 = b0 + 4 * (kU * kWave + lane); e0 < hi[q]; e0 += 4 * kWave) {
+                int32_t gt[4];
+                load4(e0, gt);
+                add4(e0, lo[q], hi[q], gt);
+            }
         }
     }
     __syncthreads();
+    // per-row-block partials, summed by k_gene_count_reduce (global atomics into the 28k counters — 341 row blocks on every
+    // address — took ~0.9 of this pass's 1.4 ms)
     for (int g = threadIdx.x; g < tile_genes; g += kMomThreads) {
         const uint64_t gene = (uint64_t)gbase + g;
-        if (gene < n_cols && s_cnt[g]) atomicAdd(&cnt[gene], s_cnt[g]);
+        if (gene < n_cols) cnt[rb * n_cols + gene] = s_cnt[g];
     }
+}
+__global__ void k_gene_count_reduce(const uint32_t* __restrict__ part, uint64_t n_cols, uint64_t n_blocks, uint32_t* __restrict__ cnt) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_cols) return;
+    uint32_t c = 0;
+    for (uint64_t b = 0; b < n_blocks; ++b) c += part[b * n_cols + j];
+    cnt[j] = c;
 }
 
 // Fixed-order sum of the per-row-block partials -> packed f64 [cnt | sum | sq | n_rows].
@@ -671,15 +717,19 @@ int32_t ensure_pattern_counts(srx_mat* m) {
     if (m->n_rows && m->nnz) {
         uint64_t nb, rpb;
         block_geometry(m, nb, rpb);
+        uint32_t* part;
+        SRX_TRY(scratch(ctx, "mom_part_cnt", nb * G * sizeof(uint32_t), (void**)&part));
         const dim3 grid((unsigned)(nb * m->n_tiles));
         const size_t lds = (size_t)m->tile_genes * 4;
         ProfScope ps(ctx, SRX_K_MOMENTS, (double)m->nnz * (m->d_idx16 ? 2.0 : 4.0) + (double)(m->n_rows + 1) * 8.0 + (double)G * 4.0);
         if (m->d_idx16)
             hipLaunchKernelGGL(k_gene_count<uint16_t>, grid, dim3(kMomThreads), lds, ctx->stream, m->d_indptr, m->d_tile_ptr,
-                               (const uint16_t*)m->d_idx16, m->n_rows, G, m->n_tiles, m->tile_genes, rpb, m->d_cnt_pat);
+                               (const uint16_t*)m->d_idx16, m->n_rows, G, m->n_tiles, m->tile_genes, rpb, part);
         else
             hipLaunchKernelGGL(k_gene_count<int32_t>, grid, dim3(kMomThreads), lds, ctx->stream, m->d_indptr, m->d_tile_ptr,
-                               (const int32_t*)m->d_indices, m->n_rows, G, m->n_tiles, m->tile_genes, rpb, m->d_cnt_pat);
+                               (const int32_t*)m->d_indices, m->n_rows, G, m->n_tiles, m->tile_genes, rpb, part);
+        hipLaunchKernelGGL(k_gene_count_reduce, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)part, G, nb,
+                           m->d_cnt_pat);
         SRX_HIP(ctx, hipGetLastError());
     }
     m->cnt_pat_valid = true;
