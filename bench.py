@@ -361,11 +361,46 @@ def attributed(prof, steps):
     return per, serial
 
 
-def roof(d, kernel, note):
+LDS_PEAK_GBS = 128 * 256 * 2.4          # 128 B / clk / CU x 256 CUs x 2.4 GHz = 78 643 GB/s (MI355X_MICROARCH.md)
+LDS_F64_ATOMIC_LANES_PER_S = 2.5 * 256 * 2.4e9     # random-address ds_add_f64: 2.5 lanes / clk / CU (bench_micro/lds_atomic_banks.hip)
+
+
+def roof(d, kernel, note, other=None):
+    """The contract's roofline object (HBM: algorithmic bytes / live hipEvent time).  `other`: what ELSE bounds the kernel —
+    the resource its inner loop actually runs on, measured the same way (work per launch / the same launch time)."""
     return {"bound": "hbm", "kernel": kernel, "achieved": d.get("GBps"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": d.get("frac_of_peak"), "traffic": d.get("hbm_traffic_per_launch"), "launches": d.get("launches"),
             "avg_ms": d.get("avg_ms"), "alg_bytes_per_launch": d.get("alg_bytes_per_launch"),
-            **({"aux_bytes_per_launch": d["aux_bytes_per_launch"]} if d.get("aux_bytes_per_launch") else {}), "note": note}
+            **({"aux_bytes_per_launch": d["aux_bytes_per_launch"]} if d.get("aux_bytes_per_launch") else {}),
+            **({"other_bounds": other} if other else {}), "note": note}
+
+
+def other_bounds(name, d, nnz_sel, n_cells, sigma=0.3):
+    """Secondary rooflines of the two kernels whose inner loop does not run on HBM (DESIGN.md sections 3b / 3c)."""
+    ms = d.get("avg_ms")
+    if not ms or not nnz_sel or not n_cells:
+        return None
+    t = ms * 1e-3
+    if name == "spmm_fwd":
+        # every kept entry reads its gene's 64 panel columns from LDS (4 slices x 16 columns x 4 B), plus ~12 % of padded slots
+        lds_bytes = nnz_sel * 64 * 4.0
+        return {"lds_read": {"achieved": lds_bytes / t / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
+                             "frac": lds_bytes / t / 1e9 / LDS_PEAK_GBS,
+                             "note": "panel reads: kept entries x 64 columns x 4 B out of the LDS panel slices (padded record "
+                                     "slots not counted); the LDS cannot hold the 2000 x 50 panel (400 KB), so ANY gather "
+                                     "formulation moves these bytes: 0.30 ms at the LDS peak against 0.16 ms of HBM time"}}
+    if name == "gram_sparse":
+        import math
+        m = nnz_sel / n_cells
+        products = n_cells * (m * m * math.exp(sigma * sigma) + m) / 2.0       # sum over cells of m_i (m_i + 1) / 2, log-normal m_i
+        return {"lds_f64_atomics": {"achieved": products / t, "peak": LDS_F64_ATOMIC_LANES_PER_S, "unit": "lane-atomics/s",
+                                    "frac": products / t / LDS_F64_ATOMIC_LANES_PER_S, "products_per_launch_estimate": products,
+                                    "note": "one f64 LDS atomic lane per scalar product; peak = the measured random-address "
+                                            "ds_add_f64 rate"},
+                "l1_fill": {"achieved": products * 8.0 / t / 1e9, "unit": "GB/s requested by the suffix gathers (8 B per product)",
+                            "note": "profiles/r04_pmc_gram.md: 2.98e8 L1->L2 requests of 64 B per launch = 0.125 per clock and "
+                                    "CU, the per-CU miss throughput an HBM stream gets too"}}
+    return None
 
 
 def cold_step(B, config, n_global, storage, reps=3):
@@ -941,9 +976,11 @@ def main():
                 "cpu_baseline_threads": (extra.get("cpu_baseline") or {}).get("cores"),
             },
             # the kernel class with the largest share of the step (live HIP-event timing on the stream it runs on)
-            "roofline": roof(dom, KERNEL_SYMBOL.get(dom_name, dom_name), ROOF_NOTE.get(dom_name, "")),
+            "roofline": roof(dom, KERNEL_SYMBOL.get(dom_name, dom_name), ROOF_NOTE.get(dom_name, ""),
+                             other_bounds(dom_name, dom, main_["nnz_selected"], row1 - row0)),
             # BASELINE.json's second metric: the CSR x 64-column-panel SpMM against the HBM peak
-            "roofline_spmm": roof(prof.get("spmm_fwd", {}), KERNEL_SYMBOL["spmm_fwd"], ROOF_NOTE["spmm_fwd"]),
+            "roofline_spmm": roof(prof.get("spmm_fwd", {}), KERNEL_SYMBOL["spmm_fwd"], ROOF_NOTE["spmm_fwd"],
+                                  other_bounds("spmm_fwd", prof.get("spmm_fwd", {}), main_["nnz_selected"], row1 - row0)),
             "kernels": prof,
             "kernel_ms_per_step": per,
             # step time outside every bracketed class (launch gaps, host waits, scans, small copies)
