@@ -105,30 +105,28 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);      // row bounds and scales are then scalars
     constexpr int kWaves = kMomThreads / kWave;
 
-    // 4 consecutive entries per lane: one 16-byte (8-byte for 16-bit indices) load of the indices and one
-    // (f32) or two (f64) of the values, from the 4-entry boundary at or before the segment start; entries
-    // outside [lo, hi) are masked (the arrays are padded by 16 entries).
-    // A row's segment in one of the 4 gene tiles is ~200 entries — one load pair per lane — and the 140 KB
-    // of accumulators allow 16 waves per CU, so a wave keeps kMomRows row segments in flight (pointer loads
-    // of all of them, then data loads of all of them, then the atomics): with one segment per wave only
-    // ~20 KB per CU were outstanding against the ~60 KB that HBM latency x bandwidth asks for.
-#ifndef MOM_ROWS
-#define MOM_ROWS 4
-#endif
-    constexpr int kMomRows = MOM_ROWS;
+    // 4 consecutive entries per lane: one 16-byte (8-byte for 16-bit indices) load of the indices and one (f32) or two (f64) of
+    // the values, from a 4-entry boundary; entries outside the segment are masked (the arrays are padded by 16 entries).
+    // A row's segment in one of 3 gene tiles is ~280 entries, a wave step is 256 slots: one segment per step left the second
+    // step of nearly every segment at 10 % fill — 8 steps for 4 segments, and the pass is VALU-issue-bound (60 instructions per
+    // value, profiles/r04_pmc_gram.md).  So a wave works on BATCHES of kBR row segments laid end to end in one slot space
+    // (slot = 4 entries of one segment; segment u owns the slots S[u] .. S[u + 1]): 4 segments = ~284 slots = 5 steps at 89 %
+    // fill; a lane finds its segment with kBR - 1 compares against the (wave-uniform) prefix sums and selects the segment's
+    // base, offset, length and scale.  The first kBS steps of a batch are fetched ahead (two batches ping-pong: the loads
+    // of one are in flight while the other is evaluated); longer batches take their remaining steps with plain loads.
+    constexpr int kBR = sizeof(T) == 4 ? 3 : 2;      // f64 values: half the batch (a chunk is 10 registers instead of 6)
+    constexpr int kBS = sizeof(T) == 4 ? (sizeof(I) == 4 ? 4 : 4) : 3;
     struct Chunk {
-        int gg[4];
+        std::conditional_t<sizeof(I) == 4, int4, uint2> gi;       // the four column indices as loaded (16-bit ones stay packed)
         T v[4];
     };
+    auto gene_of = [](const Chunk& c, int j) -> int {
+        if constexpr (sizeof(I) == 4) return j == 0 ? c.gi.x : j == 1 ? c.gi.y : j == 2 ? c.gi.z : c.gi.w;
+        else return (int)(((j < 2 ? c.gi.x : c.gi.y) >> (16 * (j & 1))) & 0xffffu);
+    };
     auto load_chunk = [&](int64_t e0, Chunk& c) {
-        if constexpr (sizeof(I) == 4) {
-            const int4 g4 = *reinterpret_cast<const int4*>(idx + e0);
-            c.gg[0] = g4.x; c.gg[1] = g4.y; c.gg[2] = g4.z; c.gg[3] = g4.w;
-        } else {                                   // four 16-bit indices in one 8-byte load
-            const uint2 g2 = *reinterpret_cast<const uint2*>(idx + e0);
-            c.gg[0] = (int)(g2.x & 0xffffu); c.gg[1] = (int)(g2.x >> 16);
-            c.gg[2] = (int)(g2.y & 0xffffu); c.gg[3] = (int)(g2.y >> 16);
-        }
+        if constexpr (sizeof(I) == 4) c.gi = *reinterpret_cast<const int4*>(idx + e0);
+        else c.gi = *reinterpret_cast<const uint2*>(idx + e0);        // four 16-bit indices in one 8-byte load
         if constexpr (sizeof(T) == 4) {
             const float4 t4 = *reinterpret_cast<const float4*>(vals + e0);
             c.v[0] = t4.x; c.v[1] = t4.y; c.v[2] = t4.z; c.v[3] = t4.w;
@@ -145,9 +143,8 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     // The magic constant's bit pattern is NOT subtracted per value: the accumulators sum bits(1.5 * 2^52 + x * 2^shift) =
     // bits(1.5 * 2^52) + round(x * 2^shift) in wrapping 64-bit arithmetic and k_moments_reduce takes count x bits(1.5 * 2^52)
     // off again (the per-gene counts are known).  Positions are tested as 32-bit offsets from the segment start.
-    auto add_chunk = [&](int64_t e0, int64_t lo, int64_t hi, const Chunk& c, double scale) {
-        const int rel = (int)(e0 - lo);                    // >= -3
-        const unsigned len = (unsigned)(hi - lo);
+    auto add_chunk = [&](int64_t e0, int rel /* position of the chunk's first entry in its segment: >= -3 */, unsigned len,
+                         const Chunk& c, double scale) {
         // XF: the four logarithms first, as independent straight-line chains the compiler can interleave (the accumulators
         // leave room for 4 waves per SIMD: a wave has to bring its own instruction-level parallelism); the rare argument
         // classes are patched afterwards (entries outside the segment hold padding values: evaluated, never used)
@@ -202,7 +199,7 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if ((unsigned)(rel + j) < len) {
-                const int32_t g0 = c.gg[j] - gbase;
+                const int32_t g0 = gene_of(c, j) - gbase;
                 double x0 = (double)c.v[j];
                 if constexpr (XF) {
                     x0 = y4[j];
@@ -229,52 +226,105 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
             }
         }
     };
-    // Two groups of kMomRows / 2 row segments, worked on alternately: the pointers and the data of one are fetched while the
-    // other is evaluated (ping-pong between two register sets; the loads are unconditional — lanes past a segment's end read
-    // its first chunk again — because a branch around a load makes the compiler's wait for this group's data wait for the
-    // other group's loads too).
-    constexpr int kGrp = kMomRows / 2;
-    struct Group {
-        int64_t lo[kGrp], hi[kGrp];
-        double scale[kGrp];
-        Chunk c[kGrp];
+    // (all offsets of a row block fit 32 bits: block_geometry keeps rows_per_block x n_cols below 2^31)
+    int64_t blk_lo, blk_hi_;
+    seg_bounds(indptr, tp, n_rows, n_tiles, tile, r0 < n_rows ? r0 : 0, blk_lo, blk_hi_);
+    const int64_t base = blk_lo & ~(int64_t)3;
+    struct Batch {                   // wave-uniform but for `c`: five scalars per segment
+        int eb[kBR];                 // (4-entry boundary at or before the segment start) - base - 4 S: entry of slot s = base + eb + 4 s
+        int q[kBR];                  // 4 S + (segment start - its boundary): position of slot s's first entry in the segment = 4 s - q
+        int len[kBR];                // segment length
+        int S[kBR + 1];              // first slot of segment u; S[kBR] = slots of the batch
+        double scale[kBR];
+        Chunk c[kBS];
     };
-    auto fetch = [&](Group& g, uint64_t rbase) {
+    // slot `slot` of the batch -> its chunk's first entry, that entry's position in the segment, the segment's length / scale
+    auto locate = [&](const Batch& g, int slot, int64_t& e0, int& rel, unsigned& len, double& scale) {
+        int eb = g.eb[0], q = g.q[0], ln = g.len[0];
+        double sc = g.scale[0];
 #pragma unroll
-        for (int u = 0; u < kGrp; ++u) {
+        for (int u = 1; u < kBR; ++u) {
+            const bool in = slot >= g.S[u];
+            eb = in ? g.eb[u] : eb;
+            q = in ? g.q[u] : q;
+            ln = in ? g.len[u] : ln;
+            sc = in ? g.scale[u] : sc;
+        }
+        e0 = base + (int64_t)(eb + 4 * slot);
+        rel = 4 * slot - q;
+        len = (unsigned)ln;
+        scale = sc;
+    };
+    auto fetch = [&](Batch& g, uint64_t rbase) {
+        int S = 0;
+#pragma unroll
+        for (int u = 0; u < kBR; ++u) {
             const uint64_t r = rbase + (uint64_t)u * kWaves;
+            int64_t lo = base, hi = base;
             g.scale[u] = 1.0;
-            g.lo[u] = g.hi[u] = 0;
             if (r < r1) {
-                seg_bounds(indptr, tp, n_rows, n_tiles, tile, r, g.lo[u], g.hi[u]);
+                seg_bounds(indptr, tp, n_rows, n_tiles, tile, r, lo, hi);
                 if constexpr (XF) {
                     const double sr = row_sum[r];
                     g.scale[u] = sr == 0.0 ? 0.0 : target / sr;            // scale/mod.rs:9-15
                 }
             }
+            const int64_t b0 = lo & ~(int64_t)3;
+            const int a = (int)(lo - b0);
+            g.len[u] = (int)(hi - lo);
+            g.S[u] = S;
+            g.eb[u] = (int)(b0 - base) - 4 * S;
+            g.q[u] = 4 * S + a;
+            S += (a + g.len[u] + 3) >> 2;
         }
+        g.S[kBR] = S;
+        // the loads are unconditional (slots past the batch read the first segment's first chunk again): a branch around a load
+        // makes the compiler's wait for this batch's data wait for the other batch's loads too
 #pragma unroll
-        for (int u = 0; u < kGrp; ++u) {
-            const int64_t b0 = g.lo[u] & ~(int64_t)3, e0 = b0 + 4 * lane;
-            load_chunk(e0 < g.hi[u] ? e0 : b0, g.c[u]);
+        for (int st = 0; st < kBS; ++st) {
+            const int slot = st * kWave + lane;
+            int64_t e0;
+            int rel;
+            unsigned len;
+            double sc;
+            locate(g, slot < S ? slot : 0, e0, rel, len, sc);
+            load_chunk(e0, g.c[st]);
         }
     };
-    auto compute = [&](const Group& g) {
+    auto compute = [&](const Batch& g) {
+        const int S = g.S[kBR];
 #pragma unroll
-        for (int u = 0; u < kGrp; ++u) {
-            const int64_t e0 = (g.lo[u] & ~(int64_t)3) + 4 * lane;
-            if (e0 < g.hi[u]) add_chunk(e0, g.lo[u], g.hi[u], g.c[u], g.scale[u]);
-            // segments longer than 256 entries: the rest, one chunk at a time
-            for (int64_t e1 = e0 + 4 * kWave; e1 < g.hi[u]; e1 += 4 * kWave) {
-                Chunk cc;
-                load_chunk(e1, cc);
-                add_chunk(e1, g.lo[u], g.hi[u], cc, g.scale[u]);
+        for (int st = 0; st < kBS; ++st) {
+            if (st * kWave >= S) break;                    // wave-uniform
+            int slot = st * kWave + lane;
+            // (recomputed here, opaquely: left to itself the compiler keeps the six located values of every prefetched step of
+            //  both batches alive from `fetch` on — 40 to 70 registers, spilled)
+            asm volatile("" : "+v"(slot));
+            if (slot < S) {
+                int64_t e0;
+                int rel;
+                unsigned len;
+                double sc;
+                locate(g, slot, e0, rel, len, sc);
+                add_chunk(e0, rel, len, g.c[st], sc);
             }
+            __builtin_amdgcn_sched_barrier(0);             // one step's temporaries at a time (the unrolled steps interleaved: spills)
+        }
+        // batches longer than kBS steps (long rows): the rest, a step at a time
+        for (int slot = kBS * kWave + lane; slot < S; slot += kWave) {
+            int64_t e0;
+            int rel;
+            unsigned len;
+            double sc;
+            locate(g, slot, e0, rel, len, sc);
+            Chunk cc;
+            load_chunk(e0, cc);
+            add_chunk(e0, rel, len, cc, sc);
         }
     };
     {
-        const uint64_t stride = (uint64_t)kWaves * kGrp;
-        Group A, B;
+        const uint64_t stride = (uint64_t)kWaves * kBR;
+        Batch A, B;
         uint64_t rbase = r0 + wave;
         fetch(A, rbase);
         while (rbase < r1) {
@@ -637,6 +687,13 @@ static void block_geometry(const srx_mat* m, uint64_t& n_blocks, uint64_t& rows_
     n_blocks = want < by_rows ? want : by_rows;
     rows_per_block = (m->n_rows + n_blocks - 1) / n_blocks;
     if (rows_per_block < 1) rows_per_block = 1;
+    // the moments pass addresses a row block's entries with 32-bit offsets from the block's first entry (a row holds at most
+    // n_cols entries)
+    const uint64_t cap = std::max<uint64_t>(1, 0x7fffffffull / std::max<uint64_t>(m->n_cols, 1));
+    if (rows_per_block > cap) {
+        rows_per_block = cap;
+        n_blocks = (m->n_rows + rows_per_block - 1) / rows_per_block;
+    }
 }
 
 // This shard's (cnt, sum, sumsq) per gene and its row count, packed as 3G+1 doubles in a scratch buffer.
