@@ -72,13 +72,13 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     uint64_t rows_per_block, const double* __restrict__ row_sum, double target, double fx_sum, double fx_sq,
     uint32_t* __restrict__ poison, double* __restrict__ part_sum, double* __restrict__ part_sq) {
     extern __shared__ double lds[];
-    double* s_sum = lds;
-    double* s_sq = lds + tile_genes;
+    double* s_acc = lds;            // per gene {sum, sum of squares} side by side: one address computation per value, the second
+                                    // atomic at the instruction's immediate offset
     // behind the accumulators (tile_genes * 16 B): the log1p table
     // (the table from global memory instead — 2 KB, L1-resident, one vector load per value — was tried: 5.7 ms against 3.5)
     const Log1pTabEntry* s_tab = reinterpret_cast<const Log1pTabEntry*>(reinterpret_cast<char*>(lds) + (size_t)tile_genes * 16);
     if constexpr (XF) stage_log1p_table(const_cast<Log1pTabEntry*>(s_tab));
-    for (int g = threadIdx.x; g < tile_genes; g += kMomThreads) { s_sum[g] = 0.0; s_sq[g] = 0.0; }
+    for (int g = threadIdx.x; g < 2 * tile_genes; g += kMomThreads) s_acc[g] = 0.0;
     __syncthreads();
 
     // The gene tiles of one row block run on the SAME XCD (consecutive workgroup ids go round the 8 XCDs): a row's tile segments
@@ -214,15 +214,16 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
                     // (a poisoned value adds nothing while the reduction still takes its magic bits off: the gene's sums are
                     //  replaced by NaN anyway)
 #ifdef MOM_NOATOM
-                    if (is + iq == 12345ull) s_sum[g0] = 1.0;
+                    if (is + iq == 12345ull) s_acc[2 * g0] = 1.0;
                     continue;
 #endif
-                    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&s_sum[g0]), is, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&s_sq[g0]), iq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    unsigned long long* a2 = reinterpret_cast<unsigned long long*>(s_acc) + 2 * g0;
+                    __hip_atomic_fetch_add(a2, is, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(a2 + 1, iq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     continue;
                 }
-                __hip_atomic_fetch_add(&s_sum[g0], x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(&s_sq[g0], x0 * x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&s_acc[2 * g0], x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&s_acc[2 * g0 + 1], x0 * x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     };
@@ -239,21 +240,28 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
         Chunk c[kBS];
     };
     // slot `slot` of the batch -> its chunk's first entry, that entry's position in the segment, the segment's length / scale
+    // (X_sel = X[0] + sum_u [slot >= S[u]] (X[u] - X[u - 1]) in wrapping 32-bit arithmetic — exact for integers and for the two
+    //  halves of a double's bit pattern alike: the differences are wave-uniform (SALU), a lane pays one v_cndmask per segment
+    //  boundary and word and one add; a chain of selects between SGPR values costs three VALU instructions per select, the
+    //  constant bus taking one scalar operand per instruction)
     auto locate = [&](const Batch& g, int slot, int64_t& e0, int& rel, unsigned& len, double& scale) {
-        int eb = g.eb[0], q = g.q[0], ln = g.len[0];
-        double sc = g.scale[0];
+        const unsigned long long sc0 = (unsigned long long)__double_as_longlong(g.scale[0]);
+        unsigned eb = (unsigned)g.eb[0], q = (unsigned)g.q[0], ln = (unsigned)g.len[0], slo = (unsigned)sc0, shi = (unsigned)(sc0 >> 32);
 #pragma unroll
         for (int u = 1; u < kBR; ++u) {
             const bool in = slot >= g.S[u];
-            eb = in ? g.eb[u] : eb;
-            q = in ? g.q[u] : q;
-            ln = in ? g.len[u] : ln;
-            sc = in ? g.scale[u] : sc;
+            const unsigned long long a = (unsigned long long)__double_as_longlong(g.scale[u]),
+                                     b = (unsigned long long)__double_as_longlong(g.scale[u - 1]);
+            eb += in ? (unsigned)g.eb[u] - (unsigned)g.eb[u - 1] : 0u;
+            q += in ? (unsigned)g.q[u] - (unsigned)g.q[u - 1] : 0u;
+            ln += in ? (unsigned)g.len[u] - (unsigned)g.len[u - 1] : 0u;
+            slo += in ? (unsigned)a - (unsigned)b : 0u;
+            shi += in ? (unsigned)(a >> 32) - (unsigned)(b >> 32) : 0u;
         }
-        e0 = base + (int64_t)(eb + 4 * slot);
-        rel = 4 * slot - q;
-        len = (unsigned)ln;
-        scale = sc;
+        e0 = base + (int64_t)(int)(eb + 4u * (unsigned)slot);
+        rel = (int)(4u * (unsigned)slot - q);
+        len = ln;
+        scale = __longlong_as_double((long long)(((unsigned long long)shi << 32) | slo));
     };
     auto fetch = [&](Batch& g, uint64_t rbase) {
         int S = 0;
@@ -339,8 +347,8 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     for (int g = threadIdx.x; g < tile_genes; g += kMomThreads) {
         uint64_t gene = (uint64_t)gbase + g;
         if (gene < n_cols) {
-            part_sum[rb * n_cols + gene] = s_sum[g];
-            part_sq[rb * n_cols + gene] = s_sq[g];
+            part_sum[rb * n_cols + gene] = s_acc[2 * g];
+            part_sq[rb * n_cols + gene] = s_acc[2 * g + 1];
         }
     }
 }
