@@ -108,8 +108,8 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     // 4 consecutive entries per lane: one 16-byte (8-byte for 16-bit indices) load of the indices and one (f32) or two (f64) of
     // the values, from a 4-entry boundary; entries outside the segment are masked (the arrays are padded by 16 entries).
     // A row's segment in one of 3 gene tiles is ~280 entries, a wave step is 256 slots: one segment per step left the second
-    // step of nearly every segment at 10 % fill — 8 steps for 4 segments, and the pass is VALU-issue-bound (60 instructions per
-    // value, profiles/r04_pmc_gram.md).  So a wave works on BATCHES of kBR row segments laid end to end in one slot space
+    // step of nearly every segment at 10 % fill behind a dependent load — and the pass is bound by the latency of its chains at
+    // 4 waves per SIMD (60 VALU instructions per value, profiles/r04_pmc_gram.md).  So a wave works on BATCHES of kBR row segments laid end to end in one slot space
     // (slot = 4 entries of one segment; segment u owns the slots S[u] .. S[u + 1]): 4 segments = ~284 slots = 5 steps at 89 %
     // fill; a lane finds its segment with kBR - 1 compares against the (wave-uniform) prefix sums and selects the segment's
     // base, offset, length and scale.  The first kBS steps of a batch are fetched ahead (two batches ping-pong: the loads
