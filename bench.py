@@ -55,20 +55,20 @@ KERNEL_SYMBOL = {"normalize_log1p": "k_row_apply<T> / k_normalize<T> (the separa
 ROOF_NOTE = {
     "gram_sparse": "algorithmic bytes = what any Gram kernel must move: the row-major HVG-compacted matrix (8-byte entries) and "
                    "its row pointers read once + the packed upper triangle of G written once; the 12-byte owner records and block "
-                   "offsets this kernel reads besides are `aux_bytes_per_launch`.  Not an HBM-bound kernel: N m(m+1)/2 = 3.4e9 scalar "
-                   "products per launch at c3, each one lane of an f64 LDS atomic (LDS pipe 72 % busy, 14 clk per ~34-lane "
-                   "instruction) fed by one gathered 8-byte operand (every row suffix is re-read once per kept entry of its "
-                   "row: 19 GB of L2 requests, 11-19 GB through the fabric per launch) — profiles/r02_pmc_gram.md.  Round 3 knock-outs "
-                   "(DESIGN.md section 3c): without the atomics 3.73 of 3.91 ms, without atomics and suffix loads 3.11 (13-14 scalar "
-                   "instructions per record on the CU's one scalar unit); an inline-asm core with 5 of them: 3.92 ms, and 1.99 without "
-                   "its suffix loads — the launch is its 2.98e8 L1->L2 requests, 0.125 per clock and CU",
+                   "offsets this kernel reads besides are `aux_bytes_per_launch`.  Not an HBM-bound kernel (`other_bounds`): N m(m+1)/2 "
+                   "= 3.4-3.7e9 scalar products per launch at c3, each one lane of an f64 LDS atomic fed by one gathered 8-byte "
+                   "operand (every row suffix is re-read once per kept entry of its row: 2.98e8 L1->L2 requests = 19 GB per launch, "
+                   "0.124 per clock and CU, L2 hits 66 % with the misses mostly compulsory per XCD, LDS pipe 70 % busy — "
+                   "profiles/r04_pmc_gram.md).  Knock-outs of round 3 (DESIGN.md section 3c): without the atomics 3.73 of 3.91 ms, an "
+                   "inline-asm core with 5 instead of 14 scalar instructions per record 3.92 ms, and 1.99 without its suffix loads",
     "spmm_fwd": "algorithmic bytes: the row-major compacted matrix (nnz_w * 8) + row pointers and row order (N * 12) + the "
                 "k x 64 f32 panel once per workgroup column slice + the output, which for this launch (the transform) is the "
-                "N x n_pc f64 score matrix written by the SpMM itself.  What bounds it, by knock-out builds of the kernel "
-                "(round 3, DESIGN.md section 3c): without the multiplication (LDS reads + FMAs) the launch takes the SAME time, "
-                "without the score stores 0.45 instead of 0.65 ms — the arithmetic is hidden; the kernel is its ~0.45 ms of record "
-                "and pointer reads (one pass over the matrix per 16-column panel slice: 4 passes, 85 % L2 hits, per-CU L1-miss "
-                "throughput) plus ~0.2 ms of scattered 128-byte score-row pieces",
+                "N x n_pc f64 score matrix written by the SpMM itself (rows of n_pc rounded up to 16 doubles in HBM).  What bounds "
+                "it (`other_bounds`, profiles/r04_pmc_spmm.md, knock-outs of round 3 in DESIGN.md section 3c): every kept entry "
+                "reads its gene's panel row from LDS — 0.5 of the LDS read peak, which the 400 KB panel against 160 KB of LDS makes "
+                "inherent to a gather formulation — behind ~80 dependent row steps per wave at one workgroup per CU; the matrix is "
+                "walked once per 16-column panel slice (4 passes, 80 % L2 hits).  The densified MFMA form: 8.7 ms "
+                "(bench_micro/spmm_mfma_dense.hip, profiles/r04_knockouts.md)",
 }
 
 
