@@ -226,6 +226,16 @@ class Bench:
             print(f"[bench rank {rank}] communicator check failed: {self.comm_info}", file=sys.stderr)
             sys.exit(3)
 
+    def overlap_info(self):
+        """How the Gram solver's exchange ran on this rank (srx_comm_overlap_info): split in three pieces with two of them under
+        the second half of the stripe kernel, and whether that half ran on the CU-masked stream."""
+        n, masked = C.c_int32(0), C.c_int32(0)
+        try:
+            self.F.check(self.lib.srx_comm_overlap_info(self.ctx.handle, C.byref(n), C.byref(masked)), self.ctx.handle)
+        except Exception:       # noqa: BLE001
+            return {}
+        return {"gram_exchange_split_launches": n.value, "gram_exchange_cu_masked": bool(masked.value)}
+
     def sync_all(self):
         self.ctx.synchronize()               # every kernel of the path runs on this context's streams (the pipeline joins them)
         if self.dist is not None:
@@ -959,6 +969,7 @@ def main():
                 "cells_global": n_global, "genes": genes, "nnz_rank0": main_["nnz"], "hvg": a.hvg, "n_pc": a.npc,
                 "panel_width": 64, "parallelism": f"row-shard x{world} (nnz-balanced)",
                 **(B.comm_info if B.dist is not None else {}),
+                **(B.overlap_info() if B.dist is not None else {}),
                 "nnz_hvg_compacted_rank0": main_["nnz_selected"],
                 "subspace_iterations": main_["iters"], "pca_residual": main_["residual"], "pca_solver": main_["solver"],
                 "hvg_selection": "f64 moments of ln_1p(v * scale) from the raw matrix: identical to the reference's at f32 storage",

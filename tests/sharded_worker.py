@@ -22,7 +22,12 @@ def main():
     n, g = int(z["n_rows"]), int(z["n_cols"])
     indptr, indices, values = z["indptr"], z["indices"], z["values"]
     cut = np.zeros(world + 1, dtype=np.uint64)
-    F.check(lib.srx_partition_rows(F.ptr(indptr), n, world, F.ptr(cut)))
+    if mode == "resident-empty":                # the LAST rank holds no rows (more ranks than work, a filter that emptied a shard)
+        F.check(lib.srx_partition_rows(F.ptr(indptr), n, world - 1, F.ptr(cut)))
+        cut[world] = n
+        mode = "resident"
+    else:
+        F.check(lib.srx_partition_rows(F.ptr(indptr), n, world, F.ptr(cut)))
     r0, r1 = int(cut[rank]), int(cut[rank + 1])
     lo, hi = int(indptr[r0]), int(indptr[r1])
     group = StarGroup(rank, world, key=key)
@@ -73,7 +78,7 @@ def main():
         res.update(scores=r.x_pca, comps=r.components, evr=r.explained_variance_ratio, mean=r.mean, std=r.std,
                    hv=r.selected, n_global=int(r.info.n_cells_global), sum_row=r.row_sums)
     res["r0"], res["r1"] = r0, r1
-    np.savez(os.path.join(out_dir, f"rank{rank}_{mode}.npz"), **res)
+    np.savez(os.path.join(out_dir, f"rank{rank}_{sys.argv[5]}.npz"), **res)
     group.barrier()
     group.close()         # the context outlives the matrices: both go with the process
 

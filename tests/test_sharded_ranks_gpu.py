@@ -68,3 +68,29 @@ def test_row_sharded_ranks_match_single_rank(ctx, tmp_path, world, solver):
         for r in rs[1:]:
             assert np.allclose(r["comps"], rs[0]["comps"], rtol=0, atol=1e-9)
         assert col_err(got, scores) < TOL
+
+
+def test_a_rank_without_rows_takes_part_in_every_sum(ctx, tmp_path):
+    """Three ranks, the last one EMPTY (srx_partition_rows over two ranks + an empty range): it uploads a 0-row shard, runs the
+    same pipeline, contributes zeros to every sum over the ranks and arrives at the same per-gene results; its own score block is
+    0 x n_pc.  (With an RCCL communicator such a rank must issue the same collectives as the others: launch_gram decides the split
+    of the Gram exchange from rank-invariant data — ADVICE r3; this test covers the rest of the path on the host transport.)"""
+    import ctypes as C
+    import singlerust_amd as sr
+    from singlerust_amd import _ffi as F
+    m, _ = synth_host(23, 5000, 2500, 0.05)
+    n_hvg, n_pc = 200, 8
+    np.savez(os.path.join(tmp_path, "input.npz"), n_rows=m.n_rows, n_cols=m.n_cols, indptr=m.indptr, indices=m.indices,
+             values=m.values, n_hvg=n_hvg, n_pc=n_pc, solver=1, chunk=900)
+    a = sr.IMAnnData.new_basic((m.n_rows, m.n_cols, m.indptr, m.indices, m.values), ctx=ctx, store=1)
+    opts = F.PcaOpts(n_pc, -1, -1, -1, 0, 0, 1, 0.0, 5)
+    pr = F.PipelineResult()
+    F.check(F.lib().srx_pipeline(a.x().handle, 1e4, n_hvg, C.byref(opts), C.byref(pr)), ctx.handle)
+    scores, comps, evr, hv = np.zeros((m.n_rows, n_pc)), np.zeros((n_hvg, n_pc)), np.zeros(n_pc), np.zeros(n_hvg, np.uint64)
+    F.check(F.lib().srx_result_fetch(a.x().handle, F.ptr(scores), F.ptr(comps), F.ptr(evr), None, None, F.ptr(hv)), ctx.handle)
+    rs = launch(3, "resident-empty", tmp_path)
+    assert rs[2]["r0"] == rs[2]["r1"] == m.n_rows and rs[2]["scores"].shape == (0, n_pc)
+    for r in rs:
+        assert int(r["n_global"]) == m.n_rows and np.array_equal(r["hv"], hv)
+        assert np.allclose(r["evr"], evr, rtol=1e-6) and col_err(r["comps"], comps) < TOL
+    assert col_err(np.concatenate([r["scores"] for r in rs], axis=0), scores) < TOL
