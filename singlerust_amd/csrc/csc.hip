@@ -26,7 +26,7 @@
 
 namespace srx {
 
-int32_t scan_exclusive(srx_ctx* ctx, const int64_t* d_in, uint64_t n, int64_t* d_out, int64_t** total_dev);   // pca.hip
+int32_t scan_exclusive(srx_ctx* ctx, const int64_t* d_in, uint64_t n, int64_t* d_out, int64_t** total_dev);   // pca_form.hip
 
 __global__ void k_hist(const int32_t* __restrict__ idx, uint64_t nnz, int64_t* __restrict__ cnt) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
