@@ -345,7 +345,7 @@ use std::cell::{Cell, RefCell};
 
 struct Resident {
     key: XKey,
-    x_elem: IMArrayElement,                     // a clone of the X slot's Arc: while the cache holds it the allocation cannot be
+    _x_elem: IMArrayElement,                    // a clone of the X slot's Arc: while the cache holds it the allocation cannot be
                                                 // freed, so its ADDRESS (part of the key) cannot be recycled by another matrix
     dev: DeviceX<'static>,                      // (the context is the thread's own, alive as long as the thread)
     host_stale: bool,                           // the device holds newer values than the IMAnnData
@@ -396,7 +396,7 @@ fn with_resident<R>(adata: &IMAnnData, f: impl FnOnce(&mut DeviceX<'static>) -> 
                 // (a stale host copy of ANOTHER matrix cannot be written back from here: lazy mode asks for flush() first)
                 let ctx: &'static Ctx = unsafe { &*(c as *const Ctx) };
                 *slot = None;                    // the old handle's HBM is free before the new upload asks for its own
-                *slot = Some(Resident { key, x_elem: adata.x(), dev: DeviceX::upload(ctx, adata)?, host_stale: false, keep_f32: false });
+                *slot = Some(Resident { key, _x_elem: adata.x(), dev: DeviceX::upload(ctx, adata)?, host_stale: false, keep_f32: false });
             }
             f(&mut slot.as_mut().expect("resident").dev)
         })
@@ -442,7 +442,7 @@ pub fn flush(adata: &mut IMAnnData) -> Result<()> {
 }
 /// The device-side result of a filter becomes the resident handle of the IMAnnData that holds the same subset.
 fn adopt(adata: &IMAnnData, dev: DeviceX<'static>) {
-    TLS.with(|t| *t.resident.borrow_mut() = Some(Resident { key: x_key(adata), x_elem: adata.x(), dev, host_stale: false, keep_f32: false }));
+    TLS.with(|t| *t.resident.borrow_mut() = Some(Resident { key: x_key(adata), _x_elem: adata.x(), dev, host_stale: false, keep_f32: false }));
 }
 
 pub mod statistics_free {
