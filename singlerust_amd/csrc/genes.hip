@@ -112,10 +112,11 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     // 4 waves per SIMD (60 VALU instructions per value, profiles/r04_pmc_gram.md).  So a wave works on BATCHES of kBR row segments laid end to end in one slot space
     // (slot = 4 entries of one segment; segment u owns the slots S[u] .. S[u + 1]): 4 segments = ~284 slots = 5 steps at 89 %
     // fill; a lane finds its segment with kBR - 1 compares against the (wave-uniform) prefix sums and selects the segment's
-    // base, offset, length and scale.  The first kBS steps of a batch are fetched ahead (two batches ping-pong: the loads
-    // of one are in flight while the other is evaluated); longer batches take their remaining steps with plain loads.
+    // base, offset, length and scale.  kBS steps of loads are in flight all the time (a step of the current batch is evaluated, then
+    // the same step of the next batch is fetched into the registers it freed); longer batches take their remaining steps with
+    // plain loads.  (4 segments / 5 steps fill better, 89 %, and are slower: 2.88 against 2.82 ms.)
     constexpr int kBR = sizeof(T) == 4 ? 3 : 2;      // f64 values: half the batch (a chunk is 10 registers instead of 6)
-    constexpr int kBS = sizeof(T) == 4 ? (sizeof(I) == 4 ? 4 : 4) : 3;
+    constexpr int kBS = sizeof(T) == 4 ? 4 : 3;
     struct Chunk {
         std::conditional_t<sizeof(I) == 4, int4, uint2> gi;       // the four column indices as loaded (16-bit ones stay packed)
         T v[4];
@@ -237,7 +238,6 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
         int len[kBR];                // segment length
         int S[kBR + 1];              // first slot of segment u; S[kBR] = slots of the batch
         double scale[kBR];
-        Chunk c[kBS];
     };
     // slot `slot` of the batch -> its chunk's first entry, that entry's position in the segment, the segment's length / scale
     // (X_sel = X[0] + sum_u [slot >= S[u]] (X[u] - X[u - 1]) in wrapping 32-bit arithmetic — exact for integers and for the two
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
         len = ln;
         scale = __longlong_as_double((long long)(((unsigned long long)shi << 32) | slo));
     };
-    auto fetch = [&](Batch& g, uint64_t rbase) {
+    auto describe = [&](Batch& g, uint64_t rbase) {
         int S = 0;
 #pragma unroll
         for (int u = 0; u < kBR; ++u) {
@@ -286,61 +286,63 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
             S += (a + g.len[u] + 3) >> 2;
         }
         g.S[kBR] = S;
-        // the loads are unconditional (slots past the batch read the first segment's first chunk again): a branch around a load
-        // makes the compiler's wait for this batch's data wait for the other batch's loads too
-#pragma unroll
-        for (int st = 0; st < kBS; ++st) {
-            const int slot = st * kWave + lane;
-            int64_t e0;
-            int rel;
-            unsigned len;
-            double sc;
-            locate(g, slot < S ? slot : 0, e0, rel, len, sc);
-            load_chunk(e0, g.c[st]);
-        }
     };
-    auto compute = [&](const Batch& g) {
-        const int S = g.S[kBR];
-#pragma unroll
-        for (int st = 0; st < kBS; ++st) {
-            if (st * kWave >= S) break;                    // wave-uniform
-            int slot = st * kWave + lane;
-            // (recomputed here, opaquely: left to itself the compiler keeps the six located values of every prefetched step of
-            //  both batches alive from `fetch` on — 40 to 70 registers, spilled)
-            asm volatile("" : "+v"(slot));
-            if (slot < S) {
-                int64_t e0;
-                int rel;
-                unsigned len;
-                double sc;
-                locate(g, slot, e0, rel, len, sc);
-                add_chunk(e0, rel, len, g.c[st], sc);
-            }
-            __builtin_amdgcn_sched_barrier(0);             // one step's temporaries at a time (the unrolled steps interleaved: spills)
-        }
-        // batches longer than kBS steps (long rows): the rest, a step at a time
-        for (int slot = kBS * kWave + lane; slot < S; slot += kWave) {
+    // the load of step `st` of a batch: unconditional (slots past the batch read the first segment's first chunk again: a branch
+    // around a load makes the compiler's wait for one step's data wait for every load issued since)
+    auto issue = [&](const Batch& g, int st, Chunk& c) {
+        const int slot = st * kWave + lane;
+        int64_t e0;
+        int rel;
+        unsigned len;
+        double sc;
+        locate(g, slot < g.S[kBR] ? slot : 0, e0, rel, len, sc);
+        load_chunk(e0, c);
+    };
+    auto step = [&](const Batch& g, int st, const Chunk& c) {
+        int slot = st * kWave + lane;
+        // (recomputed here, opaquely: left to itself the compiler keeps the located values of every prefetched step alive from
+        //  `issue` on — spilled)
+        asm volatile("" : "+v"(slot));
+        if (slot < g.S[kBR]) {
             int64_t e0;
             int rel;
             unsigned len;
             double sc;
             locate(g, slot, e0, rel, len, sc);
-            Chunk cc;
-            load_chunk(e0, cc);
-            add_chunk(e0, rel, len, cc, sc);
+            add_chunk(e0, rel, len, c, sc);
         }
     };
     {
+        // ONE set of kBS chunk registers: step st of the current batch is evaluated, then step st of the NEXT batch is fetched into
+        // the registers it has just freed — kBS steps of loads in flight all the time with half the registers two whole batches
+        // took (which left the scheduler no room to overlap the logarithms of two steps)
         const uint64_t stride = (uint64_t)kWaves * kBR;
-        Batch A, B;
+        Batch cur, nxt;
+        Chunk c[kBS];
         uint64_t rbase = r0 + wave;
-        fetch(A, rbase);
+        describe(cur, rbase);
+#pragma unroll
+        for (int st = 0; st < kBS; ++st) issue(cur, st, c[st]);
         while (rbase < r1) {
-            fetch(B, rbase + stride);
-            compute(A);
-            fetch(A, rbase + 2 * stride);
-            compute(B);
-            rbase += 2 * stride;
+            describe(nxt, rbase + stride);
+#pragma unroll
+            for (int st = 0; st < kBS; ++st) {
+                if (st * kWave < cur.S[kBR]) step(cur, st, c[st]);          // (wave-uniform)
+                issue(nxt, st, c[st]);
+            }
+            // batches longer than kBS steps (long rows): the rest, a step at a time
+            for (int slot = kBS * kWave + lane; slot < cur.S[kBR]; slot += kWave) {
+                int64_t e0;
+                int rel;
+                unsigned len;
+                double sc;
+                locate(cur, slot, e0, rel, len, sc);
+                Chunk cc;
+                load_chunk(e0, cc);
+                add_chunk(e0, rel, len, cc, sc);
+            }
+            cur = nxt;
+            rbase += stride;
         }
     }
     __syncthreads();
