@@ -259,6 +259,7 @@ struct RowXf {
     bool write_back = false;      // moments pass only: store the transformed value in place (at the storage precision)
 };
 int32_t upload_on(srx_ctx* ctx, const srx_csr* h, int32_t store, hipStream_t stream, srx_mat** out);   // ctx.hip
+int32_t tiles_from_idx16(srx_mat* m, hipStream_t stream);     // genes.hip: 32-bit indices + gene-tile cuts from an uploaded 16-bit mirror
 hipError_t dev_malloc(srx_ctx* ctx, void** p, size_t bytes);     // ctx.hip: hipMalloc, or a recycled buffer while ctx->pool_on
 void pool_clear(srx_ctx* ctx);
 int32_t ensure_tiles(srx_mat* m);

@@ -46,6 +46,7 @@ int32_t pinned(srx_ctx* ctx, size_t bytes, void** out) {
 static int32_t parallel_h2d(srx_ctx* ctx, const void* src, void* dst, uint64_t n, bool narrow, size_t elem_bytes,
                             uint64_t n_cols, bool* bad);
 static int32_t parallel_d2h(srx_ctx* ctx, void* dst, const void* src, size_t bytes);
+static int32_t parallel_d2h_rows(srx_ctx* ctx, void* dst, const void* src, uint64_t rows, size_t width, size_t dev_pitch);
 
 // Small/medium blocks go through the pinned staging buffer so the copy is a true async DMA
 // ordered on the ctx stream; large blocks (values of the whole matrix, the score matrix) go through the
@@ -69,18 +70,8 @@ int32_t d2h(srx_ctx* ctx, void* host, const void* dev, size_t bytes) {
 int32_t d2h_rows(srx_ctx* ctx, void* host, const void* dev, uint64_t rows, size_t width, size_t dev_pitch) {
     if (dev_pitch == width) return d2h(ctx, host, dev, rows * width);
     if (rows == 0 || width == 0) return SRX_OK;
-    // strided DMA into the pinned staging buffer (64 MiB pieces), dense memcpy out of it
-    const uint64_t per = std::max<uint64_t>(1, (64u << 20) / width);
-    void* p;
-    SRX_TRY(pinned(ctx, (size_t)std::min<uint64_t>(per, rows) * width, &p));
-    for (uint64_t r0 = 0; r0 < rows; r0 += per) {
-        const uint64_t nr = std::min<uint64_t>(per, rows - r0);
-        SRX_HIP(ctx, hipMemcpy2DAsync(p, width, static_cast<const char*>(dev) + r0 * dev_pitch, dev_pitch, width, nr,
-                                      hipMemcpyDeviceToHost, ctx->stream));
-        SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        memcpy(static_cast<char*>(host) + r0 * width, p, nr * width);
-    }
-    return SRX_OK;
+    SRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return parallel_d2h_rows(ctx, host, dev, rows, width, dev_pitch);
 }
 
 int32_t h2d(srx_ctx* ctx, void* dev, const void* host, size_t bytes) {
@@ -353,8 +344,8 @@ static int32_t ensure_up_workers(srx_ctx* ctx) {
     return SRX_OK;
 }
 
-// `n` elements from host `src` to device `dst`.  narrow: src is u64[n], dst i32[n], values >= n_cols set *bad;
-// otherwise a plain copy of n * elem_bytes bytes.
+// `n` elements from host `src` to device `dst`.  narrow: src is u64[n], dst i32[n] (elem_bytes 4) or u16[n] (elem_bytes 2),
+// values >= n_cols set *bad; otherwise a plain copy of n * elem_bytes bytes.
 static int32_t parallel_h2d(srx_ctx* ctx, const void* src, void* dst, uint64_t n, bool narrow, size_t elem_bytes,
                             uint64_t n_cols, bool* bad) {
     if (n == 0) return SRX_OK;
@@ -378,7 +369,17 @@ static int32_t parallel_h2d(srx_ctx* ctx, const void* src, void* dst, uint64_t n
             const uint64_t cnt = std::min<uint64_t>(per_chunk, e1 - off);
             if (used[buf]) e = hipEventSynchronize(w.ev[buf]);          // the DMA out of this buffer has finished
             if (e != hipSuccess) break;
-            if (narrow) {
+            if (narrow && elem_bytes == sizeof(uint16_t)) {
+                const uint64_t* s = static_cast<const uint64_t*>(src) + off;
+                uint16_t* d = static_cast<uint16_t*>(w.pin[buf]);
+                uint64_t over = 0;
+                for (uint64_t i = 0; i < cnt; ++i) {
+                    const uint64_t v = s[i];
+                    over |= (uint64_t)(v >= n_cols);
+                    d[i] = (uint16_t)v;
+                }
+                bad_local |= (int)over;
+            } else if (narrow) {
                 const uint64_t* s = static_cast<const uint64_t*>(src) + off;
                 int32_t* d = static_cast<int32_t*>(w.pin[buf]);
                 uint64_t over = 0;
@@ -453,6 +454,52 @@ static int32_t parallel_d2h(srx_ctx* ctx, void* dst, const void* src, size_t byt
     return SRX_OK;
 }
 
+// ... and of `rows` rows of `width` bytes that lie `dev_pitch` bytes apart on the device (the score rows, padded to whole
+// 128-byte pieces) into a dense host matrix: the workers take row ranges, the DMA engine does the strided read
+// (hipMemcpy2DAsync into the dense pinned buffer), the memcpy out of the other buffer runs under it.
+static int32_t parallel_d2h_rows(srx_ctx* ctx, void* dst, const void* src, uint64_t rows, size_t width, size_t dev_pitch) {
+    if (rows == 0 || width == 0) return SRX_OK;
+    if (width > kUpChunkBytes) return fail(ctx, SRX_E_ARG, "D2H: a row of %zu bytes exceeds the staging buffers", width);
+    SRX_TRY(ensure_up_workers(ctx));
+    const int device = ctx->device;
+    const uint64_t per_chunk = kUpChunkBytes / width;                   // rows per staging buffer
+    int nw = (int)std::min<uint64_t>(kUpWorkers, (rows + per_chunk - 1) / per_chunk);
+    if (nw < 1) nw = 1;
+    const uint64_t share = (rows + nw - 1) / nw;
+    std::vector<hipError_t> err(nw, hipSuccess);
+    auto run = [&](int t) {
+        srx_ctx::UpWorker& w = ctx->up_workers[t];
+        hipError_t e = hipSetDevice(device);
+        const uint64_t r0 = std::min<uint64_t>(rows, (uint64_t)t * share), r1 = std::min<uint64_t>(rows, r0 + share);
+        uint64_t prev_row = 0, prev_cnt = 0;
+        int buf = 0;
+        for (uint64_t r = r0; r < r1 && e == hipSuccess; r += per_chunk, buf ^= 1) {
+            const uint64_t cnt = std::min<uint64_t>(per_chunk, r1 - r);
+            e = hipMemcpy2DAsync(w.pin[buf], width, static_cast<const char*>(src) + r * dev_pitch, dev_pitch, width, cnt,
+                                 hipMemcpyDeviceToHost, w.stream);
+            if (e == hipSuccess) e = hipEventRecord(w.ev[buf], w.stream);
+            if (prev_cnt && e == hipSuccess) {
+                e = hipEventSynchronize(w.ev[buf ^ 1]);
+                if (e == hipSuccess) memcpy(static_cast<char*>(dst) + prev_row * width, w.pin[buf ^ 1], prev_cnt * width);
+            }
+            prev_row = r;
+            prev_cnt = cnt;
+        }
+        if (prev_cnt && e == hipSuccess) {
+            e = hipEventSynchronize(w.ev[buf ^ 1]);
+            if (e == hipSuccess) memcpy(static_cast<char*>(dst) + prev_row * width, w.pin[buf ^ 1], prev_cnt * width);
+        }
+        err[t] = e;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nw; ++t) th.emplace_back(run, t);
+    run(0);
+    for (auto& x : th) x.join();
+    for (int t = 0; t < nw; ++t)
+        if (err[t] != hipSuccess) return fail(ctx, SRX_E_HIP, "D2H worker %d: %s", t, hipGetErrorString(err[t]));
+    return SRX_OK;
+}
+
 // H2D of a host CSR slice with the u64 -> i32 index narrowing, the value conversion and the canonical-CSR
 // validation, every kernel on `stream`.  `h->indptr` may be a window of a larger row-offset array (a row tile of
 // a backed matrix: indptr[0] != 0, indices / values pointing at the tile's first entry) — it is rebased on the
@@ -485,13 +532,22 @@ int32_t upload_on(srx_ctx* ctx, const srx_csr* h, int32_t store, hipStream_t str
     if (rc) return bail(rc);
     (void)hipMemsetAsync(d_flag, 0, sizeof(int), stream);
 
-    // indices (u64 -> i32 on the way into the pinned staging buffers: 4 of the 8 bytes cross PCIe) and, when the
-    // dtype is the storage type, the values: the H2D workers
+    // indices (u64 -> i32 on the way into the pinned staging buffers: 4 of the 8 bytes cross PCIe; with at most 65536 columns
+    // u64 -> u16: 2 of the 8 — the 16-bit mirror the column passes walk arrives ready-made, and the 32-bit indices + the
+    // gene-tile cuts of every row are made from it on the device, genes.hip) and, when the dtype is the storage type, the
+    // values: the H2D workers
     bool f32 = is_f32(m);
     const bool plain_values = (h->dtype == SRX_F32 && f32) || (h->dtype == SRX_F64 && !f32);
     if (h->nnz) {
         bool bad_col = false;
-        rc = parallel_h2d(ctx, h->indices, m->d_indices, h->nnz, true, sizeof(int32_t), h->n_cols, &bad_col);
+        if (h->n_cols <= 65536) {
+            e = dev_malloc(ctx, (void**)&m->d_idx16, (h->nnz + 16) * sizeof(uint16_t));
+            if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "upload: %s", hipGetErrorString(e)));
+            rc = parallel_h2d(ctx, h->indices, m->d_idx16, h->nnz, true, sizeof(uint16_t), h->n_cols, &bad_col);
+            if (!rc && !bad_col) rc = tiles_from_idx16(m, stream);
+        } else {
+            rc = parallel_h2d(ctx, h->indices, m->d_indices, h->nnz, true, sizeof(int32_t), h->n_cols, &bad_col);
+        }
         if (rc) return bail(rc);
         if (bad_col) return bail(fail(ctx, SRX_E_BOUNDS, "column index out of bounds (>= n_cols = %llu)",
                                       (unsigned long long)h->n_cols));

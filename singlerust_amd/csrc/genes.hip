@@ -605,16 +605,18 @@ __global__ void k_narrow16(const int32_t* __restrict__ idx, uint64_t nnz, uint64
 // the cut at `bound` is the row's start + the number of entries below it = the popcounts of the waves' `idx < bound` ballots
 // (scalar instructions; no search, no second pass).  k_tile_ptr's binary searches + k_narrow16 read the indices twice and
 // moved 10.9 GB at c3 (2.3 ms of a cold step's 14.7); this moves 6.6.
-template <int NB>
-__global__ __launch_bounds__(256) void k_narrow16_tiles(const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx,
-                                                        uint64_t n_rows, int tile_genes, uint16_t* __restrict__ out,
+// WIDEN: the other way round — the 16-bit mirror came over PCIe (upload_on: a quarter of the host's index bytes cross the
+// link) and the 32-bit indices are made from it, with the same cuts.
+template <int NB, bool WIDEN>
+__global__ __launch_bounds__(256) void k_narrow16_tiles(const int64_t* __restrict__ indptr, int32_t* idx,
+                                                        uint64_t n_rows, int tile_genes, uint16_t* out,
                                                         int64_t* __restrict__ tp) {
     const int lane = lane_id();
     const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x / kWave);
     constexpr int kU = 4;
     for (uint64_t r = global_wave_id(); r < n_rows; r += n_waves) {
         const int64_t lo = indptr[r], hi = indptr[r + 1];
-        int cnt[NB];
+        int cnt[NB > 0 ? NB : 1];
 #pragma unroll
         for (int b = 0; b < NB; ++b) cnt[b] = 0;
         for (int64_t e0 = lo; e0 < hi; e0 += kU * kWave) {
@@ -622,12 +624,16 @@ __global__ __launch_bounds__(256) void k_narrow16_tiles(const int64_t* __restric
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 const int64_t e = e0 + u * kWave + lane;
-                v[u] = e < hi ? idx[e] : 0x7fffffff;
+                if constexpr (WIDEN) v[u] = e < hi ? (int32_t)out[e] : 0x7fffffff;
+                else v[u] = e < hi ? idx[e] : 0x7fffffff;
             }
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 const int64_t e = e0 + u * kWave + lane;
-                if (e < hi) out[e] = (uint16_t)v[u];
+                if (e < hi) {
+                    if constexpr (WIDEN) idx[e] = v[u];
+                    else out[e] = (uint16_t)v[u];
+                }
 #pragma unroll
                 for (int b = 0; b < NB; ++b) cnt[b] += __popcll(__ballot(v[u] < (b + 1) * tile_genes));
             }
@@ -641,6 +647,44 @@ __global__ __launch_bounds__(256) void k_narrow16_tiles(const int64_t* __restric
     if (blockIdx.x == 0 && threadIdx.x < 16) out[indptr[n_rows] + threadIdx.x] = (uint16_t)0;
 }
 
+template <bool WIDEN>
+static int32_t launch_narrow16_tiles(srx_mat* m, int nt, int tg, hipStream_t stream) {
+    srx_ctx* ctx = m->ctx;
+    const unsigned g = (unsigned)std::min<uint64_t>((m->n_rows + 3) / 4, (uint64_t)ctx->n_cus * 32);
+    auto go = [&](auto nb) {
+        hipLaunchKernelGGL((k_narrow16_tiles<decltype(nb)::value, WIDEN>), dim3(g ? g : 1), dim3(256), 0, stream, m->d_indptr,
+                           m->d_indices, m->n_rows, tg, m->d_idx16, m->d_tile_ptr);
+    };
+    switch (nt - 1) {
+        case 0: go(std::integral_constant<int, 0>{}); break;
+        case 1: go(std::integral_constant<int, 1>{}); break;
+        case 2: go(std::integral_constant<int, 2>{}); break;
+        case 3: go(std::integral_constant<int, 3>{}); break;
+        case 4: go(std::integral_constant<int, 4>{}); break;
+        case 5: go(std::integral_constant<int, 5>{}); break;
+        case 6: go(std::integral_constant<int, 6>{}); break;
+        case 7: go(std::integral_constant<int, 7>{}); break;
+        default: go(std::integral_constant<int, 8>{}); break;
+    }
+    SRX_HIP(ctx, hipGetLastError());
+    return SRX_OK;
+}
+
+// upload_on's second half for a matrix of at most 65536 columns: d_idx16 holds the column indices; d_indices and the tile cuts
+// follow from it.  (m->d_indptr is in place; at most 7 tiles at 65536 columns.)
+int32_t tiles_from_idx16(srx_mat* m, hipStream_t stream) {
+    srx_ctx* ctx = m->ctx;
+    int nt, tg;
+    tile_geometry(m, nt, tg);
+    if (nt > 9 || !m->d_idx16 || m->d_tile_ptr) return fail(ctx, SRX_E_ARG, "tiles_from_idx16: %d gene tiles", nt);
+    if (m->n_rows == 0) return SRX_OK;
+    if (nt > 1) SRX_HIP(ctx, dev_malloc(ctx, (void**)&m->d_tile_ptr, (size_t)(nt - 1) * m->n_rows * sizeof(int64_t)));
+    SRX_TRY(launch_narrow16_tiles<true>(m, nt, tg, stream));
+    m->n_tiles = nt;
+    m->tile_genes = tg;
+    return SRX_OK;
+}
+
 int32_t ensure_tiles(srx_mat* m) {
     srx_ctx* ctx = m->ctx;
     if (m->n_tiles) return SRX_OK;
@@ -649,22 +693,7 @@ int32_t ensure_tiles(srx_mat* m) {
     if (nt > 1 && nt <= 9 && m->n_cols <= 65536 && !m->d_idx16 && !m->d_tile_ptr && m->n_rows > 0) {
         SRX_HIP(ctx, dev_malloc(ctx, (void**)&m->d_tile_ptr, (size_t)(nt - 1) * m->n_rows * sizeof(int64_t)));
         SRX_HIP(ctx, dev_malloc(ctx, (void**)&m->d_idx16, (m->nnz + 16) * sizeof(uint16_t)));
-        const unsigned g = (unsigned)std::min<uint64_t>((m->n_rows + 3) / 4, (uint64_t)ctx->n_cus * 32);
-        auto go = [&](auto nb) {
-            hipLaunchKernelGGL(k_narrow16_tiles<decltype(nb)::value>, dim3(g ? g : 1), dim3(256), 0, ctx->stream, m->d_indptr, m->d_indices,
-                               m->n_rows, tg, m->d_idx16, m->d_tile_ptr);
-        };
-        switch (nt - 1) {
-            case 1: go(std::integral_constant<int, 1>{}); break;
-            case 2: go(std::integral_constant<int, 2>{}); break;
-            case 3: go(std::integral_constant<int, 3>{}); break;
-            case 4: go(std::integral_constant<int, 4>{}); break;
-            case 5: go(std::integral_constant<int, 5>{}); break;
-            case 6: go(std::integral_constant<int, 6>{}); break;
-            case 7: go(std::integral_constant<int, 7>{}); break;
-            default: go(std::integral_constant<int, 8>{}); break;
-        }
-        SRX_HIP(ctx, hipGetLastError());
+        SRX_TRY(launch_narrow16_tiles<false>(m, nt, tg, ctx->stream));
         m->n_tiles = nt;
         m->tile_genes = tg;
         return SRX_OK;

@@ -206,6 +206,12 @@ def test_tile_cuts_against_the_oracle(ctx, n_genes):
     lens[[3, 1200]] = 0
     m2 = oracle.Csr(2500, n_genes, np.concatenate([[0], np.cumsum(lens)]), ix[keep], vals[keep])
     a = adata_of(m2, ctx)
+    # up to 65 536 genes the upload sends the indices as 16-bit values and widens them on the device: what the handle holds is
+    # the host's pattern
+    from singlerust_amd import _ffi as F
+    ip_d, ix_d = np.zeros(2501, np.uint64), np.zeros(len(m2.indices), np.uint64)
+    F.check(F.lib().srx_matrix_download_pattern(a.x().handle, F.ptr(ip_d), F.ptr(ix_d)), ctx.handle)
+    assert np.array_equal(ip_d, m2.indptr) and np.array_equal(ix_d, m2.indices)
     assert np.array_equal(statistics.compute_number(a, sr.Direction.Column), oracle.compute_number(m2, COLUMN))
     assert np.array_equal(statistics.compute_sum(a, sr.Direction.Column), oracle.compute_sum(m2, COLUMN))
     np.testing.assert_allclose(statistics.compute_variance(a, sr.Direction.Column), oracle.compute_variance(m2, COLUMN), rtol=1e-9,
