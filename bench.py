@@ -546,8 +546,8 @@ def incl_h2d(B, H, what):
             "value": n / best[0], "unit": "cells/s", "upload_GBps_of_host_bytes": H.host_bytes / best[1] / 1e9,
             "d2h_GBps": scores.nbytes / best[3] / 1e9,
             "note": f"{what}: srx_matrix_upload of the reference-layout host CSR (u64 offsets / indices, f32 values: "
-                    f"{H.host_bytes / 1e9:.1f} GB; the H2D workers narrow the indices on the host side of the link) + srx_pipeline "
-                    "(first call on the handle: it also builds the pattern-only structures and allocates the result block) + "
+                    f"{H.host_bytes / 1e9:.1f} GB; the H2D workers narrow the indices to 16 bits on the host side of the link: 6 of a non-zero's 12 bytes cross it) + srx_pipeline "
+                    "(first call on the handle: it also counts the non-zeros per gene and allocates the result block) + "
                     "srx_result_fetch of the f64 scores; best of the runs.  The upload dominates — the drop-in uploads once and "
                     "runs the whole path on the handle; a matrix larger than HBM goes through the backed session (--backed)"}
 
@@ -769,7 +769,7 @@ def backed_run(B, config=None, cells_override=0, n_runs=None):
                    **(B.comm_info if B.dist is not None and B.comm_info else {})},
         "h2d": {"host_bytes_per_sweep_rank0": host_bytes, "GBps_sweep1_rank0": host_bytes / best["sweep1_s"] / 1e9,
                 "GBps_sweep2_rank0": host_bytes / best["sweep2_s"] / 1e9,
-                "note": "both sweeps cross PCIe (u64 indices narrowed to i32 on the host side of the link); upload-bound: the "
+                "note": "both sweeps cross PCIe (u64 indices narrowed to 16 bits on the host side of the link: 6 of a non-zero's 12 bytes cross it); upload-bound: the "
                         "kernels of a tile run under the upload of the next one"},
         "runs": runs, "setup": {"host_generate_s": t_gen},
     }
