@@ -117,6 +117,7 @@ struct srx_ctx {
         hipEvent_t ev[2] = {nullptr, nullptr};
     };
     std::vector<UpWorker> up_workers;
+    hipStream_t direct_stream = nullptr;     // upload_on: values the caller holds in pinned memory go straight from there (no staging copy)
     hipEvent_t async_ev[kAsyncSlots] = {nullptr, nullptr, nullptr, nullptr};
 };
 

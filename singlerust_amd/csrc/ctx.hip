@@ -519,7 +519,12 @@ int32_t upload_on(srx_ctx* ctx, const srx_csr* h, int32_t store, hipStream_t str
     tt[0] = trace ? now() : 0.0;
     SRX_TRY(srx_matrix_alloc(ctx, h->n_rows, h->n_cols, h->nnz, h->dtype, store, &m));
     tt[1] = trace ? now() : 0.0;
-    auto bail = [&](int32_t rc) { srx_matrix_free(m); return rc; };
+    bool direct_values = false;          // a DMA out of the caller's pinned values is in flight on ctx->direct_stream
+    auto bail = [&](int32_t rc) {
+        if (direct_values) (void)hipStreamSynchronize(ctx->direct_stream);
+        srx_matrix_free(m);
+        return rc;
+    };
     hipError_t e = hipMemcpy(m->d_indptr, h->indptr, (h->n_rows + 1) * sizeof(int64_t), hipMemcpyHostToDevice);
     tt[2] = trace ? now() : 0.0;
     if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "H2D indptr: %s", hipGetErrorString(e)));
@@ -540,6 +545,20 @@ int32_t upload_on(srx_ctx* ctx, const srx_csr* h, int32_t store, hipStream_t str
     const bool plain_values = (h->dtype == SRX_F32 && f32) || (h->dtype == SRX_F64 && !f32);
     if (h->nnz) {
         bool bad_col = false;
+        // values the caller holds in PINNED memory (hipHostMalloc / hipHostRegister: a backed reader's tile buffers) need no
+        // staging copy: one DMA straight out of them, under the workers' index narrowing
+        if (plain_values && h->nnz * val_bytes(m) >= (8u << 20)) {
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, h->values) == hipSuccess && at.type == hipMemoryTypeHost) {
+                if (!ctx->direct_stream) e = hipStreamCreateWithFlags(&ctx->direct_stream, hipStreamNonBlocking);
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(m->d_values, h->values, h->nnz * val_bytes(m), hipMemcpyHostToDevice, ctx->direct_stream);
+                if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "H2D values: %s", hipGetErrorString(e)));
+                direct_values = true;
+            } else {
+                (void)hipGetLastError();           // a plain pointer: not an error
+            }
+        }
         if (h->n_cols <= 65536) {
             e = dev_malloc(ctx, (void**)&m->d_idx16, (h->nnz + 16) * sizeof(uint16_t));
             if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "upload: %s", hipGetErrorString(e)));
@@ -552,7 +571,11 @@ int32_t upload_on(srx_ctx* ctx, const srx_csr* h, int32_t store, hipStream_t str
         if (bad_col) return bail(fail(ctx, SRX_E_BOUNDS, "column index out of bounds (>= n_cols = %llu)",
                                       (unsigned long long)h->n_cols));
         tt[3] = trace ? now() : 0.0;
-        if (plain_values) {
+        if (direct_values) {
+            e = hipStreamSynchronize(ctx->direct_stream);
+            direct_values = false;
+            if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "H2D values: %s", hipGetErrorString(e)));
+        } else if (plain_values) {
             rc = parallel_h2d(ctx, h->values, m->d_values, h->nnz, false, val_bytes(m), 0, nullptr);
             if (rc) return bail(rc);
         }
@@ -658,6 +681,7 @@ void srx_ctx_destroy(srx_ctx* ctx) {
         }
         if (uw.stream) (void)hipStreamDestroy(uw.stream);
     }
+    if (ctx->direct_stream) (void)hipStreamDestroy(ctx->direct_stream);
     for (auto e : ctx->async_ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);

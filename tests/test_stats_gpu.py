@@ -344,3 +344,39 @@ def test_compute_qc_variables_matches_oracle(ctx, dtype):
     statistics.qc_vars_inplace(a)
     assert set(a.obs) >= {"num_genes_per_cell", "sum_expr_per_cell", "var_expr_per_cell", "std_dev_per_cell"}
     assert set(a.var) >= {"num_cells_per_gene", "sum_expr_per_gene", "var_expr_per_gene", "std_dev_per_gene"}
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_upload_from_pinned_caller_buffers(ctx, dtype):
+    """Values the caller holds in PINNED host memory (hipHostMalloc — a backed reader's tile buffers) are copied by one DMA straight
+    out of them, under the workers' index narrowing (upload_on); pageable values go through the staging buffers.  Same handle
+    either way: pattern, values and the per-gene sums."""
+    import ctypes as C
+    import singlerust_amd as sr
+    from singlerust_amd import _ffi as F
+    from singlerust_amd.memory import statistics
+    m = create_large_test_data(40_000, 3000, 40.0, seed=77, dtype=np.uint16)          # ~3M non-zeros: above the direct-copy threshold (8 MiB)
+    vals = m.values.astype(dtype)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+    hip.hipHostFree.argtypes = [C.c_void_p]
+    raw = C.c_void_p()
+    assert hip.hipHostMalloc(C.byref(raw), vals.nbytes, 0) == 0
+    try:
+        ctype = C.c_float if dtype == np.float32 else C.c_double
+        pinned = np.ctypeslib.as_array(C.cast(raw, C.POINTER(ctype)), shape=(len(vals),))
+        pinned[:] = vals
+        store = F.STORE_F32 if dtype == np.float32 else F.STORE_F64
+        got = []
+        for v in (pinned, vals):
+            d = sr.DeviceCsr.upload(ctx, m.n_rows, m.n_cols, m.indptr.astype(np.uint64), m.indices.astype(np.uint64), v, store)
+            a = sr.IMAnnData(d, None, None, [], [])
+            ip_d, ix_d = np.zeros(m.n_rows + 1, np.uint64), np.zeros(len(vals), np.uint64)
+            F.check(F.lib().srx_matrix_download_pattern(d.handle, F.ptr(ip_d), F.ptr(ix_d)), ctx.handle)
+            assert np.array_equal(ip_d, m.indptr) and np.array_equal(ix_d, m.indices)
+            got.append((d.values(np.float64), statistics.compute_sum(a, sr.Direction.Column)))
+            d.free()
+        assert np.array_equal(got[0][0], vals.astype(np.float64)) and np.array_equal(got[1][0], got[0][0])
+        assert np.array_equal(got[0][1], got[1][1])
+    finally:
+        hip.hipHostFree(raw)
