@@ -393,7 +393,12 @@ fn with_resident<R>(adata: &IMAnnData, f: impl FnOnce(&mut DeviceX<'static>) -> 
         TLS.with(|t| {
             let mut slot = t.resident.borrow_mut();
             if slot.as_ref().map_or(true, |s| s.key != key) {
-                // (a stale host copy of ANOTHER matrix cannot be written back from here: lazy mode asks for flush() first)
+                // the handle about to be dropped may hold the only current values of ANOTHER matrix (lazy mode): they cannot
+                // be written back from here (that IMAnnData is not in reach), and dropping them silently would leave its host
+                // copy pre-transform for good
+                if slot.as_ref().map_or(false, |s| s.host_stale) {
+                    bail!("a lazy write-back of another X is pending: call flush() on that IMAnnData first (or invalidate() to discard it)");
+                }
                 let ctx: &'static Ctx = unsafe { &*(c as *const Ctx) };
                 *slot = None;                    // the old handle's HBM is free before the new upload asks for its own
                 *slot = Some(Resident { key, _x_elem: adata.x(), dev: DeviceX::upload(ctx, adata)?, host_stale: false, keep_f32: false });
@@ -546,6 +551,11 @@ pub mod processing_free {
         after_inplace(adata, false)                         // X becomes DynCsrMatrix::F64 whatever it was
     }
     pub fn normalize_total(adata: &IMAnnData, target_sum: f64, direction: Direction) -> anyhow::Result<IMAnnData> {
+        // `deep_clone` copies the HOST X: with a lazy write-back pending that is the pre-transform matrix (and a `&IMAnnData`
+        // cannot be flushed from here) — the same refusal as the copying filters below
+        if host_is_stale(adata) {
+            bail!("normalize_total: a lazy write-back of X is pending — call flush(adata) first (or use normalize_total_inplace)");
+        }
         let mut new_data = adata.deep_clone();              // :319, as in the reference
         normalize_total_inplace(&mut new_data, target_sum, direction)?;
         flush(&mut new_data)?;                              // a returned copy is always current
@@ -558,6 +568,9 @@ pub mod processing_free {
         after_inplace(adata, true)                          // F32 stays F32, every other dtype becomes F64
     }
     pub fn log1p_transform(adata: &IMAnnData) -> anyhow::Result<IMAnnData> {
+        if host_is_stale(adata) {
+            bail!("log1p_transform: a lazy write-back of X is pending — call flush(adata) first (or use log1p_transform_inplace)");
+        }
         let mut new_data = adata.deep_clone();
         log1p_transform_inplace(&mut new_data)?;
         flush(&mut new_data)?;
