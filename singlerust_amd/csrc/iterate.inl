@@ -517,6 +517,10 @@ __global__ __launch_bounds__(1024) void k_chol_factor_panels(const double* __res
 // registers (the j / i loops are fully unrolled: static register indices), R transposed in LDS so that
 // the i-loop of a column reads consecutive words (wave-uniform addresses: broadcast, no conflicts).
 // One wave per workgroup: k / 64 workgroups spread over as many compute units.
+// (Round 4, measured and not kept: the RIGHT-LOOKING form — w_j = wp_j / R[j][j], then wp_c -= w_j R[j][c], 63 - j independent
+//  multiply-subtracts per step — with R[j][c] as wave-uniform scalar loads at compile-time offsets: 33.6 us against 32.3, 153
+//  exposed scalar-cache round trips on the one wave of a SIMD; with the rows of R prefetched from LDS into a second register
+//  buffer the compiler hoists every row's reads to the top and spills 14 KB.)
 __global__ __launch_bounds__(64) void k_trsm_rows(const double* __restrict__ Wp, const double* __restrict__ R,
                                                   const double* __restrict__ dinv, int k, double* __restrict__ W) {
     __shared__ double Rt[L][L];          // Rt[j][i] = R[i][j]
