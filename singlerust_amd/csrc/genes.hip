@@ -447,46 +447,65 @@ __global__ void k_gene_count_reduce(const uint32_t* __restrict__ part, uint64_t 
 
 // Fixed-order sum of the per-row-block partials -> packed f64 [cnt | sum | sq | n_rows].
 // `cnt`: this shard's per-gene non-zero counts (pattern-only, k_gene_count).
-__global__ void k_moments_reduce(const double* __restrict__ part_sum, const double* __restrict__ part_sq, uint64_t n_cols,
-                                 uint64_t n_blocks, uint64_t n_rows, const uint32_t* __restrict__ cnt, double inv_fx_sum,
-                                 double inv_fx_sq, const uint32_t* __restrict__ poison, double* __restrict__ packed) {
-    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j == 0) packed[3 * n_cols] = (double)n_rows;
-    if (j >= n_cols) return;
+// Workgroup = 64 genes x kRedSlices slices of the row blocks (a thread per gene alone: 111 workgroups of one dependent walk over
+// all 341 partials each, 45 us at c3 — a fixed cost of the step however few rows a rank holds).  The fixed-point partials are
+// integers: the slices add in any order.
+constexpr int kRedSlices = 8;
+__global__ __launch_bounds__(64 * kRedSlices) void k_moments_reduce(
+    const double* __restrict__ part_sum, const double* __restrict__ part_sq, uint64_t n_cols, uint64_t n_blocks, uint64_t n_rows,
+    const uint32_t* __restrict__ cnt, double inv_fx_sum, double inv_fx_sq, const uint32_t* __restrict__ poison,
+    double* __restrict__ packed) {
+    __shared__ unsigned long long red[2][kRedSlices][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const uint64_t j = (uint64_t)blockIdx.x * 64 + lane;
+    if (blockIdx.x == 0 && threadIdx.x == 0) packed[3 * n_cols] = (double)n_rows;
+    const bool live = j < n_cols;
     double s = 0.0, q = 0.0;
     if (inv_fx_sum != 0.0) {                 // fixed-point partials (transformed values): exact integer sums
-        long long is = 0, iq = 0;
-        // (integer sums: any order; eight blocks' partials in flight per thread — one at a time this kernel took 55-65 us)
-        uint64_t b = 0;
-        for (; b + 8 <= n_blocks; b += 8) {
-            unsigned long long xs[8], xq[8];
+        unsigned long long is = 0, iq = 0;
+        if (live) {
+            // (four blocks' partials in flight per thread)
+            uint64_t b = slice;
+            for (; b + 3 * kRedSlices < n_blocks; b += 4 * kRedSlices) {
+                unsigned long long xs[4], xq[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                xs[u] = (unsigned long long)__double_as_longlong(part_sum[(b + u) * n_cols + j]);
-                xq[u] = (unsigned long long)__double_as_longlong(part_sq[(b + u) * n_cols + j]);
+                for (int u = 0; u < 4; ++u) {
+                    xs[u] = (unsigned long long)__double_as_longlong(part_sum[(b + u * kRedSlices) * n_cols + j]);
+                    xq[u] = (unsigned long long)__double_as_longlong(part_sq[(b + u * kRedSlices) * n_cols + j]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    is += xs[u];
+                    iq += xq[u];
+                }
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                is = (long long)((unsigned long long)is + xs[u]);
-                iq = (long long)((unsigned long long)iq + xq[u]);
+            for (; b < n_blocks; b += kRedSlices) {
+                is += (unsigned long long)__double_as_longlong(part_sum[b * n_cols + j]);
+                iq += (unsigned long long)__double_as_longlong(part_sq[b * n_cols + j]);
             }
         }
-        for (; b < n_blocks; ++b) {
-            is = (long long)((unsigned long long)is + (unsigned long long)__double_as_longlong(part_sum[b * n_cols + j]));
-            iq = (long long)((unsigned long long)iq + (unsigned long long)__double_as_longlong(part_sq[b * n_cols + j]));
+        red[0][slice][lane] = is;
+        red[1][slice][lane] = iq;
+        __syncthreads();
+        if (slice != 0 || !live) return;
+#pragma unroll
+        for (int u = 1; u < kRedSlices; ++u) {
+            is += red[0][u][lane];
+            iq += red[1][u][lane];
         }
         // every contribution carried the bit pattern of the 1.5 * 2^52 rounding constant along (k_gene_moments): off again
         const unsigned long long cn = (unsigned long long)cnt[j];
         const unsigned long long magic_bits = (unsigned long long)__double_as_longlong(6755399441055744.0);
-        is = (long long)((unsigned long long)is - cn * magic_bits);
-        iq = (long long)((unsigned long long)iq - cn * magic_bits);
-        s = (double)is * inv_fx_sum;
-        q = (double)iq * inv_fx_sq;
+        s = (double)(long long)(is - cn * magic_bits) * inv_fx_sum;
+        q = (double)(long long)(iq - cn * magic_bits) * inv_fx_sq;
         if (poison[j]) s = q = __builtin_nan("");
-    } else
-    for (uint64_t b = 0; b < n_blocks; ++b) {
-        s += part_sum[b * n_cols + j];
-        q += part_sq[b * n_cols + j];
+    } else {
+        // f64 partials of the raw values: ONE fixed order (the row blocks in sequence), by the first slice
+        if (slice != 0 || !live) return;
+        for (uint64_t b = 0; b < n_blocks; ++b) {
+            s += part_sum[b * n_cols + j];
+            q += part_sq[b * n_cols + j];
+        }
     }
     packed[j] = (double)cnt[j];
     packed[n_cols + j] = s;
@@ -792,7 +811,7 @@ static int32_t local_moments(srx_mat* m, double** packed_out, RowXf xf = RowXf{}
             if (m->d_idx16) SRX_TRY(pick(double{}, uint16_t{}, (const uint16_t*)m->d_idx16, (const double*)m->d_values));
             else SRX_TRY(pick(double{}, int32_t{}, (const int32_t*)m->d_indices, (const double*)m->d_values));
         }
-        hipLaunchKernelGGL(k_moments_reduce, dim3((unsigned)((G + 255) / 256 + 1)), dim3(256), 0, ctx->stream, p_sum, p_sq, G, nb,
+        hipLaunchKernelGGL(k_moments_reduce, dim3((unsigned)((G + 63) / 64 ? (G + 63) / 64 : 1)), dim3(64 * kRedSlices), 0, ctx->stream, p_sum, p_sq, G, nb,
                            m->n_rows, (const uint32_t*)m->d_cnt_pat, fx_sum != 0.0 ? 1.0 / fx_sum : 0.0,
                            fx_sq != 0.0 ? 1.0 / fx_sq : 0.0, (const uint32_t*)d_poison, packed);
     }
@@ -1079,7 +1098,7 @@ __global__ void k_hvg_gather(const double* __restrict__ var, uint32_t G, const d
 // rank_out[gene] for every candidate (zeroed by k_hvg_gather; the others keep 0xffffffff): candidates above it under
 // (variance desc, index asc).  Block (x, y): candidates 256 x .. against the y-th tile of the candidate list; partial ranks
 // are summed with integer atomics.
-constexpr int kCandTile = 512;
+constexpr int kCandTile = 128;      // (512: 44 us per launch at c3 — each thread walks a whole tile; 128: four times the workgroups, a quarter of the walk)
 __global__ __launch_bounds__(256) void k_rank_candidates(const double* __restrict__ var, const uint32_t* __restrict__ counter,
                                                          uint32_t n, uint32_t cap, const uint32_t* __restrict__ cand,
                                                          uint32_t* __restrict__ rank_out) {
