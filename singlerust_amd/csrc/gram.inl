@@ -42,7 +42,9 @@ __global__ __launch_bounds__(256) void k_rec_count(const int64_t* __restrict__ r
     if (threadIdx.x == 0) blk_total[blockIdx.x] = (int64_t)(part[0] + part[1] + part[2] + part[3]);
 }
 // exclusive scan of the block totals by one workgroup: base[0 .. n], base[n] = all records
-__global__ __launch_bounds__(1024) void k_rec_scan(const int64_t* __restrict__ blk_total, uint64_t n, int64_t* __restrict__ base) {
+// (`also`, nullable: one more number the host wants with the same read-back — copied to base[n + 1])
+__global__ __launch_bounds__(1024) void k_rec_scan(const int64_t* __restrict__ blk_total, uint64_t n, int64_t* __restrict__ base,
+                                                   const int64_t* __restrict__ also = nullptr) {
     __shared__ int64_t wsum[16];
     __shared__ int64_t carry_s;
     if (threadIdx.x == 0) carry_s = 0;
@@ -66,7 +68,10 @@ __global__ __launch_bounds__(1024) void k_rec_scan(const int64_t* __restrict__ b
         if (threadIdx.x == 1023) carry_s = before + inc;
         __syncthreads();
     }
-    if (threadIdx.x == 0) base[n] = carry_s;
+    if (threadIdx.x == 0) {
+        base[n] = carry_s;
+        if (also) base[n + 1] = *also;
+    }
 }
 
 template <typename VT>

@@ -248,15 +248,22 @@ int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words, int k,
         SRX_TRY(gram_plan(ctx, k, N, g));
         int64_t *blk_total, *rec_base;
         SRX_TRY(scratch(ctx, "pca_brtot", g.n_rblk * sizeof(int64_t), (void**)&blk_total));
-        SRX_TRY(scratch(ctx, "pca_brbase", (g.n_rblk + 1) * sizeof(int64_t), (void**)&rec_base));
+        SRX_TRY(scratch(ctx, "pca_brbase", (g.n_rblk + 2) * sizeof(int64_t), (void**)&rec_base));
         hipLaunchKernelGGL(k_rec_count, dim3((unsigned)g.n_rblk), dim3(256), 0, ctx->stream, (const int64_t*)rm.ptr, N, g.rblk, blk_total);
-        hipLaunchKernelGGL(k_rec_scan, dim3(1), dim3(1024), 0, ctx->stream, (const int64_t*)blk_total, g.n_rblk, rec_base);
+        hipLaunchKernelGGL(k_rec_scan, dim3(1), dim3(1024), 0, ctx->stream, (const int64_t*)blk_total, g.n_rblk, rec_base,
+                           (const int64_t*)d_total);
         SRX_HIP(ctx, hipGetLastError());
         d_nrecs = rec_base + g.n_rblk;
     }
     int64_t total = 0;
-    SRX_TRY(d2h(ctx, &total, d_total, sizeof(int64_t)));
-    if (d_nrecs) SRX_TRY(d2h(ctx, &rm.n_recs, d_nrecs, sizeof(int64_t)));     // (the stream has drained: a copy, no wait)
+    if (d_nrecs) {                            // {records, compacted size}: ONE copy (the scan kernel put the second number next to the first)
+        int64_t both[2] = {0, 0};
+        SRX_TRY(d2h(ctx, both, d_nrecs, sizeof both));
+        rm.n_recs = both[0];
+        total = both[1];
+    } else {
+        SRX_TRY(d2h(ctx, &total, d_total, sizeof(int64_t)));
+    }
     if (t256p) {
         SRX_TRY(scan_exclusive(ctx, cnt256, n256, t256.tptr, nullptr));
         SRX_TRY(alloc_tiled(m, N, (uint64_t)total, k, KT, t256));
@@ -378,7 +385,7 @@ int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce) 
     if (!empty) {
         SRX_TRY(scratch(ctx, "pca_boff", g.n_rblk * (size_t)(g.n_wg + 1) * sizeof(uint32_t), (void**)&boff));
         SRX_TRY(scratch(ctx, "pca_brtot", g.n_rblk * sizeof(int64_t), (void**)&blk_total));
-        SRX_TRY(scratch(ctx, "pca_brbase", (g.n_rblk + 1) * sizeof(int64_t), (void**)&rec_base));
+        SRX_TRY(scratch(ctx, "pca_brbase", (g.n_rblk + 2) * sizeof(int64_t), (void**)&rec_base));
         // SRX_K_BUCKET: record counts, their read-back, the bucket pass — the compacted matrix read once (twice through L2),
         // the records written once
         ProfScope ps(ctx, SRX_K_BUCKET, (double)rm.nnz * sizeof(GramPk<VT>) + (double)(rm.n_rows + 1) * 8.0 * 2.0);
