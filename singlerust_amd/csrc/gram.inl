@@ -289,19 +289,82 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     // gone out: when its records are first read, a slab later, every load issued after it has long been waited for — the
     // compiler waits for ALL outstanding loads at that point (vmcnt is in order and it cannot count across the loop), so a
     // refill issued last would be a full round trip exposed per slab.
+    // f32 entries (8 bytes): TWO records per load instruction.  What the operand fetch costs is the load INSTRUCTION — one wave
+    // load per ~18.6 clocks and CU whether it serves 16, 36 or 64 lanes, one run of addresses or four (bench_micro/l2_gather.hip:
+    // 3.0-3.2 ms per 1e8 loads on 256 CUs, the rate this kernel ran at with one ~36-entry suffix per load) — so lanes 0-31 take
+    // record 2p and lanes 32-63 record 2p + 1, 16 bytes (two consecutive entries) per lane: half the load instructions, the same
+    // number of LDS atomics (two per lane).  Lanes past a record's end re-read its first two entries (same line: nothing more is
+    // fetched; no branch or exec mask around the load).
+    constexpr bool kPair = sizeof(VT) == 4;
+    constexpr int kL = kUnroll / 2;                  // load instructions of a batch of kUnroll records
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    struct LoadedP {
+        u4 raw[kL];                                  // (j, v) of entries 2 l and 2 l + 1 of the lane's record
+        uint32_t lenrb[kL][2];                       // wave-uniform: the two records of a load
+        VT va[kL][2];
+    };
+    const bool hi = lane >= 32;
+    const uint32_t l2 = (uint32_t)(lane & 31) * 2u;
+    auto batchP = [&](const Slab& sl, int u0) -> LoadedP {
+        LoadedP l;
+#pragma unroll
+        for (int u = 0; u < kL; ++u) {               // lanes past sl.n hold empty records: len 0, pos 0
+            const uint32_t posA = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.pos, u0 + 2 * u);
+            const uint32_t posB = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.pos, u0 + 2 * u + 1);
+            l.lenrb[u][0] = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.lenrb, u0 + 2 * u);
+            l.lenrb[u][1] = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.lenrb, u0 + 2 * u + 1);
+            l.va[u][0] = readlane_v(sl.r.va, u0 + 2 * u);
+            l.va[u][1] = readlane_v(sl.r.va, u0 + 2 * u + 1);
+            const uint32_t pos = hi ? posB : posA;
+            const uint32_t len = (hi ? l.lenrb[u][1] : l.lenrb[u][0]) & 0xffu;
+            const uint32_t off = l2 < len ? l2 : 0u;
+            l.raw[u] = *reinterpret_cast<const u4*>(reinterpret_cast<const char*>(sl.rmb) + (size_t)((pos + off) * 8u));
+        }
+        return l;
+    };
+    auto processP = [&](const LoadedP& l) {
+#pragma unroll
+        for (int u = 0; u < kL; ++u) {
+            const uint32_t lenrb = hi ? l.lenrb[u][1] : l.lenrb[u][0];
+            const VT va = hi ? l.va[u][1] : l.va[u][0];
+            const int rbase = (int)lenrb >> 8;
+            const uint32_t len = lenrb & 0xffu;
+            // (the components go through scalars: __builtin_bit_cast of a vector ELEMENT read component 0 for .y and .w alike)
+            const unsigned j0 = l.raw[u].x, b0 = l.raw[u].y, j1 = l.raw[u].z, b1 = l.raw[u].w;
+            if (l2 < len)
+                __hip_atomic_fetch_add(&acc[rbase + (int)j0], gram_product(va, (VT)__uint_as_float(b0)), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (l2 + 1u < len)
+                __hip_atomic_fetch_add(&acc[rbase + (int)j1], gram_product(va, (VT)__uint_as_float(b1)), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
     auto consume = [&](const Slab& sl, Slab& other) {
         const int n = (int)sl.n;
-        Loaded A = batch(sl, 0), B;
-        other = next_slab();
+        if constexpr (kPair) {
+            LoadedP A = batchP(sl, 0), B;
+            other = next_slab();
 #pragma unroll
-        for (int u0 = 0; u0 < kWave; u0 += 2 * kUnroll) {
-            // no branch around a batch's loads (slots past n are empty records, their loads hit the block's first line):
-            // after a conditional load the compiler's wait for A's entries also waits for B's
-            B = batch(sl, u0 + kUnroll);
-            process(A);
-            if (u0 + 2 * kUnroll < kWave) A = batch(sl, u0 + 2 * kUnroll);
-            process(B);
-            if (u0 + 2 * kUnroll >= n) break;
+            for (int u0 = 0; u0 < kWave; u0 += 2 * kUnroll) {
+                B = batchP(sl, u0 + kUnroll);
+                processP(A);
+                if (u0 + 2 * kUnroll < kWave) A = batchP(sl, u0 + 2 * kUnroll);
+                processP(B);
+                if (u0 + 2 * kUnroll >= n) break;
+            }
+        } else {
+            Loaded A = batch(sl, 0), B;
+            other = next_slab();
+#pragma unroll
+            for (int u0 = 0; u0 < kWave; u0 += 2 * kUnroll) {
+                // no branch around a batch's loads (slots past n are empty records, their loads hit the block's first line):
+                // after a conditional load the compiler's wait for A's entries also waits for B's
+                B = batch(sl, u0 + kUnroll);
+                process(A);
+                if (u0 + 2 * kUnroll < kWave) A = batch(sl, u0 + 2 * kUnroll);
+                process(B);
+                if (u0 + 2 * kUnroll >= n) break;
+            }
         }
     };
     {
