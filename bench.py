@@ -57,10 +57,10 @@ ROOF_NOTE = {
                    "its row pointers read once + the packed upper triangle of G written once; the 12-byte owner records and block "
                    "offsets this kernel reads besides are `aux_bytes_per_launch`.  Not an HBM-bound kernel (`other_bounds`): N m(m+1)/2 "
                    "= 3.4-3.7e9 scalar products per launch at c3, each one lane of an f64 LDS atomic fed by one gathered 8-byte "
-                   "operand (every row suffix is re-read once per kept entry of its row: 2.98e8 L1->L2 requests = 19 GB per launch, "
-                   "0.124 per clock and CU, L2 hits 66 % with the misses mostly compulsory per XCD, LDS pipe 70 % busy — "
-                   "profiles/r04_pmc_gram.md).  Knock-outs of round 3 (DESIGN.md section 3c): without the atomics 3.73 of 3.91 ms, an "
-                   "inline-asm core with 5 instead of 14 scalar instructions per record 3.92 ms, and 1.99 without its suffix loads",
+                   "operand.  The operand fetch costs per load INSTRUCTION (~18.6 clk per CU whatever the lanes or runs it serves, "
+                   "bench_micro/l2_gather.hip: the one-suffix-per-load kernel of rounds 2-3, 1.0e8 loads, ran at exactly that rate, "
+                   "3.89 ms); a load now serves two owner records (16 bytes per lane): 6.2e7 loads, 3.17 ms, VALU 95 % and LDS pipe "
+                   "88 % busy (profiles/r04_pmc_gram.md)",
     "spmm_fwd": "algorithmic bytes: the row-major compacted matrix (nnz_w * 8) + row pointers and row order (N * 12) + the "
                 "k x 64 f32 panel once per workgroup column slice + the output, which for this launch (the transform) is the "
                 "N x n_pc f64 score matrix written by the SpMM itself (rows of n_pc rounded up to 16 doubles in HBM).  What bounds "
@@ -373,6 +373,7 @@ def attributed(prof, steps):
 
 LDS_PEAK_GBS = 128 * 256 * 2.4          # 128 B / clk / CU x 256 CUs x 2.4 GHz = 78 643 GB/s (MI355X_MICROARCH.md)
 LDS_F64_ATOMIC_LANES_PER_S = 2.5 * 256 * 2.4e9     # random-address ds_add_f64: 2.5 lanes / clk / CU (bench_micro/lds_atomic_banks.hip)
+GATHER_LOADS_PER_S = 1e8 / 3.04e-3                 # L2-resident wave loads of the Gram kernel's shape (bench_micro/l2_gather.hip)
 
 
 def roof(d, kernel, note, other=None):
@@ -403,13 +404,17 @@ def other_bounds(name, d, nnz_sel, n_cells, sigma=0.3):
         import math
         m = nnz_sel / n_cells
         products = n_cells * (m * m * math.exp(sigma * sigma) + m) / 2.0       # sum over cells of m_i (m_i + 1) / 2, log-normal m_i
+        loads = nnz_sel * 1.07 / 2.0
         return {"lds_f64_atomics": {"achieved": products / t, "peak": LDS_F64_ATOMIC_LANES_PER_S, "unit": "lane-atomics/s",
                                     "frac": products / t / LDS_F64_ATOMIC_LANES_PER_S, "products_per_launch_estimate": products,
                                     "note": "one f64 LDS atomic lane per scalar product; peak = the measured random-address "
                                             "ds_add_f64 rate"},
-                "l1_fill": {"achieved": products * 8.0 / t / 1e9, "unit": "GB/s requested by the suffix gathers (8 B per product)",
-                            "note": "profiles/r04_pmc_gram.md: 2.98e8 L1->L2 requests of 64 B per launch = 0.125 per clock and "
-                                    "CU, the per-CU miss throughput an HBM stream gets too"}}
+                "gather_loads": {"achieved": loads / t, "peak": GATHER_LOADS_PER_S, "unit": "load instructions/s",
+                                 "frac": loads / t / GATHER_LOADS_PER_S, "loads_per_launch_estimate": loads,
+                                 "note": "one load instruction per TWO owner records (records = kept entries x 1.07: a suffix longer "
+                                         "than 64 entries is several); peak = the L2-resident rate of bench_micro/l2_gather.hip, "
+                                         "1e8 wave loads in 3.04 ms on 256 CUs with 16 waves x 8 loads in flight (5.0 ms out of the "
+                                         "Infinity Cache, 6.3 out of HBM: 59 % of this kernel's requests hit L2)"}}
     return None
 
 
