@@ -300,8 +300,8 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
     struct LoadedP {
         u4 raw[kL];                                  // (j, v) of entries 2 l and 2 l + 1 of the lane's record
-        uint32_t lenrb[kL][2];                       // wave-uniform: the two records of a load
-        VT va[kL][2];
+        uint32_t lenrb[kL];                          // per lane: its record's length and row base ...
+        VT va[kL];                                   // ... and value (selected once, when the load is issued)
     };
     const bool hi = lane >= 32;
     const uint32_t l2 = (uint32_t)(lane & 31) * 2u;
@@ -311,12 +311,13 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
         for (int u = 0; u < kL; ++u) {               // lanes past sl.n hold empty records: len 0, pos 0
             const uint32_t posA = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.pos, u0 + 2 * u);
             const uint32_t posB = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.pos, u0 + 2 * u + 1);
-            l.lenrb[u][0] = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.lenrb, u0 + 2 * u);
-            l.lenrb[u][1] = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.lenrb, u0 + 2 * u + 1);
-            l.va[u][0] = readlane_v(sl.r.va, u0 + 2 * u);
-            l.va[u][1] = readlane_v(sl.r.va, u0 + 2 * u + 1);
+            const uint32_t lrA = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.lenrb, u0 + 2 * u);
+            const uint32_t lrB = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.lenrb, u0 + 2 * u + 1);
+            const VT vaA = readlane_v(sl.r.va, u0 + 2 * u), vaB = readlane_v(sl.r.va, u0 + 2 * u + 1);
             const uint32_t pos = hi ? posB : posA;
-            const uint32_t len = (hi ? l.lenrb[u][1] : l.lenrb[u][0]) & 0xffu;
+            l.lenrb[u] = hi ? lrB : lrA;
+            l.va[u] = hi ? vaB : vaA;
+            const uint32_t len = l.lenrb[u] & 0xffu;
             const uint32_t off = l2 < len ? l2 : 0u;
             l.raw[u] = *reinterpret_cast<const u4*>(reinterpret_cast<const char*>(sl.rmb) + (size_t)((pos + off) * 8u));
         }
@@ -325,8 +326,8 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     auto processP = [&](const LoadedP& l) {
 #pragma unroll
         for (int u = 0; u < kL; ++u) {
-            const uint32_t lenrb = hi ? l.lenrb[u][1] : l.lenrb[u][0];
-            const VT va = hi ? l.va[u][1] : l.va[u][0];
+            const uint32_t lenrb = l.lenrb[u];
+            const VT va = l.va[u];
             const int rbase = (int)lenrb >> 8;
             const uint32_t len = lenrb & 0xffu;
             // (the components go through scalars: __builtin_bit_cast of a vector ELEMENT read component 0 for .y and .w alike)
