@@ -329,6 +329,37 @@ def test_spmm_and_gram_kernels_vs_scipy(ctx, store, n, g, density, k):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("store", [1, 2])
+def test_gram_record_piece_and_pair_boundaries(ctx, store):
+    """The sparse Gram kernel works on RECORDS — one kept entry x at most 64 entries of its row's suffix, a longer suffix cut into
+    several — and, for f32 entries, serves TWO records per load instruction (lanes 0-31 / 32-63, two consecutive entries per lane).
+    Rows of 1, 2, 3, 31 .. 33, 63 .. 66, 127 .. 130 and 200 kept entries put suffixes on every side of those boundaries (odd and even
+    lengths, pieces of exactly 64, a last piece of 1), the last rows end at the end of the entry array, empty rows sit between them;
+    integer values: X^T X must be exact."""
+    import scipy.sparse as sp
+    from singlerust_amd import _ffi
+    rng = np.random.default_rng(99)
+    k = g = 320
+    lens = [1, 2, 3, 0, 31, 32, 33, 63, 64, 65, 66, 0, 127, 128, 129, 130, 200, 0, 5, 64, 1]
+    lens = lens * 3
+    rows, cols, vals = [], [], []
+    for r, n in enumerate(lens):
+        c = np.sort(rng.choice(g, n, replace=False))
+        rows += [r] * n
+        cols += list(c)
+        vals += list(rng.integers(1, 7, n))
+    x = sp.csr_matrix((np.array(vals, dtype=np.float64), (rows, cols)), shape=(len(lens), g))
+    x.sort_indices()
+    import singlerust_amd as sr
+    a = sr.IMAnnData.new_basic(x, ctx=ctx, store=store)
+    sel = np.arange(k).astype(np.uint64)
+    P = rng.standard_normal((k, 64))
+    y, t, gram = np.zeros((len(lens), 64)), np.zeros((k, 64)), np.zeros((k, k))
+    _ffi.check(_ffi.lib().srx_spmm(a.x().handle, _ffi.ptr(sel), k, _ffi.ptr(P), _ffi.ptr(y), _ffi.ptr(t), _ffi.ptr(gram)), ctx.handle)
+    assert np.array_equal(gram, (x.T @ x).toarray())
+
+
+@pytest.mark.gpu
 def test_pipeline_device_selection_ties_and_results(ctx):
     """The pipeline selects HighlyVariable(n) on the device (k_gene_var / k_hvg_rank / k_sel_finish): the
     selection and its ORDER must equal the stable descending sort of the oracle (dim_red/mod.rs:135-140)
