@@ -131,12 +131,32 @@ __global__ __launch_bounds__(256) void k_row_sum(const int64_t* __restrict__ ind
     for (uint64_t r = wave; r < n_rows; r += n_waves) {
         const int64_t lo = indptr[r], hi = indptr[r + 1];
         double s = 0.0;
-        int64_t p = lo + lane;
-        for (; p + 3 * kWave < hi; p += 4 * kWave) {
-            T a = vals[p], b = vals[p + kWave], c = vals[p + 2 * kWave], d = vals[p + 3 * kWave];
-            s += (double)a; s += (double)b; s += (double)c; s += (double)d;
+        if constexpr (sizeof(T) == 4) {
+            // four consecutive values per lane and load (16 bytes at the row's own 4-byte alignment: fine on gfx950) — one value per
+            // lane was 17M load instructions per launch at c3, ~0.5 ms of the memory pipeline's instruction rate alone.  (f32
+            // values summed in f64: the order does not show unless a row spans more than 2^29 in magnitude.)
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+            const int64_t n4 = (hi - lo) >> 2;
+            int64_t q = lane;
+            for (; q + kWave < n4; q += 2 * kWave) {
+                const f4u a = *reinterpret_cast<const f4u*>(vals + lo + 4 * q), b = *reinterpret_cast<const f4u*>(vals + lo + 4 * (q + kWave));
+                s += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
+                s += ((double)b.x + (double)b.y) + ((double)b.z + (double)b.w);
+            }
+            if (q < n4) {
+                const f4u a = *reinterpret_cast<const f4u*>(vals + lo + 4 * q);
+                s += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
+            }
+            const int64_t t = lo + 4 * n4 + lane;
+            if (t < hi) s += (double)vals[t];
+        } else {
+            int64_t p = lo + lane;
+            for (; p + 3 * kWave < hi; p += 4 * kWave) {
+                T a = vals[p], b = vals[p + kWave], c = vals[p + 2 * kWave], d = vals[p + 3 * kWave];
+                s += (double)a; s += (double)b; s += (double)c; s += (double)d;
+            }
+            for (; p < hi; p += kWave) s += (double)vals[p];
         }
-        for (; p < hi; p += kWave) s += (double)vals[p];
         s = wave_sum(s);
         if (lane == 0) out[r] = s;
     }
