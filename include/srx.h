@@ -129,7 +129,11 @@ int32_t srx_partition_rows(const uint64_t* indptr, uint64_t n_rows, int32_t n_ra
 
 /* ---- matrix ------------------------------------------------------------------------------ */
 /* Narrowing upload of a reference-layout CSR (u64 -> i32 column indices on device, i64 row
- * offsets).  Validates sortedness/bounds on device (SRX_E_FORMAT / SRX_E_BOUNDS). */
+ * offsets).  Validates sortedness/bounds on device (SRX_E_FORMAT / SRX_E_BOUNDS).
+ * The indices are narrowed on the HOST side of the link by the transfer workers (to 16 bits
+ * when n_cols <= 65536: 2 of their 8 bytes cross PCIe); the host buffers may be pageable or
+ * pinned (hipHostMalloc / hipHostRegister: values of the storage type are then copied by one
+ * DMA straight out of them).  The call returns when every host buffer has been read. */
 int32_t srx_matrix_upload(srx_ctx* ctx, const srx_csr* host, int32_t store, srx_mat** out);
 /* CSC storage (ArrayData::CscMatrix / DynCscMatrix): `host` describes X (n_rows cells x n_cols
  * genes) with indptr = col_offsets[n_cols+1], indices = row_indices[nnz] (sorted per column).
