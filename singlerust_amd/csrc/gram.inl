@@ -71,15 +71,22 @@ __global__ __launch_bounds__(1024) void k_rec_scan(const int64_t* __restrict__ b
     if (threadIdx.x == 0) {
         base[n] = carry_s;
         if (also) base[n + 1] = *also;
+        base[n + 2] = 0;                  // the bucket pass's value statistics (gram_stat below): zeroed here, before it runs
+        base[n + 3] = 0;
     }
 }
+// Value statistics of the compacted matrix, made by the bucket pass for the stripe kernel's fixed-point mode (f32 entries):
+// [0] bits of max |v|, [1] ~bits of the smallest non-zero |v| (a max again: 0 = none), [2] != 0: a negative value was seen.
+__device__ __forceinline__ uint32_t* gram_stat(int64_t* rec_base, uint64_t n_rblk) { return reinterpret_cast<uint32_t*>(rec_base + n_rblk + 2); }
 
 template <typename VT>
 __global__ __launch_bounds__(kBucketThreads) void k_bucket(const int64_t* __restrict__ rm_ptr, const GramPk<VT>* __restrict__ rm,
                                                            uint64_t n_rows, uint32_t rblk, int k, int sr_shift, int n_wg, int n_stripes,
                                                            const int64_t* __restrict__ rec_base, uint32_t* __restrict__ boff,
-                                                           GramRec<VT>* __restrict__ recs) {
+                                                           GramRec<VT>* __restrict__ recs, uint32_t* __restrict__ gstat /* gram_stat(): f32 only */) {
     extern __shared__ double lds_raw[];
+    __shared__ uint32_t s_stat[3];
+    if (threadIdx.x < 3) s_stat[threadIdx.x] = 0u;
     uint32_t* hist = reinterpret_cast<uint32_t*>(lds_raw);        // n_wg + 1 counters, then rblk + 1 row ends
     uint32_t* rptr = hist + n_wg + 1;                             // row starts of the block, relative to its first entry
     const uint64_t rb = blockIdx.x;
@@ -121,11 +128,29 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket(const int64_t* __rest
             }
         }
     };
-    walk([&](uint32_t p, int j, VT, uint32_t end) {
+    uint32_t vmax_b = 0u, vmin_nb = 0u, neg = 0u;
+    walk([&](uint32_t p, int j, VT v, uint32_t end) {
         __hip_atomic_fetch_add(&hist[gram_owner(j, sr_shift, n_wg, n_stripes)], (end - p + 63u) >> 6, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
+        if constexpr (sizeof(VT) == 4) {
+            const uint32_t b = __float_as_uint(v), ab = b & 0x7fffffffu;
+            vmax_b = ab > vmax_b ? ab : vmax_b;
+            vmin_nb = (ab != 0u && ~ab > vmin_nb) ? ~ab : vmin_nb;
+            neg |= b >> 31;
+        }
     });
+    if constexpr (sizeof(VT) == 4) {
+        if (vmax_b) atomicMax(&s_stat[0], vmax_b);
+        if (vmin_nb) atomicMax(&s_stat[1], vmin_nb);
+        if (neg) atomicOr(&s_stat[2], 1u);
+    }
     __syncthreads();
+    if constexpr (sizeof(VT) == 4) {
+        if (threadIdx.x < 3 && gstat && s_stat[threadIdx.x]) {
+            if (threadIdx.x == 2) atomicOr(&gstat[2], 1u);
+            else atomicMax(&gstat[threadIdx.x], s_stat[threadIdx.x]);
+        }
+    }
     // exclusive scan of the n_wg counters by wave 0, 64 at a time
     if (wave == 0) {
         uint32_t carry = 0;
@@ -188,7 +213,8 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     const int64_t* __restrict__ rm_ptr, const GramPk<VT>* __restrict__ rm, const uint32_t* __restrict__ boff,
     const int64_t* __restrict__ rec_base, const GramRec<VT>* __restrict__ recs, uint64_t n_rblk, uint32_t rblk, int k,
     int sr_shift, int n_wg, int n_stripes, uint32_t n_chunk, int w0 /* first owner of this launch */, int n_w /* owners in it */,
-    double* __restrict__ Gp /* packed upper triangle, ACCUMULATED into (global f64 atomics) */) {
+    double* __restrict__ Gp /* packed upper triangle, ACCUMULATED into (global f64 atomics) */,
+    const uint32_t* __restrict__ gstat /* gram_stat(), nullable */) {
     using Entry = GramPk<VT>;
     using Rec = GramRec<VT>;
     // suffix loads in flight per batch: 16-byte f64 entries take twice the registers (8 of them spilled)
@@ -203,6 +229,30 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     __syncthreads();
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    // FIXED-POINT mode (f32 entries, decided from the bucket pass's statistics — the same for every workgroup of the launch):
+    // no negative value and the binary exponents of all non-zero |v| within 6 of the largest's (normalised + log1p'd counts are).  A
+    // product va * v is then formed in f32 ALREADY SCALED by a power of two (va carries it: p 2^kq < 2^31, kq from the exponent of
+    // max |v|), rounded to an integer and added with a 64-bit INTEGER LDS atomic — `ds_add_u64` on random addresses runs at 1.9x the
+    // rate of `ds_add_f64` (bench_micro/lds_atomic_banks.hip) and the LDS pipe was this kernel's wall; the conversion costs what the
+    // f32 -> f64 conversion cost.  Every product is off by at most half a unit = 2^-30 of the largest possible one — what the f32
+    // rounding of a typical product is (2^-24 of itself); a product above 2^-7 of the largest has >= 2^24 units and loses nothing.
+    // Integer sums do not depend on the order the atomics land in.  Otherwise (negative values, a wide range, f64 entries): f32
+    // products converted to f64, `ds_add_f64`, as before.
+    bool fx = false;
+    float fx_scale = 1.f;
+    double fx_inv = 1.0;
+    if constexpr (sizeof(VT) == 4) {
+        if (gstat) {
+            const uint32_t vmax_b = gstat[0], vmin_b = ~gstat[1], neg = gstat[2];
+            const int emax = (int)(vmax_b >> 23) - 127, emin = (int)(vmin_b >> 23) - 127;
+            if (neg == 0u && vmax_b != 0u && vmax_b < 0x7f800000u && gstat[1] != 0u && emax - emin <= 6 && emax > -48 && emax < 48) {
+                const int kq = 29 - 2 * emax;             // p < 2^(2 emax + 2): p 2^kq < 2^31
+                fx = true;
+                fx_scale = __uint_as_float((uint32_t)(kq + 127) << 23);
+                fx_inv = __longlong_as_double((long long)(1023 - kq) << 52);
+            }
+        }
+    }
     // Workgroup = (owner w, chunk z of n_chunk consecutive row blocks); blockIdx = z * n_wg + w, so the dispatcher starts
     // all owners of a chunk together and they walk its rows in the same order: what one workgroup pulls into its
     // XCD's L2 the ~60 others on that XCD hit (free-running persistent workgroups drift tens of MB apart: L2 hit rate
@@ -251,6 +301,9 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
         sl.n = i0 < cur.n ? (cur.n - i0 < (uint32_t)kWave ? cur.n - i0 : (uint32_t)kWave) : 0u;
         sl.r = Rec{0u, 0u, (VT)0};
         if ((uint32_t)lane < sl.n) sl.r = cur.rc[i0 + lane];
+        if constexpr (sizeof(VT) == 4) {
+            if (fx) sl.r.va *= fx_scale;          // (a power of two: exact; once per 64 records)
+        }
         i0 += kWave;
         return sl;
     };
@@ -323,7 +376,7 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
         }
         return l;
     };
-    auto processP = [&](const LoadedP& l) {
+    auto processP = [&](const LoadedP& l, auto fxc) {
 #pragma unroll
         for (int u = 0; u < kL; ++u) {
             const uint32_t lenrb = l.lenrb[u];
@@ -332,15 +385,25 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
             const uint32_t len = lenrb & 0xffu;
             // (the components go through scalars: __builtin_bit_cast of a vector ELEMENT read component 0 for .y and .w alike)
             const unsigned j0 = l.raw[u].x, b0 = l.raw[u].y, j1 = l.raw[u].z, b1 = l.raw[u].w;
-            if (l2 < len)
-                __hip_atomic_fetch_add(&acc[rbase + (int)j0], gram_product(va, (VT)__uint_as_float(b0)), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (l2 + 1u < len)
-                __hip_atomic_fetch_add(&acc[rbase + (int)j1], gram_product(va, (VT)__uint_as_float(b1)), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            if constexpr (decltype(fxc)::value) {
+                unsigned long long* const accu = reinterpret_cast<unsigned long long*>(acc);
+                if (l2 < len)
+                    __hip_atomic_fetch_add(accu + rbase + (int)j0, (unsigned long long)(unsigned)(__builtin_fmaf((float)va, __uint_as_float(b0), 0.5f)),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (l2 + 1u < len)
+                    __hip_atomic_fetch_add(accu + rbase + (int)j1, (unsigned long long)(unsigned)(__builtin_fmaf((float)va, __uint_as_float(b1), 0.5f)),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                if (l2 < len)
+                    __hip_atomic_fetch_add(&acc[rbase + (int)j0], gram_product(va, (VT)__uint_as_float(b0)), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (l2 + 1u < len)
+                    __hip_atomic_fetch_add(&acc[rbase + (int)j1], gram_product(va, (VT)__uint_as_float(b1)), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
     };
-    auto consume = [&](const Slab& sl, Slab& other) {
+    auto consume = [&](const Slab& sl, Slab& other, auto fxc) {
         const int n = (int)sl.n;
         if constexpr (kPair) {
             LoadedP A = batchP(sl, 0), B;
@@ -348,9 +411,9 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
 #pragma unroll
             for (int u0 = 0; u0 < kWave; u0 += 2 * kUnroll) {
                 B = batchP(sl, u0 + kUnroll);
-                processP(A);
+                processP(A, fxc);
                 if (u0 + 2 * kUnroll < kWave) A = batchP(sl, u0 + 2 * kUnroll);
-                processP(B);
+                processP(B, fxc);
                 if (u0 + 2 * kUnroll >= n) break;
             }
         } else {
@@ -368,26 +431,28 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
             }
         }
     };
-    {
+    auto run = [&](auto fxc) {
         Slab S = next_slab(), T;
         T.n = 0;
         while (S.n > 0) {
-            consume(S, T);
+            consume(S, T, fxc);
             if (T.n == 0) break;
-            consume(T, S);
+            consume(T, S, fxc);
         }
-    }
+    };
+    if (fx) run(std::true_type{});
+    else run(std::false_type{});
     __syncthreads();
     // flush: the upper-triangle part of both stripes, added to the packed matrix (row splits and, in backed
     // mode, earlier row tiles have been there before)
     for (int e = threadIdx.x; e < SR * WA; e += blockDim.x) {
         const int r = e / WA, c = a0 + e % WA, row = a0 + r;
-        const double v = acc[e];
+        const double v = fx ? (double)__double_as_longlong(acc[e]) * fx_inv : acc[e];
         if (row < k && c >= row && v != 0.0) atomicAdd(&Gp[tri_index(row, c, k)], v);
     }
     for (int e = threadIdx.x; e < SR * WB; e += blockDim.x) {
         const int r = e / WB, c = b0 + e % WB, row = b0 + r;
-        const double v = acc[SR * WA + e];
+        const double v = fx ? (double)__double_as_longlong(acc[SR * WA + e]) * fx_inv : acc[SR * WA + e];
         if (row < k && c >= row && v != 0.0) atomicAdd(&Gp[tri_index(row, c, k)], v);
     }
 }

@@ -248,7 +248,7 @@ int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words, int k,
         SRX_TRY(gram_plan(ctx, k, N, g));
         int64_t *blk_total, *rec_base;
         SRX_TRY(scratch(ctx, "pca_brtot", g.n_rblk * sizeof(int64_t), (void**)&blk_total));
-        SRX_TRY(scratch(ctx, "pca_brbase", (g.n_rblk + 2) * sizeof(int64_t), (void**)&rec_base));
+        SRX_TRY(scratch(ctx, "pca_brbase", (g.n_rblk + 4) * sizeof(int64_t), (void**)&rec_base));
         hipLaunchKernelGGL(k_rec_count, dim3((unsigned)g.n_rblk), dim3(256), 0, ctx->stream, (const int64_t*)rm.ptr, N, g.rblk, blk_total);
         hipLaunchKernelGGL(k_rec_scan, dim3(1), dim3(1024), 0, ctx->stream, (const int64_t*)blk_total, g.n_rblk, rec_base,
                            (const int64_t*)d_total);
@@ -385,7 +385,7 @@ int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce) 
     if (!empty) {
         SRX_TRY(scratch(ctx, "pca_boff", g.n_rblk * (size_t)(g.n_wg + 1) * sizeof(uint32_t), (void**)&boff));
         SRX_TRY(scratch(ctx, "pca_brtot", g.n_rblk * sizeof(int64_t), (void**)&blk_total));
-        SRX_TRY(scratch(ctx, "pca_brbase", (g.n_rblk + 2) * sizeof(int64_t), (void**)&rec_base));
+        SRX_TRY(scratch(ctx, "pca_brbase", (g.n_rblk + 4) * sizeof(int64_t), (void**)&rec_base));
         // SRX_K_BUCKET: record counts, their read-back, the bucket pass — the compacted matrix read once (twice through L2),
         // the records written once
         ProfScope ps(ctx, SRX_K_BUCKET, (double)rm.nnz * sizeof(GramPk<VT>) + (double)(rm.n_rows + 1) * 8.0 * 2.0);
@@ -403,7 +403,8 @@ int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce) 
         SRX_HIP(ctx, hipMemsetAsync(recs + n_recs, 0, kGramUnroll * sizeof(GramRec<VT>), ctx->stream));
         hipLaunchKernelGGL((k_bucket<VT>), dim3((unsigned)g.n_rblk), dim3(kBucketThreads),
                            (size_t)(g.n_wg + 1 + g.rblk + 1 + kBucketGroup) * sizeof(uint32_t), ctx->stream, rm.ptr,
-                           (const GramPk<VT>*)rm.pk, rm.n_rows, g.rblk, rm.k, g.sr_shift, g.n_wg, g.n_stripes, rec_base, boff, recs);
+                           (const GramPk<VT>*)rm.pk, rm.n_rows, g.rblk, rm.k, g.sr_shift, g.n_wg, g.n_stripes, rec_base, boff, recs,
+                           reinterpret_cast<uint32_t*>(rec_base + g.n_rblk + 2));
         SRX_HIP(ctx, hipGetLastError());
     }
     // SRX_K_GRAM: the stripe kernel alone.  Algorithmic bytes = what ANY Gram kernel must move: the compacted matrix and its
@@ -417,7 +418,7 @@ int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce) 
         if (empty) return;
         hipLaunchKernelGGL((k_gram_stripes<VT>), dim3((unsigned)(n_w * g.n_z)), dim3(kGramWaves * kWave), g.lds_bytes, st,
                            rm.ptr, (const GramPk<VT>*)rm.pk, boff, rec_base, recs, g.n_rblk, g.rblk, rm.k, g.sr_shift, g.n_wg,
-                           g.n_stripes, g.n_chunk, w0, n_w, Gp);
+                           g.n_stripes, g.n_chunk, w0, n_w, Gp, (const uint32_t*)(rec_base ? reinterpret_cast<uint32_t*>(rec_base + g.n_rblk + 2) : nullptr));
     };
     // Sharded rows: owner w holds the stripes w and n_stripes - 1 - w, so the owners [0, h) hold the rows [0, h SR) and
     // [k - h SR, k) of the triangle — two contiguous ranges of the packed array — and the others the rows between.  Two
