@@ -59,8 +59,9 @@ ROOF_NOTE = {
                    "= 3.4-3.7e9 scalar products per launch at c3, each one lane of an f64 LDS atomic fed by one gathered 8-byte "
                    "operand.  The operand fetch costs per load INSTRUCTION (~18.6 clk per CU whatever the lanes or runs it serves, "
                    "bench_micro/l2_gather.hip: the one-suffix-per-load kernel of rounds 2-3, 1.0e8 loads, ran at exactly that rate, "
-                   "3.89 ms); a load now serves two owner records (16 bytes per lane): 6.2e7 loads, 3.17 ms, VALU 95 % and LDS pipe "
-                   "88 % busy (profiles/r04_pmc_gram.md)",
+                   "3.89 ms); a load now serves two owner records (16 bytes per lane): 6.2e7 loads, 3.17 ms with ds_add_f64 (VALU 95 %, "
+                   "LDS pipe 88 % busy), 2.81 ms with the products rounded to fixed point and added as 64-bit integers (LDS 53 %, VALU "
+                   "100 % busy: profiles/r04_pmc_gram.md)",
     "spmm_fwd": "algorithmic bytes: the row-major compacted matrix (nnz_w * 8) + row pointers and row order (N * 12) + the "
                 "k x 64 f32 panel once per workgroup column slice + the output, which for this launch (the transform) is the "
                 "N x n_pc f64 score matrix written by the SpMM itself (rows of n_pc rounded up to 16 doubles in HBM).  What bounds "
@@ -373,6 +374,7 @@ def attributed(prof, steps):
 
 LDS_PEAK_GBS = 128 * 256 * 2.4          # 128 B / clk / CU x 256 CUs x 2.4 GHz = 78 643 GB/s (MI355X_MICROARCH.md)
 LDS_F64_ATOMIC_LANES_PER_S = 2.5 * 256 * 2.4e9     # random-address ds_add_f64: 2.5 lanes / clk / CU (bench_micro/lds_atomic_banks.hip)
+LDS_U64_ATOMIC_LANES_PER_S = 64 / 13.6 * 256 * 2.4e9   # random-address ds_add_u64: 13.6 clk per 64 lanes (same microbenchmark)
 GATHER_LOADS_PER_S = 1e8 / 3.04e-3                 # L2-resident wave loads of the Gram kernel's shape (bench_micro/l2_gather.hip)
 
 
@@ -405,10 +407,13 @@ def other_bounds(name, d, nnz_sel, n_cells, sigma=0.3):
         m = nnz_sel / n_cells
         products = n_cells * (m * m * math.exp(sigma * sigma) + m) / 2.0       # sum over cells of m_i (m_i + 1) / 2, log-normal m_i
         loads = nnz_sel * 1.07 / 2.0
-        return {"lds_f64_atomics": {"achieved": products / t, "peak": LDS_F64_ATOMIC_LANES_PER_S, "unit": "lane-atomics/s",
-                                    "frac": products / t / LDS_F64_ATOMIC_LANES_PER_S, "products_per_launch_estimate": products,
-                                    "note": "one f64 LDS atomic lane per scalar product; peak = the measured random-address "
-                                            "ds_add_f64 rate"},
+        return {"lds_atomics": {"achieved": products / t, "peak": LDS_U64_ATOMIC_LANES_PER_S, "unit": "lane-atomics/s",
+                                "frac": products / t / LDS_U64_ATOMIC_LANES_PER_S, "products_per_launch_estimate": products,
+                                "note": "one 64-bit LDS atomic lane per scalar product — INTEGER atomics (the kernel's fixed-point "
+                                        "mode: non-negative f32 values of bounded range, which the bench's are); peak = the measured "
+                                        "random-address ds_add_u64 rate (ds_add_f64: 2.5 lanes per clock and CU, 0.53 of it)"},
+                "valu": {"note": "the kernel's wall since the atomics are integer ones: SQ_ACTIVE_INST_VALU = 100 % of the launch "
+                                 "(profiles/r04_pmc_gram.md), 16 instructions per owner record"},
                 "gather_loads": {"achieved": loads / t, "peak": GATHER_LOADS_PER_S, "unit": "load instructions/s",
                                  "frac": loads / t / GATHER_LOADS_PER_S, "loads_per_launch_estimate": loads,
                                  "note": "one load instruction per TWO owner records (records = kept entries x 1.07: a suffix longer "
