@@ -177,7 +177,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket(const int64_t* __rest
         const uint32_t len = end - p, nch = (len + 63u) >> 6;
         uint32_t slot = __hip_atomic_fetch_add(&hist[gram_owner(j, sr_shift, n_wg, n_stripes)], nch, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t rb8 = (uint32_t)gram_row_base(j, k, sr_shift, n_wg, n_stripes) << 8;
+        const uint32_t rb8 = (uint32_t)gram_row_base(j, k, sr_shift, n_wg, n_stripes) << 11;      // BYTE offset of the row's accumulators (x 8, signed), above the length byte
         for (uint32_t o = 0; o < len; o += kWave, ++slot)
             rcb[slot] = GramRec<VT>{p + o, (len - o < (uint32_t)kWave ? len - o : (uint32_t)kWave) | rb8, v};
     });
@@ -330,10 +330,10 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     auto process = [&](const Loaded& l) {
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            const int rbase = (int)l.lenrb[u] >> 8;
+            double* const row = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + ((int)l.lenrb[u] >> 8));      // (signed: a row base may be negative)
             const uint32_t len = l.lenrb[u] & 0xffu;
             if ((uint32_t)lane < len)
-                __hip_atomic_fetch_add(&acc[rbase + l.e[u].j], gram_product(l.va[u], l.e[u].v), __ATOMIC_RELAXED,
+                __hip_atomic_fetch_add(row + l.e[u].j, gram_product(l.va[u], l.e[u].v), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
@@ -381,24 +381,26 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
         for (int u = 0; u < kL; ++u) {
             const uint32_t lenrb = l.lenrb[u];
             const VT va = l.va[u];
-            const int rbase = (int)lenrb >> 8;
+            char* const rowb = reinterpret_cast<char*>(acc) + ((int)lenrb >> 8);      // the record carries the row's byte offset (signed: column indices are absolute)
             const uint32_t len = lenrb & 0xffu;
             // (the components go through scalars: __builtin_bit_cast of a vector ELEMENT read component 0 for .y and .w alike)
             const unsigned j0 = l.raw[u].x, b0 = l.raw[u].y, j1 = l.raw[u].z, b1 = l.raw[u].w;
             if constexpr (decltype(fxc)::value) {
-                unsigned long long* const accu = reinterpret_cast<unsigned long long*>(acc);
+                // (the row's address first: one shift-add per product instead of a shift and a three-operand add)
+                unsigned long long* const accu = reinterpret_cast<unsigned long long*>(rowb);
                 if (l2 < len)
-                    __hip_atomic_fetch_add(accu + rbase + (int)j0, (unsigned long long)(unsigned)(__builtin_fmaf((float)va, __uint_as_float(b0), 0.5f)),
+                    __hip_atomic_fetch_add(accu + (int)j0, (unsigned long long)(unsigned)(__builtin_fmaf((float)va, __uint_as_float(b0), 0.5f)),
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (l2 + 1u < len)
-                    __hip_atomic_fetch_add(accu + rbase + (int)j1, (unsigned long long)(unsigned)(__builtin_fmaf((float)va, __uint_as_float(b1), 0.5f)),
+                    __hip_atomic_fetch_add(accu + (int)j1, (unsigned long long)(unsigned)(__builtin_fmaf((float)va, __uint_as_float(b1), 0.5f)),
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
+                double* const accd = reinterpret_cast<double*>(rowb);
                 if (l2 < len)
-                    __hip_atomic_fetch_add(&acc[rbase + (int)j0], gram_product(va, (VT)__uint_as_float(b0)), __ATOMIC_RELAXED,
+                    __hip_atomic_fetch_add(accd + (int)j0, gram_product(va, (VT)__uint_as_float(b0)), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (l2 + 1u < len)
-                    __hip_atomic_fetch_add(&acc[rbase + (int)j1], gram_product(va, (VT)__uint_as_float(b1)), __ATOMIC_RELAXED,
+                    __hip_atomic_fetch_add(accd + (int)j1, gram_product(va, (VT)__uint_as_float(b1)), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
