@@ -132,17 +132,17 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket(const int64_t* __rest
     walk([&](uint32_t p, int j, VT v, uint32_t end) {
         __hip_atomic_fetch_add(&hist[gram_owner(j, sr_shift, n_wg, n_stripes)], (end - p + 63u) >> 6, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
-        if constexpr (sizeof(VT) == 4) {
+        if constexpr (sizeof(VT) == 4) {        // (a stored zero makes the smallest |v| zero: the range test fails, the f64 mode runs)
             const uint32_t b = __float_as_uint(v), ab = b & 0x7fffffffu;
             vmax_b = ab > vmax_b ? ab : vmax_b;
-            vmin_nb = (ab != 0u && ~ab > vmin_nb) ? ~ab : vmin_nb;
-            neg |= b >> 31;
+            vmin_nb = ~ab > vmin_nb ? ~ab : vmin_nb;
+            neg |= b;
         }
     });
     if constexpr (sizeof(VT) == 4) {
         if (vmax_b) atomicMax(&s_stat[0], vmax_b);
         if (vmin_nb) atomicMax(&s_stat[1], vmin_nb);
-        if (neg) atomicOr(&s_stat[2], 1u);
+        if (neg >> 31) atomicOr(&s_stat[2], 1u);
     }
     __syncthreads();
     if constexpr (sizeof(VT) == 4) {
