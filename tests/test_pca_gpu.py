@@ -329,13 +329,18 @@ def test_spmm_and_gram_kernels_vs_scipy(ctx, store, n, g, density, k):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("values", ["counts", "negative", "wide", "fractions"])
 @pytest.mark.parametrize("store", [1, 2])
-def test_gram_record_piece_and_pair_boundaries(ctx, store):
+def test_gram_record_piece_and_pair_boundaries(ctx, store, values):
     """The sparse Gram kernel works on RECORDS — one kept entry x at most 64 entries of its row's suffix, a longer suffix cut into
     several — and, for f32 entries, serves TWO records per load instruction (lanes 0-31 / 32-63, two consecutive entries per lane).
     Rows of 1, 2, 3, 31 .. 33, 63 .. 66, 127 .. 130 and 200 kept entries put suffixes on every side of those boundaries (odd and even
     lengths, pieces of exactly 64, a last piece of 1), the last rows end at the end of the entry array, empty rows sit between them;
-    integer values: X^T X must be exact."""
+    integer values: X^T X must be exact.
+    `values` picks the accumulation mode of the f32 kernel: small counts run in FIXED POINT (64-bit integer LDS atomics on products
+    scaled by a power of two: non-negative values whose exponents lie within 6 of the largest's); a negative value, or values 1 and
+    3000 side by side, send the launch to the f64 atomics (integers: still exact); "fractions" are non-integers in [0.75, 9] — the
+    fixed-point products must stay within the f32 product rounding of the exact sums."""
     import scipy.sparse as sp
     from singlerust_amd import _ffi
     rng = np.random.default_rng(99)
@@ -347,7 +352,14 @@ def test_gram_record_piece_and_pair_boundaries(ctx, store):
         c = np.sort(rng.choice(g, n, replace=False))
         rows += [r] * n
         cols += list(c)
-        vals += list(rng.integers(1, 7, n))
+        if values == "counts":
+            vals += list(rng.integers(1, 7, n))
+        elif values == "negative":
+            vals += list(rng.integers(1, 7, n) * rng.choice([-1, 1], n))
+        elif values == "wide":
+            vals += list(rng.choice([1, 3000], n))
+        else:
+            vals += list(np.float32(rng.uniform(0.75, 9.0, n)))
     x = sp.csr_matrix((np.array(vals, dtype=np.float64), (rows, cols)), shape=(len(lens), g))
     x.sort_indices()
     import singlerust_amd as sr
@@ -356,7 +368,12 @@ def test_gram_record_piece_and_pair_boundaries(ctx, store):
     P = rng.standard_normal((k, 64))
     y, t, gram = np.zeros((len(lens), 64)), np.zeros((k, 64)), np.zeros((k, k))
     _ffi.check(_ffi.lib().srx_spmm(a.x().handle, _ffi.ptr(sel), k, _ffi.ptr(P), _ffi.ptr(y), _ffi.ptr(t), _ffi.ptr(gram)), ctx.handle)
-    assert np.array_equal(gram, (x.T @ x).toarray())
+    want = (x.T @ x).toarray()
+    if values == "fractions":
+        # f32 products (2^-24 of each) at store 1, f64 products at store 2; the sums themselves are exact (integers / f64)
+        np.testing.assert_allclose(gram, want, rtol=2e-7 if store == 1 else 1e-14, atol=0)
+    else:
+        assert np.array_equal(gram, want)
 
 
 @pytest.mark.gpu
