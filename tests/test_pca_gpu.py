@@ -377,6 +377,33 @@ def test_gram_record_piece_and_pair_boundaries(ctx, store, values):
 
 
 @pytest.mark.gpu
+def test_fixed_point_gram_sums_do_not_depend_on_the_order_of_the_atomics(ctx):
+    """f32 entries, non-negative non-integer values of bounded range: the stripe kernel adds fixed-point products with INTEGER LDS
+    atomics, so a workgroup's sums do not depend on the order its atomics land in.  With one chunk of cells per owner (<= 16 384
+    cells: every entry of G receives exactly one global addition) repeated launches must agree to the last bit — with f64 atomics
+    they differ in the last bits from run to run."""
+    from singlerust_amd import _ffi
+    import singlerust_amd as sr
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    n, g, k = 12_000, 1500, 900
+    x = sp.random(n, g, density=0.08, random_state=11, format="csr", dtype=np.float64,
+                  data_rvs=lambda s: np.float32(rng.uniform(0.8, 9.0, s)).astype(np.float64))
+    x.sort_indices()
+    a = sr.IMAnnData.new_basic(x, ctx=ctx, store=1)
+    sel = np.sort(rng.choice(g, k, replace=False)).astype(np.uint64)
+    P = rng.standard_normal((k, 64))
+    grams = []
+    for _ in range(3):
+        y, t, gram = np.zeros((n, 64)), np.zeros((k, 64)), np.zeros((k, k))
+        _ffi.check(_ffi.lib().srx_spmm(a.x().handle, _ffi.ptr(sel), k, _ffi.ptr(P), _ffi.ptr(y), _ffi.ptr(t), _ffi.ptr(gram)), ctx.handle)
+        grams.append(gram)
+    assert np.array_equal(grams[0], grams[1]) and np.array_equal(grams[0], grams[2])
+    A = x[:, sel.astype(np.int64)]
+    np.testing.assert_allclose(grams[0], (A.T @ A).toarray(), rtol=3e-7, atol=1e-6)
+
+
+@pytest.mark.gpu
 def test_pipeline_device_selection_ties_and_results(ctx):
     """The pipeline selects HighlyVariable(n) on the device (k_gene_var / k_hvg_rank / k_sel_finish): the
     selection and its ORDER must equal the stable descending sort of the oracle (dim_red/mod.rs:135-140)
