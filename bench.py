@@ -62,6 +62,12 @@ ROOF_NOTE = {
                    "3.89 ms); a load now serves two owner records (16 bytes per lane): 6.2e7 loads, 3.17 ms with ds_add_f64 (VALU 95 %, "
                    "LDS pipe 88 % busy), 2.81 ms with the products rounded to fixed point and added as 64-bit integers (LDS 53 %, VALU "
                    "100 % busy: profiles/r04_pmc_gram.md)",
+    "gene_moments": "algorithmic bytes (SURVEY.md 8(d), fused normalise + log1p + moments): every non-zero's 16-bit index and f32 value read "
+                    "once, the transformed value stored back in place (nnz * 10) + row pointers, gene-tile cuts and row sums.  What "
+                    "bounds it: reading those 6.6 GB and writing 4.4 GB back takes 2.1-2.25 ms however the arrays are walked "
+                    "(bench_micro/segment_read.hip: flat stream 2.11 ms, the kernel's (row block, gene tile) batch walk 2.25) — "
+                    "the pass with its f64 logarithms, fixed-point conversions and 2.2e9 integer LDS atomic lanes is 0.5 ms above "
+                    "that, latency-bound at 4 waves per SIMD (VALU 61 % busy, profiles/r04_pmc_gram.md, r04_knockouts.md)",
     "spmm_fwd": "algorithmic bytes: the row-major compacted matrix (nnz_w * 8) + row pointers and row order (N * 12) + the "
                 "k x 64 f32 panel once per workgroup column slice + the output, which for this launch (the transform) is the "
                 "N x n_pc f64 score matrix written by the SpMM itself (rows of n_pc rounded up to 16 doubles in HBM).  What bounds "
@@ -967,6 +973,8 @@ def main():
         cand = {k_: v for k_, v in per.items() if k_ not in ("iterate", "dense_apply", "select")}
         dom_name = max(cand, key=cand.get) if cand else None
         dom = prof.get(dom_name, {})
+        rest = {k_: v for k_, v in cand.items() if k_ != dom_name}
+        dom2_name = max(rest, key=rest.get) if rest else None
         out = {
             "metric": "cells/sec end-to-end normalise->HVG->50-PC PCA; SpMM achieved HBM GB/s vs peak",
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -999,6 +1007,9 @@ def main():
             # the kernel class with the largest share of the step (live HIP-event timing on the stream it runs on)
             "roofline": roof(dom, KERNEL_SYMBOL.get(dom_name, dom_name), ROOF_NOTE.get(dom_name, ""),
                              other_bounds(dom_name, dom, main_["nnz_selected"], row1 - row0)),
+            # the class with the second largest share (the Gram kernel and the moments pass are within a few per cent of each other)
+            "roofline_next": roof(prof.get(dom2_name, {}), KERNEL_SYMBOL.get(dom2_name, dom2_name), ROOF_NOTE.get(dom2_name, ""),
+                                  other_bounds(dom2_name, prof.get(dom2_name, {}), main_["nnz_selected"], row1 - row0)) if dom2_name else None,
             # BASELINE.json's second metric: the CSR x 64-column-panel SpMM against the HBM peak
             "roofline_spmm": roof(prof.get("spmm_fwd", {}), KERNEL_SYMBOL["spmm_fwd"], ROOF_NOTE["spmm_fwd"],
                                   other_bounds("spmm_fwd", prof.get("spmm_fwd", {}), main_["nnz_selected"], row1 - row0)),
