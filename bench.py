@@ -130,7 +130,7 @@ def usable_cores():
 
 def load_traffic(config):
     """HBM bytes per pipeline step from the committed PMC passes (profiles/make_traffic.py), per bench kernel class."""
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{config}.json")
         try:
             with open(path) as fh:
@@ -773,7 +773,7 @@ def backed_run(B, config=None, cells_override=0, n_runs=None):
     out = {
         "metric": "cells/sec end-to-end normalise->HVG->50-PC PCA; SpMM achieved HBM GB/s vs peak",
         "value": cells / best["total_s"], "unit": "cells/s", "n_gpus": B.world, "steps": len(runs), "warmup": 0,
-        "ms_per_step": best["total_s"] * 1e3, "higher_is_better": True, "scaling": "strong" if B.world > 1 else "weak",
+        "ms_per_step": best["total_s"] * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{config} OUT OF CORE: {cells} cells x {genes} genes, density {density}, seed {seed}; the CSR "
                                f"(rank 0: {host_bytes / 1e9:.1f} GB: u64 offsets / indices + f32 values) stays in "
@@ -854,7 +854,7 @@ def main():
     cells, genes, density, seed = CONFIGS[a.config]
     if a.cells:
         cells = a.cells
-    scaling = a.scaling if a.scaling != "auto" else ("strong" if world > 1 else "weak")
+    scaling = a.scaling if a.scaling != "auto" else "strong"      # (N = 1: the label of the N > 1 runs of the same command)
     n_global = cells if scaling == "strong" or world == 1 else cells * world
     p = B.params(a.config, n_global, a.skew)
     row0, row1 = B.shard(p, n_global)
@@ -970,11 +970,33 @@ def main():
         step_alg = sum(prof[k_]["alg_bytes_per_launch"] * prof[k_]["launches"] / a.steps for k_ in serial_cls)
         step_aux = sum(prof[k_].get("aux_bytes_per_launch", 0.0) * prof[k_]["launches"] / a.steps for k_ in serial_cls)
         step_traffic = sum(traffic[k_] for k_ in serial_cls if traffic.get(k_)) if traffic else None
-        cand = {k_: v for k_, v in per.items() if k_ not in ("iterate", "dense_apply", "select")}
-        dom_name = max(cand, key=cand.get) if cand else None
+        # `roofline` names the dominant kernel of the largest STAGE of the step, `roofline_next` that of the second largest —
+        # stage sums, not single classes: the Gram kernel and the moments pass are within 1 % of each other as classes and the
+        # choice used to flip from run to run; as stages (Gram formation = compaction + owner records + stripe
+        # kernel against normalise + moments = row sums + moments pass) they are 1.5 ms apart.
+        STAGES = {"gram_formation": ("hvg_compact", "gram_bucket", "gram_sparse"), "normalise_moments": ("row_sums", "gene_moments"),
+                  "transform": ("spmm_fwd", "spmm_t")}
+        stage_ms = {sn: sum(per.get(c, 0.0) for c in cls) for sn, cls in STAGES.items()}
+        order = sorted(stage_ms, key=stage_ms.get, reverse=True)
+
+        def stage_block(sn):
+            cls = [c for c in STAGES[sn] if c in prof]
+            alg = sum(prof[c]["alg_bytes_per_launch"] * prof[c]["launches"] / a.steps for c in cls)
+            aux = sum(prof[c].get("aux_bytes_per_launch", 0.0) * prof[c]["launches"] / a.steps for c in cls)
+            trf = sum(traffic[c] for c in cls if traffic.get(c)) if traffic and all(traffic.get(c) for c in cls) else None
+            t = stage_ms[sn] * 1e-3
+            return {"name": sn, "classes": {c: per.get(c) for c in cls}, "ms_per_step": stage_ms[sn], "alg_bytes_per_step": alg,
+                    "aux_bytes_per_step": aux, "achieved_GBps": alg / t / 1e9 if t else None,
+                    "frac": alg / t / 1e9 / HBM_PEAK_GBS if t else None, "hbm_traffic_per_step": trf,
+                    "traffic_over_alg": trf / alg if trf and alg else None}
+
+        def dominant(sn):
+            cls = {c: per.get(c, 0.0) for c in STAGES[sn] if c in prof}
+            return max(cls, key=cls.get) if cls else None
+        dom_name = dominant(order[0]) if order else None
         dom = prof.get(dom_name, {})
-        rest = {k_: v for k_, v in cand.items() if k_ != dom_name}
-        dom2_name = max(rest, key=rest.get) if rest else None
+        dom2_name = dominant(order[1]) if len(order) > 1 else None
+        gram_stage = stage_block("gram_formation")
         out = {
             "metric": "cells/sec end-to-end normalise->HVG->50-PC PCA; SpMM achieved HBM GB/s vs peak",
             "value": value, "unit": "cells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -1003,13 +1025,26 @@ def main():
                 "incl_h2d_pageable_cells_per_s": (extra.get("incl_h2d_pageable") or {}).get("value"),
                 "cpu_baseline_cells_per_s": (extra.get("cpu_baseline") or {}).get("value"),
                 "cpu_baseline_threads": (extra.get("cpu_baseline") or {}).get("cores"),
+                "cold_cells_per_s": (extra.get("cold_step") or {}).get("value"),
+                "roofline_spmm_frac": (prof.get("spmm_fwd") or {}).get("frac_of_peak"),
+                "roofline_spmm_ms": (prof.get("spmm_fwd") or {}).get("avg_ms"),
+                "skewed_genes_ms_per_step": (extra.get("skewed_genes") or {}).get("ms_per_step"),
+                "hard_spectrum_ms_per_step": (extra.get("hard_spectrum") or {}).get("ms_per_step"),
+                "gram_formation_ms_per_step": gram_stage["ms_per_step"],
+                "gram_formation_traffic_over_alg": gram_stage["traffic_over_alg"],
+                "iterate_ms_per_step": per.get("iterate"),
+                "scaling_note": ("one GPU: `scaling` carries the label the same command gives at N > 1 (strong: BASELINE.json "
+                                 "configs[3], the same cells row-sharded), so that the per-N lines of a scaling run read alike"
+                                 if world == 1 else None),
             },
             # the kernel class with the largest share of the step (live HIP-event timing on the stream it runs on)
-            "roofline": roof(dom, KERNEL_SYMBOL.get(dom_name, dom_name), ROOF_NOTE.get(dom_name, ""),
-                             other_bounds(dom_name, dom, main_["nnz_selected"], row1 - row0)),
-            # the class with the second largest share (the Gram kernel and the moments pass are within a few per cent of each other)
-            "roofline_next": roof(prof.get(dom2_name, {}), KERNEL_SYMBOL.get(dom2_name, dom2_name), ROOF_NOTE.get(dom2_name, ""),
-                                  other_bounds(dom2_name, prof.get(dom2_name, {}), main_["nnz_selected"], row1 - row0)) if dom2_name else None,
+            "roofline": {**roof(dom, KERNEL_SYMBOL.get(dom_name, dom_name), ROOF_NOTE.get(dom_name, ""),
+                                other_bounds(dom_name, dom, main_["nnz_selected"], row1 - row0)),
+                         "stage": stage_block(order[0]) if order else None},
+            # the dominant kernel of the second largest stage
+            "roofline_next": ({**roof(prof.get(dom2_name, {}), KERNEL_SYMBOL.get(dom2_name, dom2_name), ROOF_NOTE.get(dom2_name, ""),
+                                      other_bounds(dom2_name, prof.get(dom2_name, {}), main_["nnz_selected"], row1 - row0)),
+                               "stage": stage_block(order[1])} if dom2_name else None),
             # BASELINE.json's second metric: the CSR x 64-column-panel SpMM against the HBM peak
             "roofline_spmm": roof(prof.get("spmm_fwd", {}), KERNEL_SYMBOL["spmm_fwd"], ROOF_NOTE["spmm_fwd"],
                                   other_bounds("spmm_fwd", prof.get("spmm_fwd", {}), main_["nnz_selected"], row1 - row0)),

@@ -31,8 +31,8 @@
 extern "C" {
 #endif
 
-#define SRX_ABI_VERSION 5      /* 2: srx_matrix_reserve_results, kernel classes 7-9, srx_synth_params.skew; 3: kernel class 10;
-                                  4: srx_comm_info, srx_prof_get_aux; 5: srx_comm_overlap_info */
+#define SRX_ABI_VERSION 6      /* 2: srx_matrix_reserve_results, kernel classes 7-9, srx_synth_params.skew; 3: kernel class 10;
+                                  4: srx_comm_info, srx_prof_get_aux; 5: srx_comm_overlap_info; 6: srx_gram_mode_info, srx_gram_exchange_ranges */
 
 typedef struct srx_ctx srx_ctx;   /* one GPU + stream + (optional) RCCL communicator      */
 typedef struct srx_mat srx_mat;   /* device-resident CSR (the `X` of an IMAnnData)        */
@@ -122,6 +122,16 @@ int32_t srx_comm_info(srx_ctx* ctx, int32_t* kind_out, int32_t* n_ranks_out, int
  * CU mask keeps it off the CUs left to the collective (0: the mask could not be set, or no split exchange yet).
  * Introspection for tests and the bench line; either pointer may be NULL. */
 int32_t srx_comm_overlap_info(srx_ctx* ctx, int32_t* split_exchanges_out, int32_t* cu_masked_out);
+/* Which accumulation mode the LAST sparse Gram launch of this context ran in (the kernel decides on the device, from value
+ * statistics of the compacted matrix — summed over the ranks first when the rows are sharded, so that every rank takes the
+ * same mode): *mode_out = 0 (no launch yet), 1 (f64 LDS atomics), 2 (fixed-point products, 64-bit integer LDS atomics:
+ * non-negative values whose binary exponents lie within 6 of the largest's).  Drains the stream.  Introspection for tests. */
+int32_t srx_gram_mode_info(srx_ctx* ctx, int32_t* mode_out);
+/* The Gram solver's one exchange when the rows are sharded over RCCL ranks: the packed upper triangle of X_sel^T X_sel
+ * (k (k + 1) / 2 doubles, row-major) is summed in THREE all-reduces — offsets_out[0] .. [1] and [2] .. [3] first (under the
+ * second half of the stripe kernel), [1] .. [2] after it; offsets_out[3] = k (k + 1) / 2.  The ranges depend on k alone (every
+ * rank, with or without rows, issues the same three calls).  Pure host helper, no GPU needed. */
+int32_t srx_gram_exchange_ranges(uint64_t k, uint64_t* offsets_out);
 /* Contiguous nnz-balanced row ranges: cut[r]..cut[r+1] is rank r's rows (cut has
  * n_ranks+1 entries).  Pure host helper, no GPU needed. */
 int32_t srx_partition_rows(const uint64_t* indptr, uint64_t n_rows, int32_t n_ranks,

@@ -5,7 +5,7 @@
 #![allow(non_camel_case_types, dead_code)]
 use std::os::raw::{c_char, c_void};
 
-pub const SRX_ABI_VERSION: i32 = 5;
+pub const SRX_ABI_VERSION: i32 = 6;
 pub const SRX_UNIQUE_ID_BYTES: usize = 128;
 pub const SRX_OK: i32 = 0;
 pub const SRX_E_ARG: i32 = -1;
@@ -146,6 +146,8 @@ extern "C" {
     pub fn srx_comm_info(ctx: *mut SrxCtx, kind_out: *mut i32, n_ranks_out: *mut i32, rccl_version_out: *mut i32,
                          ranks_seen_out: *mut i32) -> i32;
     pub fn srx_comm_overlap_info(ctx: *mut SrxCtx, split_exchanges_out: *mut i32, cu_masked_out: *mut i32) -> i32;
+    pub fn srx_gram_mode_info(ctx: *mut SrxCtx, mode_out: *mut i32) -> i32;
+    pub fn srx_gram_exchange_ranges(k: u64, offsets_out: *mut u64) -> i32;
     pub fn srx_partition_rows(indptr: *const u64, n_rows: u64, n_ranks: i32, cut_out: *mut u64) -> i32;
     pub fn srx_matrix_upload(ctx: *mut SrxCtx, host: *const SrxCsr, store: i32, out: *mut *mut SrxMat) -> i32;
     pub fn srx_matrix_upload_csc(ctx: *mut SrxCtx, host: *const SrxCsr, store: i32, out: *mut *mut SrxMat) -> i32;

@@ -92,6 +92,8 @@ _SIGS = {
     "srx_comm_destroy": (C.c_int32, [P]),
     "srx_comm_info": (C.c_int32, [P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "srx_comm_overlap_info": (C.c_int32, [P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "srx_gram_mode_info": (C.c_int32, [P, C.POINTER(C.c_int32)]),
+    "srx_gram_exchange_ranges": (C.c_int32, [C.c_uint64, P]),
     "srx_partition_rows": (C.c_int32, [P, C.c_uint64, C.c_int32, P]),
     "srx_matrix_upload": (C.c_int32, [P, C.POINTER(Csr), C.c_int32, C.POINTER(P)]),
     "srx_matrix_upload_csc": (C.c_int32, [P, C.POINTER(Csr), C.c_int32, C.POINTER(P)]),

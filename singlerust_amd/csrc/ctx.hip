@@ -512,6 +512,19 @@ int32_t upload_on(srx_ctx* ctx, const srx_csr* h, int32_t store, hipStream_t str
     const uint64_t base = h->indptr[0];
     if (h->indptr[h->n_rows] - base != h->nnz)
         return fail(ctx, SRX_E_FORMAT, "X is not a CSR matrix: row_offsets do not span nnz");
+    // Every row offset is checked HERE, on the host, before anything on the device walks a row by them: the 16-bit upload path
+    // (k_narrow16_tiles<WIDEN>) reads and writes indptr[r] .. indptr[r + 1] ahead of k_validate_rows, and a non-monotone or
+    // out-of-range interior offset would send it outside the index arrays.  8 bytes per row: ~1 ms at 1.3M rows.
+    {
+        uint64_t bad = 0, prev = base;
+        const uint64_t hi = base + h->nnz;
+        for (uint64_t r = 1; r <= h->n_rows; ++r) {
+            const uint64_t v = h->indptr[r];
+            bad |= (uint64_t)(v < prev) | (uint64_t)(v > hi);
+            prev = v;
+        }
+        if (bad) return fail(ctx, SRX_E_FORMAT, "X is not a CSR matrix: row_offsets are not monotone within [0, nnz]");
+    }
     srx_mat* m = nullptr;
     constexpr bool trace = false;                 // (development: reports uploads that take > 100 ms, by phase)
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -548,13 +561,18 @@ int32_t upload_on(srx_ctx* ctx, const srx_csr* h, int32_t store, hipStream_t str
         // values the caller holds in PINNED memory (hipHostMalloc / hipHostRegister: a backed reader's tile buffers) need no
         // staging copy: one DMA straight out of them, under the workers' index narrowing
         if (plain_values && h->nnz * val_bytes(m) >= (8u << 20)) {
-            hipPointerAttribute_t at;
-            if (hipPointerGetAttributes(&at, h->values) == hipSuccess && at.type == hipMemoryTypeHost) {
+            // (first AND last byte: a registration that covers only a prefix of the array is not good enough; and if the copy
+            //  cannot be queued all the same the values go through the staging workers like pageable ones — ADVICE r4)
+            hipPointerAttribute_t at, at_end;
+            const char* last = static_cast<const char*>(h->values) + h->nnz * val_bytes(m) - 1;
+            if (hipPointerGetAttributes(&at, h->values) == hipSuccess && at.type == hipMemoryTypeHost &&
+                hipPointerGetAttributes(&at_end, last) == hipSuccess && at_end.type == hipMemoryTypeHost) {
                 if (!ctx->direct_stream) e = hipStreamCreateWithFlags(&ctx->direct_stream, hipStreamNonBlocking);
                 if (e == hipSuccess)
                     e = hipMemcpyAsync(m->d_values, h->values, h->nnz * val_bytes(m), hipMemcpyHostToDevice, ctx->direct_stream);
-                if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "H2D values: %s", hipGetErrorString(e)));
-                direct_values = true;
+                direct_values = e == hipSuccess;
+                if (!direct_values) (void)hipGetLastError();
+                e = hipSuccess;
             } else {
                 (void)hipGetLastError();           // a plain pointer: not an error
             }
@@ -571,11 +589,16 @@ int32_t upload_on(srx_ctx* ctx, const srx_csr* h, int32_t store, hipStream_t str
         if (bad_col) return bail(fail(ctx, SRX_E_BOUNDS, "column index out of bounds (>= n_cols = %llu)",
                                       (unsigned long long)h->n_cols));
         tt[3] = trace ? now() : 0.0;
+        bool staged_values = plain_values && !direct_values;
         if (direct_values) {
             e = hipStreamSynchronize(ctx->direct_stream);
             direct_values = false;
-            if (e != hipSuccess) return bail(fail(ctx, SRX_E_HIP, "H2D values: %s", hipGetErrorString(e)));
-        } else if (plain_values) {
+            if (e != hipSuccess) {                 // the DMA out of the caller's pages failed: the staging workers instead
+                (void)hipGetLastError();
+                staged_values = true;
+            }
+        }
+        if (staged_values) {
             rc = parallel_h2d(ctx, h->values, m->d_values, h->nnz, false, val_bytes(m), 0, nullptr);
             if (rc) return bail(rc);
         }

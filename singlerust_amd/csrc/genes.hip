@@ -154,14 +154,9 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const double x = (double)c.v[j] * scale;
-#ifdef MOM_NOLOG
-                y4[j] = x * 0.125;
-                continue;
-#endif
                 if constexpr (sizeof(T) == 4) y4[j] = log1p_f64_moment_common(x, s_tab);
                 else y4[j] = log1p_f64_fast(x, s_tab);
             }
-#ifndef MOM_NOLOG
             if constexpr (sizeof(T) == 4) {
                 bool any_rare = false;
 #pragma unroll
@@ -174,11 +169,7 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
                     }
                 }
             }
-#endif
         }
-#ifdef MOM_NOWB
-        if (y4[0] == 123.456)
-#endif
         if constexpr (XF && WB) {
             // the chunk's values go back as one 16-byte store (two for f64) when all four belong to the segment
             T o[4];
@@ -218,10 +209,6 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
                     const unsigned long long iq = (unsigned long long)__double_as_longlong(__builtin_fma(x0 * x0, fx_sq, kMagic));
                     // (a poisoned value adds nothing while the reduction still takes its magic bits off: the gene's sums are
                     //  replaced by NaN anyway)
-#ifdef MOM_NOATOM
-                    if (is + iq == 12345ull) s_acc[2 * g0] = 1.0;
-                    continue;
-#endif
                     unsigned long long* a2 = reinterpret_cast<unsigned long long*>(s_acc) + 2 * g0;
                     __hip_atomic_fetch_add(a2, is, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(a2 + 1, iq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -739,7 +726,7 @@ int32_t ensure_tiles(srx_mat* m) {
     return SRX_OK;
 }
 
-static void block_geometry(const srx_mat* m, uint64_t& n_blocks, uint64_t& rows_per_block) {
+static int32_t block_geometry(const srx_mat* m, uint64_t& n_blocks, uint64_t& rows_per_block) {
     // four workgroups per CU, one resident at a time (the accumulators fill the LDS): c3, XF + write-back pass, 1 / 2 / 4 / 8 / 16
     // per CU: 3.23 / 3.12 / 3.06 / 3.10 / 3.19 ms (shorter workgroups even out the CUs; more of them means more partial sums)
     uint64_t want = (uint64_t)(4 * m->ctx->n_cus) / (uint64_t)m->n_tiles;
@@ -755,7 +742,13 @@ static void block_geometry(const srx_mat* m, uint64_t& n_blocks, uint64_t& rows_
     if (rows_per_block > cap) {
         rows_per_block = cap;
         n_blocks = (m->n_rows + rows_per_block - 1) / rows_per_block;
+        // every block leaves a partial (sum, sumsq) pair per gene: a matrix so wide that the 32-bit cap asks for thousands of
+        // blocks would make those buffers larger than the matrix — refused, not attempted
+        if ((double)n_blocks * (double)std::max<uint64_t>(m->n_cols, 1) * 16.0 > 8.0 * 1024 * 1024 * 1024)
+            return fail(m->ctx, SRX_E_ARG, "gene statistics: %llu columns x %llu row blocks exceed the partial-sum budget (matrix too wide)",
+                        (unsigned long long)m->n_cols, (unsigned long long)n_blocks);
     }
+    return SRX_OK;
 }
 
 // This shard's (cnt, sum, sumsq) per gene and its row count, packed as 3G+1 doubles in a scratch buffer.
@@ -765,7 +758,7 @@ static int32_t local_moments(srx_mat* m, double** packed_out, RowXf xf = RowXf{}
     SRX_TRY(ensure_tiles(m));
     const uint64_t G = m->n_cols;
     uint64_t nb, rpb;
-    block_geometry(m, nb, rpb);
+    SRX_TRY(block_geometry(m, nb, rpb));
     double *p_sum, *p_sq, *packed;
     SRX_TRY(scratch(ctx, "mom_part_sum", nb * (G ? G : 1) * sizeof(double), (void**)&p_sum));
     SRX_TRY(scratch(ctx, "mom_part_sq", nb * (G ? G : 1) * sizeof(double), (void**)&p_sq));
@@ -835,7 +828,7 @@ int32_t ensure_pattern_counts(srx_mat* m) {
     SRX_HIP(ctx, hipMemsetAsync(m->d_cnt_pat, 0, (G ? G : 1) * sizeof(uint32_t), ctx->stream));
     if (m->n_rows && m->nnz) {
         uint64_t nb, rpb;
-        block_geometry(m, nb, rpb);
+        SRX_TRY(block_geometry(m, nb, rpb));
         uint32_t* part;
         SRX_TRY(scratch(ctx, "mom_part_cnt", nb * G * sizeof(uint32_t), (void**)&part));
         const dim3 grid((unsigned)(nb * m->n_tiles));
@@ -1421,7 +1414,7 @@ int32_t srx_compute_min_max(srx_mat* m, int32_t direction, double* mn, double* m
     hipLaunchKernelGGL(k_fill_u64, dim3(g1), dim3(256), 0, ctx->stream, d, G, (unsigned long long)f64_key(INFINITY));
     hipLaunchKernelGGL(k_fill_u64, dim3(g1), dim3(256), 0, ctx->stream, d + G, G, (unsigned long long)f64_key(-INFINITY));
     uint64_t nb, rpb;
-    block_geometry(m, nb, rpb);
+    SRX_TRY(block_geometry(m, nb, rpb));
     const size_t lds = (size_t)m->tile_genes * 16;
     dim3 grid((unsigned)(nb * m->n_tiles));
     if (is_f32(m)) {

@@ -79,6 +79,31 @@ __global__ __launch_bounds__(1024) void k_rec_scan(const int64_t* __restrict__ b
 // [0] bits of max |v|, [1] ~bits of the smallest non-zero |v| (a max again: 0 = none), [2] != 0: a negative value was seen.
 __device__ __forceinline__ uint32_t* gram_stat(int64_t* rec_base, uint64_t n_rblk) { return reinterpret_cast<uint32_t*>(rec_base + n_rblk + 2); }
 
+// Sharded rows: the mode has to be the SAME on every rank (it decides how the products are rounded), so the statistics are
+// combined over the ranks first.  The path's collective is a SUM of doubles: each rank marks the biased exponent of its
+// largest |v| and of its smallest non-zero |v| in a 256-bin histogram each (+ one count of "a negative value was seen") ...
+constexpr int kGstatBins = 2 * 256 + 1;
+__global__ void k_gstat_onehot(const uint32_t* __restrict__ gstat, double* __restrict__ bins) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t vmax_b = gstat[0], nmin = gstat[1];
+    if (vmax_b) bins[vmax_b >> 23] += 1.0;                    // (NaN / inf land in bin 255: the range test fails everywhere)
+    if (nmin) bins[256 + ((~nmin) >> 23)] += 1.0;
+    if (gstat[2]) bins[512] += 1.0;
+}
+// ... and after the sum every rank rebuilds the three words from the highest / lowest marked bin: the kernel's test only
+// looks at the exponents, so a mantissa of zero stands for the values.  A rank without entries marks nothing.
+__global__ void k_gstat_decode(const double* __restrict__ bins, uint32_t* __restrict__ gstat) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int emax = -1, emin = -1;
+    for (int b = 0; b < 256; ++b) {
+        if (bins[b] != 0.0) emax = b;
+        if (bins[256 + b] != 0.0 && emin < 0) emin = b;
+    }
+    gstat[0] = emax < 0 ? 0u : ((uint32_t)emax << 23) | (emax == 255 ? 1u : 0u);
+    gstat[1] = emin < 0 ? 0u : ~((uint32_t)emin << 23);
+    gstat[2] = bins[512] != 0.0 ? 1u : 0u;
+}
+
 template <typename VT>
 __global__ __launch_bounds__(kBucketThreads) void k_bucket(const int64_t* __restrict__ rm_ptr, const GramPk<VT>* __restrict__ rm,
                                                            uint64_t n_rows, uint32_t rblk, int k, int sr_shift, int n_wg, int n_stripes,
@@ -214,7 +239,7 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     const int64_t* __restrict__ rec_base, const GramRec<VT>* __restrict__ recs, uint64_t n_rblk, uint32_t rblk, int k,
     int sr_shift, int n_wg, int n_stripes, uint32_t n_chunk, int w0 /* first owner of this launch */, int n_w /* owners in it */,
     double* __restrict__ Gp /* packed upper triangle, ACCUMULATED into (global f64 atomics) */,
-    const uint32_t* __restrict__ gstat /* gram_stat(), nullable */) {
+    uint32_t* __restrict__ gstat /* gram_stat(), nullable; word 3 receives the mode this launch ran in (srx_gram_mode_info) */) {
     using Entry = GramPk<VT>;
     using Rec = GramRec<VT>;
     // suffix loads in flight per batch: 16-byte f64 entries take twice the registers (8 of them spilled)
@@ -253,6 +278,7 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
             }
         }
     }
+    if (gstat && blockIdx.x == 0 && threadIdx.x == 0) gstat[3] = fx ? 2u : 1u;
     // Workgroup = (owner w, chunk z of n_chunk consecutive row blocks); blockIdx = z * n_wg + w, so the dispatcher starts
     // all owners of a chunk together and they walk its rows in the same order: what one workgroup pulls into its
     // XCD's L2 the ~60 others on that XCD hit (free-running persistent workgroups drift tens of MB apart: L2 hit rate
@@ -372,7 +398,7 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
             l.va[u] = hi ? vaB : vaA;
             const uint32_t len = l.lenrb[u] & 0xffu;
             const uint32_t off = l2 < len ? l2 : 0u;
-            l.raw[u] = *reinterpret_cast<const u4*>(reinterpret_cast<const char*>(sl.rmb) + (size_t)((pos + off) * 8u));
+            l.raw[u] = *reinterpret_cast<const u4*>(reinterpret_cast<const char*>(sl.rmb) + (size_t)(pos + off) * 8u);      // (64-bit byte offset: a block of 512 cells x k entries may pass 2^29)
         }
         return l;
     };

@@ -25,12 +25,10 @@ __global__ void k_gram_expand(const double* __restrict__ P, int k, const double*
 // fragment W[kk + (l >> 4)][16 t + (l & 15)] is coalesced as it stands.  The K slices (split-K 16 across
 // workgroups x 4 waves inside one: ~4000 waves for k = 2000) are combined in LDS, then with f64 atomics into the zeroed Wp.
 // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg (not the f32 map).
-#ifndef SRX_DENSE_SPLIT          // measured at k = 2000 (split x waves: us): 16x4 21.8, 8x8 21.9, 8x4 18.8, 4x4 17.8, 4x8 17.5, 8x2 28.3, 4x16 36.3 —
-#define SRX_DENSE_SPLIT 4       // the f64 atomics into Wp (k x 64 x split) weigh more than the number of waves in flight
-#define SRX_DENSE_WAVES 8
-#endif
-constexpr int kDenseSplit = SRX_DENSE_SPLIT;
-constexpr int kDenseWaves = SRX_DENSE_WAVES;             // waves of a workgroup: consecutive quarters of the workgroup's K slice
+// measured at k = 2000 (split x waves: us): 16x4 21.8, 8x8 21.9, 8x4 18.8, 4x4 17.8, 4x8 17.5, 8x2 28.3, 4x16 36.3 — the f64
+// atomics into Wp (k x 64 x split) weigh more than the number of waves in flight
+constexpr int kDenseSplit = 4;
+constexpr int kDenseWaves = 8;                           // waves of a workgroup: consecutive quarters of the workgroup's K slice
 typedef double dvec4 __attribute__((ext_vector_type(4)));
 // Workgroup = 32 output rows x 64 columns x one K slice, its four waves on consecutive quarters of the slice (four waves per
 // SIMD keep ~4x the loads in flight: one wave per SIMD left the load latency of every group of 16 K indices exposed, 27 us

@@ -11,7 +11,8 @@ namespace srx {
 
 #include "gram.inl"
 
-int32_t gram_plan(srx_ctx* ctx, int k, uint64_t n_rows, GramPlan& g) {
+// The part of the plan that depends on k alone: stripe height, stripes, owners.
+static void gram_stripes_of(int k, GramPlan& g) {
     g.k = k;
     // the largest stripe height whose two stripes fit 64 KiB (two workgroups per CU); one row per stripe up to 160 KiB
     // (c3, k = 2000: SR = 4 — two workgroups per CU — 3.9 ms; SR = 8, one workgroup per CU: 4.29-4.47; SR = 2: 4.17)
@@ -21,6 +22,19 @@ int32_t gram_plan(srx_ctx* ctx, int k, uint64_t n_rows, GramPlan& g) {
     g.n_stripes = (k + sr - 1) / sr;
     g.n_stripes += g.n_stripes & 1;
     g.n_wg = g.n_stripes / 2;
+}
+// Sharded rows: the packed triangle crosses the ranks in three pieces (launch_gram).  Rows [0, r_lo) and [r_hi, k) belong to
+// the first half of the owners, the rows between to the second half.
+static void gram_exchange_rows(const GramPlan& g, int& r_lo, int& r_hi) {
+    const int SR = 1 << g.sr_shift, h = g.n_wg / 2;
+    r_lo = std::min(g.k, h * SR);
+    r_hi = std::min(g.k, std::max(r_lo, (g.n_stripes - h) * SR));
+}
+static size_t packed_row_offset(int row, int k) { return (size_t)row * (size_t)k - (size_t)row * (size_t)(row - 1) / 2; }      // of (row, row)
+
+int32_t gram_plan(srx_ctx* ctx, int k, uint64_t n_rows, GramPlan& g) {
+    gram_stripes_of(k, g);
+    const int sr = 1 << g.sr_shift;
     size_t widest = 0;
     for (int w = 0; w < g.n_wg; ++w) {
         const int a0 = w * sr, b0 = (g.n_stripes - 1 - w) * sr;
@@ -407,6 +421,21 @@ int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce) 
                            reinterpret_cast<uint32_t*>(rec_base + g.n_rblk + 2));
         SRX_HIP(ctx, hipGetLastError());
     }
+    // Sharded rows, f32 entries: the fixed-point / f64 decision from the statistics of ALL ranks' compacted values (one more
+    // all-reduce of 513 doubles; an empty rank takes part with nothing marked).  Only where every rank is known to make the
+    // same number of calls — the resident solve (`reduce` given); a backed session's tiles decide per tile (their number may
+    // differ between the ranks; the sums of two modes differ by the fixed-point quantum).
+    if (sizeof(VT) == 4 && reduce && ctx->n_ranks > 1) {
+        double* bins = nullptr;
+        SRX_TRY(scratch(ctx, "pca_gstat_bins", kGstatBins * sizeof(double), (void**)&bins));
+        SRX_HIP(ctx, hipMemsetAsync(bins, 0, kGstatBins * sizeof(double), ctx->stream));
+        uint32_t* gs = empty ? nullptr : reinterpret_cast<uint32_t*>(rec_base + g.n_rblk + 2);
+        if (gs) hipLaunchKernelGGL(k_gstat_onehot, dim3(1), dim3(64), 0, ctx->stream, (const uint32_t*)gs, bins);
+        SRX_TRY(allreduce_f64(ctx, bins, kGstatBins));
+        if (gs) hipLaunchKernelGGL(k_gstat_decode, dim3(1), dim3(64), 0, ctx->stream, (const double*)bins, gs);
+        SRX_HIP(ctx, hipGetLastError());
+    }
+    if (!empty) ctx->gram_mode_word = reinterpret_cast<const uint32_t*>(rec_base + g.n_rblk + 2) + 3;
     // SRX_K_GRAM: the stripe kernel alone.  Algorithmic bytes = what ANY Gram kernel must move: the compacted matrix and its
     // row pointers read once, the packed triangle written once.  The owner records and block offsets are this kernel's own
     // auxiliary input (aux bytes).  Every row suffix is read once per kept entry of its row (from L2 / Infinity Cache): that
@@ -418,7 +447,7 @@ int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce) 
         if (empty) return;
         hipLaunchKernelGGL((k_gram_stripes<VT>), dim3((unsigned)(n_w * g.n_z)), dim3(kGramWaves * kWave), g.lds_bytes, st,
                            rm.ptr, (const GramPk<VT>*)rm.pk, boff, rec_base, recs, g.n_rblk, g.rblk, rm.k, g.sr_shift, g.n_wg,
-                           g.n_stripes, g.n_chunk, w0, n_w, Gp, (const uint32_t*)(rec_base ? reinterpret_cast<uint32_t*>(rec_base + g.n_rblk + 2) : nullptr));
+                           g.n_stripes, g.n_chunk, w0, n_w, Gp, rec_base ? reinterpret_cast<uint32_t*>(rec_base + g.n_rblk + 2) : (uint32_t*)nullptr);
     };
     // Sharded rows: owner w holds the stripes w and n_stripes - 1 - w, so the owners [0, h) hold the rows [0, h SR) and
     // [k - h SR, k) of the triangle — two contiguous ranges of the packed array — and the others the rows between.  Two
@@ -428,9 +457,10 @@ int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce) 
     // and halving them costs more than nothing.)
     if (split) {
         SRX_TRY(ensure_comm_streams(ctx));
-        const int SR = 1 << g.sr_shift, k = rm.k;
-        const int r_lo = std::min(k, h * SR), r_hi = std::min(k, std::max(r_lo, (g.n_stripes - h) * SR));      // rows [0, r_lo) + [r_hi, k): the first launch
-        auto off = [&](int row) { return (size_t)row * (size_t)k - (size_t)row * (size_t)(row - 1) / 2; };      // packed offset of (row, row)
+        const int k = rm.k;
+        int r_lo, r_hi;
+        gram_exchange_rows(g, r_lo, r_hi);                                       // rows [0, r_lo) + [r_hi, k): the first launch
+        auto off = [&](int row) { return packed_row_offset(row, k); };
         launch(0, h, ctx->stream);
         SRX_HIP(ctx, hipGetLastError());
         SRX_HIP(ctx, hipEventRecord(ctx->comm_fork, ctx->stream));
@@ -463,3 +493,17 @@ template int32_t launch_gram<float>(srx_ctx*, const RowMajor&, double*, bool*);
 template int32_t launch_gram<double>(srx_ctx*, const RowMajor&, double*, bool*);
 
 }  // namespace srx
+
+extern "C" int32_t srx_gram_exchange_ranges(uint64_t k, uint64_t* offsets_out) {
+    using namespace srx;
+    if (!offsets_out || k < 1 || k > 16384) return fail(nullptr, SRX_E_ARG, "srx_gram_exchange_ranges: bad arguments");
+    GramPlan g;
+    gram_stripes_of((int)k, g);
+    int r_lo, r_hi;
+    gram_exchange_rows(g, r_lo, r_hi);
+    offsets_out[0] = 0;
+    offsets_out[1] = packed_row_offset(r_lo, (int)k);
+    offsets_out[2] = packed_row_offset(r_hi, (int)k);
+    offsets_out[3] = packed_row_offset((int)k, (int)k);
+    return SRX_OK;
+}

@@ -316,10 +316,7 @@ __global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
     // panel reads per chunk were re-interleaved with the multiply-adds two reads deep by the scheduler — 16 LDS round
     // trips per chunk, 1.7 us per row; the copy of the next row's pointers at the top of the body waited for the loads
     // just issued; four 8-byte stores per lane behind exec branches.
-#ifndef SPMM_KSUB
-#define SPMM_KSUB 2
-#endif
-    constexpr int kSub = sizeof(VT) == 4 && CL == 4 ? SPMM_KSUB : 1;
+    constexpr int kSub = sizeof(VT) == 4 && CL == 4 ? 2 : 1;
     constexpr int kBatch = kSub * 4 * Q;                        // records of a batch
     const uint64_t stride = n_wg * kGroups, i_first = wg * kGroups + threadIdx.x / Q, last_row = n_rows ? n_rows - 1 : 0;
     if (i_first >= n_rows) return;
@@ -350,17 +347,10 @@ __global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
     int st = 0;
     PT a0 = PT(0), a1 = PT(0), a2 = PT(0), a3 = PT(0), ax = PT(0);
     bool done = false;
-#ifdef SPMM_TIMING
-    long long tW = 0, tM = 0, tO = 0, tRows = 0, tBatches = 0;
-#define SPMM_STAMP(x) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(0) : "memory"); const long long x = wall_clock64();
-#endif
     struct Out { uint64_t row; PT o[4]; PT x; };
     auto store_row = [&](const Out& q) {
         const PT o0 = q.o[0], o1 = q.o[1], o2 = q.o[2], o3 = q.o[3], ox = q.x;
         const uint64_t row_o = q.row;
-#ifdef SPMM_NOSTORE
-        if (o0 == PT(123456.0))
-#endif
         if (scores) {
             if constexpr (CL == 5) {
                 if (colx < n_cols) {
@@ -408,21 +398,10 @@ __global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
         // the loads stay HERE (`rm` is not `__restrict__`: a load nothing can alias may be moved across this barrier, and the
         // compiler then sinks it to its first use — behind the multiplication)
         asm volatile("" ::: "memory");
-#ifdef SPMM_TIMING
-        const long long t1 = wall_clock64();
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kSub * (int)sizeof(GramPk<VT>) / 8) : "memory");   // cur is here
-        const long long t2 = wall_clock64();
-        tW += t2 - t1;
-        ++tBatches;
-#endif
 #pragma unroll
         for (int c = 0; c < kSub; ++c) {
             const int s0 = st + c * 4 * Q;
             if (s0 >= n && c > 0) break;
-#ifdef SPMM_NOMUL
-            a0 += (PT)cur.r[c][0].v + (PT)cur.r[c][1].j + (PT)cur.r[c][2].v + (PT)cur.r[c][3].v;
-            continue;
-#endif
             // the lane's own four records: byte offset of the gene in the slice, value zeroed past the row's end (the
             // column is then a valid one of a later row, or of the zeroed tail) or outside the launch's gene range
             int off[4];
@@ -464,11 +443,6 @@ __global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
                 }
             }
         }
-#ifdef SPMM_TIMING
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const long long t3 = wall_clock64();
-        tM += t3 - t2;
-#endif
         if (!last) {
             st += kBatch;
             return;
@@ -498,28 +472,15 @@ __global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
         lo_nn = rm_ptr[row_nn];
         hi_nn = rm_ptr[row_nn + 1];
         row_n3 = row_at(i + 3 * stride);
-#ifdef SPMM_TIMING
-        tO += wall_clock64() - t3;
-        ++tRows;
-#endif
     };
     Batch A, B;
     load_batch(A, rr, 0, n);
-#ifdef SPMM_TIMING
-    const long long tk0 = wall_clock64();
-#endif
     for (;;) {
         step(A, B);
         if (done) break;
         step(B, A);
         if (done) break;
     }
-#ifdef SPMM_TIMING
-    if (threadIdx.x % 64 == 0 && (threadIdx.x / 64) % 5 == 0 && blockIdx.x % 67 == 0 && tRows)
-        printf("[spmm timing blk %d wave %d] rows %lld, %.2f batches per row, %.0f ns per row: waiting for the batch %.0f, multiply %.0f, output + next pointers (issue) %.0f\n",
-               (int)blockIdx.x, (int)(threadIdx.x / 64), tRows, (double)tBatches / tRows, (wall_clock64() - tk0) * 10.0 / tRows,
-               tW * 10.0 / tRows, tM * 10.0 / tRows, tO * 10.0 / tRows);
-#endif
 }
 
 // ---- transposed SpMM: T = A^T Y (k x l), s = 1^T Y ---------------------------------------------

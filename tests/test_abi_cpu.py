@@ -71,7 +71,7 @@ def test_rust_bindings_follow_the_header():
 
 
 def test_abi_version(lib):
-    assert lib.srx_abi_version() == 5
+    assert lib.srx_abi_version() == 6
 
 
 def test_struct_layouts_match_header():

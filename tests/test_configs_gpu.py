@@ -68,13 +68,12 @@ def test_config0_shape_every_stage_against_the_oracle(ctx, store, vtol):
     assert np.abs(wc @ (wc.T @ comps) - comps).max() < 1e-4
 
 
-@pytest.mark.parametrize("store,vtol", [(1, 1e-6), (2, 4e-16)])
-def test_config1_shape_against_the_oracle(ctx, store, vtol):
+def config1_shape_against_the_oracle(ctx, store, vtol, skew, label):
     import scipy.sparse as sp
     import singlerust_amd as sr
     from singlerust_amd.memory import statistics as st
     n, g = 100_000, 20_000
-    m, _ = synth_host(2002, n, g, 0.05)
+    m, _ = synth_host(2002, n, g, 0.05, skew=skew)
     assert 0.9e8 < len(m.values) < 1.1e8
     a, scores, comps, evr, mean, std, hv = pipeline(ctx, m, store, 2000, 50)
     lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))            # serial C loops over 1e8 non-zeros
@@ -98,9 +97,25 @@ def test_config1_shape_against_the_oracle(ctx, store, vtol):
     assert np.allclose(mean, mu, rtol=1e-5, atol=1e-7) and np.allclose(std, sd, rtol=1e-5)
     assert np.allclose(evr, wv / np.trace(cov), rtol=1e-5)
     # slack budget 0: all 50 components at the plain 1e-5 at either storage (measured at f32: loadings 1.0e-7, scores 2.8e-7)
-    assert_components_within_conditioning(comps, vv, wv, store, "c2-shape loading", max_slack=0)
+    assert_components_within_conditioning(comps, vv, wv, store, label + " loading", max_slack=0)
     want_scores = (xs @ (vv / sd[:, None])) - (mu / sd) @ vv
-    assert_components_within_conditioning(scores, np.asarray(want_scores), wv, store, "c2-shape score", max_slack=0)
+    assert_components_within_conditioning(scores, np.asarray(want_scores), wv, store, label + " score", max_slack=0)
+    return xs
+
+
+@pytest.mark.parametrize("store,vtol", [(1, 1e-6), (2, 4e-16)])
+def test_config1_shape_against_the_oracle(ctx, store, vtol):
+    config1_shape_against_the_oracle(ctx, store, vtol, 0, "c2-shape")
+
+
+@pytest.mark.parametrize("store,vtol", [(1, 1e-6), (2, 4e-16)])
+def test_config1_shape_skewed_gene_densities_against_the_oracle(ctx, store, vtol):
+    """The SKEWED generator (gene density ~ 1 / sqrt(index): the selected genes are the dense ones, about twice the kept
+    entries per cell, suffixes longer than one 64-entry record piece, Gram owners of very different weight) through the
+    same checks as the uniform matrix: HighlyVariable(2000) index for index, all 50 components at the plain 1e-5."""
+    xs = config1_shape_against_the_oracle(ctx, store, vtol, 1, "c2-shape skewed")
+    per_cell = xs.nnz / xs.shape[0]
+    assert per_cell > 1.5 * 0.05 * 2000          # the kept entries per cell really are well above the uniform matrix's 100
 
 
 def test_wide_matrix_without_the_16bit_index_mirror(ctx, tmp_path):

@@ -71,11 +71,12 @@ def adata_of(m, ctx, store=0):
     return sr.IMAnnData.new_basic((m.n_rows, m.n_cols, m.indptr, m.indices, m.values), ctx=ctx, store=store)
 
 
-def synth_host(seed, n, g, density):
+def synth_host(seed, n, g, density, skew=0):
     from singlerust_amd import _ffi
     lib = _ffi.lib()
     p = _ffi.SynthParams()
     lib.srx_synth_defaults(C.byref(p), seed, n, g, density)
+    p.skew = skew
     ip = np.zeros(n + 1, dtype=np.uint64)
     lib.srx_synth_indptr(C.byref(p), 0, n, _ffi.ptr(ip))
     idx = np.zeros(int(ip[-1]), np.uint64)
@@ -401,6 +402,79 @@ def test_fixed_point_gram_sums_do_not_depend_on_the_order_of_the_atomics(ctx):
     assert np.array_equal(grams[0], grams[1]) and np.array_equal(grams[0], grams[2])
     A = x[:, sel.astype(np.int64)]
     np.testing.assert_allclose(grams[0], (A.T @ A).toarray(), rtol=3e-7, atol=1e-6)
+
+
+def gram_of(ctx, x, store):
+    """X^T X of a scipy CSR through srx_spmm's Gram output + the mode the stripe kernel ran in (srx_gram_mode_info)."""
+    from singlerust_amd import _ffi
+    import singlerust_amd as sr
+    n, g = x.shape
+    a = sr.IMAnnData.new_basic(x, ctx=ctx, store=store)
+    sel = np.arange(g).astype(np.uint64)
+    P = np.zeros((g, 64))
+    y, t, gram = np.zeros((n, 64)), np.zeros((g, 64)), np.zeros((g, g))
+    _ffi.check(_ffi.lib().srx_spmm(a.x().handle, _ffi.ptr(sel), g, _ffi.ptr(P), _ffi.ptr(y), _ffi.ptr(t), _ffi.ptr(gram)), ctx.handle)
+    mode = C.c_int32(0)
+    _ffi.check(_ffi.lib().srx_gram_mode_info(ctx.handle, C.byref(mode)), ctx.handle)
+    return gram, mode.value
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,want_mode", [("spread6", 2), ("spread7", 1), ("spread6_fraction", 2), ("one_negative", 1),
+                                            ("stored_zero", 1), ("huge", 1), ("tiny", 1), ("all_equal", 2)])
+def test_gram_mode_switch_at_its_boundaries(ctx, case, want_mode):
+    """The f32 stripe kernel picks its accumulation mode on the device (gram.inl): FIXED POINT (mode 2) when no value is
+    negative and the binary exponents of the non-zero values lie within 6 of the largest's, f64 atomics (mode 1) otherwise.
+    Each case sits on one side of one of those tests — an exponent spread of exactly 6 and of exactly 7, a single negative
+    value among 40 000, a single STORED zero, a largest exponent outside the +-48 the scale factor is built for — with values
+    that are powers of two times small integers, so that X^T X is exact in EITHER mode: the mode must be the one stated and the
+    result must equal scipy's to the bit.  f64 storage runs the same cases through the f64 kernel (mode 1 always)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(17)
+    n, g = 3000, 160
+    x = sp.random(n, g, density=0.09, random_state=3, format="csr", dtype=np.float64)
+    nnz = x.nnz
+    lo, hi = {"spread6": (0, 6), "spread7": (-1, 6), "spread6_fraction": (-9, -3), "one_negative": (0, 3), "stored_zero": (0, 3),
+              "huge": (50, 52), "tiny": (-52, -50), "all_equal": (2, 2)}[case]
+    e = rng.integers(lo, hi + 1, nnz)
+    e[0], e[-1] = lo, hi                                  # both ends of the range are really there
+    x.data = np.ldexp(rng.integers(1, 2, nnz).astype(np.float64), e)          # exact powers of two: the exponent IS e
+    # ("spread6_fraction": 2^-9 .. 2^-3 — non-integers whose products are still exact powers of two)
+    if case == "one_negative":
+        x.data[nnz // 2] = -x.data[nnz // 2]
+    if case == "stored_zero":
+        x.data[nnz // 3] = 0.0                            # an explicit zero stays in the structure (canonical CSR allows it)
+    x.sort_indices()
+    want = (x.T @ x).toarray()
+    got, mode = gram_of(ctx, x, 1)
+    assert mode == want_mode, (case, mode)
+    assert np.array_equal(got, want), case
+    got64, mode64 = gram_of(ctx, x, 2)
+    assert mode64 == 1 and np.array_equal(got64, want)
+
+
+@pytest.mark.gpu
+def test_fixed_point_gram_rounding_stays_below_the_f32_product_rounding(ctx):
+    """Exponent spread exactly 6 with full 24-bit mantissas (the worst case the fixed-point mode accepts): every product is
+    rounded to a multiple of 2^-kq, half a unit = 2^-30 of the largest possible product.  Against the exact f64 sums of the
+    f32 values every entry must be within (half a quantum per product) + (the f32 rounding of the products, 2^-24 of each: the
+    scaled product is formed by one f32 FMA — what the f64-atomics mode's f32 products carry too)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(23)
+    n, g = 6000, 120
+    x = sp.random(n, g, density=0.1, random_state=5, format="csr", dtype=np.float64)
+    m = np.float32(rng.uniform(1.0, 2.0, x.nnz)).astype(np.float64)
+    e = rng.integers(0, 7, x.nnz)
+    e[0], e[-1] = 0, 6
+    x.data = np.ldexp(m, e)                                # [1, 128): exponents 0 .. 6
+    x.sort_indices()
+    want = (x.T @ x).toarray()
+    got, mode = gram_of(ctx, x, 1)
+    assert mode == 2
+    count = ((x != 0).astype(np.float64).T @ (x != 0).astype(np.float64)).toarray()
+    quantum = 2.0 ** -(29 - 2 * 6)                         # kq = 29 - 2 emax
+    assert (np.abs(got - want) <= 0.5 * quantum * count + 2.0 ** -24 * want + 1e-9).all()
+    assert np.abs(got - want).max() <= 2.0 ** -23 * np.abs(want).max()
 
 
 @pytest.mark.gpu

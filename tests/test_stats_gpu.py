@@ -218,6 +218,12 @@ def test_tile_cuts_against_the_oracle(ctx, n_genes):
                                atol=1e-9)
 
 
+def statistics_row_numbers(a):
+    import singlerust_amd as sr
+    from singlerust_amd.memory import statistics
+    return statistics.compute_number(a, sr.Direction.Row)
+
+
 def test_error_behaviour(ctx):
     """Unsupported dtype -> the macro's panic message; bad CSR -> SRX_E_FORMAT / SRX_E_BOUNDS;
     NaN variance in HVG ranking -> SRX_E_NAN (partial_cmp().unwrap(), dim_red/mod.rs:138)."""
@@ -233,6 +239,23 @@ def test_error_behaviour(ctx):
     with pytest.raises(sr.SrxError) as e:
         sr.IMAnnData.new_basic((1, 3, [0, 2], [2, 1], np.array([1.0, 2.0])), ctx=ctx)
     assert e.value.code == _ffi.E_FORMAT
+    # corrupted INTERIOR row offsets (first and last are fine: the span test passes) on both upload routes — at most 65 536
+    # columns, where the device walks the rows of the 16-bit indices before the canonical-CSR validation, and beyond:
+    # a clean SRX_E_FORMAT, and the context is still good afterwards
+    rng = np.random.default_rng(4)
+    for n_cols in (300, 70_000):
+        n_rows, per = 2000, 5
+        indptr = (np.arange(n_rows + 1) * per).astype(np.uint64)
+        idx = (rng.integers(0, n_cols - 100, (n_rows, 1)) + np.cumsum(rng.integers(1, 11, (n_rows, per)), axis=1)).ravel().astype(np.uint64)
+        vals = np.ones(n_rows * per, np.float32)
+        for bad_at, bad_val in ((700, 10 ** 12), (700, 5), (1999, n_rows * per + 1), (1, 2 ** 63)):
+            ip = indptr.copy()
+            ip[bad_at] = bad_val
+            with pytest.raises(sr.SrxError) as e:
+                sr.IMAnnData.new_basic((n_rows, n_cols, ip, idx, vals), ctx=ctx)
+            assert e.value.code == _ffi.E_FORMAT and "row_offsets" in str(e.value)
+        ok = sr.IMAnnData.new_basic((n_rows, n_cols, indptr, idx, vals), ctx=ctx)
+        assert statistics_row_numbers(ok).tolist() == [per] * n_rows
     a = sr.IMAnnData.new_basic((2, 2, [0, 1, 2], [0, 1], np.array([np.nan, 1.0])), ctx=ctx)
     with pytest.raises(sr.SrxError) as e:
         dim_red.select_features(a, sr.FeatureSelection.HighlyVariable(1))
