@@ -164,16 +164,6 @@ int32_t srx_comm_overlap_info(srx_ctx* ctx, int32_t* split_exchanges_out, int32_
     return SRX_OK;
 }
 
-int32_t srx_gram_mode_info(srx_ctx* ctx, int32_t* mode_out) {
-    if (!ctx || !mode_out) return fail(ctx, SRX_E_ARG, "srx_gram_mode_info: null argument");
-    *mode_out = 0;
-    if (!ctx->gram_mode_word) return SRX_OK;
-    uint32_t w = 0;
-    SRX_TRY(d2h(ctx, &w, ctx->gram_mode_word, sizeof w));
-    *mode_out = (int32_t)w;
-    return SRX_OK;
-}
-
 int32_t srx_comm_destroy(srx_ctx* ctx) {
     if (!ctx) return fail(nullptr, SRX_E_ARG, "null ctx");
     ctx->host_allreduce = nullptr;

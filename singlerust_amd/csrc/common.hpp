@@ -75,7 +75,8 @@ struct srx_ctx {
     // sharded rows: the second half of the Gram kernel runs here, off the CUs left to the collective (launch_gram)
     hipStream_t gram_stream = nullptr;
     bool gram_stream_masked = false;
-    const uint32_t* gram_mode_word = nullptr;   // device word the last stripe kernel left its mode in (srx_gram_mode_info)
+    const uint32_t* gram_mode_word = nullptr;   // the value statistics the last stripe kernel decided its mode from (srx_gram_mode_info)
+    bool gram_mode_f32 = false;
     uint32_t gram_splits = 0;                // Gram exchanges run in the split arrangement (srx_comm_overlap_info)
     hipEvent_t gram_fork = nullptr, gram_join = nullptr;
     std::string err;

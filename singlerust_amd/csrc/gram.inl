@@ -77,6 +77,14 @@ __global__ __launch_bounds__(1024) void k_rec_scan(const int64_t* __restrict__ b
 }
 // Value statistics of the compacted matrix, made by the bucket pass for the stripe kernel's fixed-point mode (f32 entries):
 // [0] bits of max |v|, [1] ~bits of the smallest non-zero |v| (a max again: 0 = none), [2] != 0: a negative value was seen.
+// The decision itself (host and device: srx_gram_mode_info applies it to the words the launch read): fixed point when no value is
+// negative and the binary exponents of all non-zero |v| lie within 6 of the largest's; kq: p < 2^(2 emax + 2), so p 2^kq < 2^31.
+__host__ __device__ inline bool gram_fixed_point_mode(uint32_t vmax_b, uint32_t nmin, uint32_t neg, int& kq) {
+    const uint32_t vmin_b = ~nmin;
+    const int emax = (int)(vmax_b >> 23) - 127, emin = (int)(vmin_b >> 23) - 127;
+    kq = 29 - 2 * emax;
+    return neg == 0u && vmax_b != 0u && vmax_b < 0x7f800000u && nmin != 0u && emax - emin <= 6 && emax > -48 && emax < 48;
+}
 __device__ __forceinline__ uint32_t* gram_stat(int64_t* rec_base, uint64_t n_rblk) { return reinterpret_cast<uint32_t*>(rec_base + n_rblk + 2); }
 
 // Sharded rows: the mode has to be the SAME on every rank (it decides how the products are rounded), so the statistics are
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     const int64_t* __restrict__ rec_base, const GramRec<VT>* __restrict__ recs, uint64_t n_rblk, uint32_t rblk, int k,
     int sr_shift, int n_wg, int n_stripes, uint32_t n_chunk, int w0 /* first owner of this launch */, int n_w /* owners in it */,
     double* __restrict__ Gp /* packed upper triangle, ACCUMULATED into (global f64 atomics) */,
-    uint32_t* __restrict__ gstat /* gram_stat(), nullable; word 3 receives the mode this launch ran in (srx_gram_mode_info) */) {
+    const uint32_t* __restrict__ gstat /* gram_stat(), nullable */) {
     using Entry = GramPk<VT>;
     using Rec = GramRec<VT>;
     // suffix loads in flight per batch: 16-byte f64 entries take twice the registers (8 of them spilled)
@@ -268,17 +276,14 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     double fx_inv = 1.0;
     if constexpr (sizeof(VT) == 4) {
         if (gstat) {
-            const uint32_t vmax_b = gstat[0], vmin_b = ~gstat[1], neg = gstat[2];
-            const int emax = (int)(vmax_b >> 23) - 127, emin = (int)(vmin_b >> 23) - 127;
-            if (neg == 0u && vmax_b != 0u && vmax_b < 0x7f800000u && gstat[1] != 0u && emax - emin <= 6 && emax > -48 && emax < 48) {
-                const int kq = 29 - 2 * emax;             // p < 2^(2 emax + 2): p 2^kq < 2^31
+            int kq;
+            if (gram_fixed_point_mode(gstat[0], gstat[1], gstat[2], kq)) {
                 fx = true;
                 fx_scale = __uint_as_float((uint32_t)(kq + 127) << 23);
                 fx_inv = __longlong_as_double((long long)(1023 - kq) << 52);
             }
         }
     }
-    if (gstat && blockIdx.x == 0 && threadIdx.x == 0) gstat[3] = fx ? 2u : 1u;
     // Workgroup = (owner w, chunk z of n_chunk consecutive row blocks); blockIdx = z * n_wg + w, so the dispatcher starts
     // all owners of a chunk together and they walk its rows in the same order: what one workgroup pulls into its
     // XCD's L2 the ~60 others on that XCD hit (free-running persistent workgroups drift tens of MB apart: L2 hit rate
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
             l.va[u] = hi ? vaB : vaA;
             const uint32_t len = l.lenrb[u] & 0xffu;
             const uint32_t off = l2 < len ? l2 : 0u;
-            l.raw[u] = *reinterpret_cast<const u4*>(reinterpret_cast<const char*>(sl.rmb) + (size_t)(pos + off) * 8u);      // (64-bit byte offset: a block of 512 cells x k entries may pass 2^29)
+            l.raw[u] = *reinterpret_cast<const u4*>(reinterpret_cast<const char*>(sl.rmb) + (size_t)((pos + off) * 8u));      // (32-bit: a block holds at most rblk x k = 512 x 16384 = 2^23 entries — gram_plan checks; the 64-bit multiply spilled 56 VGPRs)
         }
         return l;
     };

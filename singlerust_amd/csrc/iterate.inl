@@ -34,9 +34,13 @@ typedef double dvec4 __attribute__((ext_vector_type(4)));
 // SIMD keep ~4x the loads in flight: one wave per SIMD left the load latency of every group of 16 K indices exposed, 27 us
 // per application against ~7 us of MFMA time); the waves' partial tiles meet in LDS (ds_add_f64), then one f64 atomic per
 // output element and K slice into the zeroed Wp.
+// (Round 5: the waves' partial tiles used to meet in LDS through ds_add_f64 — 32 atomic instructions per wave at ~25 clocks each,
+//  2.7 us of an 18 us launch.  Now every wave STORES its tile in accumulator-register order ([wave][register][lane]: conflict-free,
+//  4 clocks a store), and thread t adds the eight partials of the four (register, lane) slots it is given and sends them out.)
+constexpr size_t kDenseLds = (size_t)kDenseWaves * 32 * 64 * sizeof(double);      // 128 KiB, dynamic: one workgroup per CU (252 of them)
 __global__ __launch_bounds__(kDenseWaves * 64) void k_dense_apply(const double* __restrict__ C, const double* __restrict__ W, int k,
                                                                   double* __restrict__ Wp) {
-    __shared__ double red[32][L];
+    extern __shared__ double red[];                // [wave][acc register 0 .. 31][lane]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int row0 = blockIdx.x * 32;
@@ -44,7 +48,6 @@ __global__ __launch_bounds__(kDenseWaves * 64) void k_dense_apply(const double* 
     const int kq = kchunk / kDenseWaves;
     const int kbeg = blockIdx.y * kchunk + wv * kq;
     const int kend = kbeg + kq < k ? kbeg + kq : k;
-    for (int e = threadIdx.x; e < 32 * L; e += kDenseWaves * 64) (&red[0][0])[e] = 0.0;
     dvec4 acc[2][4];
 #pragma unroll
     for (int sI = 0; sI < 2; ++sI)
@@ -84,18 +87,26 @@ __global__ __launch_bounds__(kDenseWaves * 64) void k_dense_apply(const double* 
         load(f0, kk + 32);
         fma(f1);
     }
-    __syncthreads();                             // (the tile is zeroed)
-    // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+    // register index q = (sI * 4 + t) * 4 + v; C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * v
 #pragma unroll
     for (int sI = 0; sI < 2; ++sI)
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) atomicAdd(&red[16 * sI + lk + 4 * v][16 * t + li], acc[sI][t][v]);
+            for (int v = 0; v < 4; ++v) red[((size_t)wv * 32 + (sI * 4 + t) * 4 + v) * 64 + lane] = acc[sI][t][v];
     __syncthreads();
-    for (int e = threadIdx.x; e < 32 * L; e += kDenseWaves * 64) {
-        const int r = row0 + e / L;
-        if (r < k) atomicAdd(&Wp[(size_t)r * L + (e % L)], (&red[0][0])[e]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = wv + kDenseWaves * i;          // 512 threads x 4 slots = the 32 registers x 64 lanes of a tile
+        double part[kDenseWaves];
+#pragma unroll
+        for (int w2 = 0; w2 < kDenseWaves; ++w2) part[w2] = red[((size_t)w2 * 32 + q) * 64 + lane];
+        double sum = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < kDenseWaves; ++w2) sum += part[w2];
+        const int sI = q >> 4, t = (q >> 2) & 3, v = q & 3;
+        const int r = row0 + 16 * sI + lk + 4 * v;
+        if (r < k) atomicAdd(&Wp[(size_t)r * L + 16 * t + li], sum);
     }
 }
 
@@ -276,10 +287,11 @@ __global__ __launch_bounds__(1024) void k_gram1_part(const double* __restrict__ 
 // block the partial sums of || A1[:, c] - theta_c A2[:, c] ||^2 and the entry of largest |.| of A2[:, c] (ties: the smallest
 // row).  k_resid_final adds the partials in fixed order.  (Round 2: two k_right_mul launches, the residuals on ONE workgroup, a scalar kernel.)
 constexpr int kRitzBlocks = 128;
-__global__ __launch_bounds__(256) void k_ritz_post(const double* __restrict__ W, const double* __restrict__ Wp,
+// `zero_wp`: the rows of Wp are left ZEROED once read (Wp is the destination of the next application of C).
+__global__ __launch_bounds__(256) void k_ritz_post(const double* __restrict__ W, double* __restrict__ Wp,
                                                    const double* __restrict__ M, const double* __restrict__ theta, int k,
                                                    double* __restrict__ A1, double* __restrict__ A2,
-                                                   double* __restrict__ part /* [blocks][3][64]: r2, best value, its row */) {
+                                                   double* __restrict__ part /* [blocks][3][64]: r2, best value, its row */, int zero_wp) {
     __shared__ double sm[L][L + 1];
     __shared__ double s_r[4][L], s_v[4][L], s_j[4][L];
     for (int e = threadIdx.x; e < L * L; e += 256) sm[e / L][e % L] = M[e];
@@ -289,13 +301,17 @@ __global__ __launch_bounds__(256) void k_ritz_post(const double* __restrict__ W,
     double acc = 0.0, best = 0.0, best_j = 0.0;
     for (int j = blockIdx.x * 4 + sub; j < k; j += gridDim.x * 4) {
         const double* rw = W + (size_t)j * L;
-        const double* rp = Wp + (size_t)j * L;
+        double* rp = Wp + (size_t)j * L;
         double a1 = 0.0, a2 = 0.0;
 #pragma unroll 8
         for (int b = 0; b < L; ++b) {
             const double m = sm[b][c];
             a1 += rp[b] * m;
             a2 += rw[b] * m;
+        }
+        if (zero_wp) {                           // (the 64 threads of a row are the lanes of ONE wave: all have read the row)
+            asm volatile("" ::: "memory");
+            rp[c] = 0.0;
         }
         A1[(size_t)j * L + c] = a1;
         A2[(size_t)j * L + c] = a2;
@@ -356,9 +372,15 @@ __global__ void k_identity_block(int k, double* __restrict__ W) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < k * L) W[e] = (e / L == e % L) ? 1.0 : 0.0;
 }
-__global__ void k_init_block(uint64_t seed, int k, int l_act, double* __restrict__ Wp) {
+// (z0 .. z2, nullable: blocks of the same shape left ZEROED — the destinations of the warm-up's applications of C, which
+//  accumulate into zeroed blocks: no memset launch in front of any of them)
+__global__ void k_init_block(uint64_t seed, int k, int l_act, double* __restrict__ Wp, double* __restrict__ z0, double* __restrict__ z1,
+                             double* __restrict__ z2) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= k * L) return;
+    if (z0) z0[e] = 0.0;
+    if (z1) z1[e] = 0.0;
+    if (z2) z2[e] = 0.0;
     const int j = e / L, cc = e % L;
     double v = 0.0;
     if (cc < l_act) {
@@ -519,8 +541,11 @@ __global__ __launch_bounds__(1024) void k_chol_factor_panels(const double* __res
 //  multiply-subtracts per step — with R[j][c] as wave-uniform scalar loads at compile-time offsets: 33.6 us against 32.3, 153
 //  exposed scalar-cache round trips on the one wave of a SIMD; with the rows of R prefetched from LDS into a second register
 //  buffer the compiler hoists every row's reads to the top and spills 14 KB.)
-__global__ __launch_bounds__(64) void k_trsm_rows(const double* __restrict__ Wp, const double* __restrict__ R,
-                                                  const double* __restrict__ dinv, int k, double* __restrict__ W) {
+// z0 .. z2 (nullable): blocks whose rows this thread leaves ZEROED once its source row is in registers — the source itself and
+// the other scratch blocks of the sweep, i.e. the destinations of the next applications of C (accumulated into zeroed blocks:
+// eight memset launches per solve gone); a thread owns its row in every block, so the source may be one of them (or W itself).
+__global__ __launch_bounds__(64) void k_trsm_rows(const double* Wp, const double* __restrict__ R,
+                                                  const double* __restrict__ dinv, int k, double* W, double* z0, double* z1, double* z2) {
     __shared__ double Rt[L][L];          // Rt[j][i] = R[i][j]
     __shared__ double di[L];
     for (int e = threadIdx.x; e < L * L; e += 64) Rt[e & 63][e >> 6] = R[e];
@@ -532,6 +557,18 @@ __global__ __launch_bounds__(64) void k_trsm_rows(const double* __restrict__ Wp,
     const double* src = Wp + (size_t)row * L;
 #pragma unroll
     for (int j = 0; j < L; ++j) w[j] = src[j];
+    asm volatile("" ::: "memory");                 // the row is read before anything of it is overwritten
+    {
+        typedef double d2z __attribute__((ext_vector_type(2)));
+        double* const zs[3] = {z0, z1, z2};
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            if (zs[b] && zs[b] != W) {
+                d2z* zr = reinterpret_cast<d2z*>(zs[b] + (size_t)row * L);
+#pragma unroll
+                for (int j = 0; j < L / 2; ++j) zr[j] = d2z{0.0, 0.0};
+            }
+    }
 #pragma unroll
     for (int j = 0; j < L; ++j) {
         double acc0 = w[j], acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;      // (eight chains instead of four: 32 -> 56 us, the row spills)
@@ -549,6 +586,88 @@ __global__ __launch_bounds__(64) void k_trsm_rows(const double* __restrict__ Wp,
     double* dst = W + (size_t)row * L;
 #pragma unroll
     for (int j = 0; j < L; ++j) dst[j] = w[j];
+}
+
+// The same substitution on the f64 matrix cores, for the plain CholeskyQR (round 5; k_trsm_rows — one thread per row, a
+// 2016-step dependent chain with an LDS read per step — took 33 us a launch, three launches per solve).  Blocked by 16 columns
+// and TRANSPOSED, X = W^T:   X_J = R_JJ^-T (Wp_J^T - sum_{I<J} R_IJ^T X_I),   J = 0 .. 3,
+// a wave owning 16 rows of W (= 16 columns of X).  Every product is D(16x16) += A(16x4) B(4x16) on v_mfma_f64_16x16x4 with
+// the contraction index taken in the order the accumulator registers hold it: a finished tile X_I sits in the C/D layout
+// (lane: column l & 15, rows (l >> 4) + 4 reg), which IS the B operand of step `reg` when the A operand supplies
+// R[16 I + (l >> 4) + 4 reg][16 J + (l & 15)] — so the tiles never leave the registers (no LDS relayout between the stages),
+// and the only LDS traffic are the reads of R and of the four inverted diagonal blocks.  Those inverses (16 x 16 upper
+// triangular, by back substitution, one thread per column) are made by the first wave of every workgroup: 120 FMAs each.
+// A forward substitution through explicitly inverted DIAGONAL BLOCKS is what blocked TRSM implementations do; it is backward
+// stable up to the condition of a 16 x 16 diagonal block.  Columns >= n (R's rows zero, dinv = 0) come out zero, as from
+// k_trsm_rows; the robust mode (dropped columns: dinv = 0 with a unit row in R) keeps k_trsm_rows.
+// z0 .. z2: as in k_trsm_rows (the rows of those blocks are left zeroed once the wave's own 16 source rows are in registers).
+constexpr int kTrsmTiles = 4;              // waves (16-row tiles) per workgroup
+__global__ __launch_bounds__(kTrsmTiles * 64) void k_trsm_mfma(const double* Wp, const double* __restrict__ R,
+                                                               const double* __restrict__ dinv, int k, double* W, double* z0,
+                                                               double* z1, double* z2) {
+    constexpr int LD = L + 2;
+    __shared__ double Rs[L][LD];                 // R, row-major (zero below the diagonal)
+    __shared__ double Xi[4][16][16 + 1];         // Xi[J][a][b] = (R_JJ^-1)[a][b]
+    __shared__ double ds[L];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < L * L; e += kTrsmTiles * 64) Rs[e >> 6][e & 63] = R[e];
+    if (tid < L) ds[tid] = dinv[tid];
+    __syncthreads();
+    if (tid < L) {
+        const int J = tid >> 4, c = tid & 15, o = 16 * J;
+        double x[16];
+#pragma unroll
+        for (int i = 15; i >= 0; --i) {
+            double acc = 0.0;
+#pragma unroll
+            for (int mm = i + 1; mm < 16; ++mm) acc = __builtin_fma(Rs[o + i][o + mm], x[mm], acc);      // (x[mm] = 0 for mm > c)
+            x[i] = i == c ? ds[o + i] : (i < c ? -acc * ds[o + i] : 0.0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Xi[J][i][c] = x[i];
+    }
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int row = (blockIdx.x * kTrsmTiles + wv) * 16 + m;
+    const bool ok = row < k;
+    const size_t base = (size_t)(ok ? row : 0) * L;
+    dvec4 T[4], X[4];
+#pragma unroll
+    for (int J = 0; J < 4; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[J][r] = ok ? Wp[base + 16 * J + g + 4 * r] : 0.0;
+    asm volatile("" ::: "memory");               // the wave's source rows are read before any block's rows are overwritten
+    if (ok) {
+        double* const zs[3] = {z0, z1, z2};
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            if (zs[b] && zs[b] != W) {
+#pragma unroll
+                for (int J = 0; J < 4; ++J)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) zs[b][base + 16 * J + g + 4 * r] = 0.0;
+            }
+    }
+#pragma unroll
+    for (int J = 0; J < 4; ++J) {
+        dvec4 t = T[J];
+#pragma unroll
+        for (int I = 0; I < J; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                t = __builtin_amdgcn_mfma_f64_16x16x4f64(-Rs[16 * I + g + 4 * r][16 * J + m], X[I][r], t, 0, 0, 0);
+        dvec4 d = dvec4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d = __builtin_amdgcn_mfma_f64_16x16x4f64(Xi[J][g + 4 * r][m], t[r], d, 0, 0, 0);
+        X[J] = d;
+    }
+    if (ok) {
+#pragma unroll
+        for (int J = 0; J < 4; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W[base + 16 * J + g + 4 * r] = X[J][r];
+    }
 }
 
 // ---- Chebyshev filter between two Rayleigh–Ritz steps ----------------------------------------------

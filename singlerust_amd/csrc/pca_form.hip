@@ -391,7 +391,10 @@ int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce) 
     const int h = g.n_wg / 2;
     const bool split = reduce && comm_is_rccl(ctx) && (ctx->n_ranks > 1 || force_split) && h >= 1 && g.n_wg - h >= 1;
     const bool empty = rm.n_rows == 0;
-    if (empty && !split) return SRX_OK;
+    // (f32 entries, sharded rows: the accumulation mode is decided from the statistics of ALL ranks — one small all-reduce that a
+    //  rank without rows makes too, below)
+    const bool stat_exchange = sizeof(VT) == 4 && reduce && ctx->n_ranks > 1;
+    if (empty && !split && !stat_exchange) return SRX_OK;
     uint32_t* boff = nullptr;
     int64_t *blk_total = nullptr, *rec_base = nullptr;
     GramRec<VT>* recs = nullptr;
@@ -425,7 +428,7 @@ int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce) 
     // all-reduce of 513 doubles; an empty rank takes part with nothing marked).  Only where every rank is known to make the
     // same number of calls — the resident solve (`reduce` given); a backed session's tiles decide per tile (their number may
     // differ between the ranks; the sums of two modes differ by the fixed-point quantum).
-    if (sizeof(VT) == 4 && reduce && ctx->n_ranks > 1) {
+    if (stat_exchange) {
         double* bins = nullptr;
         SRX_TRY(scratch(ctx, "pca_gstat_bins", kGstatBins * sizeof(double), (void**)&bins));
         SRX_HIP(ctx, hipMemsetAsync(bins, 0, kGstatBins * sizeof(double), ctx->stream));
@@ -435,7 +438,11 @@ int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce) 
         if (gs) hipLaunchKernelGGL(k_gstat_decode, dim3(1), dim3(64), 0, ctx->stream, (const double*)bins, gs);
         SRX_HIP(ctx, hipGetLastError());
     }
-    if (!empty) ctx->gram_mode_word = reinterpret_cast<const uint32_t*>(rec_base + g.n_rblk + 2) + 3;
+    if (empty && !split) return SRX_OK;
+    if (!empty) {                              // (srx_gram_mode_info: the words the stripe kernel decides from)
+        ctx->gram_mode_word = reinterpret_cast<const uint32_t*>(rec_base + g.n_rblk + 2);
+        ctx->gram_mode_f32 = sizeof(VT) == 4;
+    }
     // SRX_K_GRAM: the stripe kernel alone.  Algorithmic bytes = what ANY Gram kernel must move: the compacted matrix and its
     // row pointers read once, the packed triangle written once.  The owner records and block offsets are this kernel's own
     // auxiliary input (aux bytes).  Every row suffix is read once per kept entry of its row (from L2 / Infinity Cache): that
@@ -447,7 +454,7 @@ int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce) 
         if (empty) return;
         hipLaunchKernelGGL((k_gram_stripes<VT>), dim3((unsigned)(n_w * g.n_z)), dim3(kGramWaves * kWave), g.lds_bytes, st,
                            rm.ptr, (const GramPk<VT>*)rm.pk, boff, rec_base, recs, g.n_rblk, g.rblk, rm.k, g.sr_shift, g.n_wg,
-                           g.n_stripes, g.n_chunk, w0, n_w, Gp, rec_base ? reinterpret_cast<uint32_t*>(rec_base + g.n_rblk + 2) : (uint32_t*)nullptr);
+                           g.n_stripes, g.n_chunk, w0, n_w, Gp, (const uint32_t*)(rec_base ? reinterpret_cast<uint32_t*>(rec_base + g.n_rblk + 2) : nullptr));
     };
     // Sharded rows: owner w holds the stripes w and n_stripes - 1 - w, so the owners [0, h) hold the rows [0, h SR) and
     // [k - h SR, k) of the triangle — two contiguous ranges of the packed array — and the others the rows between.  Two
@@ -493,6 +500,18 @@ template int32_t launch_gram<float>(srx_ctx*, const RowMajor&, double*, bool*);
 template int32_t launch_gram<double>(srx_ctx*, const RowMajor&, double*, bool*);
 
 }  // namespace srx
+
+extern "C" int32_t srx_gram_mode_info(srx_ctx* ctx, int32_t* mode_out) {
+    using namespace srx;
+    if (!ctx || !mode_out) return fail(ctx, SRX_E_ARG, "srx_gram_mode_info: null argument");
+    *mode_out = 0;
+    if (!ctx->gram_mode_word) return SRX_OK;
+    uint32_t w[3] = {0, 0, 0};
+    SRX_TRY(d2h(ctx, w, ctx->gram_mode_word, sizeof w));
+    int kq;
+    *mode_out = ctx->gram_mode_f32 && gram_fixed_point_mode(w[0], w[1], w[2], kq) ? 2 : 1;
+    return SRX_OK;
+}
 
 extern "C" int32_t srx_gram_exchange_ranges(uint64_t k, uint64_t* offsets_out) {
     using namespace srx;

@@ -240,7 +240,12 @@ static int32_t graphed(srx_ctx* ctx, bool enable, const std::string& key, Fn&& e
 template <typename Apply>
 static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, const Resolved& o, Apply&& apply,
                                 const void* apply_id, bool graphable, const int* d_status_sel, double& resid, int& iters,
-                                bool& converged) {
+                                bool& converged, bool acc_apply) {
+    // `acc_apply` (the Gram solver): `apply` ACCUMULATES into a zeroed destination and w.T is free.  The applications of a sweep
+    // then rotate through three scratch blocks (Wp, A1, T), and the kernels that are the last to read a block leave it zeroed
+    // (the CholeskyQR's substitution: all three; the Ritz tail: Wp; the filter step: its Z) — the eight memset launches a solve
+    // used to queue in front of its applications are gone (~40 us of a 1 ms iteration).  Invariants: after `orth` Wp, A1 and T
+    // are zero; after a Ritz step Wp and T are zero, A1 = (C W) U, A2 = W U.
     const size_t kl = (size_t)k * L;
     const bool use_graph = graphable && !getenv("SRX_NO_GRAPH");
     const bool use_cheb = l_act > o.n_pc && !o.robust && !o.direct;      // both solvers: the filter only needs `apply`
@@ -257,11 +262,11 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     SRX_TRY(scratch(ctx, "pca_ritzpart", (size_t)kRitzBlocks * 3 * L * sizeof(double), (void**)&d_ritz));
     SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_jacobi_eig2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(J2Lds)));
     // what a captured segment depends on besides its own schedule: shapes, options, every buffer it touches
-    char key0[256];
-    snprintf(key0, sizeof key0, "k%d l%d p%d w%d r%d n%d s%llu|%p %p %p %p %p %p %p %p %p", k, l_act, o.power, o.warm,
-             (o.robust ? 1 : 0) + (o.direct ? 2 : 0), o.n_pc,
-             (unsigned long long)o.seed, apply_id, (void*)w.W, (void*)w.Wp, (void*)w.A1, (void*)w.A2, (void*)w.small,
-             (void*)w.gpart, (void*)d_status, (void*)d_status_sel);       // (d_ritz, d_res: allocated with d_status, never regrown)
+    char key0[320];
+    snprintf(key0, sizeof key0, "k%d l%d p%d w%d r%d n%d s%llu t%a|%p %p %p %p %p %p %p %p %p %p", k, l_act, o.power, o.warm,
+             (o.robust ? 1 : 0) + (o.direct ? 2 : 0) + (acc_apply ? 4 : 0), o.n_pc,
+             (unsigned long long)o.seed, o.tol, apply_id, (void*)w.W, (void*)w.Wp, (void*)w.A1, (void*)w.A2, (void*)w.small,
+             (void*)w.gpart, (void*)d_status, (void*)d_status_sel, (void*)w.T);       // (d_ritz, d_res: allocated with d_status, never regrown)
     const std::string key_base(key0);
 
     // Everything below only ENQUEUES work: the l x l factorisations run on the device, and the one
@@ -286,24 +291,40 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
             if (nb < 0) return nb;
             hipLaunchKernelGGL(k_chol_factor_panels, dim3(1), dim3(1024), 0, ctx->stream, (const double*)w.gpart, nb, l_act, w.dM, w.dDinv, d_status);
         }
-        hipLaunchKernelGGL(k_trsm_rows, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, src, w.dM, w.dDinv, k, w.W);
+        double* const zT = acc_apply ? w.T : nullptr;           // (the matrix-free solver's apply overwrites its destination and uses T itself)
+        double* const zWp = acc_apply ? w.Wp : nullptr;
+        double* const zA1 = acc_apply ? w.A1 : nullptr;
+        if (o.robust)
+            hipLaunchKernelGGL(k_trsm_rows, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, src, (const double*)w.dM, (const double*)w.dDinv, k, w.W, zWp, zA1, zT);
+        else
+            hipLaunchKernelGGL(k_trsm_mfma, dim3((k + 16 * kTrsmTiles - 1) / (16 * kTrsmTiles)), dim3(kTrsmTiles * 64), 0, ctx->stream, src,
+                               (const double*)w.dM, (const double*)w.dDinv, k, w.W, zWp, zA1, zT);
         SRX_HIP(ctx, hipGetLastError());
         if (o.robust) {                         // second pass: the first one may have run on a shifted Gram matrix
             SRX_TRY(gram2(ctx, w, w.W, w.W, k));
             hipLaunchKernelGGL(k_chol_factor, dim3(1), dim3(1024), 0, ctx->stream, w.dHG + L * L, l_act, w.dM, w.dDinv, d_status, 1);
-            hipLaunchKernelGGL(k_trsm_rows, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, (const double*)w.W, w.dM, w.dDinv, k, w.W);
+            hipLaunchKernelGGL(k_trsm_rows, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, (const double*)w.W, (const double*)w.dM, (const double*)w.dDinv, k, w.W,
+                               (double*)nullptr, (double*)nullptr, (double*)nullptr);
             SRX_HIP(ctx, hipGetLastError());
         }
         return SRX_OK;
     };
     // `n` applications of C starting from `src`, ping-ponging between Wp and A1 (no copies); returns where
     // the result is
-    auto apply_n = [&](const double* src, int n, const double** out) -> int32_t {
+    // (`after_orth`: Wp, A1 and T are zero; otherwise — after a Ritz step — Wp and T are)
+    auto apply_n = [&](const double* src, int n, bool after_orth, const double** out) -> int32_t {
         const double* cur = src;
+        double* const cand[3] = {w.Wp, w.A1, acc_apply ? w.T : nullptr};
+        bool zero[3] = {acc_apply, acc_apply && after_orth, acc_apply};
         for (int t = 0; t < n; ++t) {
-            double* dst = (cur == w.Wp) ? w.A1 : w.Wp;
-            SRX_TRY(apply(cur, dst, false));
-            cur = dst;
+            int pick = -1;
+            for (int c = 0; c < 3 && pick < 0; ++c)
+                if (cand[c] && cand[c] != cur && zero[c]) pick = c;
+            for (int c = 0; c < 3 && pick < 0; ++c)
+                if (cand[c] && cand[c] != cur) pick = c;
+            SRX_TRY(apply(cur, cand[pick], zero[pick]));
+            zero[pick] = false;
+            cur = cand[pick];
         }
         *out = cur;
         return SRX_OK;
@@ -316,7 +337,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     // residuals are measured on the vectors actually formed, so a loosely rotated basis is judged as what it is: at the
     // default tolerances (1e-7 / 1e-9) such a step is never accepted as converged — the next, exact one decides.
     auto ritz_kernels = [&](int slot, bool loose = false, bool wp_zero = false) -> int32_t {
-        SRX_TRY(apply(w.W, w.Wp, wp_zero));
+        SRX_TRY(apply(w.W, w.Wp, wp_zero || acc_apply));          // (Gram solver: Wp is zero after every CholeskyQR / filter step)
         {
             // H = W^T (C W) as partial sums -> eigen-solve (adds them on load) -> Ritz vectors, C x Ritz vectors, residual and
             // largest-entry partials in one pass -> the step's scalars: 4 launches (9 on the old route)
@@ -326,10 +347,14 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
             // block): off-diagonal norm 1e-3 of the diagonal is enough — the Ritz residual it reports, 1.63e-3 at c3, is the same
             // to three digits as with 1e-5 (1.62e-3), one Jacobi sweep less; at 1e-2 it reads 1.7e-2 and the filter takes a degree more
             constexpr double loose_tol2 = 1e-6;
+            // an exact step: the off-diagonal norm the solver leaves behind shows up in the Ritz residuals as at most that norm
+            // over theta_npc, i.e. sqrt(tol2) x (theta_1 / theta_npc) x a few — 1e-4 of the residual tolerance keeps it two
+            // orders below what the step is judged on (tol 1e-7: 1e-22, one sweep of the quadratic tail less than 1e-30)
+            const double exact_tol2 = std::max(1e-30, (o.tol * 1e-4) * (o.tol * 1e-4));
             hipLaunchKernelGGL(k_jacobi_eig2, dim3(1), dim3(kJ2Threads), sizeof(J2Lds), ctx->stream, (const double*)w.gpart, nb, l_act,
-                               w.dM2, w.dTheta, d_status, loose ? loose_tol2 : 1e-30);
-            hipLaunchKernelGGL(k_ritz_post, dim3(kRitzBlocks), dim3(256), 0, ctx->stream, (const double*)w.W, (const double*)w.Wp,
-                               (const double*)w.dM2, (const double*)w.dTheta, k, w.A1, w.A2, d_ritz);
+                               w.dM2, w.dTheta, d_status, loose ? loose_tol2 : exact_tol2);
+            hipLaunchKernelGGL(k_ritz_post, dim3(kRitzBlocks), dim3(256), 0, ctx->stream, (const double*)w.W, w.Wp,
+                               (const double*)w.dM2, (const double*)w.dTheta, k, w.A1, w.A2, d_ritz, acc_apply ? 1 : 0);
             hipLaunchKernelGGL(k_resid_final, dim3(1), dim3(1024), 0, ctx->stream, (const double*)d_ritz, kRitzBlocks,
                                (const double*)w.dTheta, o.n_pc, l_act, d_status, d_status_sel, w.dRho, w.dColmax,
                                d_res + kSlotDoubles * slot);
@@ -350,7 +375,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         // continue from the ROTATED block A1 = (C W) U (same span): its columns are close to eigenvectors,
         // so the next projected matrix is close to diagonal and its Jacobi solve takes 2-3 sweeps, not 8
         const double* res;
-        SRX_TRY(apply_n(w.A1, o.power - 1, &res));
+        SRX_TRY(apply_n(w.A1, o.power - 1, false, &res));
         return orth(res);
     };
     double spread = 1.0;               // theta_1 / theta_l of the last collected Ritz step
@@ -370,7 +395,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     // one sweep WITHOUT a Rayleigh–Ritz step: `power` applications of C, then CholeskyQR
     auto plain_sweep = [&]() -> int32_t {
         const double* res;
-        SRX_TRY(apply_n(w.W, o.power, &res));
+        SRX_TRY(apply_n(w.W, o.power, true, &res));
         return orth(res);
     };
 
@@ -381,6 +406,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         if (o.direct) {                    // W = I (k x k, k = l_act): H = C itself, Ritz pairs = eigenpairs whatever the rank
             hipLaunchKernelGGL(k_identity_block, dim3((unsigned)((kl + 255) / 256)), dim3(256), 0, ctx->stream, k, w.W);
             SRX_HIP(ctx, hipGetLastError());
+            if (acc_apply) SRX_HIP(ctx, hipMemsetAsync(w.Wp, 0, kl * 8, ctx->stream));      // (no start block, no CholeskyQR: nothing has zeroed it)
             return ritz_kernels(0, false);
         }
         // With a warm-up sweep the random block goes straight into C^power: the CholeskyQR that ends the sweep is the first
@@ -388,8 +414,11 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         // the Gaussian W — kappa ~ 1.4 at k = 2000, l = 64 — was orthonormalised first).  Without one (matrix-free solver,
         // robust mode) the Rayleigh-Ritz step needs an orthonormal block: CholeskyQR2 on the random start.
         const bool start_orth = o.robust || o.warm < 1;
+        // (Gram solver: the start block goes into W and the three scratch blocks start zeroed; with start_orth the block goes
+        //  into Wp, and the CholeskyQR that follows leaves the three zeroed)
         hipLaunchKernelGGL(k_init_block, dim3((unsigned)((kl + 255) / 256)), dim3(256), 0, ctx->stream, o.seed, k, l_act,
-                           start_orth ? w.Wp : w.W);
+                           start_orth ? w.Wp : w.W, acc_apply && !start_orth ? w.Wp : (double*)nullptr,
+                           acc_apply ? w.A1 : (double*)nullptr, acc_apply ? w.T : (double*)nullptr);
         if (start_orth) {
             SRX_TRY(orth(w.Wp));
             SRX_TRY(orth(w.W));
@@ -404,7 +433,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         hipLaunchKernelGGL(k_cheb_first, dim3(cheb_grid), dim3(256), 0, ctx->stream, w.A1, (const double*)w.A2,
                            (const double*)w.dTheta, l_act, kl);
         SRX_HIP(ctx, hipGetLastError());
-        return apply(w.A1, w.Wp, false);
+        return apply(w.A1, w.Wp, acc_apply);          // (Gram solver: the Ritz tail left Wp zeroed)
     };
     // the rest of a degree-d filter (Z = C Y1 is in Wp, cur = A1, prev = A2), CholeskyQR, Ritz step
     auto cheb_rest = [&](int d, int slot) -> int32_t {
@@ -688,6 +717,7 @@ int32_t run_pca(srx_ctx* ctx, const RowMajor* parts, int n_parts, const Tiled* t
     // Runs a plan of deflation rounds with the solver's `apply`; `reset` restores the undeflated operator, `deflate`
     // removes the eigenpairs a round has resolved (w.A2 / w.dTheta, leading n columns).  SRX_E_NOCONV (breakdown) or
     // converged == false (budget spent) leave the decision to the caller.
+    const bool acc_apply = o.solver == 1;            // the dense application accumulates into a zeroed block; w.T is free
     auto run_plan = [&](const std::vector<int>& plan, int budget, bool robust, auto& apply, const void* apply_id, bool graphable,
                         auto& reset, auto& deflate, double bail = 0.0) -> int32_t {
         SRX_TRY(reset());
@@ -715,7 +745,7 @@ int32_t run_pca(srx_ctx* ctx, const RowMajor* parts, int n_parts, const Tiled* t
             {
                 ProfScope ps_it(ctx, SRX_K_ITERATE, (double)k * k * 8.0);
                 SRX_TRY(subspace_iterate(ctx, w, k, l_r, o_r, apply, apply_id, graphable, hv ? hv->d_status : nullptr, resid_r,
-                                         iters_r, conv_r));
+                                         iters_r, conv_r, acc_apply));
             }
             resid = std::max(resid, resid_r);
             iters += iters_r + o.warm;
@@ -789,7 +819,7 @@ int32_t run_pca(srx_ctx* ctx, const RowMajor* parts, int n_parts, const Tiled* t
         auto apply = [&](const double* Win, double* Wout, bool out_zeroed) -> int32_t {
             ProfScope ps(ctx, SRX_K_DENSE, (double)k * k * 8.0 + 2.0 * k * L * 8.0);
             if (!out_zeroed) SRX_HIP(ctx, hipMemsetAsync(Wout, 0, kl * 8, ctx->stream));
-            hipLaunchKernelGGL(k_dense_apply, dim3((k + 31) / 32, kDenseSplit), dim3(kDenseWaves * 64), 0, ctx->stream, C, Win, k, Wout);
+            hipLaunchKernelGGL(k_dense_apply, dim3((k + 31) / 32, kDenseSplit), dim3(kDenseWaves * 64), kDenseLds, ctx->stream, C, Win, k, Wout);
             SRX_HIP(ctx, hipGetLastError());
             return SRX_OK;
         };
@@ -800,6 +830,7 @@ int32_t run_pca(srx_ctx* ctx, const RowMajor* parts, int n_parts, const Tiled* t
             return SRX_OK;
         };
         Range r_("srx:iterate");
+        SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_dense_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDenseLds));
         SRX_TRY(solve(apply, C, true, reset, deflate));
     } else {
         if (n_parts != 1 || !t256p) return fail(ctx, SRX_E_ARG, "pca: the SpMM solver needs the matrix resident in one piece");
@@ -880,6 +911,10 @@ int32_t resolve_opts(srx_ctx* ctx, const srx_pca_opts* opts, int k, uint64_t Ng,
     if (o.max_iter == 0) o.max_iter = o.solver == 1 ? 200 : 600;
     o.power = o.solver == 1 ? 3 : 1;
     o.warm = o.solver == 1 ? 2 : 0;
+    // (Round 5, measured at c3 with the schedule overridden — warm-up sweeps x applications per sweep: 2 x 3 (this) 0.97 ms, residual
+    //  1.0e-8; 1 x 6 0.90 ms, the same residuals to four digits — one CholeskyQR less, on a block of condition (theta_1 / theta_l)^6; 1 x 5
+    //  0.88 ms, 4.9e-8; 1 x 4 and 2 x 2 need a third Ritz step, 1.2-1.3 ms.  The 0.07-0.1 ms are not worth a CholeskyQR on the sixth
+    //  power of the spectrum's spread: kept at 2 x 3.  profiles/r05_knockouts.md)
     if (o.solver == 1 && k > 16384) return fail(ctx, SRX_E_ARG, "pca: the Gram solver holds a k x k f64 matrix; k=%d is too large", k);
     // default tolerance on the relative Ritz residual: what the arithmetic of the solver supports
     if (o.tol == 0.0) o.tol = f32 ? 1e-7 : 1e-9;

@@ -184,3 +184,33 @@ def test_integration_excerpts_are_the_shim():
                 "pub fn compute_number<B: Backend>(adata: AnnData<B>, direction: Direction, mode: ComputationMode) -> anyhow::Result<Vec<u32>>",
                 "pub fn compute_sum<B: Backend>(adata: AnnData<B>, direction: Direction, mode: ComputationMode) -> anyhow::Result<Vec<f64>>"):
         assert sig in shim, sig
+
+
+def test_hot_kernels_do_not_spill_registers(tmp_path):
+    """The Gram stripe kernel runs at a 64-VGPR budget with two register sets of loads in flight: a one-line change (a 64-bit
+    multiply in the load address, a store through what had been a read-only pointer) tipped its f32 instantiation into 56
+    spilled VGPRs and cost 0.3 ms per step before any test noticed (round 5).  Compile the device code of the two files that
+    hold the three largest kernels and read the code-object metadata: no VGPR spill, no scratch."""
+    import concurrent.futures as cf
+    import subprocess
+    from singlerust_amd import build
+    csrc = os.path.join(ROOT, "singlerust_amd", "csrc")
+    wanted = {"pca_form.hip": ["k_gram_stripesIfE", "k_gram_stripesIdE"],
+              "pca_solve.hip": ["k_spmm_rowsIffLi4ELb0ELi4EE"]}
+
+    def asm(src):
+        out = str(tmp_path / (src + ".s"))
+        subprocess.check_call([build._hipcc(), *[f for f in build.FLAGS if f != "-Wall"], "-w", "-S", "--cuda-device-only", "-o", out,
+                               os.path.join(csrc, src)], stderr=subprocess.DEVNULL)
+        return open(out).read()
+    with cf.ThreadPoolExecutor(max_workers=2) as ex:
+        texts = dict(zip(wanted, ex.map(asm, wanted)))
+    for src, kernels in wanted.items():
+        meta = texts[src]
+        for kname in kernels:
+            m = re.search(r"\.name:\s+(\S*%s\S*)\n(.*?)\.wavefront_size" % re.escape(kname), meta, flags=re.S)
+            assert m, f"{kname} not found in {src}"
+            body = m.group(2)
+            spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", body).group(1))
+            scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", body).group(1))
+            assert spill == 0 and scratch == 0, f"{m.group(1)}: {spill} spilled VGPRs, {scratch} B of scratch"
