@@ -247,16 +247,17 @@ __global__ void k_gram2_reduce(const double* __restrict__ part, int n_blocks, do
     HG[e] = s;
 }
 
-// ONE product of two k x 64 blocks, H = A^T B (A == B: the Gram matrix of a block), as kGram1Blocks partial 64 x 64 sums
-// over row slices.  The consumer — k_chol_factor_panels or k_jacobi_eig2, through (part, n_part) — adds the partials in fixed
-// order while it loads the matrix: no reduction kernel between the two, and half the arithmetic of k_gram2_part, which forms
-// both products whichever is wanted.
+// ONE product of two k x 64 blocks, H = A^T B (A == B: the Gram matrix of a block): kGram1Blocks workgroups, one row slice each,
+// their partial 64 x 64 sums ADDED into one zeroed matrix with global f64 atomics (round 5; until then 16 partial matrices that the
+// consumer summed on load — 512 KB through the one CU the Cholesky / Jacobi workgroup runs on: ~6 us of the factorisation's 34 and
+// ~15 of the eigen-solve's 190, the 384 threads of the latter taking 11 trips of 16 loads).  The consumer reads H once and leaves it
+// ZEROED for the next product; half the arithmetic of k_gram2_part, which forms both products whichever is wanted.
 constexpr int kGram1Blocks = 16;
 // On the f64 matrix cores: wave w of a workgroup owns the 16 x 16 output tile (w / 4, w % 4); both operands come straight
 // from global memory in fragment order (lane l: row kk + (l >> 4), column 16 t + (l & 15) — 128 contiguous bytes per
 // 16 lanes), eight K-steps of loads in flight.  (The LDS-staged scalar version was LDS-read bound: 24 us a launch.)
 __global__ __launch_bounds__(1024) void k_gram1_part(const double* __restrict__ A, const double* __restrict__ B, int k,
-                                                     double* __restrict__ part /* [blocks][64*64] */) {
+                                                     double* __restrict__ H /* 64 x 64, accumulated into */) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int ti = wv >> 2, tj = wv & 3;
@@ -278,9 +279,8 @@ __global__ __launch_bounds__(1024) void k_gram1_part(const double* __restrict__ 
         for (int u = 0; u < kU; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
     }
     // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
-    double* out = part + (size_t)blockIdx.x * L * L;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) out[(16 * ti + lk + 4 * v) * L + 16 * tj + li] = acc[v];
+    for (int v = 0; v < 4; ++v) atomicAdd(&H[(16 * ti + lk + 4 * v) * L + 16 * tj + li], acc[v]);
 }
 
 // The tail of a Rayleigh–Ritz step in one pass over the rows: A1 = Wp U (= C W U), A2 = W U (the Ritz vectors), and per
@@ -460,29 +460,39 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     return __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
 }
 constexpr int kCholPanel = 8;
-__global__ __launch_bounds__(1024) void k_chol_factor_panels(const double* __restrict__ G, int n_part, int n, double* __restrict__ Rout,
-                                                             double* __restrict__ dinv, int* __restrict__ status) {
+// Round 5: the trailing update on the f64 matrix cores and the inverted 16 x 16 diagonal blocks of R as a second output
+// (k_trsm_mfma's operands).  Round 3's scalar update (k_chol_factor_panels, gone) read two LDS words per multiply-add — ~900 wave-level LDS reads
+// per panel, 2 us of the 4.5 us a panel took (36 us a launch, three launches per solve); as 16 x 16 tiles, D -= P_K^T P_L with the
+// panel's 8 rows as the contraction index (two v_mfma_f64_16x16x4 per tile, <= 10 tiles on as many waves), a lane reads 2 + 2
+// operands and moves its 4 tile entries in and out.  Rows of a tile that are finished (< j1) get a zero A operand: untouched.
+// Xi[J][a][b] = (R_JJ^-1)[a][b], upper triangular, by back substitution (one thread per column; dinv = 0 — a column >= n —
+// gives a zero column).
+__global__ __launch_bounds__(1024) void k_chol_factor_mfma(double* __restrict__ G /* k_gram1_part's sum: read once, left zeroed */, int n,
+                                                           double* __restrict__ Rout, double* __restrict__ dinv,
+                                                           double* __restrict__ Xi_out, int* __restrict__ status) {
     __shared__ double A[L][L + 1];           // the rows of a finished panel hold R
+    __shared__ double s_dinv[L];
     __shared__ int s_bad;
     const int tid = threadIdx.x;
-    for (int e = tid; e < L * L; e += 1024) {      // G = the sum of n_part <= 16 partial matrices (k_gram1_part), in fixed order
-        const int r = e >> 6, c = e & 63;
-        double v[kGram1Blocks];
+    const int lane = tid & 63, wv = tid >> 6;
+    {
+        double g4[4];
 #pragma unroll
-        for (int p = 0; p < kGram1Blocks; ++p) v[p] = p < n_part ? G[(size_t)p * L * L + e] : 0.0;      // all in flight
-        double g = 0.0;
+        for (int u = 0; u < 4; ++u) g4[u] = G[tid + 1024 * u];
 #pragma unroll
-        for (int p = 0; p < kGram1Blocks; ++p) g += v[p];
-        A[r][c] = (r < n && c < n) ? g : 0.0;
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 1024 * u, r = e >> 6, c = e & 63;
+            A[r][c] = (r < n && c < n) ? g4[u] : 0.0;
+            G[e] = 0.0;
+        }
     }
     if (tid == 0) s_bad = 0;
+    if (tid < L) s_dinv[tid] = 0.0;
     __syncthreads();
     for (int j0 = 0; j0 < n; j0 += kCholPanel) {
         const int j1 = j0 + kCholPanel < n ? j0 + kCholPanel : n;
         if (tid < kWave) {
-            // lane c holds column c of the panel's rows in registers; pivots and multipliers travel by v_readlane (a pivot
-            // step through LDS — read the pivot, write the row, read the multipliers, update — was 0.6 us of latency,
-            // the same as the one-barrier-per-step kernel)
+            // (as in k_chol_factor_panels: lane c holds column c of the panel's rows in registers; pivots and multipliers by v_readlane)
             const int c = tid;
             double a[kCholPanel];
 #pragma unroll
@@ -493,10 +503,10 @@ __global__ __launch_bounds__(1024) void k_chol_factor_panels(const double* __res
                 if (j < j1) {                                   // (uniform)
                     const double d = readlane_v(a[jj], j);
                     if (!(d > 0.0) && c == 0) s_bad = 1;
-                    const double inv = d > 1e-290 ? fast_rsqrt(d) : rsqrt(d);      // (the library's: ~10 dependent operations)
+                    const double inv = d > 1e-290 ? fast_rsqrt(d) : rsqrt(d);
                     const double rjc = (c >= j && c < n) ? a[jj] * inv : 0.0;
                     a[jj] = rjc;                                // row j of R (zero left of the diagonal and right of n)
-                    if (c == j) dinv[j] = inv;
+                    if (c == j) s_dinv[j] = inv;
 #pragma unroll
                     for (int rr = jj + 1; rr < kCholPanel; ++rr) {
                         const int r = j0 + rr;
@@ -509,28 +519,59 @@ __global__ __launch_bounds__(1024) void k_chol_factor_panels(const double* __res
             }
 #pragma unroll
             for (int jj = 0; jj < kCholPanel; ++jj)
-                if (j0 + jj < j1) {
-                    A[j0 + jj][c] = a[jj];
-                    Rout[(size_t)(j0 + jj) * L + c] = a[jj];
-                }
+                if (j0 + jj < j1) A[j0 + jj][c] = a[jj];      // (R and dinv go out once, at the end: a global store in front of a
+                                                                //  barrier is a round trip to L2 the whole workgroup waits for — 8 panels of it)
         }
         __syncthreads();
-        // trailing rows r >= j1: a_rc -= sum over the panel of r_jr r_jc, c >= r
+        // trailing tiles (K, Lt), K0 <= K <= Lt <= 3, K0 = the tile that holds row j1: wave w takes the w-th of them
+        if (j1 < L) {
+            const int K0 = j1 >> 4;
+            int K = -1, Lt = -1, t = wv;
+            for (int kk = K0; kk < 4 && K < 0; ++kk) {
+                const int cnt = 4 - kk;
+                if (t < cnt) {
+                    K = kk;
+                    Lt = kk + t;
+                } else t -= cnt;
+            }
+            if (K >= 0) {                                       // (wave-uniform)
+                const int m = lane & 15, g = lane >> 4;
+                dvec4 d;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = tid + 1024 * u, r = e >> 6, c = e & 63;
-            if (r >= j1 && c >= r && c < n) {
-                double acc = A[r][c];
-                for (int j = j0; j < j1; ++j) acc -= A[j][r] * A[j][c];
-                A[r][c] = acc;
+                for (int v = 0; v < 4; ++v) d[v] = A[16 * K + g + 4 * v][16 * Lt + m];
+#pragma unroll
+                for (int sI = 0; sI < kCholPanel / 4; ++sI) {
+                    const int j = j0 + 4 * sI + g;
+                    const bool live = j < j1;
+                    const double a = (live && 16 * K + m >= j1) ? A[live ? j : 0][16 * K + m] : 0.0;
+                    const double b = live ? A[j][16 * Lt + m] : 0.0;
+                    d = __builtin_amdgcn_mfma_f64_16x16x4f64(-a, b, d, 0, 0, 0);
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) A[16 * K + g + 4 * v][16 * Lt + m] = d[v];
             }
         }
         __syncthreads();
     }
-    for (int e = tid; e < L * L; e += 1024)
-        if ((e >> 6) >= n) Rout[e] = 0.0;
-    if (tid < L && tid >= n) dinv[tid] = 0.0;
+    for (int e = tid; e < L * L; e += 1024) {
+        const int r = e >> 6, c = e & 63;
+        Rout[e] = (r < n && c >= r) ? A[r][c] : 0.0;          // (a finished row is zero right of n; below the diagonal the tiles hold leftovers)
+    }
+    if (tid < L) dinv[tid] = tid < n ? s_dinv[tid] : 0.0;
     if (tid == 0 && s_bad) atomicOr(status, kStatChol);
+    if (tid < L) {                                             // the four inverted diagonal blocks
+        const int J = tid >> 4, c = tid & 15, o = 16 * J;
+        double x[16];
+#pragma unroll
+        for (int i = 15; i >= 0; --i) {
+            double acc = 0.0;
+#pragma unroll
+            for (int mm = i + 1; mm < 16; ++mm) acc = __builtin_fma(A[o + i][o + mm], x[mm], acc);      // (x[mm] = 0 for mm > c)
+            x[i] = i == c ? s_dinv[o + i] : (i < c ? -acc * s_dinv[o + i] : 0.0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Xi_out[(J * 16 + i) * 16 + c] = x[i];
+    }
 }
 
 // W[row] R = Wp[row]: w_j = (wp_j - sum_{i<j} w_i R[i][j]) / R[j][j], one thread per row, the row in
@@ -595,48 +636,40 @@ __global__ __launch_bounds__(64) void k_trsm_rows(const double* Wp, const double
 // the contraction index taken in the order the accumulator registers hold it: a finished tile X_I sits in the C/D layout
 // (lane: column l & 15, rows (l >> 4) + 4 reg), which IS the B operand of step `reg` when the A operand supplies
 // R[16 I + (l >> 4) + 4 reg][16 J + (l & 15)] — so the tiles never leave the registers (no LDS relayout between the stages),
-// and the only LDS traffic are the reads of R and of the four inverted diagonal blocks.  Those inverses (16 x 16 upper
-// triangular, by back substitution, one thread per column) are made by the first wave of every workgroup: 120 FMAs each.
+// and R and the four inverted diagonal blocks are read straight from global memory, all loads in flight at once (no LDS, no
+// barrier: 18 -> see profiles/r05_rocprof_c3.md).  Those inverses (16 x 16 upper triangular, by back substitution, one thread per
+// column) are k_chol_factor_mfma's second output.
 // A forward substitution through explicitly inverted DIAGONAL BLOCKS is what blocked TRSM implementations do; it is backward
 // stable up to the condition of a 16 x 16 diagonal block.  Columns >= n (R's rows zero, dinv = 0) come out zero, as from
 // k_trsm_rows; the robust mode (dropped columns: dinv = 0 with a unit row in R) keeps k_trsm_rows.
 // z0 .. z2: as in k_trsm_rows (the rows of those blocks are left zeroed once the wave's own 16 source rows are in registers).
 constexpr int kTrsmTiles = 4;              // waves (16-row tiles) per workgroup
 __global__ __launch_bounds__(kTrsmTiles * 64) void k_trsm_mfma(const double* Wp, const double* __restrict__ R,
-                                                               const double* __restrict__ dinv, int k, double* W, double* z0,
-                                                               double* z1, double* z2) {
-    constexpr int LD = L + 2;
-    __shared__ double Rs[L][LD];                 // R, row-major (zero below the diagonal)
-    __shared__ double Xi[4][16][16 + 1];         // Xi[J][a][b] = (R_JJ^-1)[a][b]
-    __shared__ double ds[L];
+                                                               const double* __restrict__ Xi /* k_chol_factor_mfma: [4][16][16] */,
+                                                               int k, double* W, double* z0, double* z1, double* z2) {
     const int tid = threadIdx.x;
-    for (int e = tid; e < L * L; e += kTrsmTiles * 64) Rs[e >> 6][e & 63] = R[e];
-    if (tid < L) ds[tid] = dinv[tid];
-    __syncthreads();
-    if (tid < L) {
-        const int J = tid >> 4, c = tid & 15, o = 16 * J;
-        double x[16];
-#pragma unroll
-        for (int i = 15; i >= 0; --i) {
-            double acc = 0.0;
-#pragma unroll
-            for (int mm = i + 1; mm < 16; ++mm) acc = __builtin_fma(Rs[o + i][o + mm], x[mm], acc);      // (x[mm] = 0 for mm > c)
-            x[i] = i == c ? ds[o + i] : (i < c ? -acc * ds[o + i] : 0.0);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) Xi[J][i][c] = x[i];
-    }
-    __syncthreads();
     const int lane = tid & 63, wv = tid >> 6;
     const int m = lane & 15, g = lane >> 4;
     const int row = (blockIdx.x * kTrsmTiles + wv) * 16 + m;
     const bool ok = row < k;
     const size_t base = (size_t)(ok ? row : 0) * L;
+    // every operand is asked for up front (the tile's 16 entries per lane, the 24 entries of R's six blocks above the diagonal,
+    // the 16 of the inverted diagonal blocks — R and Xi are 34 KB, L2-resident): one round trip, then the chain of 40 MFMAs
     dvec4 T[4], X[4];
+    double ra[4][4][4], xa[4][4];           // ra[I][J][r] (I < J): -R[16 I + g + 4 r][16 J + m];  xa[J][r]: Xi[J][g + 4 r][m]
 #pragma unroll
     for (int J = 0; J < 4; ++J)
 #pragma unroll
         for (int r = 0; r < 4; ++r) T[J][r] = ok ? Wp[base + 16 * J + g + 4 * r] : 0.0;
+#pragma unroll
+    for (int J = 0; J < 4; ++J) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xa[J][r] = Xi[(J * 16 + g + 4 * r) * 16 + m];
+#pragma unroll
+        for (int I = 0; I < J; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ra[I][J][r] = -R[(size_t)(16 * I + g + 4 * r) * L + 16 * J + m];
+    }
     asm volatile("" ::: "memory");               // the wave's source rows are read before any block's rows are overwritten
     if (ok) {
         double* const zs[3] = {z0, z1, z2};
@@ -655,11 +688,10 @@ __global__ __launch_bounds__(kTrsmTiles * 64) void k_trsm_mfma(const double* Wp,
 #pragma unroll
         for (int I = 0; I < J; ++I)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                t = __builtin_amdgcn_mfma_f64_16x16x4f64(-Rs[16 * I + g + 4 * r][16 * J + m], X[I][r], t, 0, 0, 0);
+            for (int r = 0; r < 4; ++r) t = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[I][J][r], X[I][r], t, 0, 0, 0);
         dvec4 d = dvec4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) d = __builtin_amdgcn_mfma_f64_16x16x4f64(Xi[J][g + 4 * r][m], t[r], d, 0, 0, 0);
+        for (int r = 0; r < 4; ++r) d = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[J][r], t[r], d, 0, 0, 0);
         X[J] = d;
     }
     if (ok) {
@@ -777,4 +809,5 @@ __global__ __launch_bounds__(1024) void k_resid_final(const double* __restrict__
     out[2] = theta[n_pc - 1] > 0 ? theta[l_act - 1] / theta[n_pc - 1] : 1.0;
     out[3] = status_sel ? (double)*status_sel : 0.0;
     out[4] = theta[l_act - 1] > 0 ? theta[0] / theta[l_act - 1] : 1.0;
+    out[5] = (double)status[1];               // full sweeps the eigen-solve of this step took (trace output)
 }

@@ -24,6 +24,14 @@
 // descending in theta; rows / columns >= n are 0, theta[c >= n] = 0; kStatEig on non-convergence after 30 sweeps.
 // `off_tol2`: the sweep loop stops when sum_{i<j} a_ij^2 <= off_tol2 * sum_i a_ii^2, measured before a sweep's first round;
 // the solve leaves after that round (the state is one round better than measured; players are back in their own slots).
+// `n_want` (round 5): the sum on the left runs over the pairs with at least one WANTED index — the n_want largest diagonal
+// entries, ranked one sweep earlier (the ranks of the leading entries do not move once the first sweep is through).  A Ritz
+// step asks for n_pc pairs of a block with 14 guard columns whose Ritz values crowd together (theta_64 / theta_50 = 0.97 on the
+// bench matrix): the guard x guard block is a dense perturbation of a multiple of the identity and takes the cyclic Jacobi its
+// full ~5 sweeps, while everything a wanted pair's residual sees — its row — is at rounding level two sweeps earlier.
+// Rotations between two guard indices leave the norm of every wanted row unchanged, so stopping early costs the wanted pairs
+// nothing; U stays orthogonal whatever is left in the guard block, whose diagonal entries are then Rayleigh quotients, not
+// eigenvalues: theta_l, the filter's bound, errs upward (a valid bound).  n_want >= n: the plain criterion.
 
 constexpr int kJ2BWaves = 5;                              // wave 0: one block per lane, the 32 rotation makers among them; waves 1-4: two
 constexpr int kJ2BThreads = kJ2BWaves * kWave;            // blocks per thread.  6 waves in all: at most two per SIMD, i.e. 256 registers
@@ -97,6 +105,7 @@ struct alignas(16) J2Lds {
     double pend[2][L / 2];       // squared pivots the round of that parity annihilates
     double red[kJ2BWaves];
     int rank[L];
+    int want[L];                 // per slot (= player, at a sweep's first round): 1 when its diagonal entry ranks among the wanted
     int flag;
 };
 
@@ -181,26 +190,33 @@ __device__ __forceinline__ void j2_u_rounds(double (&u)[L], const J2Lds& S, int&
     ((J2Round<Rs + 1>::apply(u, S.tu[par]), j2_barrier(), par ^= 1), ...);
 }
 
-__global__ __launch_bounds__(kJ2Threads) void k_jacobi_eig2(const double* __restrict__ H, int n_part, int n, double* __restrict__ U,
-                                                            double* __restrict__ theta, int* __restrict__ status, double off_tol2) {
+__global__ __launch_bounds__(kJ2Threads) void k_jacobi_eig2(double* __restrict__ H /* k_gram1_part's sum: read once, left zeroed */, int n, double* __restrict__ U,
+                                                            double* __restrict__ theta, int* __restrict__ status, double off_tol2,
+                                                            int n_want) {
     static_assert(L == 64, "the block mapping is written for l = 64");
     extern __shared__ double j2_lds_raw[];
     J2Lds& S = *reinterpret_cast<J2Lds*>(j2_lds_raw);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
     const int lane = tid & (kWave - 1);
-    // H = the sum of n_part <= 16 partial matrices (k_gram1_part), in fixed order: summed into the second copy of the matrix
-    // (free until round 0 writes it), all partial loads of an entry in flight; then symmetrised, the diagonal parked in scale[0]
+    // H goes into the second copy of the matrix (free until round 0 writes it), all of a thread's loads in flight at once; then it is
+    // symmetrised, the diagonal parked in scale[0]
     {
         double* const T = &S.A[1][0][0];
-        for (int e = tid; e < L * L; e += kJ2Threads) {
-            double v[kGram1Blocks];
+        constexpr int kPer = (L * L + kJ2Threads - 1) / kJ2Threads;
+        double hv[kPer];
 #pragma unroll
-            for (int p = 0; p < kGram1Blocks; ++p) v[p] = p < n_part ? H[(size_t)p * L * L + e] : 0.0;
-            double h = 0.0;
+        for (int u = 0; u < kPer; ++u) {
+            const int e = tid + u * kJ2Threads;
+            hv[u] = e < L * L ? H[e] : 0.0;
+        }
 #pragma unroll
-            for (int p = 0; p < kGram1Blocks; ++p) h += v[p];
-            T[e] = h;
+        for (int u = 0; u < kPer; ++u) {
+            const int e = tid + u * kJ2Threads;
+            if (e < L * L) {
+                T[e] = hv[u];
+                H[e] = 0.0;
+            }
         }
         j2_barrier();
         for (int e = tid; e < L * L; e += kJ2Threads) {
@@ -210,7 +226,10 @@ __global__ __launch_bounds__(kJ2Threads) void k_jacobi_eig2(const double* __rest
             if (a == b) S.scale[0][a] = in ? T[e] : 0.0;
         }
     }
-    if (tid < L) S.scale[1][tid] = 1.0;
+    if (tid < L) {
+        S.scale[1][tid] = 1.0;
+        S.want[tid] = 1;               // the first sweep's measurement: every pair
+    }
     if (tid == 0) S.flag = 0;
     j2_barrier();
     // prologue: the rotations of round 0 from the matrix as loaded (pair m = slots 2m, 2m + 1 = players 2m, 2m + 1)
@@ -262,8 +281,22 @@ __global__ __launch_bounds__(kJ2Threads) void k_jacobi_eig2(const double* __rest
         // the next pair's players as seen from the block: x on the row side (slot 2I + h), y on the column side (slot 2J + g)
         const int fh = fsel >> 1, fg = fsel & 1;
         const int xs = 2 * bI[0] + fh, ys = 2 * bJ[0] + fg;
+        int want_next = 1, sweep_count = 0;
         for (int sweep = 0; sweep < 31 && !converged; ++sweep) {
-            for (int r = 0; r < kJ2Rounds; ++r) {
+            sweep_count = sweep;
+            double wq[2][4];                  // 1 where the entry's pair has a wanted index (ranks of the sweep before), else 0
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int wI0 = S.want[2 * bI[v]], wI1 = S.want[2 * bI[v] + 1], wJ0 = S.want[2 * bJ[v]], wJ1 = S.want[2 * bJ[v] + 1];
+                wq[v][0] = (wI0 | wJ0) ? 1.0 : 0.0;
+                wq[v][1] = (wI0 | wJ1) ? 1.0 : 0.0;
+                wq[v][2] = (wI1 | wJ0) ? 1.0 : 0.0;
+                wq[v][3] = (wI1 | wJ1) ? 1.0 : 0.0;
+            }
+            // one round: the blocks' rotation, next round's rotations made by the 32 fold threads; `measure` (round 0 only, a
+            // compile-time copy of the body: the other 62 rounds carry none of it): this thread's share of the off-diagonal norm
+            // BEFORE the round, over the pairs with a wanted index
+            auto round_body = [&](auto measure) -> double {
                 const int nxt = par ^ 1;
                 double offsq = 0.0;
                 const double* const Ar = Ab + par * kCopy;
@@ -285,7 +318,9 @@ __global__ __launch_bounds__(kJ2Threads) void k_jacobi_eig2(const double* __rest
                     const j2_d2 r0 = *reinterpret_cast<const j2_d2*>(Ar + s0[v]), r1 = *reinterpret_cast<const j2_d2*>(Ar + s0[v] + kJ2Ld);
                     const double b00 = r0.x, b01 = r0.y, b10 = r1.x, b11 = r1.y;
                     const double tI = rI.x, tJ = rJ.x, cc = rI.y * rJ.y;
-                    offsq += b00 * b00 + b01 * b01 + b10 * b10 + b11 * b11;     // off-diagonal norm before this round: this thread's share
+                    if constexpr (decltype(measure)::value)
+                        offsq = __builtin_fma(wq[v][0] * b00, b00, __builtin_fma(wq[v][1] * b01, b01,
+                                __builtin_fma(wq[v][2] * b10, b10, __builtin_fma(wq[v][3] * b11, b11, offsq))));
                     // rows: new_p = c (p - t q), new_q = c (q + t p); then the same on the columns; one common factor
                     const double t00 = __builtin_fma(-tI, b10, b00), t01 = __builtin_fma(-tI, b11, b01);
                     const double t10 = __builtin_fma(tI, b00, b10), t11 = __builtin_fma(tI, b01, b11);
@@ -315,30 +350,45 @@ __global__ __launch_bounds__(kJ2Threads) void k_jacobi_eig2(const double* __rest
                     S.scale[nxt][2 * fm + 1] = scq * c;
                     S.pend[nxt][fm] = val * val;
                 }
-                if (r == 0) {                             // (all 64 lanes of the wave take part in the reduction)
-                    const double off = wave_sum(offsq);
-                    if (lane == 0) S.red[wave] = off;
+                return offsq;
+            };
+            // round 0: measured
+            {
+                const double off_mine = wave_sum(round_body(std::true_type{}));      // (all 64 lanes of the wave take part in the reduction)
+                if (lane == 0) S.red[wave] = off_mine;
+                j2_barrier();
+                if (wave == 0) {
+                    double off = (lane < kJ2BWaves ? S.red[lane] : 0.0) +
+                                 (lane < L / 2 && (S.want[2 * lane] | S.want[2 * lane + 1]) ? S.pend[par][lane] : 0.0);
+                    const double dv = S.rec[par][lane >> 1][2 + (lane & 1)];
+                    double dg = dv * dv;
+                    off = wave_sum(off);
+                    dg = wave_sum(dg);
+                    if (lane == 0) S.flag = !(off > off_tol2 * dg) ? 1 : (sweep >= 30 ? 2 : 0);
+                    // who is wanted at the NEXT sweep's measurement: rank of this slot's diagonal entry among the 64
+                    int rk = 0;
+                    for (int j = 0; j < L; ++j) {
+                        const double other = S.rec[par][j >> 1][2 + (j & 1)];
+                        rk += (other > dv || (other == dv && j < lane)) ? 1 : 0;
+                    }
+                    want_next = rk < n_want ? 1 : 0;
                 }
                 j2_barrier();
-                if (r == 0) {
-                    if (wave == 0) {
-                        double off = (lane < kJ2BWaves ? S.red[lane] : 0.0) + (lane < L / 2 ? S.pend[par][lane] : 0.0);
-                        const double dv = S.rec[par][lane >> 1][2 + (lane & 1)];
-                        double dg = dv * dv;
-                        off = wave_sum(off);
-                        dg = wave_sum(dg);
-                        if (lane == 0) S.flag = !(off > off_tol2 * dg) ? 1 : (sweep >= 30 ? 2 : 0);
-                    }
-                    j2_barrier();
-                    if (S.flag) {
-                        converged = true;
-                        break;
-                    }
+                if (wave == 0) S.want[lane] = want_next;       // (read again at the next sweep's start: barriers between)
+                if (S.flag) {
+                    converged = true;
+                    break;
                 }
-                par = nxt;
+                par ^= 1;
+            }
+            for (int r = 1; r < kJ2Rounds; ++r) {
+                (void)round_body(std::false_type{});
+                j2_barrier();
+                par ^= 1;
             }
         }
         if (tid == 0 && S.flag == 2) atomicOr(status, kStatEig);
+        if (tid == 0) status[1] = sweep_count;             // (diagnostics: SRX_PCA_TRACE prints the sweeps of the last eigen-solve)
         // eigenvalues: the diagonal after the last round applied (round 0 of a sweep: every player sits in its own slot),
         // descending; padded indices (>= n) go last
         if (tid < L) {

@@ -161,7 +161,7 @@ static uint64_t mix64(uint64_t x) {
 
 struct Work {                   // k x 64 f64 state, replicated per rank
     double *W, *Wp, *T, *A1, *A2, *small, *mu, *d, *gpart;
-    double *dHG, *dM, *dM2, *dTheta, *dRho, *dColmax, *dSgn, *dDinv;
+    double *dHG, *dM, *dM2, *dTheta, *dRho, *dColmax, *dSgn, *dDinv, *dXi;
 };
 
 static int32_t alloc_work(srx_ctx* ctx, int k, Work& w) {
@@ -171,7 +171,7 @@ static int32_t alloc_work(srx_ctx* ctx, int k, Work& w) {
     SRX_TRY(scratch(ctx, "pca_T", (kl + L) * 8, (void**)&w.T));
     SRX_TRY(scratch(ctx, "pca_A1", kl * 8, (void**)&w.A1));
     SRX_TRY(scratch(ctx, "pca_A2", kl * 8, (void**)&w.A2));
-    SRX_TRY(scratch(ctx, "pca_small", (6 * L * L + 8 * L) * 8, (void**)&w.small));
+    SRX_TRY(scratch(ctx, "pca_small", (6 * L * L + 8 * L + 4 * 16 * 16) * 8, (void**)&w.small));
     SRX_TRY(scratch(ctx, "pca_mu", (size_t)k * 8, (void**)&w.mu));
     SRX_TRY(scratch(ctx, "pca_d", (size_t)k * 8, (void**)&w.d));
     SRX_TRY(scratch(ctx, "pca_g2part", (size_t)kGram2Blocks * 2 * L * L * 8, (void**)&w.gpart));
@@ -183,6 +183,7 @@ static int32_t alloc_work(srx_ctx* ctx, int k, Work& w) {
     w.dColmax = w.dRho + L;
     w.dSgn = w.dColmax + L;
     w.dDinv = w.dSgn + L;
+    w.dXi = w.small + 6 * L * L + 8 * L;       // the CholeskyQR's inverted 16 x 16 diagonal blocks of R
     return SRX_OK;
 }
 
@@ -256,7 +257,12 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     }
     int* d_status;
     double* d_res;
-    SRX_TRY(scratch(ctx, "pca_status", 256, (void**)&d_status));
+    // the status words and, behind them, the ONE 64 x 64 matrix the partial products of a block pair are summed into (k_gram1_part:
+    // global f64 atomics; its single consumer — the Cholesky factorisation or the eigen-solve — reads it once and leaves it zeroed;
+    // the memset that clears the status words at the start of a solve clears it too)
+    constexpr size_t kStatusBytes = 256;
+    SRX_TRY(scratch(ctx, "pca_status", kStatusBytes + (size_t)L * L * sizeof(double), (void**)&d_status));
+    double* const d_h1 = reinterpret_cast<double*>(reinterpret_cast<char*>(d_status) + kStatusBytes);
     SRX_TRY(scratch(ctx, "pca_res", kSlots * kSlotDoubles * sizeof(double), (void**)&d_res));
     double* d_ritz;
     SRX_TRY(scratch(ctx, "pca_ritzpart", (size_t)kRitzBlocks * 3 * L * sizeof(double), (void**)&d_ritz));
@@ -275,12 +281,12 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
 
     // orthonormalise src -> W  (CholeskyQR: G = src^T src = R^T R, W = src R^-1; src == W is fine: every
     // thread of the substitution owns one row); G lands in dHG + L*L
-    auto gram1 = [&](const double* A, const double* B) -> int32_t {       // partial sums of A^T B in w.gpart
+    auto gram1 = [&](const double* A, const double* B) -> int32_t {       // A^T B summed into d_h1 (zero between uses)
         int nb = (k + 31) / 32;
         if (nb > kGram1Blocks) nb = kGram1Blocks;
-        hipLaunchKernelGGL(k_gram1_part, dim3(nb), dim3(1024), 0, ctx->stream, A, B, k, w.gpart);
+        hipLaunchKernelGGL(k_gram1_part, dim3(nb), dim3(1024), 0, ctx->stream, A, B, k, d_h1);
         SRX_HIP(ctx, hipGetLastError());
-        return nb;
+        return 1;
     };
     auto orth = [&](const double* src) -> int32_t {
         if (o.robust) {
@@ -289,7 +295,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         } else {
             const int32_t nb = gram1(src, src);
             if (nb < 0) return nb;
-            hipLaunchKernelGGL(k_chol_factor_panels, dim3(1), dim3(1024), 0, ctx->stream, (const double*)w.gpart, nb, l_act, w.dM, w.dDinv, d_status);
+            hipLaunchKernelGGL(k_chol_factor_mfma, dim3(1), dim3(1024), 0, ctx->stream, d_h1, l_act, w.dM, w.dDinv, w.dXi, d_status);
         }
         double* const zT = acc_apply ? w.T : nullptr;           // (the matrix-free solver's apply overwrites its destination and uses T itself)
         double* const zWp = acc_apply ? w.Wp : nullptr;
@@ -298,7 +304,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
             hipLaunchKernelGGL(k_trsm_rows, dim3((k + 63) / 64), dim3(64), 0, ctx->stream, src, (const double*)w.dM, (const double*)w.dDinv, k, w.W, zWp, zA1, zT);
         else
             hipLaunchKernelGGL(k_trsm_mfma, dim3((k + 16 * kTrsmTiles - 1) / (16 * kTrsmTiles)), dim3(kTrsmTiles * 64), 0, ctx->stream, src,
-                               (const double*)w.dM, (const double*)w.dDinv, k, w.W, zWp, zA1, zT);
+                               (const double*)w.dM, (const double*)w.dXi, k, w.W, zWp, zA1, zT);
         SRX_HIP(ctx, hipGetLastError());
         if (o.robust) {                         // second pass: the first one may have run on a shifted Gram matrix
             SRX_TRY(gram2(ctx, w, w.W, w.W, k));
@@ -351,8 +357,9 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
             // over theta_npc, i.e. sqrt(tol2) x (theta_1 / theta_npc) x a few — 1e-4 of the residual tolerance keeps it two
             // orders below what the step is judged on (tol 1e-7: 1e-22, one sweep of the quadratic tail less than 1e-30)
             const double exact_tol2 = std::max(1e-30, (o.tol * 1e-4) * (o.tol * 1e-4));
-            hipLaunchKernelGGL(k_jacobi_eig2, dim3(1), dim3(kJ2Threads), sizeof(J2Lds), ctx->stream, (const double*)w.gpart, nb, l_act,
-                               w.dM2, w.dTheta, d_status, loose ? loose_tol2 : exact_tol2);
+            hipLaunchKernelGGL(k_jacobi_eig2, dim3(1), dim3(kJ2Threads), sizeof(J2Lds), ctx->stream, d_h1, l_act,
+                               w.dM2, w.dTheta, d_status, loose ? loose_tol2 : exact_tol2,
+                               o.direct ? l_act : std::min(l_act, o.n_pc + 4));      // (the guard columns' block need not be diagonal: jacobi.inl)
             hipLaunchKernelGGL(k_ritz_post, dim3(kRitzBlocks), dim3(256), 0, ctx->stream, (const double*)w.W, w.Wp,
                                (const double*)w.dM2, (const double*)w.dTheta, k, w.A1, w.A2, d_ritz, acc_apply ? 1 : 0);
             hipLaunchKernelGGL(k_resid_final, dim3(1), dim3(1024), 0, ctx->stream, (const double*)d_ritz, kRitzBlocks,
@@ -402,7 +409,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     // segment "start": random block, CholeskyQR2, warm-up sweeps (the first Ritz residuals are O(1) whatever
     // happens — no Rayleigh–Ritz step to learn that), first Ritz step
     auto seg_start = [&]() -> int32_t {
-        SRX_HIP(ctx, hipMemsetAsync(d_status, 0, 256, ctx->stream));
+        SRX_HIP(ctx, hipMemsetAsync(d_status, 0, kStatusBytes + (size_t)L * L * sizeof(double), ctx->stream));
         if (o.direct) {                    // W = I (k x k, k = l_act): H = C itself, Ritz pairs = eigenpairs whatever the rank
             hipLaunchKernelGGL(k_identity_block, dim3((unsigned)((kl + 255) / 256)), dim3(256), 0, ctx->stream, k, w.W);
             SRX_HIP(ctx, hipGetLastError());
@@ -478,8 +485,8 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         SRX_TRY(collect(slot, r, ratio));
         resid = r;
         if (getenv("SRX_PCA_TRACE"))
-            fprintf(stderr, "[srx pca] sweep %d (ritz step %d): residual %.3e, theta_l/theta_npc %.3e\n", iters + o.warm,
-                    n_ritz, r, ratio);
+            fprintf(stderr, "[srx pca] sweep %d (ritz step %d): residual %.3e, theta_l/theta_npc %.3e, %d Jacobi sweeps\n", iters + o.warm,
+                    n_ritz, r, ratio, (int)ctx->pin_async[kSlotDoubles * slot + 5]);
         if (r <= o.tol) {
             converged = true;
             break;
