@@ -85,38 +85,54 @@ __host__ __device__ inline bool gram_fixed_point_mode(uint32_t vmax_b, uint32_t 
     kq = 29 - 2 * emax;
     return neg == 0u && vmax_b != 0u && vmax_b < 0x7f800000u && nmin != 0u && emax - emin <= 6 && emax > -48 && emax < 48;
 }
+// f64 entries (round 5): the same rule on the HIGH words of the doubles (11-bit exponents); products are formed in f64 already scaled,
+// p 2^kq < 2^47 (kq = 45 - 2 emax), rounded to integers by the 1.5 x 2^52 constant — a chunk of 16k cells adds at most 2^14 of them
+// to an accumulator: < 2^61 —, half a unit = 2^-48 of the largest possible product; a product 2^-14 of the largest (both values
+// at the small end of a 6-exponent spread) keeps 2^-34 of itself.
+__host__ __device__ inline bool gram_fixed_point_mode64(uint32_t vmax_hi, uint32_t nmin_hi, uint32_t neg, int& kq) {
+    const uint32_t vmin_hi = ~nmin_hi;
+    const int emax = (int)(vmax_hi >> 20) - 1023, emin = (int)(vmin_hi >> 20) - 1023;
+    kq = 45 - 2 * emax;
+    return neg == 0u && vmax_hi != 0u && vmax_hi < 0x7ff00000u && nmin_hi != 0u && emax - emin <= 6 && emax > -200 && emax < 200;
+}
 __device__ __forceinline__ uint32_t* gram_stat(int64_t* rec_base, uint64_t n_rblk) { return reinterpret_cast<uint32_t*>(rec_base + n_rblk + 2); }
 
 // Sharded rows: the mode has to be the SAME on every rank (it decides how the products are rounded), so the statistics are
 // combined over the ranks first.  The path's collective is a SUM of doubles: each rank marks the biased exponent of its
 // largest |v| and of its smallest non-zero |v| in a 256-bin histogram each (+ one count of "a negative value was seen") ...
-constexpr int kGstatBins = 2 * 256 + 1;
+// (EB exponent bits: 8 for f32 entries, 11 for the high words of f64 entries; SH: the shift that brings the biased exponent down)
+template <int EB> constexpr int gstat_bins() { return 2 * (1 << EB) + 1; }
+constexpr int kGstatBins = gstat_bins<8>();
+template <int EB>
 __global__ void k_gstat_onehot(const uint32_t* __restrict__ gstat, double* __restrict__ bins) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    constexpr int NB = 1 << EB, SH = 31 - EB;
     const uint32_t vmax_b = gstat[0], nmin = gstat[1];
-    if (vmax_b) bins[vmax_b >> 23] += 1.0;                    // (NaN / inf land in bin 255: the range test fails everywhere)
-    if (nmin) bins[256 + ((~nmin) >> 23)] += 1.0;
-    if (gstat[2]) bins[512] += 1.0;
+    if (vmax_b) bins[vmax_b >> SH] += 1.0;                    // (NaN / inf land in the last bin: the range test fails everywhere)
+    if (nmin) bins[NB + ((~nmin) >> SH)] += 1.0;
+    if (gstat[2]) bins[2 * NB] += 1.0;
 }
 // ... and after the sum every rank rebuilds the three words from the highest / lowest marked bin: the kernel's test only
 // looks at the exponents, so a mantissa of zero stands for the values.  A rank without entries marks nothing.
+template <int EB>
 __global__ void k_gstat_decode(const double* __restrict__ bins, uint32_t* __restrict__ gstat) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    constexpr int NB = 1 << EB, SH = 31 - EB;
     int emax = -1, emin = -1;
-    for (int b = 0; b < 256; ++b) {
+    for (int b = 0; b < NB; ++b) {
         if (bins[b] != 0.0) emax = b;
-        if (bins[256 + b] != 0.0 && emin < 0) emin = b;
+        if (bins[NB + b] != 0.0 && emin < 0) emin = b;
     }
-    gstat[0] = emax < 0 ? 0u : ((uint32_t)emax << 23) | (emax == 255 ? 1u : 0u);
-    gstat[1] = emin < 0 ? 0u : ~((uint32_t)emin << 23);
-    gstat[2] = bins[512] != 0.0 ? 1u : 0u;
+    gstat[0] = emax < 0 ? 0u : ((uint32_t)emax << SH) | (emax == NB - 1 ? 1u : 0u);
+    gstat[1] = emin < 0 ? 0u : ~((uint32_t)emin << SH);
+    gstat[2] = bins[2 * NB] != 0.0 ? 1u : 0u;
 }
 
 template <typename VT>
 __global__ __launch_bounds__(kBucketThreads) void k_bucket(const int64_t* __restrict__ rm_ptr, const GramPk<VT>* __restrict__ rm,
                                                            uint64_t n_rows, uint32_t rblk, int k, int sr_shift, int n_wg, int n_stripes,
                                                            const int64_t* __restrict__ rec_base, uint32_t* __restrict__ boff,
-                                                           GramRec<VT>* __restrict__ recs, uint32_t* __restrict__ gstat /* gram_stat(): f32 only */) {
+                                                           GramRec<VT>* __restrict__ recs, uint32_t* __restrict__ gstat /* gram_stat() */) {
     extern __shared__ double lds_raw[];
     __shared__ uint32_t s_stat[3];
     if (threadIdx.x < 3) s_stat[threadIdx.x] = 0u;
@@ -165,24 +181,23 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket(const int64_t* __rest
     walk([&](uint32_t p, int j, VT v, uint32_t end) {
         __hip_atomic_fetch_add(&hist[gram_owner(j, sr_shift, n_wg, n_stripes)], (end - p + 63u) >> 6, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
-        if constexpr (sizeof(VT) == 4) {        // (a stored zero makes the smallest |v| zero: the range test fails, the f64 mode runs)
-            const uint32_t b = __float_as_uint(v), ab = b & 0x7fffffffu;
+        {                                       // (a stored zero makes the smallest |v| zero: the range test fails, the f64 atomics run)
+            uint32_t b;                             // f64 entries: the high word (sign, exponent, 20 mantissa bits)
+            if constexpr (sizeof(VT) == 4) b = __float_as_uint(v);
+            else b = (uint32_t)((unsigned long long)__double_as_longlong(v) >> 32);
+            const uint32_t ab = b & 0x7fffffffu;
             vmax_b = ab > vmax_b ? ab : vmax_b;
             vmin_nb = ~ab > vmin_nb ? ~ab : vmin_nb;
             neg |= b;
         }
     });
-    if constexpr (sizeof(VT) == 4) {
-        if (vmax_b) atomicMax(&s_stat[0], vmax_b);
-        if (vmin_nb) atomicMax(&s_stat[1], vmin_nb);
-        if (neg >> 31) atomicOr(&s_stat[2], 1u);
-    }
+    if (vmax_b) atomicMax(&s_stat[0], vmax_b);
+    if (vmin_nb) atomicMax(&s_stat[1], vmin_nb);
+    if (neg >> 31) atomicOr(&s_stat[2], 1u);
     __syncthreads();
-    if constexpr (sizeof(VT) == 4) {
-        if (threadIdx.x < 3 && gstat && s_stat[threadIdx.x]) {
-            if (threadIdx.x == 2) atomicOr(&gstat[2], 1u);
-            else atomicMax(&gstat[threadIdx.x], s_stat[threadIdx.x]);
-        }
+    if (threadIdx.x < 3 && gstat && s_stat[threadIdx.x]) {
+        if (threadIdx.x == 2) atomicOr(&gstat[2], 1u);
+        else atomicMax(&gstat[threadIdx.x], s_stat[threadIdx.x]);
     }
     // exclusive scan of the n_wg counters by wave 0, 64 at a time
     if (wave == 0) {
@@ -272,16 +287,16 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     // Integer sums do not depend on the order the atomics land in.  Otherwise (negative values, a wide range, f64 entries): f32
     // products converted to f64, `ds_add_f64`, as before.
     bool fx = false;
-    float fx_scale = 1.f;
+    VT fx_scale = (VT)1;
     double fx_inv = 1.0;
-    if constexpr (sizeof(VT) == 4) {
-        if (gstat) {
-            int kq;
-            if (gram_fixed_point_mode(gstat[0], gstat[1], gstat[2], kq)) {
-                fx = true;
-                fx_scale = __uint_as_float((uint32_t)(kq + 127) << 23);
-                fx_inv = __longlong_as_double((long long)(1023 - kq) << 52);
-            }
+    if (gstat) {
+        int kq;
+        const bool ok = sizeof(VT) == 4 ? gram_fixed_point_mode(gstat[0], gstat[1], gstat[2], kq)
+                                        : gram_fixed_point_mode64(gstat[0], gstat[1], gstat[2], kq);
+        if (ok) {
+            fx = true;
+            fx_scale = (VT)__longlong_as_double((long long)(1023 + kq) << 52);      // 2^kq (exact in either type)
+            fx_inv = __longlong_as_double((long long)(1023 - kq) << 52);
         }
     }
     // Workgroup = (owner w, chunk z of n_chunk consecutive row blocks); blockIdx = z * n_wg + w, so the dispatcher starts
@@ -332,9 +347,7 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
         sl.n = i0 < cur.n ? (cur.n - i0 < (uint32_t)kWave ? cur.n - i0 : (uint32_t)kWave) : 0u;
         sl.r = Rec{0u, 0u, (VT)0};
         if ((uint32_t)lane < sl.n) sl.r = cur.rc[i0 + lane];
-        if constexpr (sizeof(VT) == 4) {
-            if (fx) sl.r.va *= fx_scale;          // (a power of two: exact; once per 64 records)
-        }
+        if (fx) sl.r.va *= fx_scale;              // (a power of two: exact; once per 64 records)
         i0 += kWave;
         return sl;
     };
@@ -358,14 +371,25 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
         }
         return l;
     };
-    auto process = [&](const Loaded& l) {
+    auto process = [&](const Loaded& l, auto fxc) {
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             double* const row = reinterpret_cast<double*>(reinterpret_cast<char*>(acc) + ((int)l.lenrb[u] >> 8));      // (signed: a row base may be negative)
             const uint32_t len = l.lenrb[u] & 0xffu;
-            if ((uint32_t)lane < len)
-                __hip_atomic_fetch_add(row + l.e[u].j, gram_product(l.va[u], l.e[u].v), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((uint32_t)lane < len) {
+                if constexpr (decltype(fxc)::value && sizeof(VT) == 8) {
+                    // va carries 2^kq: the product rounded to an integer by the 1.5 x 2^52 constant (0 <= p 2^kq < 2^47), its bits minus
+                    // the constant's = the integer; ds_add_u64 runs at 1.9x the rate of ds_add_f64
+                    const double kMagic = 6755399441055744.0;
+                    const unsigned long long bits =
+                        (unsigned long long)__double_as_longlong(__builtin_fma((double)l.va[u], (double)l.e[u].v, kMagic)) - 0x4338000000000000ull;
+                    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(row) + l.e[u].j, bits, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    __hip_atomic_fetch_add(row + l.e[u].j, gram_product(l.va[u], l.e[u].v), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
         }
     };
     // All batches of slab `sl`, two in flight (ping-pong between two register sets: a `now = next` copy makes the compiler
@@ -457,9 +481,9 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
                 // no branch around a batch's loads (slots past n are empty records, their loads hit the block's first line):
                 // after a conditional load the compiler's wait for A's entries also waits for B's
                 B = batch(sl, u0 + kUnroll);
-                process(A);
+                process(A, fxc);
                 if (u0 + 2 * kUnroll < kWave) A = batch(sl, u0 + 2 * kUnroll);
-                process(B);
+                process(B, fxc);
                 if (u0 + 2 * kUnroll >= n) break;
             }
         }

@@ -391,9 +391,9 @@ int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce) 
     const int h = g.n_wg / 2;
     const bool split = reduce && comm_is_rccl(ctx) && (ctx->n_ranks > 1 || force_split) && h >= 1 && g.n_wg - h >= 1;
     const bool empty = rm.n_rows == 0;
-    // (f32 entries, sharded rows: the accumulation mode is decided from the statistics of ALL ranks — one small all-reduce that a
-    //  rank without rows makes too, below)
-    const bool stat_exchange = sizeof(VT) == 4 && reduce && ctx->n_ranks > 1;
+    // (sharded rows: the accumulation mode is decided from the statistics of ALL ranks — one small all-reduce that a rank without
+    //  rows makes too, below)
+    const bool stat_exchange = reduce && ctx->n_ranks > 1;
     if (empty && !split && !stat_exchange) return SRX_OK;
     uint32_t* boff = nullptr;
     int64_t *blk_total = nullptr, *rec_base = nullptr;
@@ -424,18 +424,20 @@ int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce) 
                            reinterpret_cast<uint32_t*>(rec_base + g.n_rblk + 2));
         SRX_HIP(ctx, hipGetLastError());
     }
-    // Sharded rows, f32 entries: the fixed-point / f64 decision from the statistics of ALL ranks' compacted values (one more
-    // all-reduce of 513 doubles; an empty rank takes part with nothing marked).  Only where every rank is known to make the
+    // Sharded rows: the fixed-point / f64 decision from the statistics of ALL ranks' compacted values (one more all-reduce of
+    // 513 doubles — 4097 for f64 entries; an empty rank takes part with nothing marked).  Only where every rank is known to make the
     // same number of calls — the resident solve (`reduce` given); a backed session's tiles decide per tile (their number may
     // differ between the ranks; the sums of two modes differ by the fixed-point quantum).
     if (stat_exchange) {
+        constexpr int EB = sizeof(VT) == 4 ? 8 : 11;             // exponent bits of the statistics words (f64 entries: high words)
+        constexpr int n_bins = gstat_bins<EB>();
         double* bins = nullptr;
-        SRX_TRY(scratch(ctx, "pca_gstat_bins", kGstatBins * sizeof(double), (void**)&bins));
-        SRX_HIP(ctx, hipMemsetAsync(bins, 0, kGstatBins * sizeof(double), ctx->stream));
+        SRX_TRY(scratch(ctx, "pca_gstat_bins", gstat_bins<11>() * sizeof(double), (void**)&bins));
+        SRX_HIP(ctx, hipMemsetAsync(bins, 0, n_bins * sizeof(double), ctx->stream));
         uint32_t* gs = empty ? nullptr : reinterpret_cast<uint32_t*>(rec_base + g.n_rblk + 2);
-        if (gs) hipLaunchKernelGGL(k_gstat_onehot, dim3(1), dim3(64), 0, ctx->stream, (const uint32_t*)gs, bins);
-        SRX_TRY(allreduce_f64(ctx, bins, kGstatBins));
-        if (gs) hipLaunchKernelGGL(k_gstat_decode, dim3(1), dim3(64), 0, ctx->stream, (const double*)bins, gs);
+        if (gs) hipLaunchKernelGGL(k_gstat_onehot<EB>, dim3(1), dim3(64), 0, ctx->stream, (const uint32_t*)gs, bins);
+        SRX_TRY(allreduce_f64(ctx, bins, n_bins));
+        if (gs) hipLaunchKernelGGL(k_gstat_decode<EB>, dim3(1), dim3(64), 0, ctx->stream, (const double*)bins, gs);
         SRX_HIP(ctx, hipGetLastError());
     }
     if (empty && !split) return SRX_OK;
@@ -509,7 +511,7 @@ extern "C" int32_t srx_gram_mode_info(srx_ctx* ctx, int32_t* mode_out) {
     uint32_t w[3] = {0, 0, 0};
     SRX_TRY(d2h(ctx, w, ctx->gram_mode_word, sizeof w));
     int kq;
-    *mode_out = ctx->gram_mode_f32 && gram_fixed_point_mode(w[0], w[1], w[2], kq) ? 2 : 1;
+    *mode_out = (ctx->gram_mode_f32 ? gram_fixed_point_mode(w[0], w[1], w[2], kq) : gram_fixed_point_mode64(w[0], w[1], w[2], kq)) ? 2 : 1;
     return SRX_OK;
 }
 

@@ -371,18 +371,26 @@ def test_gram_record_piece_and_pair_boundaries(ctx, store, values):
     _ffi.check(_ffi.lib().srx_spmm(a.x().handle, _ffi.ptr(sel), k, _ffi.ptr(P), _ffi.ptr(y), _ffi.ptr(t), _ffi.ptr(gram)), ctx.handle)
     want = (x.T @ x).toarray()
     if values == "fractions":
-        # f32 products (2^-24 of each) at store 1, f64 products at store 2; the sums themselves are exact (integers / f64)
-        np.testing.assert_allclose(gram, want, rtol=2e-7 if store == 1 else 1e-14, atol=0)
+        # f32 products (2^-24 of each) at store 1; at store 2 f64 products rounded to the fixed-point quantum (round 5: values
+        # below 16, kq = 39: half a unit = 2^-40 per product); the sums themselves are exact (integers)
+        nzp = (x != 0).astype(np.float64)
+        count = (nzp.T @ nzp).toarray()
+        if store == 1:
+            np.testing.assert_allclose(gram, want, rtol=2e-7, atol=0)
+        else:
+            assert (np.abs(gram - want) <= count * 2.0 ** -40 + 1e-14 * np.abs(want)).all()
     else:
         assert np.array_equal(gram, want)
 
 
 @pytest.mark.gpu
-def test_fixed_point_gram_sums_do_not_depend_on_the_order_of_the_atomics(ctx):
-    """f32 entries, non-negative non-integer values of bounded range: the stripe kernel adds fixed-point products with INTEGER LDS
-    atomics, so a workgroup's sums do not depend on the order its atomics land in.  With one chunk of cells per owner (<= 16 384
-    cells: every entry of G receives exactly one global addition) repeated launches must agree to the last bit — with f64 atomics
-    they differ in the last bits from run to run."""
+@pytest.mark.parametrize("store", [1, 2])
+def test_fixed_point_gram_sums_do_not_depend_on_the_order_of_the_atomics(ctx, store):
+    """Non-negative non-integer values of bounded range: the stripe kernel adds fixed-point products with INTEGER LDS atomics (f32
+    entries: products scaled below 2^31; f64 entries, round 5: below 2^47 through the 1.5 x 2^52 constant), so a workgroup's sums
+    do not depend on the order its atomics land in.  With one chunk of cells per owner (<= 16 384 cells: every entry of G
+    receives exactly one global addition) repeated launches must agree to the last bit — with f64 atomics they differ in the
+    last bits from run to run."""
     from singlerust_amd import _ffi
     import singlerust_amd as sr
     import scipy.sparse as sp
@@ -391,7 +399,7 @@ def test_fixed_point_gram_sums_do_not_depend_on_the_order_of_the_atomics(ctx):
     x = sp.random(n, g, density=0.08, random_state=11, format="csr", dtype=np.float64,
                   data_rvs=lambda s: np.float32(rng.uniform(0.8, 9.0, s)).astype(np.float64))
     x.sort_indices()
-    a = sr.IMAnnData.new_basic(x, ctx=ctx, store=1)
+    a = sr.IMAnnData.new_basic(x, ctx=ctx, store=store)
     sel = np.sort(rng.choice(g, k, replace=False)).astype(np.uint64)
     P = rng.standard_normal((k, 64))
     grams = []
@@ -399,9 +407,13 @@ def test_fixed_point_gram_sums_do_not_depend_on_the_order_of_the_atomics(ctx):
         y, t, gram = np.zeros((n, 64)), np.zeros((k, 64)), np.zeros((k, k))
         _ffi.check(_ffi.lib().srx_spmm(a.x().handle, _ffi.ptr(sel), k, _ffi.ptr(P), _ffi.ptr(y), _ffi.ptr(t), _ffi.ptr(gram)), ctx.handle)
         grams.append(gram)
+    mode = C.c_int32(0)
+    _ffi.check(_ffi.lib().srx_gram_mode_info(ctx.handle, C.byref(mode)), ctx.handle)
+    assert mode.value == 2
     assert np.array_equal(grams[0], grams[1]) and np.array_equal(grams[0], grams[2])
     A = x[:, sel.astype(np.int64)]
-    np.testing.assert_allclose(grams[0], (A.T @ A).toarray(), rtol=3e-7, atol=1e-6)
+    # f64 entries: half a unit = 2^-48 of the largest possible product per product (values < 16: products < 2^8, kq = 39)
+    np.testing.assert_allclose(grams[0], (A.T @ A).toarray(), rtol=3e-7 if store == 1 else 1e-13, atol=1e-6 if store == 1 else 1e-9)
 
 
 def gram_of(ctx, x, store):
@@ -428,7 +440,9 @@ def test_gram_mode_switch_at_its_boundaries(ctx, case, want_mode):
     Each case sits on one side of one of those tests — an exponent spread of exactly 6 and of exactly 7, a single negative
     value among 40 000, a single STORED zero, a largest exponent outside the +-48 the scale factor is built for — with values
     that are powers of two times small integers, so that X^T X is exact in EITHER mode: the mode must be the one stated and the
-    result must equal scipy's to the bit.  f64 storage runs the same cases through the f64 kernel (mode 1 always)."""
+    result must equal scipy's to the bit.  f64 storage runs the same cases through the f64 kernel, which takes the same
+    decision on the high words of the doubles (round 5): the same mode, except where f64's wider exponent range admits what
+    f32's scale factor does not ("huge" / "tiny": exponents +-50 are inside f64's +-200)."""
     import scipy.sparse as sp
     rng = np.random.default_rng(17)
     n, g = 3000, 160
@@ -450,7 +464,9 @@ def test_gram_mode_switch_at_its_boundaries(ctx, case, want_mode):
     assert mode == want_mode, (case, mode)
     assert np.array_equal(got, want), case
     got64, mode64 = gram_of(ctx, x, 2)
-    assert mode64 == 1 and np.array_equal(got64, want)
+    want_mode64 = 2 if case in ("huge", "tiny") else want_mode
+    assert mode64 == want_mode64, (case, mode64)
+    assert np.array_equal(got64, want)
 
 
 @pytest.mark.gpu
