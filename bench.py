@@ -920,6 +920,23 @@ def main():
                     "noconv_steps": r["noconv_steps"]}
         attempt("hard_spectrum", f_hard)
 
+        def f_budget():
+            # The shard one rank holds at P = 2 / 4 / 8 ranks (the first n / P cells), timed here on ONE GPU without communication:
+            # the measured input of the strong-scaling prediction — the sharded kernels shrink with 1 / P, the
+            # replicated part (selection, the k x 64 iteration, launch gaps) does not.  NOT a multi-GPU measurement.
+            out = {"note": "per-rank compute of the shard a rank holds at P ranks, on one GPU, no communication; predicted_speedup adds "
+                           "exchange_ms (moments 0.05 + the exposed half of the 16 MB Gram ring at ~77 GB/s per direction + one host "
+                           "read) and divides the 1-GPU step by the sum: a budget, not a measurement"}
+            for P in (2, 4, 8):
+                n_p = n_global // P
+                r = B.run(a.config, n_global, 0, n_p, a.storage, 5, 2, solver=a.solver)
+                per, _ = attributed(r["prof"], 5)
+                exch = 0.05 + (P - 1) / P * 16.0e6 * 0.5 / 77e9 * 1e3 + 0.03
+                out[str(P)] = {"cells": n_p, "ms_per_step": r["ms_per_step"], "iterate_ms": per.get("iterate"),
+                               "exchange_ms": exch, "predicted_speedup": main_["ms_per_step"] / (r["ms_per_step"] + exch)}
+            return out
+        attempt("strong_scaling_budget", f_budget)
+
         if not a.no_cpu_baseline:
             # the host-side legs at the metric's configuration in FULL (--host-sample-cells 0, the default): the whole matrix
             # in the reference layout on the host — H2D-inclusive rate from pinned and from pageable caller buffers, the
@@ -1033,6 +1050,8 @@ def main():
                 "gram_formation_ms_per_step": gram_stage["ms_per_step"],
                 "gram_formation_traffic_over_alg": gram_stage["traffic_over_alg"],
                 "iterate_ms_per_step": per.get("iterate"),
+                "predicted_speedup_8_gpus": ((extra.get("strong_scaling_budget") or {}).get("8") or {}).get("predicted_speedup"),
+                "shard_step_ms_at_8_ranks": ((extra.get("strong_scaling_budget") or {}).get("8") or {}).get("ms_per_step"),
                 "scaling_note": ("one GPU: `scaling` carries the label the same command gives at N > 1 (strong: BASELINE.json "
                                  "configs[3], the same cells row-sharded), so that the per-N lines of a scaling run read alike"
                                  if world == 1 else None),
