@@ -225,9 +225,20 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket(const int64_t* __rest
         const uint32_t len = end - p, nch = (len + 63u) >> 6;
         uint32_t slot = __hip_atomic_fetch_add(&hist[gram_owner(j, sr_shift, n_wg, n_stripes)], nch, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t rb8 = (uint32_t)gram_row_base(j, k, sr_shift, n_wg, n_stripes) << 11;      // BYTE offset of the row's accumulators (x 8, signed), above the length byte
-        for (uint32_t o = 0; o < len; o += kWave, ++slot)
-            rcb[slot] = GramRec<VT>{p + o, (len - o < (uint32_t)kWave ? len - o : (uint32_t)kWave) | rb8, v};
+        if constexpr (sizeof(VT) == 4) {
+            // f32 entries (round 5): the record in the form the stripe kernel's scalar unit consumes it — the piece's BYTE offset in the
+            // block, and n0 | n1 << 6 | row base << 12: n0 / n1 = the lanes of a HALF wave whose first / second entry lies inside the
+            // piece (lane l of a half takes entries 2 l and 2 l + 1), the row's accumulators as a signed byte offset
+            const uint32_t rb = (uint32_t)gram_row_base(j, k, sr_shift, n_wg, n_stripes) << 15;      // (x 8 bytes, above the 12 count bits)
+            for (uint32_t o = 0; o < len; o += kWave, ++slot) {
+                const uint32_t L = len - o < (uint32_t)kWave ? len - o : (uint32_t)kWave;
+                rcb[slot] = GramRec<VT>{(p + o) * 8u, ((L + 1u) >> 1) | ((L >> 1) << 6) | rb, v};
+            }
+        } else {
+            const uint32_t rb8 = (uint32_t)gram_row_base(j, k, sr_shift, n_wg, n_stripes) << 11;      // BYTE offset of the row's accumulators (x 8, signed), above the length byte
+            for (uint32_t o = 0; o < len; o += kWave, ++slot)
+                rcb[slot] = GramRec<VT>{p + o, (len - o < (uint32_t)kWave ? len - o : (uint32_t)kWave) | rb8, v};
+        }
     });
 }
 
@@ -334,6 +345,7 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
         Rec r;
         uint32_t n;
         const Entry* rmb;
+        unsigned long long base;          // rmb, made wave-uniform for the compiler (v_readfirstlane: once per slab)
     };
     auto next_slab = [&]() -> Slab {
         while (i0 >= cur.n && rb < rb1) {
@@ -344,6 +356,11 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
         }
         Slab sl;
         sl.rmb = cur.rmb;
+        {
+            const unsigned long long bp = (unsigned long long)reinterpret_cast<uintptr_t>(cur.rmb);
+            sl.base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bp >> 32)) << 32) |
+                      (unsigned)__builtin_amdgcn_readfirstlane((int)(bp & 0xffffffffull));
+        }
         sl.n = i0 < cur.n ? (cur.n - i0 < (uint32_t)kWave ? cur.n - i0 : (uint32_t)kWave) : 0u;
         sl.r = Rec{0u, 0u, (VT)0};
         if ((uint32_t)lane < sl.n) sl.r = cur.rc[i0 + lane];
@@ -406,55 +423,134 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     constexpr bool kPair = sizeof(VT) == 4;
     constexpr int kL = kUnroll / 2;                  // load instructions of a batch of kUnroll records
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-    struct LoadedP {
+    struct LoadedP {                                 // the two records of each load as SCALARS (v_readlane results), the loaded entries
         u4 raw[kL];                                  // (j, v) of entries 2 l and 2 l + 1 of the lane's record
-        uint32_t lenrb[kL];                          // per lane: its record's length and row base ...
-        VT va[kL];                                   // ... and value (selected once, when the load is issued)
+        uint32_t lrA[kL], lrB[kL];                   // n0 | n1 << 6 | row base (bytes) << 12 of the record of lanes 0-31 / 32-63
+        uint32_t vaA[kL], vaB[kL];                   // the records' values (bit patterns)
     };
     const bool hi = lane >= 32;
-    const uint32_t l2 = (uint32_t)(lane & 31) * 2u;
+    const uint32_t l16 = (uint32_t)(lane & 31) * 16u;        // a lane's byte offset inside its record's piece
+    auto va_word = [](VT v) -> int {
+        if constexpr (sizeof(VT) == 4) return __builtin_bit_cast(int, v);
+        else return 0;                                       // (the pair path is the f32 one)
+    };
+    // Round 5: the delivery of a record's fields to its half of the wave is gone.  Until then every field (position, counts | row
+    // base, value) went from two v_readlane results through two v_mov and a v_cndmask into a per-lane register — a VOP3 takes ONE
+    // scalar operand and the lane mask is one — and the clamp of the lanes past a piece's end, the 64-bit address and the two
+    // `lane < count` compares were VALU work too: 28.6 VALU instructions per load, VALU 100 % busy (profiles/r05_pmc_gram.md).
+    // Now the CONSUMERS run once per half with the half's scalars as operands and the lane masks come from the scalar unit:
+    // exec = s_bfm_b64(count, 0 | 32) — the lanes of a half whose entry exists; the load is issued for exactly those lanes (no clamp,
+    // no compare), a product is v_fma_f32(s_va, v_b, 0.5) -> v_cvt_u32 -> v_lshl_add(v_j, 3, s_row) -> ds_add_u64.  2 + 13 VALU and
+    // ~18 scalar instructions per load beside the six v_readlane.  Inline assembly: the compiler turns every per-half choice back
+    // into selects.  The loads are invisible to its wait counting, so the waits are explicit: vmcnt(after + kL - 1 - u) for load u
+    // of a set, `after` = the loads issued since that set's (the other set's kL, or none behind a slab's last set; memory reads
+    // return in order; the compiler's own waits — for a slab's records — can only come out too strict, not too lax).
     auto batchP = [&](const Slab& sl, int u0) -> LoadedP {
         LoadedP l;
+        const unsigned long long base = sl.base;     // (the block's first entry as a SCALAR pair: the load's saddr operand)
+      if constexpr (kPair) {                           // (f32 entries only: this lambda is instantiated for f64 too)
+        static_assert(kL == 4, "the load block below is written for four loads");
+        uint32_t pA[kL], pB[kL];
 #pragma unroll
-        for (int u = 0; u < kL; ++u) {               // lanes past sl.n hold empty records: len 0, pos 0
-            const uint32_t posA = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.pos, u0 + 2 * u);
-            const uint32_t posB = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.pos, u0 + 2 * u + 1);
-            const uint32_t lrA = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.lenrb, u0 + 2 * u);
-            const uint32_t lrB = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.lenrb, u0 + 2 * u + 1);
-            const VT vaA = readlane_v(sl.r.va, u0 + 2 * u), vaB = readlane_v(sl.r.va, u0 + 2 * u + 1);
-            const uint32_t pos = hi ? posB : posA;
-            l.lenrb[u] = hi ? lrB : lrA;
-            l.va[u] = hi ? vaB : vaA;
-            const uint32_t len = l.lenrb[u] & 0xffu;
-            const uint32_t off = l2 < len ? l2 : 0u;
-            l.raw[u] = *reinterpret_cast<const u4*>(reinterpret_cast<const char*>(sl.rmb) + (size_t)((pos + off) * 8u));      // (32-bit: a block holds at most rblk x k = 512 x 16384 = 2^23 entries — gram_plan checks; the 64-bit multiply spilled 56 VGPRs)
+        for (int u = 0; u < kL; ++u) {               // lanes past sl.n hold empty records: counts 0, position 0
+            pA[u] = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.pos, u0 + 2 * u);
+            pB[u] = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.pos, u0 + 2 * u + 1);
+            l.lrA[u] = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.lenrb, u0 + 2 * u);
+            l.lrB[u] = (uint32_t)__builtin_amdgcn_readlane((int)sl.r.lenrb, u0 + 2 * u + 1);
+            l.vaA[u] = (uint32_t)__builtin_amdgcn_readlane(va_word(sl.r.va), u0 + 2 * u);
+            l.vaB[u] = (uint32_t)__builtin_amdgcn_readlane(va_word(sl.r.va), u0 + 2 * u + 1);
         }
+        // (s_bfm_b64 takes its width from bits 0-5 of the operand: n0 sits there, no extraction; one block for the four loads: one
+        //  restore of exec)
+        uint32_t off;
+        unsigned long long m;
+#define SRX_GRAM_LOAD(U)                                                           \
+        "s_bfm_b64 %[m], %[lrA" U "], 0\n\t"                                       \
+        "s_mov_b64 exec, %[m]\n\t"                                                 \
+        "v_add_u32 %[off], %[pA" U "], %[l16]\n\t"                                  \
+        "s_bfm_b64 exec, %[lrB" U "], 32\n\t"                                      \
+        "v_add_u32 %[off], %[pB" U "], %[l16]\n\t"                                  \
+        "s_or_b64 exec, exec, %[m]\n\t"                                            \
+        "global_load_dwordx4 %[raw" U "], %[off], %[base]\n\t"
+        asm volatile(SRX_GRAM_LOAD("0") SRX_GRAM_LOAD("1") SRX_GRAM_LOAD("2") SRX_GRAM_LOAD("3") "s_mov_b64 exec, -1"
+                     : [raw0] "=&v"(l.raw[0]), [raw1] "=&v"(l.raw[1]), [raw2] "=&v"(l.raw[2]), [raw3] "=&v"(l.raw[3]), [off] "=&v"(off),
+                       [m] "=&s"(m)
+                     : [lrA0] "s"(l.lrA[0]), [lrB0] "s"(l.lrB[0]), [pA0] "s"(pA[0]), [pB0] "s"(pB[0]), [lrA1] "s"(l.lrA[1]),
+                       [lrB1] "s"(l.lrB[1]), [pA1] "s"(pA[1]), [pB1] "s"(pB[1]), [lrA2] "s"(l.lrA[2]), [lrB2] "s"(l.lrB[2]),
+                       [pA2] "s"(pA[2]), [pB2] "s"(pB[2]), [lrA3] "s"(l.lrA[3]), [lrB3] "s"(l.lrB[3]), [pA3] "s"(pA[3]),
+                       [pB3] "s"(pB[3]), [l16] "v"(l16), [base] "s"(base)
+                     : "memory");
+#undef SRX_GRAM_LOAD
+      }
         return l;
     };
-    auto processP = [&](const LoadedP& l, auto fxc) {
+    auto processP = [&](const LoadedP& l, auto fxc, auto after) {
+        constexpr int kAfter = decltype(after)::value;
+        if constexpr (decltype(fxc)::value) {
+            // The two HALVES of the wave run the product and the LDS address with their own record's scalars as operands (exec = the
+            // half's lanes whose entry exists: s_bfm_b64 on the count the record carries); they write disjoint lanes of the same two
+            // registers, and the conversion and the LDS atomic are then issued ONCE for both halves — an LDS atomic costs the pipe its
+            // issue whatever the number of active lanes (a first version with one atomic per half doubled SQ_INSTS_LDS and ran at
+            // 2.97 ms against the compiler's 2.73: profiles/r05_knockouts.md).  v62 / v63: the 64-bit addend (the product's integer,
+            // zero above it) — fixed registers because inline assembly cannot name the halves of a 64-bit operand.
+#define SRX_GRAM_ENTRY(VAA, VAB, J, B, NA, NB)                                     \
+            NA                                                                     \
+            "s_mov_b64 exec, %[m]\n\t"                                             \
+            "v_fma_f32 v62, %[" VAA "], %[" B "], 0.5\n\t"                         \
+            "v_lshl_add_u32 %[a], %[" J "], 3, %[rowA]\n\t"                       \
+            NB                                                                     \
+            "v_fma_f32 v62, %[" VAB "], %[" B "], 0.5\n\t"                         \
+            "v_lshl_add_u32 %[a], %[" J "], 3, %[rowB]\n\t"                       \
+            "s_or_b64 exec, exec, %[m]\n\t"                                        \
+            "v_cvt_u32_f32 v62, v62\n\t"                                          \
+            "ds_add_u64 %[a], v[62:63]\n\t"
+#define SRX_GRAM_LOADP(LRA, LRB, VAA, VAB, J0, B0, J1, B1)                          \
+            "s_ashr_i32 %[rowA], %[" LRA "], 12\n\t"                               \
+            "s_ashr_i32 %[rowB], %[" LRB "], 12\n\t"                               \
+            SRX_GRAM_ENTRY(VAA, VAB, J0, B0,                                       \
+                           "s_bfm_b64 %[m], %[" LRA "], 0\n\t",                    \
+                           "s_bfm_b64 exec, %[" LRB "], 32\n\t")                   \
+            SRX_GRAM_ENTRY(VAA, VAB, J1, B1,                                       \
+                           "s_lshr_b32 %[t], %[" LRA "], 6\n\ts_bfm_b64 %[m], %[t], 0\n\t",   \
+                           "s_lshr_b32 %[t], %[" LRB "], 6\n\ts_bfm_b64 exec, %[t], 32\n\t")
 #pragma unroll
-        for (int u = 0; u < kL; ++u) {
-            const uint32_t lenrb = l.lenrb[u];
-            const VT va = l.va[u];
-            char* const rowb = reinterpret_cast<char*>(acc) + ((int)lenrb >> 8);      // the record carries the row's byte offset (signed: column indices are absolute)
-            const uint32_t len = lenrb & 0xffu;
-            // (the components go through scalars: __builtin_bit_cast of a vector ELEMENT read component 0 for .y and .w alike)
-            const unsigned j0 = l.raw[u].x, b0 = l.raw[u].y, j1 = l.raw[u].z, b1 = l.raw[u].w;
-            if constexpr (decltype(fxc)::value) {
-                // (the row's address first: one shift-add per product instead of a shift and a three-operand add)
-                unsigned long long* const accu = reinterpret_cast<unsigned long long*>(rowb);
-                if (l2 < len)
-                    __hip_atomic_fetch_add(accu + (int)j0, (unsigned long long)(unsigned)(__builtin_fmaf((float)va, __uint_as_float(b0), 0.5f)),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (l2 + 1u < len)
-                    __hip_atomic_fetch_add(accu + (int)j1, (unsigned long long)(unsigned)(__builtin_fmaf((float)va, __uint_as_float(b1), 0.5f)),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else {
+            for (int u = 0; u < kL; u += 2) {
+                const unsigned j0 = l.raw[u].x, b0 = l.raw[u].y, j1 = l.raw[u].z, b1 = l.raw[u].w;
+                const unsigned j2 = l.raw[u + 1].x, b2 = l.raw[u + 1].y, j3 = l.raw[u + 1].z, b3 = l.raw[u + 1].w;
+                uint32_t a, t, rowA, rowB;
+                unsigned long long m;
+                asm volatile(
+                    "v_mov_b32 v63, 0\n\t"
+                    "s_waitcnt vmcnt(%[cnt0])\n\t"
+                    SRX_GRAM_LOADP("lrA0", "lrB0", "vaA0", "vaB0", "j0", "b0", "j1", "b1")
+                    "s_waitcnt vmcnt(%[cnt1])\n\t"
+                    SRX_GRAM_LOADP("lrA1", "lrB1", "vaA1", "vaB1", "j2", "b2", "j3", "b3")
+                    "s_mov_b64 exec, -1"
+                    : [a] "=&v"(a), [t] "=&s"(t), [rowA] "=&s"(rowA), [rowB] "=&s"(rowB), [m] "=&s"(m)
+                    : [lrA0] "s"(l.lrA[u]), [lrB0] "s"(l.lrB[u]), [vaA0] "s"(l.vaA[u]), [vaB0] "s"(l.vaB[u]), [lrA1] "s"(l.lrA[u + 1]),
+                      [lrB1] "s"(l.lrB[u + 1]), [vaA1] "s"(l.vaA[u + 1]), [vaB1] "s"(l.vaB[u + 1]), [j0] "v"(j0), [b0] "v"(b0), [j1] "v"(j1),
+                      [b1] "v"(b1), [j2] "v"(j2), [b2] "v"(b2), [j3] "v"(j3), [b3] "v"(b3), [cnt0] "n"(kAfter + kL - 1 - u),
+                      [cnt1] "n"(kAfter + kL - 2 - u)
+                    : "memory", "v62", "v63");
+            }
+#undef SRX_GRAM_LOADP
+#undef SRX_GRAM_ENTRY
+        } else {
+            // f64 atomics (a negative value, a wide range): the per-lane form, products converted to f64
+#pragma unroll
+            for (int u = 0; u < kL; ++u) {
+                u4 rw = l.raw[u];                    // (the wait names the registers it is for: nothing that reads them moves above it)
+                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rw) : "n"(kAfter + kL - 1 - u) : "memory");
+                const uint32_t lr = hi ? l.lrB[u] : l.lrA[u];
+                const VT va = __uint_as_float(hi ? l.vaB[u] : l.vaA[u]);
+                char* const rowb = reinterpret_cast<char*>(acc) + ((int)lr >> 12);
+                const uint32_t n0 = lr & 63u, n1 = (lr >> 6) & 63u, lh = (uint32_t)(lane & 31);
+                const unsigned j0 = rw.x, b0 = rw.y, j1 = rw.z, b1 = rw.w;
                 double* const accd = reinterpret_cast<double*>(rowb);
-                if (l2 < len)
+                if (lh < n0)
                     __hip_atomic_fetch_add(accd + (int)j0, gram_product(va, (VT)__uint_as_float(b0)), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (l2 + 1u < len)
+                if (lh < n1)
                     __hip_atomic_fetch_add(accd + (int)j1, gram_product(va, (VT)__uint_as_float(b1)), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -463,15 +559,31 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     auto consume = [&](const Slab& sl, Slab& other, auto fxc) {
         const int n = (int)sl.n;
         if constexpr (kPair) {
-            LoadedP A = batchP(sl, 0), B;
-            other = next_slab();
+            using LoadsAfter = std::integral_constant<int, kL>;
+            using NoneAfter = std::integral_constant<int, 0>;
+            if constexpr (decltype(fxc)::value) {
+                LoadedP A = batchP(sl, 0), B;
+                other = next_slab();
 #pragma unroll
-            for (int u0 = 0; u0 < kWave; u0 += 2 * kUnroll) {
-                B = batchP(sl, u0 + kUnroll);
-                processP(A, fxc);
-                if (u0 + 2 * kUnroll < kWave) A = batchP(sl, u0 + 2 * kUnroll);
-                processP(B, fxc);
-                if (u0 + 2 * kUnroll >= n) break;
+                for (int u0 = 0; u0 < kWave; u0 += 2 * kUnroll) {
+                    B = batchP(sl, u0 + kUnroll);
+                    processP(A, fxc, LoadsAfter{});
+                    if (u0 + 2 * kUnroll < kWave) {
+                        A = batchP(sl, u0 + 2 * kUnroll);
+                        processP(B, fxc, LoadsAfter{});
+                    } else {
+                        processP(B, fxc, NoneAfter{});
+                    }
+                    if (u0 + 2 * kUnroll >= n) break;
+                }
+            } else {
+                // (the f64-atomics form of the f32 kernel — a negative value, a wide range — takes one set of loads at a time: it is the
+                //  rare route, and two sets in flight beside the fixed-point route's cost the kernel a spilled register)
+                other = next_slab();
+                for (int u0 = 0; u0 < kWave && u0 < n; u0 += kUnroll) {
+                    LoadedP A = batchP(sl, u0);
+                    processP(A, fxc, NoneAfter{});
+                }
             }
         } else {
             Loaded A = batch(sl, 0), B;
