@@ -562,6 +562,43 @@ def test_pipeline_nan_variance_is_an_error(ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("store", [1, 2])
+def test_fixed_point_moments_range_boundary(ctx, store):
+    """The pipeline's gene moments are exact FIXED-POINT sums of y = ln_1p(v * scale) (62 bits for n_rows values below 64): a
+    transformed value at or beyond 64 — v * scale >= e^64 - 1 = 6.2e27, which a target_sum that large allows — poisons its gene and
+    the selection reports SRX_E_NAN (documented limit; the reference would carry the value).  Just below the
+    boundary (ln_1p = 63.8) the moments, the HVG list and the stored values are the oracle's."""
+    import singlerust_amd as sr
+    from singlerust_amd import _ffi
+    from singlerust_amd.memory import statistics as st
+    m, _ = synth_host(41, 400, 200, 0.1)
+    # cell 7 keeps ONE entry: its value is the whole row sum, so v * scale = target_sum exactly
+    ip = m.indptr.astype(np.int64)
+    keep = np.ones(len(m.values), bool)
+    keep[ip[7] + 1:ip[8]] = False
+    cnt = np.diff(ip)
+    cnt[7] = 1
+    m2 = oracle.Csr(m.n_rows, m.n_cols, np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64), m.indices[keep], m.values[keep])
+    opts = _ffi.PcaOpts(5, -1, -1, -1, 0, 0, 0, 0.0, 0)
+    res = _ffi.PipelineResult()
+    for target, ok in ((5.0e27, True), (7.0e27, False)):          # ln_1p: 63.78 / 64.11
+        a = adata_of(m2, ctx, store)
+        if ok:
+            _ffi.check(_ffi.lib().srx_pipeline(a.x().handle, target, 40, C.byref(opts), C.byref(res)), ctx.handle)
+            lg = oracle.log1p_transform(oracle.normalize_total(m2, target, ROW))
+            assert rel_err(a.x_values(np.float64), lg.values.astype(np.float64)) <= (1e-6 if store == 1 else 4e-16)
+            want_var = oracle.compute_variance(lg, COLUMN)
+            hv = np.zeros(int(res.pca.k), np.uint64)
+            _ffi.check(_ffi.lib().srx_result_fetch(a.x().handle, None, None, None, None, None, _ffi.ptr(hv)), ctx.handle)
+            assert np.array_equal(hv, oracle.select_hvg(want_var, 40))
+            assert np.allclose(st.compute_variance(a, sr.Direction.Column), want_var, rtol=1e-4 if store == 1 else 1e-11, atol=1e-12)
+        else:
+            with pytest.raises(sr.SrxError) as e:
+                _ffi.check(_ffi.lib().srx_pipeline(a.x().handle, target, 40, C.byref(opts), C.byref(res)), ctx.handle)
+            assert e.value.code == _ffi.E_NAN
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,g,hvg,npc,store", [
     (60, 40, 12, 3, 2),          # k < 64: the block is narrower than l
     (300, 170, 129, 5, 2),       # k just over one 128-tile
