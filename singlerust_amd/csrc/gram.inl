@@ -285,6 +285,12 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     const int WA = k - a0, WB = k - b0 > 0 ? k - b0 : 0;
     const int n_acc = SR * (WA + WB);
     for (int e = threadIdx.x; e < n_acc; e += blockDim.x) acc[e] = 0.0;
+    {
+        // the assembly core forms LDS addresses as (row base of the record) + 8 x column: the accumulators must start at LDS offset 0
+        // (they do: the kernel has no static shared memory); anything else must fail loudly, not add into the wrong words
+        typedef __attribute__((address_space(3))) double lds_double;
+        if ((uint32_t)(uintptr_t)(lds_double*)acc != 0u) __builtin_trap();
+    }
     __syncthreads();
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);

@@ -241,7 +241,11 @@ static int32_t graphed(srx_ctx* ctx, bool enable, const std::string& key, Fn&& e
 template <typename Apply>
 static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, const Resolved& o, Apply&& apply,
                                 const void* apply_id, bool graphable, const int* d_status_sel, double& resid, int& iters,
-                                bool& converged, bool acc_apply) {
+                                bool& converged, bool acc_apply, bool resume = false, bool* bailed_first = nullptr) {
+    // `resume`: the block is the one a one-round plan just left at its FIRST Ritz step (flat tail: `*bailed_first`), with the
+    // speculative first filter step already queued behind it — W, A2 = Ritz vectors, theta, A1 = Y1, Wp = C Y1, the Ritz tail's
+    // partial sums: everything this round's own start segment (start block, warm-up sweeps, first Ritz step: ~0.45 ms at k =
+    // 1000) would recompute, for the same 64-column block.  Only the step's scalars are re-made for this round's n_pc.
     // `acc_apply` (the Gram solver): `apply` ACCUMULATES into a zeroed destination and w.T is free.  The applications of a sweep
     // then rotate through three scratch blocks (Wp, A1, T), and the kernels that are the last to read a block leave it zeroed
     // (the CholeskyQR's substitution: all three; the Ritz tail: Wp; the filter step: its Z) — the eight memset launches a solve
@@ -472,15 +476,23 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     int q_applied = o.warm * o.power + 1;          // applications of C the block has seen (warm-up + first Ritz step)
     double r_last = INFINITY, rate_meas = 0.0;
     int sweeps_since = 0;
-    SRX_TRY(graphed(ctx, use_graph, key_base + "|start", seg_start));
+    if (bailed_first) *bailed_first = false;
+    if (resume) {
+        hipLaunchKernelGGL(k_resid_final, dim3(1), dim3(1024), 0, ctx->stream, (const double*)d_ritz, kRitzBlocks,
+                           (const double*)w.dTheta, o.n_pc, l_act, d_status, d_status_sel, w.dRho, w.dColmax, d_res + kSlotDoubles * slot);
+        SRX_HIP(ctx, hipGetLastError());
+    } else {
+        SRX_TRY(graphed(ctx, use_graph, key_base + "|start", seg_start));
+    }
     SRX_TRY(ritz_readback(slot));
     for (;;) {
         ++iters;
         ++n_ritz;
         const bool first = n_ritz == 1;
         const bool cheb = use_cheb;
-        if (cheb && first) SRX_TRY(graphed(ctx, use_graph, key_base + "|cheb0", cheb_spec));   // speculative: Y1, C Y1
-        else if (first && !o.direct) SRX_TRY(graphed(ctx, use_graph, key_base + "|adv", advance));   // speculative: completes this sweep
+        if (cheb && first) {
+            if (!resume) SRX_TRY(graphed(ctx, use_graph, key_base + "|cheb0", cheb_spec));   // speculative: Y1, C Y1 (resume: already there)
+        } else if (first && !o.direct) SRX_TRY(graphed(ctx, use_graph, key_base + "|adv", advance));   // speculative: completes this sweep
         double r, ratio;
         SRX_TRY(collect(slot, r, ratio));
         resid = r;
@@ -494,6 +506,7 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         if (iters >= o.max_iter) break;
         if (first && o.bail_ratio > 0.0 && ratio > o.bail_ratio) {
             if (getenv("SRX_PCA_TRACE")) fprintf(stderr, "[srx pca] flat tail (theta_l / theta_npc = %.3f): leaving the round to the safe plan\n", ratio);
+            if (bailed_first) *bailed_first = cheb;         // (the block and the queued first filter step are the next plan's to continue from)
             break;                                 // converged stays false
         }
         if (cheb) {
@@ -725,9 +738,10 @@ int32_t run_pca(srx_ctx* ctx, const RowMajor* parts, int n_parts, const Tiled* t
     // removes the eigenpairs a round has resolved (w.A2 / w.dTheta, leading n columns).  SRX_E_NOCONV (breakdown) or
     // converged == false (budget spent) leave the decision to the caller.
     const bool acc_apply = o.solver == 1;            // the dense application accumulates into a zeroed block; w.T is free
+    bool bailed_first = false;               // the last plan was left at its first Ritz step (flat tail) with its block intact
     auto run_plan = [&](const std::vector<int>& plan, int budget, bool robust, auto& apply, const void* apply_id, bool graphable,
-                        auto& reset, auto& deflate, double bail = 0.0) -> int32_t {
-        SRX_TRY(reset());
+                        auto& reset, auto& deflate, double bail = 0.0, bool resume = false) -> int32_t {
+        if (!resume) SRX_TRY(reset());      // (resume: nothing was deflated, C is as expanded)
         resid = 0.0;
         converged = true;
         iters = 0;
@@ -752,7 +766,7 @@ int32_t run_pca(srx_ctx* ctx, const RowMajor* parts, int n_parts, const Tiled* t
             {
                 ProfScope ps_it(ctx, SRX_K_ITERATE, (double)k * k * 8.0);
                 SRX_TRY(subspace_iterate(ctx, w, k, l_r, o_r, apply, apply_id, graphable, hv ? hv->d_status : nullptr, resid_r,
-                                         iters_r, conv_r, acc_apply));
+                                         iters_r, conv_r, acc_apply, resume && r == 0 && l_r == l_act, &bailed_first));
             }
             resid = std::max(resid, resid_r);
             iters += iters_r + o.warm;
@@ -786,8 +800,11 @@ int32_t run_pca(srx_ctx* ctx, const RowMajor* parts, int n_parts, const Tiled* t
                 fprintf(stderr, "[srx pca] plan A (%zu round(s)) %s at residual %.3e: rounds of <= %d components instead\n",
                         plan_a.size(), rc == SRX_OK ? "stalled" : "broke down", resid, plan_b[0]);
             const int spent = iters;
-            rc = run_plan(plan_b, o.max_iter, false, apply, apply_id, graphable, reset, deflate);
-            iters += spent;
+            // (left at the first Ritz step for its flat tail: the safe plan's first round continues from that block — the same 64
+            //  columns, the same warm-up and Ritz step it would redo from a new random start)
+            const bool resume = rc == SRX_OK && bailed_first && plan_a.size() == 1;
+            rc = run_plan(plan_b, o.max_iter, false, apply, apply_id, graphable, reset, deflate, 0.0, resume);
+            iters += resume ? 0 : spent;
         }
         if (rc == SRX_E_NOCONV) {
             // last resort: a block whose spectrum spans more than ~1e8 between two CholeskyQRs (small exact-rank
