@@ -214,3 +214,14 @@ def test_hot_kernels_do_not_spill_registers(tmp_path):
             spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", body).group(1))
             scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", body).group(1))
             assert spill == 0 and scratch == 0, f"{m.group(1)}: {spill} spilled VGPRs, {scratch} B of scratch"
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check (`__graft_entry__.build()`: compile every HIP source, build the oracle, import the package, compare
+    the library's ABI version with the header's) must pass on CPU — it once carried a literal version and would have failed the
+    round's build check after an ABI bump."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()
