@@ -723,6 +723,19 @@ __global__ void k_cheb_first(double* __restrict__ A1, const double* __restrict__
     const double a = 2.0 / cheb_b(theta, l_act);
     A1[e] = a * A1[e] - A2[e];
 }
+// A second filter straight behind a CholeskyQR, no Ritz step between (round 5): the block W is orthonormal, Z = C W; Y0 = W goes into
+// `prev`, Y1 = a Z - W into `cur`, Z is left zeroed — the state k_cheb_first leaves after a Ritz step, with W in the place of the
+// Ritz vectors (its columns still are, nearly: a filtered, re-orthonormalised set of Ritz vectors).
+__global__ void k_cheb_first2(double* __restrict__ Z, const double* __restrict__ W, double* __restrict__ cur, double* __restrict__ prev,
+                              const double* __restrict__ theta, int l_act, size_t n) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const double a = 2.0 / cheb_b(theta, l_act);
+    const double wv = W[e];
+    cur[e] = a * Z[e] - wv;
+    prev[e] = wv;
+    Z[e] = 0.0;
+}
 // prev <- 2 (a Z - cur) - prev   (Y_{j+1} from Z = C Y_j, Y_j, Y_{j-1})
 // (Z is left ZEROED: it is the destination of the next application of C, which accumulates into a zeroed block)
 __global__ void k_cheb_step(double* __restrict__ Z, const double* __restrict__ cur, double* __restrict__ prev,

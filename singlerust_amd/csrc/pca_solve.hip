@@ -446,8 +446,8 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         SRX_HIP(ctx, hipGetLastError());
         return apply(w.A1, w.Wp, acc_apply);          // (Gram solver: the Ritz tail left Wp zeroed)
     };
-    // the rest of a degree-d filter (Z = C Y1 is in Wp, cur = A1, prev = A2), CholeskyQR, Ritz step
-    auto cheb_rest = [&](int d, int slot) -> int32_t {
+    // the rest of a degree-d filter (Z = C Y1 is in Wp, cur = A1, prev = A2) and the CholeskyQR behind it
+    auto cheb_filter = [&](int d) -> int32_t {
         double *cur = w.A1, *prev = w.A2;
         for (int j = 1; j < d; ++j) {
             if (j > 1) SRX_TRY(apply(cur, w.Wp, true));          // (the step before left Wp zeroed)
@@ -459,7 +459,24 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         }
         hipLaunchKernelGGL(k_cheb_scale, dim3(cheb_grid), dim3(256), 0, ctx->stream, cur, (const double*)w.dTheta, l_act, d, kl);
         SRX_HIP(ctx, hipGetLastError());
-        SRX_TRY(orth(cur));
+        return orth(cur);
+    };
+    // ... then, where ONE filter of the degree the block can take will not reach the tolerance anyway (flat tails: theta_l / theta_npc
+    // = 0.97 gains 10x per degree-10 filter), a SECOND filter straight behind the CholeskyQR — C W, Y1 = a C W - W, C Y1, the
+    // recurrence, the CholeskyQR — and only then the Ritz step: the projected Gram product, the eigen-solve, the Ritz tail and a
+    // host decision less per pair of filters.  The bounds and the column scales are the last Ritz step's (the block still is that
+    // step's Ritz vectors, filtered and re-orthonormalised); the CholeskyQR between the two takes the leading directions out of
+    // the guard columns as a Ritz step would.
+    auto cheb_rest = [&](int d, int d2, int slot) -> int32_t {
+        SRX_TRY(cheb_filter(d));
+        if (d2 > 0) {
+            SRX_TRY(apply(w.W, w.Wp, acc_apply));                // (Gram solver: the CholeskyQR left Wp, A1, T zeroed)
+            hipLaunchKernelGGL(k_cheb_first2, dim3(cheb_grid), dim3(256), 0, ctx->stream, w.Wp, (const double*)w.W, w.A1, w.A2,
+                               (const double*)w.dTheta, l_act, kl);
+            SRX_HIP(ctx, hipGetLastError());
+            SRX_TRY(apply(w.A1, w.Wp, true));
+            SRX_TRY(cheb_filter(d2));
+        }
         return ritz_kernels(slot, false, true);          // (Wp: zeroed by the last filter step, untouched by the CholeskyQR)
     };
     // segment "next": [advance] + (m - 1) plain sweeps + a Ritz step into `slot`
@@ -531,17 +548,31 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
                 if (d > d_safe) d = d_safe;
             }
             if (d < 2) d = 2;
-            q_applied += d;                    // d - 1 applications in the filter + the one of the Ritz step
-            iters += (d + o.power - 1) / o.power;      // counted in sweep equivalents (max_iter bounds applications of C)
+            // the degree the tolerance asks for against the degree this filter may have: a second one behind it when one cannot do
+            int d2 = 0;
+            if (ta > 1.0) {
+                const int d_need = (int)std::ceil(std::acosh(std::max(4.0 * r / o.tol, 1.0)) / std::acosh(ta) - 1e-9);
+                if (d_need > d + 1) {
+                    const double t1 = 2.0 * (spread > 1.0 ? spread : 1.0) - 1.0;
+                    const int d_safe = t1 > 1.0 + 1e-9 ? (int)std::floor(32.9 / std::acosh(t1)) : 12;
+                    d2 = std::min(std::min(d_need - d, 12), std::min(d_safe, q_applied + d));
+                    if (d2 < 2) d2 = 0;
+                }
+            }
+            q_applied += d + d2;               // d - 1 (+ d2) applications in the filter(s) + the one of the Ritz step
+            iters += (d + d2 + o.power - 1) / o.power;      // counted in sweep equivalents (max_iter bounds applications of C)
             slot = (slot + 1) % kSlots;
             char kn[64];
-            snprintf(kn, sizeof kn, "|cheb f%d d%d s%d", first ? 1 : 0, d, slot);
+            snprintf(kn, sizeof kn, "|cheb f%d d%d e%d s%d", first ? 1 : 0, d, d2, slot);
             SRX_TRY(graphed(ctx, use_graph, key_base + kn, [&]() -> int32_t {
                 if (!first) SRX_TRY(cheb_spec());      // later rounds: nothing was queued speculatively
-                return cheb_rest(d, slot);
+                return cheb_rest(d, d2, slot);
             }));
             SRX_TRY(ritz_readback(slot));
-            if (getenv("SRX_PCA_TRACE")) fprintf(stderr, "[srx pca] Chebyshev filter of degree %d (t_a = %.3f)\n", d, ta);
+            if (getenv("SRX_PCA_TRACE")) {
+                if (d2) fprintf(stderr, "[srx pca] Chebyshev filters of degree %d and %d, a CholeskyQR between them (t_a = %.3f)\n", d, d2, ta);
+                else fprintf(stderr, "[srx pca] Chebyshev filter of degree %d (t_a = %.3f)\n", d, ta);
+            }
             r_last = INFINITY;                 // the filter's gain says nothing about the rate of plain sweeps
             sweeps_since = 0;
             continue;
