@@ -61,17 +61,19 @@ ROOF_NOTE = {
                    "bench_micro/l2_gather.hip: the one-suffix-per-load kernel of rounds 2-3, 1.0e8 loads, ran at exactly that rate, "
                    "3.89 ms); a load now serves two owner records (16 bytes per lane): 6.2e7 loads, 3.17 ms with ds_add_f64 (VALU 95 %, "
                    "LDS pipe 88 % busy), 2.81 ms with the products rounded to fixed point and added as 64-bit integers (LDS 53 %, VALU "
-                   "100 % busy: profiles/r04_pmc_gram.md)",
+                   "100 % busy: profiles/r04_pmc_gram.md), 2.66 ms since round 5 with the record fields as scalar operands and the lane "
+                   "masks from the scalar unit (inline assembly: 21 VALU + 18 scalar instructions per load instead of 28.6 + 6; no issue "
+                   "port is the wall any more, SQ_WAIT_ANY 30 %: profiles/r05_pmc_gram.md, r05_knockouts.md)",
     "gene_moments": "algorithmic bytes (SURVEY.md 8(d), fused normalise + log1p + moments): every non-zero's 16-bit index and f32 value read "
                     "once, the transformed value stored back in place (nnz * 10) + row pointers, gene-tile cuts and row sums.  What "
                     "bounds it: reading those 6.6 GB and writing 4.4 GB back takes 2.1-2.25 ms however the arrays are walked "
                     "(bench_micro/segment_read.hip: flat stream 2.11 ms, the kernel's (row block, gene tile) batch walk 2.25) — "
                     "the pass with its f64 logarithms, fixed-point conversions and 2.2e9 integer LDS atomic lanes is 0.5 ms above "
-                    "that, latency-bound at 4 waves per SIMD (VALU 61 % busy, profiles/r04_pmc_gram.md, r04_knockouts.md)",
+                    "that, latency-bound at 4 waves per SIMD (VALU 61 % busy, profiles/r05_pmc_gram.md, r04_knockouts.md)",
     "spmm_fwd": "algorithmic bytes: the row-major compacted matrix (nnz_w * 8) + row pointers and row order (N * 12) + the "
                 "k x 64 f32 panel once per workgroup column slice + the output, which for this launch (the transform) is the "
                 "N x n_pc f64 score matrix written by the SpMM itself (rows of n_pc rounded up to 16 doubles in HBM).  What bounds "
-                "it (`other_bounds`, profiles/r04_pmc_spmm.md, knock-outs of round 3 in DESIGN.md section 3c): every kept entry "
+                "it (`other_bounds`, profiles/r05_pmc_spmm.md / r04_pmc_spmm.md, knock-outs of round 3 in DESIGN.md section 3c): every kept entry "
                 "reads its gene's panel row from LDS — 0.5 of the LDS read peak, which the 400 KB panel against 160 KB of LDS makes "
                 "inherent to a gather formulation — behind ~80 dependent row steps per wave at one workgroup per CU; the matrix is "
                 "walked once per 16-column panel slice (4 passes, 80 % L2 hits).  The densified MFMA form: 8.7 ms "
@@ -418,8 +420,9 @@ def other_bounds(name, d, nnz_sel, n_cells, sigma=0.3):
                                 "note": "one 64-bit LDS atomic lane per scalar product — INTEGER atomics (the kernel's fixed-point "
                                         "mode: non-negative f32 values of bounded range, which the bench's are); peak = the measured "
                                         "random-address ds_add_u64 rate (ds_add_f64: 2.5 lanes per clock and CU, 0.53 of it)"},
-                "valu": {"note": "the kernel's wall since the atomics are integer ones: SQ_ACTIVE_INST_VALU = 100 % of the launch "
-                                 "(profiles/r04_pmc_gram.md), 16 instructions per owner record"},
+                "valu": {"note": "round 4: SQ_ACTIVE_INST_VALU = 100 % of the launch at 28.6 instructions per load; round 5 (assembly "
+                                 "core): 21 VALU + 18 scalar instructions per load = 2.1 / 1.8 ms-equivalents of issue in a 2.66 ms launch "
+                                 "(profiles/r05_pmc_gram.md)"},
                 "gather_loads": {"achieved": loads / t, "peak": GATHER_LOADS_PER_S, "unit": "load instructions/s",
                                  "frac": loads / t / GATHER_LOADS_PER_S, "loads_per_launch_estimate": loads,
                                  "note": "one load instruction per TWO owner records (records = kept entries x 1.07: a suffix longer "
