@@ -32,7 +32,7 @@ static void gram_exchange_rows(const GramPlan& g, int& r_lo, int& r_hi) {
 }
 static size_t packed_row_offset(int row, int k) { return (size_t)row * (size_t)k - (size_t)row * (size_t)(row - 1) / 2; }      // of (row, row)
 
-int32_t gram_plan(srx_ctx* ctx, int k, uint64_t n_rows, GramPlan& g) {
+int32_t gram_plan(srx_ctx* ctx, int k, uint64_t n_rows, GramPlan& g, double entries_per_cell, int entry_bytes) {
     gram_stripes_of(k, g);
     const int sr = 1 << g.sr_shift;
     size_t widest = 0;
@@ -46,8 +46,23 @@ int32_t gram_plan(srx_ctx* ctx, int k, uint64_t n_rows, GramPlan& g) {
     g.rblk = 512u;      // c3: bucket pass + stripe kernel 4.89 ms with 1024-cell blocks, 4.78 with 512, 5.07 with 256
     g.n_rblk = (n_rows + g.rblk - 1) / g.rblk;
     const int per_cu = g.lds_bytes <= 65536 ? 2 : 1;
-    // chunks of consecutive row blocks: ~16k cells each, at least one block per wave, and enough chunks to fill the device
-    uint64_t chunk = std::max<uint64_t>(16384 / g.rblk, kGramWaves);      // c3: 4.5 ms with 16k-cell chunks, 5.2 with 32k, 5.0 with 8k
+    // chunks of consecutive row blocks, at least one block per wave and enough chunks to fill the device.  Round 5, with the assembly
+    // core, c3 / f32 (72 entries of 8 bytes per cell), cells per chunk: 8k 3.35 ms, 12k 2.90, 16k 2.65, 20k 2.54, 24k 2.48, 28k 2.46, 32k
+    // 2.45, 36k 2.54, 40k 2.65, 48k 2.91, 64k 3.34, 128k 3.96: every (owner, chunk) workgroup flushes its 8000 sums with global atomics
+    // — fewer chunks, fewer flushes — until the owners of a chunk drift apart in it and the L2 stops serving one's reads from another's.
+    // What a chunk should hold is WORK, ~9e7 scalar products (32k cells of 72 kept entries): under skewed gene densities (147 entries
+    // per cell, owners of very different weight: they drift apart sooner) 8k cells take 7.4 ms where 16k took 10.7 and 32k 12.5; and no
+    // more than ~19 MB of entries (f64 storage, 16-byte entries: 16k cells 4.4 ms, 32k 5.8).  (Rounds 2-4, VALU-bound kernels: flat
+    // from 16k to 64k cells, 16k kept.)
+    uint64_t chunk = 16384 / g.rblk;
+    if (entries_per_cell > 0.0 && entry_bytes > 0) {
+        const double m = entries_per_cell;
+        double cells = 9.0e7 / (0.5 * m * (m + 1.0));
+        cells = std::min(cells, 18.9e6 / (m * (double)entry_bytes));
+        chunk = (uint64_t)(cells / g.rblk + 0.5);
+        if (chunk > 65536 / g.rblk) chunk = 65536 / g.rblk;
+    }
+    chunk = std::max<uint64_t>(chunk, kGramWaves);
     const uint64_t want_wgs = (uint64_t)ctx->n_cus * per_cu;
     while (chunk > kGramWaves && ((g.n_rblk + chunk - 1) / chunk) * (uint64_t)g.n_wg < want_wgs) chunk /= 2;
     g.n_chunk = (uint32_t)chunk;
@@ -386,7 +401,7 @@ template <typename VT>
 int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce) {
     if (reduce) *reduce = false;
     GramPlan g;
-    SRX_TRY(gram_plan(ctx, rm.k, rm.n_rows, g));
+    SRX_TRY(gram_plan(ctx, rm.k, rm.n_rows, g, rm.n_rows ? (double)rm.nnz / (double)rm.n_rows : 0.0, (int)sizeof(GramPk<VT>)));
     static const bool force_split = getenv("SRX_GRAM_OVERLAP") != nullptr;      // test switch: the split with a 1-rank communicator
     const int h = g.n_wg / 2;
     const bool split = reduce && comm_is_rccl(ctx) && (ctx->n_ranks > 1 || force_split) && h >= 1 && g.n_wg - h >= 1;

@@ -168,7 +168,9 @@ int32_t launch_tile_ptr(srx_ctx* ctx, const int64_t* indptr, const int32_t* idx,
                         int tile_genes, int64_t* tp);
 
 // ---- pca_form.hip: the HVG-compacted matrix and G = A^T A --------------------------------------------
-int32_t gram_plan(srx_ctx* ctx, int k, uint64_t n_rows, GramPlan& g);
+// (entries_per_cell, entry_bytes: the compacted matrix's mean row length and entry size — they size the stripe kernel's chunks; 0 where
+//  only the blocks are wanted)
+int32_t gram_plan(srx_ctx* ctx, int k, uint64_t n_rows, GramPlan& g, double entries_per_cell = 0.0, int entry_bytes = 0);
 int grid_rows(const srx_ctx* ctx, uint64_t n_rows, int rows_per_block);
 int32_t scan_exclusive(srx_ctx* ctx, const int64_t* d_in, uint64_t n, int64_t* d_out, int64_t** total_dev);
 int32_t build_compact(srx_mat* m, const std::vector<int32_t>& remap, int k, CompactCsr& c, RowMajor& rm);
