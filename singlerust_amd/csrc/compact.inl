@@ -262,49 +262,230 @@ __global__ __launch_bounds__(256) void k_rowcount(const int64_t* __restrict__ in
 // scratch array as long as the matrix — so that the fill pass never walks the column indices again: per row it reads its
 // ~72 words (one coalesced load), gathers the ~72 values and stores the entries.  Needs n_cols <= 65536 (16-bit positions and
 // columns) and the row-major layout alone (no 256-tiled view).
-template <typename I>
-__global__ __launch_bounds__(256) void k_rowcount_list(const int64_t* __restrict__ indptr, const I* __restrict__ idx,
-                                                       const uint32_t* __restrict__ g_bits, const uint32_t* __restrict__ g_prefix,
-                                                       int n_words, uint64_t n_rows, int k, int64_t* __restrict__ cntrow,
-                                                       uint32_t* __restrict__ kept) {
+// Round 5: the same list, 0.82 -> 0.67 ms.  The selection is expanded into a 16-bit table in LDS — gene -> compacted column,
+// 0xffff = dropped, one entry more for the lanes behind a row's end — so that the test of an entry is ONE 2-byte LDS read at the
+// gene's own address (round 4: the mask word and the prefix word, two reads: the LDS pipe was its bound); a lane's rank comes
+// from the two mbcnt instructions with the row's running count as their addend, the list word from one OR with a scalar, the
+// store address from the row's base in scalar registers and the rank alone — 11 instructions per 64-entry slot, written out
+// (inline assembly: no branch inside a slot).  A wave walks its rows as a sequence of BATCHES (up to 1024 entries of one row) with
+// two register sets: the 16 loads of the next batch — always 16, so that the wait before a batch's work is a fixed count — are
+// in flight while this one is worked on.  What is left (profiles/r05_knockouts.md): without its loads the pass takes 0.68 ms,
+// without its stores 0.64, the scalar skeleton around the slots alone 0.4 — it runs at the rate its waves issue instructions,
+// and a second resident workgroup per CU only takes the issue slots the first one leaves (358 / 584 us for the two).
+constexpr int kCountThreads = 1024;
+// a value every lane holds alike, told to the compiler (scalar registers, scalar branches)
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__global__ __launch_bounds__(kCountThreads) void k_rowcount_list(const int64_t* __restrict__ indptr, const uint16_t* __restrict__ idx,
+                                                                 const uint32_t* __restrict__ g_bits, const uint32_t* __restrict__ g_prefix,
+                                                                 int n_words, uint64_t n_rows, uint64_t nnz, int k,
+                                                                 int64_t* __restrict__ cntrow, uint32_t* __restrict__ kept) {
     extern __shared__ double lds_raw[];
-    const SelLds sel = stage_selection(g_bits, g_prefix, n_words, reinterpret_cast<uint32_t*>(lds_raw));
+    uint16_t* col = reinterpret_cast<uint16_t*>(lds_raw);          // 32 n_words + 1 entries
+    const int n_genes = n_words * 32;
+    for (int g = threadIdx.x; g <= n_genes; g += blockDim.x) {
+        uint32_t c = 0xffffu;
+        if (g < n_genes) {
+            const uint32_t w = g_bits[g >> 5], bit = 1u << (g & 31);
+            if (w & bit) {
+                c = g_prefix[g >> 5] + (uint32_t)__popc(w & (bit - 1u));
+                if (c >= (uint32_t)k) c = 0xffffu;       // only a broken selection (NaN variances) has such columns: dropped
+            }
+        }
+        col[g] = (uint16_t)c;
+    }
+    __syncthreads();
+    const uint32_t behind = (uint32_t)n_genes;                     // the table's last entry: dropped
     const uint64_t wave = global_wave_id();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();
-    // (Round 4: four entries per lane and load — 8-byte loads of the index mirror, ranks from four ballots per 256-entry chunk:
-    //  bit-identical lists, 1.16-1.36 ms against 0.78.  Unlike k_gene_count, where the same change took 1.34 -> 0.54 ms, this pass is
-    //  bound by its ~24 VALU instructions and two LDS reads per entry slot, not by its 2-byte loads.)
-    constexpr int kCountUnroll = 16;          // 1024 entries in flight: a ~840-entry row is one round trip
-    for (uint64_t r0 = wave * kCompactRows; r0 < n_rows; r0 += n_waves * kCompactRows) {
-        const int nr = (int)(n_rows - r0 < (uint64_t)kCompactRows ? n_rows - r0 : kCompactRows);
-        uint32_t mine = 0;                    // lane i: row r0 + i
-        for (int i = 0; i < nr; ++i) {
-            const int64_t lo = indptr[r0 + i], hi = indptr[r0 + i + 1];
-            uint32_t rank0 = 0;               // kept entries of the row before this batch (wave-uniform)
-            for (int64_t base = lo; base < hi; base += kCountUnroll * kWave) {
-                int32_t g[kCountUnroll];
-#pragma unroll
-                for (int u = 0; u < kCountUnroll; ++u) {
-                    const int64_t p = base + u * kWave + lane;
-                    g[u] = p < hi ? (int32_t)idx[p] : -1;
-                }
-#pragma unroll
-                for (int u = 0; u < kCountUnroll; ++u) {
-                    int c = g[u] >= 0 ? sel.column(g[u]) : -1;
-                    if (c >= k) c = -1;       // only a broken selection (NaN variances) has such columns: dropped
-                    const unsigned long long mask = __ballot(c >= 0);
-                    if (c >= 0) {
-                        const uint32_t rank = rank0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                        const uint32_t pos = (uint32_t)(base - lo) + (uint32_t)(u * kWave + lane);
-                        kept[lo + rank] = (pos << 16) | (uint32_t)c;
-                    }
-                    rank0 += (uint32_t)__popcll(mask);
-                }
-            }
-            if (lane == i) mine = rank0;
+    const uint32_t lane16 = (uint32_t)lane << 16;
+    constexpr int kU = 16;                    // 1024 entries per batch: a ~840-entry row is one
+    constexpr uint32_t kBatch = kU * kWave;
+    struct Cur {                              // a batch: entries [b, b + 1024) of row r (all wave-uniform)
+        uint64_t r;
+        int64_t lo;
+        uint32_t n, b;
+        int64_t plo, phi;                     // the row pointers of the row BEHIND r in this wave's order, asked for when r was opened:
+    };                                        // a row's pointers arrive a batch before they are wanted (a scalar load per row in
+                                              // the wave's way cost 630 of a batch's 4500 cycles)
+    auto ask_next = [&](Cur& c) {
+        uint64_t rn = next_compact_row(c.r, n_waves);
+        if (rn >= n_rows) rn = n_rows - 1;     // (not followed: any valid row)
+        rn = (uint64_t)uniform64((int64_t)rn);
+        c.plo = indptr[rn];
+        c.phi = indptr[rn + 1];
+    };
+    auto open_row = [&](Cur& c, uint64_t r) {  // the first row of the wave
+        r = (uint64_t)uniform64((int64_t)r);
+        c.r = r;
+        c.lo = uniform64(indptr[r]);
+        c.n = (uint32_t)(uniform64(indptr[r + 1]) - c.lo);
+        c.b = 0;
+        ask_next(c);
+    };
+    auto open_next = [&](Cur& c, uint64_t r) { // r = the row behind c.r: its pointers are there
+        c.r = (uint64_t)uniform64((int64_t)r);
+        c.lo = uniform64(c.plo);
+        c.n = (uint32_t)(uniform64(c.phi) - c.lo);
+        c.b = 0;
+        ask_next(c);
+    };
+    // the batch behind c, in this wave's order of rows: 1 = there it is, 0 = no row is left, 2 = c is now at a row whose batches
+    // may run past the array's end (one of its last rows: the plain loop at the end takes over)
+    auto advance = [&](Cur& c) -> int {
+        if (c.b + kBatch < c.n) {
+            c.b += kBatch;
+            return 1;
         }
-        if (lane < nr) cntrow[r0 + lane] = (int64_t)mine;     // 8 counters = one 64-byte line
+        const uint64_t r = (uint64_t)uniform64((int64_t)next_compact_row(c.r, n_waves));
+        if (r >= n_rows) return 0;
+        open_next(c, r);
+        return ((uint64_t)c.lo + c.n + kBatch <= nnz) ? 1 : 2;
+    };
+    // the 16 loads of a batch, unpredicated (what lies behind the row's end is the next rows' entries: replaced by `behind`
+    // before use; the rows whose batches could run past the ARRAY's end are left to the plain loop at the end).  Inline
+    // assembly: the compiler waits for ALL outstanding loads before the first use of any (it cannot tell the two register sets
+    // apart across the loop); the wait is written out below, as a count.
+    static_assert(kU == 16, "16 loads of 2-byte indices");
+    auto issue = [&](uint32_t (&g)[kU], const Cur& c) {
+        const unsigned long long base = (unsigned long long)uniform64((int64_t)(idx + c.lo + c.b));      // (a scalar register pair)
+        const uint32_t off = (uint32_t)lane * 2u;
+        asm volatile(
+            "global_load_ushort %0, %16, %17\n\tglobal_load_ushort %1, %16, %17 offset:128\n\t"
+            "global_load_ushort %2, %16, %17 offset:256\n\tglobal_load_ushort %3, %16, %17 offset:384\n\t"
+            "global_load_ushort %4, %16, %17 offset:512\n\tglobal_load_ushort %5, %16, %17 offset:640\n\t"
+            "global_load_ushort %6, %16, %17 offset:768\n\tglobal_load_ushort %7, %16, %17 offset:896\n\t"
+            "global_load_ushort %8, %16, %17 offset:1024\n\tglobal_load_ushort %9, %16, %17 offset:1152\n\t"
+            "global_load_ushort %10, %16, %17 offset:1280\n\tglobal_load_ushort %11, %16, %17 offset:1408\n\t"
+            "global_load_ushort %12, %16, %17 offset:1536\n\tglobal_load_ushort %13, %16, %17 offset:1664\n\t"
+            "global_load_ushort %14, %16, %17 offset:1792\n\tglobal_load_ushort %15, %16, %17 offset:1920"
+            : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]),
+              "=&v"(g[8]), "=&v"(g[9]), "=&v"(g[10]), "=&v"(g[11]), "=&v"(g[12]), "=&v"(g[13]), "=&v"(g[14]), "=&v"(g[15])
+            : "v"(off), "s"(base)
+            : "memory");
+    };
+    // the same batch by plain loads clamped to the array's last entry (the compiler's own waits): the array's last rows
+    auto issue_plain = [&](uint32_t (&g)[kU], const Cur& c) {
+        const uint32_t last = (uint32_t)(nnz - 1 - ((uint64_t)c.lo + c.b));      // (nnz > lo + b: the row has entries there)
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const uint32_t o = (uint32_t)(u * kWave + lane);
+            g[u] = (uint32_t)idx[c.lo + c.b + (o < last ? o : last)];
+        }
+    };
+    // Everything but the 16 most recent vector-memory operations — the loads of the batch behind this one — has completed: this
+    // batch's registers hold its loads.  (Stores count in vmcnt like loads: the wait also covers the stores of the batch worked
+    // on before.  Leaving those outstanding as well — a wait count of 16 + that batch's slots — was measured: 0.48 ms SLOWER.)
+    auto arrived = [&](uint32_t (&g)[kU]) {
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        // (the registers are handed to the work below by these two statements only: tests/test_abi_cpu.py checks the listing
+        //  for reads of a set between its loads and here)
+        asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6]), "+v"(g[7]));
+        asm volatile("" : "+v"(g[8]), "+v"(g[9]), "+v"(g[10]), "+v"(g[11]), "+v"(g[12]), "+v"(g[13]), "+v"(g[14]), "+v"(g[15]));
+    };
+    uint32_t rank0 = 0, mine = 0;             // kept entries of the row before this slot (wave-uniform); lane i: count of row (r & ~7) + i
+    auto work = [&](uint32_t (&g)[kU], const Cur& c) {
+        const int rem = __builtin_amdgcn_readfirstlane((int)(c.n - c.b));      // (wave-uniform: the tests on it are scalar branches)
+        if (c.b == 0) rank0 = 0;
+        char* krow = reinterpret_cast<char*>(kept + c.lo);
+        const int left = rem - lane;           // > 64 u: this lane's entry of slot u exists
+        // (groups of four slots: one that lies inside the row reads the table at its genes as they are; only the group holding the
+        //  row's end sends the lanes behind it to the table's last entry; a group behind the end is not looked at)
+#pragma unroll
+        for (int q = 0; q < kU / 4; ++q) {
+            if (rem <= q * 4 * kWave) break;
+            if (rem < (q + 1) * 4 * kWave) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[4 * q + j] = col[left > (4 * q + j) * kWave ? g[4 * q + j] : behind];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[4 * q + j] = col[g[4 * q + j]];       // (the reads of all groups in flight together)
+            }
+        }
+        // Four slots per statement, no branch inside (the listing the compiler makes of the same steps spends 2.6 branches per slot
+        // — around the store, at the row's end —, and the pass waits on instruction issue, not on memory): the kept lanes become
+        // the exec mask, their ranks come from the mbcnt pair over the running count, the list word from one OR with the slot's
+        // scalar position, one store, and the count moves on by the mask's population.  A slot behind the row's end holds 0xffff
+        // everywhere: an empty mask.
+        uint32_t vr = rank0;                   // (the running count in a vector register: mbcnt's addend)
+        const unsigned long long kr = (unsigned long long)krow;
+#define SRX_COUNT_SLOT(C)                                     \
+    "v_cmp_ne_u32_e32 vcc, 0xffff, " C "\n\t"                 \
+    "s_and_saveexec_b64 %[sv], vcc\n\t"                      \
+    "v_mbcnt_lo_u32_b32 %[t], vcc_lo, %[vr]\n\t"             \
+    "v_mbcnt_hi_u32_b32 %[t], vcc_hi, %[t]\n\t"              \
+    "v_or3_b32 %[w], " C ", %[l16], %[p]\n\t"                \
+    "v_lshlrev_b32_e32 %[t], 2, %[t]\n\t"                    \
+    "global_store_dword %[t], %[w], %[kr]\n\t"               \
+    "s_mov_b64 exec, %[sv]\n\t"                              \
+    "s_bcnt1_i32_b64 %[nk], vcc\n\t"                         \
+    "v_add_u32_e32 %[vr], %[nk], %[vr]\n\t"                  \
+    "s_add_i32 %[p], %[p], 0x400000\n\t"
+#pragma unroll
+        for (int q = 0; q < kU / 4; ++q) {
+            if (rem <= q * 4 * kWave) break;   // (wave-uniform)
+            unsigned long long sv;
+            uint32_t nk, t, w, p16 = (c.b + (uint32_t)(q * 4 * kWave)) << 16;
+            asm volatile(SRX_COUNT_SLOT("%[c0]") SRX_COUNT_SLOT("%[c1]") SRX_COUNT_SLOT("%[c2]") SRX_COUNT_SLOT("%[c3]")
+                         : [vr] "+v"(vr), [p] "+s"(p16), [sv] "=&s"(sv), [nk] "=&s"(nk), [t] "=&v"(t), [w] "=&v"(w)
+                         : [c0] "v"(g[4 * q]), [c1] "v"(g[4 * q + 1]), [c2] "v"(g[4 * q + 2]), [c3] "v"(g[4 * q + 3]), [l16] "v"(lane16),
+                           [kr] "s"(kr)
+                         : "vcc", "scc", "memory");
+        }
+#undef SRX_COUNT_SLOT
+        rank0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)vr);
+        if (c.b + kBatch >= c.n) {             // the row's last batch: its count; 8 counters = one 64-byte line
+            const int i = __builtin_amdgcn_readfirstlane((int)(c.r % kCompactRows));
+            if (lane == i) mine = rank0;
+            if (i == kCompactRows - 1 || c.r + 1 == n_rows) {
+                if (lane <= i) cntrow[c.r - (uint64_t)i + lane] = (int64_t)mine;
+            }
+        }
+    };
+    if (wave * kCompactRows >= n_rows) return;
+    Cur a;
+    open_row(a, wave * kCompactRows);
+    uint32_t gA[kU], gB[kU];
+    if ((uint64_t)a.lo + a.n + kBatch <= nnz) {
+        // Two batches per turn, straight-line: the loads behind a batch are ALWAYS issued (with nothing behind it: the same batch
+        // again, into the set that is not used any more), so that no branch separates a set's loads from its wait.
+        issue(gA, a);
+        int st;
+        for (;;) {
+            Cur b = a;
+            st = __builtin_amdgcn_readfirstlane(advance(b));
+            issue(gB, st == 1 ? b : a);
+            arrived(gA);
+            work(gA, a);
+            a = b;
+            if (st != 1) break;
+            Cur c = b;
+            st = __builtin_amdgcn_readfirstlane(advance(c));
+            issue(gA, st == 1 ? c : b);
+            arrived(gB);
+            work(gB, b);
+            a = c;
+            if (st != 1) break;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the loads issued behind the last batch)
+        if (st == 0) {
+            return;
+        }
+    }
+    // the array's last rows (a batch's 1024 entries may run past the array's end): one batch at a time, plain loads
+    for (;;) {
+        if (a.n != 0) issue_plain(gA, a);
+        work(gA, a);
+        if (a.b + kBatch < a.n) {
+            a.b += kBatch;
+            continue;
+        }
+        const uint64_t r = (uint64_t)uniform64((int64_t)next_compact_row(a.r, n_waves));
+        if (r >= n_rows) break;
+        open_next(a, r);
     }
 }
 

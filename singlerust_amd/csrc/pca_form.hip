@@ -243,16 +243,19 @@ int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words, int k,
     ProfScope ps(ctx, SRX_K_COMPACT, (double)m->nnz * s_i * ((!t256p && m->n_cols <= 65536) ? 1.0 : 2.0) +
                                          (double)(N + 1) * 8.0 * 2.0);
     const size_t cnt_lds = sel_lds + 4 * (size_t)kCompactRows * kWave * sizeof(uint32_t);      // + 8 x 64 counters per wave
-    const bool list = !t256p && m->n_cols <= 65536;
+    const bool list = !t256p && m->n_cols <= 65536 && m->d_idx16;      // (the 16-bit index mirror: there whenever n_cols <= 65536, ensure_tiles)
     uint32_t* kept = nullptr;
     if (list) {
         SRX_TRY(scratch(ctx, "pca_keptlist", (m->nnz + 64) * sizeof(uint32_t), (void**)&kept));
-        if (m->d_idx16)
-            hipLaunchKernelGGL((k_rowcount_list<uint16_t>), dim3(grid_rows(ctx, N, 4)), dim3(256), sel_lds, ctx->stream, m->d_indptr,
-                               (const uint16_t*)m->d_idx16, d_sel, d_sel + n_words, n_words, N, k, cntrow, kept);
-        else
-            hipLaunchKernelGGL((k_rowcount_list<int32_t>), dim3(grid_rows(ctx, N, 4)), dim3(256), sel_lds, ctx->stream, m->d_indptr,
-                               (const int32_t*)m->d_indices, d_sel, d_sel + n_words, n_words, N, k, cntrow, kept);
+        // one 1024-thread workgroup per 16-bit gene table (2 bytes per gene + the entry for the lanes behind a row's end): two per
+        // CU at 28k genes, one at 65536
+        const size_t col_lds = ((size_t)n_words * 32 + 1) * sizeof(uint16_t);
+        const int per_cu = std::max(1, std::min(2, (int)(160 * 1024 / (col_lds + 1024))));
+        const uint64_t visits = (N + (uint64_t)kCompactRows * (kCountThreads / kWave) - 1) / ((uint64_t)kCompactRows * (kCountThreads / kWave));
+        const unsigned cgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(visits, (uint64_t)ctx->n_cus * per_cu));
+        SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_rowcount_list, hipFuncAttributeMaxDynamicSharedMemorySize, (int)col_lds));
+        hipLaunchKernelGGL(k_rowcount_list, dim3(cgrid), dim3(kCountThreads), col_lds, ctx->stream, m->d_indptr,
+                           (const uint16_t*)m->d_idx16, d_sel, d_sel + n_words, n_words, N, m->nnz, k, cntrow, kept);
     } else if (!t256p) {
         const size_t bits_lds = (size_t)n_words * sizeof(uint32_t);
         if (m->d_idx16)

@@ -195,7 +195,7 @@ def test_hot_kernels_do_not_spill_registers(tmp_path):
     import subprocess
     from singlerust_amd import build
     csrc = os.path.join(ROOT, "singlerust_amd", "csrc")
-    wanted = {"pca_form.hip": ["k_gram_stripesIfE", "k_gram_stripesIdE"],
+    wanted = {"pca_form.hip": ["k_gram_stripesIfE", "k_gram_stripesIdE", "k_rowcount_listEPKl"],
               "pca_solve.hip": ["k_spmm_rowsIffLi4ELb0ELi4EE"]}
 
     def asm(src):
@@ -214,6 +214,48 @@ def test_hot_kernels_do_not_spill_registers(tmp_path):
             spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", body).group(1))
             scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", body).group(1))
             assert spill == 0 and scratch == 0, f"{m.group(1)}: {spill} spilled VGPRs, {scratch} B of scratch"
+    _check_count_pass_listing(texts["pca_form.hip"])
+
+
+def _check_count_pass_listing(text):
+    """k_rowcount_list issues the 16 loads of a batch in one assembly statement and waits for them by a count, one batch later
+    (`s_waitcnt vmcnt(16)` + two empty statements that hand the registers over).  The compiler believes the registers are valid
+    from the load statement on: a copy it placed between the loads and the hand-over (phi resolution, live-range splitting)
+    would read registers whose loads are still in flight — a first form of the kernel did exactly that on one path.  Walk the
+    listing: between a load block and the hand-over that follows it in the text, no instruction outside the assembly blocks
+    may name a register the block loads into."""
+    for mangled in ("k_rowcount_listEPKl",):
+        m = re.search(r"^(_ZN3srx\S*%s\S*):.*?s_endpgm" % mangled, text, flags=re.S | re.M)
+        assert m, mangled
+        lines = m.group(0).split("\n")
+        i, blocks = 0, 0
+        while i < len(lines):
+            if "#ASMSTART" in lines[i] and i + 1 < len(lines) and re.search(r"global_load_(ushort|dword) v\d+, v\d+, s\[", lines[i + 1]):
+                dests = set()
+                j = i + 1
+                while "#ASMEND" not in lines[j]:
+                    dests.add(re.search(r"global_load_\w+ (v\d+),", lines[j]).group(1))
+                    j += 1
+                assert len(dests) == 16, (mangled, dests)
+                blocks += 1
+                # forward to the hand-over: an empty assembly statement
+                k_, inside = j + 1, False
+                while not ("#ASMSTART" in lines[k_] and "#ASMEND" in lines[k_ + 1]):
+                    ln = lines[k_]
+                    if "#ASMSTART" in ln:
+                        inside = True
+                    elif "#ASMEND" in ln:
+                        inside = False
+                    elif not inside and not ln.strip().startswith((";", ".")) and ln.strip():
+                        regs = set(re.findall(r"\bv(\d+)\b", ln)) | {str(x) for a, b in re.findall(r"v\[(\d+):(\d+)\]", ln)
+                                                                    for x in range(int(a), int(b) + 1)}
+                        hit = {f"v{r}" for r in regs} & dests
+                        assert not hit, f"{mangled}: `{ln.strip()}` touches {sorted(hit)} while their loads are in flight"
+                    k_ += 1
+                    assert k_ + 1 < len(lines), f"{mangled}: no hand-over behind a load block"
+                i = j
+            i += 1
+        assert blocks >= 3, (mangled, blocks)       # before the loop, and one per half of its body
 
 
 def test_graft_entry_build_runs():

@@ -639,6 +639,52 @@ def test_fused_pipeline_odd_shapes(ctx, n, g, hvg, npc, store):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("store", [1, 2])
+def test_fused_pipeline_long_empty_and_last_rows(ctx, store):
+    """The compaction's count pass walks a row in batches of 1024 entries with the next batch's loads in flight, leaves the rows
+    whose batches could run past the array's end to a plain loop, and packs eight row counts into one store: rows of exactly
+    1024 / 1025 / 2048 entries, rows of several batches, empty rows (also as a wave's first, a group's last and the matrix's
+    last row), a long LAST row — and enough rows that both the streamed and the plain route are taken (the streamed one needs
+    1024 entries of array behind a row).  The pipeline's selection, components and scores against the oracle."""
+    from singlerust_amd import _ffi
+    rng = np.random.default_rng(5150 + store)
+    n, g, hvg, npc = 4200, 6000, 900, 6
+    lens = rng.integers(20, 400, size=n)
+    for r, L in [(0, 0), (7, 0), (8, 1024), (9, 1025), (15, 2048), (16, 3500), (17, 0), (100, 5999), (101, 1), (1023, 2049),
+                 (2048, 1023), (n - 9, 0), (n - 8, 4100), (n - 3, 0), (n - 2, 1024), (n - 1, 3000)]:
+        lens[r] = L
+    lens[200:260] = 0                              # whole groups of eight without an entry
+    ip = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    idx = np.concatenate([np.sort(rng.choice(g, size=int(L), replace=False)) for L in lens]).astype(np.uint64)
+    # planted structure on top of noise, so that the leading components are well separated
+    z = rng.normal(size=(n, 3))
+    load = rng.normal(size=(3, g))
+    rows = np.repeat(np.arange(n), lens)
+    val = np.exp(0.6 * np.einsum("ij,ij->i", z[rows], load[:, idx.astype(np.int64)].T) + 0.3 * rng.normal(size=idx.size)).astype(np.float32)
+    val = np.maximum(np.round(val * 3), 1).astype(np.float32)
+    m = oracle.Csr(n, g, ip, idx, val)
+    a = adata_of(m, ctx, store)
+    opts = _ffi.PcaOpts(npc, -1, -1, -1, 0, 0, 0, 0.0, 7)
+    res = _ffi.PipelineResult()
+    _ffi.check(_ffi.lib().srx_pipeline(a.x().handle, 1e4, hvg, C.byref(opts), C.byref(res)), ctx.handle)
+    scores, comps = np.zeros((n, npc)), np.zeros((hvg, npc))
+    evr, hv = np.zeros(npc), np.zeros(hvg, np.uint64)
+    _ffi.check(_ffi.lib().srx_result_fetch(a.x().handle, _ffi.ptr(scores), _ffi.ptr(comps), _ffi.ptr(evr), None, None,
+                                           _ffi.ptr(hv)), ctx.handle)
+    lg = oracle.log1p_transform(oracle.normalize_total(m, 1e4, ROW))
+    assert np.array_equal(hv, pca_oracle.select_features_hvg(lg, hvg))
+    assert int(res.pca.nnz_selected) == int(np.isin(idx, hv).sum())          # every kept entry, counted once
+    want_scores, want_comps, want_evr, *_ = pca_oracle.pca_inplace(lg, npc, None, None, hv)
+    lead = 3                                       # the planted directions; the noise components behind them are close together
+    tol = 1e-5 if store == 1 else 1e-7
+    assert col_err(scores[:, :lead], want_scores[:, :lead]) < tol
+    assert col_err(comps[:, :lead], want_comps[:, :lead]) < tol
+    q1, _ = np.linalg.qr(comps); q2, _ = np.linalg.qr(want_comps)
+    assert np.linalg.norm(q1 @ q1.T - q2 @ q2.T) < 1e-3
+    np.testing.assert_allclose(evr[:lead], want_evr[:lead], rtol=1e-5)
+
+
+@pytest.mark.gpu
 def test_pipeline_medium_scale_vs_oracle(ctx):
     """20k cells x 6000 genes, HVG(1000), 30 PCs through the fused pipeline (device selection, 8 gene tiles of
     128 -> 36 tile pairs, Chebyshev rounds, graphs) against the oracle's densify + exact SVD: scores and
