@@ -108,7 +108,7 @@ static int32_t backed_gram_tile(srx_backed* b, srx_mat* m, RowXf xf) {
     if (b->dev_sel) SRX_TRY(build_tiled_fused(m, b->hv.d_bits, b->hv.n_words, b->k, rm, nullptr, xf, true));
     else SRX_TRY(build_tiled_fused(m, b->remap, b->k, rm, nullptr, xf, true));
     SRX_TRY(launch_gram<VT>(ctx, rm, b->d_gram));            // accumulates into the session's packed matrix
-    SRX_TRY(build_row_order(ctx, rm));
+    if (!rm.perm) SRX_TRY(build_row_order(ctx, rm));          // (made inside the fused compaction where that one ran)
     // keep the row-major records of this tile for the transform: exact-size copies out of the scratch buffers
     RowMajor keep = rm;
     keep.ptr = nullptr;

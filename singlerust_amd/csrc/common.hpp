@@ -121,6 +121,7 @@ struct srx_ctx {
     std::vector<UpWorker> up_workers;
     hipStream_t direct_stream = nullptr;     // upload_on: values the caller holds in pinned memory go straight from there (no staging copy)
     hipEvent_t async_ev[kAsyncSlots] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t d2h_ev = nullptr;        // d2h_begin / d2h_end: a small read-back the host waits for while the stream goes on
 };
 
 struct srx_pca_state {           // what the last srx_pca / srx_pipeline left in HBM
@@ -221,6 +222,10 @@ inline int32_t fail(srx_ctx* ctx, int32_t code, const char* fmt, ...) {
 int32_t scratch(srx_ctx* ctx, const char* name, size_t bytes, void** out);
 int32_t pinned(srx_ctx* ctx, size_t bytes, void** out);
 int32_t d2h(srx_ctx* ctx, void* host, const void* dev, size_t bytes);   // via pinned, synchronises
+// the same small copy in two halves: `begin` queues it (pinned staging + an event), `end` waits for THAT event only — what the
+// caller queues between the two runs on the device while the host is woken
+int32_t d2h_begin(srx_ctx* ctx, const void* dev, size_t bytes);
+int32_t d2h_end(srx_ctx* ctx, void* host, size_t bytes);
 int32_t h2d(srx_ctx* ctx, void* dev, const void* host, size_t bytes);
 int32_t d2h_rows(srx_ctx* ctx, void* host, const void* dev, uint64_t rows, size_t width, size_t dev_pitch);   // strided rows -> dense
 

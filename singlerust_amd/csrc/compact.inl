@@ -500,6 +500,9 @@ __global__ __launch_bounds__(256) void k_tfill_list(const int64_t* __restrict__ 
         stage_log1p_table(s_tab);
         __syncthreads();
     }
+    // the 64 entries behind the last row are READ by the forward kernel (a row's last chunk runs past its end: value masked to
+    // 0, column used as is): they must name a real column, or 0 x panel[garbage] is NaN (this used to be a memset launch)
+    if (blockIdx.x == 0 && threadIdx.x < 64) rm[rm_ptr[n_rows] + threadIdx.x] = GramPk<T>{};
     const uint64_t wave = global_wave_id();
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) / kWave;
     const int lane = lane_id();

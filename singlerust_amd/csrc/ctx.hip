@@ -67,6 +67,20 @@ int32_t d2h(srx_ctx* ctx, void* host, const void* dev, size_t bytes) {
 }
 
 // `rows` rows of `width` bytes, `dev_pitch` bytes apart on the device, to a dense host matrix
+int32_t d2h_begin(srx_ctx* ctx, const void* dev, size_t bytes) {
+    void* p;
+    SRX_TRY(pinned(ctx, bytes, &p));
+    if (!ctx->d2h_ev) SRX_HIP(ctx, hipEventCreateWithFlags(&ctx->d2h_ev, hipEventDisableTiming));
+    SRX_HIP(ctx, hipMemcpyAsync(p, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SRX_HIP(ctx, hipEventRecord(ctx->d2h_ev, ctx->stream));
+    return SRX_OK;
+}
+int32_t d2h_end(srx_ctx* ctx, void* host, size_t bytes) {
+    SRX_HIP(ctx, hipEventSynchronize(ctx->d2h_ev));
+    memcpy(host, ctx->pinned, bytes);
+    return SRX_OK;
+}
+
 int32_t d2h_rows(srx_ctx* ctx, void* host, const void* dev, uint64_t rows, size_t width, size_t dev_pitch) {
     if (dev_pitch == width) return d2h(ctx, host, dev, rows * width);
     if (rows == 0 || width == 0) return SRX_OK;
@@ -705,6 +719,7 @@ void srx_ctx_destroy(srx_ctx* ctx) {
         if (uw.stream) (void)hipStreamDestroy(uw.stream);
     }
     if (ctx->direct_stream) (void)hipStreamDestroy(ctx->direct_stream);
+    if (ctx->d2h_ev) (void)hipEventDestroy(ctx->d2h_ev);
     for (auto e : ctx->async_ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);

@@ -1001,7 +1001,7 @@ int32_t select_hvg_host(srx_ctx* ctx, const std::vector<double>& var, uint64_t n
 // operation order (csr.rs:179-185: no FMA contraction — explicit _rn intrinsics), stable descending order
 // (ties keep the ascending gene index), NaN -> status bit 1 (the reference panics).
 __global__ void k_gene_var(const uint64_t* __restrict__ cnt, const double* __restrict__ sum, const double* __restrict__ sq,
-                           uint64_t G, double* __restrict__ var, int* __restrict__ status) {
+                           uint64_t G, double* __restrict__ var, uint32_t* __restrict__ rank, uint32_t rank_init) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= G) return;
     double v = 0.0;
@@ -1011,7 +1011,7 @@ __global__ void k_gene_var(const uint64_t* __restrict__ cnt, const double* __res
         v = __dsub_rn(__ddiv_rn(sq[j], c), __dmul_rn(mean, mean));
     }
     var[j] = v;
-    if (v != v) atomicOr(status, 1);
+    rank[j] = rank_init;          // (candidate route: 0xffffffff = not a candidate; full ranking: the partial ranks start at 0)
 }
 
 // rank of every gene under (variance desc, index asc) by counting.  Block (x, y): genes 256 x .. 256 x + 255
@@ -1019,32 +1019,37 @@ __global__ void k_gene_var(const uint64_t* __restrict__ cnt, const double* __res
 // wholly before the block's genes wins ties (>=), wholly after loses them (>), only the tile holding the
 // block's own genes needs the index compare.  Partial ranks are summed with integer atomics (exact, any order).
 constexpr int kRankTile = 2048;
-__global__ __launch_bounds__(256) void k_hvg_rank(const double* __restrict__ var, uint32_t G, uint32_t* __restrict__ rank_out,
-                                                  const uint32_t* __restrict__ counter = nullptr, uint32_t n = 0, uint32_t cap = 0) {
-    __shared__ double tile[kRankTile];
-    if (counter && *counter >= n && *counter <= cap) return;      // the candidates did (k_rank_candidates): nothing to do
-    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t base = blockIdx.y * kRankTile;
+// one (block of 256 genes, comparison tile) pair of the full ranking; `tile`: kRankTile doubles of LDS; all 256 threads
+__device__ __forceinline__ void full_rank_pair(const double* __restrict__ var, uint32_t G, uint32_t* __restrict__ rank_out, uint32_t bx,
+                                               uint32_t by, double* tile) {
+    const uint32_t j = bx * 256 + threadIdx.x;
+    const uint32_t base = by * kRankTile;
     for (uint32_t e = threadIdx.x; e < kRankTile; e += 256) tile[e] = base + e < G ? var[base + e] : -INFINITY;
     __syncthreads();
-    if (j >= G) return;
-    const double mine = var[j];
-    const uint32_t j_lo = blockIdx.x * 256, j_hi = j_lo + 255;
-    uint32_t rank = 0;
-    if (base + kRankTile - 1 < j_lo) {                       // every gene of the tile precedes every gene of the block
+    if (j < G) {
+        const double mine = var[j];
+        const uint32_t j_lo = bx * 256, j_hi = j_lo + 255;
+        uint32_t rank = 0;
+        if (base + kRankTile - 1 < j_lo) {                       // every gene of the tile precedes every gene of the block
 #pragma unroll 8
-        for (int e = 0; e < kRankTile; ++e) rank += tile[e] >= mine ? 1u : 0u;
-    } else if (base > j_hi) {
+            for (int e = 0; e < kRankTile; ++e) rank += tile[e] >= mine ? 1u : 0u;
+        } else if (base > j_hi) {
 #pragma unroll 8
-        for (int e = 0; e < kRankTile; ++e) rank += tile[e] > mine ? 1u : 0u;
-    } else {
+            for (int e = 0; e < kRankTile; ++e) rank += tile[e] > mine ? 1u : 0u;
+        } else {
 #pragma unroll 4
-        for (int e = 0; e < kRankTile; ++e) {
-            const double o = tile[e];
-            rank += (o > mine || (o == mine && base + e < j)) ? 1u : 0u;
+            for (int e = 0; e < kRankTile; ++e) {
+                const double o = tile[e];
+                rank += (o > mine || (o == mine && base + e < j)) ? 1u : 0u;
+            }
         }
+        atomicAdd(&rank_out[j], rank);
     }
-    atomicAdd(&rank_out[j], rank);
+    __syncthreads();                                             // (the tile is re-filled by the caller's next pair)
+}
+__global__ __launch_bounds__(256) void k_hvg_rank(const double* __restrict__ var, uint32_t G, uint32_t* __restrict__ rank_out) {
+    __shared__ double tile[kRankTile];
+    full_rank_pair(var, G, rank_out, blockIdx.x, blockIdx.y, tile);
 }
 
 // ---- the same ranks for the genes that can be selected only --------------------------------------------------------------
@@ -1055,55 +1060,96 @@ __global__ __launch_bounds__(256) void k_hvg_rank(const double* __restrict__ var
 // the full ranking runs instead — decided on the device.
 // O(M^2) instead of O(G^2) comparisons: 173 -> ~25 us at 28k genes, n = 2000.
 constexpr int kRankSample = 512;
-__global__ __launch_bounds__(kRankSample) void k_hvg_threshold(const double* __restrict__ var, uint32_t G, uint32_t n,
-                                                              double* __restrict__ thr, uint32_t* __restrict__ counter,
-                                                              int force_miss /* test switch: a threshold nothing reaches */) {
+constexpr int kSelThreads = 1024;
+// One workgroup: the threshold from the sample, the candidate list (gene ids in any order: the ranks are a strict total order),
+// rank_out[candidate] = 0, and the decision: `counter` = number of candidates M if n <= M <= cap, else 0xffffffff with
+// rank_out zeroed for EVERY gene — the full ranking takes over in k_rank_selected.  (Round 5: threshold, gather, the fallback's
+// reset and its early-exit launch were four kernels of 5-17 us each on the step's critical path.)
+__global__ __launch_bounds__(kSelThreads) void k_hvg_candidates(const double* __restrict__ var, uint32_t G, uint32_t n, uint32_t cap,
+                                                                uint32_t* __restrict__ counter, uint32_t* __restrict__ cand,
+                                                                uint32_t* __restrict__ rank_out,
+                                                                int force_miss /* test switch: a threshold nothing reaches */) {
     __shared__ double sv[kRankSample];
+    __shared__ double s_thr;
+    __shared__ uint32_t s_cnt;
     const uint32_t S = G < (uint32_t)kRankSample ? G : (uint32_t)kRankSample;
-    const uint32_t t = threadIdx.x;
-    const double mine = t < S ? var[(uint64_t)t * G / S] : -INFINITY;
-    sv[t] = mine;
+    const uint32_t t = threadIdx.x, lane = t & 63;
+    if (t < (uint32_t)kRankSample) sv[t] = t < S ? var[(uint64_t)t * G / S] : -INFINITY;
     if (t == 0) {
-        *thr = force_miss ? INFINITY : -INFINITY;      // every gene a candidate unless a sample element says otherwise
-        *counter = 0u;
+        s_thr = force_miss ? INFINITY : -INFINITY;      // every gene a candidate unless a sample element says otherwise
+        s_cnt = 0u;
     }
     __syncthreads();
-    if (force_miss || S < (uint32_t)kRankSample || t >= S) return;       // few genes: rank them all
-    const double q = (double)n / (double)G;
-    const double kq = (q + 4.0 * sqrt(q * (1.0 - q) / (double)S)) * (double)S + 1.0;
-    if (!(kq < (double)(S - 1))) return;
-    uint32_t rk = 0;
-    for (uint32_t e = 0; e < S; ++e) {
-        const double o = sv[e];
-        rk += (o > mine || (o == mine && e < t)) ? 1u : 0u;
+    if (!force_miss && S == (uint32_t)kRankSample) {          // (uniform)
+        const double q = (double)n / (double)G;
+        const double kq = (q + 4.0 * sqrt(q * (1.0 - q) / (double)S)) * (double)S + 1.0;
+        // the sample in descending order (bitonic network in LDS, 256 compare-exchanges per step: ranking every element against
+        // every other one took 17 us of one workgroup); equal values may stand in any order — the threshold is a VALUE
+        for (uint32_t size = 2; size <= (uint32_t)kRankSample; size <<= 1)
+            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                if (t < (uint32_t)kRankSample / 2) {
+                    const uint32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                    const bool desc = (lo & size) == 0;
+                    const double a = sv[lo], b = sv[hi];
+                    if (desc ? a < b : a > b) {
+                        sv[lo] = b;
+                        sv[hi] = a;
+                    }
+                }
+                __syncthreads();
+            }
+        if (t == 0 && kq < (double)(S - 1)) s_thr = sv[(uint32_t)kq];       // (NaN variances in the sample: whatever stands there — the status word reports them)
     }
-    if (rk == (uint32_t)kq) *thr = mine;                   // (NaN variances: no element may get this rank — thr stays -inf)
-}
-__global__ void k_hvg_gather(const double* __restrict__ var, uint32_t G, const double* __restrict__ thr,
-                             uint32_t* __restrict__ counter, uint32_t* __restrict__ cand, uint32_t* __restrict__ rank_out) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = j < G && var[j] >= *thr;
-    const unsigned long long m = __ballot(in);
-    uint32_t base = 0;
-    if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = __shfl(base, 0, 64);
-    if (in) {
-        cand[base + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = j;
-        rank_out[j] = 0u;
+    __syncthreads();
+    const double thr = s_thr;
+    constexpr int kAhead = 8;                 // variances of eight rounds in flight (a round per load was 0.5 us of latency each)
+    for (uint32_t base = 0; base < G; base += kSelThreads * kAhead) {
+        double v[kAhead];
+#pragma unroll
+        for (int a = 0; a < kAhead; ++a) {
+            const uint32_t j = base + a * kSelThreads + t;
+            v[a] = j < G ? var[j] : -INFINITY;
+        }
+#pragma unroll
+        for (int a = 0; a < kAhead; ++a) {
+            const uint32_t j = base + a * kSelThreads + t;
+            const bool in = j < G && v[a] >= thr;
+            const unsigned long long m = __ballot(in);
+            uint32_t at = 0;
+            if (lane == 0 && m) at = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+            at = __shfl(at, 0, 64);
+            if (in) {
+                cand[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = j;
+                rank_out[j] = 0u;
+            }
+        }
     }
+    __syncthreads();
+    const uint32_t M = s_cnt;
+    const bool ok = M >= n && M <= cap;
+    if (!ok)
+        for (uint32_t j = t; j < G; j += kSelThreads) rank_out[j] = 0u;          // the full ranking's partial sums start from zero
+    if (t == 0) *counter = ok ? M : 0xffffffffu;
 }
-// rank_out[gene] for every candidate (zeroed by k_hvg_gather; the others keep 0xffffffff): candidates above it under
-// (variance desc, index asc).  Block (x, y): candidates 256 x .. against the y-th tile of the candidate list; partial ranks
-// are summed with integer atomics.
+// rank_out[gene] for every candidate: candidates above it under (variance desc, index asc).  Pair (x, y): candidates 256 x ..
+// against the y-th tile of kCandTile of the candidate list; partial ranks are summed with integer atomics.  Where the
+// candidates cannot be used (`counter` = 0xffffffff: fewer than n, more than the list the launch was sized for, NaN variances)
+// the same workgroups walk the pairs of the FULL ranking instead.
 constexpr int kCandTile = 128;      // (512: 44 us per launch at c3 — each thread walks a whole tile; 128: four times the workgroups, a quarter of the walk)
-__global__ __launch_bounds__(256) void k_rank_candidates(const double* __restrict__ var, const uint32_t* __restrict__ counter,
-                                                         uint32_t n, uint32_t cap, const uint32_t* __restrict__ cand,
-                                                         uint32_t* __restrict__ rank_out) {
-    __shared__ double tv[kCandTile];
-    __shared__ uint32_t ti[kCandTile];
+__global__ __launch_bounds__(256) void k_rank_selected(const double* __restrict__ var, uint32_t G, const uint32_t* __restrict__ counter,
+                                                       const uint32_t* __restrict__ cand, uint32_t* __restrict__ rank_out) {
+    __shared__ double tile[kRankTile];
     const uint32_t M = *counter;
+    if (M == 0xffffffffu) {
+        const uint32_t gb = (G + 255) / 256, gy = (G + kRankTile - 1) / kRankTile;
+        for (uint32_t p = blockIdx.y * gridDim.x + blockIdx.x; p < gb * gy; p += gridDim.x * gridDim.y)
+            full_rank_pair(var, G, rank_out, p % gb, p / gb, tile);
+        return;
+    }
+    double* tv = tile;
+    uint32_t* ti = reinterpret_cast<uint32_t*>(tile + kCandTile);
     const uint32_t base = blockIdx.y * kCandTile;
-    if (M < n || M > cap || blockIdx.x * 256 >= M || base >= M) return;  // (uniform; M outside [n, cap]: the full ranking takes over)
+    if (blockIdx.x * 256 >= M || base >= M) return;           // (uniform)
     for (uint32_t e = threadIdx.x; e < kCandTile; e += 256) {
         const uint32_t g = base + e < M ? cand[base + e] : 0xffffffffu;
         ti[e] = g;
@@ -1122,59 +1168,54 @@ __global__ __launch_bounds__(256) void k_rank_candidates(const double* __restric
     }
     if (rank) atomicAdd(&rank_out[gi], rank);
 }
-// the fallback: with fewer than n candidates the ranks start from zero for the full count (k_hvg_rank_fallback)
-__global__ void k_rank_reset(const uint32_t* __restrict__ counter, uint32_t n, uint32_t cap, uint32_t G, uint32_t* __restrict__ rank_out) {
-    if (*counter >= n && *counter <= cap) return;
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < G) rank_out[j] = 0u;
-}
-
-// gene of rank r < n goes to sel_rank[r]; flag[gene] = rank < n
-__global__ void k_hvg_take(const uint32_t* __restrict__ rank, uint32_t G, uint32_t n, int32_t* __restrict__ sel_rank,
-                           uint8_t* __restrict__ flag) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= G) return;
-    const bool take = rank[j] < n;
-    flag[j] = take ? 1 : 0;
-    if (take) sel_rank[rank[j]] = (int32_t)j;
-}
 
 // One workgroup: selection bitmask + per-word prefix counts (what the compaction kernels stage in LDS), and
 // the per-slot (ascending gene order) centring / scaling vectors of the PCA from the all-cells moments
 // (pca/mod.rs:87-91: mean = sum/N, var = sumsq/N - mean^2, ddof 0); trace = sum_s dinv_s^2 ss_s, summed in a
 // fixed tree.  n_words <= 2048 (G <= 65536).
-__global__ __launch_bounds__(1024) void k_sel_finish(const uint8_t* __restrict__ flag, const double* __restrict__ sum,
+__global__ __launch_bounds__(1024) void k_sel_finish(const uint32_t* __restrict__ rank, const double* __restrict__ gene_var,
+                                                     const double* __restrict__ sum,
                                                      const double* __restrict__ sq, uint32_t G, uint32_t take, int n_words,
-                                                     double n_cells, int center, int scale, uint32_t* __restrict__ bits,
+                                                     double n_cells, int center, int scale, int32_t* __restrict__ sel_rank,
+                                                     int* __restrict__ status, uint32_t* __restrict__ bits,
                                                      uint32_t* __restrict__ prefix, double* __restrict__ mu,
                                                      double* __restrict__ sd, double* __restrict__ dinv,
                                                      double* __restrict__ trace) {
     __shared__ uint32_t s_bits[2048], s_pre[2048], s_wave[16];
     __shared__ double s_tr[1024];
+    __shared__ int s_nan;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    // two words per thread
-    uint32_t b[2] = {0u, 0u};
+    if (t == 0) s_nan = 0;
+    __syncthreads();
+    // the gene of rank r < take goes to sel_rank[r] and into the mask (two words per thread); a NaN variance anywhere is the
+    // status word's bit 0 (the reference panics there: select_hvg_host)
+    bool nan = false;
+    constexpr int kAhead = 8;                 // (the loads of eight rounds in flight)
+    for (uint32_t base = 0; base < (uint32_t)n_words * 32; base += 1024 * kAhead) {       // (a wave: 64 consecutive genes = two mask words)
+        uint32_t rk[kAhead];
+        double v[kAhead];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int w = 2 * t + h;
-        if (w < n_words) {
-            const uint32_t g0 = (uint32_t)w * 32;
-            uint32_t acc = 0;
-            if (g0 + 32 <= G) {
-                const uint4 f0 = *reinterpret_cast<const uint4*>(flag + g0), f1 = *reinterpret_cast<const uint4*>(flag + g0 + 16);
-                const uint32_t ws[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+        for (int a = 0; a < kAhead; ++a) {
+            const uint32_t g = base + a * 1024 + t;
+            rk[a] = g < G ? rank[g] : 0xffffffffu;
+            v[a] = g < G ? gene_var[g] : 0.0;
+        }
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc |= ((ws[q] >> (8 * r)) & 1u) << (4 * q + r);
-            } else {
-                for (int r = 0; r < 32; ++r)
-                    if (g0 + r < G && flag[g0 + r]) acc |= 1u << r;
-            }
-            b[h] = acc;
-            s_bits[w] = acc;
+        for (int a = 0; a < kAhead; ++a) {
+            const uint32_t g = base + a * 1024 + t;
+            nan |= v[a] != v[a];
+            const bool in = rk[a] < take;      // (a gene behind G: 0xffffffff, never below `take`)
+            if (in) sel_rank[rk[a]] = (int32_t)g;
+            const unsigned long long m = __ballot(in);
+            if (lane == 0 && (g >> 5) < (uint32_t)n_words) s_bits[g >> 5] = (uint32_t)m;
+            if (lane == 32 && (g >> 5) < (uint32_t)n_words) s_bits[g >> 5] = (uint32_t)(m >> 32);
         }
     }
+    if (nan) s_nan = 1;
+    __syncthreads();
+    uint32_t b[2] = {0u, 0u};
+    if (2 * t < n_words) b[0] = s_bits[2 * t];
+    if (2 * t + 1 < n_words) b[1] = s_bits[2 * t + 1];
     // exclusive scan of the popcounts: per-thread pair, wave scan, wave totals
     const uint32_t c0 = (uint32_t)__popc(b[0]), c1 = (uint32_t)__popc(b[1]);
     uint32_t inc = c0 + c1;
@@ -1227,7 +1268,10 @@ __global__ __launch_bounds__(1024) void k_sel_finish(const uint8_t* __restrict__
         if (t < half) s_tr[t] += s_tr[t + half];
         __syncthreads();
     }
-    if (t == 0) *trace = s_tr[0];
+    if (t == 0) {
+        *trace = s_tr[0];
+        *status = s_nan;
+    }
 }
 
 // Device-side HighlyVariable(n): fills the scratch buffers named below; nothing is read back.
@@ -1238,10 +1282,8 @@ int32_t select_hvg_device(srx_mat* m, uint64_t n, int center, int scale, HvgDev&
     const uint64_t take = n < G ? n : G;
     const int n_words = (int)((G + 31) / 32);
     double *d_var, *d_f;
-    uint8_t* d_flag;
     uint32_t* d_rank;
     SRX_TRY(scratch(ctx, "hvg_var", (G ? G : 1) * sizeof(double), (void**)&d_var));
-    SRX_TRY(scratch(ctx, "hvg_flag", (G ? G : 1) + 64, (void**)&d_flag));
     SRX_TRY(scratch(ctx, "hvg_rankv", (G ? G : 1) * sizeof(uint32_t), (void**)&d_rank));
     SRX_TRY(scratch(ctx, "hvg_rank", (take ? take : 1) * sizeof(int32_t), (void**)&out.d_sel_rank));
     SRX_TRY(scratch(ctx, "pca_selbits", (size_t)(2 * n_words ? 2 * n_words : 1) * sizeof(uint32_t), (void**)&out.d_bits));
@@ -1254,37 +1296,28 @@ int32_t select_hvg_device(srx_mat* m, uint64_t n, int center, int scale, HvgDev&
     out.d_trace = d_f + 3 * take;
     out.k = (int)take;
     out.n_words = n_words;
-    SRX_HIP(ctx, hipMemsetAsync(out.d_status, 0, 256, ctx->stream));
     const unsigned gb = (unsigned)((G + 255) / 256 ? (G + 255) / 256 : 1);
     const unsigned gy = (unsigned)((G + kRankTile - 1) / kRankTile ? (G + kRankTile - 1) / kRankTile : 1);
-    hipLaunchKernelGGL(k_gene_var, dim3(gb), dim3(256), 0, ctx->stream, m->d_cnt, m->d_sum, m->d_sq, G, d_var, out.d_status);
     static const bool full_rank = getenv("SRX_HVG_FULL_RANK") != nullptr;       // A/B switch: rank every gene
-    if (full_rank || take == 0 || G < (uint64_t)kRankSample) {
-        SRX_HIP(ctx, hipMemsetAsync(d_rank, 0, (G ? G : 1) * sizeof(uint32_t), ctx->stream));
-        hipLaunchKernelGGL(k_hvg_rank, dim3(gb, gy), dim3(256), 0, ctx->stream, d_var, (uint32_t)G, d_rank, (const uint32_t*)nullptr, 0u, 0u);
+    const bool all = full_rank || take == 0 || G < (uint64_t)kRankSample;
+    // four launches (round 4: eleven): variances; threshold + candidate list + the decision; the ranks; mask, vectors, status
+    hipLaunchKernelGGL(k_gene_var, dim3(gb), dim3(256), 0, ctx->stream, m->d_cnt, m->d_sum, m->d_sq, G, d_var, d_rank, all ? 0u : 0xffffffffu);
+    if (all) {
+        hipLaunchKernelGGL(k_hvg_rank, dim3(gb, gy), dim3(256), 0, ctx->stream, d_var, (uint32_t)G, d_rank);
     } else {
         uint32_t* d_cand;
-        double* d_thr;
-        SRX_TRY(scratch(ctx, "hvg_cand", ((G ? G : 1) + 4) * sizeof(uint32_t), (void**)&d_cand));
-        SRX_TRY(scratch(ctx, "hvg_thr", 2 * sizeof(double), (void**)&d_thr));
-        uint32_t* d_counter = reinterpret_cast<uint32_t*>(d_thr + 1);
-        SRX_HIP(ctx, hipMemsetAsync(d_rank, 0xff, (G ? G : 1) * sizeof(uint32_t), ctx->stream));
+        SRX_TRY(scratch(ctx, "hvg_cand", ((G ? G : 1) + 8) * sizeof(uint32_t), (void**)&d_cand));
+        uint32_t* d_counter = d_cand + G + 4;
         static const int force_miss = getenv("SRX_HVG_FORCE_MISS") ? 1 : 0;       // exercises the device-side fallback
-        hipLaunchKernelGGL(k_hvg_threshold, dim3(1), dim3(kRankSample), 0, ctx->stream, d_var, (uint32_t)G, (uint32_t)take, d_thr, d_counter,
-                           force_miss);
-        hipLaunchKernelGGL(k_hvg_gather, dim3(gb), dim3(256), 0, ctx->stream, d_var, (uint32_t)G, d_thr, d_counter, d_cand, d_rank);
         const uint32_t cap = (uint32_t)std::min<uint64_t>(G, std::max<uint64_t>(4 * take, 4096));
-        hipLaunchKernelGGL(k_rank_candidates, dim3((cap + 255) / 256, (cap + kCandTile - 1) / kCandTile), dim3(256), 0, ctx->stream, d_var,
-                           d_counter, (uint32_t)take, cap, d_cand, d_rank);
-        hipLaunchKernelGGL(k_rank_reset, dim3(gb), dim3(256), 0, ctx->stream, d_counter, (uint32_t)take, cap, (uint32_t)G, d_rank);
-        hipLaunchKernelGGL(k_hvg_rank, dim3(gb, gy), dim3(256), 0, ctx->stream, d_var, (uint32_t)G, d_rank, (const uint32_t*)d_counter,
-                           (uint32_t)take, cap);
+        hipLaunchKernelGGL(k_hvg_candidates, dim3(1), dim3(kSelThreads), 0, ctx->stream, d_var, (uint32_t)G, (uint32_t)take, cap, d_counter, d_cand,
+                           d_rank, force_miss);
+        hipLaunchKernelGGL(k_rank_selected, dim3((cap + 255) / 256, (cap + kCandTile - 1) / kCandTile), dim3(256), 0, ctx->stream, d_var,
+                           (uint32_t)G, d_counter, d_cand, d_rank);
     }
-    hipLaunchKernelGGL(k_hvg_take, dim3(gb), dim3(256), 0, ctx->stream, d_rank, (uint32_t)G, (uint32_t)take, out.d_sel_rank,
-                       d_flag);
-    hipLaunchKernelGGL(k_sel_finish, dim3(1), dim3(1024), 0, ctx->stream, d_flag, m->d_sum, m->d_sq, (uint32_t)G, (uint32_t)take, n_words,
-                       (double)m->n_rows_global, center, scale, out.d_bits, out.d_bits + n_words, out.d_mu, out.d_sd,
-                       out.d_dinv, out.d_trace);
+    hipLaunchKernelGGL(k_sel_finish, dim3(1), dim3(1024), 0, ctx->stream, d_rank, d_var, m->d_sum, m->d_sq, (uint32_t)G, (uint32_t)take, n_words,
+                       (double)m->n_rows_global, center, scale, out.d_sel_rank, out.d_status, out.d_bits, out.d_bits + n_words, out.d_mu,
+                       out.d_sd, out.d_dinv, out.d_trace);
     SRX_HIP(ctx, hipGetLastError());
     return SRX_OK;
 }

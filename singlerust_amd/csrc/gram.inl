@@ -132,9 +132,19 @@ template <typename VT>
 __global__ __launch_bounds__(kBucketThreads) void k_bucket(const int64_t* __restrict__ rm_ptr, const GramPk<VT>* __restrict__ rm,
                                                            uint64_t n_rows, uint32_t rblk, int k, int sr_shift, int n_wg, int n_stripes,
                                                            const int64_t* __restrict__ rec_base, uint32_t* __restrict__ boff,
-                                                           GramRec<VT>* __restrict__ recs, uint32_t* __restrict__ gstat /* gram_stat() */) {
+                                                           GramRec<VT>* __restrict__ recs, uint32_t* __restrict__ gstat /* gram_stat() */,
+                                                           int64_t n_recs, double* __restrict__ zero_g, uint64_t n_zero_g) {
     extern __shared__ double lds_raw[];
     __shared__ uint32_t s_stat[3];
+    // side jobs that used to be memset launches in front of this kernel (4-5 us each on the step's critical path): the
+    // kGramUnroll records behind the last one (the stripe kernel's batches read past the end) and, for a fresh sum, the packed
+    // triangle the stripe kernel adds into
+    if (blockIdx.x == 0)
+        for (uint32_t e = threadIdx.x; e < kGramUnroll * sizeof(GramRec<VT>) / 4; e += kBucketThreads)
+            reinterpret_cast<uint32_t*>(recs + n_recs)[e] = 0u;
+    if (zero_g)
+        for (uint64_t e = (uint64_t)blockIdx.x * kBucketThreads + threadIdx.x; e < n_zero_g; e += (uint64_t)gridDim.x * kBucketThreads)
+            zero_g[e] = 0.0;
     if (threadIdx.x < 3) s_stat[threadIdx.x] = 0u;
     uint32_t* hist = reinterpret_cast<uint32_t*>(lds_raw);        // n_wg + 1 counters, then rblk + 1 row ends
     uint32_t* rptr = hist + n_wg + 1;                             // row starts of the block, relative to its first entry

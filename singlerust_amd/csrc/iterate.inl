@@ -375,8 +375,9 @@ __global__ void k_identity_block(int k, double* __restrict__ W) {
 // (z0 .. z2, nullable: blocks of the same shape left ZEROED — the destinations of the warm-up's applications of C, which
 //  accumulate into zeroed blocks: no memset launch in front of any of them)
 __global__ void k_init_block(uint64_t seed, int k, int l_act, double* __restrict__ Wp, double* __restrict__ z0, double* __restrict__ z1,
-                             double* __restrict__ z2) {
+                             double* __restrict__ z2, uint32_t* __restrict__ zw, int n_zw /* words zeroed besides (the solver's status block) */) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = e; i < n_zw; i += gridDim.x * blockDim.x) zw[i] = 0u;
     if (e >= k * L) return;
     if (z0) z0[e] = 0.0;
     if (z1) z1[e] = 0.0;

@@ -161,7 +161,7 @@ static int32_t pca_device(srx_mat* m, const uint64_t* sel, uint64_t k64, const s
         SRX_TRY(build_compact(m, remap, k, cc, rm));
         if (need_t256) SRX_TRY(retile(m, cc, KT, t256));
     }
-    if (!need_t256) SRX_TRY(build_row_order(ctx, rm));      // the transform walks rows by length
+    if (!need_t256 && !rm.perm) SRX_TRY(build_row_order(ctx, rm));      // the transform walks rows by length (the fused compaction has made it already)
     st.info = srx_pca_info{};
     st.info.n_cells_global = Ng;
     st.info.k = (uint32_t)k;

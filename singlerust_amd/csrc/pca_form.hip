@@ -288,22 +288,31 @@ int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words, int k,
         d_nrecs = rec_base + g.n_rblk;
     }
     int64_t total = 0;
-    if (d_nrecs) {                            // {records, compacted size}: ONE copy (the scan kernel put the second number next to the first)
+    {                                         // {records, compacted size}: ONE copy (the scan kernel put the second number next to the first)
         int64_t both[2] = {0, 0};
-        SRX_TRY(d2h(ctx, both, d_nrecs, sizeof both));
-        rm.n_recs = both[0];
-        total = both[1];
-    } else {
-        SRX_TRY(d2h(ctx, &total, d_total, sizeof(int64_t)));
+        SRX_TRY(d2h_begin(ctx, d_nrecs ? (const void*)d_nrecs : (const void*)d_total, d_nrecs ? sizeof both : sizeof(int64_t)));
+        // the order of the rows by length (what the transform walks) needs the row pointers only: queued HERE, it runs while
+        // the host is woken by the copy (the device used to idle through that round trip, ~30 us per step)
+        if (!t256p) {
+            rm.n_rows = N;
+            SRX_TRY(build_row_order(ctx, rm));
+        }
+        SRX_TRY(d2h_end(ctx, both, d_nrecs ? sizeof both : sizeof(int64_t)));
+        if (d_nrecs) {
+            rm.n_recs = both[0];
+            total = both[1];
+        } else {
+            total = both[0];
+        }
     }
     if (t256p) {
         SRX_TRY(scan_exclusive(ctx, cnt256, n256, t256.tptr, nullptr));
         SRX_TRY(alloc_tiled(m, N, (uint64_t)total, k, KT, t256));
     }
     SRX_TRY(scratch(ctx, "pca_rm_pk", ((size_t)total + 64) * pb, &rm.pk));
-    // the 64 entries behind the last row are READ by the forward kernel (a row's last chunk runs past its end: value masked
-    // to 0, column used as is): they must name a real column, or 0 x panel[garbage] is NaN
-    SRX_HIP(ctx, hipMemsetAsync((char*)rm.pk + (size_t)total * pb, 0, 64 * pb, ctx->stream));
+    // (the 64 entries behind the last row, read by the forward kernel: zeroed by the fill kernel — the list route's by its
+    //  first workgroup, the others by a memset)
+    if (!list) SRX_HIP(ctx, hipMemsetAsync((char*)rm.pk + (size_t)total * pb, 0, 64 * pb, ctx->stream));
     rm.n_rows = N;
     rm.nnz = (uint64_t)total;
     rm.k = k;
@@ -400,8 +409,9 @@ static int32_t ensure_comm_streams(srx_ctx* ctx) {
 // Whether the exchange is split is decided from rank-invariant data only (k, the communicator): a rank WITHOUT rows — more
 // ranks than non-empty rows, a skewed cut, a filter that emptied a shard — skips the kernels and issues the same three
 // collectives with the same counts as everybody else.
+// `zero_first`: a fresh sum — the triangle is zeroed on the way (by the bucket pass; a rank without rows: a memset)
 template <typename VT>
-int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce) {
+int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce, bool zero_first) {
     if (reduce) *reduce = false;
     GramPlan g;
     SRX_TRY(gram_plan(ctx, rm.k, rm.n_rows, g, rm.n_rows ? (double)rm.nnz / (double)rm.n_rows : 0.0, (int)sizeof(GramPk<VT>)));
@@ -412,6 +422,7 @@ int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce) 
     // (sharded rows: the accumulation mode is decided from the statistics of ALL ranks — one small all-reduce that a rank without
     //  rows makes too, below)
     const bool stat_exchange = reduce && ctx->n_ranks > 1;
+    if (zero_first && empty) SRX_HIP(ctx, hipMemsetAsync(Gp, 0, (size_t)rm.k * (rm.k + 1) / 2 * sizeof(double), ctx->stream));
     if (empty && !split && !stat_exchange) return SRX_OK;
     uint32_t* boff = nullptr;
     int64_t *blk_total = nullptr, *rec_base = nullptr;
@@ -435,11 +446,11 @@ int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce) 
         }
         SRX_TRY(scratch(ctx, "pca_brecs", ((size_t)n_recs + kGramUnroll) * sizeof(GramRec<VT>), (void**)&recs));
         if (ctx->prof_mask & (1u << SRX_K_BUCKET)) ctx->prof[SRX_K_BUCKET].bytes += (double)n_recs * sizeof(GramRec<VT>);
-        SRX_HIP(ctx, hipMemsetAsync(recs + n_recs, 0, kGramUnroll * sizeof(GramRec<VT>), ctx->stream));
         hipLaunchKernelGGL((k_bucket<VT>), dim3((unsigned)g.n_rblk), dim3(kBucketThreads),
                            (size_t)(g.n_wg + 1 + g.rblk + 1 + kBucketGroup) * sizeof(uint32_t), ctx->stream, rm.ptr,
                            (const GramPk<VT>*)rm.pk, rm.n_rows, g.rblk, rm.k, g.sr_shift, g.n_wg, g.n_stripes, rec_base, boff, recs,
-                           reinterpret_cast<uint32_t*>(rec_base + g.n_rblk + 2));
+                           reinterpret_cast<uint32_t*>(rec_base + g.n_rblk + 2), n_recs, zero_first ? Gp : (double*)nullptr,
+                           (uint64_t)rm.k * (rm.k + 1) / 2);
         SRX_HIP(ctx, hipGetLastError());
     }
     // Sharded rows: the fixed-point / f64 decision from the statistics of ALL ranks' compacted values (one more all-reduce of
@@ -516,8 +527,8 @@ int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce) 
     return SRX_OK;
 }
 
-template int32_t launch_gram<float>(srx_ctx*, const RowMajor&, double*, bool*);
-template int32_t launch_gram<double>(srx_ctx*, const RowMajor&, double*, bool*);
+template int32_t launch_gram<float>(srx_ctx*, const RowMajor&, double*, bool*, bool);
+template int32_t launch_gram<double>(srx_ctx*, const RowMajor&, double*, bool*, bool);
 
 }  // namespace srx
 

@@ -182,7 +182,7 @@ int32_t build_tiled_fused(srx_mat* m, const uint32_t* d_sel, int n_words, int k,
 int32_t build_tiled_fused(srx_mat* m, const std::vector<int32_t>& remap, int k, RowMajor& rm, Tiled* t256, RowXf xf = RowXf{},
                           bool want_recs = false);
 template <typename VT>
-int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce = nullptr);
+int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce = nullptr, bool zero_first = false);
 inline size_t gram_packed_count(int k) { return (size_t)k * (size_t)(k + 1) / 2; }
 
 // ---- pca_solve.hip: products, iteration, solver ------------------------------------------------------

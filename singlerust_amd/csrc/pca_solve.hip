@@ -413,8 +413,8 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
     // segment "start": random block, CholeskyQR2, warm-up sweeps (the first Ritz residuals are O(1) whatever
     // happens — no Rayleigh–Ritz step to learn that), first Ritz step
     auto seg_start = [&]() -> int32_t {
-        SRX_HIP(ctx, hipMemsetAsync(d_status, 0, kStatusBytes + (size_t)L * L * sizeof(double), ctx->stream));
         if (o.direct) {                    // W = I (k x k, k = l_act): H = C itself, Ritz pairs = eigenpairs whatever the rank
+            SRX_HIP(ctx, hipMemsetAsync(d_status, 0, kStatusBytes + (size_t)L * L * sizeof(double), ctx->stream));
             hipLaunchKernelGGL(k_identity_block, dim3((unsigned)((kl + 255) / 256)), dim3(256), 0, ctx->stream, k, w.W);
             SRX_HIP(ctx, hipGetLastError());
             if (acc_apply) SRX_HIP(ctx, hipMemsetAsync(w.Wp, 0, kl * 8, ctx->stream));      // (no start block, no CholeskyQR: nothing has zeroed it)
@@ -427,9 +427,11 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         const bool start_orth = o.robust || o.warm < 1;
         // (Gram solver: the start block goes into W and the three scratch blocks start zeroed; with start_orth the block goes
         //  into Wp, and the CholeskyQR that follows leaves the three zeroed)
+        // (the status words and the 64 x 64 projected matrix behind them start from zero: the start block's kernel does it)
         hipLaunchKernelGGL(k_init_block, dim3((unsigned)((kl + 255) / 256)), dim3(256), 0, ctx->stream, o.seed, k, l_act,
                            start_orth ? w.Wp : w.W, acc_apply && !start_orth ? w.Wp : (double*)nullptr,
-                           acc_apply ? w.A1 : (double*)nullptr, acc_apply ? w.T : (double*)nullptr);
+                           acc_apply ? w.A1 : (double*)nullptr, acc_apply ? w.T : (double*)nullptr, reinterpret_cast<uint32_t*>(d_status),
+                           (int)((kStatusBytes + (size_t)L * L * sizeof(double)) / 4));
         if (start_orth) {
             SRX_TRY(orth(w.Wp));
             SRX_TRY(orth(w.W));
@@ -704,10 +706,10 @@ int32_t run_pca(srx_ctx* ctx, const RowMajor* parts, int n_parts, const Tiled* t
     Work w;
     st.d_small = nullptr;
     SRX_TRY(alloc_work(ctx, k, w));
-    if (hv) {                          // selection made on the device: centring / scaling vectors are already there
-        if (o.center) SRX_HIP(ctx, hipMemcpyAsync(w.mu, hv->d_mu, (size_t)k * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (hv) {                          // selection made on the device: centring / scaling vectors are already there — read in place
+        if (o.center) w.mu = hv->d_mu;      // (they are only ever read; two device copies per step were 9 us on the critical path)
         else SRX_HIP(ctx, hipMemsetAsync(w.mu, 0, (size_t)k * 8, ctx->stream));
-        SRX_HIP(ctx, hipMemcpyAsync(w.d, hv->d_dinv, (size_t)k * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        w.d = hv->d_dinv;
     } else {
         SRX_TRY(h2d(ctx, w.mu, mu.data(), (size_t)k * 8));
         SRX_TRY(h2d(ctx, w.d, dinv.data(), (size_t)k * 8));
@@ -858,9 +860,8 @@ int32_t run_pca(srx_ctx* ctx, const RowMajor* parts, int n_parts, const Tiled* t
         if (!Pk) {
             Range r_("srx:gram");
             SRX_TRY(scratch(ctx, "pca_gpacked", n_packed * sizeof(double), (void**)&Pk));
-            SRX_HIP(ctx, hipMemsetAsync(Pk, 0, n_packed * sizeof(double), ctx->stream));
             bool reduced = false;
-            SRX_TRY(launch_gram<VT>(ctx, *rmp, Pk, &reduced));        // (sharded rows: the exchange overlaps the second half)
+            SRX_TRY(launch_gram<VT>(ctx, *rmp, Pk, &reduced, true));  // (a fresh sum: zeroed on the way; sharded rows: the exchange overlaps the second half)
             if (!reduced) SRX_TRY(allreduce_f64(ctx, Pk, n_packed));
         } else {
             SRX_TRY(allreduce_f64(ctx, Pk, n_packed));            // the one exchange of this solver: the packed upper triangle
