@@ -44,6 +44,10 @@ int32_t gram_plan(srx_ctx* ctx, int k, uint64_t n_rows, GramPlan& g, double entr
     g.lds_bytes = (size_t)sr * widest * 8;
     if (g.lds_bytes > 163840) return fail(ctx, SRX_E_ARG, "pca: %d selected features exceed the Gram kernel's LDS stripes", k);
     g.rblk = 512u;      // c3: bucket pass + stripe kernel 4.89 ms with 1024-cell blocks, 4.78 with 512, 5.07 with 256
+    // an owner record names its piece by a 32-bit BYTE offset from its row block's first entry (a row holds at most k entries of at
+    // most 16 bytes): 512 x 16384 x 16 = 2^27 — asserted, not assumed
+    if ((uint64_t)g.rblk * (uint64_t)k * 16u >= (1ull << 31))
+        return fail(ctx, SRX_E_ARG, "pca: %d selected features exceed the owner records' 32-bit offsets", k);
     g.n_rblk = (n_rows + g.rblk - 1) / g.rblk;
     const int per_cu = g.lds_bytes <= 65536 ? 2 : 1;
     // chunks of consecutive row blocks, at least one block per wave and enough chunks to fill the device.  Round 5, with the assembly
