@@ -269,7 +269,7 @@ class Bench:
         self.F.check(self.lib.srx_partition_rows(self.F.ptr(ip), n_global, self.world, self.F.ptr(cut)))
         return int(cut[self.rank]), int(cut[self.rank + 1])
 
-    def run(self, config, n_global, row0, row1, storage, steps, warmup, solver=0, hvg=None, skew=0, tolerate_noconv=False):
+    def run(self, config, n_global, row0, row1, storage, steps, warmup, solver=0, hvg=None, skew=0, tolerate_noconv=False, headline=False):
         """K timed pipeline steps on rows [row0, row1) of the synthetic matrix; returns the measurements of this rank
         (times already maxed over ranks)."""
         a, F, sr, lib, ctx = self.a, self.F, self.sr, self.lib, self.ctx
@@ -318,48 +318,77 @@ class Bench:
                    F.K_COMPACT: "hvg_compact", F.K_GRAM: "gram_sparse", F.K_BUCKET: "gram_bucket", F.K_ITERATE: "iterate",
                    F.K_DENSE: "dense_apply",
                    F.K_SPMM_FWD: "spmm_fwd", F.K_SPMM_T: "spmm_t"}
-        ctx.prof_enable(sum(1 << c for c in classes))
-        ctx.prof_reset()
-        elapsed, done = 0.0, 0
-        stage = {"normalize": 0.0, "moments": 0.0, "select": 0.0, "pca": 0.0}
-        iters = []
-        while done < steps:
-            if used >= n_copies:            # restoring copies from the pristine matrix is outside the clock
-                for c in copies:
-                    c.copy_values_from(pristine)
-                used = 0
-            chunk = min(steps - done, n_copies - used)
-            self.sync_all()
-            t0 = time.perf_counter()
-            for _ in range(chunk):
-                ts = time.perf_counter()
-                step(copies[used]); used += 1
-                if os.environ.get("SRX_BENCH_TRACE"):
-                    print(f"[bench] step {done} copy {used - 1}: {(time.perf_counter() - ts) * 1e3:.2f} ms host, "
-                          f"pca stage {res.ms_pca:.2f} ms", file=sys.stderr)
-                stage["normalize"] += res.ms_normalize; stage["moments"] += res.ms_moments
-                stage["select"] += res.ms_select; stage["pca"] += res.ms_pca
-                iters.append(int(res.pca.n_iter))
-            self.sync_all()
-            elapsed += time.perf_counter() - t0
-            done += chunk
-        if self.dist is not None:
-            elapsed = self.dist.allreduce_max(elapsed)
-        prof = {}
-        for cls_, name in classes.items():
-            ms, n, b = ctx.prof_get(cls_)
-            if n:
-                aux = ctx.prof_get_aux(cls_)
-                prof[name] = {"launches": n, "avg_ms": ms / n, "alg_bytes_per_launch": b / n,
-                              **({"aux_bytes_per_launch": aux / n} if aux else {}),
-                              "GBps": (b / n) / (ms / n * 1e-3) / 1e9 if ms > 0 else None,
-                              "frac_of_peak": (b / n) / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None}
+        stage_classes = (F.K_COMPACT, F.K_BUCKET, F.K_GRAM)      # the roofline object's stage (Gram formation)
+
+        def timed_pass(n_steps, mask):
+            """n_steps pipeline steps between two synchronisations, the class timers of `mask` on: seconds, per-class records,
+            the pipeline's own stage clocks, iteration counts."""
+            nonlocal used
+            ctx.prof_enable(mask)
+            ctx.prof_reset()
+            elapsed_, done = 0.0, 0
+            stage_ = {"normalize": 0.0, "moments": 0.0, "select": 0.0, "pca": 0.0}
+            iters_ = []
+            while done < n_steps:
+                if used >= n_copies:            # restoring copies from the pristine matrix is outside the clock
+                    for c in copies:
+                        c.copy_values_from(pristine)
+                    used = 0
+                chunk = min(n_steps - done, n_copies - used)
+                self.sync_all()
+                t0 = time.perf_counter()
+                for _ in range(chunk):
+                    ts = time.perf_counter()
+                    step(copies[used]); used += 1
+                    if os.environ.get("SRX_BENCH_TRACE"):
+                        print(f"[bench] step {done} copy {used - 1}: {(time.perf_counter() - ts) * 1e3:.2f} ms host, "
+                              f"pca stage {res.ms_pca:.2f} ms", file=sys.stderr)
+                    stage_["normalize"] += res.ms_normalize; stage_["moments"] += res.ms_moments
+                    stage_["select"] += res.ms_select; stage_["pca"] += res.ms_pca
+                    iters_.append(int(res.pca.n_iter))
+                self.sync_all()
+                elapsed_ += time.perf_counter() - t0
+                done += chunk
+            if self.dist is not None:
+                elapsed_ = self.dist.allreduce_max(elapsed_)
+            prof_ = {}
+            for cls_, name in classes.items():
+                if not (mask >> cls_) & 1:
+                    continue
+                ms, n, b = ctx.prof_get(cls_)
+                if n:
+                    aux = ctx.prof_get_aux(cls_)
+                    prof_[name] = {"launches": n, "avg_ms": ms / n, "alg_bytes_per_launch": b / n,
+                                   **({"aux_bytes_per_launch": aux / n} if aux else {}),
+                                   "GBps": (b / n) / (ms / n * 1e-3) / 1e9 if ms > 0 else None,
+                                   "frac_of_peak": (b / n) / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None}
+            return elapsed_, prof_, stage_, iters_
+
+        all_mask = sum(1 << c for c in classes)
+        breakdown = None
+        if headline:
+            # The K timed steps carry the class timers of the roofline object's stage only (compaction, owner records, stripe
+            # kernel: six event records per step); a timer is two event records around its launches, and with all eight classes
+            # on the records themselves cost 0.05-0.08 ms of a 9.7 ms step (measured: 9.74-9.81 against 9.66-9.74 with none).
+            # The other classes are timed in a SEPARATE pass of a few steps behind the clock, reported as such.
+            elapsed, prof, stage, iters = timed_pass(steps, sum(1 << c for c in stage_classes))
+            bd_steps = max(3, min(steps, 8))
+            bd_elapsed, bd_prof, _, _ = timed_pass(bd_steps, all_mask)
+            for name, rec in bd_prof.items():
+                if name not in prof:
+                    # (downstream divides a class's launches by the K timed steps: the record is scaled to K steps' worth)
+                    prof[name] = {**rec, "launches": rec["launches"] * steps / bd_steps, "timed_in": "breakdown pass"}
+            breakdown = {"steps": bd_steps, "ms_per_step": bd_elapsed / bd_steps * 1e3,
+                         "kernel_ms_per_step": {name: rec["avg_ms"] * rec["launches"] / bd_steps for name, rec in bd_prof.items()},
+                         "note": "all class timers on, behind the timed region: the source of every class time outside the Gram formation stage"}
+        else:
+            elapsed, prof, stage, iters = timed_pass(steps, all_mask)
         ctx.prof_enable(0)
         out = {"elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "nnz": nnz, "prof": prof,
                "stage_ms_per_step": {k_: v / steps for k_, v in stage.items()}, "iters": iters,
                "residual": float(res.pca.residual), "nnz_selected": int(res.pca.nnz_selected),
                "solver": {1: "gram", 2: "spmm"}.get(int(res.pca.solver), "?"), "generate_s": t_gen, "copies": n_copies,
-               "noconv_steps": len(failures), "genes": int(info.n_cols)}
+               "noconv_steps": len(failures), "genes": int(info.n_cols), "breakdown": breakdown}
         for c in copies:
             c.free()
         pristine.free()
@@ -861,7 +890,7 @@ def main():
     n_global = cells if scaling == "strong" or world == 1 else cells * world
     p = B.params(a.config, n_global, a.skew)
     row0, row1 = B.shard(p, n_global)
-    main_ = B.run(a.config, n_global, row0, row1, a.storage, a.steps, a.warmup, solver=a.solver, skew=a.skew)
+    main_ = B.run(a.config, n_global, row0, row1, a.storage, a.steps, a.warmup, solver=a.solver, skew=a.skew, headline=True)
     weak = None
     if world > 1 and scaling == "strong" and not a.lean:
         # the other reading of the scaling question: per-GPU work fixed (the config's cells on EVERY GPU)
@@ -1072,8 +1101,13 @@ def main():
                                   other_bounds("spmm_fwd", prof.get("spmm_fwd", {}), main_["nnz_selected"], row1 - row0)),
             "kernels": prof,
             "kernel_ms_per_step": per,
-            # step time outside every bracketed class (launch gaps, host waits, scans, small copies)
-            "unattributed_ms_per_step": main_["ms_per_step"] - serial,
+            # step time outside every bracketed class (launch gaps, host waits, scans, small copies) — of the breakdown pass, whose
+            # step carries all the class timers (its own step time minus its own class times); the timed steps carry three
+            "unattributed_ms_per_step": ((main_["breakdown"]["ms_per_step"] - sum(v for k_, v in main_["breakdown"]["kernel_ms_per_step"].items()
+                                                                                  if k_ not in ("dense_apply", "normalize_log1p")))
+                                         if main_.get("breakdown") else main_["ms_per_step"] - serial),
+            "class_timers": ({"timed_region": ["hvg_compact", "gram_bucket", "gram_sparse"], "breakdown_pass": main_["breakdown"]}
+                             if main_.get("breakdown") else None),
             "step_roofline": {"step_alg_bytes": step_alg, "step_aux_bytes": step_aux, "step_hbm_traffic": step_traffic,
                               "achieved_GBps": step_alg / (main_["ms_per_step"] * 1e-3) / 1e9,
                               "frac_of_peak": step_alg / (main_["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
