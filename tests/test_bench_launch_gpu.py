@@ -27,6 +27,7 @@ def test_two_rank_bench_line():
     lines0 = [ln for ln in outs[0][0].decode().splitlines() if ln.strip()]
     assert len(lines0) == 1, lines0                        # one JSON line, nothing else on rank 0's stdout
     assert not outs[1][0].decode().strip()                 # and nothing at all on the other rank's
+    assert len(lines0[0]) < 8000                           # a record the driver parses, not a document
     d = json.loads(lines0[0])
     # N > 1 defaults to STRONG scaling (BASELINE.json configs[3]: the same cells row-sharded over the GPUs) and carries a
     # `weak` block measured after it
@@ -60,6 +61,7 @@ def test_self_launch_two_ranks():
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
     assert len(lines) == 1, lines
+    assert len(lines[0]) < 8000
     d = json.loads(lines[0])
     c = d["config"]
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and c["cells_global"] == cells
@@ -92,10 +94,33 @@ def test_backed_run_across_two_ranks():
     assert p2.returncode == 0, p2.stderr.decode()[-3000:]
     d1 = json.loads([ln for ln in p1.stdout.decode().splitlines() if ln.strip()][-1])
     lines2 = [ln for ln in p2.stdout.decode().splitlines() if ln.strip()]
-    assert len(lines2) == 1
+    assert len(lines2) == 1 and len(lines2[0]) < 8000
     d2 = json.loads(lines2[0])
     assert d2["n_gpus"] == 2 and d2["config"]["cells_global"] == cells and d2["config"]["n_ranks_seen"] == 2
     r1, r2 = d1["runs"][0], d2["runs"][0]
     assert r2["cells_global_seen"] == cells == r1["cells_global_seen"]
     assert r1["residual"] < 1e-6 and r2["residual"] < 1e-6
     assert abs(d2["value"] - cells / (d2["ms_per_step"] * 1e-3)) <= 1e-6 * d2["value"]
+
+
+def test_default_command_prints_a_bounded_record():
+    """The driver's own command shape (one GPU, no --lean, every side block and the CPU baselines on — at a reduced cell count
+    so that the test stays short): ONE stdout line under 8000 bytes with roofline and cpu_baseline in it; the full document in
+    bench_full.json."""
+    cells = 60000
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--cells", str(cells), "--steps", "3", "--warmup", "1",
+           "--cpu-sample-cells", "2000"]
+    p = subprocess.run(cmd, env=_clean_env(SRX_BENCH_NO_C5="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, timeout=1200)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    assert len(lines[0]) < 8000, len(lines[0])
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "roofline_next",
+              "roofline_spmm", "cpu_baseline", "gpu_over_cpu"):
+        assert k in d, k
+    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert "note" not in lines[0]
+    with open(os.path.join(ROOT, "bench_full.json")) as fh:
+        full = json.loads(fh.read())
+    assert full["value"] == d["value"] and "kernels" in full and "strong_scaling_budget" in full
