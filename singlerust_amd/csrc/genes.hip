@@ -65,7 +65,12 @@ __device__ __forceinline__ void seg_bounds(const int64_t* __restrict__ indptr, c
 //  test and one ds_read_b64 instead of the ~30-instruction logarithm.  Bit-identical results, 16x fewer logarithms, and
 //  3.64 ms against 3.18: the four dependent LDS reads of a chunk queue behind the other waves' atomics, and the arithmetic
 //  they replace was what hid that latency.)
-template <typename T, typename I, bool XF, bool WB = false>
+// BL (round 6): the accumulators in BLOCKS of 32 genes — 32 sums (256 bytes: every bank once), then the 32 sums of squares — instead
+// of {sum, sum of squares} pairs side by side.  With the pairs a wave's 64 sum atomics only ever touch the banks 0, 1 mod 4 and its
+// 64 square atomics the banks 2, 3 mod 4: half of the LDS's bank pairs per instruction (68 % of the LDS pipe's active cycles were
+// bank conflicts, profiles/r05_pmc_gram.md).  One more VALU instruction per value for the address; the second atomic stays at an
+// immediate offset (256 bytes).
+template <typename T, typename I, bool XF, bool WB = false, bool BL = false>
 __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     const int64_t* __restrict__ indptr, const int64_t* __restrict__ tp, const I* __restrict__ idx,
     std::conditional_t<WB, T, const T>* __restrict__ vals, uint64_t n_rows, uint64_t n_cols, int n_tiles, int tile_genes,
@@ -76,9 +81,12 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
                                     // atomic at the instruction's immediate offset
     // behind the accumulators (tile_genes * 16 B): the log1p table
     // (the table from global memory instead — 2 KB, L1-resident, one vector load per value — was tried: 5.7 ms against 3.5)
-    const Log1pTabEntry* s_tab = reinterpret_cast<const Log1pTabEntry*>(reinterpret_cast<char*>(lds) + (size_t)tile_genes * 16);
+    const int tile_pad = BL ? (tile_genes + 31) & ~31 : tile_genes;
+    constexpr int kSqOff = BL ? 32 : 1;                      // 8-byte words between a gene's sum and its sum of squares
+    auto acc_slot = [](int g0) -> int { return BL ? ((g0 >> 5) << 6) + (g0 & 31) : 2 * g0; };
+    const Log1pTabEntry* s_tab = reinterpret_cast<const Log1pTabEntry*>(reinterpret_cast<char*>(lds) + (size_t)tile_pad * 16);
     if constexpr (XF) stage_log1p_table(const_cast<Log1pTabEntry*>(s_tab));
-    for (int g = threadIdx.x; g < 2 * tile_genes; g += kMomThreads) s_acc[g] = 0.0;
+    for (int g = threadIdx.x; g < 2 * tile_pad; g += kMomThreads) s_acc[g] = 0.0;
     __syncthreads();
 
     // The gene tiles of one row block run on the SAME XCD (consecutive workgroup ids go round the 8 XCDs): a row's tile segments
@@ -209,13 +217,13 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
                     const unsigned long long iq = (unsigned long long)__double_as_longlong(__builtin_fma(x0 * x0, fx_sq, kMagic));
                     // (a poisoned value adds nothing while the reduction still takes its magic bits off: the gene's sums are
                     //  replaced by NaN anyway)
-                    unsigned long long* a2 = reinterpret_cast<unsigned long long*>(s_acc) + 2 * g0;
+                    unsigned long long* a2 = reinterpret_cast<unsigned long long*>(s_acc) + acc_slot(g0);
                     __hip_atomic_fetch_add(a2, is, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(a2 + 1, iq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(a2 + kSqOff, iq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     continue;
                 }
-                __hip_atomic_fetch_add(&s_acc[2 * g0], x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(&s_acc[2 * g0 + 1], x0 * x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&s_acc[acc_slot(g0)], x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&s_acc[acc_slot(g0) + kSqOff], x0 * x0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     };
@@ -340,8 +348,8 @@ __global__ __launch_bounds__(kMomThreads) void k_gene_moments(
     for (int g = threadIdx.x; g < tile_genes; g += kMomThreads) {
         uint64_t gene = (uint64_t)gbase + g;
         if (gene < n_cols) {
-            part_sum[rb * n_cols + gene] = s_acc[2 * g];
-            part_sq[rb * n_cols + gene] = s_acc[2 * g + 1];
+            part_sum[rb * n_cols + gene] = s_acc[acc_slot(g)];
+            part_sq[rb * n_cols + gene] = s_acc[acc_slot(g) + kSqOff];
         }
     }
 }
@@ -766,7 +774,10 @@ static int32_t local_moments(srx_mat* m, double** packed_out, RowXf xf = RowXf{}
     // the per-gene counts depend on the sparsity pattern only: counted once per pattern (here, or by srx_matrix_prepare), kept
     // on the matrix (clones inherit them)
     SRX_TRY(ensure_pattern_counts(m));
-    const size_t lds = (size_t)m->tile_genes * 16 + (xf.row_sum ? (size_t)kLog1pTabBytes : 0);
+    // SRX_MOM_BLOCKED=1: the accumulators in blocks of 32 genes (no half-bank restriction; measured slower: 2.81 against 2.75 ms,
+    // profiles/r06_knockouts.md); default: the {sum, sum of squares} pairs
+    const bool blocked = xf.row_sum && getenv("SRX_MOM_BLOCKED") && atoi(getenv("SRX_MOM_BLOCKED"));
+    const size_t lds = (size_t)(blocked ? (m->tile_genes + 31) & ~31 : m->tile_genes) * 16 + (xf.row_sum ? (size_t)kLog1pTabBytes : 0);
     // s_i = 2 when the 16-bit index mirror exists (n_cols <= 65536), 4 otherwise
     const double bytes = (double)m->nnz * ((m->n_cols <= 65536 ? 2.0 : 4.0) + val_bytes(m)) + (double)(m->n_rows + 1) * 8.0 +
                          (double)G * 24.0 + (xf.row_sum ? (double)m->n_rows * 8.0 : 0.0) +
@@ -797,7 +808,9 @@ static int32_t local_moments(srx_mat* m, double** packed_out, RowXf xf = RowXf{}
         auto pick = [&](auto tval, auto tidx, const auto* idxp, const auto* valp) -> int32_t {
             using T = decltype(tval);
             using I = decltype(tidx);
+            if (xf.row_sum && xf.write_back && blocked) return launch(k_gene_moments<T, I, true, true, true>, idxp, const_cast<T*>(valp));
             if (xf.row_sum && xf.write_back) return launch(k_gene_moments<T, I, true, true>, idxp, const_cast<T*>(valp));
+            if (xf.row_sum && blocked) return launch(k_gene_moments<T, I, true, false, true>, idxp, valp);
             if (xf.row_sum) return launch(k_gene_moments<T, I, true>, idxp, valp);
             return launch(k_gene_moments<T, I, false>, idxp, valp);
         };

@@ -85,6 +85,15 @@ template <> struct Vec4<double> {
     __device__ __forceinline__ double& operator[](int i) { return i == 0 ? a.x : i == 1 ? a.y : i == 2 ? b.x : b.y; }
 };
 
+// f(integral_constant<int, I>) for I = 0 .. N-1: a loop whose index is a compile-time constant in the body
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
 // DPP row rotate inside each 16-lane row (v_mov_b32_dpp row_ror:S) — no LDS traffic.
 template <int S>
 __device__ __forceinline__ int ror16(int x) {

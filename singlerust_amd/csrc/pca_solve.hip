@@ -50,9 +50,42 @@ template <typename VT, typename PT>
 bool fwd_rows_fits(int) { return true; }
 template bool fwd_rows_fits<float, float>(int);
 template bool fwd_rows_fits<double, double>(int);
+// Forward product by gene ranges of the whole panel, one quad per row (k_spmm_ranges): f32 entries and panels, rows in
+// length order, 32-bit record offsets, at most 8 ranges (k <= 4096: beyond, a row's run per range is too short to fill chunks).
+// NOT the default: conflict-free in the LDS and one walk of the matrix, and 0.89 ms against the column-slice kernel's 0.62 at c3
+// (profiles/r06_pmc_spmm.md: 62 % of its wave-cycles waiting — the accumulators of a block's rows, held in registers across the
+// range phases, leave no room for the 16 panel reads in flight the column-slice kernel hides its LDS latency with, and every
+// phase starts with 128 KB of panel through one barrier).  SRX_FWD_RANGES=1 runs it (parity tests, the profile's table).
+static bool fwd_ranges_on() {
+    const char* e = getenv("SRX_FWD_RANGES");          // (read per launch: the parity tests switch kernels inside one process)
+    return e && atoi(e) != 0;
+}
+template <int S, int NT, int D>
+static int32_t launch_fwd_ranges(srx_ctx* ctx, const RowMajor& r, const float* P, const float* cvec, int n_cols, double* scores, float* Y,
+                                 int ld) {
+    constexpr int G = RgCfg<float>::kGenes;
+    const size_t lds = (size_t)G * L * sizeof(float);
+    const uint64_t n_slots = (r.n_rows + 15) / 16;
+    uint64_t n_wg = (n_slots + (uint64_t)(NT / 64) * S - 1) / ((uint64_t)(NT / 64) * S);
+    if (n_wg > (uint64_t)ctx->n_cus) n_wg = (uint64_t)ctx->n_cus;      // one workgroup per CU (the range fills the LDS)
+    if (n_wg < 1) n_wg = 1;
+    const double out_bytes = scores ? (double)r.n_rows * n_cols * 8.0 : (double)r.n_rows * L * sizeof(float);
+    ProfScope ps(ctx, SRX_K_SPMM_FWD, (double)r.nnz * sizeof(GramPk<float>) + (double)(r.n_rows + 1) * 8.0 + out_bytes +
+                                          (double)r.k * L * sizeof(float) + (r.perm ? (double)r.n_rows * 4.0 : 0.0));
+    SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_spmm_ranges<float, float, S, NT, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_spmm_ranges<float, float, S, NT, D>), dim3((unsigned)n_wg), dim3(NT), lds, ctx->stream, r.ptr,
+                       (const GramPk<float>*)r.pk, (const uint32_t*)r.perm, r.n_rows, r.k, P, cvec, n_cols, scores, Y, ld);
+    SRX_HIP(ctx, hipGetLastError());
+    return SRX_OK;
+}
+
 template <typename VT, typename PT>
 static int32_t launch_fwd_rows(srx_ctx* ctx, const RowMajor& r, const PT* P, const PT* cvec, int n_cols, double* scores, PT* Y,
                                int ld) {
+    if constexpr (std::is_same<VT, float>::value && std::is_same<PT, float>::value) {
+        if (fwd_ranges_on() && r.nnz + 256 < (1ull << 32) && r.k <= 8 * RgCfg<float>::kGenes && n_cols <= L)
+            return launch_fwd_ranges<2, 1024, 2>(ctx, r, P, cvec, n_cols, scores, Y, ld);
+    }
     const int Qr = fwd_rows_q<PT>(r.k);
     auto go = [&](auto qtag, auto rtag, auto cltag, int k_lo, int k_hi, int accumulate) -> int32_t {
         constexpr int Q = decltype(qtag)::value;
@@ -1080,7 +1113,14 @@ int32_t srx_spmm(srx_mat* m, const uint64_t* sel, uint64_t k64, const double* pa
             std::vector<PT> hp(kl + L, PT(0));
             for (size_t e = 0; e < kl; ++e) hp[e] = (PT)panel[e];
             SRX_TRY(h2d(ctx, P, hp.data(), (kl + L) * sizeof(PT)));
-            SRX_TRY((launch_fwd<VT, PT>(ctx, c, P, P + kl, Y)));
+            // SRX_SPMM_ROWS=1 (kernel-level parity tests): the product from the row-major records — the kernels the transform
+            // runs (k_spmm_ranges, or k_spmm_rows under SRX_FWD_RANGES=0) — instead of the tile-major view
+            if (getenv("SRX_SPMM_ROWS") && atoi(getenv("SRX_SPMM_ROWS"))) {
+                if (!crm.perm) SRX_TRY(build_row_order(ctx, crm));
+                SRX_TRY((launch_fwd_rows<VT, PT>(ctx, crm, P, P + kl, L, (double*)nullptr, Y, L)));
+            } else {
+                SRX_TRY((launch_fwd<VT, PT>(ctx, c, P, P + kl, Y)));
+            }
             if (y_out) {
                 std::vector<PT> hy(c.n_rows * (size_t)L);
                 SRX_TRY(d2h(ctx, hy.data(), Y, hy.size() * sizeof(PT)));

@@ -483,6 +483,198 @@ __global__ __launch_bounds__(kFwdRowsThreads) void k_spmm_rows(
     }
 }
 
+// ---- forward SpMM over gene RANGES of the whole 64-column panel, one QUAD per row (round 6) -------------------------
+// k_spmm_rows above cuts the panel's COLUMNS (16 per workgroup): a gene of the slice is 64 bytes, so the four rows a
+// ds_read_b128 serves per LDS cycle (its fixed lane groups of 16) hit four 16-bank windows chosen by gene mod 4 — 2.1 cycles per
+// read on random genes (half of the LDS pipe's time is bank conflicts, profiles/r05_pmc_spmm.md) — and the matrix is walked once
+// per slice (4 walks for n_pc = 50).  Here the panel's GENES are cut instead: the LDS holds all 64 columns of G = 512 genes
+// (256 bytes per gene, 128 KB) and the workgroup walks the ranges in phases over a block of 256 S rows whose accumulators stay
+// in registers.  Entries of a row are column-sorted, so phase r consumes the run [cursor, first j >= hi) and leaves the cursor
+// for phase r + 1: the matrix is read ONCE.
+// A row is taken by the four lanes of a quad: lane w owns the 16 columns 16 w .. 16 w + 15 as four 16-byte pieces, and reads
+// piece (i + quad) mod 4 with its i-th ds_read_b128 — the hardware serves a b128 read in fixed groups of 16 lanes
+// {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, .. whose four quads have four different (quad mod 4): their 16 reads cover the 64
+// banks once whatever the genes.  CONFLICT-FREE (SQ_LDS_BANK_CONFLICT = 0, profiles/r06_pmc_spmm.md).
+// A wave holds 16 rows at a time, in lockstep: rows come in length order (`perm`), 16 neighbours per wave slot, slots dealt
+// round-robin over all waves of the grid.  A lane loads 8 consecutive records of its row's run (a quad: a chunk of 32) and
+// entry t of the chunk reaches the quad's lanes by a quad_perm DPP broadcast from lane t / 8.
+// (First form of the round, one 16-LANE group per row with the chunk replicated in its four quads: conflict-free too, but the
+//  per-record preparation and the record loads were done four times over — 2.5e8 VALU instructions against the column-slice
+//  kernel's 1.7e8 — 0.82 ms against 0.62: profiles/r06_knockouts.md.)
+template <typename PT> struct RgCfg;
+template <> struct RgCfg<float> { static constexpr int kGenes = 512; };
+template <> struct RgCfg<double> { static constexpr int kGenes = 256; };
+
+template <typename VT, typename PT, int S /* wave slots (rows per quad) per block, <= 4 */, int kRgThreads /* 512: 256 registers a wave */,
+          int kDeep /* entries whose panel reads are in flight together */>
+__global__ __launch_bounds__(kRgThreads) void k_spmm_ranges(
+    const int64_t* __restrict__ rm_ptr, const GramPk<VT>* rm /* NOT __restrict__: the prefetches must stay where they are issued */,
+    const uint32_t* __restrict__ perm /* nullable */, uint64_t n_rows, int k, const PT* __restrict__ P /* k x 64 */,
+    const PT* __restrict__ cvec /* 64 */, int n_cols, double* __restrict__ scores /* n_rows x ld f64 (nullable) */,
+    PT* __restrict__ Y /* n_rows x 64 (nullable) */, int ld) {
+    static_assert(S >= 1 && S <= 4, "a lane of the quad keeps one slot's cursor");
+    static_assert(kDeep >= 1 && kDeep <= 8 && 8 % kDeep == 0, "groups of entries inside a lane's 8 records");
+    constexpr int G = RgCfg<PT>::kGenes;
+    constexpr int RPL = sizeof(VT) == 4 ? 8 : 4;                // records per lane and chunk
+    constexpr int kChunk = 4 * RPL;
+    constexpr int kRowBytes = L * (int)sizeof(PT);
+    constexpr int kPiece = 4 * (int)sizeof(PT);                 // one ds_read: four columns
+    constexpr int kWaves = kRgThreads / 64;
+    extern __shared__ double lds_raw[];
+    char* panel = reinterpret_cast<char*>(lds_raw);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (scalar: slot arithmetic in SGPRs)
+    const int quad = lane >> 2, w4 = lane & 3;
+    const uint64_t n_waves = (uint64_t)gridDim.x * kWaves;
+    const uint64_t W = (uint64_t)blockIdx.x * kWaves + wave;
+    const uint64_t n_slots = (n_rows + 15) / 16;
+    const uint64_t per_wave = (n_slots + n_waves - 1) / n_waves;
+    const int n_blocks = (int)((per_wave + S - 1) / S);         // the same for every wave: the phases are barriers
+    const int n_ranges = (k + G - 1) / G;
+    // piece i of this lane: columns 16 w4 + 4 ((i + quad) & 3) .. + 3 (pcb: its byte offset in a gene's panel row)
+    int pc[4], pcb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        pc[i] = 16 * w4 + 4 * ((i + quad) & 3);
+        pcb[i] = pc[i] * (int)sizeof(PT);
+    }
+    struct Chunk { GramPk<VT> r[RPL]; };
+    auto load_chunk = [&](Chunk& c, uint32_t at) {
+        const GramPk<VT>* p = rm + at + RPL * w4;               // (the array is padded by a wave of records)
+#pragma unroll
+        for (int u = 0; u < RPL; ++u) c.r[u] = p[u];
+    };
+    auto row_of = [&](int b, int s_) -> uint64_t {              // the row of this lane's quad in slot s_ of block b, or n_rows
+        const uint64_t pos = 16 * (((uint64_t)b * S + s_) * n_waves + W) + quad;
+        if (pos >= n_rows) return n_rows;
+        return perm ? (uint64_t)perm[pos] : pos;
+    };
+    for (int b = 0; b < n_blocks; ++b) {
+        // lane w of a quad keeps the cursor and the end of the quad's row in slot w
+        uint32_t curv = 0u, endv = 0u;
+        if (w4 < S) {
+            const uint64_t row = row_of(b, w4);
+            if (row < n_rows) {
+                curv = (uint32_t)rm_ptr[row];
+                endv = (uint32_t)rm_ptr[row + 1];
+            }
+        }
+        PT acc[S][4][4];
+#pragma unroll
+        for (int s_ = 0; s_ < S; ++s_)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[s_][i][0] = acc[s_][i][1] = acc[s_][i][2] = acc[s_][i][3] = PT(0);
+        for (int r = 0; r < n_ranges; ++r) {
+            const int lo = r * G, hi = lo + G < k ? lo + G : k;
+            __syncthreads();                                    // everyone is done with the previous range
+            for (int e = threadIdx.x; e < G * (L / 4); e += kRgThreads) {
+                const int jl = e / (L / 4), c4 = e % (L / 4);
+                Vec4<PT> v;
+                if (lo + jl < k) v.load(P + (size_t)(lo + jl) * L + c4 * 4);
+                else v[0] = v[1] = v[2] = v[3] = PT(0);         // (a masked entry multiplies whatever gene its low bits name by 0)
+                v.store(reinterpret_cast<PT*>(panel + (size_t)jl * kRowBytes) + c4 * 4);
+            }
+            __syncthreads();
+            // one chunk: count the entries of this range (a prefix: columns ascend), multiply them, move the cursor
+            auto process = [&](Chunk& ch, uint32_t& c, uint32_t e, PT (&a)[4][4]) -> bool {
+                const int rem = (int)(e - c) - RPL * w4;          // entries of the row left from this lane's first record on
+                int t8[RPL];
+                PT val[RPL];
+                int cnt = 0;
+#pragma unroll
+                for (int u = 0; u < RPL; ++u) {
+                    const int j = ch.r[u].j;
+                    const bool ok = u < rem && j < hi;
+                    cnt += ok ? 1 : 0;
+                    val[u] = ok ? (PT)ch.r[u].v : PT(0);
+                    t8[u] = (j & (G - 1)) * kRowBytes;
+                }
+                cnt += __builtin_amdgcn_update_dpp(0, cnt, 0xb1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
+                cnt += __builtin_amdgcn_update_dpp(0, cnt, 0x4e, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    if (!__any(cnt > RPL * w)) break;
+                    // kDeep entries at a time: their 4 kDeep panel reads, then their multiply-adds; the barrier keeps the
+                    // scheduler from hoisting the reads of every entry of the chunk
+#pragma unroll
+                    for (int u0 = 0; u0 < RPL; u0 += kDeep) {
+                        if (u0 > 0 && !__any(cnt > RPL * w + u0)) break;
+                        Vec4<PT> pv[kDeep][4];
+#pragma unroll
+                        for (int d = 0; d < kDeep; ++d) {
+                            const int tb = quad_bcast<4>(t8[u0 + d], w);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) pv[d][i].load(reinterpret_cast<const PT*>(panel + tb + pcb[i]));
+                        }
+#pragma unroll
+                        for (int d = 0; d < kDeep; ++d) {
+                            const PT v = quad_bcast_v<4>(val[u0 + d], w);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                a[i][0] += v * pv[d][i][0];
+                                a[i][1] += v * pv[d][i][1];
+                                a[i][2] += v * pv[d][i][2];
+                                a[i][3] += v * pv[d][i][3];
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                c += (uint32_t)cnt;
+                return __any(cnt == kChunk) != 0;
+            };
+            Chunk A, B;
+            load_chunk(A, (uint32_t)quad_bcast<4>((int)curv, 0));
+            static_for<S>([&](auto tag) {
+                constexpr int s_ = decltype(tag)::value;
+                uint32_t c = (uint32_t)quad_bcast<4>((int)curv, s_);
+                const uint32_t e = (uint32_t)quad_bcast<4>((int)endv, s_);
+                // the next slot's first chunk is in flight while this one is multiplied (its cursor is the previous phase's)
+                if constexpr (s_ + 1 < S) load_chunk(B, (uint32_t)quad_bcast<4>((int)curv, s_ + 1));
+                asm volatile("" ::: "memory");
+                // (nothing of this slot's arithmetic above the loads: a compare of chunk A hoisted there makes the wave wait for A
+                //  before it has issued B)
+                __builtin_amdgcn_sched_barrier(0);
+                bool more = process(A, c, e, acc[s_]);
+                while (more) {                                  // a run longer than a chunk: rare (mean 18 entries of 32)
+                    load_chunk(A, c);
+                    more = process(A, c, e, acc[s_]);
+                }
+                curv = w4 == s_ ? c : curv;
+                if constexpr (s_ + 1 < S) A = B;
+            });
+        }
+        // the block's rows: centring term, then the scores (f64, obsm["X_pca"] layout) or the panel product
+#pragma unroll
+        for (int s_ = 0; s_ < S; ++s_) {
+            const uint64_t row = row_of(b, s_);
+            if (row >= n_rows) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col0 = pc[i];
+                Vec4<PT> cv4;
+                cv4.load(cvec + col0);
+                const PT o0 = acc[s_][i][0] - cv4[0], o1 = acc[s_][i][1] - cv4[1], o2 = acc[s_][i][2] - cv4[2], o3 = acc[s_][i][3] - cv4[3];
+                if (scores) {
+                    double* dst = scores + row * (uint64_t)ld + col0;
+                    if (col0 + 3 < n_cols && ld % 2 == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0) {
+                        *reinterpret_cast<double2*>(dst) = double2{(double)o0, (double)o1};
+                        *reinterpret_cast<double2*>(dst + 2) = double2{(double)o2, (double)o3};
+                    } else {
+                        if (col0 + 0 < n_cols) dst[0] = (double)o0;
+                        if (col0 + 1 < n_cols) dst[1] = (double)o1;
+                        if (col0 + 2 < n_cols) dst[2] = (double)o2;
+                        if (col0 + 3 < n_cols) dst[3] = (double)o3;
+                    }
+                } else {
+                    Vec4<PT> o;
+                    o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
+                    o.store(Y + row * L + col0);
+                }
+            }
+        }
+    }
+}
+
 // ---- transposed SpMM: T = A^T Y (k x l), s = 1^T Y ---------------------------------------------
 // Workgroup = (gene tile, row block), 1024 threads; the tile's 256 x 64 accumulators live in
 // LDS (128 KiB as f64).  A wave takes 16 consecutive cells at a time: their tile segments

@@ -329,6 +329,68 @@ def test_spmm_and_gram_kernels_vs_scipy(ctx, store, n, g, density, k):
     assert np.array_equal(gram, want_g)                     # integer counts: exact in f64, any order
 
 
+@pytest.mark.parametrize("kernel", ["ranges", "rows"])
+@pytest.mark.parametrize("k", [64, 512, 513, 1500, 2000, 4096, 4100])
+def test_forward_spmm_from_row_major_records(ctx, kernel, k, monkeypatch):
+    """The transform's kernel k_spmm_rows (column slices of the panel in LDS) and round 6's k_spmm_ranges (one quad per row, gene
+    ranges of 512 through the LDS, chunks of 32 records; built, conflict-free, slower: SRX_FWD_RANGES=1) against scipy, through srx_spmm's row-major
+    route: rows of 0, 1, 31 .. 33, 63 .. 65 and 200 kept entries (chunk boundaries), runs of > 32 entries inside ONE gene range
+    (the rare second chunk of a run), rows whose entries all fall in the last range, a row count that is not a multiple of 16,
+    k on both sides of the range size and of the 8-range limit (4100: the launcher falls back on the column-slice kernel)."""
+    import scipy.sparse as sp
+    from singlerust_amd import _ffi
+    import singlerust_amd as sr
+    monkeypatch.setenv("SRX_SPMM_ROWS", "1")
+    monkeypatch.setenv("SRX_FWD_RANGES", "1" if kernel == "ranges" else "0")
+    rng = np.random.default_rng(k)
+    g = k + 37
+    lens = [0, 1, 2, 31, 32, 33, 0, 63, 64, 65, 200, 5, 17, 18, 19, 0, 1]
+    lens = [min(n, k) for n in lens] * 5 + [min(40, k)] * 2
+    rows, cols, vals = [], [], []
+    for r, n in enumerate(lens):
+        if r % 7 == 3 and k > 100:        # a run inside one range / at the top of the column space
+            lo = (k - 90) if r % 2 else (k // 2 // 512) * 512
+            c = lo + np.sort(rng.choice(min(90, k - lo), min(n, min(90, k - lo)), replace=False))
+        else:
+            c = np.sort(rng.choice(k, n, replace=False))
+        rows += [r] * len(c)
+        cols += list(c)
+        vals += list(rng.integers(1, 9, len(c)))
+    n_rows = len(lens)
+    assert n_rows % 16 != 0
+    sel = np.sort(rng.choice(g, k, replace=False)).astype(np.uint64)
+    x = sp.csr_matrix((np.array(vals, dtype=np.float64), (rows, sel[np.array(cols, dtype=np.int64)].astype(np.int64))), shape=(n_rows, g))
+    x.sort_indices()
+    a = sr.IMAnnData.new_basic(x, ctx=ctx, store=1)
+    P = rng.standard_normal((k, 64))
+    y = np.zeros((n_rows, 64))
+    _ffi.check(_ffi.lib().srx_spmm(a.x().handle, _ffi.ptr(sel), k, _ffi.ptr(P), _ffi.ptr(y), None, None), ctx.handle)
+    want = x[:, sel.astype(np.int64)] @ P.astype(np.float32).astype(np.float64)
+    assert np.abs(y - want).max() <= 2e-6 * np.abs(want).max()
+    assert not y[np.array(lens) == 0].any()
+
+
+@pytest.mark.parametrize("kernel", ["ranges", "rows"])
+def test_forward_spmm_row_major_kernels_agree_on_a_bench_shaped_matrix(ctx, kernel, monkeypatch):
+    """60k cells of the bench generator, 2000 selected genes: the new kernel's panel product against scipy (several blocks per wave,
+    every workgroup of the grid busy, rows in length order)."""
+    import scipy.sparse as sp
+    from singlerust_amd import _ffi
+    monkeypatch.setenv("SRX_SPMM_ROWS", "1")
+    monkeypatch.setenv("SRX_FWD_RANGES", "1" if kernel == "ranges" else "0")
+    n, g, k = 60_000, 28_000, 2000
+    m, _ = synth_host(3, n, g, 0.03)
+    a = adata_of(m, ctx, 1)
+    rng = np.random.default_rng(6)
+    sel = np.sort(rng.choice(g, k, replace=False)).astype(np.uint64)
+    P = rng.standard_normal((k, 64))
+    y = np.zeros((n, 64))
+    _ffi.check(_ffi.lib().srx_spmm(a.x().handle, _ffi.ptr(sel), k, _ffi.ptr(P), _ffi.ptr(y), None, None), ctx.handle)
+    A = sp.csr_matrix((m.values.astype(np.float64), m.indices.astype(np.int64), m.indptr.astype(np.int64)), shape=(n, g))[:, sel.astype(np.int64)]
+    want = A @ P.astype(np.float32).astype(np.float64)
+    assert np.abs(y - want).max() <= 2e-6 * np.abs(want).max()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("values", ["counts", "negative", "wide", "fractions"])
 @pytest.mark.parametrize("store", [1, 2])
