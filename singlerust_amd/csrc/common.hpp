@@ -75,7 +75,8 @@ struct srx_ctx {
     // sharded rows: the second half of the Gram kernel runs here, off the CUs left to the collective (launch_gram)
     hipStream_t gram_stream = nullptr;
     bool gram_stream_masked = false;
-    const uint32_t* gram_mode_word = nullptr;   // the value statistics the last stripe kernel decided its mode from (srx_gram_mode_info)
+    uint32_t* d_gram_mode = nullptr;         // copy of the value statistics the last stripe kernel decided its mode from (srx_gram_mode_info)
+    int gram_mode_state = 0;                 // 0: none (no launch / no rows on this rank), 1: f64 atomics forced, 2: decided from d_gram_mode
     bool gram_mode_f32 = false;
     uint32_t gram_splits = 0;                // Gram exchanges run in the split arrangement (srx_comm_overlap_info)
     hipEvent_t gram_fork = nullptr, gram_join = nullptr;
@@ -122,6 +123,8 @@ struct srx_ctx {
     hipStream_t direct_stream = nullptr;     // upload_on: values the caller holds in pinned memory go straight from there (no staging copy)
     hipEvent_t async_ev[kAsyncSlots] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t d2h_ev = nullptr;        // d2h_begin / d2h_end: a small read-back the host waits for while the stream goes on
+    void* pin_d2h = nullptr;            // ... its own pinned slot
+    bool d2h_pending = false;
 };
 
 struct srx_pca_state {           // what the last srx_pca / srx_pipeline left in HBM

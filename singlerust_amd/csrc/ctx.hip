@@ -67,17 +67,27 @@ int32_t d2h(srx_ctx* ctx, void* host, const void* dev, size_t bytes) {
 }
 
 // `rows` rows of `width` bytes, `dev_pitch` bytes apart on the device, to a dense host matrix
+// A small read-back the host waits for while the stream goes on.  Its own pinned slot (it used to stage through
+// ctx->pinned, which any d2h() in between overwrites and any larger pinned() request frees) and a pending flag: one at a time.
+constexpr size_t kSplitReadBytes = 256;
 int32_t d2h_begin(srx_ctx* ctx, const void* dev, size_t bytes) {
-    void* p;
-    SRX_TRY(pinned(ctx, bytes, &p));
+    if (bytes > kSplitReadBytes) return fail(ctx, SRX_E_ARG, "d2h_begin: %zu bytes exceed the split read-back slot", bytes);
+    if (ctx->d2h_pending) {              // (an error return between a begin and its end: the abandoned copy is waited out)
+        SRX_HIP(ctx, hipEventSynchronize(ctx->d2h_ev));
+        ctx->d2h_pending = false;
+    }
+    if (!ctx->pin_d2h) SRX_HIP(ctx, hipHostMalloc(&ctx->pin_d2h, kSplitReadBytes));
     if (!ctx->d2h_ev) SRX_HIP(ctx, hipEventCreateWithFlags(&ctx->d2h_ev, hipEventDisableTiming));
-    SRX_HIP(ctx, hipMemcpyAsync(p, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SRX_HIP(ctx, hipMemcpyAsync(ctx->pin_d2h, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     SRX_HIP(ctx, hipEventRecord(ctx->d2h_ev, ctx->stream));
+    ctx->d2h_pending = true;
     return SRX_OK;
 }
 int32_t d2h_end(srx_ctx* ctx, void* host, size_t bytes) {
+    if (!ctx->d2h_pending) return fail(ctx, SRX_E_ARG, "d2h_end without d2h_begin");
+    ctx->d2h_pending = false;
     SRX_HIP(ctx, hipEventSynchronize(ctx->d2h_ev));
-    memcpy(host, ctx->pinned, bytes);
+    memcpy(host, ctx->pin_d2h, bytes);
     return SRX_OK;
 }
 
@@ -720,6 +730,8 @@ void srx_ctx_destroy(srx_ctx* ctx) {
     }
     if (ctx->direct_stream) (void)hipStreamDestroy(ctx->direct_stream);
     if (ctx->d2h_ev) (void)hipEventDestroy(ctx->d2h_ev);
+    if (ctx->pin_d2h) (void)hipHostFree(ctx->pin_d2h);
+    if (ctx->d_gram_mode) (void)hipFree(ctx->d_gram_mode);
     for (auto e : ctx->async_ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);

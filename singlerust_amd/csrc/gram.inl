@@ -86,14 +86,19 @@ __host__ __device__ inline bool gram_fixed_point_mode(uint32_t vmax_b, uint32_t 
     return neg == 0u && vmax_b != 0u && vmax_b < 0x7f800000u && nmin != 0u && emax - emin <= 6 && emax > -48 && emax < 48;
 }
 // f64 entries (round 5): the same rule on the HIGH words of the doubles (11-bit exponents); products are formed in f64 already scaled,
-// p 2^kq < 2^47 (kq = 45 - 2 emax), rounded to integers by the 1.5 x 2^52 constant — a chunk of 16k cells adds at most 2^14 of them
-// to an accumulator: < 2^61 —, half a unit = 2^-48 of the largest possible product; a product 2^-14 of the largest (both values
-// at the small end of a 6-exponent spread) keeps 2^-34 of itself.
+// p 2^kq < 2^47 (kq = 45 - 2 emax), rounded to integers by the 1.5 x 2^52 constant — a chunk of at most 65536 cells (gram_plan's cap,
+// asserted there) adds at most 2^16 of them to an accumulator: < 2^63, read back as UNSIGNED by the flush.  Half a unit = 2^-48 of the
+// largest possible product.  ACCURACY BOUND: the exponent spread allowed is 4, not the f32 rule's 6 — a product of two
+// values at the small end is then >= 2^-10 of the largest possible one and keeps 2^-38 of itself (3.6e-12; with 6: 2^-34 = 6e-11,
+// too close to the f64 path's default residual tolerance of 1e-9); the sums of typical products keep ~2^-46.  The f64 atomics keep
+// 1e-16 per product and depend on the order they land in; SRX_GRAM_F64_ATOMICS=1 forces them (either storage).  Resident solves
+// decide the mode once, from statistics summed over the ranks; a backed session decides per tile and rank — its sums then depend
+// on the tile / rank layout by the quantum.
 __host__ __device__ inline bool gram_fixed_point_mode64(uint32_t vmax_hi, uint32_t nmin_hi, uint32_t neg, int& kq) {
     const uint32_t vmin_hi = ~nmin_hi;
     const int emax = (int)(vmax_hi >> 20) - 1023, emin = (int)(vmin_hi >> 20) - 1023;
     kq = 45 - 2 * emax;
-    return neg == 0u && vmax_hi != 0u && vmax_hi < 0x7ff00000u && nmin_hi != 0u && emax - emin <= 6 && emax > -200 && emax < 200;
+    return neg == 0u && vmax_hi != 0u && vmax_hi < 0x7ff00000u && nmin_hi != 0u && emax - emin <= 4 && emax > -200 && emax < 200;
 }
 __device__ __forceinline__ uint32_t* gram_stat(int64_t* rec_base, uint64_t n_rblk) { return reinterpret_cast<uint32_t*>(rec_base + n_rblk + 2); }
 
@@ -461,6 +466,10 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     // into selects.  The loads are invisible to its wait counting, so the waits are explicit: vmcnt(after + kL - 1 - u) for load u
     // of a set, `after` = the loads issued since that set's (the other set's kL, or none behind a slab's last set; memory reads
     // return in order; the compiler's own waits — for a slab's records — can only come out too strict, not too lax).
+    // (The blocks below end with `s_mov_b64 exec, -1`: they run under wave-uniform control flow only — a 1024-thread workgroup, slab /
+    //  batch loops whose bounds are scalars — so the mask on entry IS -1; saving and restoring it would be two more scalar instructions
+    //  per block on a kernel that issues 18 of them per load already.  tests/test_abi_cpu.py walks the listing: no instruction outside
+    //  the assembly blocks may touch a register whose load is still in flight.)
     auto batchP = [&](const Slab& sl, int u0) -> LoadedP {
         LoadedP l;
         const unsigned long long base = sl.base;     // (the block's first entry as a SCALAR pair: the load's saddr operand)
@@ -627,17 +636,20 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     };
     if (fx) run(std::true_type{});
     else run(std::false_type{});
+    // (the assembly core's ds_add_u64 are invisible to the compiler's wait counting: drained explicitly before the barrier the flush
+    //  reads the accumulators behind — the compiler's own release fence put a wait here too, but nothing obliged it to.  ADVICE r5)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     // flush: the upper-triangle part of both stripes, added to the packed matrix (row splits and, in backed
     // mode, earlier row tiles have been there before)
     for (int e = threadIdx.x; e < SR * WA; e += blockDim.x) {
         const int r = e / WA, c = a0 + e % WA, row = a0 + r;
-        const double v = fx ? (double)__double_as_longlong(acc[e]) * fx_inv : acc[e];
+        const double v = fx ? (double)(unsigned long long)__double_as_longlong(acc[e]) * fx_inv : acc[e];
         if (row < k && c >= row && v != 0.0) atomicAdd(&Gp[tri_index(row, c, k)], v);
     }
     for (int e = threadIdx.x; e < SR * WB; e += blockDim.x) {
         const int r = e / WB, c = b0 + e % WB, row = b0 + r;
-        const double v = fx ? (double)__double_as_longlong(acc[SR * WA + e]) * fx_inv : acc[SR * WA + e];
+        const double v = fx ? (double)(unsigned long long)__double_as_longlong(acc[SR * WA + e]) * fx_inv : acc[SR * WA + e];
         if (row < k && c >= row && v != 0.0) atomicAdd(&Gp[tri_index(row, c, k)], v);
     }
 }

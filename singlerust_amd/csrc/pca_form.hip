@@ -66,6 +66,10 @@ int32_t gram_plan(srx_ctx* ctx, int k, uint64_t n_rows, GramPlan& g, double entr
         chunk = (uint64_t)(cells / g.rblk + 0.5);
         if (chunk > 65536 / g.rblk) chunk = 65536 / g.rblk;
     }
+    // the fixed-point accumulators of a chunk: at most 2^16 products below 2^47 each (f64 entries; f32: below 2^31) in 64 bits, read
+    // back unsigned — the cap is part of that bound, whoever changes the sizing above
+    static_assert(65536ull * (1ull << 47) <= (1ull << 63), "chunk cap x product bound must fit the accumulator");
+    if (chunk * g.rblk > 65536) chunk = 65536 / g.rblk;
     chunk = std::max<uint64_t>(chunk, kGramWaves);
     const uint64_t want_wgs = (uint64_t)ctx->n_cus * per_cu;
     while (chunk > kGramWaves && ((g.n_rblk + chunk - 1) / chunk) * (uint64_t)g.n_wg < want_wgs) chunk /= 2;
@@ -474,8 +478,15 @@ int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce, 
         SRX_HIP(ctx, hipGetLastError());
     }
     if (empty && !split) return SRX_OK;
-    if (!empty) {                              // (srx_gram_mode_info: the words the stripe kernel decides from)
-        ctx->gram_mode_word = reinterpret_cast<const uint32_t*>(rec_base + g.n_rblk + 2);
+    // SRX_GRAM_F64_ATOMICS=1: no fixed point whatever the statistics say (the kernel gets no statistics)
+    const bool force_f64 = getenv("SRX_GRAM_F64_ATOMICS") && atoi(getenv("SRX_GRAM_F64_ATOMICS"));
+    // srx_gram_mode_info: the three words the stripe kernel decides from, COPIED (they live in a scratch buffer the next, larger
+    // compaction may free, and the next k_rec_scan zeroes them: ADVICE r5) into a buffer of the context's own, on the stream,
+    // behind whatever made them final; a rank without rows, and a forced mode, say so instead of leaving the last launch's words
+    ctx->gram_mode_state = empty ? 0 : (force_f64 ? 1 : 2);
+    if (!empty && !force_f64) {
+        if (!ctx->d_gram_mode) SRX_HIP(ctx, hipMalloc((void**)&ctx->d_gram_mode, 4 * sizeof(uint32_t)));
+        SRX_HIP(ctx, hipMemcpyAsync(ctx->d_gram_mode, rec_base + g.n_rblk + 2, 3 * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
         ctx->gram_mode_f32 = sizeof(VT) == 4;
     }
     // SRX_K_GRAM: the stripe kernel alone.  Algorithmic bytes = what ANY Gram kernel must move: the compacted matrix and its
@@ -489,7 +500,8 @@ int32_t launch_gram(srx_ctx* ctx, const RowMajor& rm, double* Gp, bool* reduce, 
         if (empty) return;
         hipLaunchKernelGGL((k_gram_stripes<VT>), dim3((unsigned)(n_w * g.n_z)), dim3(kGramWaves * kWave), g.lds_bytes, st,
                            rm.ptr, (const GramPk<VT>*)rm.pk, boff, rec_base, recs, g.n_rblk, g.rblk, rm.k, g.sr_shift, g.n_wg,
-                           g.n_stripes, g.n_chunk, w0, n_w, Gp, (const uint32_t*)(rec_base ? reinterpret_cast<uint32_t*>(rec_base + g.n_rblk + 2) : nullptr));
+                           g.n_stripes, g.n_chunk, w0, n_w, Gp,
+                           (const uint32_t*)(rec_base && !force_f64 ? reinterpret_cast<uint32_t*>(rec_base + g.n_rblk + 2) : nullptr));
     };
     // Sharded rows: owner w holds the stripes w and n_stripes - 1 - w, so the owners [0, h) hold the rows [0, h SR) and
     // [k - h SR, k) of the triangle — two contiguous ranges of the packed array — and the others the rows between.  Two
@@ -540,9 +552,13 @@ extern "C" int32_t srx_gram_mode_info(srx_ctx* ctx, int32_t* mode_out) {
     using namespace srx;
     if (!ctx || !mode_out) return fail(ctx, SRX_E_ARG, "srx_gram_mode_info: null argument");
     *mode_out = 0;
-    if (!ctx->gram_mode_word) return SRX_OK;
+    if (ctx->gram_mode_state == 0) return SRX_OK;                  // no launch yet, or the last one had no rows on this rank
+    if (ctx->gram_mode_state == 1) {                               // SRX_GRAM_F64_ATOMICS
+        *mode_out = 1;
+        return SRX_OK;
+    }
     uint32_t w[3] = {0, 0, 0};
-    SRX_TRY(d2h(ctx, w, ctx->gram_mode_word, sizeof w));
+    SRX_TRY(d2h(ctx, w, ctx->d_gram_mode, sizeof w));
     int kq;
     *mode_out = (ctx->gram_mode_f32 ? gram_fixed_point_mode(w[0], w[1], w[2], kq) : gram_fixed_point_mode64(w[0], w[1], w[2], kq)) ? 2 : 1;
     return SRX_OK;

@@ -518,7 +518,6 @@ __global__ __launch_bounds__(kRgThreads) void k_spmm_ranges(
     constexpr int RPL = sizeof(VT) == 4 ? 8 : 4;                // records per lane and chunk
     constexpr int kChunk = 4 * RPL;
     constexpr int kRowBytes = L * (int)sizeof(PT);
-    constexpr int kPiece = 4 * (int)sizeof(PT);                 // one ds_read: four columns
     constexpr int kWaves = kRgThreads / 64;
     extern __shared__ double lds_raw[];
     char* panel = reinterpret_cast<char*>(lds_raw);

@@ -219,10 +219,14 @@ int32_t srx_synth_generate(srx_ctx* ctx, const srx_synth_params* p, uint64_t row
         hipLaunchKernelGGL((k_synth_fill<double>), dim3((unsigned)g), dim3(256), 0, ctx->stream, c, row_begin, n,
                            m->d_indptr, m->d_indices, (double*)m->d_values);
     e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) {
+    // the handle leaves in the state srx_matrix_upload leaves one in: the 16-bit index mirror and the gene-tile cuts are made where
+    // the indices are written (the upload's H2D workers narrow on the host side of the link and tiles_from_idx16 cuts the tiles
+    // before the upload returns) — not by the first statistics call on the handle
+    int32_t rc = e == hipSuccess ? ensure_tiles(m) : SRX_OK;
+    if (e == hipSuccess && rc == SRX_OK) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess || rc != SRX_OK) {
         srx_matrix_free(m);
-        return fail(ctx, SRX_E_HIP, "synth fill kernel: %s", hipGetErrorString(e));
+        return e != hipSuccess ? fail(ctx, SRX_E_HIP, "synth fill kernel: %s", hipGetErrorString(e)) : rc;
     }
     *out = m;
     return SRX_OK;

@@ -215,6 +215,9 @@ def test_hot_kernels_do_not_spill_registers(tmp_path):
             scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", body).group(1))
             assert spill == 0 and scratch == 0, f"{m.group(1)}: {spill} spilled VGPRs, {scratch} B of scratch"
     _check_count_pass_listing(texts["pca_form.hip"])
+    for mangled, min_loads in (("k_gram_stripesIfE", 32), ("k_rowcount_listEPKl", 32)):
+        _check_no_use_of_registers_in_flight(texts["pca_form.hip"], mangled, min_loads)
+    _check_stripe_kernel_drains_its_lds_atomics(texts["pca_form.hip"])
 
 
 def _check_count_pass_listing(text):
@@ -256,6 +259,68 @@ def _check_count_pass_listing(text):
                 i = j
             i += 1
         assert blocks >= 3, (mangled, blocks)       # before the loop, and one per half of its body
+
+
+def _vregs(ln):
+    r = set(int(x) for x in re.findall(r"\bv(\d+)\b", ln))
+    for a, b in re.findall(r"v\[(\d+):(\d+)\]", ln):
+        r |= set(range(int(a), int(b) + 1))
+    return r
+
+
+def _check_no_use_of_registers_in_flight(text, mangled, min_asm_loads):
+    """The inline-assembly cores (k_gram_stripes<float>, k_rowcount_list) issue global loads the compiler cannot see and wait for
+    them with hard-coded `s_waitcnt vmcnt(N)`.  Memory operations return in order, so the listing can be replayed: a
+    queue of the destination registers of every vector-memory operation in flight (assembly blocks and compiler code alike; stores
+    count), popped by every `s_waitcnt vmcnt(N)` down to its N youngest.  No instruction OUTSIDE an assembly block may name a
+    register that is still in the queue (a copy placed there by phi resolution or live-range splitting would read or clobber a
+    register whose load has not landed).  Linear walk of the text: exact for the unrolled bodies, an approximation at loop back edges."""
+    m = re.search(r"^(_ZN3srx\S*%s\S*):.*?s_endpgm" % mangled, text, flags=re.S | re.M)
+    assert m, mangled
+    queue, inside, n_asm_loads = [], False, 0
+    for ln in m.group(0).split("\n"):
+        s_ = ln.strip()
+        if "#ASMSTART" in s_:
+            inside = True
+            continue
+        if "#ASMEND" in s_:
+            inside = False
+            continue
+        if not s_ or s_.startswith((";", ".")) or s_.endswith(":"):
+            continue
+        w = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", s_)
+        if w:
+            n = int(w.group(1))
+            queue = queue[len(queue) - n:] if 0 < n < len(queue) else ([] if n == 0 else queue)
+            continue
+        in_flight = set().union(*queue) if queue else set()
+        if re.match(r"(global|buffer|scratch|flat)_(load|store|atomic)", s_):
+            dst = _vregs(s_.split()[1].rstrip(",")) if re.match(r"\w+_load", s_) else set()
+            if inside and dst:
+                n_asm_loads += 1
+            hit = (_vregs(s_) - dst) & in_flight
+            assert inside or not hit, f"{mangled}: `{s_}` reads {sorted(hit)} while their loads are in flight"
+            queue.append(dst)
+            continue
+        if inside:
+            continue                   # the assembly blocks carry their own waits
+        hit = _vregs(s_) & in_flight
+        assert not hit, f"{mangled}: `{s_}` touches v{sorted(hit)} while their loads are in flight"
+    assert n_asm_loads >= min_asm_loads, (mangled, n_asm_loads)
+
+
+def _check_stripe_kernel_drains_its_lds_atomics(text):
+    """The stripe kernel's ds_add_u64 sit in assembly blocks: the drain before the flush's barrier is an explicit
+    `s_waitcnt lgkmcnt(0)` of its own, not whatever the compiler's fence happens to emit."""
+    m = re.search(r"^(_ZN3srx\S*k_gram_stripesIfE\S*):.*?s_endpgm", text, flags=re.S | re.M)
+    assert m
+    lines = m.group(0).split("\n")
+    assert any("ds_add_u64" in ln for ln in lines)
+    found = False
+    for i, ln in enumerate(lines):
+        if "#ASMSTART" in ln and "s_waitcnt lgkmcnt(0)" in lines[i + 1] and "#ASMEND" in lines[i + 2]:
+            found = found or any("s_barrier" in x for x in lines[i + 3:i + 12])
+    assert found
 
 
 def test_graft_entry_build_runs():

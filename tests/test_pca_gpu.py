@@ -495,23 +495,29 @@ def gram_of(ctx, x, store):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,want_mode", [("spread6", 2), ("spread7", 1), ("spread6_fraction", 2), ("one_negative", 1),
-                                            ("stored_zero", 1), ("huge", 1), ("tiny", 1), ("all_equal", 2)])
-def test_gram_mode_switch_at_its_boundaries(ctx, case, want_mode):
+                                            ("stored_zero", 1), ("huge", 1), ("tiny", 1), ("all_equal", 2), ("spread4", 2),
+                                            ("spread5", 2), ("forced_f64_atomics", 1)])
+def test_gram_mode_switch_at_its_boundaries(ctx, case, want_mode, monkeypatch):
     """The f32 stripe kernel picks its accumulation mode on the device (gram.inl): FIXED POINT (mode 2) when no value is
     negative and the binary exponents of the non-zero values lie within 6 of the largest's, f64 atomics (mode 1) otherwise.
     Each case sits on one side of one of those tests — an exponent spread of exactly 6 and of exactly 7, a single negative
     value among 40 000, a single STORED zero, a largest exponent outside the +-48 the scale factor is built for — with values
     that are powers of two times small integers, so that X^T X is exact in EITHER mode: the mode must be the one stated and the
     result must equal scipy's to the bit.  f64 storage runs the same cases through the f64 kernel, which takes the same
-    decision on the high words of the doubles (round 5): the same mode, except where f64's wider exponent range admits what
-    f32's scale factor does not ("huge" / "tiny": exponents +-50 are inside f64's +-200)."""
+    decision on the high words of the doubles (round 5) with a spread of at most 4 (round 6: a product at the small end of a
+    6-exponent spread would keep only 2^-34 of itself, too close to the f64 path's 1e-9 tolerance): the same mode except at spreads
+    5 and 6, and where f64's wider exponent range admits what f32's scale factor does not ("huge" / "tiny": exponents +-50 are
+    inside f64's +-200).  SRX_GRAM_F64_ATOMICS=1 forces the f64 atomics at either storage."""
     import scipy.sparse as sp
     rng = np.random.default_rng(17)
     n, g = 3000, 160
     x = sp.random(n, g, density=0.09, random_state=3, format="csr", dtype=np.float64)
     nnz = x.nnz
     lo, hi = {"spread6": (0, 6), "spread7": (-1, 6), "spread6_fraction": (-9, -3), "one_negative": (0, 3), "stored_zero": (0, 3),
-              "huge": (50, 52), "tiny": (-52, -50), "all_equal": (2, 2)}[case]
+              "huge": (50, 52), "tiny": (-52, -50), "all_equal": (2, 2), "spread4": (0, 4), "spread5": (0, 5),
+              "forced_f64_atomics": (0, 3)}[case]
+    if case == "forced_f64_atomics":
+        monkeypatch.setenv("SRX_GRAM_F64_ATOMICS", "1")
     e = rng.integers(lo, hi + 1, nnz)
     e[0], e[-1] = lo, hi                                  # both ends of the range are really there
     x.data = np.ldexp(rng.integers(1, 2, nnz).astype(np.float64), e)          # exact powers of two: the exponent IS e
@@ -526,7 +532,7 @@ def test_gram_mode_switch_at_its_boundaries(ctx, case, want_mode):
     assert mode == want_mode, (case, mode)
     assert np.array_equal(got, want), case
     got64, mode64 = gram_of(ctx, x, 2)
-    want_mode64 = 2 if case in ("huge", "tiny") else want_mode
+    want_mode64 = 2 if case in ("huge", "tiny") else (1 if case in ("spread5", "spread6", "spread6_fraction") else want_mode)
     assert mode64 == want_mode64, (case, mode64)
     assert np.array_equal(got64, want)
 
