@@ -273,7 +273,8 @@ class Bench:
         self.F.check(self.lib.srx_partition_rows(self.F.ptr(ip), n_global, self.world, self.F.ptr(cut)))
         return int(cut[self.rank]), int(cut[self.rank + 1])
 
-    def run(self, config, n_global, row0, row1, storage, steps, warmup, solver=0, hvg=None, skew=0, tolerate_noconv=False, headline=False):
+    def run(self, config, n_global, row0, row1, storage, steps, warmup, solver=0, hvg=None, skew=0, tolerate_noconv=False, headline=False,
+            per_step=False):
         """K timed pipeline steps on rows [row0, row1) of the synthetic matrix; returns the measurements of this rank
         (times already maxed over ranks)."""
         a, F, sr, lib, ctx = self.a, self.F, self.sr, self.lib, self.ctx
@@ -344,6 +345,9 @@ class Bench:
                 for _ in range(chunk):
                     ts = time.perf_counter()
                     step(copies[used]); used += 1
+                    if per_step:                # every step between two synchronisations of its own: min / median over the steps
+                        self.sync_all()
+                        step_ms.append((time.perf_counter() - ts) * 1e3)
                     if os.environ.get("SRX_BENCH_TRACE"):
                         print(f"[bench] step {done} copy {used - 1}: {(time.perf_counter() - ts) * 1e3:.2f} ms host, "
                               f"pca stage {res.ms_pca:.2f} ms", file=sys.stderr)
@@ -369,6 +373,7 @@ class Bench:
             return elapsed_, prof_, stage_, iters_
 
         all_mask = sum(1 << c for c in classes)
+        step_ms = []
         breakdown = None
         if headline:
             # The K timed steps carry the class timers of the roofline object's stage only (compaction, owner records, stripe
@@ -392,7 +397,7 @@ class Bench:
                "stage_ms_per_step": {k_: v / steps for k_, v in stage.items()}, "iters": iters,
                "residual": float(res.pca.residual), "nnz_selected": int(res.pca.nnz_selected),
                "solver": {1: "gram", 2: "spmm"}.get(int(res.pca.solver), "?"), "generate_s": t_gen, "copies": n_copies,
-               "noconv_steps": len(failures), "genes": int(info.n_cols), "breakdown": breakdown}
+               "noconv_steps": len(failures), "genes": int(info.n_cols), "breakdown": breakdown, "step_ms": sorted(step_ms)}
         for c in copies:
             c.free()
         pristine.free()
@@ -468,7 +473,8 @@ def other_bounds(name, d, nnz_sel, n_cells, sigma=0.3):
 def cold_step(B, config, n_global, storage, reps=3):
     """What a caller pays who runs the path ONCE per dataset: srx_pipeline on a FRESH handle — no srx_matrix_prepare, no
     srx_matrix_reserve_results before the clock; the matrix itself resident in HBM.  The first call builds the pattern-only
-    structures (16-bit index mirror, gene-tile cuts, per-gene counts) and allocates the result block inside the step.  Run after
+    structures the handle does not carry yet — the per-gene counts; the 16-bit index mirror and the gene-tile cuts are made where the
+    indices are written, by srx_matrix_upload and (round 6) srx_synth_generate alike — and allocates the result block inside the step.  Run after
     the timed region, so the context is warm (scratch buffers, captured graphs, code objects): the cost measured is the
     matrix's own.  `prepare_ms` / `reserve_ms`: the two set-up calls timed on their own on another fresh handle."""
     a, F, sr, lib, ctx = B.a, B.F, B.sr, B.lib, B.ctx
@@ -858,6 +864,7 @@ def compact_record(full):
                 "kind", "rccl_version", "n_ranks", "n_ranks_seen", "launcher", "gram_exchange_split_launches",
                 "gram_exchange_cu_masked", "nnz_hvg_compacted_rank0", "pca_residual", "pca_solver", "cold_step_ms", "prepare_ms",
                 "f64_storage_ms_per_step", "incl_h2d_cells_per_s", "incl_h2d_pageable_cells_per_s", "skewed_genes_ms_per_step",
+                "skewed_genes_ms_min", "skewed_genes_ms_median",
                 "hard_spectrum_ms_per_step", "gram_formation_ms_per_step", "iterate_ms_per_step", "predicted_speedup_8_gpus",
                 "shard_step_ms_at_8_ranks", "tile_rows")
     config = {k_: _r(cfg[k_]) for k_ in keep_cfg if cfg.get(k_) is not None}
@@ -1015,9 +1022,13 @@ def main():
         attempt("roofline_spmm_iter", f_iter)
 
         def f_skew():
-            r = B.run(a.config, n_global, 0, n_global, a.storage, 3, 1, solver=a.solver, skew=1 - a.skew, tolerate_noconv=True)
-            per, _ = attributed(r["prof"], 3)
-            return {"skew": 1 - a.skew, "steps": 3, "ms_per_step": r["ms_per_step"], "kernel_ms_per_step": per,
+            # (3 steps after 1 warm-up read 17.8 on one box and 19.6 on another — 10 steps, each between its own
+            #  synchronisations, minimum and median reported)
+            r = B.run(a.config, n_global, 0, n_global, a.storage, 10, 2, solver=a.solver, skew=1 - a.skew, tolerate_noconv=True, per_step=True)
+            per, _ = attributed(r["prof"], 10)
+            sm = r["step_ms"]
+            return {"skew": 1 - a.skew, "steps": 10, "ms_per_step": r["ms_per_step"], "kernel_ms_per_step": per,
+                    "step_ms_min": sm[0] if sm else None, "step_ms_median": sm[len(sm) // 2] if sm else None,
                     "nnz_hvg_compacted": r["nnz_selected"], "noconv_steps": r["noconv_steps"],
                     "note": "srx_synth skew = 1: gene density ~ 1/sqrt(gene index) (7x between the first and the last genes): "
                             "contention on the per-gene LDS accumulators of the moments pass, owners of very different weight "
@@ -1158,6 +1169,8 @@ def main():
                 "roofline_spmm_frac": (prof.get("spmm_fwd") or {}).get("frac_of_peak"),
                 "roofline_spmm_ms": (prof.get("spmm_fwd") or {}).get("avg_ms"),
                 "skewed_genes_ms_per_step": (extra.get("skewed_genes") or {}).get("ms_per_step"),
+                "skewed_genes_ms_min": (extra.get("skewed_genes") or {}).get("step_ms_min"),
+                "skewed_genes_ms_median": (extra.get("skewed_genes") or {}).get("step_ms_median"),
                 "hard_spectrum_ms_per_step": (extra.get("hard_spectrum") or {}).get("ms_per_step"),
                 "gram_formation_ms_per_step": gram_stage["ms_per_step"],
                 "gram_formation_traffic_over_alg": gram_stage["traffic_over_alg"],

@@ -294,6 +294,10 @@ __global__ __launch_bounds__(kGramWaves * 64, 8) void k_gram_stripes(
     // suffix loads in flight per batch: 16-byte f64 entries take twice the registers (8 of them spilled)
     constexpr int kUnroll = sizeof(VT) == 8 ? kGramUnroll / 2 : kGramUnroll;
     extern __shared__ double acc[];
+    // (Round 6, measured and not kept: the owners that land on one XCD — consecutive workgroup ids go round the 8 XCDs — as a CONTIGUOUS
+    //  range of w, so that an XCD's L2 would only have to bring in the row suffixes from its first owner's columns on, 1 - x / 16 of
+    //  the matrix instead of all of it: FETCH_SIZE did not move (7.64e6 KiB against 7.62e6: the traffic is capacity misses on
+    //  re-reads, 59 % L2 hits either way, not first touches) and the launch went from 2.48 to 2.77 ms: profiles/r06_pmc_gram.md.)
     const int w = w0 + blockIdx.x % n_w, z = blockIdx.x / n_w;
     const int SR = 1 << sr_shift;
     const int a0 = w * SR, b0 = (n_stripes - 1 - w) * SR;

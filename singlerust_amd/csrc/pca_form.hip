@@ -43,7 +43,7 @@ int32_t gram_plan(srx_ctx* ctx, int k, uint64_t n_rows, GramPlan& g, double entr
     }
     g.lds_bytes = (size_t)sr * widest * 8;
     if (g.lds_bytes > 163840) return fail(ctx, SRX_E_ARG, "pca: %d selected features exceed the Gram kernel's LDS stripes", k);
-    g.rblk = 512u;      // c3: bucket pass + stripe kernel 4.89 ms with 1024-cell blocks, 4.78 with 512, 5.07 with 256
+    g.rblk = 512u;      // (round 6, assembly core: 256 / 384 / 512 / 1024 cells: stripes 2.55 / 2.55 / 2.47 / 2.49, records 0.89 / 0.87 / 0.89 / 1.07 ms) c3: bucket pass + stripe kernel 4.89 ms with 1024-cell blocks, 4.78 with 512, 5.07 with 256
     // an owner record names its piece by a 32-bit BYTE offset from its row block's first entry (a row holds at most k entries of at
     // most 16 bytes): 512 x 16384 x 16 = 2^27 — asserted, not assumed
     if ((uint64_t)g.rblk * (uint64_t)k * 16u >= (1ull << 31))

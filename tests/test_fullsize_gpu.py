@@ -228,3 +228,91 @@ def test_backed_session_at_full_c3_size_matches_the_resident_pipeline(ctx):
         s = 1.0 if np.dot(scores[:, c], scores0[:, c]) >= 0 else -1.0
         assert np.linalg.norm(scores[:, c] - s * scores0[:, c]) <= 1e-5 * np.linalg.norm(scores0[:, c])
     assert np.abs(scores.mean(axis=0)).max() < 1e-6 * np.abs(scores).max()
+
+
+def test_backed_session_at_full_c5_size_matches_the_resident_pipeline(ctx):
+    """configs[4] AS SPECIFIED, at its full size, on the one GPU a test box has: the 10M x 30k matrix (6.0e9 non-zeros, 72 GB in the
+    reference layout) stays in HOST memory and goes through the backed session as 250k-cell tiles (two sweeps: statistics, then
+    compaction + Gram), against the resident pipeline on the same matrix generated in HBM (48 GB): per-cell counts and sums of
+    the raw tiles bit-equal at their GLOBAL row offsets (beyond 2^32 entries), HighlyVariable(2000) identical in content and
+    order, explained variance and the scores of a 50k-cell sample equal to rounding.  (the streamed form had run at
+    this size inside bench.py only.)"""
+    import concurrent.futures as cf
+    import singlerust_amd as sr
+    from singlerust_amd import _ffi as F
+    from singlerust_amd.memory import statistics
+    try:
+        import psutil
+        if psutil.virtual_memory().available < 110 * 2 ** 30:
+            pytest.skip("needs ~80 GB of host memory for the reference-layout matrix")
+    except ImportError:
+        pass
+    lib = F.lib()
+    n, g, density, seed = CONFIGS["c5"]
+    p = F.SynthParams()
+    lib.srx_synth_defaults(C.byref(p), seed, n, g, density)
+    # resident reference
+    h = C.c_void_p()
+    F.check(lib.srx_synth_generate(ctx.handle, C.byref(p), 0, n, F.F32, F.STORE_F32, C.byref(h)), ctx.handle)
+    dev = sr.DeviceCsr(ctx, h)
+    a = sr.IMAnnData(dev, None, None, [], [])
+    raw_row_sums = statistics.compute_sum(a, sr.Direction.Row)
+    raw_row_num = statistics.compute_number(a, sr.Direction.Row)
+    opts = F.PcaOpts(50, -1, -1, -1, 0, 0, 1, 0.0, 12345)
+    res = F.PipelineResult()
+    F.check(lib.srx_pipeline(dev.handle, 1e4, 2000, C.byref(opts), C.byref(res)), ctx.handle)
+    ns = 50_000
+    scores0, evr0, hv0 = np.zeros((n, 50)), np.zeros(50), np.zeros(2000, np.uint64)
+    F.check(lib.srx_result_fetch(dev.handle, F.ptr(scores0), None, F.ptr(evr0), None, None, F.ptr(hv0)), ctx.handle)
+    head0, tail0 = scores0[:ns].copy(), scores0[-ns:].copy()
+    del scores0
+    dev.free()
+    # the same matrix on the host, reference layout (u64 offsets / indices, f32 values)
+    tile = 250_000
+    ip = np.zeros(n + 1, dtype=np.uint64)
+    lib.srx_synth_indptr(C.byref(p), 0, n, F.ptr(ip))
+    nnz = int(ip[-1])
+    assert nnz > 2 ** 32
+    idx, val = np.empty(nnz, np.uint64), np.empty(nnz, np.float32)
+
+    def fill(r0):
+        r1 = min(n, r0 + 50_000)
+        e0, e1 = int(ip[r0]), int(ip[r1])
+        sub = (ip[r0:r1 + 1] - ip[r0]).astype(np.uint64)
+        lib.srx_synth_fill_host(C.byref(p), r0, r1, F.ptr(sub), F.ptr(idx[e0:e1]), F.ptr(val[e0:e1]))
+    with cf.ThreadPoolExecutor(max_workers=min(64, os.cpu_count() or 1)) as ex:
+        list(ex.map(fill, range(0, n, 50_000)))
+
+    def tiles():
+        for r0 in range(0, n, tile):
+            r1 = min(n, r0 + tile)
+            e0 = int(ip[r0])
+            yield r0, r1, F.Csr(r1 - r0, g, int(ip[r1]) - e0, ip[r0:].ctypes.data, idx[e0:].ctypes.data, val[e0:].ctypes.data, F.F32)
+
+    b = C.c_void_p()
+    F.check(lib.srx_backed_create(ctx.handle, g, F.STORE_F32, C.byref(b)), ctx.handle)
+    xf = F.BACKED_NORMALIZE | F.BACKED_LOG1P
+    row_sums = np.zeros(n)
+    row_num = np.zeros(n, np.uint32)
+    for r0, r1, t in tiles():
+        F.check(lib.srx_backed_stats_tile(b, C.byref(t), 1e4, xf, F.ptr(row_num[r0:r1]), F.ptr(row_sums[r0:r1])), ctx.handle)
+    assert np.array_equal(row_sums, raw_row_sums) and np.array_equal(row_num, raw_row_num)
+    assert int(row_num.astype(np.int64).sum()) == nnz
+    n_out = C.c_uint64()
+    hv = np.zeros(2000, np.uint64)
+    F.check(lib.srx_backed_select(b, 2000, None, 0, C.byref(opts), F.ptr(hv), C.byref(n_out)), ctx.handle)
+    assert n_out.value == 2000 and np.array_equal(hv, hv0)              # identical selection, identical order
+    for r0, r1, t in tiles():
+        F.check(lib.srx_backed_gram_tile(b, C.byref(t), 1e4, xf), ctx.handle)
+    info = F.PcaInfo()
+    F.check(lib.srx_backed_solve(b, C.byref(info)), ctx.handle)
+    assert info.n_cells_global == n and info.residual <= 1e-7
+    scores, evr = np.zeros((n, 50)), np.zeros(50)
+    F.check(lib.srx_backed_fetch(b, F.ptr(scores), None, F.ptr(evr), None, None, None), ctx.handle)
+    lib.srx_backed_destroy(b)
+    np.testing.assert_allclose(evr, evr0, rtol=1e-6)
+    for got, want in ((scores[:ns], head0), (scores[-ns:], tail0)):
+        for c in range(50):
+            s = 1.0 if np.dot(got[:, c], want[:, c]) >= 0 else -1.0
+            assert np.linalg.norm(got[:, c] - s * want[:, c]) <= 1e-5 * np.linalg.norm(want[:, c]), c
+    assert np.abs(scores.mean(axis=0)).max() < 1e-6 * np.abs(scores).max()
