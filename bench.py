@@ -132,7 +132,7 @@ def usable_cores():
 
 def load_traffic(config):
     """HBM bytes per pipeline step from the committed PMC passes (profiles/make_traffic.py), per bench kernel class."""
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{config}.json")
         try:
             with open(path) as fh:

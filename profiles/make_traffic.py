@@ -5,7 +5,9 @@ both counters are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes read (64
 128-B request) -> doubled; WRITE_SIZE is taken as is (it matches known write volumes of the
 streaming kernels here: normalise writes nnz*4 B and WRITE_SIZE reports exactly that).
 
-Usage: make_traffic.py FETCH_results.db WRITE_results.db workload-tag pipeline-steps-in-the-profiled-run > profiles/rNN_traffic_<tag>.json"""
+Usage: make_traffic.py FETCH_results.db WRITE_results.db workload-tag [pipeline-steps-in-the-profiled-run | auto] > profiles/rNN_traffic_<tag>.json
+(`auto`, the default: the launches of k_gene_moments — the moments pass runs exactly once per pipeline step; the r05 table was made with
+a hand-counted 4 where the bench had run 7 steps)"""
 import json
 import sqlite3
 import sys
@@ -25,6 +27,9 @@ def per_kernel(path, counter):
 def main(fetch_db, write_db, tag, steps):
     f = per_kernel(fetch_db, "FETCH_SIZE")
     w = per_kernel(write_db, "WRITE_SIZE")
+    if steps is None:
+        once = [n for name, (_, n) in f.items() if "k_gene_moments" in name]
+        steps = float(max(once)) if once else 1.0
     out = {"workload": tag, "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes); "
            "KiB -> bytes; FETCH x2 (gfx950 correction); per-launch averages", "kernels": {}}
     for name in sorted(set(f) | set(w)):
@@ -38,4 +43,4 @@ def main(fetch_db, write_db, tag, steps):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4]))
+    main(sys.argv[1], sys.argv[2], sys.argv[3], None if len(sys.argv) < 5 or sys.argv[4] == "auto" else float(sys.argv[4]))
