@@ -52,32 +52,14 @@ KERNEL_SYMBOL = {"normalize_log1p": "k_row_apply<T> / k_normalize<T> (the separa
                  "spmm_t": "k_spmm_t", "gram_sparse": "k_gram_stripes<float>",
                  "gram_bucket": "k_rec_count + k_rec_scan + k_bucket (owner records of the Gram kernel)",
                  "iterate": "k x 64 subspace iteration (hipGraph replays)", "dense_apply": "k_dense_apply"}
+# what each roofline object's bytes are and what the kernel is really bound by: DESIGN.md section 7 (the prose lives there, not in the line)
 ROOF_NOTE = {
-    "gram_sparse": "algorithmic bytes = what any Gram kernel must move: the row-major HVG-compacted matrix (8-byte entries) and "
-                   "its row pointers read once + the packed upper triangle of G written once; the 12-byte owner records and block "
-                   "offsets this kernel reads besides are `aux_bytes_per_launch`.  Not an HBM-bound kernel (`other_bounds`): N m(m+1)/2 "
-                   "= 3.4-3.7e9 scalar products per launch at c3, each one lane of an f64 LDS atomic fed by one gathered 8-byte "
-                   "operand.  The operand fetch costs per load INSTRUCTION (~18.6 clk per CU whatever the lanes or runs it serves, "
-                   "bench_micro/l2_gather.hip: the one-suffix-per-load kernel of rounds 2-3, 1.0e8 loads, ran at exactly that rate, "
-                   "3.89 ms); a load now serves two owner records (16 bytes per lane): 6.2e7 loads, 3.17 ms with ds_add_f64 (VALU 95 %, "
-                   "LDS pipe 88 % busy), 2.81 ms with the products rounded to fixed point and added as 64-bit integers (LDS 53 %, VALU "
-                   "100 % busy: profiles/r04_pmc_gram.md), 2.66 ms since round 5 with the record fields as scalar operands and the lane "
-                   "masks from the scalar unit (inline assembly: 21 VALU + 18 scalar instructions per load instead of 28.6 + 6; no issue "
-                   "port is the wall any more, SQ_WAIT_ANY 30 %: profiles/r05_pmc_gram.md, r05_knockouts.md)",
-    "gene_moments": "algorithmic bytes (SURVEY.md 8(d), fused normalise + log1p + moments): every non-zero's 16-bit index and f32 value read "
-                    "once, the transformed value stored back in place (nnz * 10) + row pointers, gene-tile cuts and row sums.  What "
-                    "bounds it: reading those 6.6 GB and writing 4.4 GB back takes 2.1-2.25 ms however the arrays are walked "
-                    "(bench_micro/segment_read.hip: flat stream 2.11 ms, the kernel's (row block, gene tile) batch walk 2.25) — "
-                    "the pass with its f64 logarithms, fixed-point conversions and 2.2e9 integer LDS atomic lanes is 0.5 ms above "
-                    "that, latency-bound at 4 waves per SIMD (VALU 61 % busy, profiles/r05_pmc_gram.md, r04_knockouts.md)",
-    "spmm_fwd": "algorithmic bytes: the row-major compacted matrix (nnz_w * 8) + row pointers and row order (N * 12) + the "
-                "k x 64 f32 panel once per workgroup column slice + the output, which for this launch (the transform) is the "
-                "N x n_pc f64 score matrix written by the SpMM itself (rows of n_pc rounded up to 16 doubles in HBM).  What bounds "
-                "it (`other_bounds`, profiles/r05_pmc_spmm.md / r04_pmc_spmm.md, knock-outs of round 3 in DESIGN.md section 3c): every kept entry "
-                "reads its gene's panel row from LDS — 0.5 of the LDS read peak, which the 400 KB panel against 160 KB of LDS makes "
-                "inherent to a gather formulation — behind ~80 dependent row steps per wave at one workgroup per CU; the matrix is "
-                "walked once per 16-column panel slice (4 passes, 80 % L2 hits).  The densified MFMA form: 8.7 ms "
-                "(bench_micro/spmm_mfma_dense.hip, profiles/r04_knockouts.md)",
+    "gram_sparse": "alg. bytes = compacted matrix + row pointers read once, packed G written once; bound by its gather loads and the "
+                   "L2s' fabric side, not HBM: DESIGN.md sections 3b, 7; profiles/r06_pmc_gram.md",
+    "gene_moments": "alg. bytes = 16-bit index + f32 value read, transformed value stored back (nnz * 10) + pointers, cuts, row sums; "
+                    "latency-bound 0.5 ms above its read + store floor: DESIGN.md section 7; profiles/r06_pmc_gram.md",
+    "spmm_fwd": "alg. bytes = compacted matrix + pointers / row order + panel + the N x n_pc f64 scores; bound by its record reads and "
+                "stores: DESIGN.md section 3c; profiles/r06_pmc_spmm.md",
 }
 
 
@@ -1015,7 +997,7 @@ def main():
             fw, tr = r["prof"].get("spmm_fwd", {}), r["prof"].get("spmm_t", {})
             return {"steps": 2, "ms_per_step": r["ms_per_step"], "subspace_iterations": r["iters"], "pca_residual": r["residual"],
                     "spmm_fwd": roof(fw, KERNEL_SYMBOL["spmm_fwd"], "f64 panels (the matrix-free iteration runs its products in f64)"),
-                    "spmm_t": roof(tr, KERNEL_SYMBOL["spmm_t"], "N m 64 f64 LDS lane-atomics per launch; without them the launch takes the same time (DESIGN.md section 3c): ~8 instructions per non-zero for 64 multiply-adds"),
+                    "spmm_t": roof(tr, KERNEL_SYMBOL["spmm_t"], "N m 64 f64 LDS lane-atomics per launch; without them the launch takes the same time (profiles/history.md): ~8 instructions per non-zero for 64 multiply-adds"),
                     "note": "--solver 2: the matrix-free subspace iteration, one forward and one transposed SpMM per application of "
                             "C — the kernels BASELINE.json's second metric means; the default Gram solver runs the forward "
                             "SpMM once per solve (roofline_spmm)"}

@@ -124,7 +124,7 @@ static int32_t launch_fwd_rows(srx_ctx* ctx, const RowMajor& r, const PT* P, con
     // of 4 of 16; 5 of 10 instead of 7 of 8 with f64 panels) and stays inside the panel's 64 columns
     constexpr int Qmax = sizeof(PT) == 4 ? 4 : 2;
     const int wide_slices = (n_cols + 5 * Qmax - 1) / (5 * Qmax), narrow_slices = (n_cols + 4 * Qmax - 1) / (4 * Qmax);
-    // (f32 panels: 3 slices of 20 columns measured the same 0.64-0.70 ms as 4 of 16 — the launch is not bound by its passes, §3c —
+    // (f32 panels: 3 slices of 20 columns measured the same 0.64-0.70 ms as 4 of 16 — the launch is not bound by its passes, DESIGN.md 3c —
     //  with the LDS pipe 66 % busy instead of 51 (the 80-byte gene stride conflicts more) and 1.8 GB fetched instead of 1.2:
     //  the wide form is for f64 panels, 1.85 -> 1.35 ms; SRX_FWD_WIDE=1 forces it)
     const bool wide = Qr == Qmax && (size_t)r.k * 5 * Qmax * sizeof(PT) <= (size_t)163840 && wide_slices < narrow_slices &&
