@@ -365,6 +365,8 @@ __global__ __launch_bounds__(kJ2Threads) void k_jacobi_eig2(double* __restrict__
                     off = wave_sum(off);
                     dg = wave_sum(dg);
                     if (lane == 0) S.flag = !(off > off_tol2 * dg) ? 1 : (sweep >= 30 ? 2 : 0);
+                    // (diagnostics, SRX_PCA_TRACE: the measured off-diagonal norm over the diagonal's, per sweep, as float bits)
+                    if (lane == 0 && sweep < 32) status[16 + sweep] = __float_as_int((float)sqrt(off / dg));
                     // who is wanted at the NEXT sweep's measurement: rank of this slot's diagonal entry among the 64
                     int rk = 0;
                     for (int j = 0; j < L; ++j) {

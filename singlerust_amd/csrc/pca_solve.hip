@@ -548,9 +548,21 @@ static int32_t subspace_iterate(srx_ctx* ctx, const Work& w, int k, int l_act, c
         double r, ratio;
         SRX_TRY(collect(slot, r, ratio));
         resid = r;
-        if (getenv("SRX_PCA_TRACE"))
+        if (getenv("SRX_PCA_TRACE")) {
             fprintf(stderr, "[srx pca] sweep %d (ritz step %d): residual %.3e, theta_l/theta_npc %.3e, %d Jacobi sweeps\n", iters + o.warm,
                     n_ritz, r, ratio, (int)ctx->pin_async[kSlotDoubles * slot + 5]);
+            // the eigen-solve's off-diagonal norm (wanted pairs) over the diagonal's at every sweep's measurement (a drain: trace only)
+            int st[64];
+            if (d2h(ctx, st, d_status, sizeof st) == SRX_OK) {
+                fprintf(stderr, "[srx pca]   Jacobi off / diag per sweep:");
+                for (int q = 0; q <= (int)ctx->pin_async[kSlotDoubles * slot + 5] && q < 32; ++q) {
+                    float f;
+                    memcpy(&f, &st[16 + q], 4);
+                    fprintf(stderr, " %.2e", (double)f);
+                }
+                fprintf(stderr, "\n");
+            }
+        }
         if (r <= o.tol) {
             converged = true;
             break;
