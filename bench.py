@@ -892,6 +892,11 @@ def compact_record(full):
     if full.get("h2d"):          # --backed
         rec["h2d"] = _pick(full["h2d"], ("host_bytes_per_sweep_rank0", "GBps_sweep1_rank0", "GBps_sweep2_rank0"))
     rec["full"] = "bench_full.json (+ stderr)"
+    # never lose the line to its own bound: optional members go first (cannot happen with the fields above; a guard, not a path)
+    for drop in ("kernel_ms_per_step", "runs", "h2d", "weak", "roofline_next", "roofline_spmm"):
+        if len(json.dumps(rec)) <= MAX_LINE_BYTES:
+            break
+        rec.pop(drop, None)
     return rec
 
 
