@@ -196,7 +196,7 @@ def test_hot_kernels_do_not_spill_registers(tmp_path):
     from singlerust_amd import build
     csrc = os.path.join(ROOT, "singlerust_amd", "csrc")
     wanted = {"pca_form.hip": ["k_gram_stripesIfE", "k_gram_stripesIdE", "k_rowcount_listEPKl"],
-              "pca_solve.hip": ["k_spmm_rowsIffLi4ELb0ELi4EE"]}
+              "pca_solve.hip": ["k_spmm_rowsIffLi4ELb0ELi4EE", "k_spmm_rangesIffLi2ELi1024ELi2EE"]}
 
     def asm(src):
         out = str(tmp_path / (src + ".s"))
