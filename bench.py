@@ -455,8 +455,9 @@ def other_bounds(name, d, nnz_sel, n_cells, sigma=0.3):
 def cold_step(B, config, n_global, storage, reps=3):
     """What a caller pays who runs the path ONCE per dataset: srx_pipeline on a FRESH handle — no srx_matrix_prepare, no
     srx_matrix_reserve_results before the clock; the matrix itself resident in HBM.  The first call builds the pattern-only
-    structures the handle does not carry yet — the per-gene counts; the 16-bit index mirror and the gene-tile cuts are made where the
-    indices are written, by srx_matrix_upload and (round 6) srx_synth_generate alike — and allocates the result block inside the step.  Run after
+    structures the handle does not carry yet — none since round 6 for up to 38 000 genes: the 16-bit index mirror, the gene-tile cuts and
+    the per-gene counts are made in one walk where the indices are written, by srx_matrix_upload and srx_synth_generate alike — and
+    allocates the result block inside the step.  Run after
     the timed region, so the context is warm (scratch buffers, captured graphs, code objects): the cost measured is the
     matrix's own.  `prepare_ms` / `reserve_ms`: the two set-up calls timed on their own on another fresh handle."""
     a, F, sr, lib, ctx = B.a, B.F, B.sr, B.lib, B.ctx

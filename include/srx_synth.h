@@ -63,8 +63,8 @@ int32_t srx_synth_fill_host(const srx_synth_params* p, uint64_t row_begin, uint6
                             const uint64_t* indptr, uint64_t* indices_out, float* values_out);
 /* Device generator: allocates an srx_mat holding rows [row_begin, row_end) and fills it in
  * HBM.  dtype = logical dtype of the values (SRX_F32 typical), store = srx_store.  The handle leaves
- * in the state srx_matrix_upload leaves one in: with the 16-bit index mirror (n_cols <= 65536) and
- * the gene-tile cuts (the per-gene counts are still owed: srx_matrix_prepare or the first call). */
+ * in the state srx_matrix_upload leaves one in: with the 16-bit index mirror (n_cols <= 65536), the
+ * gene-tile cuts and (n_cols <= 38000) the per-gene non-zero counts. */
 int32_t srx_synth_generate(srx_ctx* ctx, const srx_synth_params* p, uint64_t row_begin,
                            uint64_t row_end, int32_t dtype, int32_t store, srx_mat** out);
 

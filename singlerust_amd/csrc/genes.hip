@@ -625,10 +625,19 @@ __global__ void k_narrow16(const int32_t* __restrict__ idx, uint64_t nnz, uint64
 // moved 10.9 GB at c3 (2.3 ms of a cold step's 14.7); this moves 6.6.
 // WIDEN: the other way round — the 16-bit mirror came over PCIe (upload_on: a quarter of the host's index bytes cross the
 // link) and the 32-bit indices are made from it, with the same cuts.
-template <int NB, bool WIDEN>
-__global__ __launch_bounds__(256) void k_narrow16_tiles(const int64_t* __restrict__ indptr, int32_t* idx,
+// COUNT (round 6): the walk also makes the per-gene non-zero counts (csr.rs:24-36) — a 32-bit counter per gene in LDS (n_cols <= 38 000:
+// 152 KB), one LDS atomic per entry, per-workgroup partials summed by k_gene_count_reduce — so that a handle leaves the upload / the
+// generation with ALL its pattern-only structures and the first pipeline call on it pays no k_gene_count (0.54 + 0.12 ms at c3: VERDICT
+// r5 item 5).  1024-thread workgroups then (the counters hold a CU to one workgroup).
+template <int NB, bool WIDEN, bool COUNT = false>
+__global__ __launch_bounds__(COUNT ? 1024 : 256) void k_narrow16_tiles(const int64_t* __restrict__ indptr, int32_t* idx,
                                                         uint64_t n_rows, int tile_genes, uint16_t* out,
-                                                        int64_t* __restrict__ tp) {
+                                                        int64_t* __restrict__ tp, uint32_t n_cols = 0, uint32_t* __restrict__ cnt_part = nullptr) {
+    extern __shared__ uint32_t s_hist[];
+    if constexpr (COUNT) {
+        for (uint32_t g = threadIdx.x; g < n_cols; g += blockDim.x) s_hist[g] = 0u;
+        __syncthreads();
+    }
     const int lane = lane_id();
     const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x / kWave);
     constexpr int kU = 4;
@@ -651,6 +660,9 @@ __global__ __launch_bounds__(256) void k_narrow16_tiles(const int64_t* __restric
                 if (e < hi) {
                     if constexpr (WIDEN) idx[e] = v[u];
                     else out[e] = (uint16_t)v[u];
+                    if constexpr (COUNT) {
+                        if ((uint32_t)v[u] < n_cols) __hip_atomic_fetch_add(&s_hist[v[u]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
 #pragma unroll
                 for (int b = 0; b < NB; ++b) cnt[b] += __popcll(__ballot(v[u] < (b + 1) * tile_genes));
@@ -663,26 +675,56 @@ __global__ __launch_bounds__(256) void k_narrow16_tiles(const int64_t* __restric
     }
     // (the 16 padding entries behind the last non-zero)
     if (blockIdx.x == 0 && threadIdx.x < 16) out[indptr[n_rows] + threadIdx.x] = (uint16_t)0;
+    if constexpr (COUNT) {
+        __syncthreads();
+        for (uint32_t g = threadIdx.x; g < n_cols; g += blockDim.x) cnt_part[(uint64_t)blockIdx.x * n_cols + g] = s_hist[g];
+    }
 }
+
+__global__ void k_gene_count_reduce(const uint32_t* __restrict__ part, uint64_t n_cols, uint64_t n_blocks, uint32_t* __restrict__ cnt);
 
 template <bool WIDEN>
 static int32_t launch_narrow16_tiles(srx_mat* m, int nt, int tg, hipStream_t stream) {
     srx_ctx* ctx = m->ctx;
-    const unsigned g = (unsigned)std::min<uint64_t>((m->n_rows + 3) / 4, (uint64_t)ctx->n_cus * 32);
-    auto go = [&](auto nb) {
-        hipLaunchKernelGGL((k_narrow16_tiles<decltype(nb)::value, WIDEN>), dim3(g ? g : 1), dim3(256), 0, stream, m->d_indptr,
-                           m->d_indices, m->n_rows, tg, m->d_idx16, m->d_tile_ptr);
+    // the counting form where a counter per gene fits the LDS and the counts are still owed
+    const bool count = m->n_cols * 4 <= 155648 && !m->cnt_pat_valid && m->n_rows > 0 && m->nnz > 0;
+    const unsigned g = count ? (unsigned)std::min<uint64_t>((m->n_rows + 15) / 16, (uint64_t)ctx->n_cus * 2)
+                             : (unsigned)std::min<uint64_t>((m->n_rows + 3) / 4, (uint64_t)ctx->n_cus * 32);
+    uint32_t* part = nullptr;
+    if (count) {
+        if (!m->d_cnt_pat) SRX_HIP(ctx, dev_malloc(ctx, (void**)&m->d_cnt_pat, m->n_cols * sizeof(uint32_t)));
+        SRX_TRY(scratch(ctx, stream == ctx->stream ? "n16_part_cnt" : "n16_part_cnt_side", (size_t)g * m->n_cols * sizeof(uint32_t), (void**)&part));
+    }
+    auto go = [&](auto nb) -> int32_t {
+        constexpr int NBv = decltype(nb)::value;
+        if (count) {
+            const size_t lds = m->n_cols * sizeof(uint32_t);
+            SRX_HIP(ctx, hipFuncSetAttribute((const void*)k_narrow16_tiles<NBv, WIDEN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_narrow16_tiles<NBv, WIDEN, true>), dim3(g ? g : 1), dim3(1024), lds, stream, m->d_indptr, m->d_indices,
+                               m->n_rows, tg, m->d_idx16, m->d_tile_ptr, (uint32_t)m->n_cols, part);
+        } else {
+            hipLaunchKernelGGL((k_narrow16_tiles<NBv, WIDEN, false>), dim3(g ? g : 1), dim3(256), 0, stream, m->d_indptr, m->d_indices,
+                               m->n_rows, tg, m->d_idx16, m->d_tile_ptr, 0u, (uint32_t*)nullptr);
+        }
+        return SRX_OK;
     };
+    int32_t rc;
     switch (nt - 1) {
-        case 0: go(std::integral_constant<int, 0>{}); break;
-        case 1: go(std::integral_constant<int, 1>{}); break;
-        case 2: go(std::integral_constant<int, 2>{}); break;
-        case 3: go(std::integral_constant<int, 3>{}); break;
-        case 4: go(std::integral_constant<int, 4>{}); break;
-        case 5: go(std::integral_constant<int, 5>{}); break;
-        case 6: go(std::integral_constant<int, 6>{}); break;
-        case 7: go(std::integral_constant<int, 7>{}); break;
-        default: go(std::integral_constant<int, 8>{}); break;
+        case 0: rc = go(std::integral_constant<int, 0>{}); break;
+        case 1: rc = go(std::integral_constant<int, 1>{}); break;
+        case 2: rc = go(std::integral_constant<int, 2>{}); break;
+        case 3: rc = go(std::integral_constant<int, 3>{}); break;
+        case 4: rc = go(std::integral_constant<int, 4>{}); break;
+        case 5: rc = go(std::integral_constant<int, 5>{}); break;
+        case 6: rc = go(std::integral_constant<int, 6>{}); break;
+        case 7: rc = go(std::integral_constant<int, 7>{}); break;
+        default: rc = go(std::integral_constant<int, 8>{}); break;
+    }
+    SRX_TRY(rc);
+    if (count) {
+        hipLaunchKernelGGL(k_gene_count_reduce, dim3((unsigned)((m->n_cols + 255) / 256)), dim3(256), 0, stream, (const uint32_t*)part, m->n_cols,
+                           (uint64_t)g, m->d_cnt_pat);
+        m->cnt_pat_valid = true;
     }
     SRX_HIP(ctx, hipGetLastError());
     return SRX_OK;
